@@ -1,0 +1,95 @@
+"""ctypes binding of libavsi_hip.so (the C ABI of include/avsi_hip.h).
+
+Loading is lazy; ``lib()`` raises RuntimeError loudly when the shared library has not been
+built (``make -C csrc`` or ``__graft_entry__.build()``) -- there is no fallback path.
+"""
+import ctypes
+import os
+from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int32, c_int64, c_size_t, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libavsi_hip.so")
+ABI_VERSION = 1
+
+AVSI_OK = 0
+
+
+class AvsiError(RuntimeError):
+    pass
+
+
+class FrontendArgs(Structure):
+    """Mirror of ``avsi_frontend_args`` (include/avsi_hip.h)."""
+    _fields_ = [
+        ("wav", c_void_p), ("batch", c_int32), ("num_samples", c_int32), ("wav_stride", c_int64),
+        ("frame_len", c_int32), ("hop", c_int32), ("nfft", c_int32), ("num_frames", c_int32),
+        ("num_bins", c_int32), ("table", c_void_p),
+        ("mean", c_void_p), ("stdev", c_void_p),
+        ("mask", c_void_p), ("mask_stride_b", c_int64), ("mask_stride_t", c_int64),
+        ("out_stft", c_void_p), ("stft_stride_b", c_int64), ("stft_stride_t", c_int64),
+        ("out_spec", c_void_p), ("spec_stride_b", c_int64), ("spec_stride_t", c_int64),
+        ("out_feat", c_void_p), ("feat_stride_b", c_int64), ("feat_stride_t", c_int64),
+        ("feat_cols", c_int32),
+        ("out_logmel", c_void_p), ("logmel_stride_b", c_int64), ("logmel_stride_t", c_int64),
+        ("num_mel", c_int32), ("mel_start", c_void_p), ("mel_len", c_void_p), ("mel_w", c_void_p),
+        ("mel_w_stride", c_int32),
+        ("spec_power", c_float), ("log_spec", c_int32), ("eps", c_float),
+    ]
+
+
+# name -> (restype, argtypes); every symbol include/avsi_hip.h declares
+PROTOTYPES = {
+    "avsi_abi_version": (c_int, []),
+    "avsi_status_string": (c_char_p, [c_int]),
+    "avsi_frontend_table_floats": (c_size_t, [c_int, c_int]),
+    "avsi_frontend_init_tables": (c_int, [c_void_p, c_int, c_int, c_void_p]),
+    "avsi_frontend_f32": (c_int, [POINTER(FrontendArgs), c_void_p]),
+}
+
+_lib = None
+
+
+def lib():
+    """Return the loaded CDLL; raise if it is not built or its ABI version mismatches."""
+    global _lib
+    if _lib is None:
+        if not os.path.isfile(LIB_PATH):
+            raise AvsiError(
+                "libavsi_hip.so not found at %s: build it with `make -C %s` (or "
+                "`python -c 'import __graft_entry__ as g; g.build()'`). There is no CPU fallback."
+                % (LIB_PATH, os.path.dirname(LIB_PATH)))
+        handle = ctypes.CDLL(LIB_PATH)
+        for name, (restype, argtypes) in PROTOTYPES.items():
+            fn = getattr(handle, name)      # AttributeError if a declared symbol is missing
+            fn.restype = restype
+            fn.argtypes = argtypes
+        got = handle.avsi_abi_version()
+        if got != ABI_VERSION:
+            raise AvsiError("libavsi_hip.so ABI version %d, host layer expects %d: rebuild" % (got, ABI_VERSION))
+        _lib = handle
+    return _lib
+
+
+def check(status, what):
+    if status != AVSI_OK:
+        msg = lib().avsi_status_string(status)
+        raise AvsiError("%s failed: %s (%d)" % (what, msg.decode() if msg else "?", status))
+
+
+def require_cuda(*tensors):
+    """Every compute entry point goes through this: device tensors only, no fallback."""
+    import torch
+    if not torch.cuda.is_available():
+        raise AvsiError("no GPU visible: the avsi_amd hot path runs on MI355X only (no CPU fallback)")
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise AvsiError("expected a device tensor, got %s" % (t.device,))
+
+
+def stream_ptr():
+    import torch
+    return c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def ptr(t):
+    return c_void_p(t.data_ptr()) if t is not None else c_void_p(0)

@@ -1,0 +1,172 @@
+"""DSP operators of the hot path on MI355X (host side).
+
+Same names, arguments and defaults as the reference module
+``av_speech_inpainting/audio_processing.py`` (get_stft :25-42, get_spectrogram :45-56,
+get_log_mel_spectrogram :59-72), taking and returning torch device tensors instead of TF graph
+nodes.  The reference builds these as separate TF ops; here ``frontend()`` runs the whole chain
+(frame, window, rFFT, |.|, log, z-norm, mask, log-mel) as ONE gfx950 kernel through the C ABI
+(``avsi_frontend_f32``), and the per-op functions are thin views over it.
+"""
+import ctypes
+import math
+
+import numpy as np
+import torch
+
+from . import _lib
+
+_TABLES = {}     # (device index, frame_len, nfft) -> device table
+_MEL = {}        # (device index, cfg) -> (start, len, w, stride)
+
+
+def ms_to_samples(ms, sample_rate):
+    """int(round(ms / 1e3 * sample_rate)) -- reference audio_processing.py:27-28."""
+    return int(round(ms / 1e3 * sample_rate))
+
+
+def num_frames(num_samples, step):
+    """Frames produced by tf.contrib.signal.stft(pad_end=True): ceil(N / step)."""
+    return -(-int(num_samples) // int(step))
+
+
+def _tables(device, frame_len, nfft):
+    key = (device.index, frame_len, nfft)
+    tab = _TABLES.get(key)
+    if tab is None:
+        L = _lib.lib()
+        n = L.avsi_frontend_table_floats(frame_len, nfft)
+        if n == 0:
+            raise _lib.AvsiError("unsupported STFT geometry frame_len=%d nfft=%d" % (frame_len, nfft))
+        tab = torch.empty(n, dtype=torch.float32, device=device)
+        _lib.check(L.avsi_frontend_init_tables(_lib.ptr(tab), frame_len, nfft, _lib.stream_ptr()),
+                   "avsi_frontend_init_tables")
+        _TABLES[key] = tab
+    return tab
+
+
+def linear_to_mel_weight_matrix(num_mel_bins=80, num_spec_bins=257, sample_rate=16000,
+                                lower_edge_freq=125.0, upper_edge_freq=7600.0):
+    """HTK-mel triangular filterbank [num_spec_bins, num_mel_bins] (host, float64 -> float32).
+
+    Role of tf.signal.linear_to_mel_weight_matrix at audio_processing.py:63-64: un-normalised
+    triangles on the mel scale 1127 ln(1 + f/700), DC row zero."""
+    def mel(f):
+        return 1127.0 * np.log1p(np.asarray(f, dtype=np.float64) / 700.0)
+    bins = mel(np.linspace(0.0, sample_rate / 2.0, num_spec_bins)[1:])[:, None]
+    e = np.linspace(mel(lower_edge_freq), mel(upper_edge_freq), num_mel_bins + 2)
+    up = (bins - e[None, :-2]) / (e[None, 1:-1] - e[None, :-2])
+    down = (e[None, 2:] - bins) / (e[None, 2:] - e[None, 1:-1])
+    w = np.clip(np.minimum(up, down), 0.0, None)
+    return np.concatenate([np.zeros((1, num_mel_bins)), w], axis=0).astype(np.float32)
+
+
+def _mel_bands(device, num_mel_bins, num_spec_bins, sample_rate, lower, upper):
+    """Band form of the mel matrix for the kernel: per band first bin, tap count, taps."""
+    key = (device.index, num_mel_bins, num_spec_bins, sample_rate, float(lower), float(upper))
+    hit = _MEL.get(key)
+    if hit is None:
+        w = linear_to_mel_weight_matrix(num_mel_bins, num_spec_bins, sample_rate, lower, upper)
+        start = np.zeros(num_mel_bins, dtype=np.int32)
+        length = np.zeros(num_mel_bins, dtype=np.int32)
+        for m in range(num_mel_bins):
+            nz = np.nonzero(w[:, m])[0]
+            if len(nz):
+                start[m], length[m] = nz[0], nz[-1] - nz[0] + 1
+        stride = max(1, int(length.max()))
+        taps = np.zeros((num_mel_bins, stride), dtype=np.float32)
+        for m in range(num_mel_bins):
+            taps[m, :length[m]] = w[start[m]:start[m] + length[m], m]
+        hit = (torch.from_numpy(start).to(device), torch.from_numpy(length).to(device),
+               torch.from_numpy(taps).to(device), stride)
+        _MEL[key] = hit
+    return hit
+
+
+def frontend(sources, sample_rate=16000, window_size=24, step_size=12, n_fft=512,
+             num_frames_out=None, num_bins=None, mean=None, std=None, masks=None,
+             want_stft=False, want_spec=False, want_feat=False, want_logmel=False,
+             power=1.0, log=True, eps=1e-6, time_major=False, feat_cols=None,
+             num_mel_bins=80, lower_edge_freq=125.0, upper_edge_freq=7600.0):
+    """Fused front end: ONE kernel from waveform to every requested output.
+
+    sources [B, N] float32 (device).  Returns a dict with the requested keys:
+      'stft'   complex64 [B, T, F]                      (get_stft, audio_processing.py:25-42)
+      'spec'   float32 [B, T, F]  |X|^power -> log -> (.-mean)/std  (models.py:32-33)
+      'feat'   'spec' * masks; [B, T, feat_cols] or, time_major, [T, B, feat_cols] with
+               columns >= F zero (the BLSTM's padded input layout)              (models.py:35)
+      'logmel' float32 [B, T, num_mel_bins]  log(mel_W . |X|^2 + eps)  (audio_processing.py:59-72)
+    """
+    _lib.require_cuda(sources, mean, std, masks)
+    L = _lib.lib()
+    if sources.dtype != torch.float32 or sources.dim() != 2:
+        raise _lib.AvsiError("sources must be float32 [B, N]")
+    if sources.stride(1) != 1:
+        sources = sources.contiguous()
+    dev = sources.device
+    B, N = sources.shape
+    frame_len = ms_to_samples(window_size, sample_rate)
+    hop = ms_to_samples(step_size, sample_rate)
+    T_full = num_frames(N, hop)
+    T = T_full if num_frames_out is None else int(num_frames_out)
+    F = n_fft // 2 + 1 if num_bins is None else int(num_bins)
+
+    a = _lib.FrontendArgs()
+    a.wav, a.batch, a.num_samples, a.wav_stride = _lib.ptr(sources), B, N, sources.stride(0)
+    a.frame_len, a.hop, a.nfft, a.num_frames, a.num_bins = frame_len, hop, n_fft, T, F
+    tab = _tables(dev, frame_len, n_fft)
+    a.table = _lib.ptr(tab)
+    keep = [tab]
+    if mean is not None:
+        mean = mean.to(torch.float32).contiguous()
+        std = std.to(torch.float32).contiguous()
+        a.mean, a.stdev = _lib.ptr(mean), _lib.ptr(std)
+        keep += [mean, std]
+    if masks is not None:
+        if masks.dtype != torch.float32 or masks.stride(2) != 1:
+            masks = masks.to(torch.float32).contiguous()
+        a.mask, a.mask_stride_b, a.mask_stride_t = _lib.ptr(masks), masks.stride(0), masks.stride(1)
+        keep.append(masks)
+    out = {}
+    if want_stft:
+        st = torch.empty((B, T, F, 2), dtype=torch.float32, device=dev)
+        a.out_stft, a.stft_stride_b, a.stft_stride_t = _lib.ptr(st), st.stride(0), st.stride(1)
+        out['stft'] = torch.view_as_complex(st)
+    if want_spec:
+        sp = torch.empty((B, T, F), dtype=torch.float32, device=dev)
+        a.out_spec, a.spec_stride_b, a.spec_stride_t = _lib.ptr(sp), sp.stride(0), sp.stride(1)
+        out['spec'] = sp
+    if want_feat:
+        cols = F if feat_cols is None else int(feat_cols)
+        if time_major:
+            ft = torch.empty((T, B, cols), dtype=torch.float32, device=dev)
+            a.feat_stride_b, a.feat_stride_t = ft.stride(1), ft.stride(0)
+        else:
+            ft = torch.empty((B, T, cols), dtype=torch.float32, device=dev)
+            a.feat_stride_b, a.feat_stride_t = ft.stride(0), ft.stride(1)
+        a.out_feat, a.feat_cols = _lib.ptr(ft), cols
+        out['feat'] = ft
+    if want_logmel:
+        ms, ml, mw, mstride = _mel_bands(dev, num_mel_bins, n_fft // 2 + 1, sample_rate,
+                                         lower_edge_freq, upper_edge_freq)
+        lm = torch.empty((B, T, num_mel_bins), dtype=torch.float32, device=dev)
+        a.out_logmel, a.logmel_stride_b, a.logmel_stride_t = _lib.ptr(lm), lm.stride(0), lm.stride(1)
+        a.num_mel, a.mel_start, a.mel_len, a.mel_w, a.mel_w_stride = (
+            num_mel_bins, _lib.ptr(ms), _lib.ptr(ml), _lib.ptr(mw), mstride)
+        out['logmel'] = lm
+    a.spec_power, a.log_spec, a.eps = float(power), int(bool(log)), float(eps)
+    _lib.check(L.avsi_frontend_f32(ctypes.byref(a), _lib.stream_ptr()), "avsi_frontend_f32")
+    return out
+
+
+def _out_dims(out_shape, T_full, F_full):
+    """out_shape all-zero = no slice (reference tf.cond at audio_processing.py:38-40)."""
+    if out_shape is None or all(int(s) == 0 for s in out_shape):
+        return T_full, F_full
+    return int(out_shape[1]), int(out_shape[2])
+
+
+def get_stft(sources, sample_rate=16000, window_size=25, step_size=10, n_fft=512, out_shape=[0, 0, 0]):
+    """Compute STFT -- reference audio_processing.py:25-42.  Returns complex64 [B, T, F]."""
+    hop = ms_to_samples(step_size, sample_rate)
+    T, F = _out_dims(out_shape, num_frames(sources.shape[1], hop), n_fft // 2 + 1)
+    return frontend(sources, sample_rate, window_size, step_size, n_fft, T, F, want_stft=True)['stft']

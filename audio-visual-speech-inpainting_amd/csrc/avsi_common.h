@@ -1,0 +1,19 @@
+// Shared host-side helpers of the gfx950 hot-path library (not part of the C ABI).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/avsi_hip.h"
+
+#define AVSI_ABI_VERSION 1
+
+// Launch-status helper: peek the sticky error after a launch without synchronising.
+static inline int avsi_launch_status() {
+    return hipGetLastError() == hipSuccess ? AVSI_OK : AVSI_ERR_LAUNCH;
+}
+
+static inline int64_t avsi_ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
+static inline int64_t avsi_round_up(int64_t a, int64_t b) { return avsi_ceil_div(a, b) * b; }
+
+// MI355X: 256 CUs in 8 XCDs.  Used only to size persistent grids.
+#define AVSI_NUM_CU 256
+#define AVSI_NUM_XCD 8

@@ -1,0 +1,326 @@
+// Fused speech front end for gfx950 (MI355X): framing + periodic-Hann window + 512-point real
+// FFT + |X|^p / log / z-norm / mask (+ sparse-triangular log-mel), one pass over HBM.
+//
+// Replaces tf.contrib.signal.stft (reference audio_processing.py:35-36), get_spectrogram
+// (:45-56), get_log_mel_spectrogram (:59-72) and the elementwise chain of
+// StackedBLSTMModel.__init__ (models.py:31-35).
+//
+// Work decomposition (wave = 64 lanes):
+//   - a tile = 16 consecutive frames of one utterance; a 256-thread workgroup owns a tile and
+//     walks tiles persistently (tile = blockIdx.x, += gridDim.x);
+//   - the tile's samples ((16-1)*hop + frame_len floats) are read from HBM once with 16-byte
+//     loads into LDS, so the 50 % frame overlap is served from LDS, not re-read;
+//   - the 512-point real FFT of a frame is a 256-point complex FFT of z[n] = x[2n] + j x[2n+1],
+//     factored 16 x 16: each 16-lane group owns one frame, each lane runs a 16-point FFT
+//     entirely in registers, one transposition through LDS, a second in-register 16-point FFT;
+//   - the epilogue maps thread -> frequency bin (so per-bin twiddle / mean / std stay in
+//     registers and every global store is a full coalesced row), recovers X[k] from Z[k] and
+//     Z[256-k], and writes every requested output exactly once.
+#include "avsi_common.h"
+
+namespace {
+
+constexpr int FR = 16;        // frames per tile
+constexpr int TPB = 256;      // threads per workgroup
+constexpr int ZSTRIDE = 272;  // complex elements per frame in LDS: 16 rows x 17 (bank padding)
+constexpr int PSTRIDE = 260;  // floats per frame of the power-spectrum tile
+
+struct cf {
+    float r, i;
+};
+
+__device__ __forceinline__ cf cmul(cf a, cf w) { return {a.r * w.r - a.i * w.i, a.r * w.i + a.i * w.r}; }
+
+// forward 4-point DFT, in place, natural order
+__device__ __forceinline__ void fft4(cf& x0, cf& x1, cf& x2, cf& x3) {
+    const cf a{x0.r + x2.r, x0.i + x2.i}, b{x0.r - x2.r, x0.i - x2.i};
+    const cf c{x1.r + x3.r, x1.i + x3.i}, d{x1.r - x3.r, x1.i - x3.i};
+    x0 = {a.r + c.r, a.i + c.i};
+    x2 = {a.r - c.r, a.i - c.i};
+    x1 = {b.r + d.i, b.i - d.r};
+    x3 = {b.r - d.i, b.i + d.r};
+}
+
+// W16^m = exp(-2 pi j m / 16), m = n1*k2 for n1,k2 in 0..3
+__device__ __forceinline__ cf w16(int m) {
+    constexpr float C1 = 0.92387953251128674f, S1 = 0.38268343236508977f, R = 0.70710678118654752f;
+    switch (m) {
+        case 0: return {1.f, 0.f};
+        case 1: return {C1, -S1};
+        case 2: return {R, -R};
+        case 3: return {S1, -C1};
+        case 4: return {0.f, -1.f};
+        case 6: return {-R, -R};
+        default: return {-C1, S1};  // m == 9
+    }
+}
+
+// 16-point forward DFT in registers.  In: v[n].  Out: X[k] sits at v[pos16(k)].
+__device__ __forceinline__ constexpr int pos16(int k) { return 4 * (k & 3) + (k >> 2); }
+
+__device__ __forceinline__ void fft16(cf (&v)[16]) {
+#pragma unroll
+    for (int n1 = 0; n1 < 4; ++n1) fft4(v[n1], v[n1 + 4], v[n1 + 8], v[n1 + 12]);  // -> y[n1][k2] at v[n1+4k2]
+#pragma unroll
+    for (int n1 = 1; n1 < 4; ++n1)
+#pragma unroll
+        for (int k2 = 1; k2 < 4; ++k2) v[n1 + 4 * k2] = cmul(v[n1 + 4 * k2], w16(n1 * k2));
+#pragma unroll
+    for (int k2 = 0; k2 < 4; ++k2) fft4(v[4 * k2], v[4 * k2 + 1], v[4 * k2 + 2], v[4 * k2 + 3]);
+}
+
+// table layout (floats): window[512] (zero past frame_len) | W256^m (m<256) as (re,im) | W512^k (k<=256)
+constexpr int TAB_WIN = 0;
+constexpr int TAB_TW256 = 512;
+constexpr int TAB_TW512 = 512 + 512;
+constexpr int TAB_FLOATS = 512 + 512 + 2 * 257 + 2;
+
+__global__ void frontend_tables_kernel(float* tab, int frame_len) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < 512) {
+        // periodic Hann: 0.5 - 0.5 cos(2 pi n / L)
+        tab[TAB_WIN + i] = i < frame_len ? (float)(0.5 - 0.5 * cospi(2.0 * i / frame_len)) : 0.f;
+    }
+    if (i < 256) {
+        tab[TAB_TW256 + 2 * i] = (float)cospi(2.0 * i / 256.0);
+        tab[TAB_TW256 + 2 * i + 1] = (float)(-sinpi(2.0 * i / 256.0));
+    }
+    if (i <= 256) {
+        tab[TAB_TW512 + 2 * i] = (float)cospi(2.0 * i / 512.0);
+        tab[TAB_TW512 + 2 * i + 1] = (float)(-sinpi(2.0 * i / 512.0));
+    }
+}
+
+// NB = number of 32-sample column groups that can hold non-zero window taps = ceil(frame_len/32)
+template <int NB>
+__global__ __launch_bounds__(TPB) void frontend_kernel(const avsi_frontend_args a, const int tiles_per_utt,
+                                                       const int n_tiles, const int seg_floats) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* s_wav = reinterpret_cast<float*>(smem);
+    cf* s_z = reinterpret_cast<cf*>(smem + (size_t)seg_floats * 4);
+    float* s_pow = reinterpret_cast<float*>(smem + (size_t)seg_floats * 4 + (size_t)FR * ZSTRIDE * 8);
+
+    const int tid = threadIdx.x;
+    const int f = tid >> 4;   // frame of the tile handled in the FFT phase
+    const int ln = tid & 15;  // lane within the frame's 16-lane group
+    const int S = a.hop, N = a.num_samples, T = a.num_frames, F = a.num_bins;
+    const float* __restrict__ tab = a.table;
+
+    // ---- per-lane constants of the FFT phase
+    float2 win[NB];
+#pragma unroll
+    for (int b = 0; b < NB; ++b) win[b] = *reinterpret_cast<const float2*>(tab + TAB_WIN + 2 * ln + 32 * b);
+    cf tw[16];
+#pragma unroll
+    for (int k2 = 1; k2 < 16; ++k2) {
+        const float2 w = *reinterpret_cast<const float2*>(tab + TAB_TW256 + 2 * ((ln * k2) & 255));
+        tw[k2] = {w.x, w.y};
+    }
+    // ---- per-bin constants of the epilogue (thread <-> bin k = tid)
+    const int k = tid;
+    const float2 wk = *reinterpret_cast<const float2*>(tab + TAB_TW512 + 2 * k);
+    const bool have_norm = a.mean != nullptr;
+    const float mean_k = (have_norm && k < F) ? a.mean[k] : 0.f;
+    const float std_k = (have_norm && k < F) ? a.stdev[k] : 1.f;
+    const float mean_n = (have_norm && F > 256) ? a.mean[256] : 0.f;  // Nyquist bin
+    const float std_n = (have_norm && F > 256) ? a.stdev[256] : 1.f;
+    const bool want_pow = a.out_logmel != nullptr;
+
+    for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const int b = tile / tiles_per_utt;
+        const int t0 = (tile - b * tiles_per_utt) * FR;
+
+        // ---- 1. stage the tile's samples: HBM -> LDS, 16 B per lane, zero past the signal end
+        {
+            const int64_t s0 = (int64_t)t0 * S;
+            const float* src = a.wav + (int64_t)b * a.wav_stride + s0;
+            const int valid = (int)max((int64_t)0, min((int64_t)seg_floats, (int64_t)N - s0));
+            const bool vec = ((reinterpret_cast<uintptr_t>(src) & 15) == 0);
+            for (int i = tid * 4; i < seg_floats; i += TPB * 4) {
+                float4 v;
+                if (vec && i + 3 < valid) {
+                    v = *reinterpret_cast<const float4*>(src + i);
+                } else {
+                    v.x = i < valid ? src[i] : 0.f;
+                    v.y = i + 1 < valid ? src[i + 1] : 0.f;
+                    v.z = i + 2 < valid ? src[i + 2] : 0.f;
+                    v.w = i + 3 < valid ? src[i + 3] : 0.f;
+                }
+                *reinterpret_cast<float4*>(s_wav + i) = v;
+            }
+        }
+        __syncthreads();
+
+        // ---- 2. window + first 16-point FFT (over n2, with n = ln + 16 n2) + twiddle
+        cf v[16];
+        {
+            const float* fr = s_wav + f * S + 2 * ln;
+#pragma unroll
+            for (int n2 = 0; n2 < 16; ++n2) {
+                if (n2 < NB) {
+                    const float2 x = *reinterpret_cast<const float2*>(fr + 32 * n2);
+                    v[n2] = {x.x * win[n2].x, x.y * win[n2].y};
+                } else {
+                    v[n2] = {0.f, 0.f};
+                }
+            }
+        }
+        fft16(v);
+        cf* zf = s_z + f * ZSTRIDE;
+        zf[ln] = v[pos16(0)];
+#pragma unroll
+        for (int k2 = 1; k2 < 16; ++k2) zf[k2 * 17 + ln] = cmul(v[pos16(k2)], tw[k2]);
+        __syncthreads();
+
+        // ---- 3. transposition: lane k2 = ln gathers its 16 n1 values
+#pragma unroll
+        for (int n1 = 0; n1 < 16; ++n1) v[n1] = zf[ln * 17 + n1];
+        __syncthreads();
+
+        // ---- 4. second 16-point FFT (over n1): Z[16 k1 + ln], stored in natural order
+        fft16(v);
+#pragma unroll
+        for (int k1 = 0; k1 < 16; ++k1) zf[16 * k1 + ln] = v[pos16(k1)];
+        __syncthreads();
+
+        // ---- 5. epilogue, thread <-> bin k: X[k] = E[k] + W512^k O[k]
+        //         E = (Z[k] + conj Z[256-k]) / 2,  O = -j (Z[k] - conj Z[256-k]) / 2
+        const int km = (256 - k) & 255;
+#pragma unroll 4
+        for (int ff = 0; ff < FR; ++ff) {
+            const int t = t0 + ff;
+            if (t >= T) break;
+            const cf zk = s_z[ff * ZSTRIDE + k], zm = s_z[ff * ZSTRIDE + km];
+            const cf e{0.5f * (zk.r + zm.r), 0.5f * (zk.i - zm.i)};
+            const cf o{0.5f * (zk.i + zm.i), -0.5f * (zk.r - zm.r)};
+            const cf wo = cmul(o, {wk.x, wk.y});
+            const cf x{e.r + wo.r, e.i + wo.i};
+            const float p2 = x.r * x.r + x.i * x.i;
+            if (want_pow) s_pow[ff * PSTRIDE + k] = p2;
+            if (k < F) {
+                if (a.out_stft) {
+                    float* o2 = a.out_stft + (int64_t)b * a.stft_stride_b + (int64_t)t * a.stft_stride_t + 2 * k;
+                    o2[0] = x.r;
+                    o2[1] = x.i;
+                }
+                if (a.out_spec || a.out_feat) {
+                    float s = __builtin_amdgcn_sqrtf(p2);
+                    if (a.spec_power != 1.f) s = (a.spec_power == 2.f) ? s * s : __powf(s, a.spec_power);
+                    if (a.log_spec) s = __logf(s + a.eps);
+                    if (have_norm) s = (s - mean_k) / std_k;
+                    if (a.out_spec) a.out_spec[(int64_t)b * a.spec_stride_b + (int64_t)t * a.spec_stride_t + k] = s;
+                    if (a.out_feat) {
+                        const float m =
+                            a.mask ? a.mask[(int64_t)b * a.mask_stride_b + (int64_t)t * a.mask_stride_t + k] : 1.f;
+                        a.out_feat[(int64_t)b * a.feat_stride_b + (int64_t)t * a.feat_stride_t + k] = s * m;
+                    }
+                }
+            }
+        }
+        // Nyquist bin (k = 256) and zero fill of the padded feature columns: thread <-> frame
+        if (tid < FR && t0 + tid < T) {
+            const int t = t0 + tid;
+            const cf z0 = s_z[tid * ZSTRIDE];
+            const float xr = z0.r - z0.i;  // X[256] = Re Z[0] - Im Z[0], purely real
+            if (want_pow) s_pow[tid * PSTRIDE + 256] = xr * xr;
+            if (F > 256) {
+                if (a.out_stft) {
+                    float* o2 = a.out_stft + (int64_t)b * a.stft_stride_b + (int64_t)t * a.stft_stride_t + 512;
+                    o2[0] = xr;
+                    o2[1] = 0.f;
+                }
+                if (a.out_spec || a.out_feat) {
+                    float s = fabsf(xr);
+                    if (a.spec_power != 1.f) s = (a.spec_power == 2.f) ? s * s : __powf(s, a.spec_power);
+                    if (a.log_spec) s = __logf(s + a.eps);
+                    if (have_norm) s = (s - mean_n) / std_n;
+                    if (a.out_spec) a.out_spec[(int64_t)b * a.spec_stride_b + (int64_t)t * a.spec_stride_t + 256] = s;
+                    if (a.out_feat) {
+                        const float m =
+                            a.mask ? a.mask[(int64_t)b * a.mask_stride_b + (int64_t)t * a.mask_stride_t + 256] : 1.f;
+                        a.out_feat[(int64_t)b * a.feat_stride_b + (int64_t)t * a.feat_stride_t + 256] = s * m;
+                    }
+                }
+            }
+            if (a.out_feat)
+                for (int c = F; c < a.feat_cols; ++c)
+                    a.out_feat[(int64_t)b * a.feat_stride_b + (int64_t)t * a.feat_stride_t + c] = 0.f;
+        }
+
+        // ---- 6. log-mel: sparse triangular bands over the power spectrum tile
+        if (want_pow) {
+            __syncthreads();
+            const int items = FR * a.num_mel;
+            for (int it = tid; it < items; it += TPB) {
+                const int ff = it / a.num_mel, m = it - ff * a.num_mel;
+                const int t = t0 + ff;
+                if (t >= T) continue;
+                const int st = a.mel_start[m], len = a.mel_len[m];
+                const float* w = a.mel_w + (int64_t)m * a.mel_w_stride;
+                const float* p = s_pow + ff * PSTRIDE + st;
+                float acc = 0.f;
+                for (int j = 0; j < len; ++j) acc = fmaf(p[j], w[j], acc);
+                a.out_logmel[(int64_t)b * a.logmel_stride_b + (int64_t)t * a.logmel_stride_t + m] = __logf(acc + a.eps);
+            }
+        }
+        __syncthreads();  // LDS is re-staged by the next tile
+    }
+}
+
+}  // namespace
+
+extern "C" size_t avsi_frontend_table_floats(int frame_len, int nfft) {
+    if (nfft != 512 || frame_len <= 0 || frame_len > 512) return 0;
+    return TAB_FLOATS;
+}
+
+extern "C" int avsi_frontend_init_tables(float* table, int frame_len, int nfft, void* stream) {
+    if (!table) return AVSI_ERR_INVALID_ARG;
+    if (nfft != 512 || frame_len <= 0 || frame_len > 512 || (frame_len & 1)) return AVSI_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(frontend_tables_kernel, dim3(3), dim3(256), 0, (hipStream_t)stream, table, frame_len);
+    return avsi_launch_status();
+}
+
+extern "C" int avsi_frontend_f32(const avsi_frontend_args* args, void* stream) {
+    if (!args) return AVSI_ERR_INVALID_ARG;
+    const avsi_frontend_args& a = *args;
+    if (!a.wav || !a.table || a.batch <= 0 || a.num_samples <= 0 || a.wav_stride < a.num_samples)
+        return AVSI_ERR_INVALID_ARG;
+    if (a.nfft != 512 || a.frame_len <= 0 || a.frame_len > 512 || (a.frame_len & 1) || a.hop <= 0 || (a.hop & 1))
+        return AVSI_ERR_UNSUPPORTED;
+    const int t_full = (int)avsi_ceil_div(a.num_samples, a.hop);
+    if (a.num_frames <= 0 || a.num_frames > t_full) return AVSI_ERR_INVALID_ARG;
+    if (a.num_bins <= 0 || a.num_bins > a.nfft / 2 + 1) return AVSI_ERR_INVALID_ARG;
+    if ((a.mean == nullptr) != (a.stdev == nullptr)) return AVSI_ERR_INVALID_ARG;
+    if (a.out_feat && a.feat_cols < a.num_bins) return AVSI_ERR_INVALID_ARG;
+    if (a.out_logmel) {
+        if (a.num_mel <= 0 || !a.mel_start || !a.mel_len || !a.mel_w || a.mel_w_stride <= 0) return AVSI_ERR_INVALID_ARG;
+    }
+    if (!a.out_stft && !a.out_spec && !a.out_feat && !a.out_logmel) return AVSI_OK;
+
+    const int nb_need = (a.frame_len + 31) / 32;
+    const int nb = nb_need <= 8 ? 8 : (nb_need <= 12 ? 12 : 16);  // template instance actually launched
+    const int seg = (int)avsi_round_up((int64_t)(FR - 1) * a.hop + 32 * nb, 4);
+    const size_t lds = (size_t)seg * 4 + (size_t)FR * ZSTRIDE * 8 + (a.out_logmel ? (size_t)FR * PSTRIDE * 4 : 0);
+    if (lds > 160 * 1024) return AVSI_ERR_UNSUPPORTED;
+    const int tiles_per_utt = (int)avsi_ceil_div(a.num_frames, FR);
+    const int64_t n_tiles64 = (int64_t)a.batch * tiles_per_utt;
+    if (n_tiles64 > INT32_MAX) return AVSI_ERR_UNSUPPORTED;
+    const int n_tiles = (int)n_tiles64;
+    const int wg_per_cu = (int)(160 * 1024 / lds) > 4 ? 4 : (int)(160 * 1024 / lds);
+    const int grid = n_tiles < AVSI_NUM_CU * wg_per_cu ? n_tiles : AVSI_NUM_CU * wg_per_cu;
+    const hipStream_t st = (hipStream_t)stream;
+
+#define AVSI_FE_LAUNCH(NBV)                                                                                   \
+    do {                                                                                                      \
+        if (lds > 64 * 1024)                                                                                  \
+            (void)hipFuncSetAttribute((const void*)frontend_kernel<NBV>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                      (int)lds);                                                              \
+        hipLaunchKernelGGL(frontend_kernel<NBV>, dim3(grid), dim3(TPB), lds, st, a, tiles_per_utt, n_tiles, seg); \
+    } while (0)
+    if (nb == 8) AVSI_FE_LAUNCH(8);
+    else if (nb == 12) AVSI_FE_LAUNCH(12);
+    else AVSI_FE_LAUNCH(16);
+#undef AVSI_FE_LAUNCH
+    return avsi_launch_status();
+}

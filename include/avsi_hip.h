@@ -1,0 +1,98 @@
+/*
+ * avsi_hip.h -- C ABI of the MI355X (gfx950) speech-inpainting hot path.
+ *
+ * The reference (dr-pato/audio-visual-speech-inpainting) has no FFI: its hot path is a
+ * TensorFlow-1.x graph executed by sess.run().  Each entry point below replaces the TF
+ * op(s) cited next to it (file:line relative to the reference's av_speech_inpainting/).
+ * INTEGRATION.md shows the ctypes stub a maintainer of the reference would add.
+ *
+ * Conventions
+ *   - every function returns 0 (AVSI_OK) or a negative avsi_status; nothing throws or aborts;
+ *   - all tensor pointers are DEVICE pointers owned by the caller (e.g. torch data_ptr());
+ *   - `stream` is a hipStream_t passed as void*; launches are asynchronous on it;
+ *   - no hidden allocation, no global state: workspaces are caller-provided and sized by
+ *     the matching *_workspace_bytes() query; distinct streams may be used concurrently;
+ *   - float means IEEE binary32; "row" strides / leading dimensions are in ELEMENTS.
+ */
+#ifndef AVSI_HIP_H
+#define AVSI_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum avsi_status {
+    AVSI_OK = 0,
+    AVSI_ERR_INVALID_ARG = -1,   /* null pointer, non-positive size, bad stride           */
+    AVSI_ERR_UNSUPPORTED = -2,   /* shape outside what the gfx950 kernels are built for   */
+    AVSI_ERR_LAUNCH = -3,        /* hipGetLastError() != hipSuccess after a launch        */
+    AVSI_ERR_WORKSPACE = -4      /* workspace null or too small                           */
+} avsi_status;
+
+/* ABI version (bumped on any signature change) and a static string for a status code. */
+int avsi_abi_version(void);
+const char* avsi_status_string(int status);
+
+/* ------------------------------------------------------------------------------------
+ * Front end: framing + periodic-Hann window + rFFT + |.| + log + z-norm + mask (+ log-mel)
+ * Replaces tf.contrib.signal.stft (audio_processing.py:35-36), get_spectrogram
+ * (audio_processing.py:45-56), get_log_mel_spectrogram (audio_processing.py:59-72) and
+ * the three elementwise ops of StackedBLSTMModel.__init__ (models.py:31-35), fused.
+ * ------------------------------------------------------------------------------------ */
+
+/* Number of floats of the per-(frame_len, nfft) constant table (window + FFT twiddles). */
+size_t avsi_frontend_table_floats(int frame_len, int nfft);
+/* Fill `table` (device, avsi_frontend_table_floats() floats) on `stream`. */
+int avsi_frontend_init_tables(float* table, int frame_len, int nfft, void* stream);
+
+typedef struct avsi_frontend_args {
+    /* input waveform [B, N], row stride wav_stride (>= N) */
+    const float* wav;
+    int32_t batch;            /* B */
+    int32_t num_samples;      /* N */
+    int64_t wav_stride;
+    /* framing: T = ceil(N / hop) frames exist; frames [0, num_frames) are produced */
+    int32_t frame_len;        /* 384  (even, <= nfft) */
+    int32_t hop;              /* 192  (even)          */
+    int32_t nfft;             /* 512                  */
+    int32_t num_frames;       /* <= ceil(N / hop): the out_shape[1] slice of get_stft */
+    int32_t num_bins;         /* <= nfft/2+1: the out_shape[2] slice (audio_feat_dim) */
+    const float* table;       /* from avsi_frontend_init_tables(frame_len, nfft) */
+    /* optional per-bin normalisation (models.py:33); both null or both set */
+    const float* mean;        /* [num_bins] */
+    const float* stdev;       /* [num_bins] */
+    /* optional mask [B, T, num_bins] (models.py:35) with element strides */
+    const float* mask;
+    int64_t mask_stride_b, mask_stride_t;
+    /* outputs, each optional (null = skip); element strides per batch / per frame */
+    float* out_stft;          /* interleaved re,im: [.., num_bins, 2]; strides count floats */
+    int64_t stft_stride_b, stft_stride_t;
+    float* out_spec;          /* |X|^power, log(. + eps) if log_spec, then (.-mean)/std */
+    int64_t spec_stride_b, spec_stride_t;
+    float* out_feat;          /* out_spec * mask */
+    int64_t feat_stride_b, feat_stride_t;
+    int32_t feat_cols;        /* >= num_bins: columns [num_bins, feat_cols) are zero-filled */
+    float* out_logmel;        /* log(melW^T |X|^2 + eps) [.., num_mel] */
+    int64_t logmel_stride_b, logmel_stride_t;
+    /* band structure of the (sparse, triangular) mel matrix: band m has taps
+       mel_w[m * mel_w_stride + j] on bins mel_start[m] + j, j < mel_len[m] */
+    int32_t num_mel;
+    const int32_t* mel_start;
+    const int32_t* mel_len;
+    const float* mel_w;
+    int32_t mel_w_stride;
+    /* spectrogram options (audio_processing.py:45-50) */
+    float spec_power;         /* 1 = magnitude */
+    int32_t log_spec;         /* 1 = log(. + eps) */
+    float eps;                /* 1e-6 */
+} avsi_frontend_args;
+
+int avsi_frontend_f32(const avsi_frontend_args* args, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* AVSI_HIP_H */
