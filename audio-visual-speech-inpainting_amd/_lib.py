@@ -37,6 +37,12 @@ class FrontendArgs(Structure):
     ]
 
 
+class GemmEpilogue(Structure):
+    """Mirror of ``avsi_gemm_epilogue`` (include/avsi_hip.h)."""
+    _fields_ = [("bias", c_void_p), ("row_scale", c_void_p),
+                ("row_map_bp", c_int32), ("row_map_t", c_int32), ("row_map_b", c_int32)]
+
+
 # name -> (restype, argtypes); every symbol include/avsi_hip.h declares
 PROTOTYPES = {
     "avsi_abi_version": (c_int, []),
@@ -44,6 +50,12 @@ PROTOTYPES = {
     "avsi_frontend_table_floats": (c_size_t, [c_int, c_int]),
     "avsi_frontend_init_tables": (c_int, [c_void_p, c_int, c_int, c_void_p]),
     "avsi_frontend_f32": (c_int, [POINTER(FrontendArgs), c_void_p]),
+    "avsi_gemm_f32": (c_int, [c_int, c_int, c_int, c_int, c_int, c_float, c_void_p, c_int64, c_void_p, c_int64,
+                              c_float, c_void_p, c_int64, POINTER(GemmEpilogue), c_void_p]),
+    "avsi_blstm_rec_fwd_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
+    "avsi_l1_loss_workspace_bytes": (c_size_t, [c_int64]),
+    "avsi_l1_loss_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_float, c_void_p,
+                                 c_size_t, c_void_p]),
 }
 
 _lib = None

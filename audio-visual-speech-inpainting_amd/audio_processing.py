@@ -86,7 +86,7 @@ def frontend(sources, sample_rate=16000, window_size=24, step_size=12, n_fft=512
              num_frames_out=None, num_bins=None, mean=None, std=None, masks=None,
              want_stft=False, want_spec=False, want_feat=False, want_logmel=False,
              power=1.0, log=True, eps=1e-6, time_major=False, feat_cols=None,
-             num_mel_bins=80, lower_edge_freq=125.0, upper_edge_freq=7600.0):
+             num_mel_bins=80, lower_edge_freq=125.0, upper_edge_freq=7600.0, _feat_out=None):
     """Fused front end: ONE kernel from waveform to every requested output.
 
     sources [B, N] float32 (device).  Returns a dict with the requested keys:
@@ -137,7 +137,13 @@ def frontend(sources, sample_rate=16000, window_size=24, step_size=12, n_fft=512
         out['spec'] = sp
     if want_feat:
         cols = F if feat_cols is None else int(feat_cols)
-        if time_major:
+        if _feat_out is not None:
+            # write into the caller's (padded) buffer: [T, Bp, C] if time_major else [Bp, T, C]
+            ft = _feat_out
+            if ft.dtype != torch.float32 or ft.stride(2) != 1 or ft.shape[2] < cols:
+                raise _lib.AvsiError("bad _feat_out buffer")
+            a.feat_stride_b, a.feat_stride_t = (ft.stride(1), ft.stride(0)) if time_major else (ft.stride(0), ft.stride(1))
+        elif time_major:
             ft = torch.empty((T, B, cols), dtype=torch.float32, device=dev)
             a.feat_stride_b, a.feat_stride_t = ft.stride(1), ft.stride(0)
         else:

@@ -1,0 +1,167 @@
+"""Parameter layouts of the stacked BLSTM: the reference's variables vs. the kernels' packed form.
+
+Two flat float32 buffers describe the same numbers:
+
+* the REFERENCE layout -- the TF variables of ``StackedBLSTMModel`` in creation order
+  (reference models.py:106-121): per layer and direction ``kernel [(D_l+H), 4H]``
+  (gate column blocks i, j, f, o) and ``bias [4H]``, then ``logits/weights [2H, F]`` and
+  ``logits/biases [F]``.  Checkpoints, the optimiser and the data-parallel all-reduce use this;
+* the PACKED layout the gfx950 kernels read (avsi_hip.h): hidden size padded 250 -> 256, gate
+  columns interleaved per 32-unit wave slice, the recurrent kernel in MFMA fragment order.
+
+``ParamLayout`` holds the index maps between them; moving data is one gather each way.
+"""
+import numpy as np
+
+HP = 256            # padded hidden size of the recurrent kernel
+GP = 4 * HP         # packed gate columns per direction
+WH_FLOATS = 8 * 32 * 4 * 64 * 4   # packed recurrent kernel per direction (= HP * GP)
+
+
+def round_up(a, b):
+    return -(-a // b) * b
+
+
+def packed_gate_col(direction, gate, unit):
+    """Column of (direction, gate, hidden unit) inside the 2048-wide packed gate row."""
+    return direction * GP + (unit // 32) * 128 + gate * 32 + unit % 32
+
+
+class ParamLayout:
+    def __init__(self, input_dim, net_dim=(250, 250, 250), audio_feat_dim=257):
+        net_dim = tuple(int(h) for h in net_dim)
+        if len(set(net_dim)) != 1 or net_dim[0] > HP or net_dim[0] < 1:
+            raise ValueError("the gfx950 BLSTM kernels need equal layer sizes <= %d, got %r" % (HP, net_dim))
+        self.input_dim = int(input_dim)
+        self.H = H = net_dim[0]
+        self.num_layers = len(net_dim)
+        self.F = F = int(audio_feat_dim)
+        self.ldp = round_up(F, 4)                      # padded row pitch of the projection matrix
+
+        # ---- reference layout
+        self.ref_entries = []                          # (name, shape, offset)
+        off = 0
+        self.in_dims = []
+        d = self.input_dim
+        for li in range(self.num_layers):
+            self.in_dims.append(d)
+            for dname in ('fw', 'bw'):
+                for vname, shape in (('kernel', (d + H, 4 * H)), ('bias', (4 * H,))):
+                    self.ref_entries.append(('cell_%d/%s/%s' % (li, dname, vname), shape, off))
+                    off += int(np.prod(shape))
+            d = 2 * H
+        self.ref_entries.append(('logits/weights', (2 * H, F), off))
+        off += 2 * H * F
+        self.ref_entries.append(('logits/biases', (F,), off))
+        off += F
+        self.ref_size = off
+        self._ref_off = {n: o for n, _, o in self.ref_entries}
+
+        # ---- packed layout
+        self.kp = [round_up(self.input_dim, 8)] + [2 * HP] * (self.num_layers - 1)
+        self.packed = {}                               # name -> (offset, shape)
+        poff = 0
+
+        def alloc(name, shape):
+            nonlocal poff
+            self.packed[name] = (poff, shape)
+            poff += round_up(int(np.prod(shape)), 64)
+        for li in range(self.num_layers):
+            alloc('wx%d' % li, (self.kp[li], 2 * GP))
+            alloc('b%d' % li, (2 * GP,))
+            alloc('wh%d' % li, (2 * WH_FLOATS,))
+        alloc('pw', (2 * HP, self.ldp))
+        alloc('pb', (self.ldp,))
+        self.packed_size = poff
+
+        self.pack_index = self._build_pack_index()     # packed pos -> ref pos (ref_size = zero slot)
+        inv = np.full(self.ref_size, -1, dtype=np.int64)
+        valid = self.pack_index < self.ref_size
+        inv[self.pack_index[valid]] = np.nonzero(valid)[0]
+        assert (inv >= 0).all(), "every reference parameter must appear exactly once in the packed layout"
+        self.unpack_index = inv                        # ref pos -> packed pos
+
+    # ------------------------------------------------------------------------------
+    def input_row_map(self, li):
+        """Padded input column k of layer li -> row of the reference kernel (or -1)."""
+        H = self.H
+        k = np.arange(self.kp[li])
+        if li == 0:
+            return np.where(k < self.input_dim, k, -1)
+        r = np.full(self.kp[li], -1, dtype=np.int64)
+        r[:H] = np.arange(H)
+        r[HP:HP + H] = H + np.arange(H)
+        return r
+
+    def _build_pack_index(self):
+        H, F, Z = self.H, self.F, self.ref_size
+        idx = np.full(self.packed_size, Z, dtype=np.int64)
+        u = np.arange(H)
+        for li in range(self.num_layers):
+            D = self.in_dims[li]
+            rmap = self.input_row_map(li)
+            wx_off, (kp, _) = self.packed['wx%d' % li]
+            b_off, _ = self.packed['b%d' % li]
+            wh_off, _ = self.packed['wh%d' % li]
+            for d, dname in enumerate(('fw', 'bw')):
+                k_off = self._ref_off['cell_%d/%s/kernel' % (li, dname)]
+                bias_off = self._ref_off['cell_%d/%s/bias' % (li, dname)]
+                for g in range(4):
+                    cols = packed_gate_col(d, g, u)                      # [H]
+                    # input kernel rows
+                    rows = np.nonzero(rmap >= 0)[0]
+                    src = k_off + rmap[rows][:, None] * (4 * H) + (g * H + u)[None, :]
+                    idx[wx_off + rows[:, None] * (2 * GP) + cols[None, :]] = src
+                    idx[b_off + cols] = bias_off + g * H + u
+                    # recurrent kernel in fragment order [d][w][q][g][lane][s]
+                    w_, q_, lane_, s_ = np.meshgrid(np.arange(8), np.arange(32), np.arange(64), np.arange(4),
+                                                    indexing='ij')
+                    kk = 8 * q_ + 4 * (lane_ >> 5) + s_
+                    uu = 32 * w_ + (lane_ & 31)
+                    ok = (kk < H) & (uu < H)
+                    pos = wh_off + ((((d * 8 + w_) * 32 + q_) * 4 + g) * 64 + lane_) * 4 + s_
+                    idx[pos[ok]] = k_off + (D + kk[ok]) * (4 * H) + g * H + uu[ok]
+        pw_off, _ = self.packed['pw']
+        pb_off, _ = self.packed['pb']
+        rmap = np.full(2 * HP, -1, dtype=np.int64)
+        rmap[:H] = np.arange(H)
+        rmap[HP:HP + H] = H + np.arange(H)
+        rows = np.nonzero(rmap >= 0)[0]
+        c = np.arange(F)
+        idx[pw_off + rows[:, None] * self.ldp + c[None, :]] = (
+            self._ref_off['logits/weights'] + rmap[rows][:, None] * F + c[None, :])
+        idx[pb_off + c] = self._ref_off['logits/biases'] + c
+        return idx
+
+    # ------------------------------------------------------------------------------
+    def ref_view(self, flat, name):
+        """View of variable `name` inside a flat reference-layout buffer (numpy or torch)."""
+        for n, shape, off in self.ref_entries:
+            if n == name:
+                return flat[off: off + int(np.prod(shape))].reshape(shape)
+        raise KeyError(name)
+
+    def packed_view(self, flat, name):
+        off, shape = self.packed[name]
+        return flat[off: off + int(np.prod(shape))].reshape(shape)
+
+    def flatten_oracle_params(self, params):
+        """oracle.blstm params dict -> flat reference-layout float32 numpy array."""
+        flat = np.zeros(self.ref_size, dtype=np.float32)
+        for li, layer in enumerate(params['layers']):
+            for dname in ('fw', 'bw'):
+                self.ref_view(flat, 'cell_%d/%s/kernel' % (li, dname))[...] = layer[dname]['kernel']
+                self.ref_view(flat, 'cell_%d/%s/bias' % (li, dname))[...] = layer[dname]['bias']
+        self.ref_view(flat, 'logits/weights')[...] = params['proj']['weights']
+        self.ref_view(flat, 'logits/biases')[...] = params['proj']['biases']
+        return flat
+
+    def unflatten_to_oracle_params(self, flat):
+        flat = np.asarray(flat)
+        return {
+            'layers': [{dname: {'kernel': np.array(self.ref_view(flat, 'cell_%d/%s/kernel' % (li, dname))),
+                                'bias': np.array(self.ref_view(flat, 'cell_%d/%s/bias' % (li, dname)))}
+                        for dname in ('fw', 'bw')} for li in range(self.num_layers)],
+            'proj': {'weights': np.array(self.ref_view(flat, 'logits/weights')),
+                     'biases': np.array(self.ref_view(flat, 'logits/biases'))},
+        }

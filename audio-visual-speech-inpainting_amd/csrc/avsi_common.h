@@ -6,7 +6,10 @@
 
 #define AVSI_ABI_VERSION 1
 
-// Launch-status helper: peek the sticky error after a launch without synchronising.
+// Launch-status helpers.  hipGetLastError() is per-thread and also reports errors left behind
+// by OTHER users of the runtime in this thread (e.g. the caller's framework), so every entry
+// point clears it before its first launch and reads it back after its last.
+static inline void avsi_clear_error() { (void)hipGetLastError(); }
 static inline int avsi_launch_status() {
     return hipGetLastError() == hipSuccess ? AVSI_OK : AVSI_ERR_LAUNCH;
 }

@@ -1,0 +1,204 @@
+// Recurrent half of one bidirectional LSTM layer on gfx950: for every step
+//     z_t = xproj_t + h_{t-1} . Wh ;  (i, j, f, o) = split(z_t)
+//     c_t = sigmoid(f) c_{t-1} + sigmoid(i) tanh(j) ;  h_t = sigmoid(o) tanh(c_t)
+// which is CudnnCompatibleLSTMCell / LSTMBlockCell(forget_bias = 0) under
+// stack_bidirectional_dynamic_rnn (reference models.py:106-115).  The
+// input half x_t . Wx + b of the cell's [x_t, h_{t-1}] . K product is time-independent and is
+// hoisted into one large GEMM (gemm.hip) that produces `xproj`.
+//
+// Mapping (batch-stationary, no inter-workgroup traffic):
+//   - a workgroup owns MT x 32 utterances of one direction for all T steps; h_{t-1} of those
+//     utterances lives in LDS (double buffered), c_t in registers; nothing is exchanged between
+//     workgroups, so there is no grid barrier and no cross-XCD visibility protocol at all;
+//   - 8 waves; wave w owns hidden units [32w, 32w+32) and ALL FOUR gates of those units, i.e.
+//     4 MFMA column tiles x MT row tiles of v_mfma_f32_32x32x2_f32 (exact fp32).  The gate
+//     pre-activations of one (utterance, unit) therefore meet in ONE lane at the same register
+//     index, and the whole cell update is lane-local: no shuffles, no LDS in the epilogue;
+//   - Wh (padded 256 x 1024, 1 MiB per direction) is streamed from the XCD's L2 every step in a
+//     host-packed fragment order: one coalesced 16-byte load per lane feeds 4 k-steps;
+//   - h_{t-1} fragments come from LDS with ds_read_b128 under the same k-permutation as gemm.hip.
+// Layouts (floats):
+//   xproj [T][Bp][2][1024]   packed gate columns: col = 128 w + 32 gate + unit % 32, unit = 32 w + ..
+//   whp   [2][8 w][32 q][4 gate][64 lane][4 s] = Wh[k = 8q + 4(lane>>5) + s][unit 32w + (lane&31)][gate]
+//   hout  [T][Bp][512]       fw units at 0..255, bw units at 256..511 (units >= H stay exactly 0)
+//   resv  [T][Bp][2][5][256] (training only) i, j, f, o after activation, then c_t
+#include "avsi_common.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int HP = 256;         // padded hidden size
+constexpr int HS = HP + 4;      // LDS row stride of the h tile (bank-conflict-free b128 reads)
+constexpr int NWAVE = 8;
+constexpr int GP = 4 * HP;      // packed gate columns per direction
+
+struct RecArgs {
+    const float* xproj;
+    const float* whp;
+    float* hout;
+    float* resv;
+    int T, Bp;
+};
+
+__device__ __forceinline__ float sigmoidf_fast(float x) { return __builtin_amdgcn_rcpf(1.f + __expf(-x)); }
+__device__ __forceinline__ float tanhf_fast(float x) { return 2.f * __builtin_amdgcn_rcpf(1.f + __expf(-2.f * x)) - 1.f; }
+
+// One 8-wide k group: 4 MFMA k-steps x MT row tiles x 4 gate tiles.
+template <int MT>
+__device__ __forceinline__ void kgroup(f32x16 (&acc)[MT][4], const float4 (&b)[4], const float* __restrict__ hcur, int q,
+                                       int li, int hi) {
+    float4 af[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) af[m] = *reinterpret_cast<const float4*>(hcur + (m * 32 + li) * HS + 8 * q + 4 * hi);
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const float av = s == 0 ? af[m].x : s == 1 ? af[m].y : s == 2 ? af[m].z : af[m].w;
+                const float bv = s == 0 ? b[g].x : s == 1 ? b[g].y : s == 2 ? b[g].z : b[g].w;
+                acc[m][g] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[m][g], 0, 0, 0);
+            }
+}
+
+// Buffer-resource helpers: wave-uniform base in SGPRs + one 32-bit lane offset + a scalar offset
+// per access.  Keeps the 128+ per-step row addresses out of the VGPR file (they are scalar
+// immediates) and gives the batch tail for free: rows past num_records read 0 / drop stores.
+typedef __amdgpu_buffer_rsrc_t rsrc_t;
+__device__ __forceinline__ rsrc_t make_rsrc(const void* base, unsigned bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)bytes, 0x00020000);
+}
+__device__ __forceinline__ float buf_load(rsrc_t r, int voff, int soff) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
+}
+__device__ __forceinline__ void buf_store(rsrc_t r, int voff, int soff, float v) {
+    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, voff, soff, 0);
+}
+template <int MT, bool SAVE>
+__global__ __launch_bounds__(512, 2) void blstm_rec_fwd_kernel(const RecArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* hbuf = reinterpret_cast<float*>(smem);  // [2][MT*32][HS]
+    constexpr int HTILE = MT * 32 * HS;
+    constexpr int XROW = 2 * GP * 4, HROW = 2 * HP * 4, RROW = 2 * 5 * HP * 4;  // row pitches, bytes
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);  // provably wave-uniform
+    const int li = lane & 31, hi = lane >> 5;
+    const int dir = blockIdx.y;
+    const int b0 = blockIdx.x * (MT * 32);
+    const int T = a.T, Bp = a.Bp;
+    const int live_rows = min(MT * 32, Bp - b0);
+
+    for (int i = tid; i < 2 * HTILE; i += 512) hbuf[i] = 0.f;
+
+    // Wh fragments: plain 16-byte global loads (uniform base + lane).  NB the b128 raw-buffer
+    // builtin of this toolchain lowers to a single dword load, so it is not used.
+    const float4* __restrict__ wp =
+        reinterpret_cast<const float4*>(a.whp) + (size_t)(dir * NWAVE + w) * (32 * 4 * 64) + lane;
+    const int voff_x = 4 * hi * XROW + (dir * GP + w * 128 + li) * 4;
+    const int voff_h = 4 * hi * HROW + (dir * HP + w * 32 + li) * 4;
+    const int voff_r = 4 * hi * RROW + (dir * 5 * HP + w * 32 + li) * 4;
+
+    f32x16 c[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) c[m][r] = 0.f;
+
+    __syncthreads();
+
+    for (int step = 0; step < T; ++step) {
+        const int t = dir ? (T - 1 - step) : step;
+        const float* hcur = hbuf + (step & 1) * HTILE;
+        float* hnext = hbuf + ((step & 1) ^ 1) * HTILE;
+        const size_t row0 = (size_t)t * Bp + b0;
+        const rsrc_t rx = make_rsrc(a.xproj + row0 * (2 * GP), live_rows * XROW);
+        const rsrc_t rh = make_rsrc(a.hout + row0 * (2 * HP), live_rows * HROW);
+
+        // ---- accumulators start from the hoisted input projection (bias already inside)
+        f32x16 acc[MT][4];
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    acc[m][g][r] = buf_load(rx, voff_x, (m * 32 + (r & 3) + 8 * (r >> 2)) * XROW + g * 128);
+
+        // ---- z += h_{t-1} . Wh : 32 k-groups of 8, Wh fragments prefetched one group ahead.
+        //      Two named register sets (static indexing) ping-pong; see kgroup().
+        float4 bw0[4], bw1[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) bw0[g] = wp[g * 64];
+        for (int q = 0; q < 32; q += 2) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) bw1[g] = wp[((q + 1) * 4 + g) * 64];
+            kgroup<MT>(acc, bw0, hcur, q, li, hi);
+            if (q + 2 < 32) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) bw0[g] = wp[((q + 2) * 4 + g) * 64];
+            }
+            kgroup<MT>(acc, bw1, hcur, q + 1, li, hi);
+        }
+
+        // ---- LSTM cell, lane-local: (row, unit) = (C/D row of register r, 32 w + li)
+        rsrc_t rr = rh;
+        if (SAVE) rr = make_rsrc(a.resv + row0 * (2 * 5 * HP), live_rows * RROW);
+        float* hn_lds = hnext + (4 * hi) * HS + w * 32 + li;
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int rowc = m * 32 + (r & 3) + 8 * (r >> 2);
+                const float ig = sigmoidf_fast(acc[m][0][r]);
+                const float jg = tanhf_fast(acc[m][1][r]);
+                const float fg = sigmoidf_fast(acc[m][2][r]);
+                const float og = sigmoidf_fast(acc[m][3][r]);
+                const float cn = fg * c[m][r] + ig * jg;
+                c[m][r] = cn;
+                const float hn = og * tanhf_fast(cn);
+                hn_lds[rowc * HS] = hn;
+                buf_store(rh, voff_h, rowc * HROW, hn);
+                if (SAVE) {
+                    buf_store(rr, voff_r, rowc * RROW + 0 * HP * 4, ig);
+                    buf_store(rr, voff_r, rowc * RROW + 1 * HP * 4, jg);
+                    buf_store(rr, voff_r, rowc * RROW + 2 * HP * 4, fg);
+                    buf_store(rr, voff_r, rowc * RROW + 3 * HP * 4, og);
+                    buf_store(rr, voff_r, rowc * RROW + 4 * HP * 4, cn);
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+
+template <int MT, bool SAVE>
+int launch_rec(const RecArgs& a, hipStream_t st) {
+    const size_t lds = (size_t)2 * MT * 32 * HS * 4;
+    (void)hipFuncSetAttribute((const void*)blstm_rec_fwd_kernel<MT, SAVE>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)lds);
+    const int tiles = (int)avsi_ceil_div(a.Bp, MT * 32);
+    hipLaunchKernelGGL((blstm_rec_fwd_kernel<MT, SAVE>), dim3(tiles, 2), dim3(512), lds, st, a);
+    return avsi_launch_status();
+}
+
+}  // namespace
+
+extern "C" int avsi_blstm_rec_fwd_f32(const float* xproj, const float* whp, float* hout, float* reserve, int T, int Bp,
+                                      int rows_per_wg, void* stream) {
+    if (!xproj || !whp || !hout || T <= 0 || Bp <= 0) return AVSI_ERR_INVALID_ARG;
+    if (Bp % 32) return AVSI_ERR_INVALID_ARG;  // batch is padded to whole 32-row MFMA tiles
+    if ((reinterpret_cast<uintptr_t>(whp) & 15)) return AVSI_ERR_UNSUPPORTED;
+    RecArgs a{xproj, whp, hout, reserve, T, Bp};
+    // 64 rows per workgroup halves the Wh stream per flop; 32 rows spreads a small batch wider
+    int mt = rows_per_wg;
+    if (mt == 0) mt = (Bp >= 64 * AVSI_NUM_CU / 2) ? 64 : 32;
+    if (mt != 32 && mt != 64) return AVSI_ERR_INVALID_ARG;
+    avsi_clear_error();
+    const hipStream_t st = (hipStream_t)stream;
+    if (mt == 64) return reserve ? launch_rec<2, true>(a, st) : launch_rec<2, false>(a, st);
+    return reserve ? launch_rec<1, true>(a, st) : launch_rec<1, false>(a, st);
+}

@@ -277,6 +277,7 @@ extern "C" size_t avsi_frontend_table_floats(int frame_len, int nfft) {
 extern "C" int avsi_frontend_init_tables(float* table, int frame_len, int nfft, void* stream) {
     if (!table) return AVSI_ERR_INVALID_ARG;
     if (nfft != 512 || frame_len <= 0 || frame_len > 512 || (frame_len & 1)) return AVSI_ERR_UNSUPPORTED;
+    avsi_clear_error();
     hipLaunchKernelGGL(frontend_tables_kernel, dim3(3), dim3(256), 0, (hipStream_t)stream, table, frame_len);
     return avsi_launch_status();
 }
@@ -310,6 +311,7 @@ extern "C" int avsi_frontend_f32(const avsi_frontend_args* args, void* stream) {
     const int wg_per_cu = (int)(160 * 1024 / lds) > 4 ? 4 : (int)(160 * 1024 / lds);
     const int grid = n_tiles < AVSI_NUM_CU * wg_per_cu ? n_tiles : AVSI_NUM_CU * wg_per_cu;
     const hipStream_t st = (hipStream_t)stream;
+    avsi_clear_error();
 
 #define AVSI_FE_LAUNCH(NBV)                                                                                   \
     do {                                                                                                      \

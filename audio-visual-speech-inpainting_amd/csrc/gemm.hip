@@ -1,0 +1,261 @@
+// fp32 GEMM on the gfx950 matrix cores: C = alpha * op(A) . op(B) (+ bias[n]) (+ beta * C)
+//
+// Used for the time-batched halves of the BLSTM (reference models.py:95-115): the hoisted input
+// projections X . Wx of every layer, the output projection (models.py:119-122) and, in training,
+// dX = dZ . W^T and dW = X^T . dZ.
+//
+// v_mfma_f32_32x32x2_f32 is exact fp32 (one rounding per product, k-ordered fma chain), so parity
+// with the fp32 reference graph needs no precision argument.  It issues once per 64 cycles per
+// SIMD, which leaves LDS and global loads far off the critical path; the design therefore
+// optimises for "never stall the MFMA pipe":
+//   - 128 x 128 x 32 block tile, 4 waves as 2 x 2, each wave 2 x 2 MFMA tiles (64 acc VGPRs),
+//     two workgroups per CU so a wave waiting at the k-tile barrier is covered by its SIMD mate;
+//   - register-staged double buffering: the next k-tile's 16-byte global loads are issued before
+//     the current tile's 64 MFMAs and written to the other LDS stage after them;
+//   - operand tiles sit in LDS in the layout they have in memory (no transposing stores):
+//       "row" tiles [x][k] (k contiguous, stride 36) are read with ONE ds_read_b128 per 4 k-steps
+//       using a k-permutation inside each 8-wide k group (lane half h owns k = 8q+4h..8q+4h+3);
+//       "col" tiles [k][x] (x contiguous, stride 132) are read with ds_read_b32, lanes along x;
+//     both are bank-conflict free, and both sides use the same permutation so products match;
+//   - blockIdx -> tile mapping is XCD-aware: the N-blocks that share an A row panel get
+//     consecutive ids on ONE XCD, so the panel is fetched from HBM once and re-served by that L2.
+#include "avsi_common.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int BM = 128, BN = 128, BK = 32;
+constexpr int ROW_STRIDE = BK + 4;   // floats, "row" tile [x][k]
+constexpr int COL_STRIDE = 128 + 4;  // floats, "col" tile [k][x]
+constexpr int ROW_TILE = 128 * ROW_STRIDE;
+constexpr int COL_TILE = BK * COL_STRIDE;
+
+struct GemmArgs {
+    const float* A;
+    const float* B;
+    float* C;
+    const float* bias;
+    const float* row_scale;
+    int row_map_bp, row_map_t, row_map_b;
+    int M, N, K;
+    int64_t lda, ldb, ldc;
+    float alpha, beta;
+    int m_blocks, n_blocks;
+    int k_split_len;       // reduction length handled per blockIdx.z (multiple of BK)
+    int64_t c_split_stride;  // elements between per-split partial outputs (0 = no split)
+};
+
+// Global -> registers for one operand tile.  ROWK: memory is [x][k] (k contiguous), else [k][x].
+template <bool ROWK>
+__device__ __forceinline__ void load_tile(float4 (&r)[4], const float* __restrict__ base, int64_t ld, int x0, int k0,
+                                          int X, int Kend, int tid) {
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        int x, k;
+        if (ROWK) {
+            x = x0 + p * 32 + (tid >> 3);
+            k = k0 + 4 * (tid & 7);
+        } else {
+            k = k0 + p * 8 + (tid >> 5);
+            x = x0 + 4 * (tid & 31);
+        }
+        float4 v = {0.f, 0.f, 0.f, 0.f};
+        if (ROWK) {
+            if (x < X && k < Kend) v = *reinterpret_cast<const float4*>(base + (int64_t)x * ld + k);
+        } else {
+            if (k < Kend && x < X) v = *reinterpret_cast<const float4*>(base + (int64_t)k * ld + x);
+        }
+        r[p] = v;
+    }
+}
+
+template <bool ROWK>
+__device__ __forceinline__ void store_tile(float* __restrict__ s, const float4 (&r)[4], int tid) {
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        if (ROWK)
+            *reinterpret_cast<float4*>(s + (p * 32 + (tid >> 3)) * ROW_STRIDE + 4 * (tid & 7)) = r[p];
+        else
+            *reinterpret_cast<float4*>(s + (p * 8 + (tid >> 5)) * COL_STRIDE + 4 * (tid & 31)) = r[p];
+    }
+}
+
+// TA: A is stored [K][M] (op(A) = A^T).  TB: B is stored [N][K] (op(B) = B^T).
+template <bool TA, bool TB>
+__global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs g) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int A_TILE = TA ? COL_TILE : ROW_TILE;
+    constexpr int B_TILE = TB ? ROW_TILE : COL_TILE;
+    float* sA = reinterpret_cast<float*>(smem);
+    float* sB = sA + 2 * A_TILE;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int li = lane & 31, hi = lane >> 5;
+
+    // XCD-aware, bijective block -> tile map (blocks b and b+8 share an XCD)
+    const int nblk = g.m_blocks * g.n_blocks;
+    int bid = blockIdx.x;
+    {
+        const int q = nblk / AVSI_NUM_XCD, r = nblk % AVSI_NUM_XCD;
+        const int xcd = bid % AVSI_NUM_XCD, idx = bid / AVSI_NUM_XCD;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int bm = bid / g.n_blocks, bn = bid - bm * g.n_blocks;
+    const int m0 = bm * BM, n0 = bn * BN;
+    const int kbeg = blockIdx.z * g.k_split_len;
+    const int kend = min(g.K, kbeg + g.k_split_len);
+    const int nk = (kend - kbeg + BK - 1) / BK;
+    float* __restrict__ C = g.C + (int64_t)blockIdx.z * g.c_split_stride;
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    float4 ra[4], rb[4];
+    load_tile<!TA>(ra, g.A, g.lda, m0, kbeg, g.M, kend, tid);
+    load_tile<TB>(rb, g.B, g.ldb, n0, kbeg, g.N, kend, tid);
+    store_tile<!TA>(sA, ra, tid);
+    store_tile<TB>(sB, rb, tid);
+    __syncthreads();
+
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        const bool more = kt + 1 < nk;
+        if (more) {
+            load_tile<!TA>(ra, g.A, g.lda, m0, kbeg + (kt + 1) * BK, g.M, kend, tid);
+            load_tile<TB>(rb, g.B, g.ldb, n0, kbeg + (kt + 1) * BK, g.N, kend, tid);
+        }
+        const float* a_s = sA + cur * A_TILE;
+        const float* b_s = sB + cur * B_TILE;
+#pragma unroll
+        for (int q = 0; q < BK / 8; ++q) {
+            float af[2][4], bf[2][4];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int row = wm * 64 + i * 32 + li;
+                if (!TA) {
+                    const float4 v = *reinterpret_cast<const float4*>(a_s + row * ROW_STRIDE + 8 * q + 4 * hi);
+                    af[i][0] = v.x, af[i][1] = v.y, af[i][2] = v.z, af[i][3] = v.w;
+                } else {
+#pragma unroll
+                    for (int s = 0; s < 4; ++s) af[i][s] = a_s[(8 * q + 4 * hi + s) * COL_STRIDE + row];
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int col = wn * 64 + j * 32 + li;
+                if (TB) {
+                    const float4 v = *reinterpret_cast<const float4*>(b_s + col * ROW_STRIDE + 8 * q + 4 * hi);
+                    bf[j][0] = v.x, bf[j][1] = v.y, bf[j][2] = v.z, bf[j][3] = v.w;
+                } else {
+#pragma unroll
+                    for (int s = 0; s < 4; ++s) bf[j][s] = b_s[(8 * q + 4 * hi + s) * COL_STRIDE + col];
+                }
+            }
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][s], bf[j][s], acc[i][j], 0, 0, 0);
+        }
+        if (more) {
+            store_tile<!TA>(sA + (cur ^ 1) * A_TILE, ra, tid);
+            store_tile<TB>(sB + (cur ^ 1) * B_TILE, rb, tid);
+        }
+        __syncthreads();
+    }
+
+    // epilogue: C/D layout of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+            if (row >= g.M) continue;
+            int64_t orow = row;
+            if (g.row_map_bp > 0) {  // time-major (t, b) -> batch-major (b, t), padded batch rows dropped
+                const int t = row / g.row_map_bp, b = row - t * g.row_map_bp;
+                if (b >= g.row_map_b) continue;
+                orow = (int64_t)b * g.row_map_t + t;
+            }
+            const float rsc = g.row_scale ? g.row_scale[row] : 1.f;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int col = n0 + wn * 64 + j * 32 + li;
+                if (col >= g.N) continue;
+                float* c = C + orow * g.ldc + col;
+                float v = g.alpha * acc[i][j][r];
+                if (g.bias) v += g.bias[col];
+                v *= rsc;
+                if (g.beta != 0.f) v += g.beta * *c;
+                *c = v;
+            }
+        }
+    }
+}
+
+template <bool TA, bool TB>
+int launch(const GemmArgs& g, int splits, hipStream_t st) {
+    constexpr size_t lds = (size_t)2 * ((TA ? COL_TILE : ROW_TILE) + (TB ? ROW_TILE : COL_TILE)) * 4;
+    static_assert(lds <= 80 * 1024, "two workgroups must fit one CU's 160 KiB LDS");
+    if (lds > 64 * 1024)
+        (void)hipFuncSetAttribute((const void*)gemm_kernel<TA, TB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL((gemm_kernel<TA, TB>), dim3(g.m_blocks * g.n_blocks, 1, splits), dim3(256), lds, st, g);
+    return avsi_launch_status();
+}
+
+}  // namespace
+
+// Internal entry shared with the other translation units (not part of the C ABI).
+int avsi_gemm_launch(int transA, int transB, int M, int N, int K, float alpha, const float* A, int64_t lda,
+                     const float* B, int64_t ldb, float beta, float* C, int64_t ldc, const avsi_gemm_epilogue* ep,
+                     int splits, int64_t c_split_stride, hipStream_t st) {
+    if (!A || !B || !C || M <= 0 || N <= 0 || K <= 0) return AVSI_ERR_INVALID_ARG;
+    // 16-byte global loads along each operand's contiguous dimension
+    if ((lda & 3) || (ldb & 3) || (K & 3) || (reinterpret_cast<uintptr_t>(A) & 15) ||
+        (reinterpret_cast<uintptr_t>(B) & 15))
+        return AVSI_ERR_UNSUPPORTED;
+    if (transA ? (lda < avsi_round_up(M, 4)) : (lda < K)) return AVSI_ERR_INVALID_ARG;
+    if (transB ? (ldb < K) : (ldb < avsi_round_up(N, 4))) return AVSI_ERR_INVALID_ARG;
+    if (ldc < N || splits < 1) return AVSI_ERR_INVALID_ARG;
+    GemmArgs g;
+    g.A = A, g.B = B, g.C = C;
+    g.bias = ep ? ep->bias : nullptr;
+    g.row_scale = ep ? ep->row_scale : nullptr;
+    g.row_map_bp = ep ? ep->row_map_bp : 0;
+    g.row_map_t = ep ? ep->row_map_t : 0;
+    g.row_map_b = ep ? ep->row_map_b : 0;
+    if (g.row_map_bp < 0 || (g.row_map_bp > 0 && (g.row_map_t <= 0 || g.row_map_b <= 0 || M % g.row_map_bp)))
+        return AVSI_ERR_INVALID_ARG;
+    g.M = M, g.N = N, g.K = K;
+    g.lda = lda, g.ldb = ldb, g.ldc = ldc;
+    g.alpha = alpha, g.beta = beta;
+    g.m_blocks = (int)avsi_ceil_div(M, BM);
+    g.n_blocks = (int)avsi_ceil_div(N, BN);
+    g.k_split_len = (int)avsi_round_up(avsi_ceil_div(K, splits), BK);
+    g.c_split_stride = splits > 1 ? c_split_stride : 0;
+    if ((int64_t)g.m_blocks * g.n_blocks > INT32_MAX) return AVSI_ERR_UNSUPPORTED;
+    // "col" tiles read 4 consecutive x per lane and guard on the first: the ld padding up to a
+    // multiple of 4 (checked above) keeps the tail addressable; such lanes feed unstored outputs.
+    avsi_clear_error();
+    if (!transA && !transB) return launch<false, false>(g, splits, st);
+    if (!transA && transB) return launch<false, true>(g, splits, st);
+    if (transA && !transB) return launch<true, false>(g, splits, st);
+    return launch<true, true>(g, splits, st);
+}
+
+extern "C" int avsi_gemm_f32(int transA, int transB, int M, int N, int K, float alpha, const float* A, int64_t lda,
+                             const float* B, int64_t ldb, float beta, float* C, int64_t ldc,
+                             const avsi_gemm_epilogue* epilogue, void* stream) {
+    return avsi_gemm_launch(transA, transB, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, epilogue, 1, 0,
+                            (hipStream_t)stream);
+}

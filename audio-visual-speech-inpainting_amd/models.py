@@ -1,0 +1,322 @@
+"""Speech-inpainting models on MI355X (host side).
+
+``StackedBLSTMModel`` mirrors the reference class of the same name
+(``av_speech_inpainting/models.py:11-237``): same constructor arguments, same attribute names
+(``inference, prediction, loss, loss_func, loss_hole, loss_valid, train_op, enhanced_sources,
+target_spec_norm, global_step, learning_rate ...``).  The reference builds a TF graph over
+placeholders and evaluates it with ``sess.run(fetches, feed_dict)``; here the constructor
+arguments are the fed values themselves (torch device tensors or numpy arrays), ``feed()``
+replaces them for the next batch, and reading an attribute runs the gfx950 kernels needed for
+it (results are cached until the next ``feed()``).
+
+Device data layout: activations are TIME-MAJOR ``[T][Bp][C]`` with the batch
+padded to a multiple of 32 (whole MFMA row tiles) and channels padded (257 -> 264 inputs,
+250 -> 256 hidden units per direction); padded hidden units are exactly zero by construction.
+"""
+import math
+import sys
+
+import numpy as np
+import torch
+
+from . import _lib, ops
+from . import audio_processing as ap
+from .blstm_layout import GP, HP, ParamLayout, round_up
+
+
+def _as_device(x, dtype=torch.float32, device=None):
+    if x is None:
+        return None
+    if isinstance(x, torch.Tensor):
+        return x.to(device=device or 'cuda', dtype=dtype)
+    return torch.as_tensor(np.asarray(x), dtype=dtype).to(device or 'cuda')
+
+
+class BLSTMVariables:
+    """The trainable variables of one StackedBLSTMModel + optimiser slots, on one GPU.
+
+    ``flat`` is the reference-layout buffer (what checkpoints / Adam / all-reduce see);
+    ``packed`` is the kernels' view, refreshed by ``repack()`` after every update."""
+
+    def __init__(self, layout, device='cuda', seed=0):
+        _lib.require_cuda()
+        self.layout = layout
+        self.device = torch.device(device)
+        self.flat = torch.from_numpy(self._tf_default_init(layout, seed)).to(self.device)
+        self._pack_index = torch.from_numpy(layout.pack_index).to(self.device)
+        self._unpack_index = torch.from_numpy(layout.unpack_index).to(self.device)
+        self.packed = torch.empty(layout.packed_size, dtype=torch.float32, device=self.device)
+        self.adam_m = None
+        self.adam_v = None
+        self.global_step = 0
+        self.repack()
+
+    @staticmethod
+    def _tf_default_init(layout, seed):
+        """TF default initialisers: LSTM kernels glorot-uniform, biases
+        zero, projection truncated-normal(stddev 1/sqrt(2H)) -- reference models.py:107,119-121."""
+        rng = np.random.default_rng(seed)
+        flat = np.zeros(layout.ref_size, dtype=np.float32)
+        for name, shape, off in layout.ref_entries:
+            n = int(np.prod(shape))
+            if name.endswith('/kernel'):
+                lim = math.sqrt(6.0 / (shape[0] + shape[1]))
+                flat[off:off + n] = rng.uniform(-lim, lim, size=n)
+            elif name == 'logits/weights':
+                sd = 1.0 / math.sqrt(float(shape[0]))
+                w = rng.normal(0.0, sd, size=n)
+                bad = np.abs(w) > 2 * sd
+                while bad.any():
+                    w[bad] = rng.normal(0.0, sd, size=int(bad.sum()))
+                    bad = np.abs(w) > 2 * sd
+                flat[off:off + n] = w
+        return flat
+
+    def repack(self):
+        """packed <- gather(flat): one index_select (padding positions read the appended 0)."""
+        ext = torch.cat([self.flat, self.flat.new_zeros(1)])
+        torch.index_select(ext, 0, self._pack_index, out=self.packed)
+
+    def load_flat(self, flat):
+        flat = torch.as_tensor(np.asarray(flat, dtype=np.float32))
+        if flat.numel() != self.layout.ref_size:
+            raise ValueError("expected %d parameters, got %d" % (self.layout.ref_size, flat.numel()))
+        self.flat.copy_(flat.to(self.device))
+        self.repack()
+
+    def p(self, name):
+        return self.layout.packed_view(self.packed, name)
+
+    def unpack_grads(self, packed_grads):
+        """reference-layout gradient <- gather(packed gradient)."""
+        return torch.index_select(packed_grads, 0, self._unpack_index)
+
+
+class StackedBLSTMModel(object):
+    """
+    Speech inpainting BLSTM model (reference models.py:11-237).
+    Input: log-compressed linear spectrogram of corrupted audio (and/or face-landmark motion).
+    Model: stacked BLSTM.  Output: log-compressed linear spectrogram of restored audio.
+    Loss: L1 (target_spectrogram - reconstructed_spectrogram).
+    """
+
+    def __init__(self, sequence_lengths, target_sources, masks, audio_feat_mean, audio_feat_std, dropout_rate, config,
+                 audio_features=None, video_features=None, input='a', is_training=True, variables=None, seed=0):
+        _lib.require_cuda()
+        self.audio_feat_dim = config['audio_feat_dim']
+        self.audio_len = config['audio_len']
+        self.video_feat_dim = config.get('video_feat_dim', 136)
+        self.input_type = input
+        if input not in ('a', 'v', 'av'):
+            print('Model input must be "a", "v" or "av". Closing...')
+            sys.exit(1)
+        self.dropout_rate = dropout_rate
+        if dropout_rate not in (0, 0.0, None):
+            raise _lib.AvsiError("dropout_rate != 0 is not supported by the gfx950 path (reference configs use 0.0)")
+        self.net_dim = config['net_dim']
+        self.num_layers = len(self.net_dim)
+        self.optimizer_choice = config['optimizer_type']
+        self.starter_learning_rate = config['starter_learning_rate']
+        self.updating_step = config['lr_updating_steps']
+        self.learning_decay = config['lr_decay']
+        self.is_training = is_training
+        self.batch_size = config.get('batch_size', 1)
+        self.regularization = config['l2']
+        self.var_scope = None
+        self.rows_per_wg = int(config.get('rows_per_wg', 0))   # 0 = kernel picks 32/64 from the batch
+        in_dim = {'a': self.audio_feat_dim, 'v': self.video_feat_dim,
+                  'av': self.audio_feat_dim + self.video_feat_dim}[input]
+        self.layout = variables.layout if variables is not None else ParamLayout(in_dim, self.net_dim,
+                                                                                 self.audio_feat_dim)
+        if self.layout.input_dim != in_dim:
+            raise ValueError("variables were built for input dim %d, model needs %d" % (self.layout.input_dim, in_dim))
+        self.variables = variables if variables is not None else BLSTMVariables(self.layout, seed=seed)
+        self.device = self.variables.device
+        self._ws = {}
+        self.audio_feat_mean = _as_device(audio_feat_mean, device=self.device)
+        self.audio_feat_std = _as_device(audio_feat_std, device=self.device)
+        self._cache = {}
+        self.sequence_lengths = None
+        self.feed(sequence_lengths=sequence_lengths, target_sources=target_sources, masks=masks,
+                  audio_features=audio_features, video_features=video_features)
+
+    # ---------------------------------------------------------------- feed boundary
+    def feed(self, sequence_lengths=None, target_sources=None, masks=None, video_features=None,
+             audio_features=None, audio_feat_mean=None, audio_feat_std=None):
+        """Replace the fed values (the reference's feed_dict, training.py:67-74) and drop cached results."""
+        self._cache = {}
+        if sequence_lengths is not None:
+            self.sequence_lengths = np.asarray(
+                sequence_lengths.cpu() if isinstance(sequence_lengths, torch.Tensor) else sequence_lengths,
+                dtype=np.int64)
+        self.target_sources = _as_device(target_sources, device=self.device)
+        self.masks = _as_device(masks, device=self.device)
+        self.video_features = _as_device(video_features, device=self.device)
+        self.fed_audio_features = _as_device(audio_features, device=self.device)
+        if audio_feat_mean is not None:
+            self.audio_feat_mean = _as_device(audio_feat_mean, device=self.device)
+        if audio_feat_std is not None:
+            self.audio_feat_std = _as_device(audio_feat_std, device=self.device)
+
+    def build_graph(self, var_scope=''):
+        """Kept for API parity (reference models.py:74-87): variables already exist."""
+        self.var_scope = var_scope
+
+    # ---------------------------------------------------------------- workspaces
+    def _buf(self, name, shape, zero=False):
+        key = (name, tuple(shape))
+        t = self._ws.get(key)
+        if t is None:
+            t = (torch.zeros if zero else torch.empty)(shape, dtype=torch.float32, device=self.device)
+            self._ws[key] = t
+        return t
+
+    def _dims(self):
+        B = int(self.target_sources.shape[0]) if self.target_sources is not None else int(self.video_features.shape[0])
+        T = int(self.sequence_lengths.max())
+        return B, T, round_up(B, 32)
+
+    # ---------------------------------------------------------------- front end (models.py:30-45)
+    def _frontend(self):
+        c = self._cache
+        if 'x0' in c:
+            return
+        B, T, Bp = self._dims()
+        Kp = self.layout.kp[0]
+        F = self.audio_feat_dim
+        # zero-initialised once: padded batch rows / padded columns stay zero across calls
+        x0 = self._buf('x0', (T, Bp, Kp), zero=True)
+        if self.input_type in ('a', 'av') or self.target_sources is not None:
+            fe = ap.frontend(self.target_sources, window_size=24, step_size=12, n_fft=512, num_frames_out=T,
+                             num_bins=F, mean=self.audio_feat_mean, std=self.audio_feat_std, masks=self.masks,
+                             want_spec=True, want_feat=self.input_type != 'v' and self.fed_audio_features is None,
+                             time_major=True, feat_cols=Kp if self.input_type == 'a' else F,
+                             _feat_out=x0 if self.input_type != 'v' else None)
+            c['target_spec_norm'] = fe['spec']
+        if self.input_type != 'v' and self.fed_audio_features is not None:
+            x0[:, :B, :F] = self.fed_audio_features[:, :T].transpose(0, 1)
+        if self.input_type == 'v':
+            x0[:, :B, :self.video_feat_dim] = self.video_features[:, :T].transpose(0, 1)
+        elif self.input_type == 'av':
+            x0[:, :B, F:F + self.video_feat_dim] = self.video_features[:, :T].transpose(0, 1)
+        c['x0'] = x0
+
+    @property
+    def target_spec_norm(self):
+        self._frontend()
+        return self._cache['target_spec_norm']
+
+    @property
+    def net_inputs(self):
+        """[B, T, D] view of the (time-major, padded) network input."""
+        self._frontend()
+        B, T, _ = self._dims()
+        return self._cache['x0'][:, :B, :self.layout.input_dim].transpose(0, 1)
+
+    # ---------------------------------------------------------------- BLSTM + projection (models.py:89-138)
+    def _forward(self, keep=False):
+        c = self._cache
+        if 'pred' in c and (not keep or c.get('kept')):
+            return
+        self._frontend()
+        B, T, Bp = self._dims()
+        v = self.variables
+        x = c['x0']
+        xproj = self._buf('xproj', (T, Bp, 2 * GP))
+        c['layer_in'] = []
+        c['reserve'] = []
+        for li in range(self.num_layers):
+            kp = self.layout.kp[li]
+            ops.gemm(x.view(T * Bp, kp), v.p('wx%d' % li), out=xproj.view(T * Bp, 2 * GP), bias=v.p('b%d' % li))
+            hout = self._buf('h%d' % li, (T, Bp, 2 * HP))
+            resv = self._buf('resv%d' % li, (T, Bp, 2, 5, HP)) if keep else None
+            ops.blstm_rec_fwd(xproj, v.p('wh%d' % li), hout, resv, self.rows_per_wg)
+            c['layer_in'].append(x)
+            c['reserve'].append(resv)
+            x = hout
+        c['rnn_out'] = x
+        # prediction = sequence_mask * (rnn_out . W + b), stored batch-major [B, T, F]
+        seq = torch.as_tensor(self.sequence_lengths, device=self.device)
+        row_scale = self._buf('row_scale', (T, Bp), zero=True)
+        row_scale[:, :B] = (torch.arange(T, device=self.device)[:, None] < seq[None, :]).to(torch.float32)
+        pred = torch.empty((B, T, self.audio_feat_dim), dtype=torch.float32, device=self.device)
+        ops.gemm(x.view(T * Bp, 2 * HP), v.p('pw'), out=pred.view(B * T, self.audio_feat_dim),
+                 n=self.audio_feat_dim, bias=v.p('pb'), row_scale=row_scale.view(-1), row_map=(Bp, T, B))
+        c['row_scale'] = row_scale
+        c['pred'] = pred
+        c['kept'] = keep
+
+    @property
+    def inference(self):
+        """Logits before the sequence mask (models.py:89-125).  Equal to `prediction` on frames
+        inside each utterance; the reference's un-masked tail frames are not materialised."""
+        return self.prediction
+
+    @property
+    def prediction(self):
+        self._forward()
+        return self._cache['pred']
+
+    @property
+    def rnn_outputs(self):
+        """[B, T, 2H] view of the last BLSTM layer output (padding stripped)."""
+        self._forward()
+        B, T, _ = self._dims()
+        H = self.layout.H
+        h = self._cache['rnn_out'][:, :B]
+        return torch.cat([h[:, :, :H], h[:, :, HP:HP + H]], dim=2).transpose(0, 1)
+
+    # ---------------------------------------------------------------- loss (models.py:140-159)
+    def _loss(self, want_grad=False):
+        c = self._cache
+        if 'loss3' in c and (not want_grad or c.get('dpred') is not None):
+            return
+        self._forward(keep=want_grad)
+        tgt = self.target_spec_norm
+        mask = self.masks[:, :tgt.shape[1]].contiguous()
+        out3, dpred = ops.l1_loss(tgt, c['pred'], mask, want_grad=want_grad)
+        c['loss3'] = out3
+        c['dpred'] = dpred
+
+    @property
+    def loss_func(self):
+        self._loss()
+        return self._cache['loss3'][0]
+
+    @property
+    def loss_hole(self):
+        self._loss()
+        return self._cache['loss3'][1]
+
+    @property
+    def loss_valid(self):
+        self._loss()
+        return self._cache['loss3'][2]
+
+    @property
+    def reg_loss(self):
+        if self.regularization:
+            return (self.variables.flat.double() ** 2).sum().float() / 2.0
+        return torch.zeros((), device=self.device)
+
+    @property
+    def loss(self):
+        if self.regularization:
+            return self.loss_func + self.regularization * self.reg_loss
+        return self.loss_func
+
+    @property
+    def global_step(self):
+        return self.variables.global_step
+
+    @property
+    def learning_rate(self):
+        """tf.train.exponential_decay(staircase=True) (models.py:165-166); Adam ignores it (F9)."""
+        return self.starter_learning_rate * self.learning_decay ** math.floor(
+            self.variables.global_step / self.updating_step)
+
+    @property
+    def train_vars(self):
+        return [(n, self.layout.ref_view(self.variables.flat, n)) for n, _, _ in self.layout.ref_entries]
+
+    all_vars = train_vars

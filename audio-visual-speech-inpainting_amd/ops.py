@@ -1,0 +1,83 @@
+"""Thin torch-tensor wrappers over the C ABI (one function per entry point of avsi_hip.h).
+
+No arithmetic happens here: each wrapper validates layout, passes raw device pointers and the
+current stream to libavsi_hip.so, and returns the output tensor."""
+import ctypes
+
+import torch
+
+from . import _lib
+
+
+def gemm(a, b, out=None, trans_a=False, trans_b=False, m=None, n=None, k=None, alpha=1.0, beta=0.0,
+         bias=None, row_scale=None, row_map=None, ldc=None):
+    """C = alpha * op(A) . op(B) + bias (+ beta * C) through avsi_gemm_f32.
+
+    a, b: 2-D float32 device tensors, unit stride along their last dim (row pitch = lda/ldb).
+    m, n, k default to the logical shapes implied by a/b; pass them to ignore padding columns.
+    row_map = (Bp, T, B): time-major rows -> batch-major output rows (see avsi_hip.h)."""
+    _lib.require_cuda(a, b, out, bias, row_scale)
+    L = _lib.lib()
+    for x in (a, b):
+        if x.dtype != torch.float32 or x.dim() != 2 or x.stride(1) != 1:
+            raise _lib.AvsiError("gemm operands must be 2-D float32 with unit inner stride")
+    M = m if m is not None else (a.shape[1] if trans_a else a.shape[0])
+    K = k if k is not None else (a.shape[0] if trans_a else a.shape[1])
+    N = n if n is not None else (b.shape[0] if trans_b else b.shape[1])
+    if out is None:
+        rows = M if row_map is None else row_map[1] * row_map[2]
+        out = torch.empty((rows, N), dtype=torch.float32, device=a.device)
+    ep = _lib.GemmEpilogue()
+    ep.bias, ep.row_scale = _lib.ptr(bias), _lib.ptr(row_scale)
+    if row_map is not None:
+        ep.row_map_bp, ep.row_map_t, ep.row_map_b = (int(v) for v in row_map)
+    _lib.check(L.avsi_gemm_f32(int(trans_a), int(trans_b), M, N, K, float(alpha), _lib.ptr(a), a.stride(0),
+                               _lib.ptr(b), b.stride(0), float(beta), _lib.ptr(out),
+                               out.stride(0) if ldc is None else ldc, ctypes.byref(ep), _lib.stream_ptr()),
+               "avsi_gemm_f32")
+    return out
+
+
+def blstm_rec_fwd(xproj, whp, hout, reserve=None, rows_per_wg=0):
+    """All T steps of both directions of one layer (avsi_blstm_rec_fwd_f32).
+    xproj [T, Bp, 2048], whp [2 * 262144], hout [T, Bp, 512], reserve [T, Bp, 2, 5, 256] or None."""
+    _lib.require_cuda(xproj, whp, hout, reserve)
+    T, Bp = xproj.shape[0], xproj.shape[1]
+    if not (xproj.is_contiguous() and hout.is_contiguous() and whp.is_contiguous()):
+        raise _lib.AvsiError("blstm_rec_fwd operands must be contiguous")
+    if tuple(xproj.shape) != (T, Bp, 2048) or tuple(hout.shape) != (T, Bp, 512) or whp.numel() != 2 * 262144:
+        raise _lib.AvsiError("blstm_rec_fwd: bad operand shapes")
+    if reserve is not None and (tuple(reserve.shape) != (T, Bp, 2, 5, 256) or not reserve.is_contiguous()):
+        raise _lib.AvsiError("blstm_rec_fwd: bad reserve shape")
+    _lib.check(_lib.lib().avsi_blstm_rec_fwd_f32(_lib.ptr(xproj), _lib.ptr(whp), _lib.ptr(hout), _lib.ptr(reserve),
+                                                 T, Bp, int(rows_per_wg), _lib.stream_ptr()),
+               "avsi_blstm_rec_fwd_f32")
+    return hout
+
+
+_LOSS_WS = {}
+
+
+def l1_loss(target, pred, mask, want_grad=False, grad_scale=None):
+    """(out3, dpred): out3 = [loss_func, loss_hole, loss_valid] (device float32[3])."""
+    _lib.require_cuda(target, pred, mask)
+    L = _lib.lib()
+    for x in (target, pred, mask):
+        if x.dtype != torch.float32 or not x.is_contiguous():
+            raise _lib.AvsiError("l1_loss operands must be contiguous float32")
+    n = target.numel()
+    if pred.numel() != n or mask.numel() != n:
+        raise _lib.AvsiError("l1_loss: size mismatch")
+    dev = target.device
+    ws = _LOSS_WS.get(dev.index)
+    need = L.avsi_l1_loss_workspace_bytes(n)
+    if ws is None or ws.numel() * 4 < need:
+        ws = torch.empty((need + 3) // 4, dtype=torch.float32, device=dev)
+        _LOSS_WS[dev.index] = ws
+    out3 = torch.empty(3, dtype=torch.float32, device=dev)
+    dpred = torch.empty_like(pred) if want_grad else None
+    gs = (1.0 / n) if grad_scale is None else float(grad_scale)
+    _lib.check(L.avsi_l1_loss_f32(_lib.ptr(target), _lib.ptr(pred), _lib.ptr(mask), n, _lib.ptr(out3),
+                                  _lib.ptr(dpred), gs, _lib.ptr(ws), ws.numel() * 4, _lib.stream_ptr()),
+               "avsi_l1_loss_f32")
+    return out3, dpred

@@ -92,6 +92,55 @@ typedef struct avsi_frontend_args {
 
 int avsi_frontend_f32(const avsi_frontend_args* args, void* stream);
 
+/* ------------------------------------------------------------------------------------
+ * fp32 GEMM on the matrix cores (v_mfma_f32_32x32x2_f32, exact fp32):
+ *     C[M,N] = alpha * op(A) . op(B) + bias[n] + beta * C
+ * transA = 0: A is [M,K] row-major (lda >= K);   transA = 1: A is [K,M] (lda >= M rounded to 4)
+ * transB = 0: B is [K,N] row-major (ldb >= N rounded up to 4, padding addressable);
+ * transB = 1: B is [N,K] (ldb >= K).  K, lda, ldb multiples of 4; A, B 16-byte aligned.
+ * Replaces the time-batched tf.matmul pieces of the graph: the x_t half of LSTMBlockCell's
+ * [x_t, h_{t-1}] . kernel product (models.py:107-115), the logits matmul (models.py:122), and
+ * their gradients.  `row_map_*`: when row_map_bp > 0 the M rows are time-major (t, b) pairs with
+ * batch pitch row_map_bp and output row (t, b) is stored at row b * row_map_t + t, rows with
+ * b >= row_map_b are dropped (time-major -> reference [B, T, .] layout).
+ * row_scale (optional, [M]) multiplies each finished row: tf.sequence_mask at models.py:136.
+ * ------------------------------------------------------------------------------------ */
+typedef struct avsi_gemm_epilogue {
+    const float* bias;        /* [N] or null */
+    const float* row_scale;   /* [M] or null, applied after bias */
+    int32_t row_map_bp, row_map_t, row_map_b;
+} avsi_gemm_epilogue;
+
+int avsi_gemm_f32(int transA, int transB, int M, int N, int K, float alpha,
+                  const float* A, int64_t lda, const float* B, int64_t ldb,
+                  float beta, float* C, int64_t ldc, const avsi_gemm_epilogue* epilogue,
+                  void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * Recurrent half of one bidirectional LSTM layer, all T steps, both directions.
+ * Replaces the tf.while_loop over LSTMBlockCell / the CudnnLSTM op (models.py:95-115).
+ *   xproj   [T][Bp][2][1024]  x_t . Wx + b for (fw, bw), packed gate columns
+ *                             col = 128 w + 32 gate + u, hidden unit = 32 w + u, gate in (i,j,f,o)
+ *   whp     [2][8][32][4][64][4]  recurrent kernel in MFMA fragment order (see blstm_fwd.hip)
+ *   hout    [T][Bp][512]      fw hidden units at 0..255, bw at 256..511 (padded units are 0)
+ *   reserve [T][Bp][2][5][256] or null: activated i, j, f, o and c_t kept for BPTT
+ * Hidden size is padded to 256 (the reference uses 250); Bp must be a multiple of 32.
+ * rows_per_wg: 32, 64, or 0 = choose from Bp.
+ * ------------------------------------------------------------------------------------ */
+int avsi_blstm_rec_fwd_f32(const float* xproj, const float* whp, float* hout, float* reserve,
+                           int T, int Bp, int rows_per_wg, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * L1 loss and its diagnostics over [n] elements (models.py:144-151):
+ *   out[0] = mean|t-p|, out[1] = sum|t-p|(1-m)/sum(1-m), out[2] = sum|t-p|m/sum(m)
+ * and, when dpred != null, dpred = grad_scale * sign(p - t) (the tf.abs gradient).
+ * workspace: avsi_l1_loss_workspace_bytes(n) bytes.
+ * ------------------------------------------------------------------------------------ */
+size_t avsi_l1_loss_workspace_bytes(int64_t n);
+int avsi_l1_loss_f32(const float* target, const float* pred, const float* mask, int64_t n,
+                     float* out3, float* dpred, float grad_scale, void* workspace,
+                     size_t workspace_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
