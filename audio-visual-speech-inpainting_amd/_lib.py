@@ -70,6 +70,10 @@ def lib():
                 "libavsi_hip.so not found at %s: build it with `make -C %s` (or "
                 "`python -c 'import __graft_entry__ as g; g.build()'`). There is no CPU fallback."
                 % (LIB_PATH, os.path.dirname(LIB_PATH)))
+        # PyTorch-ROCm bundles its own libamdhip64.so (same SONAME as /opt/rocm's).  Its streams
+        # and device pointers belong to THAT runtime instance, so it must be the one already
+        # loaded when libavsi_hip.so's NEEDED entry is resolved: import torch first.
+        import torch  # noqa: F401
         handle = ctypes.CDLL(LIB_PATH)
         for name, (restype, argtypes) in PROTOTYPES.items():
             fn = getattr(handle, name)      # AttributeError if a declared symbol is missing

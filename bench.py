@@ -1,0 +1,241 @@
+#!/usr/bin/env python3
+"""Headline benchmark: masked utterances / second through the inpainting hot path on MI355X.
+
+One "step" = one pass of the hot path over one batch of synthetic GRID-shaped input that is
+already resident in HBM: fused STFT / log-spectrum front end -> 3 x BLSTM-250 forward
+(hoisted fp32-MFMA input GEMMs + recurrent kernel) -> 500->257 projection + sequence mask ->
+L1 loss (what the reference's `infer` fetches per batch, inference.py:131, minus the
+waveform reconstruction).  Workload = BASELINE.json configs[1]: audio-only 3xBLSTM-250
+inpainter on 3 s / 16 kHz clips with one 400 ms gap each.
+
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B]
+
+For N > 1 launch with torch.distributed.run (one rank per GPU); utterances are sharded across
+ranks with no data-path collective (weak scaling: per-GPU batch fixed).  Rank 0 prints ONE JSON
+line.  `roofline` is measured live with HIP events on the launch stream around the dominant
+kernel; `cpu_baseline` times the CPU oracle (a numpy port of the reference graph) on a bounded
+sample of the same workload on this node's host cores.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+N_SAMPLES = 48000          # 3 s @ 16 kHz
+T_FRAMES = 250
+F_BINS = 257
+GAP_FRAMES = 33            # 400 ms (dataset_generator.py:16-17,73)
+H = 250
+FP32_MFMA_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+HBM_PEAK_GBS = 8000.0
+
+
+def algorithmic_flops(batch, input_dim=257):
+    """forward FLOPs of the gate GEMMs, split by kernel, per `batch` utterances."""
+    d = [input_dim, 2 * H, 2 * H]
+    gemm_in = [2.0 * d[l] * (4 * H) * 2 * T_FRAMES * batch for l in range(3)]       # x_t . Wx, both dirs
+    rec = 2.0 * H * (4 * H) * 2 * T_FRAMES * batch                                   # h_{t-1} . Wh, per layer
+    proj = 2.0 * (2 * H) * F_BINS * T_FRAMES * batch
+    return gemm_in, rec, proj
+
+
+class KernelTimer:
+    """HIP-event pairs on the launch stream (torch's current stream is the stream the C ABI
+    launches on), grouped by kernel name."""
+
+    def __init__(self, torch):
+        self.torch = torch
+        self.events = {}
+
+    def wrap(self, name, fn):
+        def timed(*a, **kw):
+            s = self.torch.cuda.Event(enable_timing=True)
+            e = self.torch.cuda.Event(enable_timing=True)
+            s.record()
+            out = fn(*a, **kw)
+            e.record()
+            self.events.setdefault(name, []).append((s, e))
+            return out
+        return timed
+
+    def totals(self):
+        return {k: (sum(s.elapsed_time(e) for s, e in v), len(v)) for k, v in self.events.items()}
+
+
+def synth_batch(torch, batch, seed, device):
+    """Seeded synthetic GRID-shaped inputs generated on the device."""
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    wav = torch.clamp(torch.round(torch.randn(batch, N_SAMPLES, generator=g, device=device) * 3000.0),
+                      -32768, 32767)
+    masks = torch.ones(batch, T_FRAMES, F_BINS, device=device)
+    starts = torch.randint(0, T_FRAMES - GAP_FRAMES, (batch,), generator=g, device=device)
+    t = torch.arange(T_FRAMES, device=device)[None, :]
+    gap = (t >= starts[:, None]) & (t < starts[:, None] + GAP_FRAMES)
+    masks[gap] = 0.0
+    return wav, masks
+
+
+def cpu_baseline(torch, model, wav, masks, mean, std, sample, cpu_batch):
+    """Time the CPU oracle (float32 numpy, explicit per-step loop = the reference's
+    stack_bidirectional_dynamic_rnn schedule) on `sample` utterances of the same workload, and
+    use its output as the checker for the GPU result on those utterances."""
+    from oracle import blstm as OB
+    from oracle import frontend as OF
+    params = model.layout.unflatten_to_oracle_params(model.variables.flat.cpu().numpy())
+    w = wav[:sample].cpu().numpy()
+    m = masks[:sample].cpu().numpy()
+    mean_h, std_h = mean.cpu().numpy(), std.cpu().numpy()
+    seq = np.full(cpu_batch, T_FRAMES)
+    OB.model_forward(w[:cpu_batch], m[:cpu_batch], mean_h, std_h, seq, params, dtype=np.float32)   # warm-up
+    preds = []
+    t0 = time.perf_counter()
+    for i in range(0, sample, cpu_batch):
+        out = OB.model_forward(w[i:i + cpu_batch], m[i:i + cpu_batch], mean_h, std_h,
+                               np.full(len(w[i:i + cpu_batch]), T_FRAMES), params, dtype=np.float32)
+        preds.append(out['prediction'])
+    dt = time.perf_counter() - t0
+    pred_cpu = np.concatenate(preds).astype(np.float64)
+    # checker: reconstructed log-mel RMS, GPU vs CPU oracle, on the sample
+    model.feed(sequence_lengths=np.full(sample, T_FRAMES), target_sources=wav[:sample], masks=masks[:sample])
+    pred_gpu = model.prediction.cpu().numpy().astype(np.float64)
+    lm_cpu = OF.logmel_of_prediction(pred_cpu, mean_h, std_h)
+    lm_gpu = OF.logmel_of_prediction(pred_gpu, mean_h, std_h)
+    rms = float(np.sqrt(np.mean((lm_cpu - lm_gpu) ** 2)))
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count()
+    return {"value": sample / dt, "unit": "utterances/s", "cores": cores, "kind": "port",
+            "sample": "%d utterances in batches of %d, float32 numpy oracle (per-step loop), %.1f s"
+                      % (sample, cpu_batch, dt)}, rms
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=4096, help="utterances per GPU per step")
+    ap.add_argument("--rows-per-wg", type=int, default=0)
+    ap.add_argument("--cpu-sample", type=int, default=64)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    import avsi_amd  # noqa: F401
+    from avsi_amd import models, ops
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus %d must be launched with torch.distributed.run (one rank per GPU)" % args.gpus)
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+
+    B = args.batch
+    cfg = dict(audio_feat_dim=F_BINS, video_feat_dim=136, audio_len=N_SAMPLES, net_dim=[H, H, H],
+               optimizer_type='adam', starter_learning_rate=1e-3, lr_updating_steps=10000, lr_decay=1.0,
+               batch_size=B, l2=0.0, rows_per_wg=args.rows_per_wg)
+    wav, masks = synth_batch(torch, B, 1234 + rank, device)
+    # per-bin statistics of the synthetic set (restated compute_mean_std_features, type='spec')
+    from avsi_amd import audio_processing as ap_mod
+    spec = ap_mod.frontend(wav[:min(B, 256)], want_spec=True)['spec']
+    mean = spec.mean(dim=(0, 1))
+    std = spec.std(dim=(0, 1), unbiased=False)
+    del spec
+    seq = np.full(B, T_FRAMES)
+    model = models.StackedBLSTMModel(seq, wav, masks, mean, std, 0.0, cfg, input='a', seed=7)   # same weights on all ranks
+
+    timer = KernelTimer(torch)
+    ops.gemm = timer.wrap("gemm_kernel", ops.gemm)
+    ops.blstm_rec_fwd = timer.wrap("blstm_rec_fwd_kernel", ops.blstm_rec_fwd)
+    ap_mod.frontend = timer.wrap("frontend_kernel", ap_mod.frontend)
+
+    def step():
+        model.feed(sequence_lengths=seq, target_sources=wav, masks=masks)
+        _ = model.prediction
+        return model.loss_func
+
+    for _ in range(args.warmup):
+        step()
+    timer.events.clear()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+    loss_val = float(loss)
+
+    totals = timer.totals()
+    if rank == 0:
+        gemm_in, rec, proj = algorithmic_flops(B)
+        t_rec, n_rec = totals["blstm_rec_fwd_kernel"]
+        t_gemm, n_gemm = totals["gemm_kernel"]
+        t_fe, n_fe = totals["frontend_kernel"]
+        rec_tf = rec * n_rec / (t_rec * 1e-3) / 1e12
+        gemm_tf = (sum(gemm_in) + proj) * args.steps / (t_gemm * 1e-3) / 1e12
+        fe_gbs = 706000.0 * B * n_fe / (t_fe * 1e-3) / 1e9
+        if t_rec >= t_gemm:
+            roof = {"kernel": "blstm_rec_fwd_kernel", "bound": "mfma", "achieved": rec_tf,
+                    "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": rec_tf / FP32_MFMA_PEAK_TFLOPS,
+                    "traffic": None, "avg_launch_ms": t_rec / n_rec}
+        else:
+            roof = {"kernel": "gemm_kernel", "bound": "mfma", "achieved": gemm_tf,
+                    "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": gemm_tf / FP32_MFMA_PEAK_TFLOPS,
+                    "traffic": None, "avg_launch_ms": t_gemm / n_gemm}
+        roof["others"] = {
+            "blstm_rec_fwd_kernel": {"TFLOP/s": rec_tf, "ms_per_step": t_rec / args.steps},
+            "gemm_kernel": {"TFLOP/s": gemm_tf, "ms_per_step": t_gemm / args.steps},
+            "frontend_kernel": {"GB/s": fe_gbs, "frac_of_hbm_peak": fe_gbs / HBM_PEAK_GBS,
+                                "ms_per_step": t_fe / args.steps},
+        }
+        cpu, rms = (None, None)
+        if not args.no_cpu_baseline:
+            cpu, rms = cpu_baseline(torch, model, wav, masks, mean, std, min(args.cpu_sample, B), 32)
+        line = {
+            "metric": "masked utterances/sec (inference: front end + 3xBLSTM-250 forward + projection + L1 loss)",
+            "value": B * world * args.steps / elapsed,
+            "unit": "utterances/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "configs[1]: audio-only 3xBLSTM-250 inpainter, 3 s 16 kHz clips, one 400 ms gap, "
+                                   "HIP STFT front end + fp32-MFMA BLSTM forward",
+                       "per_gpu_batch": B, "global_batch": B * world, "frames": T_FRAMES, "parallelism": "dp%d" % world},
+            "logmel_rms_vs_cpu_oracle": rms,
+            "loss_func": loss_val,
+            "roofline": roof,
+            "cpu_baseline": cpu,
+        }
+        print(json.dumps(line))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -35,6 +35,7 @@ def _inputs(B, N, seed, gap=33):
     rng = np.random.default_rng(seed)
     wav = np.clip(np.round(rng.normal(0, 3000, size=(B, N))), -32768, 32767).astype(np.float32)
     T = -(-N // 192)
+    gap = min(gap, max(1, T // 3))
     masks = np.ones((B, T, 257), dtype=np.float32)
     for b in range(B):
         s = rng.integers(0, max(1, T - gap))
