@@ -39,18 +39,35 @@ struct RecArgs {
     float* hout;
     float* resv;
     int T, Bp;
+    unsigned long long* stamps;  // diagnostic builds only (-DAVSI_REC_STAMPS): [wg][wave][4] phase cycles
 };
+
+// In-kernel phase stamps (diagnostic build only; the shipped library never executes one).
+#ifdef AVSI_REC_STAMPS
+#define AVSI_STAMP(var)                                                                  \
+    do {                                                                                 \
+        __builtin_amdgcn_sched_barrier(0);                                               \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var)::"memory");      \
+        __builtin_amdgcn_sched_barrier(0);                                               \
+    } while (0)
+#else
+#define AVSI_STAMP(var) do { } while (0)
+#endif
 
 __device__ __forceinline__ float sigmoidf_fast(float x) { return __builtin_amdgcn_rcpf(1.f + __expf(-x)); }
 __device__ __forceinline__ float tanhf_fast(float x) { return 2.f * __builtin_amdgcn_rcpf(1.f + __expf(-2.f * x)) - 1.f; }
 
-// One 8-wide k group: 4 MFMA k-steps x MT row tiles x 4 gate tiles.
+// One 8-wide k group: 4 MFMA k-steps x MT row tiles x 4 gate tiles.  `af` holds this group's
+// h_{t-1} fragments; the NEXT group's fragments are fetched into `an` first and pinned above the
+// MFMAs (sched_barrier) so their LDS latency is covered by this group's 32 MFMAs.
 template <int MT>
-__device__ __forceinline__ void kgroup(f32x16 (&acc)[MT][4], const float4 (&b)[4], const float* __restrict__ hcur, int q,
-                                       int li, int hi) {
-    float4 af[MT];
+__device__ __forceinline__ void read_h(float4 (&af)[MT], const float* __restrict__ hcur, int q, int li, int hi) {
 #pragma unroll
     for (int m = 0; m < MT; ++m) af[m] = *reinterpret_cast<const float4*>(hcur + (m * 32 + li) * HS + 8 * q + 4 * hi);
+}
+
+template <int MT>
+__device__ __forceinline__ void kgroup(f32x16 (&acc)[MT][4], const float4 (&b)[4], const float4 (&af)[MT]) {
 #pragma unroll
     for (int s = 0; s < 4; ++s)
 #pragma unroll
@@ -76,8 +93,10 @@ __device__ __forceinline__ float buf_load(rsrc_t r, int voff, int soff) {
 __device__ __forceinline__ void buf_store(rsrc_t r, int voff, int soff, float v) {
     __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, voff, soff, 0);
 }
+// MT = 1 (32 rows) is built for TWO workgroups per CU (<= 128 VGPRs, 66.5 KB LDS each): the
+// two run out of phase, so one's xproj loads / cell epilogue / barrier hide under the other's MFMAs.
 template <int MT, bool SAVE>
-__global__ __launch_bounds__(512, 2) void blstm_rec_fwd_kernel(const RecArgs a) {
+__global__ __launch_bounds__(512, MT == 1 ? 4 : 2) void blstm_rec_fwd_kernel(const RecArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* hbuf = reinterpret_cast<float*>(smem);  // [2][MT*32][HS]
     constexpr int HTILE = MT * 32 * HS;
@@ -110,8 +129,11 @@ __global__ __launch_bounds__(512, 2) void blstm_rec_fwd_kernel(const RecArgs a) 
 
     __syncthreads();
 
+    unsigned long long ph_load = 0, ph_mfma = 0, ph_cell = 0, ph_bar = 0, s0 = 0, s1 = 0, s2 = 0, s3 = 0, s4 = 0;
+    (void)ph_load, (void)ph_mfma, (void)ph_cell, (void)ph_bar, (void)s0, (void)s1, (void)s2, (void)s3, (void)s4;
     for (int step = 0; step < T; ++step) {
         const int t = dir ? (T - 1 - step) : step;
+        AVSI_STAMP(s0);
         const float* hcur = hbuf + (step & 1) * HTILE;
         float* hnext = hbuf + ((step & 1) ^ 1) * HTILE;
         const size_t row0 = (size_t)t * Bp + b0;
@@ -130,20 +152,30 @@ __global__ __launch_bounds__(512, 2) void blstm_rec_fwd_kernel(const RecArgs a) 
 
         // ---- z += h_{t-1} . Wh : 32 k-groups of 8, Wh fragments prefetched one group ahead.
         //      Two named register sets (static indexing) ping-pong; see kgroup().
-        float4 bw0[4], bw1[4];
+#ifdef AVSI_REC_STAMPS
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // diagnostic: isolate the xproj load phase
+#endif
+        AVSI_STAMP(s1);
+        float4 bw0[4], bw1[4], af0[MT], af1[MT];
 #pragma unroll
         for (int g = 0; g < 4; ++g) bw0[g] = wp[g * 64];
+        read_h<MT>(af0, hcur, 0, li, hi);
         for (int q = 0; q < 32; q += 2) {
 #pragma unroll
             for (int g = 0; g < 4; ++g) bw1[g] = wp[((q + 1) * 4 + g) * 64];
-            kgroup<MT>(acc, bw0, hcur, q, li, hi);
+            read_h<MT>(af1, hcur, q + 1, li, hi);
+            __builtin_amdgcn_sched_barrier(0);
+            kgroup<MT>(acc, bw0, af0);
             if (q + 2 < 32) {
 #pragma unroll
                 for (int g = 0; g < 4; ++g) bw0[g] = wp[((q + 2) * 4 + g) * 64];
+                read_h<MT>(af0, hcur, q + 2, li, hi);
             }
-            kgroup<MT>(acc, bw1, hcur, q + 1, li, hi);
+            __builtin_amdgcn_sched_barrier(0);
+            kgroup<MT>(acc, bw1, af1);
         }
 
+        AVSI_STAMP(s2);
         // ---- LSTM cell, lane-local: (row, unit) = (C/D row of register r, 32 w + li)
         rsrc_t rr = rh;
         if (SAVE) rr = make_rsrc(a.resv + row0 * (2 * 5 * HP), live_rows * RROW);
@@ -171,8 +203,19 @@ __global__ __launch_bounds__(512, 2) void blstm_rec_fwd_kernel(const RecArgs a) 
                 }
             }
         }
+        AVSI_STAMP(s3);
         __syncthreads();
+        AVSI_STAMP(s4);
+#ifdef AVSI_REC_STAMPS
+        ph_load += s1 - s0, ph_mfma += s2 - s1, ph_cell += s3 - s2, ph_bar += s4 - s3;
+#endif
     }
+#ifdef AVSI_REC_STAMPS
+    if (a.stamps && lane == 0) {
+        unsigned long long* o = a.stamps + ((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * NWAVE + w) * 4;
+        o[0] = ph_load, o[1] = ph_mfma, o[2] = ph_cell, o[3] = ph_bar;
+    }
+#endif
 }
 
 template <int MT, bool SAVE>
@@ -192,7 +235,7 @@ extern "C" int avsi_blstm_rec_fwd_f32(const float* xproj, const float* whp, floa
     if (!xproj || !whp || !hout || T <= 0 || Bp <= 0) return AVSI_ERR_INVALID_ARG;
     if (Bp % 32) return AVSI_ERR_INVALID_ARG;  // batch is padded to whole 32-row MFMA tiles
     if ((reinterpret_cast<uintptr_t>(whp) & 15)) return AVSI_ERR_UNSUPPORTED;
-    RecArgs a{xproj, whp, hout, reserve, T, Bp};
+    RecArgs a{xproj, whp, hout, reserve, T, Bp, nullptr};
     // 64 rows per workgroup halves the Wh stream per flop; 32 rows spreads a small batch wider
     int mt = rows_per_wg;
     if (mt == 0) mt = (Bp >= 64 * AVSI_NUM_CU / 2) ? 64 : 32;
@@ -202,3 +245,13 @@ extern "C" int avsi_blstm_rec_fwd_f32(const float* xproj, const float* whp, floa
     if (mt == 64) return reserve ? launch_rec<2, true>(a, st) : launch_rec<2, false>(a, st);
     return reserve ? launch_rec<1, true>(a, st) : launch_rec<1, false>(a, st);
 }
+
+#ifdef AVSI_REC_STAMPS
+// Diagnostic entry (tools/rec_stamps.cpp): same kernel with phase stamps written to `stamps`.
+extern "C" int avsi_blstm_rec_fwd_stamps(const float* xproj, const float* whp, float* hout, int T, int Bp, int mt,
+                                         unsigned long long* stamps, void* stream) {
+    RecArgs a{xproj, whp, hout, nullptr, T, Bp, stamps};
+    avsi_clear_error();
+    return mt == 64 ? launch_rec<2, false>(a, (hipStream_t)stream) : launch_rec<1, false>(a, (hipStream_t)stream);
+}
+#endif

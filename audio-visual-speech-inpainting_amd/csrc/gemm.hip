@@ -81,6 +81,34 @@ __device__ __forceinline__ void store_tile(float* __restrict__ s, const float4 (
     }
 }
 
+// LDS -> registers: the A and B fragments of one 8-wide k group (4 MFMA k-steps).
+template <bool TA, bool TB>
+__device__ __forceinline__ void read_frags(float (&af)[2][4], float (&bf)[2][4], const float* __restrict__ a_s,
+                                           const float* __restrict__ b_s, int q, int wm, int wn, int li, int hi) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int row = wm * 64 + i * 32 + li;
+        if (!TA) {
+            const float4 v = *reinterpret_cast<const float4*>(a_s + row * ROW_STRIDE + 8 * q + 4 * hi);
+            af[i][0] = v.x, af[i][1] = v.y, af[i][2] = v.z, af[i][3] = v.w;
+        } else {
+#pragma unroll
+            for (int s = 0; s < 4; ++s) af[i][s] = a_s[(8 * q + 4 * hi + s) * COL_STRIDE + row];
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int col = wn * 64 + j * 32 + li;
+        if (TB) {
+            const float4 v = *reinterpret_cast<const float4*>(b_s + col * ROW_STRIDE + 8 * q + 4 * hi);
+            bf[j][0] = v.x, bf[j][1] = v.y, bf[j][2] = v.z, bf[j][3] = v.w;
+        } else {
+#pragma unroll
+            for (int s = 0; s < 4; ++s) bf[j][s] = b_s[(8 * q + 4 * hi + s) * COL_STRIDE + col];
+        }
+    }
+}
+
 // TA: A is stored [K][M] (op(A) = A^T).  TB: B is stored [N][K] (op(B) = B^T).
 template <bool TA, bool TB>
 __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs g) {
@@ -134,38 +162,22 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs g) {
         }
         const float* a_s = sA + cur * A_TILE;
         const float* b_s = sB + cur * B_TILE;
+        // fragment reads run one 8-wide k group AHEAD of the MFMAs that consume them, so the
+        // LDS latency is covered by 16 MFMAs (1024 cycles) instead of being exposed 4x per group
+        float af[2][2][4], bf[2][2][4];
+        read_frags<TA, TB>(af[0], bf[0], a_s, b_s, 0, wm, wn, li, hi);
 #pragma unroll
         for (int q = 0; q < BK / 8; ++q) {
-            float af[2][4], bf[2][4];
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                const int row = wm * 64 + i * 32 + li;
-                if (!TA) {
-                    const float4 v = *reinterpret_cast<const float4*>(a_s + row * ROW_STRIDE + 8 * q + 4 * hi);
-                    af[i][0] = v.x, af[i][1] = v.y, af[i][2] = v.z, af[i][3] = v.w;
-                } else {
-#pragma unroll
-                    for (int s = 0; s < 4; ++s) af[i][s] = a_s[(8 * q + 4 * hi + s) * COL_STRIDE + row];
-                }
-            }
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const int col = wn * 64 + j * 32 + li;
-                if (TB) {
-                    const float4 v = *reinterpret_cast<const float4*>(b_s + col * ROW_STRIDE + 8 * q + 4 * hi);
-                    bf[j][0] = v.x, bf[j][1] = v.y, bf[j][2] = v.z, bf[j][3] = v.w;
-                } else {
-#pragma unroll
-                    for (int s = 0; s < 4; ++s) bf[j][s] = b_s[(8 * q + 4 * hi + s) * COL_STRIDE + col];
-                }
-            }
+            const int cq = q & 1;
+            if (q + 1 < BK / 8) read_frags<TA, TB>(af[cq ^ 1], bf[cq ^ 1], a_s, b_s, q + 1, wm, wn, li, hi);
+            __builtin_amdgcn_sched_barrier(0);  // keep the look-ahead reads ABOVE this group's MFMAs
 #pragma unroll
             for (int s = 0; s < 4; ++s)
 #pragma unroll
                 for (int i = 0; i < 2; ++i)
 #pragma unroll
                     for (int j = 0; j < 2; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][s], bf[j][s], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[cq][i][s], bf[cq][j][s], acc[i][j], 0, 0, 0);
         }
         if (more) {
             store_tile<!TA>(sA + (cur ^ 1) * A_TILE, ra, tid);
@@ -175,6 +187,13 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs g) {
     }
 
     // epilogue: C/D layout of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
+    const bool accumulate = g.beta != 0.f;  // uniform: keeps the read-modify-write out of the common path
+    float bv[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int col = n0 + wn * 64 + j * 32 + li;
+        bv[j] = (g.bias && col < g.N) ? g.bias[col] : 0.f;
+    }
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
 #pragma unroll
@@ -193,10 +212,8 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs g) {
                 const int col = n0 + wn * 64 + j * 32 + li;
                 if (col >= g.N) continue;
                 float* c = C + orow * g.ldc + col;
-                float v = g.alpha * acc[i][j][r];
-                if (g.bias) v += g.bias[col];
-                v *= rsc;
-                if (g.beta != 0.f) v += g.beta * *c;
+                float v = (g.alpha * acc[i][j][r] + bv[j]) * rsc;
+                if (accumulate) v += g.beta * *c;
                 *c = v;
             }
         }
