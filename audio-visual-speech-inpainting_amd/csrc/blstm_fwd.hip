@@ -218,6 +218,192 @@ __global__ __launch_bounds__(512, MT == 1 ? 4 : 2) void blstm_rec_fwd_kernel(con
 #endif
 }
 
+// ------------------------------------------------------------------------------------------
+// Ping-pong variant (64 rows per workgroup as two 32-row tiles that alternate roles).
+// The straightforward kernel above spends ~22 % of every step outside the MFMA loop (xproj
+// loads 5 %, cell epilogue 12 %, barrier 5 % -- measured with tools/rec_stamps.cpp), and all 8
+// waves are in those phases at the same time, so the matrix pipe idles.  Here each step is two
+// phases separated by barriers; in a phase ONE tile issues its 512 MFMAs while, in the same
+// instruction stream, the OTHER tile runs its cell update for the step it just finished and
+// then starts the loads of its next gate pre-activations straight into its (now free)
+// accumulator registers:
+//     phase B(s): MFMA tile 1, step s   ||  cell tile 0, step s   ->  load tile 0, step s+1
+//     phase A(s): MFMA tile 0, step s+1 ||  cell tile 1, step s   ->  load tile 1, step s+1
+// A tile's h is written in one phase and read in the other, so one LDS buffer per tile suffices
+// (66.5 KB).  Wh is streamed from L2 twice per step (2 MiB per workgroup-step).
+// ------------------------------------------------------------------------------------------
+// Wave-uniform global pointer made opaque to the optimiser, so that every load through it is
+// "SGPR base + shared lane VGPR + immediate" (global_load_dwordx4 v, v_lane, s[..] offset:imm).
+typedef float v4f __attribute__((ext_vector_type(4)));
+typedef const __attribute__((address_space(1))) v4f* gptr4;
+__device__ __forceinline__ gptr4 opaque_base(const float4* p) {
+    gptr4 g = (gptr4)(const void*)p;
+    asm volatile("" : "+s"(g));
+    return g;
+}
+__device__ __forceinline__ float4 ldg4(gptr4 p, int idx) {
+    const v4f v = p[idx];
+    return make_float4(v.x, v.y, v.z, v.w);
+}
+
+template <int X, bool DO_MFMA, bool SAVE>
+__device__ __forceinline__ void pp_phase(f32x16 (&acc)[2][4], f32x16 (&c)[2], float* __restrict__ hbuf,
+                                         const float4* __restrict__ wb, const int lane, const rsrc_t rx_next,
+                                         const rsrc_t rh, const rsrc_t rr, const int voff_x, const int voff_h,
+                                         const int voff_r, const int w, const int li, const int hi) {
+    constexpr int Y = 1 - X;
+    constexpr int XROW = 2 * GP * 4, HROW = 2 * HP * 4, RROW = 2 * 5 * HP * 4;
+    const float* hx = hbuf + X * (32 * HS);                                 // tile X: read by the MFMAs
+    float* hy = hbuf + Y * (32 * HS) + (4 * hi) * HS + w * 32 + li;         // tile Y: written by the cell
+    float4 bw[2][4], af[2];
+    f32x16 nx[4];  // tile Y's next pre-activations: loaded once acc[Y] is dead, then become acc[Y]
+    if (DO_MFMA) {
+        const gptr4 wq = opaque_base(wb);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) bw[0][g] = ldg4(wq, g * 64 + lane);
+        af[0] = *reinterpret_cast<const float4*>(hx + li * HS + 4 * hi);
+    }
+#pragma unroll
+    for (int q = 0; q < 32; ++q) {
+        const int cb = q & 1;
+        if (DO_MFMA) {
+            if (q + 1 < 32) {
+                // Without the opaque base hipcc materialises one 64-bit VGPR address per load (128 of
+                // them), hoists them out of the step loop and spills them.
+                const gptr4 wq = opaque_base(wb + (q + 1) * 256);
+#pragma unroll
+                for (int g = 0; g < 4; ++g) bw[cb ^ 1][g] = ldg4(wq, g * 64 + lane);
+                af[cb ^ 1] = *reinterpret_cast<const float4*>(hx + li * HS + 8 * (q + 1) + 4 * hi);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const float av = s == 0 ? af[cb].x : s == 1 ? af[cb].y : s == 2 ? af[cb].z : af[cb].w;
+                    const float4 b4 = bw[cb][g];
+                    const float bv = s == 0 ? b4.x : s == 1 ? b4.y : s == 2 ? b4.z : b4.w;
+                    acc[X][g] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[X][g], 0, 0, 0);
+                }
+        }
+        if (q < 16) {  // one (row-register) element of tile Y per k group, in the first half of the phase
+            const int r = q;
+            const int rowc = Y * 32 + (r & 3) + 8 * (r >> 2);
+            const float ig = sigmoidf_fast(acc[Y][0][r]);
+            const float jg = tanhf_fast(acc[Y][1][r]);
+            const float fg = sigmoidf_fast(acc[Y][2][r]);
+            const float og = sigmoidf_fast(acc[Y][3][r]);
+            const float cn = fg * c[Y][r] + ig * jg;
+            c[Y][r] = cn;
+            const float hn = og * tanhf_fast(cn);
+            hy[((r & 3) + 8 * (r >> 2)) * HS] = hn;
+            buf_store(rh, voff_h, rowc * HROW, hn);
+            if (SAVE) {
+                buf_store(rr, voff_r, rowc * RROW + 0 * HP * 4, ig);
+                buf_store(rr, voff_r, rowc * RROW + 1 * HP * 4, jg);
+                buf_store(rr, voff_r, rowc * RROW + 2 * HP * 4, fg);
+                buf_store(rr, voff_r, rowc * RROW + 3 * HP * 4, og);
+                buf_store(rr, voff_r, rowc * RROW + 4 * HP * 4, cn);
+            }
+        } else if (q < 24) {
+            // second half: acc[Y] is dead, its registers take the next step's pre-activations
+            // (2 row-registers per k group; a zero-record descriptor makes these loads return 0)
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const int r = 2 * (q - 16) + e;
+                const int rowc = Y * 32 + (r & 3) + 8 * (r >> 2);
+#pragma unroll
+                for (int g = 0; g < 4; ++g) nx[g][r] = buf_load(rx_next, voff_x, rowc * XROW + g * 128);
+            }
+        }
+    }
+#pragma unroll
+    for (int g = 0; g < 4; ++g) acc[Y][g] = nx[g];
+}
+
+template <bool SAVE>
+__global__ __launch_bounds__(512, 2) void blstm_rec_fwd_pp_kernel(const RecArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* hbuf = reinterpret_cast<float*>(smem);  // [2 tiles][32][HS]
+    constexpr int XROW = 2 * GP * 4, HROW = 2 * HP * 4, RROW = 2 * 5 * HP * 4;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 31, hi = lane >> 5;
+    const int dir = blockIdx.y;
+    const int b0 = blockIdx.x * 64;
+    const int T = a.T, Bp = a.Bp;
+    const int live_rows = min(64, Bp - b0);
+
+    for (int i = tid; i < 2 * 32 * HS; i += 512) hbuf[i] = 0.f;
+
+    // wave-uniform base (SGPR pair) + lane: every fragment address is scalar base + one shared VGPR
+    const float4* __restrict__ wb = reinterpret_cast<const float4*>(a.whp) + (size_t)(dir * NWAVE + w) * (32 * 4 * 64);
+    const int voff_x = 4 * hi * XROW + (dir * GP + w * 128 + li) * 4;
+    const int voff_h = 4 * hi * HROW + (dir * HP + w * 32 + li) * 4;
+    const int voff_r = 4 * hi * RROW + (dir * 5 * HP + w * 32 + li) * 4;
+
+    f32x16 acc[2][4], c[2];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) c[m][r] = 0.f;
+
+    auto row0_of = [&](int step) { return ((size_t)(dir ? (T - 1 - step) : step)) * Bp + b0; };
+    {   // gate pre-activations of step 0 for both tiles
+        const rsrc_t rx = make_rsrc(a.xproj + row0_of(0) * (2 * GP), live_rows * XROW);
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    acc[m][g][r] = buf_load(rx, voff_x, (m * 32 + (r & 3) + 8 * (r >> 2)) * XROW + g * 128);
+    }
+    __syncthreads();
+    auto out_rsrc = [&](int step, rsrc_t& rh, rsrc_t& rr) {
+        const size_t r = row0_of(step);
+        rh = make_rsrc(a.hout + r * (2 * HP), live_rows * HROW);
+        rr = SAVE ? make_rsrc(a.resv + r * (2 * 5 * HP), live_rows * RROW) : rh;
+    };
+    // next-step pre-activations; `on` = false gives a zero-record descriptor (loads return 0, no branch)
+    auto in_rsrc = [&](int step, bool on) {
+        return make_rsrc(a.xproj + row0_of(step) * (2 * GP), on ? live_rows * XROW : 0);
+    };
+    rsrc_t rh, rr;
+    // prologue: h_{-1} = 0, so the step-0 pre-activations are final without any MFMA.
+    //   cell tile 0 (step 0) -> load tile 0 (step 1)
+    out_rsrc(0, rh, rr);
+    pp_phase<1, false, SAVE>(acc, c, hbuf, wb, lane, in_rsrc(T > 1 ? 1 : 0, T > 1), rh, rr, voff_x, voff_h, voff_r, w, li, hi);
+    __syncthreads();
+    for (int step = 0; step + 1 < T; ++step) {
+        // phase A: MFMA tile 0 (step + 1) || cell tile 1 (step) -> load tile 1 (step + 1)
+        out_rsrc(step, rh, rr);
+        pp_phase<0, true, SAVE>(acc, c, hbuf, wb, lane, in_rsrc(step + 1, true), rh, rr, voff_x, voff_h, voff_r, w, li, hi);
+        __syncthreads();
+        // phase B: MFMA tile 1 (step + 1) || cell tile 0 (step + 1) -> load tile 0 (step + 2)
+        const bool more = step + 2 < T;
+        out_rsrc(step + 1, rh, rr);
+        pp_phase<1, true, SAVE>(acc, c, hbuf, wb, lane, in_rsrc(more ? step + 2 : step + 1, more), rh, rr, voff_x, voff_h, voff_r,
+                                w, li, hi);
+        __syncthreads();
+    }
+    // epilogue: cell tile 1 (step T - 1)
+    out_rsrc(T - 1, rh, rr);
+    pp_phase<0, false, SAVE>(acc, c, hbuf, wb, lane, in_rsrc(T - 1, false), rh, rr, voff_x, voff_h, voff_r, w, li, hi);
+}
+
+template <bool SAVE>
+int launch_rec_pp(const RecArgs& a, hipStream_t st) {
+    const size_t lds = (size_t)2 * 32 * HS * 4;
+    (void)hipFuncSetAttribute((const void*)blstm_rec_fwd_pp_kernel<SAVE>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)lds);
+    const int tiles = (int)avsi_ceil_div(a.Bp, 64);
+    hipLaunchKernelGGL((blstm_rec_fwd_pp_kernel<SAVE>), dim3(tiles, 2), dim3(512), lds, st, a);
+    return avsi_launch_status();
+}
+
 template <int MT, bool SAVE>
 int launch_rec(const RecArgs& a, hipStream_t st) {
     const size_t lds = (size_t)2 * MT * 32 * HS * 4;
@@ -239,10 +425,11 @@ extern "C" int avsi_blstm_rec_fwd_f32(const float* xproj, const float* whp, floa
     // 64 rows per workgroup halves the Wh stream per flop; 32 rows spreads a small batch wider
     int mt = rows_per_wg;
     if (mt == 0) mt = (Bp >= 64 * AVSI_NUM_CU / 2) ? 64 : 32;
-    if (mt != 32 && mt != 64) return AVSI_ERR_INVALID_ARG;
+    if (mt != 32 && mt != 64 && mt != 65) return AVSI_ERR_INVALID_ARG;
     avsi_clear_error();
     const hipStream_t st = (hipStream_t)stream;
-    if (mt == 64) return reserve ? launch_rec<2, true>(a, st) : launch_rec<2, false>(a, st);
+    if (mt == 64) return reserve ? launch_rec_pp<true>(a, st) : launch_rec_pp<false>(a, st);
+    if (mt == 65) return reserve ? launch_rec<2, true>(a, st) : launch_rec<2, false>(a, st);  // A/B baseline
     return reserve ? launch_rec<1, true>(a, st) : launch_rec<1, false>(a, st);
 }
 
