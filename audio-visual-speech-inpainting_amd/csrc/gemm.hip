@@ -20,16 +20,21 @@
 //   - blockIdx -> tile mapping is XCD-aware: the N-blocks that share an A row panel get
 //     consecutive ids on ONE XCD, so the panel is fetched from HBM once and re-served by that L2.
 #include "avsi_common.h"
+#include <cstdlib>
 
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int BM = 128, BN = 128, BK = 32;
-constexpr int ROW_STRIDE = BK + 4;   // floats, "row" tile [x][k]
+constexpr int BM = 128, BN = 128;
 constexpr int COL_STRIDE = 128 + 4;  // floats, "col" tile [k][x]
-constexpr int ROW_TILE = 128 * ROW_STRIDE;
-constexpr int COL_TILE = BK * COL_STRIDE;
+// k-tile depth BK (16 or 32): "row" tile [x][k] has stride BK + 4 floats (conflict-free b128 reads)
+template <int BK> struct Tile {
+    static constexpr int ROW_STRIDE = BK + 4;
+    static constexpr int ROW_TILE = 128 * ROW_STRIDE;
+    static constexpr int COL_TILE = BK * COL_STRIDE;
+    static constexpr int NLD = BK / 8;  // float4 loads per thread per operand tile
+};
 
 struct GemmArgs {
     const float* A;
@@ -47,15 +52,17 @@ struct GemmArgs {
 };
 
 // Global -> registers for one operand tile.  ROWK: memory is [x][k] (k contiguous), else [k][x].
-template <bool ROWK>
-__device__ __forceinline__ void load_tile(float4 (&r)[4], const float* __restrict__ base, int64_t ld, int x0, int k0,
-                                          int X, int Kend, int tid) {
+template <bool ROWK, int BK>
+__device__ __forceinline__ void load_tile(float4 (&r)[Tile<BK>::NLD], const float* __restrict__ base, int64_t ld, int x0,
+                                          int k0, int X, int Kend, int tid) {
+    constexpr int KQ = BK / 4;           // float4 per row of a "row" tile
+    constexpr int RPP = 256 / KQ;        // rows covered per pass
 #pragma unroll
-    for (int p = 0; p < 4; ++p) {
+    for (int p = 0; p < Tile<BK>::NLD; ++p) {
         int x, k;
         if (ROWK) {
-            x = x0 + p * 32 + (tid >> 3);
-            k = k0 + 4 * (tid & 7);
+            x = x0 + p * RPP + tid / KQ;
+            k = k0 + 4 * (tid % KQ);
         } else {
             k = k0 + p * 8 + (tid >> 5);
             x = x0 + 4 * (tid & 31);
@@ -70,26 +77,27 @@ __device__ __forceinline__ void load_tile(float4 (&r)[4], const float* __restric
     }
 }
 
-template <bool ROWK>
-__device__ __forceinline__ void store_tile(float* __restrict__ s, const float4 (&r)[4], int tid) {
+template <bool ROWK, int BK>
+__device__ __forceinline__ void store_tile(float* __restrict__ s, const float4 (&r)[Tile<BK>::NLD], int tid) {
+    constexpr int KQ = BK / 4, RPP = 256 / KQ;
 #pragma unroll
-    for (int p = 0; p < 4; ++p) {
+    for (int p = 0; p < Tile<BK>::NLD; ++p) {
         if (ROWK)
-            *reinterpret_cast<float4*>(s + (p * 32 + (tid >> 3)) * ROW_STRIDE + 4 * (tid & 7)) = r[p];
+            *reinterpret_cast<float4*>(s + (p * RPP + tid / KQ) * Tile<BK>::ROW_STRIDE + 4 * (tid % KQ)) = r[p];
         else
             *reinterpret_cast<float4*>(s + (p * 8 + (tid >> 5)) * COL_STRIDE + 4 * (tid & 31)) = r[p];
     }
 }
 
 // LDS -> registers: the A and B fragments of one 8-wide k group (4 MFMA k-steps).
-template <bool TA, bool TB>
+template <bool TA, bool TB, int BK>
 __device__ __forceinline__ void read_frags(float (&af)[2][4], float (&bf)[2][4], const float* __restrict__ a_s,
                                            const float* __restrict__ b_s, int q, int wm, int wn, int li, int hi) {
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         const int row = wm * 64 + i * 32 + li;
         if (!TA) {
-            const float4 v = *reinterpret_cast<const float4*>(a_s + row * ROW_STRIDE + 8 * q + 4 * hi);
+            const float4 v = *reinterpret_cast<const float4*>(a_s + row * Tile<BK>::ROW_STRIDE + 8 * q + 4 * hi);
             af[i][0] = v.x, af[i][1] = v.y, af[i][2] = v.z, af[i][3] = v.w;
         } else {
 #pragma unroll
@@ -100,7 +108,7 @@ __device__ __forceinline__ void read_frags(float (&af)[2][4], float (&bf)[2][4],
     for (int j = 0; j < 2; ++j) {
         const int col = wn * 64 + j * 32 + li;
         if (TB) {
-            const float4 v = *reinterpret_cast<const float4*>(b_s + col * ROW_STRIDE + 8 * q + 4 * hi);
+            const float4 v = *reinterpret_cast<const float4*>(b_s + col * Tile<BK>::ROW_STRIDE + 8 * q + 4 * hi);
             bf[j][0] = v.x, bf[j][1] = v.y, bf[j][2] = v.z, bf[j][3] = v.w;
         } else {
 #pragma unroll
@@ -110,11 +118,12 @@ __device__ __forceinline__ void read_frags(float (&af)[2][4], float (&bf)[2][4],
 }
 
 // TA: A is stored [K][M] (op(A) = A^T).  TB: B is stored [N][K] (op(B) = B^T).
-template <bool TA, bool TB>
-__global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs g) {
+template <bool TA, bool TB, int BK>
+__global__ __launch_bounds__(256, BK == 16 ? 4 : 2) void gemm_kernel(const GemmArgs g) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int A_TILE = TA ? COL_TILE : ROW_TILE;
-    constexpr int B_TILE = TB ? ROW_TILE : COL_TILE;
+    constexpr int A_TILE = TA ? Tile<BK>::COL_TILE : Tile<BK>::ROW_TILE;
+    constexpr int B_TILE = TB ? Tile<BK>::ROW_TILE : Tile<BK>::COL_TILE;
+    constexpr int NLD = Tile<BK>::NLD;
     float* sA = reinterpret_cast<float*>(smem);
     float* sB = sA + 2 * A_TILE;
 
@@ -146,30 +155,34 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs g) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    float4 ra[4], rb[4];
-    load_tile<!TA>(ra, g.A, g.lda, m0, kbeg, g.M, kend, tid);
-    load_tile<TB>(rb, g.B, g.ldb, n0, kbeg, g.N, kend, tid);
-    store_tile<!TA>(sA, ra, tid);
-    store_tile<TB>(sB, rb, tid);
+    // Software pipeline (registers hold the tile that is ONE ahead of the LDS stage being computed):
+    //   iteration kt:  MFMAs(group 0 of stage cur) -> ds_write(regs = tile kt+1 -> stage cur^1)
+    //                  -> global loads(tile kt+2 -> regs) -> MFMAs(groups 1..) -> barrier
+    // so the global loads get a full k-tile of latency budget, the LDS writes sit in the shadow of the
+    // MFMAs, and the end of a k-tile is a bare barrier (no vmcnt wait, no LDS write) -- the exposed
+    // "wait, write, barrier" tail of the classic double-buffer loop cost ~15 % here.
+    float4 ra[NLD], rb[NLD];
+    load_tile<!TA, BK>(ra, g.A, g.lda, m0, kbeg, g.M, kend, tid);
+    load_tile<TB, BK>(rb, g.B, g.ldb, n0, kbeg, g.N, kend, tid);
+    store_tile<!TA, BK>(sA, ra, tid);
+    store_tile<TB, BK>(sB, rb, tid);
+    if (nk > 1) {
+        load_tile<!TA, BK>(ra, g.A, g.lda, m0, kbeg + BK, g.M, kend, tid);
+        load_tile<TB, BK>(rb, g.B, g.ldb, n0, kbeg + BK, g.N, kend, tid);
+    }
     __syncthreads();
 
     for (int kt = 0; kt < nk; ++kt) {
         const int cur = kt & 1;
-        const bool more = kt + 1 < nk;
-        if (more) {
-            load_tile<!TA>(ra, g.A, g.lda, m0, kbeg + (kt + 1) * BK, g.M, kend, tid);
-            load_tile<TB>(rb, g.B, g.ldb, n0, kbeg + (kt + 1) * BK, g.N, kend, tid);
-        }
         const float* a_s = sA + cur * A_TILE;
         const float* b_s = sB + cur * B_TILE;
-        // fragment reads run one 8-wide k group AHEAD of the MFMAs that consume them, so the
-        // LDS latency is covered by 16 MFMAs (1024 cycles) instead of being exposed 4x per group
+        // fragment reads run one 8-wide k group AHEAD of the MFMAs that consume them
         float af[2][2][4], bf[2][2][4];
-        read_frags<TA, TB>(af[0], bf[0], a_s, b_s, 0, wm, wn, li, hi);
+        read_frags<TA, TB, BK>(af[0], bf[0], a_s, b_s, 0, wm, wn, li, hi);
 #pragma unroll
         for (int q = 0; q < BK / 8; ++q) {
             const int cq = q & 1;
-            if (q + 1 < BK / 8) read_frags<TA, TB>(af[cq ^ 1], bf[cq ^ 1], a_s, b_s, q + 1, wm, wn, li, hi);
+            if (q + 1 < BK / 8) read_frags<TA, TB, BK>(af[cq ^ 1], bf[cq ^ 1], a_s, b_s, q + 1, wm, wn, li, hi);
             __builtin_amdgcn_sched_barrier(0);  // keep the look-ahead reads ABOVE this group's MFMAs
 #pragma unroll
             for (int s = 0; s < 4; ++s)
@@ -178,10 +191,16 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs g) {
 #pragma unroll
                     for (int j = 0; j < 2; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[cq][i][s], bf[cq][j][s], acc[i][j], 0, 0, 0);
-        }
-        if (more) {
-            store_tile<!TA>(sA + (cur ^ 1) * A_TILE, ra, tid);
-            store_tile<TB>(sB + (cur ^ 1) * B_TILE, rb, tid);
+            if (q == 0) {
+                if (kt + 1 < nk) {
+                    store_tile<!TA, BK>(sA + (cur ^ 1) * A_TILE, ra, tid);
+                    store_tile<TB, BK>(sB + (cur ^ 1) * B_TILE, rb, tid);
+                }
+                if (kt + 2 < nk) {
+                    load_tile<!TA, BK>(ra, g.A, g.lda, m0, kbeg + (kt + 2) * BK, g.M, kend, tid);
+                    load_tile<TB, BK>(rb, g.B, g.ldb, n0, kbeg + (kt + 2) * BK, g.N, kend, tid);
+                }
+            }
         }
         __syncthreads();
     }
@@ -220,13 +239,15 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs g) {
     }
 }
 
-template <bool TA, bool TB>
+template <bool TA, bool TB, int BK>
 int launch(const GemmArgs& g, int splits, hipStream_t st) {
-    constexpr size_t lds = (size_t)2 * ((TA ? COL_TILE : ROW_TILE) + (TB ? ROW_TILE : COL_TILE)) * 4;
-    static_assert(lds <= 80 * 1024, "two workgroups must fit one CU's 160 KiB LDS");
+    constexpr size_t lds = (size_t)2 * ((TA ? Tile<BK>::COL_TILE : Tile<BK>::ROW_TILE) +
+                                        (TB ? Tile<BK>::ROW_TILE : Tile<BK>::COL_TILE)) * 4;
+    static_assert(lds <= (BK == 16 ? 40 : 80) * 1024, "4 (BK=16) / 2 (BK=32) workgroups must fit one CU's 160 KiB LDS");
     if (lds > 64 * 1024)
-        (void)hipFuncSetAttribute((const void*)gemm_kernel<TA, TB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL((gemm_kernel<TA, TB>), dim3(g.m_blocks * g.n_blocks, 1, splits), dim3(256), lds, st, g);
+        (void)hipFuncSetAttribute((const void*)gemm_kernel<TA, TB, BK>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)lds);
+    hipLaunchKernelGGL((gemm_kernel<TA, TB, BK>), dim3(g.m_blocks * g.n_blocks, 1, splits), dim3(256), lds, st, g);
     return avsi_launch_status();
 }
 
@@ -258,16 +279,26 @@ int avsi_gemm_launch(int transA, int transB, int M, int N, int K, float alpha, c
     g.alpha = alpha, g.beta = beta;
     g.m_blocks = (int)avsi_ceil_div(M, BM);
     g.n_blocks = (int)avsi_ceil_div(N, BN);
-    g.k_split_len = (int)avsi_round_up(avsi_ceil_div(K, splits), BK);
+    g.k_split_len = (int)avsi_round_up(avsi_ceil_div(K, splits), 32);
     g.c_split_stride = splits > 1 ? c_split_stride : 0;
     if ((int64_t)g.m_blocks * g.n_blocks > INT32_MAX) return AVSI_ERR_UNSUPPORTED;
     // "col" tiles read 4 consecutive x per lane and guard on the first: the ld padding up to a
     // multiple of 4 (checked above) keeps the tail addressable; such lanes feed unstored outputs.
     avsi_clear_error();
-    if (!transA && !transB) return launch<false, false>(g, splits, st);
-    if (!transA && transB) return launch<false, true>(g, splits, st);
-    if (transA && !transB) return launch<true, false>(g, splits, st);
-    return launch<true, true>(g, splits, st);
+    // k-tile depth: 16 (4 workgroups per CU) wins whenever B is a "col" tile -- measured 125 vs 116
+    // TFLOP/s at K = 512 and 112 vs 93 at K = 264 -- while B^T operands prefer 32 (127 vs 117).
+    const char* env = getenv("AVSI_GEMM_BK");   // tuning override (diagnostic): 16 or 32
+    const int bk = env ? atoi(env) : (transB ? 32 : 16);
+    if (bk == 16) {
+        if (!transA && !transB) return launch<false, false, 16>(g, splits, st);
+        if (!transA && transB) return launch<false, true, 16>(g, splits, st);
+        if (transA && !transB) return launch<true, false, 16>(g, splits, st);
+        return launch<true, true, 16>(g, splits, st);
+    }
+    if (!transA && !transB) return launch<false, false, 32>(g, splits, st);
+    if (!transA && transB) return launch<false, true, 32>(g, splits, st);
+    if (transA && !transB) return launch<true, false, 32>(g, splits, st);
+    return launch<true, true, 32>(g, splits, st);
 }
 
 extern "C" int avsi_gemm_f32(int transA, int transB, int M, int N, int K, float alpha, const float* A, int64_t lda,
