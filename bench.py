@@ -123,9 +123,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch", type=int, default=4096, help="utterances per GPU per step")
+    ap.add_argument("--batch", type=int, default=8192, help="utterances per GPU per step")
     ap.add_argument("--rows-per-wg", type=int, default=0)
-    ap.add_argument("--cpu-sample", type=int, default=64)
+    ap.add_argument("--cpu-sample", type=int, default=384, help="utterances timed on the CPU oracle (~15 s)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
