@@ -53,6 +53,16 @@ PROTOTYPES = {
     "avsi_gemm_f32": (c_int, [c_int, c_int, c_int, c_int, c_int, c_float, c_void_p, c_int64, c_void_p, c_int64,
                               c_float, c_void_p, c_int64, POINTER(GemmEpilogue), c_void_p]),
     "avsi_blstm_rec_fwd_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
+    "avsi_gemm_splitk_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
+    "avsi_gemm_splitk_f32": (c_int, [c_int, c_int, c_int, c_int, c_int, c_float, c_void_p, c_int64, c_void_p, c_int64,
+                                     c_void_p, c_int, c_void_p, c_size_t, c_void_p]),
+    "avsi_blstm_rec_bwd_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
+    "avsi_relayout_rows_f32": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64, c_int, c_int, c_int,
+                                       c_int, c_void_p, c_int64, c_int64, c_void_p]),
+    "avsi_colsum_workspace_bytes": (c_size_t, [c_int64, c_int]),
+    "avsi_colsum_f32": (c_int, [c_void_p, c_int64, c_int64, c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "avsi_adam_tf_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_float, c_float, c_float, c_float,
+                                 c_int64, c_float, c_float, c_void_p]),
     "avsi_l1_loss_workspace_bytes": (c_size_t, [c_int64]),
     "avsi_l1_loss_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_float, c_void_p,
                                  c_size_t, c_void_p]),

@@ -70,16 +70,29 @@ class ParamLayout:
             alloc('wx%d' % li, (self.kp[li], 2 * GP))
             alloc('b%d' % li, (2 * GP,))
             alloc('wh%d' % li, (2 * WH_FLOATS,))
+            alloc('whb%d' % li, (2 * WH_FLOATS,))      # same numbers, fragment order of dz . Wh^T (BPTT)
         alloc('pw', (2 * HP, self.ldp))
         alloc('pb', (self.ldp,))
         self.packed_size = poff
 
         self.pack_index = self._build_pack_index()     # packed pos -> ref pos (ref_size = zero slot)
-        inv = np.full(self.ref_size, -1, dtype=np.int64)
-        valid = self.pack_index < self.ref_size
-        inv[self.pack_index[valid]] = np.nonzero(valid)[0]
-        assert (inv >= 0).all(), "every reference parameter must appear exactly once in the packed layout"
-        self.unpack_index = inv                        # ref pos -> packed pos
+
+        # ---- gradient layout produced by the backward kernels (GEMM outputs, natural k-major form)
+        self.gpacked = {}
+        goff = 0
+
+        def galloc(name, shape):
+            nonlocal goff
+            self.gpacked[name] = (goff, shape)
+            goff += round_up(int(np.prod(shape)), 64)
+        for li in range(self.num_layers):
+            galloc('dwx%d' % li, (self.kp[li], 2 * GP))
+            galloc('db%d' % li, (2 * GP,))
+            galloc('dwh%d' % li, (2, HP, GP))
+        galloc('dpw', (2 * HP, self.ldp))
+        galloc('dpb', (self.ldp,))
+        self.gpacked_size = goff
+        self.grad_index = self._build_grad_index()     # ref pos -> gpacked pos
 
     # ------------------------------------------------------------------------------
     def input_row_map(self, li):
@@ -121,6 +134,18 @@ class ParamLayout:
                     ok = (kk < H) & (uu < H)
                     pos = wh_off + ((((d * 8 + w_) * 32 + q_) * 4 + g) * 64 + lane_) * 4 + s_
                     idx[pos[ok]] = k_off + (D + kk[ok]) * (4 * H) + g * H + uu[ok]
+                    # transposed-product fragment order [d][w][q 128][lane][s]:
+                    #   Wh[unit' = 32w + (lane & 31)][packed col = 8q + 4(lane >> 5) + s]
+                    whb_off, _ = self.packed['whb%d' % li]
+                    w_, q_, lane_, s_ = np.meshgrid(np.arange(8), np.arange(128), np.arange(64), np.arange(4),
+                                                    indexing='ij')
+                    col = 8 * q_ + 4 * (lane_ >> 5) + s_              # packed col inside this direction
+                    up = 32 * w_ + (lane_ & 31)                       # unit' (row of Wh)
+                    cg = (col % 128) // 32                            # gate of that column
+                    cu = (col // 128) * 32 + col % 32                 # hidden unit of that column
+                    ok = (cg == g) & (up < H) & (cu < H)
+                    pos = whb_off + (((d * 8 + w_) * 128 + q_) * 64 + lane_) * 4 + s_
+                    idx[pos[ok]] = k_off + (D + up[ok]) * (4 * H) + g * H + cu[ok]
         pw_off, _ = self.packed['pw']
         pb_off, _ = self.packed['pb']
         rmap = np.full(2 * HP, -1, dtype=np.int64)
@@ -132,6 +157,44 @@ class ParamLayout:
             self._ref_off['logits/weights'] + rmap[rows][:, None] * F + c[None, :])
         idx[pb_off + c] = self._ref_off['logits/biases'] + c
         return idx
+
+    def _build_grad_index(self):
+        """Position of every reference parameter's gradient inside the gpacked buffer."""
+        H, F = self.H, self.F
+        gi = np.full(self.ref_size, -1, dtype=np.int64)
+        u = np.arange(H)
+        for li in range(self.num_layers):
+            D = self.in_dims[li]
+            rmap = self.input_row_map(li)
+            krows = np.nonzero(rmap >= 0)[0]                       # padded k for reference rows 0..D-1 (in order)
+            assert (rmap[krows] == np.arange(D)).all()
+            dwx_off, _ = self.gpacked['dwx%d' % li]
+            db_off, _ = self.gpacked['db%d' % li]
+            dwh_off, _ = self.gpacked['dwh%d' % li]
+            for d, dname in enumerate(('fw', 'bw')):
+                k_off = self._ref_off['cell_%d/%s/kernel' % (li, dname)]
+                bias_off = self._ref_off['cell_%d/%s/bias' % (li, dname)]
+                for g in range(4):
+                    cols = packed_gate_col(d, g, u)
+                    lcols = packed_gate_col(0, g, u)
+                    gi[k_off + np.arange(D)[:, None] * (4 * H) + (g * H + u)[None, :]] = (
+                        dwx_off + krows[:, None] * (2 * GP) + cols[None, :])
+                    gi[k_off + (D + np.arange(H))[:, None] * (4 * H) + (g * H + u)[None, :]] = (
+                        dwh_off + (d * HP + np.arange(H))[:, None] * GP + lcols[None, :])
+                    gi[bias_off + g * H + u] = db_off + cols
+        dpw_off, _ = self.gpacked['dpw']
+        dpb_off, _ = self.gpacked['dpb']
+        prow = np.concatenate([np.arange(H), HP + np.arange(H)])
+        c = np.arange(F)
+        gi[self._ref_off['logits/weights'] + np.arange(2 * H)[:, None] * F + c[None, :]] = (
+            dpw_off + prow[:, None] * self.ldp + c[None, :])
+        gi[self._ref_off['logits/biases'] + c] = dpb_off + c
+        assert (gi >= 0).all()
+        return gi
+
+    def gpacked_view(self, flat, name):
+        off, shape = self.gpacked[name]
+        return flat[off: off + int(np.prod(shape))].reshape(shape)
 
     # ------------------------------------------------------------------------------
     def ref_view(self, flat, name):

@@ -1,0 +1,198 @@
+// Backward (BPTT) of the recurrent half of one bidirectional LSTM layer on gfx950.
+//
+// Gradient of the graph the reference differentiates with tf.gradients / the CudnnLSTM backward
+// op (models.py:95-115, train_op at models.py:161-179).  For every step, walking each direction
+// against its forward order:
+//     dh   = dH_out[t] + dz_{next} . Wh^T                (next = the step processed just before)
+//     do   = dh tanh(c);  dc = dh o (1 - tanh(c)^2) + dc_next
+//     di   = dc j;  dj = dc i;  df = dc c_prev;  dc_next = dc f
+//     dz   = (di i(1-i), dj (1-j^2), df f(1-f), do o(1-o))
+// dz is written out in the packed gate-column order of xproj; the time-batched gradients
+// (dX = dZ . Wx^T, dWx = X^T . dZ, dWh = H_prev^T . dZ, db = colsum dZ) are large GEMMs / column
+// sums over dZ afterwards (gemm.hip, elementwise.hip).
+//
+// Mapping: same batch-stationary scheme as the forward kernel (a workgroup owns 32 utterances of
+// one direction, wave w owns hidden units [32w, 32w+32) x 4 gates, everything elementwise is
+// lane-local).  The recurrent product dz . Wh^T reduces over the 1024 gate columns, which are
+// spread over all 8 waves, so dz crosses LDS once per step: [32][1024 + 4] floats (131.6 KB),
+// written in C/D layout, read back as MFMA A fragments with ds_read_b128.  Wh^T (1 MiB per
+// direction) streams from L2 in host-packed fragment order, SGPR base + lane addressing.
+// Inputs of the NEXT step (dH_out, the five reserve planes, c_prev) are fetched into registers
+// before the MFMA phase so their latency hides under it.
+//
+// Layouts (floats):
+//   dhout [T][Bp][512]         gradient w.r.t. the layer output (fw 0..255, bw 256..511)
+//   resv  [T][Bp][2][5][256]   i, j, f, o (activated), c_t from the forward pass
+//   whbT  [2][8 w][128 q][64 lane][4 s] = Wh[unit' = 32w + (lane&31)][packed col = 8q + 4(lane>>5) + s]
+//   dz    [T][Bp][2][1024]     packed gate columns (col = 128 w + 32 gate + u)
+#include "avsi_common.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __amdgpu_buffer_rsrc_t rsrc_t;
+
+constexpr int HP = 256, GP = 4 * HP, NWAVE = 8;
+constexpr int ZS = GP + 4;  // LDS row stride of the dz tile (conflict-free b128 reads)
+
+struct BwdArgs {
+    const float* dhout;
+    const float* resv;
+    const float* whbT;
+    float* dz;
+    int T, Bp;
+};
+
+__device__ __forceinline__ rsrc_t make_rsrc(const void* base, unsigned bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)bytes, 0x00020000);
+}
+__device__ __forceinline__ float buf_load(rsrc_t r, int voff, int soff) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
+}
+__device__ __forceinline__ void buf_store(rsrc_t r, int voff, int soff, float v) {
+    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, voff, soff, 0);
+}
+typedef float v4f __attribute__((ext_vector_type(4)));
+typedef const __attribute__((address_space(1))) v4f* gptr4;
+__device__ __forceinline__ gptr4 opaque_base(const float4* p) {
+    gptr4 g = (gptr4)(const void*)p;
+    asm volatile("" : "+s"(g));
+    return g;
+}
+__device__ __forceinline__ float4 ldg4(gptr4 p, int idx) {
+    const v4f v = p[idx];
+    return make_float4(v.x, v.y, v.z, v.w);
+}
+
+struct StepIn {  // one step's inputs of a lane: 16 row-registers x (dH, i, j, f, o, c, c_prev)
+    float dh[16], gi[16], gj[16], gf[16], go[16], c[16], cp[16];
+};
+
+__global__ __launch_bounds__(512, 2) void blstm_rec_bwd_kernel(const BwdArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* zbuf = reinterpret_cast<float*>(smem);  // [32][ZS]
+    constexpr int HROW = 2 * HP * 4, RROW = 2 * 5 * HP * 4, ZROW = 2 * GP * 4;  // row pitches, bytes
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 31, hi = lane >> 5;
+    const int dir = blockIdx.y;
+    const int b0 = blockIdx.x * 32;
+    const int T = a.T, Bp = a.Bp;
+    const int live_rows = min(32, Bp - b0);
+
+    const float4* __restrict__ wb = reinterpret_cast<const float4*>(a.whbT) + (size_t)(dir * NWAVE + w) * (128 * 64);
+    const int voff_h = 4 * hi * HROW + (dir * HP + w * 32 + li) * 4;
+    const int voff_r = 4 * hi * RROW + (dir * 5 * HP + w * 32 + li) * 4;
+    const int voff_z = 4 * hi * ZROW + (dir * GP + w * 128 + li) * 4;
+
+    // backward step s visits forward time t: fw walks T-1 .. 0, bw walks 0 .. T-1
+    auto time_of = [&](int s) { return dir ? s : (T - 1 - s); };
+
+    auto load_step = [&](StepIn& in, int s) {
+        const int t = time_of(s);
+        const int tp = dir ? t + 1 : t - 1;                 // forward-previous step (owner of c_{prev})
+        const bool has_prev = dir ? (t + 1 < T) : (t > 0);
+        const size_t row0 = (size_t)t * Bp + b0;
+        const rsrc_t rh = make_rsrc(a.dhout + row0 * (2 * HP), live_rows * HROW);
+        const rsrc_t rr = make_rsrc(a.resv + row0 * (2 * 5 * HP), live_rows * RROW);
+        const rsrc_t rp = make_rsrc(a.resv + ((size_t)(has_prev ? tp : t) * Bp + b0) * (2 * 5 * HP),
+                                    has_prev ? live_rows * RROW : 0);   // zero records => c_prev = 0
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int rowc = (r & 3) + 8 * (r >> 2);
+            in.dh[r] = buf_load(rh, voff_h, rowc * HROW);
+            in.gi[r] = buf_load(rr, voff_r, rowc * RROW + 0 * HP * 4);
+            in.gj[r] = buf_load(rr, voff_r, rowc * RROW + 1 * HP * 4);
+            in.gf[r] = buf_load(rr, voff_r, rowc * RROW + 2 * HP * 4);
+            in.go[r] = buf_load(rr, voff_r, rowc * RROW + 3 * HP * 4);
+            in.c[r] = buf_load(rr, voff_r, rowc * RROW + 4 * HP * 4);
+            in.cp[r] = buf_load(rp, voff_r, rowc * RROW + 4 * HP * 4);
+        }
+    };
+
+    f32x16 dhrec;   // dz_{next} . Wh^T for this wave's 32 units (C/D layout)
+    float dcn[16];  // dc_next
+#pragma unroll
+    for (int r = 0; r < 16; ++r) dhrec[r] = 0.f, dcn[r] = 0.f;
+
+    StepIn cur;
+    load_step(cur, 0);
+
+    for (int s = 0; s < T; ++s) {
+        const int t = time_of(s);
+        const rsrc_t rz = make_rsrc(a.dz + ((size_t)t * Bp + b0) * (2 * GP), live_rows * ZROW);
+        // ---- elementwise BPTT, lane-local
+        float* zl = zbuf + (4 * hi) * ZS + w * 128 + li;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int rowl = (r & 3) + 8 * (r >> 2);
+            const float dh = cur.dh[r] + dhrec[r];
+            const float ig = cur.gi[r], jg = cur.gj[r], fg = cur.gf[r], og = cur.go[r];
+            const float tc = 2.f * __builtin_amdgcn_rcpf(1.f + __expf(-2.f * cur.c[r])) - 1.f;
+            const float dc = dh * og * (1.f - tc * tc) + dcn[r];
+            dcn[r] = dc * fg;
+            const float dzi = dc * jg * ig * (1.f - ig);
+            const float dzj = dc * ig * (1.f - jg * jg);
+            const float dzf = dc * cur.cp[r] * fg * (1.f - fg);
+            const float dzo = dh * tc * og * (1.f - og);
+            zl[rowl * ZS + 0] = dzi, zl[rowl * ZS + 32] = dzj, zl[rowl * ZS + 64] = dzf, zl[rowl * ZS + 96] = dzo;
+            buf_store(rz, voff_z, rowl * ZROW + 0 * 128, dzi);
+            buf_store(rz, voff_z, rowl * ZROW + 1 * 128, dzj);
+            buf_store(rz, voff_z, rowl * ZROW + 2 * 128, dzf);
+            buf_store(rz, voff_z, rowl * ZROW + 3 * 128, dzo);
+        }
+        __syncthreads();
+        if (s + 1 == T) break;
+        // ---- next step's inputs: in flight during the MFMA phase
+        load_step(cur, s + 1);
+        // ---- dhrec = dz . Wh^T over the 1024 packed gate columns (128 k-groups of 8)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dhrec[r] = 0.f;
+        float4 bw0, bw1, af0, af1;
+        {
+            const gptr4 wq = opaque_base(wb);
+            bw0 = ldg4(wq, lane);
+            af0 = *reinterpret_cast<const float4*>(zbuf + li * ZS + 4 * hi);
+        }
+        for (int q = 0; q < 128; q += 2) {
+            {
+                const gptr4 wq = opaque_base(wb + (q + 1) * 64);
+                bw1 = ldg4(wq, lane);
+                af1 = *reinterpret_cast<const float4*>(zbuf + li * ZS + 8 * (q + 1) + 4 * hi);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            dhrec = __builtin_amdgcn_mfma_f32_32x32x2f32(af0.x, bw0.x, dhrec, 0, 0, 0);
+            dhrec = __builtin_amdgcn_mfma_f32_32x32x2f32(af0.y, bw0.y, dhrec, 0, 0, 0);
+            dhrec = __builtin_amdgcn_mfma_f32_32x32x2f32(af0.z, bw0.z, dhrec, 0, 0, 0);
+            dhrec = __builtin_amdgcn_mfma_f32_32x32x2f32(af0.w, bw0.w, dhrec, 0, 0, 0);
+            if (q + 2 < 128) {
+                const gptr4 wq = opaque_base(wb + (q + 2) * 64);
+                bw0 = ldg4(wq, lane);
+                af0 = *reinterpret_cast<const float4*>(zbuf + li * ZS + 8 * (q + 2) + 4 * hi);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            dhrec = __builtin_amdgcn_mfma_f32_32x32x2f32(af1.x, bw1.x, dhrec, 0, 0, 0);
+            dhrec = __builtin_amdgcn_mfma_f32_32x32x2f32(af1.y, bw1.y, dhrec, 0, 0, 0);
+            dhrec = __builtin_amdgcn_mfma_f32_32x32x2f32(af1.z, bw1.z, dhrec, 0, 0, 0);
+            dhrec = __builtin_amdgcn_mfma_f32_32x32x2f32(af1.w, bw1.w, dhrec, 0, 0, 0);
+        }
+        __syncthreads();  // every wave is done reading zbuf before the next step overwrites it
+    }
+}
+
+}  // namespace
+
+extern "C" int avsi_blstm_rec_bwd_f32(const float* dhout, const float* reserve, const float* whbT, float* dz, int T,
+                                      int Bp, void* stream) {
+    if (!dhout || !reserve || !whbT || !dz || T <= 0 || Bp <= 0) return AVSI_ERR_INVALID_ARG;
+    if (Bp % 32) return AVSI_ERR_INVALID_ARG;
+    if (reinterpret_cast<uintptr_t>(whbT) & 15) return AVSI_ERR_UNSUPPORTED;
+    BwdArgs a{dhout, reserve, whbT, dz, T, Bp};
+    const size_t lds = (size_t)32 * ZS * 4;
+    avsi_clear_error();
+    (void)hipFuncSetAttribute((const void*)blstm_rec_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(blstm_rec_bwd_kernel, dim3(Bp / 32, 2), dim3(512), lds, (hipStream_t)stream, a);
+    return avsi_launch_status();
+}

@@ -1,0 +1,155 @@
+// Memory-bound helpers of the training / layout plumbing on gfx950:
+//   - avsi_relayout_rows_f32 : [B][T][C] <-> [T][Bp][Cp] row re-layout with optional per-row scale
+//                              and zero fill (video / fed features -> padded time-major input;
+//                              d(prediction) -> time-major gradient with the sequence mask folded in)
+//   - avsi_colsum_f32        : column sums of a [M][ld] matrix (bias gradients), two-stage, deterministic
+//   - avsi_sum_slabs_f32     : sum of split-K partial slabs (gemm.hip), deterministic
+//   - avsi_adam_tf_f32       : tf.train.AdamOptimizer update on flat buffers (models.py:168; App. A.7)
+// All are grid-stride kernels with 16-byte accesses where alignment allows.
+#include "avsi_common.h"
+
+namespace {
+
+constexpr int TPB = 256;
+
+__global__ __launch_bounds__(TPB) void relayout_rows_kernel(const float* __restrict__ src, int64_t s_sb, int64_t s_st,
+                                                            float* __restrict__ dst, int64_t d_sb, int64_t d_st, int B,
+                                                            int T, int C, int dst_cols, const float* __restrict__ scale,
+                                                            int64_t sc_sb, int64_t sc_st) {
+    // one wave per (b, t) row; lanes stride the channels
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = ((int64_t)blockIdx.x * TPB + threadIdx.x) >> 6;
+    const int64_t nwaves = ((int64_t)gridDim.x * TPB) >> 6;
+    const int64_t rows = (int64_t)B * T;
+    for (int64_t row = wave; row < rows; row += nwaves) {
+        const int b = (int)(row / T), t = (int)(row - (int64_t)b * T);
+        const float sc = scale ? scale[b * sc_sb + t * sc_st] : 1.f;
+        const float* s = src + b * s_sb + t * s_st;
+        float* d = dst + b * d_sb + t * d_st;
+        for (int c = lane; c < dst_cols; c += 64) d[c] = c < C ? s[c] * sc : 0.f;
+    }
+}
+
+constexpr int CS_ROWS = 256;  // rows per partial block
+__global__ __launch_bounds__(TPB) void colsum_partial_kernel(const float* __restrict__ x, int64_t ld, int64_t M, int N,
+                                                             float* __restrict__ part) {
+    // block (bx, by): columns [bx*256, +256), rows [by*chunk, ...)
+    const int col = blockIdx.x * TPB + threadIdx.x;
+    const int64_t chunk = (M + gridDim.y - 1) / gridDim.y;
+    const int64_t r0 = (int64_t)blockIdx.y * chunk, r1 = min(M, r0 + chunk);
+    if (col >= N) return;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int64_t r = r0;
+    for (; r + 3 < r1; r += 4) {
+        s0 += x[r * ld + col];
+        s1 += x[(r + 1) * ld + col];
+        s2 += x[(r + 2) * ld + col];
+        s3 += x[(r + 3) * ld + col];
+    }
+    for (; r < r1; ++r) s0 += x[r * ld + col];
+    part[(int64_t)blockIdx.y * N + col] = (s0 + s1) + (s2 + s3);
+}
+
+__global__ __launch_bounds__(TPB) void sum_slabs_kernel(const float* __restrict__ slabs, int64_t n, int count,
+                                                        int64_t stride, float* __restrict__ out, float alpha) {
+    for (int64_t i = (int64_t)blockIdx.x * TPB + threadIdx.x; i < n; i += (int64_t)gridDim.x * TPB) {
+        double s = 0.0;
+        for (int k = 0; k < count; ++k) s += (double)slabs[k * stride + i];
+        out[i] = (float)(alpha * s);
+    }
+}
+
+__global__ __launch_bounds__(TPB) void adam_tf_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                      float* __restrict__ m, float* __restrict__ v, int64_t n,
+                                                      float lr_t, float b1, float b2, float eps, float gscale,
+                                                      float l2) {
+    const int64_t n4 = n >> 2;
+    for (int64_t i = (int64_t)blockIdx.x * TPB + threadIdx.x; i < n4; i += (int64_t)gridDim.x * TPB) {
+        float4 pv = reinterpret_cast<float4*>(p)[i];
+        const float4 gv = reinterpret_cast<const float4*>(g)[i];
+        float4 mv = reinterpret_cast<float4*>(m)[i], vv = reinterpret_cast<float4*>(v)[i];
+        float* pp = &pv.x;
+        const float* gg = &gv.x;
+        float* mm = &mv.x;
+        float* vw = &vv.x;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float gk = gg[k] * gscale + l2 * pp[k];
+            mm[k] = b1 * mm[k] + (1.f - b1) * gk;
+            vw[k] = b2 * vw[k] + (1.f - b2) * gk * gk;
+            pp[k] -= lr_t * mm[k] / (__builtin_amdgcn_sqrtf(vw[k]) + eps);
+        }
+        reinterpret_cast<float4*>(p)[i] = pv;
+        reinterpret_cast<float4*>(m)[i] = mv;
+        reinterpret_cast<float4*>(v)[i] = vv;
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+        const int64_t i = (n4 << 2) + threadIdx.x;
+        const float gk = g[i] * gscale + l2 * p[i];
+        m[i] = b1 * m[i] + (1.f - b1) * gk;
+        v[i] = b2 * v[i] + (1.f - b2) * gk * gk;
+        p[i] -= lr_t * m[i] / (__builtin_amdgcn_sqrtf(v[i]) + eps);
+    }
+}
+
+inline int grid_for(int64_t items, int per_block) {
+    int64_t g = avsi_ceil_div(items, per_block);
+    const int64_t cap = (int64_t)AVSI_NUM_CU * 8;
+    return (int)(g < 1 ? 1 : (g > cap ? cap : g));
+}
+
+}  // namespace
+
+extern "C" int avsi_relayout_rows_f32(const float* src, int64_t src_stride_b, int64_t src_stride_t, float* dst,
+                                      int64_t dst_stride_b, int64_t dst_stride_t, int B, int T, int C, int dst_cols,
+                                      const float* row_scale, int64_t scale_stride_b, int64_t scale_stride_t,
+                                      void* stream) {
+    if (!src || !dst || B <= 0 || T <= 0 || C <= 0 || dst_cols < C) return AVSI_ERR_INVALID_ARG;
+    avsi_clear_error();
+    hipLaunchKernelGGL(relayout_rows_kernel, dim3(grid_for((int64_t)B * T, TPB / 64)), dim3(TPB), 0,
+                       (hipStream_t)stream, src, src_stride_b, src_stride_t, dst, dst_stride_b, dst_stride_t, B, T, C,
+                       dst_cols, row_scale, scale_stride_b, scale_stride_t);
+    return avsi_launch_status();
+}
+
+extern "C" size_t avsi_colsum_workspace_bytes(int64_t M, int N) {
+    const int64_t parts = avsi_ceil_div(M, CS_ROWS) > 512 ? 512 : avsi_ceil_div(M, CS_ROWS);
+    return (size_t)(parts < 1 ? 1 : parts) * N * sizeof(float);
+}
+
+extern "C" int avsi_colsum_f32(const float* x, int64_t ld, int64_t M, int N, float* out, void* workspace,
+                               size_t workspace_bytes, void* stream) {
+    if (!x || !out || M <= 0 || N <= 0 || ld < N) return AVSI_ERR_INVALID_ARG;
+    if (!workspace || workspace_bytes < avsi_colsum_workspace_bytes(M, N)) return AVSI_ERR_WORKSPACE;
+    int64_t parts = avsi_ceil_div(M, CS_ROWS);
+    if (parts > 512) parts = 512;
+    if (parts < 1) parts = 1;
+    const hipStream_t st = (hipStream_t)stream;
+    avsi_clear_error();
+    hipLaunchKernelGGL(colsum_partial_kernel, dim3((int)avsi_ceil_div(N, TPB), (int)parts), dim3(TPB), 0, st, x, ld, M,
+                       N, (float*)workspace);
+    hipLaunchKernelGGL(sum_slabs_kernel, dim3(grid_for(N, TPB)), dim3(TPB), 0, st, (const float*)workspace, (int64_t)N,
+                       (int)parts, (int64_t)N, out, 1.f);
+    return avsi_launch_status();
+}
+
+// internal (gemm.hip): out[i] = alpha * sum_k slabs[k * stride + i]
+int avsi_sum_slabs_launch(const float* slabs, int64_t n, int count, int64_t stride, float* out, float alpha,
+                          hipStream_t st) {
+    hipLaunchKernelGGL(sum_slabs_kernel, dim3(grid_for(n, TPB)), dim3(TPB), 0, st, slabs, n, count, stride, out, alpha);
+    return avsi_launch_status();
+}
+
+extern "C" int avsi_adam_tf_f32(float* param, const float* grad, float* m, float* v, int64_t n, float lr, float beta1,
+                                float beta2, float eps, int64_t step, float grad_scale, float l2, void* stream) {
+    if (!param || !grad || !m || !v || n <= 0 || step < 1) return AVSI_ERR_INVALID_ARG;
+    if ((reinterpret_cast<uintptr_t>(param) | reinterpret_cast<uintptr_t>(grad) | reinterpret_cast<uintptr_t>(m) |
+         reinterpret_cast<uintptr_t>(v)) & 15)
+        return AVSI_ERR_UNSUPPORTED;
+    // lr_t = lr sqrt(1 - b2^t) / (1 - b1^t), computed in double on the host
+    const double lr_t = (double)lr * sqrt(1.0 - pow((double)beta2, (double)step)) / (1.0 - pow((double)beta1, (double)step));
+    avsi_clear_error();
+    hipLaunchKernelGGL(adam_tf_kernel, dim3(grid_for(n >> 2, TPB)), dim3(TPB), 0, (hipStream_t)stream, param, grad, m, v,
+                       n, (float)lr_t, beta1, beta2, eps, grad_scale, l2);
+    return avsi_launch_status();
+}

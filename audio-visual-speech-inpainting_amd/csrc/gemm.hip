@@ -307,3 +307,29 @@ extern "C" int avsi_gemm_f32(int transA, int transB, int M, int N, int K, float 
     return avsi_gemm_launch(transA, transB, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, epilogue, 1, 0,
                             (hipStream_t)stream);
 }
+
+// ---- split-K: the reduction dimension is cut into `splits` contiguous chunks, one partial slab
+// per chunk (plain stores, no atomics), summed in chunk order by a second kernel: deterministic.
+// Used for the weight gradients, whose reduction runs over all T * Bp rows while the output is
+// only a few hundred tiles.
+int avsi_sum_slabs_launch(const float* slabs, int64_t n, int count, int64_t stride, float* out, float alpha,
+                          hipStream_t st);
+
+extern "C" size_t avsi_gemm_splitk_workspace_bytes(int M, int N, int splits) {
+    if (M <= 0 || N <= 0 || splits < 1) return 0;
+    return (size_t)splits * (size_t)M * (size_t)N * sizeof(float);
+}
+
+extern "C" int avsi_gemm_splitk_f32(int transA, int transB, int M, int N, int K, float alpha, const float* A,
+                                    int64_t lda, const float* B, int64_t ldb, float* C, int splits, void* workspace,
+                                    size_t workspace_bytes, void* stream) {
+    if (splits < 1 || !C) return AVSI_ERR_INVALID_ARG;
+    if (!workspace || workspace_bytes < avsi_gemm_splitk_workspace_bytes(M, N, splits)) return AVSI_ERR_WORKSPACE;
+    const hipStream_t st = (hipStream_t)stream;
+    float* ws = (float*)workspace;
+    const int rc = avsi_gemm_launch(transA, transB, M, N, K, 1.f, A, lda, B, ldb, 0.f, ws, N, nullptr, splits,
+                                    (int64_t)M * N, st);
+    if (rc != AVSI_OK) return rc;
+    // every split writes its whole slab (empty chunks write zeros), so the sum needs no memset
+    return avsi_sum_slabs_launch(ws, (int64_t)M * N, splits, (int64_t)M * N, C, alpha, st);
+}

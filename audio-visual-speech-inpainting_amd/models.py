@@ -44,7 +44,7 @@ class BLSTMVariables:
         self.device = torch.device(device)
         self.flat = torch.from_numpy(self._tf_default_init(layout, seed)).to(self.device)
         self._pack_index = torch.from_numpy(layout.pack_index).to(self.device)
-        self._unpack_index = torch.from_numpy(layout.unpack_index).to(self.device)
+        self._grad_index = torch.from_numpy(layout.grad_index).to(self.device)
         self.packed = torch.empty(layout.packed_size, dtype=torch.float32, device=self.device)
         self.adam_m = None
         self.adam_v = None
@@ -87,9 +87,9 @@ class BLSTMVariables:
     def p(self, name):
         return self.layout.packed_view(self.packed, name)
 
-    def unpack_grads(self, packed_grads):
-        """reference-layout gradient <- gather(packed gradient)."""
-        return torch.index_select(packed_grads, 0, self._unpack_index)
+    def unpack_grads(self, gpacked, out=None):
+        """reference-layout gradient <- gather(gradient buffer written by the backward kernels)."""
+        return torch.index_select(gpacked, 0, self._grad_index, out=out)
 
 
 class StackedBLSTMModel(object):
@@ -304,6 +304,102 @@ class StackedBLSTMModel(object):
         if self.regularization:
             return self.loss_func + self.regularization * self.reg_loss
         return self.loss_func
+
+    # ---------------------------------------------------------------- gradients (tf.gradients of models.py:178)
+    def _backward(self):
+        """d loss / d variables in the reference layout (cached).  Chain: L1 -> projection ->
+        per layer (top down): BPTT kernel -> dWx, dWh, db as split-K GEMMs / column sums -> dX."""
+        c = self._cache
+        if 'grads' in c:
+            return c['grads']
+        self._loss(want_grad=True)
+        B, T, Bp = self._dims()
+        v, lay = self.variables, self.layout
+        F, ldp = self.audio_feat_dim, self.layout.ldp
+        M = T * Bp
+        gp = self._buf('gpacked', (lay.gpacked_size,), zero=True)
+        # d logits, time-major + padded, sequence mask folded in (rows of padded utterances stay 0)
+        dlog = self._buf('dlog', (T, Bp, ldp), zero=True)
+        ops.relayout_rows(c['dpred'], dlog, B, T, F, ldp, (T * F, F), (ldp, Bp * ldp),
+                          row_scale=c['row_scale'], scale_strides=(1, Bp))
+        dlog2 = dlog.view(M, ldp)
+        h_top = c['rnn_out'].view(M, 2 * HP)
+        splits = max(1, min(64, M // 4096))
+        ops.gemm_splitk(h_top, dlog2, lay.gpacked_view(gp, 'dpw'), trans_a=True, m=2 * HP, n=ldp, k=M, splits=splits)
+        ops.colsum(dlog2, lay.gpacked_view(gp, 'dpb'), m=M, n=ldp)
+        dh = self._buf('dh', (T, Bp, 2 * HP))
+        ops.gemm(dlog2, v.p('pw'), out=dh.view(M, 2 * HP), trans_b=True, m=M, n=2 * HP, k=ldp)
+        dz = self._buf('dz', (T, Bp, 2 * GP))
+        for li in range(self.num_layers - 1, -1, -1):
+            kp = lay.kp[li]
+            ops.blstm_rec_bwd(dh, c['reserve'][li], v.p('whb%d' % li), dz)
+            dz2 = dz.view(M, 2 * GP)
+            x = c['layer_in'][li].view(M, kp)
+            ops.gemm_splitk(x, dz2, lay.gpacked_view(gp, 'dwx%d' % li), trans_a=True, m=kp, n=2 * GP, k=M, splits=splits)
+            ops.colsum(dz2, lay.gpacked_view(gp, 'db%d' % li), m=M, n=2 * GP)
+            # dWh[d] = H_prev^T . dZ_d : fw pairs h[t-1] with dz[t], bw pairs h[t+1] with dz[t]
+            hout = self._ws[('h%d' % li, (T, Bp, 2 * HP))].view(M, 2 * HP)
+            dwh = lay.gpacked_view(gp, 'dwh%d' % li)
+            if T > 1:
+                Mr = (T - 1) * Bp
+                ops.gemm_splitk(hout[:Mr, :HP], dz2[Bp:, :GP], dwh[0], trans_a=True, m=HP, n=GP, k=Mr, splits=splits)
+                ops.gemm_splitk(hout[Bp:, HP:], dz2[:Mr, GP:], dwh[1], trans_a=True, m=HP, n=GP, k=Mr, splits=splits)
+            else:
+                dwh.zero_()
+            if li > 0:
+                ops.gemm(dz2, v.p('wx%d' % li), out=dh.view(M, 2 * HP), trans_b=True, m=M, n=2 * HP, k=2 * GP)
+        grads = v.unpack_grads(gp, out=self._buf('grads', (lay.ref_size,)))
+        c['grads'] = grads
+        return grads
+
+    @property
+    def gradients(self):
+        """Flat reference-layout gradient of `loss_func` (+ l2 term) w.r.t. the variables."""
+        g = self._backward()
+        if self.regularization:
+            return g + self.regularization * self.variables.flat
+        return g
+
+    @property
+    def train_op(self):
+        """One optimiser step (reference models.py:161-179): Adam with the CONSTANT starter learning
+        rate, or sgd / momentum 0.9 with the staircase-decayed rate.  Under
+        torch.distributed the flat gradient is all-reduced (sum) first and averaged in the update,
+        which reproduces the single-GPU gradient of the global batch (equal per-rank batches)."""
+        c = self._cache
+        if c.get('trained'):
+            return None
+        g = self._backward()
+        v = self.variables
+        world = 1
+        if torch.distributed.is_available() and torch.distributed.is_initialized():
+            world = torch.distributed.get_world_size()
+            if world > 1:
+                torch.distributed.all_reduce(g, op=torch.distributed.ReduceOp.SUM)
+        step = v.global_step + 1
+        l2 = float(self.regularization or 0.0)
+        if self.optimizer_choice == 'adam':
+            if v.adam_m is None:
+                v.adam_m = torch.zeros_like(v.flat)
+                v.adam_v = torch.zeros_like(v.flat)
+            ops.adam_tf(v.flat, g, v.adam_m, v.adam_v, step, self.starter_learning_rate, grad_scale=1.0 / world, l2=l2)
+        elif self.optimizer_choice in ('sgd', 'momentum'):
+            lr = self.learning_rate
+            gg = g / world + l2 * v.flat if (world > 1 or l2) else g
+            if self.optimizer_choice == 'momentum':
+                if v.adam_m is None:
+                    v.adam_m = torch.zeros_like(v.flat)
+                v.adam_m.mul_(0.9).add_(gg)
+                v.flat.sub_(lr * v.adam_m)
+            else:
+                v.flat.sub_(lr * gg)
+        else:
+            print('Optimizer must be either sgd, momentum or adam. Closing...')
+            sys.exit(1)
+        v.global_step = step
+        v.repack()
+        c['trained'] = True
+        return None
 
     @property
     def global_step(self):

@@ -81,3 +81,79 @@ def l1_loss(target, pred, mask, want_grad=False, grad_scale=None):
                                   _lib.ptr(dpred), gs, _lib.ptr(ws), ws.numel() * 4, _lib.stream_ptr()),
                "avsi_l1_loss_f32")
     return out3, dpred
+
+
+_WS = {}
+
+
+def _workspace(dev, nbytes):
+    """One growing scratch buffer per device (split-K slabs, column-sum partials)."""
+    ws = _WS.get(dev.index)
+    if ws is None or ws.numel() * 4 < nbytes:
+        ws = torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=dev)
+        _WS[dev.index] = ws
+    return ws
+
+
+def gemm_splitk(a, b, out, trans_a=False, trans_b=False, m=None, n=None, k=None, alpha=1.0, splits=16):
+    """out[M, N] (contiguous) = alpha * op(A) . op(B), reduction split into `splits` slabs
+    (avsi_gemm_splitk_f32).  For weight gradients: K = all T * Bp rows."""
+    _lib.require_cuda(a, b, out)
+    L = _lib.lib()
+    M = m if m is not None else (a.shape[1] if trans_a else a.shape[0])
+    K = k if k is not None else (a.shape[0] if trans_a else a.shape[1])
+    N = n if n is not None else (b.shape[0] if trans_b else b.shape[1])
+    if not out.is_contiguous() or out.numel() != M * N:
+        raise _lib.AvsiError("gemm_splitk: out must be contiguous [M, N]")
+    need = L.avsi_gemm_splitk_workspace_bytes(M, N, splits)
+    ws = _workspace(a.device, need)
+    _lib.check(L.avsi_gemm_splitk_f32(int(trans_a), int(trans_b), M, N, K, float(alpha), _lib.ptr(a), a.stride(0),
+                                      _lib.ptr(b), b.stride(0), _lib.ptr(out), int(splits), _lib.ptr(ws),
+                                      ws.numel() * 4, _lib.stream_ptr()), "avsi_gemm_splitk_f32")
+    return out
+
+
+def blstm_rec_bwd(dhout, reserve, whbt, dz):
+    """BPTT through the recurrence of one layer (avsi_blstm_rec_bwd_f32).
+    dhout [T, Bp, 512], reserve [T, Bp, 2, 5, 256], whbt [2 * 262144] -> dz [T, Bp, 2048]."""
+    _lib.require_cuda(dhout, reserve, whbt, dz)
+    T, Bp = dhout.shape[0], dhout.shape[1]
+    ok = (tuple(dhout.shape) == (T, Bp, 512) and tuple(reserve.shape) == (T, Bp, 2, 5, 256)
+          and tuple(dz.shape) == (T, Bp, 2048) and whbt.numel() == 2 * 262144)
+    if not ok or not (dhout.is_contiguous() and reserve.is_contiguous() and dz.is_contiguous() and whbt.is_contiguous()):
+        raise _lib.AvsiError("blstm_rec_bwd: bad operand shapes / strides")
+    _lib.check(_lib.lib().avsi_blstm_rec_bwd_f32(_lib.ptr(dhout), _lib.ptr(reserve), _lib.ptr(whbt), _lib.ptr(dz),
+                                                 T, Bp, _lib.stream_ptr()), "avsi_blstm_rec_bwd_f32")
+    return dz
+
+
+def relayout_rows(src, dst, B, T, C, dst_cols, src_strides, dst_strides, row_scale=None, scale_strides=(0, 0)):
+    """dst[b, t, :dst_cols] = src[b, t, :C] * row_scale[b, t] (zero beyond C); strides are (b, t) element strides."""
+    _lib.require_cuda(src, dst, row_scale)
+    _lib.check(_lib.lib().avsi_relayout_rows_f32(_lib.ptr(src), src_strides[0], src_strides[1], _lib.ptr(dst),
+                                                 dst_strides[0], dst_strides[1], B, T, C, dst_cols,
+                                                 _lib.ptr(row_scale), scale_strides[0], scale_strides[1],
+                                                 _lib.stream_ptr()), "avsi_relayout_rows_f32")
+    return dst
+
+
+def colsum(x, out, m=None, n=None):
+    """out[n] = sum over rows of x[M, ld] (avsi_colsum_f32)."""
+    _lib.require_cuda(x, out)
+    L = _lib.lib()
+    M = x.shape[0] if m is None else m
+    N = x.shape[1] if n is None else n
+    need = L.avsi_colsum_workspace_bytes(M, N)
+    ws = _workspace(x.device, need)
+    _lib.check(L.avsi_colsum_f32(_lib.ptr(x), x.stride(0), M, N, _lib.ptr(out), _lib.ptr(ws), ws.numel() * 4,
+                                 _lib.stream_ptr()), "avsi_colsum_f32")
+    return out
+
+
+def adam_tf(param, grad, m, v, step, lr, beta1=0.9, beta2=0.999, eps=1e-8, grad_scale=1.0, l2=0.0):
+    """In-place tf.train.AdamOptimizer step on flat float32 buffers (avsi_adam_tf_f32)."""
+    _lib.require_cuda(param, grad, m, v)
+    n = param.numel()
+    _lib.check(_lib.lib().avsi_adam_tf_f32(_lib.ptr(param), _lib.ptr(grad), _lib.ptr(m), _lib.ptr(v), n, float(lr),
+                                           float(beta1), float(beta2), float(eps), int(step), float(grad_scale),
+                                           float(l2), _lib.stream_ptr()), "avsi_adam_tf_f32")

@@ -141,6 +141,49 @@ int avsi_l1_loss_f32(const float* target, const float* pred, const float* mask, 
                      float* out3, float* dpred, float grad_scale, void* workspace,
                      size_t workspace_bytes, void* stream);
 
+/* Split-K form of avsi_gemm_f32 for reductions over very many rows (weight gradients
+ * dW = X^T . dZ over all T*Bp rows): K is cut into `splits` chunks, partial [M,N] slabs go to
+ * `workspace` (avsi_gemm_splitk_workspace_bytes), then are summed in chunk order (deterministic,
+ * no atomics) into C [M,N] (contiguous, ldc = N).  No bias / epilogue options. */
+size_t avsi_gemm_splitk_workspace_bytes(int M, int N, int splits);
+int avsi_gemm_splitk_f32(int transA, int transB, int M, int N, int K, float alpha,
+                         const float* A, int64_t lda, const float* B, int64_t ldb,
+                         float* C, int splits, void* workspace, size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * BPTT through the recurrent half of one bidirectional LSTM layer (gradient of
+ * avsi_blstm_rec_fwd_f32; the reference gets it from tf.gradients over the while_loop /
+ * the CudnnLSTM backward op, models.py:95-115,178).
+ *   dhout   [T][Bp][512]        d loss / d layer output
+ *   reserve [T][Bp][2][5][256]  from the forward call
+ *   whbT    [2][8][128][64][4]  recurrent kernel, transposed-product fragment order
+ *   dz      [T][Bp][2][1024]    OUT: d loss / d gate pre-activations, packed gate columns
+ * The time-batched gradients follow as GEMMs / column sums over dz.
+ * ------------------------------------------------------------------------------------ */
+int avsi_blstm_rec_bwd_f32(const float* dhout, const float* reserve, const float* whbT, float* dz,
+                           int T, int Bp, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * Memory-bound helpers.
+ * avsi_relayout_rows_f32: dst[b*dsb + t*dst + c] = (c < C ? src[b*ssb + t*sst + c] * scale(b,t) : 0)
+ *   for c < dst_cols: moves [B,T,C] feed tensors into the padded time-major layout (and
+ *   gradients back), folding tf.sequence_mask (models.py:136) in as the row scale.
+ * avsi_colsum_f32: out[n] = sum_m x[m*ld + n] (bias gradients), deterministic two-stage.
+ * avsi_adam_tf_f32: tf.train.AdamOptimizer(lr, beta1, beta2, eps) step `step` (1-based) on flat
+ *   buffers (models.py:168): g' = grad*grad_scale + l2*p; m,v update; p -= lr_t m / (sqrt(v)+eps).
+ * ------------------------------------------------------------------------------------ */
+int avsi_relayout_rows_f32(const float* src, int64_t src_stride_b, int64_t src_stride_t,
+                           float* dst, int64_t dst_stride_b, int64_t dst_stride_t,
+                           int B, int T, int C, int dst_cols,
+                           const float* row_scale, int64_t scale_stride_b, int64_t scale_stride_t,
+                           void* stream);
+size_t avsi_colsum_workspace_bytes(int64_t M, int N);
+int avsi_colsum_f32(const float* x, int64_t ld, int64_t M, int N, float* out,
+                    void* workspace, size_t workspace_bytes, void* stream);
+int avsi_adam_tf_f32(float* param, const float* grad, float* m, float* v, int64_t n,
+                     float lr, float beta1, float beta2, float eps, int64_t step,
+                     float grad_scale, float l2, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

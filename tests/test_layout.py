@@ -29,13 +29,51 @@ def test_roundtrip_flat_oracle_params():
         np.testing.assert_array_equal(a[1], b[1])
 
 
-def test_pack_unpack_are_inverse_gathers():
+def test_pack_index_covers_every_parameter_and_pads_with_zero():
     lay = ParamLayout(393, (250, 250))
     flat = np.arange(1, lay.ref_size + 1, dtype=np.float64)
     packed = np.concatenate([flat, [0.0]])[lay.pack_index]
-    np.testing.assert_array_equal(packed[lay.unpack_index], flat)
-    # everything that is not a parameter is zero padding
-    assert np.count_nonzero(packed) == lay.ref_size
+    # forward layout: every parameter once, plus the recurrent kernels a second time (BPTT order)
+    rec = sum(250 * 1000 for _ in range(2 * 2))
+    assert np.count_nonzero(packed) == lay.ref_size + rec
+    for li in range(2):
+        a = np.sort(lay.packed_view(packed, 'wh%d' % li)[lay.packed_view(packed, 'wh%d' % li) != 0])
+        b = np.sort(lay.packed_view(packed, 'whb%d' % li)[lay.packed_view(packed, 'whb%d' % li) != 0])
+        np.testing.assert_array_equal(a, b)
+
+
+def test_grad_index_is_a_bijection_onto_parameter_slots():
+    lay = ParamLayout(257)
+    assert lay.grad_index.shape == (lay.ref_size,)
+    assert len(np.unique(lay.grad_index)) == lay.ref_size
+    assert lay.grad_index.max() < lay.gpacked_size
+    # spot check: d/d kernel[row, col] of layer 1 bw, recurrent part -> dwh1[1][k][packed col]
+    H, D = 250, 500
+    name = 'cell_1/bw/kernel'
+    off = [o for n, _, o in lay.ref_entries if n == name][0]
+    k, g, u = 17, 2, 133
+    pos = lay.grad_index[off + (D + k) * 1000 + g * H + u]
+    dwh_off, _ = lay.gpacked['dwh1']
+    assert pos == dwh_off + (1 * HP + k) * GP + (u // 32) * 128 + g * 32 + u % 32
+    # input part of layer 1: reference row 260 (bw half, unit 10) is padded row 256 + 10
+    pos = lay.grad_index[off + 260 * 1000 + g * H + u]
+    dwx_off, _ = lay.gpacked['dwx1']
+    assert pos == dwx_off + (256 + 10) * 2 * GP + packed_gate_col(1, g, u)
+
+
+def test_bptt_fragment_order():
+    """whb[d][w][q][lane][s] = Wh[unit' = 32w + (lane&31)][packed col 8q + 4(lane>>5) + s]."""
+    H = 250
+    lay = ParamLayout(257)
+    p = O.init_params(5, 257)
+    _, packed = _packed(lay, p)
+    whb = lay.packed_view(packed, 'whb2').reshape(2, 8, 128, 64, 4)
+    K = p['layers'][2]['fw']['kernel']
+    for (w, q, lane, s) in [(0, 0, 0, 0), (3, 77, 45, 3), (7, 127, 63, 3), (5, 20, 25, 1)]:
+        col, up = 8 * q + 4 * (lane >> 5) + s, 32 * w + (lane & 31)
+        g, cu = (col % 128) // 32, (col // 128) * 32 + col % 32
+        want = K[500 + up, g * H + cu] if (up < H and cu < H) else 0.0
+        assert whb[0, w, q, lane, s] == want
 
 
 def test_packed_input_projection_equals_reference_product():

@@ -1,0 +1,154 @@
+"""Training half of the hot path on the GPU: BPTT kernel + split-K weight-gradient GEMMs + column
+sums + TF-Adam, against the CPU oracle (manual BPTT in float64, itself pinned to torch.autograd in
+tests/test_oracle_blstm.py)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import blstm as O
+from oracle import frontend as OF
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def mods():
+    import avsi_amd
+    from avsi_amd import models, ops, blstm_layout
+    return models, ops, blstm_layout
+
+
+def _config(**kw):
+    cfg = dict(audio_feat_dim=257, video_feat_dim=136, audio_len=48000, net_dim=[250, 250, 250],
+               optimizer_type='adam', starter_learning_rate=1e-3, lr_updating_steps=10000, lr_decay=1.0,
+               batch_size=8, l2=0.0)
+    cfg.update(kw)
+    return cfg
+
+
+def _inputs(B, N, seed):
+    rng = np.random.default_rng(seed)
+    wav = np.clip(np.round(rng.normal(0, 3000, size=(B, N))), -32768, 32767).astype(np.float32)
+    T = -(-N // 192)
+    gap = max(1, T // 4)
+    masks = np.ones((B, T, 257), dtype=np.float32)
+    for b in range(B):
+        s = rng.integers(0, T - gap)
+        masks[b, s:s + gap] = 0
+    spec = OF.get_spectrogram(OF.get_stft(wav, window_size=24, step_size=12), log=True)
+    mean, std = OF.feature_stats(list(spec))
+    video = rng.normal(size=(B, T, 136)).astype(np.float32)
+    return wav, masks, mean.astype(np.float32), std.astype(np.float32), video, T
+
+
+def _rand_biases(params, seed):
+    rng = np.random.default_rng(seed)
+    for layer in params['layers']:
+        for d in ('fw', 'bw'):
+            layer[d]['bias'] = rng.normal(0, 0.1, size=layer[d]['bias'].shape).astype(np.float32)
+    params['proj']['biases'] = rng.normal(0, 0.1, size=params['proj']['biases'].shape).astype(np.float32)
+    return params
+
+
+def _flat_grads(layout, grads):
+    return layout.flatten_oracle_params({'layers': grads['layers'], 'proj': grads['proj']}).astype(np.float64)
+
+
+def test_helper_kernels(mods):
+    models, ops, bl = mods
+    rng = np.random.default_rng(0)
+    # column sums
+    x = rng.normal(size=(5000, 300)).astype(np.float32)
+    xt = torch.from_numpy(x).cuda()
+    out = torch.empty(257, device='cuda')
+    ops.colsum(xt, out, n=257)
+    np.testing.assert_allclose(out.cpu().numpy(), x[:, :257].astype(np.float64).sum(0), rtol=1e-5, atol=1e-3)
+    # row re-layout with scale and zero fill
+    B, T, C, Bp, Cp = 3, 5, 7, 32, 8
+    src = rng.normal(size=(B, T, C)).astype(np.float32)
+    scale = rng.uniform(size=(T, Bp)).astype(np.float32)
+    dst = torch.full((T, Bp, Cp), 9.0, device='cuda')
+    ops.relayout_rows(torch.from_numpy(src).cuda(), dst, B, T, C, Cp, (T * C, C), (Cp, Bp * Cp),
+                      row_scale=torch.from_numpy(scale).cuda(), scale_strides=(1, Bp))
+    got = dst.cpu().numpy()
+    np.testing.assert_allclose(got[:, :B, :C], src.transpose(1, 0, 2) * scale[:, :B, None], rtol=1e-6)
+    assert np.all(got[:, :B, C:] == 0) and np.all(got[:, B:] == 9.0)
+    # split-K transposed GEMM (weight-gradient shape)
+    A = rng.normal(size=(3000, 264)).astype(np.float32)
+    Z = rng.normal(size=(3000, 512)).astype(np.float32)
+    o = torch.empty(264, 512, device='cuda')
+    ops.gemm_splitk(torch.from_numpy(A).cuda(), torch.from_numpy(Z).cuda(), o, trans_a=True, splits=7)
+    ref = A.astype(np.float64).T @ Z
+    assert np.abs(o.cpu().numpy() - ref).max() < 2e-3
+
+
+def test_adam_kernel_matches_tf_form(mods):
+    models, ops, bl = mods
+    rng = np.random.default_rng(1)
+    n = 10007
+    p0 = rng.normal(size=n)
+    p, m, v = p0.copy(), np.zeros(n), np.zeros(n)
+    tp = torch.from_numpy(p0.astype(np.float32)).cuda()
+    tm, tv = torch.zeros_like(tp), torch.zeros_like(tp)
+    for step in range(1, 6):
+        g = rng.normal(size=n) * 10.0 ** rng.integers(-4, 1)
+        O.adam_tf_step(p, g, m, v, step, lr=1e-3)
+        ops.adam_tf(tp, torch.from_numpy(g.astype(np.float32)).cuda(), tm, tv, step, 1e-3)
+    np.testing.assert_allclose(tp.cpu().numpy(), p, rtol=0, atol=2e-6)
+    np.testing.assert_allclose(tm.cpu().numpy(), m, rtol=1e-5, atol=1e-7)   # fp32 slots vs float64 oracle
+
+
+@pytest.mark.parametrize("input_type,B,N", [('a', 5, 3840), ('av', 3, 2880), ('a', 34, 1920)])
+def test_gradients_match_oracle(mods, input_type, B, N):
+    models, ops, bl = mods
+    wav, masks, mean, std, video, T = _inputs(B, N, 30 + B)
+    D = {'a': 257, 'av': 393}[input_type]
+    p = _rand_biases(O.init_params(9, D), 10)
+    seq_len = np.full(B, T)
+    seq_len[0] = T - 2
+    m = models.StackedBLSTMModel(seq_len, wav, masks, mean, std, 0.0, _config(audio_len=N), video_features=video,
+                                 input=input_type)
+    m.variables.load_flat(m.layout.flatten_oracle_params(p))
+    got = m.gradients.cpu().numpy().astype(np.float64)
+    fwd = O.model_forward(wav, masks, mean, std, seq_len, p, video=video, input_type=input_type, keep=True)
+    ref = _flat_grads(m.layout, O.model_backward(fwd, masks.astype(np.float64), seq_len))
+    assert got.shape == ref.shape
+    # per-variable relative error (gradients span orders of magnitude across variables)
+    for name, shape, off in m.layout.ref_entries:
+        n = int(np.prod(shape))
+        g, r = got[off:off + n], ref[off:off + n]
+        scale = np.abs(r).max()
+        assert np.abs(g - r).max() <= 2e-3 * scale + 1e-9, (name, np.abs(g - r).max(), scale)
+        assert np.sqrt(np.mean((g - r) ** 2)) <= 2e-4 * scale + 1e-10, name
+
+
+def test_three_adam_steps_track_oracle(mods):
+    models, ops, bl = mods
+    B, N = 4, 2880
+    wav, masks, mean, std, video, T = _inputs(B, N, 50)
+    p = _rand_biases(O.init_params(11, 257), 12)
+    seq_len = np.full(B, T)
+    m = models.StackedBLSTMModel(seq_len, wav, masks, mean, std, 0.0, _config(audio_len=N), input='a')
+    m.variables.load_flat(m.layout.flatten_oracle_params(p))
+    p64 = O.cast_params(p, np.float64)
+    flat = [v for _, v in O.flatten_params(p64)]
+    ms = [np.zeros_like(v) for v in flat]
+    vs = [np.zeros_like(v) for v in flat]
+    losses_ref, losses_got = [], []
+    for step in range(1, 4):
+        fwd = O.model_forward(wav, masks, mean, std, seq_len, p64, keep=True)
+        g = O.model_backward(fwd, masks.astype(np.float64), seq_len)
+        losses_ref.append(fwd['loss'])
+        for (_, gv), pv, mv, vv in zip(O.flatten_params(g), flat, ms, vs):
+            O.adam_tf_step(pv, gv, mv, vv, step, lr=1e-3)
+        m.feed(sequence_lengths=seq_len, target_sources=wav, masks=masks)
+        losses_got.append(float(m.loss))
+        assert m.train_op is None
+        assert m.global_step == step
+    np.testing.assert_allclose(losses_got, losses_ref, rtol=5e-4)
+    assert losses_ref[2] < losses_ref[0]
+    ref_flat = m.layout.flatten_oracle_params(p64).astype(np.float64)
+    got_flat = m.variables.flat.cpu().numpy().astype(np.float64)
+    # Adam normalises the step to ~lr, so parameters agree to a small fraction of 3 * lr
+    assert np.abs(got_flat - ref_flat).max() < 5e-4
+    assert np.sqrt(np.mean((got_flat - ref_flat) ** 2)) < 2e-5
