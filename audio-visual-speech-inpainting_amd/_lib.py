@@ -37,6 +37,20 @@ class FrontendArgs(Structure):
     ]
 
 
+class IstftArgs(Structure):
+    """Mirror of ``avsi_istft_args`` (include/avsi_hip.h)."""
+    _fields_ = [
+        ("mode", c_int32),
+        ("in0", c_void_p), ("in_stride_b", c_int64), ("in_stride_t", c_int64),
+        ("in1", c_void_p), ("in1_stride_b", c_int64), ("in1_stride_t", c_int64),
+        ("in2", c_void_p), ("in2_stride_b", c_int64), ("in2_stride_t", c_int64),
+        ("mean", c_void_p), ("stdev", c_void_p),
+        ("batch", c_int32), ("num_frames", c_int32), ("num_bins", c_int32), ("frame_len", c_int32),
+        ("hop", c_int32), ("nfft", c_int32),
+        ("table", c_void_p), ("out", c_void_p), ("out_stride_b", c_int64), ("num_samples", c_int64),
+    ]
+
+
 class GemmEpilogue(Structure):
     """Mirror of ``avsi_gemm_epilogue`` (include/avsi_hip.h)."""
     _fields_ = [("bias", c_void_p), ("row_scale", c_void_p),
@@ -63,6 +77,9 @@ PROTOTYPES = {
     "avsi_colsum_f32": (c_int, [c_void_p, c_int64, c_int64, c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
     "avsi_adam_tf_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_float, c_float, c_float, c_float,
                                  c_int64, c_float, c_float, c_void_p]),
+    "avsi_istft_table_floats": (c_size_t, [c_int, c_int, c_int]),
+    "avsi_istft_init_tables": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p]),
+    "avsi_istft_f32": (c_int, [POINTER(IstftArgs), c_void_p]),
     "avsi_l1_loss_workspace_bytes": (c_size_t, [c_int64]),
     "avsi_l1_loss_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_float, c_void_p,
                                  c_size_t, c_void_p]),

@@ -176,3 +176,79 @@ def get_stft(sources, sample_rate=16000, window_size=25, step_size=10, n_fft=512
     hop = ms_to_samples(step_size, sample_rate)
     T, F = _out_dims(out_shape, num_frames(sources.shape[1], hop), n_fft // 2 + 1)
     return frontend(sources, sample_rate, window_size, step_size, n_fft, T, F, want_stft=True)['stft']
+
+
+_ITABLES = {}
+
+
+def _istft_tables(device, frame_len, hop, nfft):
+    key = (device.index, frame_len, hop, nfft)
+    tab = _ITABLES.get(key)
+    if tab is None:
+        L = _lib.lib()
+        n = L.avsi_istft_table_floats(frame_len, hop, nfft)
+        if n == 0:
+            raise _lib.AvsiError("unsupported inverse-STFT geometry frame_len=%d hop=%d nfft=%d" % (frame_len, hop, nfft))
+        tab = torch.empty(n, dtype=torch.float32, device=device)
+        _lib.check(L.avsi_istft_init_tables(_lib.ptr(tab), frame_len, hop, nfft, _lib.stream_ptr()),
+                   "avsi_istft_init_tables")
+        _ITABLES[key] = tab
+    return tab
+
+
+def _istft(mode, in0, in1, in2, mean, std, B, T, F, num_samples, sample_rate, window_size, step_size,
+           in_strides, in1_strides=(0, 0), in2_strides=(0, 0)):
+    _lib.require_cuda(in0, in1, in2, mean, std)
+    frame_len = ms_to_samples(window_size, sample_rate)
+    hop = ms_to_samples(step_size, sample_rate)
+    nfft = 512
+    full = (T - 1) * hop + frame_len
+    n_out = full if not num_samples or num_samples <= 0 else min(int(num_samples), full)
+    dev = in0.device
+    out = torch.empty((B, n_out), dtype=torch.float32, device=dev)
+    a = _lib.IstftArgs()
+    a.mode = mode
+    a.in0, a.in_stride_b, a.in_stride_t = _lib.ptr(in0), in_strides[0], in_strides[1]
+    a.in1, a.in1_stride_b, a.in1_stride_t = _lib.ptr(in1), in1_strides[0], in1_strides[1]
+    a.in2, a.in2_stride_b, a.in2_stride_t = _lib.ptr(in2), in2_strides[0], in2_strides[1]
+    a.mean, a.stdev = _lib.ptr(mean), _lib.ptr(std)
+    a.batch, a.num_frames, a.num_bins = B, T, F
+    a.frame_len, a.hop, a.nfft = frame_len, hop, nfft
+    tab = _istft_tables(dev, frame_len, hop, nfft)
+    a.table = _lib.ptr(tab)
+    a.out, a.out_stride_b, a.num_samples = _lib.ptr(out), out.stride(0), n_out
+    _lib.check(_lib.lib().avsi_istft_f32(ctypes.byref(a), _lib.stream_ptr()), "avsi_istft_f32")
+    return out
+
+
+def reconstruct_sources(stfts, num_samples=0, sample_rate=16000, window_size=16, step_size=8):
+    """Compute inverse STFT -- reference audio_processing.py:145-157.  stfts complex64 [B, T, F]."""
+    if stfts.dtype != torch.complex64 or (stfts.shape[2] - 1) * 2 != 512:
+        raise _lib.AvsiError("reconstruct_sources needs complex64 [B, T, 257] (fft length 512)")
+    x = torch.view_as_real(stfts.contiguous())
+    B, T, F = stfts.shape
+    return _istft(0, x, None, None, None, None, B, T, F, num_samples, sample_rate, window_size, step_size,
+                  (x.stride(0), x.stride(1)))
+
+
+def get_sources(mag_spectrograms, rec_ang_spectrograms, num_samples=48000, sample_rate=16000, window_size=24,
+                step_size=12):
+    """Get waveform from magnitude and phase of STFT -- reference audio_processing.py:160-164."""
+    mag = mag_spectrograms.to(torch.float32).contiguous()
+    ang = rec_ang_spectrograms.to(torch.float32).contiguous()
+    B, T, F = mag.shape
+    return _istft(1, mag, ang, None, None, None, B, T, F, num_samples, sample_rate, window_size, step_size,
+                  (mag.stride(0), mag.stride(1)))
+
+
+def enhanced_from_prediction(prediction, mean, std, target_stft, masks=None, num_samples=48000, sample_rate=16000,
+                             window_size=24, step_size=12):
+    """Fused StackedBLSTMModel.enhanced_sources (reference models.py:181-197): waveform of
+    exp(prediction*std+mean) with the phase of target_stft*masks (masks=None: oracle phase)."""
+    pred = prediction.contiguous()
+    st = torch.view_as_real(target_stft.contiguous())
+    B, T, F = pred.shape
+    m = None if masks is None else masks.to(torch.float32).contiguous()
+    return _istft(2, pred, st, m, None if mean is None else mean.contiguous(), None if std is None else std.contiguous(),
+                  B, T, F, num_samples, sample_rate, window_size, step_size, (pred.stride(0), pred.stride(1)),
+                  (st.stride(0), st.stride(1)), (0, 0) if m is None else (m.stride(0), m.stride(1)))

@@ -1,0 +1,230 @@
+// Waveform reconstruction on gfx950: (de-normalise + phase) -> inverse real FFT -> synthesis window
+// -> overlap-add, one pass over HBM.
+//
+// Replaces tf.contrib.signal.inverse_stft with inverse_stft_window_fn (reference
+// audio_processing.py:145-157) and, in its fused mode, the ops in front of it in
+// StackedBLSTMModel.enhanced_sources (models.py:181-197):
+//     mag = exp(pred * std + mean);  phi = angle(target_stft * mask)   [mask = 1: oracle phase]
+//     X   = mag (cos phi + j sin phi)                                  (audio_processing.py:160-164)
+// cos/sin(angle(S)) are Re S / |S| and Im S / |S| (angle(0) = 0 => X = mag), so no atan2 / sincos
+// is evaluated.  The generic modes take a complex spectrogram or (magnitude, phase) planes.
+//
+// Tile = 15 output hops of one utterance: the workgroup inverse-transforms the 16 frames that touch
+// them (one halo frame) with the same 16 x 16 in-register FFT as the front end
+// (z = conj(FFT256(conj Z)) / 256, Z[k] = E[k] + j O[k] built from X[k] and X[256 - k]), applies
+// w[n] / sum_k w^2 and adds the two frames that cover each sample in LDS.
+// Every output sample is written exactly once with coalesced stores; no atomics.
+#include "avsi_common.h"
+#include "fft16.h"
+
+using namespace avsi_fft;
+
+namespace {
+
+constexpr int FR = 16;
+constexpr int TPB = 256;
+constexpr int ZSTRIDE = 272;
+constexpr int XS = 258;  // complex per frame in the X tile
+
+constexpr int TAB_WIN = 0;  // synthesis window [512] (zero past frame_len)
+constexpr int TAB_TW256 = 512;
+constexpr int TAB_TW512 = 1024;
+constexpr int TAB_FLOATS = 512 + 512 + 2 * 257 + 2;
+
+__global__ void istft_tables_kernel(float* tab, int frame_len, int hop) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < 512) {
+        float v = 0.f;
+        if (i < frame_len) {
+            // inverse_stft_window_fn: w[n] / sum_k w[(n mod hop) + k hop]^2, periodic Hann forward window
+            double den = 0.0;
+            for (int j = i % hop; j < frame_len; j += hop) {
+                const double wj = 0.5 - 0.5 * cospi(2.0 * j / frame_len);
+                den += wj * wj;
+            }
+            v = (float)((0.5 - 0.5 * cospi(2.0 * i / frame_len)) / den);
+        }
+        tab[TAB_WIN + i] = v;
+    }
+    if (i < 256) {
+        tab[TAB_TW256 + 2 * i] = (float)cospi(2.0 * i / 256.0);
+        tab[TAB_TW256 + 2 * i + 1] = (float)(-sinpi(2.0 * i / 256.0));
+    }
+    if (i <= 256) {
+        tab[TAB_TW512 + 2 * i] = (float)cospi(2.0 * i / 512.0);
+        tab[TAB_TW512 + 2 * i + 1] = (float)(-sinpi(2.0 * i / 512.0));
+    }
+}
+
+__global__ __launch_bounds__(TPB) void istft_kernel(const avsi_istft_args a, const int tiles_per_utt, const int n_tiles,
+                                                    const int n_hops) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    cf* s_x = reinterpret_cast<cf*>(smem);                             // [FR][XS]   spectrum tile
+    cf* s_z = s_x + FR * XS;                                           // [FR][ZSTRIDE] FFT scratch
+    float* s_f = reinterpret_cast<float*>(s_z + FR * ZSTRIDE);         // [FR][512]  windowed frames
+
+    const int tid = threadIdx.x, f = tid >> 4, ln = tid & 15;
+    const int S = a.hop, L = a.frame_len, T = a.num_frames, F = a.num_bins;
+    const float* __restrict__ tab = a.table;
+    cf tw[16];
+#pragma unroll
+    for (int k2 = 1; k2 < 16; ++k2) {
+        const float2 w = *reinterpret_cast<const float2*>(tab + TAB_TW256 + 2 * ((ln * k2) & 255));
+        tw[k2] = {w.x, w.y};
+    }
+    const bool have_norm = a.mean != nullptr;
+
+    for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const int b = tile / tiles_per_utt;
+        const int h0 = (tile - b * tiles_per_utt) * (FR - 1);  // first output hop of the tile
+        const int t0 = h0 - 1;                                  // first frame (halo)
+
+        // ---- 1. spectrum tile -> LDS (thread <-> bin, coalesced rows), assembling X on the fly
+        for (int ff = 0; ff < FR; ++ff) {
+            const int t = t0 + ff;
+            const bool live = t >= 0 && t < T;
+            for (int k = tid; k < 257; k += TPB) {
+                cf x{0.f, 0.f};
+                if (live && k < F) {
+                    const int64_t o = (int64_t)b * a.in_stride_b + (int64_t)t * a.in_stride_t;
+                    if (a.mode == 0) {  // complex spectrogram, interleaved
+                        x = {a.in0[o + 2 * k], a.in0[o + 2 * k + 1]};
+                    } else if (a.mode == 1) {  // magnitude + phase planes
+                        float sn, cs;
+                        __sincosf(a.in1[o + k], &sn, &cs);
+                        const float m = a.in0[o + k];
+                        x = {m * cs, m * sn};
+                    } else {  // fused enhanced_sources: in0 = prediction, in1 = target STFT (complex), in2 = mask
+                        float m = a.in0[o + k];
+                        if (have_norm) m = m * a.stdev[k] + a.mean[k];
+                        m = __expf(m);
+                        const int64_t os = (int64_t)b * a.in1_stride_b + (int64_t)t * a.in1_stride_t;
+                        const float sr = a.in1[os + 2 * k], si = a.in1[os + 2 * k + 1];
+                        if (a.in2) {
+                            // models.py:186 casts the mask to complex64 and takes a FULL complex product
+                            // (a + bj)(m + 0j) = (a m - b 0) + (a 0 + b m) j; in a gap the signed zeros
+                            // decide tf.angle = atan2: (-0, +0) -> pi, everything else -> 0.  Kept as is.
+                            const float mk = a.in2[(int64_t)b * a.in2_stride_b + (int64_t)t * a.in2_stride_t + k];
+                            const float zero = 0.f;
+                            const float pr = sr * mk - si * zero, pi = sr * zero + si * mk;
+                            const float r = sqrtf(pr * pr + pi * pi);
+                            if (r > 0.f)
+                                x = {m * (pr / r), m * (pi / r)};
+                            else
+                                x = {(__builtin_signbitf(pr) && !__builtin_signbitf(pi)) ? -m : m, 0.f};
+                        } else {
+                            const float r = sqrtf(sr * sr + si * si);
+                            if (r > 0.f)
+                                x = {m * (sr / r), m * (si / r)};
+                            else
+                                x = {__builtin_signbitf(sr) && !__builtin_signbitf(si) ? -m : m, 0.f};  // atan2(+0,-0) = pi
+                        }
+                    }
+                }
+                if (k == 0 || k == 256) x.i = 0.f;  // irfft ignores the imaginary part of DC / Nyquist
+                s_x[ff * XS + k] = x;
+            }
+        }
+        __syncthreads();
+
+        // ---- 2. Z[k] = E[k] + j O[k] (conjugated for the forward-FFT trick), first 16-point FFT
+        cf v[16];
+        {
+            const cf* xf = s_x + f * XS;
+#pragma unroll
+            for (int k2 = 0; k2 < 16; ++k2) {
+                const int k = ln + 16 * k2;
+                const cf xk = xf[k], xm = xf[256 - k];
+                const float2 w = *reinterpret_cast<const float2*>(tab + TAB_TW512 + 2 * k);  // e^{-2 pi j k/512}
+                const cf e{0.5f * (xk.r + xm.r), 0.5f * (xk.i - xm.i)};
+                const cf d{0.5f * (xk.r - xm.r), 0.5f * (xk.i + xm.i)};
+                const cf o{d.r * w.x + d.i * w.y, d.i * w.x - d.r * w.y};  // d * conj(w) = d e^{+2 pi j k/512}
+                // Z = E + j O ; feed conj(Z)
+                v[k2] = {e.r - o.i, -(e.i + o.r)};
+            }
+        }
+        fft16(v);
+        cf* zf = s_z + f * ZSTRIDE;
+        zf[ln] = v[pos16(0)];
+#pragma unroll
+        for (int n2 = 1; n2 < 16; ++n2) zf[n2 * 17 + ln] = cmul(v[pos16(n2)], tw[n2]);
+        __syncthreads();
+#pragma unroll
+        for (int k1 = 0; k1 < 16; ++k1) v[k1] = zf[ln * 17 + k1];
+        __syncthreads();
+        fft16(v);
+        // ---- 3. z[16 n1 + ln] = conj(.) / 256 -> x[2n], x[2n+1]; synthesis window; store frame
+        {
+            float* ffr = s_f + f * 512;
+#pragma unroll
+            for (int n1 = 0; n1 < 16; ++n1) {
+                const int n = 16 * n1 + ln;
+                const cf z = v[pos16(n1)];
+                const float2 w = *reinterpret_cast<const float2*>(tab + TAB_WIN + 2 * n);
+                *reinterpret_cast<float2*>(ffr + 2 * n) = make_float2(z.r * (1.f / 256.f) * w.x, -z.i * (1.f / 256.f) * w.y);
+            }
+        }
+        __syncthreads();
+
+        // ---- 4. overlap-add: every sample of the 15 hops sums the frames that cover it, stored once
+        const int cover = (L + S - 1) / S;  // frames covering a sample (2 for 384 / 192)
+        const int64_t n_out = a.num_samples;
+        for (int i = tid; i < (FR - 1) * S; i += TPB) {
+            const int hop_i = i / S, r = i - hop_i * S;
+            const int h = h0 + hop_i;
+            if (h >= n_hops) break;
+            const int64_t n = (int64_t)h * S + r;
+            if (n >= n_out) continue;
+            float acc = 0.f;
+            for (int c = 0; c < cover; ++c) {
+                const int ff = hop_i + 1 - c;  // frame index inside the tile (frame t = h - c)
+                const int off = r + c * S;
+                if (ff >= 0 && off < L) acc += s_f[ff * 512 + off];
+            }
+            a.out[(int64_t)b * a.out_stride_b + n] = acc;
+        }
+        __syncthreads();
+    }
+}
+
+}  // namespace
+
+extern "C" size_t avsi_istft_table_floats(int frame_len, int hop, int nfft) {
+    if (nfft != 512 || frame_len <= 0 || frame_len > 512 || hop <= 0) return 0;
+    return TAB_FLOATS;
+}
+
+extern "C" int avsi_istft_init_tables(float* table, int frame_len, int hop, int nfft, void* stream) {
+    if (!table) return AVSI_ERR_INVALID_ARG;
+    if (nfft != 512 || frame_len <= 0 || frame_len > 512 || (frame_len & 1) || hop <= 0 || hop > frame_len)
+        return AVSI_ERR_UNSUPPORTED;
+    avsi_clear_error();
+    hipLaunchKernelGGL(istft_tables_kernel, dim3(3), dim3(256), 0, (hipStream_t)stream, table, frame_len, hop);
+    return avsi_launch_status();
+}
+
+extern "C" int avsi_istft_f32(const avsi_istft_args* args, void* stream) {
+    if (!args) return AVSI_ERR_INVALID_ARG;
+    const avsi_istft_args& a = *args;
+    if (!a.in0 || !a.out || !a.table || a.batch <= 0 || a.num_frames <= 0 || a.num_samples <= 0)
+        return AVSI_ERR_INVALID_ARG;
+    if (a.mode < 0 || a.mode > 2 || (a.mode >= 1 && !a.in1)) return AVSI_ERR_INVALID_ARG;
+    if ((a.mean == nullptr) != (a.stdev == nullptr)) return AVSI_ERR_INVALID_ARG;
+    if (a.nfft != 512 || a.frame_len <= 0 || a.frame_len > 512 || (a.frame_len & 1) || a.hop <= 0 ||
+        a.hop > a.frame_len || a.frame_len > 2 * a.hop)
+        return AVSI_ERR_UNSUPPORTED;  // the 16-frame tile carries ONE halo frame: frame_len <= 2 hop
+    if (a.num_bins <= 0 || a.num_bins > 257) return AVSI_ERR_INVALID_ARG;
+    const int64_t full = (int64_t)(a.num_frames - 1) * a.hop + a.frame_len;
+    if (a.num_samples > full) return AVSI_ERR_INVALID_ARG;
+    const int n_hops = (int)avsi_ceil_div(a.num_samples, a.hop);
+    const int tiles_per_utt = (int)avsi_ceil_div(n_hops, FR - 1);
+    const int64_t n_tiles64 = (int64_t)a.batch * tiles_per_utt;
+    if (n_tiles64 > INT32_MAX) return AVSI_ERR_UNSUPPORTED;
+    const size_t lds = (size_t)FR * XS * 8 + (size_t)FR * ZSTRIDE * 8 + (size_t)FR * 512 * 4;
+    const int n_tiles = (int)n_tiles64;
+    const int grid = n_tiles < AVSI_NUM_CU * 2 ? n_tiles : AVSI_NUM_CU * 2;
+    avsi_clear_error();
+    (void)hipFuncSetAttribute((const void*)istft_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(istft_kernel, dim3(grid), dim3(TPB), lds, (hipStream_t)stream, a, tiles_per_utt, n_tiles, n_hops);
+    return avsi_launch_status();
+}

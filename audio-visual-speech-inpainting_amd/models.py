@@ -305,6 +305,35 @@ class StackedBLSTMModel(object):
             return self.loss_func + self.regularization * self.reg_loss
         return self.loss_func
 
+    # ---------------------------------------------------------------- waveforms (models.py:181-197)
+    @property
+    def target_stft(self):
+        c = self._cache
+        if 'target_stft' not in c:
+            _, T, _ = self._dims()
+            c['target_stft'] = ap.frontend(self.target_sources, window_size=24, step_size=12, n_fft=512,
+                                           num_frames_out=T, num_bins=self.audio_feat_dim, want_stft=True)['stft']
+        return c['target_stft']
+
+    def _enhanced(self, oracle_phase):
+        key = 'enh_oracle' if oracle_phase else 'enh'
+        c = self._cache
+        if key not in c:
+            pred = self.prediction
+            masks = None if oracle_phase else self.masks[:, :pred.shape[1]]
+            c[key] = ap.enhanced_from_prediction(pred, self.audio_feat_mean, self.audio_feat_std, self.target_stft,
+                                                 masks, num_samples=self.audio_len)
+        return c[key]
+
+    @property
+    def enhanced_sources(self):
+        """exp(prediction*std+mean) with the phase of the masked target STFT, inverse STFT."""
+        return self._enhanced(False)
+
+    @property
+    def enhanced_sources_oracle_phase(self):
+        return self._enhanced(True)
+
     # ---------------------------------------------------------------- gradients (tf.gradients of models.py:178)
     def _backward(self):
         """d loss / d variables in the reference layout (cached).  Chain: L1 -> projection ->

@@ -184,6 +184,40 @@ int avsi_adam_tf_f32(float* param, const float* grad, float* m, float* v, int64_
                      float lr, float beta1, float beta2, float eps, int64_t step,
                      float grad_scale, float l2, void* stream);
 
+/* ------------------------------------------------------------------------------------
+ * Inverse STFT / waveform reconstruction: tf.contrib.signal.inverse_stft with
+ * inverse_stft_window_fn(hop) (audio_processing.py:145-157), optionally fused with the polar
+ * assembly of get_sources (audio_processing.py:160-164) and with the de-normalisation + masked
+ * phase of StackedBLSTMModel.enhanced_sources (models.py:181-197).
+ *   mode 0: in0 = complex spectrogram [B][T][num_bins][2] (strides count floats)
+ *   mode 1: in0 = magnitude, in1 = phase, both [B][T][num_bins] with the in0 strides
+ *   mode 2: in0 = prediction (normalised log-magnitude), mean/stdev optional de-normalisation,
+ *           in1 = target STFT (complex, its own strides), in2 = mask [B][T][num_bins] or null
+ *           (null = oracle phase): X = exp(in0*std+mean) * (S m)/|S m|, angle(0) = 0.
+ * Output [B][num_samples] (row stride out_stride_b), num_samples <= (T-1) hop + frame_len.
+ * Requires nfft = 512 and hop <= frame_len <= 2 hop.
+ * ------------------------------------------------------------------------------------ */
+typedef struct avsi_istft_args {
+    int32_t mode;
+    const float* in0;
+    int64_t in_stride_b, in_stride_t;
+    const float* in1;
+    int64_t in1_stride_b, in1_stride_t;
+    const float* in2;
+    int64_t in2_stride_b, in2_stride_t;
+    const float* mean;
+    const float* stdev;
+    int32_t batch, num_frames, num_bins, frame_len, hop, nfft;
+    const float* table;       /* from avsi_istft_init_tables(frame_len, hop, nfft) */
+    float* out;
+    int64_t out_stride_b;
+    int64_t num_samples;
+} avsi_istft_args;
+
+size_t avsi_istft_table_floats(int frame_len, int hop, int nfft);
+int avsi_istft_init_tables(float* table, int frame_len, int hop, int nfft, void* stream);
+int avsi_istft_f32(const avsi_istft_args* args, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

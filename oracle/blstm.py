@@ -201,8 +201,18 @@ def model_forward(wav, masks, mean, std, seq_len, params, video=None, input_type
 def enhanced_sources(pred, mean, std, target_stft, masks=None, num_samples=48000, dtype=np.float64):
     """models.py:181-197: exp(pred*std+mean) with the masked (masks given) or oracle phase."""
     mag = np.exp(pred * np.asarray(std, dtype=dtype) + np.asarray(mean, dtype=dtype))
-    st = target_stft if masks is None else target_stft * np.asarray(masks, dtype=dtype)
-    phase = np.angle(st)
+    if masks is None:
+        phase = np.angle(target_stft)
+    else:
+        # models.py:186 multiplies by tf.cast(masks, complex64): a FULL complex product
+        # (a + bj)(m + 0j) = (a m - b 0) + (a 0 + b m) j.  In a gap (m = 0) the result is a signed
+        # zero pair and tf.angle = atan2 turns (-0, +0) into pi: gap bins whose target has Re < 0
+        # and Im > 0 get phase pi, all other gap bins phase 0.  Restated literally, not "fixed".
+        a = np.real(target_stft).astype(dtype)
+        b = np.imag(target_stft).astype(dtype)
+        m = np.asarray(masks, dtype=dtype)
+        zero = np.zeros((), dtype=dtype)
+        phase = np.arctan2(a * zero + b * m, a * m - b * zero)
     return frontend.get_sources(mag, phase, num_samples=num_samples, dtype=dtype)
 
 
