@@ -1,0 +1,44 @@
+// Host-side helper of the TFRecord reader/writer (no device code): CRC-32C (Castagnoli), the
+// checksum of the TFRecord framing that TensorFlow's C++ RecordReader/RecordWriter computes
+// (the reference reads its datasets through tf.data.TFRecordDataset, dataset_reader.py:24).
+// Slicing-by-8, ~1-2 GB/s per core; tables built once, thread-safe via static initialisation.
+#include <stddef.h>
+#include <stdint.h>
+
+#include "../../include/avsi_hip.h"
+
+namespace {
+struct Crc32cTables {
+    uint32_t t[8][256];
+    Crc32cTables() {
+        for (uint32_t i = 0; i < 256; ++i) {
+            uint32_t c = i;
+            for (int k = 0; k < 8; ++k) c = (c >> 1) ^ (0x82F63B78u & (0u - (c & 1u)));
+            t[0][i] = c;
+        }
+        for (uint32_t i = 0; i < 256; ++i)
+            for (int s = 1; s < 8; ++s) t[s][i] = (t[s - 1][i] >> 8) ^ t[0][t[s - 1][i] & 0xFF];
+    }
+};
+}  // namespace
+
+extern "C" uint32_t avsi_crc32c(const void* data, size_t n, uint32_t seed) {
+    static const Crc32cTables T;
+    const uint8_t* p = static_cast<const uint8_t*>(data);
+    uint32_t c = ~seed;
+    while (n && (reinterpret_cast<uintptr_t>(p) & 7)) {
+        c = (c >> 8) ^ T.t[0][(c ^ *p++) & 0xFF];
+        --n;
+    }
+    while (n >= 8) {
+        uint64_t v;
+        __builtin_memcpy(&v, p, 8);
+        v ^= c;
+        c = T.t[7][v & 0xFF] ^ T.t[6][(v >> 8) & 0xFF] ^ T.t[5][(v >> 16) & 0xFF] ^ T.t[4][(v >> 24) & 0xFF] ^
+            T.t[3][(v >> 32) & 0xFF] ^ T.t[2][(v >> 40) & 0xFF] ^ T.t[1][(v >> 48) & 0xFF] ^ T.t[0][(v >> 56) & 0xFF];
+        p += 8;
+        n -= 8;
+    }
+    while (n--) c = (c >> 8) ^ T.t[0][(c ^ *p++) & 0xFF];
+    return ~c;
+}

@@ -218,6 +218,11 @@ size_t avsi_istft_table_floats(int frame_len, int hop, int nfft);
 int avsi_istft_init_tables(float* table, int frame_len, int hop, int nfft, void* stream);
 int avsi_istft_f32(const avsi_istft_args* args, void* stream);
 
+/* Host helper (no GPU work): CRC-32C of a buffer, continuing from `seed` (0 to start).  The
+ * TFRecord framing the reference's datasets use (tf.data.TFRecordDataset, dataset_reader.py:24)
+ * stores masked CRC-32C values of the length and payload of every record. */
+uint32_t avsi_crc32c(const void* data, size_t n, uint32_t seed);
+
 #ifdef __cplusplus
 }
 #endif

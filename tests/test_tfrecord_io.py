@@ -1,0 +1,177 @@
+"""TFRecord framing + SequenceExample codec + DataManager (host logic, no GPU).  The codec is
+cross-checked against google.protobuf (an independent encoder/decoder) when it is importable."""
+import os
+import struct
+
+import numpy as np
+import pytest
+
+import avsi_amd  # noqa: F401
+from avsi_amd import dataset_reader as dr
+from avsi_amd import tfrecord_io as tio
+
+
+def _sample(seed, T=12, N=2304, with_emb=False):
+    rng = np.random.default_rng(seed)
+    wav = np.round(rng.normal(0, 3000, N)).astype(np.float32) + 0.75       # fractional part: to_int32 truncates
+    mask = np.ones((T, 257), dtype=np.float32)
+    mask[3:6] = 0
+    video = rng.normal(size=(T, 136)).astype(np.float32)
+    labels = np.pad(rng.integers(1, 30, 7), (0, 43)).astype(np.float32)
+    emb = rng.normal(size=512).astype(np.float32) if with_emb else None
+    rec = tio.serialize_sample_fixed(T, 7, wav, video, mask, labels, "s%02d_clip" % seed, embedding=emb)
+    return rec, (T, 7, wav, video, mask, labels, ("s%02d_clip" % seed).encode(), emb)
+
+
+def test_crc32c_known_answers():
+    assert tio._crc32c(b"123456789") == 0xE3069283
+    assert tio._crc32c(b"") == 0
+    assert tio._crc32c(bytes(32)) == 0x8A9136AA
+    assert tio.masked_crc32c(b"123456789") == ((((0xE3069283 >> 15) | (0xE3069283 << 17)) + 0xa282ead8) & 0xFFFFFFFF)
+
+
+def test_framing_roundtrip_and_corruption(tmp_path):
+    path = str(tmp_path / "a.tfrecord")
+    payloads = [b"hello", b"", bytes(range(256)) * 10]
+    tio.write_records(path, payloads)
+    assert list(tio.read_records(path)) == payloads
+    raw = bytearray(open(path, "rb").read())
+    assert struct.unpack("<Q", raw[:8])[0] == 5
+    raw[14] ^= 0xFF                                         # flip a payload byte of the first record
+    open(path, "wb").write(raw)
+    with pytest.raises(IOError):
+        list(tio.read_records(path))
+    assert len(list(tio.read_records(path, verify=False))) == 3
+
+
+def test_sequence_example_roundtrip():
+    rec, (T, L, wav, video, mask, labels, name, _) = _sample(1)
+    ctx, seq = tio.decode_sequence_example(rec)
+    assert ctx['sequence_length'].tolist() == [T] and ctx['labels_length'].tolist() == [L]
+    np.testing.assert_array_equal(ctx['target_audio_wav'], wav)
+    assert ctx['sample_path'] == [name]
+    np.testing.assert_array_equal(np.stack(seq['mask']), mask)
+    np.testing.assert_array_equal(np.stack(seq['video_features']), video)
+    np.testing.assert_array_equal(np.array([s[0] for s in seq['labels']]), labels)
+
+
+def test_negative_int64_and_unpacked_lists():
+    buf = tio.encode_sequence_example({'x': np.array([-3, 5, 2 ** 40], dtype=np.int64)}, {})
+    ctx, _ = tio.decode_sequence_example(buf)
+    assert ctx['x'].tolist() == [-3, 5, 2 ** 40]
+    # un-packed repeated float (field 1, wire type 5) must also be read
+    fl = b''.join(tio._varint((1 << 3) | 5) + struct.pack('<f', v) for v in (1.5, -2.0))
+    feat = tio._ld(2, fl)
+    np.testing.assert_array_equal(tio.decode_feature(feat), [1.5, -2.0])
+
+
+def test_wire_compatible_with_google_protobuf():
+    """Encode the same SequenceExample with google.protobuf's generic descriptor machinery."""
+    pb = pytest.importorskip("google.protobuf")
+    from google.protobuf import descriptor_pb2, descriptor_pool, message_factory
+    fd = descriptor_pb2.FileDescriptorProto(name="ex.proto", package="t", syntax="proto3")
+
+    def msg(name):
+        m = fd.message_type.add()
+        m.name = name
+        return m
+
+    def field(m, name, num, typ, label=1, type_name=None, packed=None):
+        f = m.field.add()
+        f.name, f.number, f.type, f.label = name, num, typ, label
+        if type_name:
+            f.type_name = type_name
+        return f
+    T = descriptor_pb2.FieldDescriptorProto
+    m = msg("BytesList"); field(m, "value", 1, T.TYPE_BYTES, 3)
+    m = msg("FloatList"); field(m, "value", 1, T.TYPE_FLOAT, 3)
+    m = msg("Int64List"); field(m, "value", 1, T.TYPE_INT64, 3)
+    m = msg("Feature")
+    field(m, "bytes_list", 1, T.TYPE_MESSAGE, 1, ".t.BytesList")
+    field(m, "float_list", 2, T.TYPE_MESSAGE, 1, ".t.FloatList")
+    field(m, "int64_list", 3, T.TYPE_MESSAGE, 1, ".t.Int64List")
+    m = msg("FEntry"); field(m, "key", 1, T.TYPE_STRING); field(m, "value", 2, T.TYPE_MESSAGE, 1, ".t.Feature")
+    m = msg("Features"); field(m, "feature", 1, T.TYPE_MESSAGE, 3, ".t.FEntry")
+    m = msg("FeatureList"); field(m, "feature", 1, T.TYPE_MESSAGE, 3, ".t.Feature")
+    m = msg("FLEntry"); field(m, "key", 1, T.TYPE_STRING); field(m, "value", 2, T.TYPE_MESSAGE, 1, ".t.FeatureList")
+    m = msg("FeatureLists"); field(m, "feature_list", 1, T.TYPE_MESSAGE, 3, ".t.FLEntry")
+    m = msg("SequenceExample")
+    field(m, "context", 1, T.TYPE_MESSAGE, 1, ".t.Features")
+    field(m, "feature_lists", 2, T.TYPE_MESSAGE, 1, ".t.FeatureLists")
+    pool = descriptor_pool.DescriptorPool()
+    pool.Add(fd)
+    SE = message_factory.GetMessageClass(pool.FindMessageTypeByName("t.SequenceExample"))
+
+    rec, (Tn, L, wav, video, mask, labels, name, _) = _sample(2, T=4, N=64)
+    ex = SE()
+    ex.ParseFromString(rec)                                  # our bytes parse with the stock decoder
+    ctx = {e.key: e.value for e in ex.context.feature}
+    assert list(ctx['sequence_length'].int64_list.value) == [Tn]
+    np.testing.assert_array_equal(np.array(ctx['target_audio_wav'].float_list.value, dtype=np.float32), wav)
+    assert list(ctx['sample_path'].bytes_list.value) == [name]
+    fl = {e.key: e.value for e in ex.feature_lists.feature_list}
+    assert len(fl['mask'].feature) == Tn
+    np.testing.assert_array_equal(np.array(fl['mask'].feature[1].float_list.value, dtype=np.float32), mask[1])
+    # and the stock encoder's bytes parse with our decoder
+    ctx2, seq2 = tio.decode_sequence_example(ex.SerializeToString())
+    np.testing.assert_array_equal(ctx2['target_audio_wav'], wav)
+    np.testing.assert_array_equal(np.stack(seq2['video_features']), video)
+
+
+def _write_dataset(tmp_path, n, with_emb=False):
+    files, truth = [], []
+    for i in range(n):
+        rec, t = _sample(10 + i, with_emb=with_emb)
+        path = str(tmp_path / ("data_%05d.tfrecord" % (i + 1)))
+        tio.write_records(path, [rec])
+        files.append(path)
+        truth.append(t)
+    return files, truth
+
+
+def test_datamanager_batches_fixed_schema(tmp_path):
+    files, truth = _write_dataset(tmp_path, 5)
+    dm = dr.DataManager(num_audio_samples=2304, audio_feat_size=257, video_feat_size=136, buffer_size=4, mode='fixed')
+    ds = dm.get_dataset(files, shuffle=False)
+    _, it = dm.get_iterator(ds, batch_size=2, n_epochs=1)
+    batches = []
+    while True:
+        try:
+            batches.append(it.get_next())
+        except dr.OutOfRangeError:
+            break
+    assert [len(b[0]) for b in batches] == [2, 2, 1]
+    seq_len, lab_len, wav, path, labels, video, mask = batches[0]
+    assert seq_len.dtype == np.int32 and wav.dtype == np.int32 and mask.dtype == np.float32
+    assert wav.shape == (2, 2304) and video.shape == (2, 12, 136) and mask.shape == (2, 12, 257)
+    np.testing.assert_array_equal(wav[1], np.trunc(truth[1][2]).astype(np.int32))     # tf.to_int32 truncation
+    assert path[0] == truth[0][6]
+    np.testing.assert_array_equal(labels[0], truth[0][5])
+    # initializer rewinds; drop_remainder drops the short batch
+    it.initializer()
+    assert len(it.get_next()[0]) == 2
+    _, it2 = dm.get_iterator(ds, batch_size=2, n_epochs=1, drop_remainder=True)
+    assert sum(1 for _ in it2) == 2
+
+
+def test_shuffle_is_a_permutation_and_seeded(tmp_path):
+    files, truth = _write_dataset(tmp_path, 7)
+    dm = dr.DataManager(2304, 257, 136, buffer_size=3)
+    names = lambda it: [p for b in it for p in b[3]]
+    _, a = dm.get_iterator(dm.get_dataset(files, shuffle=True, seed=5), batch_size=3, n_epochs=1)
+    _, b = dm.get_iterator(dm.get_dataset(files, shuffle=True, seed=5), batch_size=3, n_epochs=1)
+    na, nb = names(a), names(b)
+    assert na == nb and sorted(na) == sorted(t[6] for t in truth) and na != [t[6] for t in truth]
+
+
+def test_embedding_reader_and_rank_sharding(tmp_path):
+    files, truth = _write_dataset(tmp_path, 6, with_emb=True)
+    dm = dr.DataManager(2304, 257, 136, buffer_size=2, embedding_size=512)
+    ds = dm.get_dataset(files, shuffle=False)
+    _, it0 = dm.get_iterator(ds, batch_size=2, n_epochs=1, shard=(0, 2))
+    _, it1 = dm.get_iterator(ds, batch_size=2, n_epochs=1, shard=(1, 2))
+    b0, b1 = list(it0), list(it1)
+    assert len(b0) == 2 and len(b1) == 1
+    assert len(b0[0]) == 8 and b0[0][3].shape == (2, 512)
+    got = [p for b in (b0[0], b1[0], b0[1]) for p in b[4]]
+    assert got == [t[6] for t in truth]
