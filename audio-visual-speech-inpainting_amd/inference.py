@@ -1,0 +1,81 @@
+"""Inference driver on MI355X: TFRecords in, inpainted ``enhanced/<prefix>.wav`` files out.
+
+``infer`` keeps the signature, directory contract and console output of the reference
+(``av_speech_inpainting/inference.py:20-170``): the model directory holds ``config.txt``,
+``audio_features_{mean,std}.npy`` and the ``sinet`` checkpoint; each utterance is written to
+``<audio_path>/<sample_path>/enhanced/<out_file_prefix>.wav`` as 16 kHz int16 truncated to
+``seq_len * 192`` samples.
+
+Phase: ``oracle_phase=True`` uses the target phase everywhere; otherwise the phase of the masked
+target STFT (zero inside gaps).  The reference then refines the gap phase with the ``lws``
+package (inference.py:141-154); ``lws`` is a third-party C extension outside this path, so the
+masked-phase reconstruction -- the input of that refinement -- is what gets written.
+"""
+import os
+import sys
+from glob import glob
+
+import numpy as np
+from scipy.io import wavfile
+
+from . import parallel
+from .config_utils import check_trainconfiguration, load_configfile
+from .dataset_reader import DataManager, OutOfRangeError
+from .training import build_model
+
+
+def infer(model_path, data_path_test, audio_path, out_file_prefix, norm=True, oracle_phase=False, batch_size=1):
+    config = check_trainconfiguration(load_configfile(os.path.join(model_path, 'config.txt')))
+    rank, world = parallel.init()
+
+    dm = DataManager(num_audio_samples=config['audio_len'], audio_feat_size=config['audio_feat_dim'],
+                     video_feat_size=config['video_feat_dim'], buffer_size=4000, mode='fixed')
+    test_files = sorted(glob(os.path.join(data_path_test, '*.tfrecord')))
+    _, test_it = dm.get_iterator(dm.get_dataset(test_files, shuffle=False), batch_size=batch_size, n_epochs=1,
+                                 drop_remainder=False, shard=(rank, world))
+
+    if norm:
+        audio_feat_mean = np.load(os.path.join(model_path, 'audio_features_mean.npy'))
+        audio_feat_std = np.load(os.path.join(model_path, 'audio_features_std.npy'))
+    else:
+        audio_feat_mean = np.zeros(config['audio_feat_dim'])
+        audio_feat_std = np.ones(config['audio_feat_dim'])
+
+    print('Building speech inpainting inference model:')
+    model = build_model(config, audio_feat_mean, audio_feat_std)
+    print('Model building done.')
+    print('done.\n')
+    print('Restore weigths:')
+    try:
+        model.variables.restore(os.path.join(model_path, 'sinet'))
+    except ValueError as e:
+        print(str(e))
+        sys.exit(2)
+    print('done.\n')
+
+    total_samples = 0
+    loss_list = []
+    print('Starting inference on dataset: {:s}'.format(data_path_test))
+    while True:
+        try:
+            test_length, _, test_target_audio, test_sample_path, _, test_video, test_mask = test_it.get_next()
+        except OutOfRangeError:
+            print('done.')
+            break
+        model.feed(sequence_lengths=test_length, target_sources=test_target_audio, video_features=test_video,
+                   masks=test_mask)
+        enhanced = model.enhanced_sources_oracle_phase if oracle_phase else model.enhanced_sources
+        loss = float(model.loss)
+        enhanced = enhanced.cpu().numpy()
+        for wav, sample_dir, seq_len in zip(enhanced, test_sample_path, test_length):
+            out_dir = os.path.join(audio_path, sample_dir.decode(), 'enhanced')
+            os.makedirs(out_dir, exist_ok=True)
+            wavfile.write(os.path.join(out_dir, out_file_prefix + '.wav'), 16000,
+                          wav[: int(seq_len) * 192].astype(np.int16))
+        loss_list.append(loss)
+        total_samples += len(test_length)
+        print('Written {:d} enhanced wavs. Total samples written so far {:d}.'.format(len(test_length), total_samples))
+
+    (mean_loss,) = parallel.all_reduce_mean_scalars([float(np.mean(loss_list)) if loss_list else 0.0])
+    print('Loss hole: {:.5}'.format(mean_loss))
+    return mean_loss

@@ -19,7 +19,7 @@ import sys
 import numpy as np
 import torch
 
-from . import _lib, ops
+from . import _lib, ops, parallel
 from . import audio_processing as ap
 from .blstm_layout import GP, HP, ParamLayout, round_up
 
@@ -86,6 +86,38 @@ class BLSTMVariables:
 
     def p(self, name):
         return self.layout.packed_view(self.packed, name)
+
+    # ---- checkpoints: the role of tf.train.Saver over all global variables (training.py:114)
+    def save(self, path):
+        """Write <path>.npz: every variable under its reference name + optimiser slots + global_step."""
+        flat = self.flat.cpu().numpy()
+        arrays = {n: self.layout.ref_view(flat, n) for n, _, _ in self.layout.ref_entries}
+        arrays['global_step'] = np.int64(self.global_step)
+        arrays['__layout__'] = np.array([self.layout.input_dim, self.layout.H, self.layout.num_layers, self.layout.F])
+        if self.adam_m is not None:
+            arrays['__adam_m__'] = self.adam_m.cpu().numpy()
+        if self.adam_v is not None:
+            arrays['__adam_v__'] = self.adam_v.cpu().numpy()
+        np.savez(path + '.npz', **arrays)
+        return path + '.npz'
+
+    def restore(self, path):
+        """Load a checkpoint written by save(); ValueError if it is not one (reference: exit(2))."""
+        fname = path if path.endswith('.npz') else path + '.npz'
+        try:
+            ck = np.load(fname)
+        except Exception as e:
+            raise ValueError("%s is not a valid checkpoint (%s)" % (path, e))
+        want = [self.layout.input_dim, self.layout.H, self.layout.num_layers, self.layout.F]
+        if '__layout__' not in ck or ck['__layout__'].tolist() != want:
+            raise ValueError("%s was saved for a different model shape" % path)
+        flat = np.zeros(self.layout.ref_size, dtype=np.float32)
+        for n, _, _ in self.layout.ref_entries:
+            self.layout.ref_view(flat, n)[...] = ck[n]
+        self.load_flat(flat)
+        self.global_step = int(ck['global_step'])
+        self.adam_m = torch.from_numpy(ck['__adam_m__']).to(self.device) if '__adam_m__' in ck else None
+        self.adam_v = torch.from_numpy(ck['__adam_v__']).to(self.device) if '__adam_v__' in ck else None
 
     def unpack_grads(self, gpacked, out=None):
         """reference-layout gradient <- gather(gradient buffer written by the backward kernels)."""
@@ -400,11 +432,8 @@ class StackedBLSTMModel(object):
             return None
         g = self._backward()
         v = self.variables
-        world = 1
-        if torch.distributed.is_available() and torch.distributed.is_initialized():
-            world = torch.distributed.get_world_size()
-            if world > 1:
-                torch.distributed.all_reduce(g, op=torch.distributed.ReduceOp.SUM)
+        world = parallel.world_size()
+        parallel.all_reduce_sum_(g)
         step = v.global_step + 1
         l2 = float(self.regularization or 0.0)
         if self.optimizer_choice == 'adam':

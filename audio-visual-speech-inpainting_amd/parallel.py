@@ -1,0 +1,64 @@
+"""Single-node data parallelism: one process per GPU, torch.distributed over RCCL (backend "nccl"
+on ROCm) for the GPUs, gloo for CPU-side tests.
+
+The hot path shards by utterance: inference needs no data-path collective; training needs ONE
+all-reduce per step over the flat reference-layout gradient buffer (4.15 M / 4.42 M floats).
+The loss is a mean over B*T*F, so summing per-rank gradients and dividing by the world size
+reproduces the single-GPU gradient of the global batch when ranks hold equal batches.
+"""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def env_world():
+    """(rank, local_rank, world_size) from the torch.distributed.run environment."""
+    return (int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0")),
+            int(os.environ.get("WORLD_SIZE", "1")))
+
+
+def init(backend=None):
+    """Initialise the default process group when launched with WORLD_SIZE > 1; returns (rank, world)."""
+    rank, local_rank, world = env_world()
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend == "nccl":
+            torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend, rank=rank, world_size=world)
+    return rank, world
+
+
+def world_size():
+    return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+
+
+def rank():
+    return dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
+
+
+def shard_range(n, rank_, world):
+    """Contiguous [lo, hi) slice of n items for `rank_` of `world` (sizes differ by at most 1)."""
+    base, extra = divmod(n, world)
+    lo = rank_ * base + min(rank_, extra)
+    return lo, lo + base + (1 if rank_ < extra else 0)
+
+
+def all_reduce_sum_(flat):
+    """In-place sum over ranks of one flat buffer (no-op on a single process)."""
+    if world_size() > 1:
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+    return flat
+
+
+def all_reduce_mean_scalars(values):
+    """Mean over ranks of a few python floats (validation losses); returns a list of floats."""
+    if world_size() == 1:
+        return list(values)
+    dev = 'cuda' if dist.get_backend() == 'nccl' else 'cpu'
+    t = torch.tensor(list(values), dtype=torch.float64, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return (t / world_size()).tolist()

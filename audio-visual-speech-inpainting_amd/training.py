@@ -1,0 +1,240 @@
+"""Training driver of the inpainting models on MI355X.
+
+``train(config_file)`` follows the reference trainer for the plain a/v/av-BLSTM models
+(``av_speech_inpainting/training_emb.py:23-383``, the internally consistent copy of
+``training.py``): same config keys, same directory contract
+(``<exp_folder>/netmodel/{config.txt, audio_features_mean.npy, audio_features_std.npy, sinet*,
+ckpt*}``, ``<exp_folder>/training_log.txt``), same console / log line formats, NaN/Inf abort with
+exit code 1, bad checkpoint with exit code 2, best-on-validation checkpoint ``sinet``, periodic
+``ckpt`` every 1000 steps, early stopping.  TensorBoard summaries are not written (tensorboard is
+not a dependency of this path).
+
+Launched under ``torch.distributed.run`` it trains data-parallel: every rank reads the same file
+list, whole batches are dealt round-robin to ranks, gradients are all-reduced (RCCL) inside
+``model.train_op``, rank 0 writes logs and checkpoints.
+"""
+import os
+import random
+import shutil
+import sys
+from glob import glob
+from time import time
+
+import numpy as np
+
+from . import models as net
+from . import parallel
+from .config_utils import check_trainconfiguration, load_configfile
+from .dataset_reader import DataManager, OutOfRangeError
+
+_INPUT_OF = {'a-blstm': 'a', 'v-blstm': 'v', 'av-blstm': 'av'}
+
+
+def build_model(config, mean, std, variables=None):
+    """Model selection of the drivers (reference training_emb.py:82-92)."""
+    kind = config['model']
+    if kind not in _INPUT_OF:
+        print('Model selection must be "a-blstm", "v-blstm" or "av-blstm" on the MI355X path '
+              '(got "{:s}"). Closing...'.format(str(kind)))
+        sys.exit(1)
+    model = net.StackedBLSTMModel(None, None, None, mean, std, 0.0, config, input=_INPUT_OF[kind],
+                                  variables=variables)
+    model.build_graph(var_scope=kind)
+    return model
+
+
+def train(config_file):
+    """
+    Train the speech inpainting model.
+    """
+    config = check_trainconfiguration(load_configfile(config_file))
+    rank, world = parallel.init()
+    chief = rank == 0
+
+    data_path = config['root_folder']
+    data_path_train = os.path.join(data_path, 'training-set')
+    data_path_val = os.path.join(data_path, 'validation-set')
+    exp_path = config['exp_folder']
+    exp_name = os.path.basename(exp_path)
+    checkpoints_dir = os.path.join(exp_path, 'netmodel')
+    log_path = os.path.join(exp_path, 'training_log.txt')
+    feat_dim = config['audio_feat_dim']
+
+    def manager():
+        return DataManager(num_audio_samples=config['audio_len'], audio_feat_size=feat_dim,
+                           video_feat_size=config['video_feat_dim'], buffer_size=4000, mode='fixed')
+    train_files = sorted(glob(os.path.join(data_path_train, '*.tfrecord')))
+    random.Random(0 if world > 1 else None).shuffle(train_files)      # same order on every rank
+    train_dm, val_dm = manager(), manager()
+    _, train_it = train_dm.get_iterator(train_dm.get_dataset(train_files, shuffle=True, seed=1234 if world > 1 else None),
+                                        batch_size=config['batch_size'], n_epochs=1, shard=(rank, world))
+    val_files = sorted(glob(os.path.join(data_path_val, '*.tfrecord')))
+    _, val_it = val_dm.get_iterator(val_dm.get_dataset(val_files, shuffle=False), batch_size=config['batch_size'],
+                                    n_epochs=1, shard=(rank, world))
+
+    audio_feat_mean = np.load(config['audio_feat_mean'])
+    audio_feat_std = np.load(config['audio_feat_std'])
+    model = build_model(config, audio_feat_mean, audio_feat_std)
+    print('Model building done.')
+
+    if chief:
+        os.makedirs(checkpoints_dir, exist_ok=True)
+        dest_config = os.path.join(checkpoints_dir, 'config.txt')
+        if os.path.abspath(dest_config) != os.path.abspath(config_file):
+            shutil.copy(config_file, dest_config)
+        shutil.copy(config['audio_feat_mean'], os.path.join(checkpoints_dir, 'audio_features_mean.npy'))
+        shutil.copy(config['audio_feat_std'], os.path.join(checkpoints_dir, 'audio_features_std.npy'))
+    log = open(log_path, 'a') if chief else open(os.devnull, 'w')
+
+    train_size = len(np.load(os.path.join(data_path_train, 'seq_lengths.npy')))
+    val_size = len(np.load(os.path.join(data_path_val, 'seq_lengths.npy')))
+    n_steps_epoch = int(train_size / config['batch_size'])
+    n_steps = n_steps_epoch * config['max_n_epochs']
+
+    header = [
+        '+-- EXPERIMENT NAME - {:s} --+'.format(exp_name),
+        '## Model type: {:s}'.format(config['model']),
+        '## Network dimensions: {:s}'.format(str(config['net_dim'])),
+        '## Optimizer: {:s}'.format(config['optimizer_type']),
+        '## Starter learning rate: {:.6f}'.format(config['starter_learning_rate']),
+        '## Learning rate update steps: {:d}'.format(config['lr_updating_steps']),
+        '## Learning rate decay: {:.6f}'.format(config['lr_decay']),
+        '## L2 regularization coefficient: {:.6f}'.format(config['l2']),
+        '## Dropout rate (no dropout if 0): {:.6f}'.format(config['dropout_rate']),
+        '## Training dataset: {:s}'.format(data_path_train),
+        '## Training size: {:d}'.format(train_size),
+        '## Validation dataset: {:s}'.format(data_path_val),
+        '## Validation size: {:d}'.format(val_size),
+        '## Batch size: {:d}'.format(config['batch_size']),
+        '## Approximated number of steps per epoch: {:d}'.format(n_steps_epoch),
+        '## Number of training epochs: {:d}'.format(config['max_n_epochs']),
+    ]
+    if config['model_ckp']:
+        try:
+            model.variables.restore(config['model_ckp'])
+            print('Model variables restored.')
+        except ValueError:
+            print('{:s} is not a valid checkpoint. Closing...'.format(config['model_ckp']))
+            sys.exit(2)
+    else:
+        log.write('\n'.join(header) + '\n')
+        log.write('## Approximated total number of steps: {:d}\n'.format(n_steps))
+        log.write('\nEpoch\tLR\tTraining loss\tValidation loss\t[TIME]\n')
+    if chief:
+        print('')
+        print('\n'.join(header))
+        print('')
+
+    tot_step = model.global_step
+    epoch_counter = int(tot_step / n_steps_epoch) if n_steps_epoch else 0
+    best_val_checkpoint = (0, 0)
+    best_val_loss = -1.0
+    cneg_epochs = 0
+    train_start_time = time()
+    lr = model.learning_rate
+    train_avg_loss = train_avg_loss_fn = val_avg_loss = float('nan')
+    epoch_duration = 0.0
+
+    for _ in range(config['max_n_epochs']):
+        epoch_counter += 1
+        n_step = 0
+        epoch_start_time = time()
+        train_it.initializer()
+        if chief:
+            print('-> Epoch {:d}'.format(epoch_counter))
+        nframe_sum = 0
+        while True:
+            try:
+                length_batch, _, audio_batch, _, _, video_batch, mask_batch = train_it.get_next()
+            except OutOfRangeError:
+                if chief:
+                    print('Completed epoch {:d} at step {:d} --> Training loss: {:3.5f} - {:3.5f}'.format(
+                        epoch_counter, tot_step, train_avg_loss, train_avg_loss_fn))
+                epoch_duration = time() - epoch_start_time
+                if chief:
+                    print('Epoch training time (seconds) = {:.6f}'.format(epoch_duration))
+                break
+            n_step += 1
+            tot_step += 1
+            model.feed(sequence_lengths=length_batch, target_sources=audio_batch, video_features=video_batch,
+                       masks=mask_batch)
+            loss, loss_fn, lr = float(model.loss), float(model.loss_func), model.learning_rate
+            model.train_op
+            if np.isnan(loss):
+                print('GOT INSTABILITY: loss is NaN. Leaving...')
+                sys.exit(1)
+            if np.isinf(loss):
+                print('GOT INSTABILITY: loss is inf. Leaving...')
+                sys.exit(1)
+            frames = np.count_nonzero(mask_batch == 0)
+            if n_step == 1:
+                nframe_sum = frames // feat_dim
+                train_avg_loss, train_avg_loss_fn = loss, loss_fn
+            else:
+                prev = nframe_sum
+                nframe_sum += frames // feat_dim
+                # reference :252-253: (avg * prev + value * count // dim) / total, floor division included
+                train_avg_loss = (train_avg_loss * prev + loss * frames // feat_dim) / nframe_sum
+                train_avg_loss_fn = (train_avg_loss_fn * prev + loss_fn * frames // feat_dim) / nframe_sum
+            if chief and (n_step % 200 == 0 or n_step == 1):
+                print('Step[{:7d}] Loss[{:3.5f}|{:3.5f}] LR[{:.6f}] Epoch training time[{:.2f}]'.format(
+                    tot_step, train_avg_loss, train_avg_loss_fn, lr, time() - epoch_start_time))
+            if chief and n_step % 1000 == 0:
+                print('Model checkpoint saved in file %s' % model.variables.save(os.path.join(checkpoints_dir, 'ckpt')))
+
+        if chief:
+            print('Start validation set evaluation...')
+        val_it.initializer()
+        n_step = 0
+        nframe_sum = 0
+        while True:
+            try:
+                length_batch, _, audio_batch, _, _, video_batch, mask_batch = val_it.get_next()
+            except OutOfRangeError:
+                break
+            n_step += 1
+            model.feed(sequence_lengths=length_batch, target_sources=audio_batch, video_features=video_batch,
+                       masks=mask_batch)
+            loss = float(model.loss_func)
+            frames = np.count_nonzero(mask_batch == 0)
+            if n_step == 1:
+                nframe_sum = frames // feat_dim
+                val_avg_loss = loss
+            else:
+                prev = nframe_sum
+                nframe_sum += frames // feat_dim
+                val_avg_loss = (val_avg_loss * prev + loss * frames // feat_dim) / nframe_sum
+            if chief and (n_step % 200 == 0 or n_step == 1):
+                print('Step[{:7d}] Loss[{:3.5f}]'.format(n_step, val_avg_loss))
+        (val_avg_loss,) = parallel.all_reduce_mean_scalars([val_avg_loss])
+        if chief:
+            print('done.')
+            print('Validation loss: {:3.5f}. Best loss so far {:2.5f} [Epoch {:d} (step {:d})]'.format(
+                val_avg_loss, best_val_loss, best_val_checkpoint[0], best_val_checkpoint[1]))
+        if best_val_checkpoint == (0, 0) or val_avg_loss < best_val_loss:
+            if chief:
+                print('Model saved in file %s' % model.variables.save(os.path.join(checkpoints_dir, 'sinet')))
+            best_val_checkpoint = (epoch_counter, tot_step)
+            best_val_loss = val_avg_loss
+            cneg_epochs = 0
+        else:
+            cneg_epochs += 1
+        if chief:
+            print('')
+        log.write('{:d}\t{:.6f}\t{:.6f}|{:.6f}\t{:.6f}\t[{:.2f}]\n'.format(
+            epoch_counter, lr, train_avg_loss, train_avg_loss_fn, val_avg_loss, epoch_duration))
+        log.flush()
+        if cneg_epochs >= config['n_earlystop_epochs']:
+            break
+
+    log.close()
+    if chief:
+        if cneg_epochs >= config['n_earlystop_epochs']:
+            print('+---- Done training: early stopped ----+')
+        else:
+            print('+---- Done training: epoch limit reached ----+')
+        print('Total training time: {:.2f} s'.format(time() - train_start_time))
+        print('{:d} epochs, {:d} steps.'.format(epoch_counter, tot_step))
+        print('Best validation checkpoint: {:d} ({:d}) - Loss: {:.5f}'.format(
+            best_val_checkpoint[0], best_val_checkpoint[1], best_val_loss))
+    return model

@@ -1,0 +1,115 @@
+"""End-to-end drivers on the GPU: synthetic TFRecord dataset -> train() -> checkpoint -> infer() -> WAVs."""
+import os
+
+import numpy as np
+import pytest
+from scipy.io import wavfile
+
+pytestmark = pytest.mark.gpu
+
+N, T = 3840, 20
+
+
+def _make_dataset(root, n, seed):
+    import avsi_amd  # noqa: F401
+    from avsi_amd import tfrecord_io as tio
+    os.makedirs(root, exist_ok=True)
+    rng = np.random.default_rng(seed)
+    for i in range(n):
+        t = np.arange(N)
+        wav = np.round(3000 * np.sin(2 * np.pi * (200 + 40 * i) * t / 16000) + rng.normal(0, 300, N)).astype(np.float32)
+        mask = np.ones((T, 257), dtype=np.float32)
+        s = rng.integers(2, T - 6)
+        mask[s:s + 4] = 0
+        video = rng.normal(size=(T, 136)).astype(np.float32)
+        rec = tio.serialize_sample_fixed(T, 3, wav, video, mask, np.zeros(50), "clip_%03d" % i)
+        tio.write_records(os.path.join(root, "data_%05d.tfrecord" % (i + 1)), [rec])
+    np.save(os.path.join(root, "seq_lengths.npy"), np.full(n, T))
+
+
+@pytest.fixture(scope="module")
+def experiment(tmp_path_factory):
+    import avsi_amd  # noqa: F401
+    from avsi_amd import audio_processing as ap
+    import torch
+    base = tmp_path_factory.mktemp("exp")
+    data = str(base / "tfrecords")
+    _make_dataset(os.path.join(data, "training-set"), 12, 0)
+    _make_dataset(os.path.join(data, "validation-set"), 4, 1)
+    _make_dataset(os.path.join(data, "test-set"), 5, 2)
+    # normalisation statistics of the training clips (the audio_preprocessing step)
+    from avsi_amd import tfrecord_io as tio
+    wavs = []
+    for f in sorted(os.listdir(os.path.join(data, "training-set"))):
+        if f.endswith(".tfrecord"):
+            ctx, _ = tio.decode_sequence_example(next(tio.read_records(os.path.join(data, "training-set", f))))
+            wavs.append(ctx['target_audio_wav'])
+    spec = ap.frontend(torch.from_numpy(np.stack(wavs)).cuda(), want_spec=True)['spec']
+    np.save(str(base / "mean.npy"), spec.mean(dim=(0, 1)).cpu().numpy().astype(np.float64))
+    np.save(str(base / "std.npy"), spec.std(dim=(0, 1), unbiased=False).cpu().numpy().astype(np.float64))
+    cfg = base / "train.config"
+    cfg.write_text("\n".join([
+        "### synthetic experiment", "model = av-blstm", "audio_feat_dim = 257", "video_feat_dim = 136",
+        "audio_len = %d" % N, "batch_size = 4", "net_dim = [250, 250, 250]", "dropout_rate = 0.0",
+        "max_n_epochs = 3", "n_earlystop_epochs = 5", "optimizer_type = adam", "starter_learning_rate = 0.001",
+        "lr_decay = 1.0", "lr_updating_steps = 10000", "l2 = 0.0", "root_folder = %s" % data,
+        "exp_folder = %s" % (base / "logs" / "av_exp0"), "device = /gpu:0",
+        "audio_feat_mean = %s" % (base / "mean.npy"), "audio_feat_std = %s" % (base / "std.npy"), ""]))
+    return base, data, str(cfg)
+
+
+def test_train_writes_reference_directory_contract(experiment, capsys):
+    from avsi_amd import training
+    base, data, cfg = experiment
+    model = training.train(cfg)
+    out = capsys.readouterr().out
+    exp = base / "logs" / "av_exp0"
+    net = exp / "netmodel"
+    for f in ("config.txt", "audio_features_mean.npy", "audio_features_std.npy", "sinet.npz"):
+        assert (net / f).is_file(), f
+    log = (exp / "training_log.txt").read_text().splitlines()
+    assert log[0] == "+-- EXPERIMENT NAME - av_exp0 --+"
+    assert "## Model type: av-blstm" in log
+    assert "Epoch\tLR\tTraining loss\tValidation loss\t[TIME]" in log
+    rows = [l for l in log if l[:1].isdigit()]
+    assert len(rows) == 3 and rows[0].split("\t")[0] == "1" and "|" in rows[0].split("\t")[2]
+    losses = [float(r.split("\t")[2].split("|")[0]) for r in rows]
+    assert losses[-1] < losses[0]                         # it learns something in 9 steps
+    assert "+---- Done training: epoch limit reached ----+" in out
+    assert "Step[      1] Loss[" in out
+    assert model.global_step == 9
+
+
+def test_resume_from_checkpoint_restores_variables(experiment):
+    import torch
+    from avsi_amd import models, training
+    from avsi_amd.config_utils import check_trainconfiguration, load_configfile
+    base, data, cfg = experiment
+    net = base / "logs" / "av_exp0" / "netmodel"
+    config = check_trainconfiguration(load_configfile(str(net / "config.txt")))
+    m = training.build_model(config, np.load(str(net / "audio_features_mean.npy")), np.load(str(net / "audio_features_std.npy")))
+    before = m.variables.flat.clone()
+    m.variables.restore(str(net / "sinet"))
+    assert not torch.equal(before, m.variables.flat)
+    assert m.variables.global_step in (3, 6, 9)
+    assert m.variables.adam_m is not None
+    with pytest.raises(ValueError):
+        m.variables.restore(str(net / "config.txt"))
+
+
+@pytest.mark.parametrize("oracle_phase", [True, False])
+def test_infer_writes_int16_wavs(experiment, oracle_phase, capsys):
+    from avsi_amd import inference
+    base, data, cfg = experiment
+    net = base / "logs" / "av_exp0" / "netmodel"
+    audio_out = base / ("audio_%d" % oracle_phase)
+    loss = inference.infer(str(net), os.path.join(data, "test-set"), str(audio_out), "av_exp0", norm=True,
+                           oracle_phase=oracle_phase, batch_size=2)
+    out = capsys.readouterr().out
+    assert "Written 2 enhanced wavs. Total samples written so far 2." in out
+    assert "Written 1 enhanced wavs. Total samples written so far 5." in out
+    assert "Loss hole:" in out and np.isfinite(loss)
+    for i in range(5):
+        rate, wav = wavfile.read(str(audio_out / ("clip_%03d" % i) / "enhanced" / "av_exp0.wav"))
+        assert rate == 16000 and wav.dtype == np.int16 and wav.shape == (T * 192,)
+        assert np.abs(wav).max() > 0
