@@ -80,6 +80,11 @@ PROTOTYPES = {
     "avsi_istft_table_floats": (c_size_t, [c_int, c_int, c_int]),
     "avsi_istft_init_tables": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p]),
     "avsi_istft_f32": (c_int, [POINTER(IstftArgs), c_void_p]),
+    "avsi_spectrogram_f32": (c_int, [c_void_p, c_void_p, c_int64, c_float, c_int, c_float, c_void_p]),
+    "avsi_logmel_f32": (c_int, [c_void_p, c_int64, c_int64, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p,
+                                c_float, c_void_p]),
+    "avsi_preemphasis_f32": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int64, c_float, c_void_p]),
+    "avsi_delta_f32": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_void_p]),
     "avsi_crc32c": (ctypes.c_uint32, [c_void_p, c_size_t, ctypes.c_uint32]),
     "avsi_l1_loss_workspace_bytes": (c_size_t, [c_int64]),
     "avsi_l1_loss_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_float, c_void_p,

@@ -252,3 +252,92 @@ def enhanced_from_prediction(prediction, mean, std, target_stft, masks=None, num
     return _istft(2, pred, st, m, None if mean is None else mean.contiguous(), None if std is None else std.contiguous(),
                   B, T, F, num_samples, sample_rate, window_size, step_size, (pred.stride(0), pred.stride(1)),
                   (st.stride(0), st.stride(1)), (0, 0) if m is None else (m.stride(0), m.stride(1)))
+
+
+# ---------------------------------------------------------------------------- per-op API (reference names)
+def get_spectrogram(stfts, power=1, log=False, out_shape=[0, 0, 0]):
+    """|X| (** power) (log(. + 1e-6)) -- reference audio_processing.py:45-56."""
+    _lib.require_cuda(stfts)
+    x = torch.view_as_real(stfts.contiguous())
+    out = torch.empty(stfts.shape, dtype=torch.float32, device=stfts.device)
+    _lib.check(_lib.lib().avsi_spectrogram_f32(_lib.ptr(x), _lib.ptr(out), out.numel(), float(power), int(bool(log)),
+                                               1e-6, _lib.stream_ptr()), "avsi_spectrogram_f32")
+    if out_shape is not None and any(int(s) != 0 for s in out_shape):
+        out = out[: out_shape[0], : out_shape[1], : out_shape[2]]
+    return out
+
+
+def get_log_mel_spectrogram(spectrograms, sample_rate=16000, num_spec_bins=257, num_mel_bins=80, lower_edge_freq=125,
+                            upper_edge_freq=7600, eps=1e-6, out_shape=[0, 0, 0]):
+    """log(spectrograms . mel_W + eps) -- reference audio_processing.py:59-72 (its out_shape slice is
+    discarded there, SURVEY B6, and so it is here)."""
+    _lib.require_cuda(spectrograms)
+    if upper_edge_freq is None:
+        upper_edge_freq = sample_rate / 2
+    sp = spectrograms.to(torch.float32).contiguous()
+    rows = sp.numel() // sp.shape[-1]
+    ms, ml, mw, stride = _mel_bands(sp.device, num_mel_bins, num_spec_bins, sample_rate, lower_edge_freq, upper_edge_freq)
+    out = torch.empty(sp.shape[:-1] + (num_mel_bins,), dtype=torch.float32, device=sp.device)
+    _lib.check(_lib.lib().avsi_logmel_f32(_lib.ptr(sp), sp.shape[-1], rows, num_mel_bins, _lib.ptr(ms), _lib.ptr(ml),
+                                          _lib.ptr(mw), stride, _lib.ptr(out), float(eps), _lib.stream_ptr()),
+               "avsi_logmel_f32")
+    return out
+
+
+_DCT = {}
+
+
+def get_mfcc(log_mel_spectrograms, num_mfccs=13, out_shape=[0, 0, 0]):
+    """First num_mfccs of DCT-II(log-mel) * rsqrt(2 M) -- reference audio_processing.py:75-82
+    (tf.signal.mfccs_from_log_mel_spectrograms), as one fp32-MFMA GEMM with the DCT basis."""
+    from . import ops
+    x = log_mel_spectrograms.to(torch.float32).contiguous()
+    M = x.shape[-1]
+    key = (x.device.index, M)
+    basis = _DCT.get(key)
+    if basis is None:
+        n = np.arange(M, dtype=np.float64)
+        k = np.arange(M, dtype=np.float64)[:, None]
+        b = (2.0 * np.cos(np.pi * k * (2.0 * n + 1.0) / (2.0 * M)) / math.sqrt(2.0 * M)).T      # [n, k]
+        basis = torch.from_numpy(np.ascontiguousarray(b, dtype=np.float32)).to(x.device)
+        _DCT[key] = basis
+    rows = x.numel() // M
+    xm = x.view(rows, M)
+    if M % 4:
+        xm = torch.nn.functional.pad(xm, (0, 4 - M % 4))
+    out = ops.gemm(xm, basis, m=rows, n=M, k=M).view(x.shape)[..., :num_mfccs]
+    if out_shape is not None and any(int(s) != 0 for s in out_shape):
+        out = out[: out_shape[0], : out_shape[1], : out_shape[2]]
+    return out
+
+
+def delta(features, N=2):
+    """Regression deltas -- reference audio_processing.py:85-94."""
+    _lib.require_cuda(features)
+    x = features.to(torch.float32).contiguous()
+    B, T, F = x.shape
+    out = torch.empty_like(x)
+    _lib.check(_lib.lib().avsi_delta_f32(_lib.ptr(x), _lib.ptr(out), B, T, F, int(N), _lib.stream_ptr()), "avsi_delta_f32")
+    return out
+
+
+def add_delta_features(features, n_delta=2, N=2):
+    """features ++ delta ++ delta-delta ... along the last axis -- reference audio_processing.py:97-104."""
+    feats = [features]
+    cur = features
+    for _ in range(n_delta):
+        cur = delta(cur, N)
+        feats.append(cur)
+    return torch.cat(feats, dim=2)
+
+
+def preemphasis(sources, alpha=0.95):
+    """y[t] = x[t] - alpha x[t-1] -- reference audio_processing.py:19-22."""
+    _lib.require_cuda(sources)
+    x = sources.to(torch.float32)
+    if x.stride(1) != 1:
+        x = x.contiguous()
+    out = torch.empty(x.shape, dtype=torch.float32, device=x.device)
+    _lib.check(_lib.lib().avsi_preemphasis_f32(_lib.ptr(x), _lib.ptr(out), x.shape[0], x.shape[1], x.stride(0),
+                                               float(alpha), _lib.stream_ptr()), "avsi_preemphasis_f32")
+    return out

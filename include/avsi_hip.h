@@ -218,6 +218,17 @@ size_t avsi_istft_table_floats(int frame_len, int hop, int nfft);
 int avsi_istft_init_tables(float* table, int frame_len, int hop, int nfft, void* stream);
 int avsi_istft_f32(const avsi_istft_args* args, void* stream);
 
+/* Stand-alone forms of the small operators of audio_processing.py (the inpainter itself uses the
+ * fused front end).  avsi_spectrogram_f32: out[i] = |stft[i]|^power, log(. + eps) if do_log
+ * (:45-56); avsi_logmel_f32: out[r][m] = log(sum_j spec[r][start[m]+j] w[m][j] + eps) (:59-72);
+ * avsi_preemphasis_f32: y[b][t] = x[b][t] - alpha x[b][t-1] (:19-22); avsi_delta_f32: regression
+ * deltas over [B][T][F] with window N, SYMMETRIC padding applied one frame at a time (:85-94). */
+int avsi_spectrogram_f32(const float* stft, float* out, int64_t n, float power, int do_log, float eps, void* stream);
+int avsi_logmel_f32(const float* spec, int64_t ld, int64_t rows, int num_mel, const int32_t* mel_start,
+                    const int32_t* mel_len, const float* mel_w, int mel_w_stride, float* out, float eps, void* stream);
+int avsi_preemphasis_f32(const float* x, float* y, int64_t B, int64_t N, int64_t ldx, float alpha, void* stream);
+int avsi_delta_f32(const float* x, float* y, int64_t B, int T, int F, int N, void* stream);
+
 /* Host helper (no GPU work): CRC-32C of a buffer, continuing from `seed` (0 to start).  The
  * TFRecord framing the reference's datasets use (tf.data.TFRecordDataset, dataset_reader.py:24)
  * stores masked CRC-32C values of the length and payload of every record. */

@@ -1,0 +1,91 @@
+"""Data-parallel contract on CPU with gloo, world_size 2 (no GPU): summing per-rank gradients of
+equal shards and dividing by the world size, then the TF-Adam update, reproduces the single-process
+step on the global batch; shard helpers partition the work."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+import avsi_amd  # noqa: F401
+from avsi_amd import parallel
+from oracle import blstm as O
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _problem():
+    rng = np.random.default_rng(0)
+    B, N = 4, 1536
+    wav = np.round(rng.normal(0, 3000, size=(B, N)))
+    T = N // 192
+    masks = np.ones((B, T, 257))
+    masks[:, 2:4] = 0
+    params = O.cast_params(O.init_params(1, 257, (6, 6), 257), np.float64)
+    return wav, masks, np.zeros(257), np.ones(257), np.full(B, T), params
+
+
+def _grads(wav, masks, mean, std, seq, params):
+    fwd = O.model_forward(wav, masks, mean, std, seq, params, keep=True)
+    g = O.model_backward(fwd, masks, seq)
+    return np.concatenate([v.reshape(-1) for _, v in O.flatten_params(g)]), fwd['loss']
+
+
+def _worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    r, w = parallel.init(backend="gloo")
+    assert (r, w) == (rank, world) and parallel.world_size() == world and parallel.rank() == rank
+    wav, masks, mean, std, seq, params = _problem()
+    lo, hi = parallel.shard_range(len(wav), rank, world)
+    g, loss = _grads(wav[lo:hi], masks[lo:hi], mean, std, seq[lo:hi], params)
+    flat = torch.from_numpy(g)
+    parallel.all_reduce_sum_(flat)
+    flat /= world
+    (mean_loss,) = parallel.all_reduce_mean_scalars([loss])
+    if rank == 0:
+        np.save(out, np.concatenate([flat.numpy(), [mean_loss]]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_gradient_average_equals_global_batch(tmp_path):
+    out = str(tmp_path / "g.npy")
+    mp.spawn(_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    got = np.load(out)
+    wav, masks, mean, std, seq, params = _problem()
+    ref, loss = _grads(wav, masks, mean, std, seq, params)
+    np.testing.assert_allclose(got[:-1], ref, rtol=1e-10, atol=1e-14)
+    assert got[-1] == pytest.approx(loss, rel=1e-12)
+    # identical Adam step from identical averaged gradients
+    p1 = np.concatenate([v.reshape(-1) for _, v in O.flatten_params(params)])
+    p2 = p1.copy()
+    O.adam_tf_step(p1, ref, np.zeros_like(p1), np.zeros_like(p1), 1)
+    O.adam_tf_step(p2, got[:-1], np.zeros_like(p2), np.zeros_like(p2), 1)
+    np.testing.assert_allclose(p1, p2, rtol=0, atol=1e-12)
+
+
+def test_shard_range_partitions_everything():
+    for n in (0, 1, 7, 8, 100):
+        for world in (1, 2, 3, 8):
+            spans = [parallel.shard_range(n, r, world) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+            sizes = [hi - lo for lo, hi in spans]
+            assert max(sizes) - min(sizes) <= 1
+
+
+def test_single_process_helpers_are_noops():
+    t = torch.arange(4.0)
+    assert parallel.world_size() == 1 and parallel.rank() == 0
+    assert torch.equal(parallel.all_reduce_sum_(t.clone()), t)
+    assert parallel.all_reduce_mean_scalars([1.5, 2.5]) == [1.5, 2.5]
