@@ -42,7 +42,7 @@ def infer(model_path, data_path_test, audio_path, out_file_prefix, norm=True, or
         audio_feat_std = np.ones(config['audio_feat_dim'])
 
     print('Building speech inpainting inference model:')
-    model = build_model(config, audio_feat_mean, audio_feat_std)
+    model = build_model(config, audio_feat_mean, audio_feat_std, is_training=False)
     print('Model building done.')
     print('done.\n')
     print('Restore weigths:')

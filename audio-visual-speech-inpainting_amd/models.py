@@ -247,6 +247,9 @@ class StackedBLSTMModel(object):
 
     # ---------------------------------------------------------------- BLSTM + projection (models.py:89-138)
     def _forward(self, keep=False):
+        # a training model keeps the BPTT reserve on its first forward, so fetching the loss and
+        # then train_op (the reference's [loss, ..., train_op] fetch list) runs the network once
+        keep = keep or bool(self.is_training)
         c = self._cache
         if 'pred' in c and (not keep or c.get('kept')):
             return
@@ -300,6 +303,7 @@ class StackedBLSTMModel(object):
 
     # ---------------------------------------------------------------- loss (models.py:140-159)
     def _loss(self, want_grad=False):
+        want_grad = want_grad or bool(self.is_training)
         c = self._cache
         if 'loss3' in c and (not want_grad or c.get('dpred') is not None):
             return

@@ -30,7 +30,7 @@ from .dataset_reader import DataManager, OutOfRangeError
 _INPUT_OF = {'a-blstm': 'a', 'v-blstm': 'v', 'av-blstm': 'av'}
 
 
-def build_model(config, mean, std, variables=None):
+def build_model(config, mean, std, variables=None, is_training=True):
     """Model selection of the drivers (reference training_emb.py:82-92)."""
     kind = config['model']
     if kind not in _INPUT_OF:
@@ -38,7 +38,7 @@ def build_model(config, mean, std, variables=None):
               '(got "{:s}"). Closing...'.format(str(kind)))
         sys.exit(1)
     model = net.StackedBLSTMModel(None, None, None, mean, std, 0.0, config, input=_INPUT_OF[kind],
-                                  variables=variables)
+                                  variables=variables, is_training=is_training)
     model.build_graph(var_scope=kind)
     return model
 
@@ -184,6 +184,7 @@ def train(config_file):
 
         if chief:
             print('Start validation set evaluation...')
+        model.is_training = False          # validation: no BPTT reserve, no gradient stream
         val_it.initializer()
         n_step = 0
         nframe_sum = 0
@@ -206,6 +207,7 @@ def train(config_file):
                 val_avg_loss = (val_avg_loss * prev + loss * frames // feat_dim) / nframe_sum
             if chief and (n_step % 200 == 0 or n_step == 1):
                 print('Step[{:7d}] Loss[{:3.5f}]'.format(n_step, val_avg_loss))
+        model.is_training = True
         (val_avg_loss,) = parallel.all_reduce_mean_scalars([val_avg_loss])
         if chief:
             print('done.')

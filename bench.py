@@ -127,6 +127,8 @@ def main():
     ap.add_argument("--rows-per-wg", type=int, default=0)
     ap.add_argument("--cpu-sample", type=int, default=384, help="utterances timed on the CPU oracle (~15 s)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--mode", choices=["infer", "train"], default="infer",
+                    help="infer = headline workload (configs[1]); train = configs[2]: AV model, fwd + BPTT + Adam")
     args = ap.parse_args()
 
     import torch
@@ -158,15 +160,29 @@ def main():
     std = spec.std(dim=(0, 1), unbiased=False)
     del spec
     seq = np.full(B, T_FRAMES)
-    model = models.StackedBLSTMModel(seq, wav, masks, mean, std, 0.0, cfg, input='a', seed=7)   # same weights on all ranks
+    train = args.mode == "train"
+    video = None
+    if train:
+        gv = torch.Generator(device=device)
+        gv.manual_seed(99 + rank)
+        video = torch.randn(B, T_FRAMES, 136, generator=gv, device=device)
+    model = models.StackedBLSTMModel(seq, wav, masks, mean, std, 0.0, cfg, video_features=video,
+                                     input='av' if train else 'a', seed=7, is_training=train)   # same weights on all ranks
 
     timer = KernelTimer(torch)
     ops.gemm = timer.wrap("gemm_kernel", ops.gemm)
     ops.blstm_rec_fwd = timer.wrap("blstm_rec_fwd_kernel", ops.blstm_rec_fwd)
     ap_mod.frontend = timer.wrap("frontend_kernel", ap_mod.frontend)
+    if train:
+        for name in ("blstm_rec_bwd", "gemm_splitk", "colsum", "adam_tf", "relayout_rows"):
+            setattr(ops, name, timer.wrap(name, getattr(ops, name)))
 
     def step():
-        model.feed(sequence_lengths=seq, target_sources=wav, masks=masks)
+        model.feed(sequence_lengths=seq, target_sources=wav, masks=masks, video_features=video)
+        if train:
+            loss = model.loss_func
+            model.train_op
+            return loss
         _ = model.prediction
         return model.loss_func
 
@@ -190,7 +206,19 @@ def main():
     loss_val = float(loss)
 
     totals = timer.totals()
-    if rank == 0:
+    if rank == 0 and train:
+        line = {"metric": "training utterances/sec (AV 3xBLSTM-250: front end + forward + BPTT + TF-Adam)",
+                "value": B * world * args.steps / elapsed, "unit": "utterances/s", "n_gpus": world,
+                "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+                "config": {"workload": "configs[2]: AV 3xBLSTM-250 training step", "per_gpu_batch": B,
+                           "global_batch": B * world, "parallelism": "dp%d" % world},
+                "loss_func": loss_val,
+                "kernel_ms_per_step": {k: v[0] / args.steps for k, v in totals.items()},
+                "calls_ms_last_step": {k: [round(s_.elapsed_time(e_), 2) for s_, e_ in v[-(len(v) // args.steps):]]
+                                       for k, v in timer.events.items()}}
+        print(json.dumps(line))
+    if rank == 0 and not train:
         gemm_in, rec, proj = algorithmic_flops(B)
         t_rec, n_rec = totals["blstm_rec_fwd_kernel"]
         t_gemm, n_gemm = totals["gemm_kernel"]
