@@ -118,6 +118,24 @@ def cpu_baseline(torch, model, wav, masks, mean, std, sample, cpu_batch):
                       % (sample, cpu_batch, dt)}, rms
 
 
+def profiled_traffic(kernel_key, batch):
+    """HBM bytes per launch from the committed PMC passes (profiles/r*_traffic_b<batch>.json: FETCH_SIZE and
+    WRITE_SIZE collected in separate rocprofv3 --pmc runs of this same command, gfx950 correction
+    applied there).  None when no profile exists for this batch size."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic_b%d.json" % batch)))
+    if not files:
+        return None
+    try:
+        k = json.load(open(files[-1]))["kernels"]
+        for name, v in k.items():
+            if name in kernel_key or kernel_key in name:
+                return v["hbm_bytes_per_launch_avg"]
+    except Exception:
+        return None
+    return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -229,11 +247,11 @@ def main():
         if t_rec >= t_gemm:
             roof = {"kernel": "blstm_rec_fwd_kernel", "bound": "mfma", "achieved": rec_tf,
                     "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": rec_tf / FP32_MFMA_PEAK_TFLOPS,
-                    "traffic": None, "avg_launch_ms": t_rec / n_rec}
+                    "traffic": profiled_traffic("blstm_rec_fwd", B), "avg_launch_ms": t_rec / n_rec}
         else:
             roof = {"kernel": "gemm_kernel", "bound": "mfma", "achieved": gemm_tf,
                     "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": gemm_tf / FP32_MFMA_PEAK_TFLOPS,
-                    "traffic": None, "avg_launch_ms": t_gemm / n_gemm}
+                    "traffic": profiled_traffic("gemm_kernel", B), "avg_launch_ms": t_gemm / n_gemm}
         roof["others"] = {
             "blstm_rec_fwd_kernel": {"TFLOP/s": rec_tf, "ms_per_step": t_rec / args.steps},
             "gemm_kernel": {"TFLOP/s": gemm_tf, "ms_per_step": t_gemm / args.steps},
