@@ -20,3 +20,9 @@ static inline int64_t avsi_round_up(int64_t a, int64_t b) { return avsi_ceil_div
 // MI355X: 256 CUs in 8 XCDs.  Used only to size persistent grids.
 #define AVSI_NUM_CU 256
 #define AVSI_NUM_XCD 8
+
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains the vector-memory
+// counter (s_waitcnt vmcnt(0)), i.e. it waits for every global load AND store the wave still has in
+// flight -- which is exactly the latency the pipelined loops keep in flight on purpose
+// (tools/mfma_f32_lds.hip: 155 -> 56-89 TFLOP/s with four in-flight loads per barrier).
+#define AVSI_LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")

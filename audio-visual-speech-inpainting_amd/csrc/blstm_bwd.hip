@@ -143,7 +143,7 @@ __global__ __launch_bounds__(512, 2) void blstm_rec_bwd_kernel(const BwdArgs a) 
             buf_store(rz, voff_z, rowl * ZROW + 2 * 128, dzf);
             buf_store(rz, voff_z, rowl * ZROW + 3 * 128, dzo);
         }
-        __syncthreads();
+        AVSI_LDS_BARRIER();  // dz visible in LDS; its global stores keep draining under the MFMA phase
         if (s + 1 == T) break;
         // ---- next step's inputs: in flight during the MFMA phase
         load_step(cur, s + 1);
@@ -178,7 +178,7 @@ __global__ __launch_bounds__(512, 2) void blstm_rec_bwd_kernel(const BwdArgs a) 
             dhrec = __builtin_amdgcn_mfma_f32_32x32x2f32(af1.z, bw1.z, dhrec, 0, 0, 0);
             dhrec = __builtin_amdgcn_mfma_f32_32x32x2f32(af1.w, bw1.w, dhrec, 0, 0, 0);
         }
-        __syncthreads();  // every wave is done reading zbuf before the next step overwrites it
+        AVSI_LDS_BARRIER();  // every wave is done reading zbuf before the next step overwrites it
     }
 }
 

@@ -376,18 +376,18 @@ __global__ __launch_bounds__(512, 2) void blstm_rec_fwd_pp_kernel(const RecArgs 
     //   cell tile 0 (step 0) -> load tile 0 (step 1)
     out_rsrc(0, rh, rr);
     pp_phase<1, false, SAVE>(acc, c, hbuf, wb, lane, in_rsrc(T > 1 ? 1 : 0, T > 1), rh, rr, voff_x, voff_h, voff_r, w, li, hi);
-    __syncthreads();
+    AVSI_LDS_BARRIER();
     for (int step = 0; step + 1 < T; ++step) {
         // phase A: MFMA tile 0 (step + 1) || cell tile 1 (step) -> load tile 1 (step + 1)
         out_rsrc(step, rh, rr);
         pp_phase<0, true, SAVE>(acc, c, hbuf, wb, lane, in_rsrc(step + 1, true), rh, rr, voff_x, voff_h, voff_r, w, li, hi);
-        __syncthreads();
+        AVSI_LDS_BARRIER();
         // phase B: MFMA tile 1 (step + 1) || cell tile 0 (step + 1) -> load tile 0 (step + 2)
         const bool more = step + 2 < T;
         out_rsrc(step + 1, rh, rr);
         pp_phase<1, true, SAVE>(acc, c, hbuf, wb, lane, in_rsrc(more ? step + 2 : step + 1, more), rh, rr, voff_x, voff_h, voff_r,
                                 w, li, hi);
-        __syncthreads();
+        AVSI_LDS_BARRIER();
     }
     // epilogue: cell tile 1 (step T - 1)
     out_rsrc(T - 1, rh, rr);

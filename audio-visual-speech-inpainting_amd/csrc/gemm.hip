@@ -26,15 +26,20 @@ namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int BM = 128, BN = 128;
-constexpr int COL_STRIDE = 128 + 4;  // floats, "col" tile [k][x]
-// k-tile depth BK (16 or 32): "row" tile [x][k] has stride BK + 4 floats (conflict-free b128 reads)
-template <int BK> struct Tile {
+constexpr int BN = 128;
+// Operand tile of X rows/cols (128 or 256) by BK (16 or 32) reduction steps.
+//   "row" tile [x][k]: k contiguous, stride BK + 4 floats (conflict-free ds_read_b128)
+//   "col" tile [k][x]: x contiguous, stride X + 4 floats (lanes along x, ds_read_b32)
+template <int BK, int X> struct Tile {
     static constexpr int ROW_STRIDE = BK + 4;
-    static constexpr int ROW_TILE = 128 * ROW_STRIDE;
+    static constexpr int COL_STRIDE = X + 4;
+    static constexpr int ROW_TILE = X * ROW_STRIDE;
     static constexpr int COL_TILE = BK * COL_STRIDE;
-    static constexpr int NLD = BK / 8;  // float4 loads per thread per operand tile
+    static constexpr int NLD = X * BK / 4 / 256;  // float4 loads per thread per operand tile
 };
+
+template <int BK, int X> using RegTile = float4[Tile<BK, X>::NLD];  // one thread's share of an operand tile
+template <int BK, int X> using OffTile = int[Tile<BK, X>::NLD];     // and its float4 offsets from the tile origin
 
 struct GemmArgs {
     const float* A;
@@ -52,20 +57,22 @@ struct GemmArgs {
 };
 
 // Global -> registers for one operand tile.  ROWK: memory is [x][k] (k contiguous), else [k][x].
-template <bool ROWK, int BK>
-__device__ __forceinline__ void load_tile(float4 (&r)[Tile<BK>::NLD], const float* __restrict__ base, int64_t ld, int x0,
-                                          int k0, int X, int Kend, int tid) {
+template <bool ROWK, int BK, int XT>
+__device__ __forceinline__ void load_tile(RegTile<BK, XT>& r, const float* __restrict__ base, int64_t ld, int x0, int k0,
+                                          int X, int Kend, int tid) {
     constexpr int KQ = BK / 4;           // float4 per row of a "row" tile
     constexpr int RPP = 256 / KQ;        // rows covered per pass
+    constexpr int XQ = XT / 4;           // float4 per k-row of a "col" tile
+    constexpr int KPP = 256 / XQ;        // k-rows covered per pass
 #pragma unroll
-    for (int p = 0; p < Tile<BK>::NLD; ++p) {
+    for (int p = 0; p < Tile<BK, XT>::NLD; ++p) {
         int x, k;
         if (ROWK) {
             x = x0 + p * RPP + tid / KQ;
             k = k0 + 4 * (tid % KQ);
         } else {
-            k = k0 + p * 8 + (tid >> 5);
-            x = x0 + 4 * (tid & 31);
+            k = k0 + p * KPP + tid / XQ;
+            x = x0 + 4 * (tid % XQ);
         }
         float4 v = {0.f, 0.f, 0.f, 0.f};
         if (ROWK) {
@@ -77,53 +84,94 @@ __device__ __forceinline__ void load_tile(float4 (&r)[Tile<BK>::NLD], const floa
     }
 }
 
-template <bool ROWK, int BK>
-__device__ __forceinline__ void store_tile(float* __restrict__ s, const float4 (&r)[Tile<BK>::NLD], int tid) {
-    constexpr int KQ = BK / 4, RPP = 256 / KQ;
+// Interior fast path.  The per-thread part of every tile address is the same for all k-tiles, so
+// it is computed ONCE (float4 index relative to the tile origin, rows clamped into the matrix so
+// no guard is needed: out-of-range rows only feed outputs that are never stored); per k-tile the
+// tile origin is one wave-uniform pointer, made opaque so each load is
+// "global_load_dwordx4 v, v_off, s[base]" with no per-load VALU address math and no exec branches
+// (those cost ~10 % of the MFMA rate in the guarded path: 131 -> 145 TFLOP/s at K = 4096).
+typedef float v4f __attribute__((ext_vector_type(4)));
+typedef const __attribute__((address_space(1))) v4f* gptr4;
+__device__ __forceinline__ gptr4 opaque_base(const float* p) {
+    gptr4 g = (gptr4)(const void*)p;
+    asm volatile("" : "+s"(g));
+    return g;
+}
+
+template <bool ROWK, int BK, int XT>
+__device__ __forceinline__ void tile_offsets(OffTile<BK, XT>& off, int64_t ld, int x0, int X, int tid) {
+    constexpr int KQ = BK / 4, RPP = 256 / KQ, XQ = XT / 4, KPP = 256 / XQ;
 #pragma unroll
-    for (int p = 0; p < Tile<BK>::NLD; ++p) {
-        if (ROWK)
-            *reinterpret_cast<float4*>(s + (p * RPP + tid / KQ) * Tile<BK>::ROW_STRIDE + 4 * (tid % KQ)) = r[p];
-        else
-            *reinterpret_cast<float4*>(s + (p * 8 + (tid >> 5)) * COL_STRIDE + 4 * (tid & 31)) = r[p];
+    for (int p = 0; p < Tile<BK, XT>::NLD; ++p) {
+        if (ROWK) {
+            const int x = min(x0 + p * RPP + tid / KQ, X - 1) - x0;            // row, clamped into the matrix
+            off[p] = (int)((x * ld) >> 2) + (tid % KQ);
+        } else {
+            const int xq = min(x0 + 4 * (tid % XQ), ((X + 3) & ~3) - 4) - x0;   // column group, clamped into the padded row
+            off[p] = (int)(((p * KPP + tid / XQ) * ld + xq) >> 2);
+        }
     }
 }
 
-// LDS -> registers: the A and B fragments of one 8-wide k group (4 MFMA k-steps).
-template <bool TA, bool TB, int BK>
-__device__ __forceinline__ void read_frags(float (&af)[2][4], float (&bf)[2][4], const float* __restrict__ a_s,
-                                           const float* __restrict__ b_s, int q, int wm, int wn, int li, int hi) {
+template <int NLD>
+__device__ __forceinline__ void load_tile_fast(float4 (&r)[NLD], const float* origin, const int (&off)[NLD]) {
+    const gptr4 b = opaque_base(origin);
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int row = wm * 64 + i * 32 + li;
+    for (int p = 0; p < NLD; ++p) {
+        const v4f v = b[off[p]];
+        r[p] = make_float4(v.x, v.y, v.z, v.w);
+    }
+}
+
+template <bool ROWK, int BK, int XT>
+__device__ __forceinline__ void store_tile(float* __restrict__ s, const RegTile<BK, XT>& r, int tid) {
+    constexpr int KQ = BK / 4, RPP = 256 / KQ, XQ = XT / 4, KPP = 256 / XQ;
+#pragma unroll
+    for (int p = 0; p < Tile<BK, XT>::NLD; ++p) {
+        if (ROWK)
+            *reinterpret_cast<float4*>(s + (p * RPP + tid / KQ) * Tile<BK, XT>::ROW_STRIDE + 4 * (tid % KQ)) = r[p];
+        else
+            *reinterpret_cast<float4*>(s + (p * KPP + tid / XQ) * Tile<BK, XT>::COL_STRIDE + 4 * (tid % XQ)) = r[p];
+    }
+}
+
+// LDS -> registers: the A (MI row tiles) and B (2 column tiles) fragments of one 8-wide k group.
+template <bool TA, bool TB, int BK, int MI>
+__device__ __forceinline__ void read_frags(float (&af)[MI][4], float (&bf)[2][4], const float* __restrict__ a_s,
+                                           const float* __restrict__ b_s, int q, int wm, int wn, int li, int hi) {
+    constexpr int BMT = 64 * MI;
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+        const int row = wm * (32 * MI) + i * 32 + li;
         if (!TA) {
-            const float4 v = *reinterpret_cast<const float4*>(a_s + row * Tile<BK>::ROW_STRIDE + 8 * q + 4 * hi);
+            const float4 v = *reinterpret_cast<const float4*>(a_s + row * Tile<BK, BMT>::ROW_STRIDE + 8 * q + 4 * hi);
             af[i][0] = v.x, af[i][1] = v.y, af[i][2] = v.z, af[i][3] = v.w;
         } else {
 #pragma unroll
-            for (int s = 0; s < 4; ++s) af[i][s] = a_s[(8 * q + 4 * hi + s) * COL_STRIDE + row];
+            for (int s = 0; s < 4; ++s) af[i][s] = a_s[(8 * q + 4 * hi + s) * Tile<BK, BMT>::COL_STRIDE + row];
         }
     }
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         const int col = wn * 64 + j * 32 + li;
         if (TB) {
-            const float4 v = *reinterpret_cast<const float4*>(b_s + col * Tile<BK>::ROW_STRIDE + 8 * q + 4 * hi);
+            const float4 v = *reinterpret_cast<const float4*>(b_s + col * Tile<BK, BN>::ROW_STRIDE + 8 * q + 4 * hi);
             bf[j][0] = v.x, bf[j][1] = v.y, bf[j][2] = v.z, bf[j][3] = v.w;
         } else {
 #pragma unroll
-            for (int s = 0; s < 4; ++s) bf[j][s] = b_s[(8 * q + 4 * hi + s) * COL_STRIDE + col];
+            for (int s = 0; s < 4; ++s) bf[j][s] = b_s[(8 * q + 4 * hi + s) * Tile<BK, BN>::COL_STRIDE + col];
         }
     }
 }
 
 // TA: A is stored [K][M] (op(A) = A^T).  TB: B is stored [N][K] (op(B) = B^T).
-template <bool TA, bool TB, int BK>
-__global__ __launch_bounds__(256, BK == 16 ? 4 : 2) void gemm_kernel(const GemmArgs g) {
+// MI = 32-row MFMA tiles per wave along M: block tile (64 MI) x 128, wave tile (32 MI) x 64.
+template <bool TA, bool TB, int BK, int MI>
+__global__ __launch_bounds__(256, (BK == 16 && MI == 2) ? 4 : 2) void gemm_kernel(const GemmArgs g) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int A_TILE = TA ? Tile<BK>::COL_TILE : Tile<BK>::ROW_TILE;
-    constexpr int B_TILE = TB ? Tile<BK>::ROW_TILE : Tile<BK>::COL_TILE;
-    constexpr int NLD = Tile<BK>::NLD;
+    constexpr int BM = 64 * MI;
+    constexpr int A_TILE = TA ? Tile<BK, BM>::COL_TILE : Tile<BK, BM>::ROW_TILE;
+    constexpr int B_TILE = TB ? Tile<BK, BN>::ROW_TILE : Tile<BK, BN>::COL_TILE;
     float* sA = reinterpret_cast<float*>(smem);
     float* sB = sA + 2 * A_TILE;
 
@@ -147,9 +195,9 @@ __global__ __launch_bounds__(256, BK == 16 ? 4 : 2) void gemm_kernel(const GemmA
     const int nk = (kend - kbeg + BK - 1) / BK;
     float* __restrict__ C = g.C + (int64_t)blockIdx.z * g.c_split_stride;
 
-    f32x16 acc[2][2];
+    f32x16 acc[MI][2];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < MI; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -161,14 +209,23 @@ __global__ __launch_bounds__(256, BK == 16 ? 4 : 2) void gemm_kernel(const GemmA
     // so the global loads get a full k-tile of latency budget, the LDS writes sit in the shadow of the
     // MFMAs, and the end of a k-tile is a bare barrier (no vmcnt wait, no LDS write) -- the exposed
     // "wait, write, barrier" tail of the classic double-buffer loop cost ~15 % here.
-    float4 ra[NLD], rb[NLD];
-    load_tile<!TA, BK>(ra, g.A, g.lda, m0, kbeg, g.M, kend, tid);
-    load_tile<TB, BK>(rb, g.B, g.ldb, n0, kbeg, g.N, kend, tid);
-    store_tile<!TA, BK>(sA, ra, tid);
-    store_tile<TB, BK>(sB, rb, tid);
+    RegTile<BK, BM> ra;
+    RegTile<BK, BN> rb;
+    OffTile<BK, BM> offa;
+    OffTile<BK, BN> offb;
+    tile_offsets<!TA, BK, BM>(offa, g.lda, m0, g.M, tid);
+    tile_offsets<TB, BK, BN>(offb, g.ldb, n0, g.N, tid);
+    // tile origins: "row" tiles advance by BK columns per k-tile, "col" tiles by BK rows
+    const float* a_org = TA ? g.A + (int64_t)kbeg * g.lda + m0 : g.A + (int64_t)m0 * g.lda + kbeg;
+    const float* b_org = TB ? g.B + (int64_t)n0 * g.ldb + kbeg : g.B + (int64_t)kbeg * g.ldb + n0;
+    const int64_t a_step = TA ? (int64_t)BK * g.lda : BK, b_step = TB ? BK : (int64_t)BK * g.ldb;
+    load_tile<!TA, BK, BM>(ra, g.A, g.lda, m0, kbeg, g.M, kend, tid);
+    load_tile<TB, BK, BN>(rb, g.B, g.ldb, n0, kbeg, g.N, kend, tid);
+    store_tile<!TA, BK, BM>(sA, ra, tid);
+    store_tile<TB, BK, BN>(sB, rb, tid);
     if (nk > 1) {
-        load_tile<!TA, BK>(ra, g.A, g.lda, m0, kbeg + BK, g.M, kend, tid);
-        load_tile<TB, BK>(rb, g.B, g.ldb, n0, kbeg + BK, g.N, kend, tid);
+        load_tile<!TA, BK, BM>(ra, g.A, g.lda, m0, kbeg + BK, g.M, kend, tid);
+        load_tile<TB, BK, BN>(rb, g.B, g.ldb, n0, kbeg + BK, g.N, kend, tid);
     }
     __syncthreads();
 
@@ -177,32 +234,38 @@ __global__ __launch_bounds__(256, BK == 16 ? 4 : 2) void gemm_kernel(const GemmA
         const float* a_s = sA + cur * A_TILE;
         const float* b_s = sB + cur * B_TILE;
         // fragment reads run one 8-wide k group AHEAD of the MFMAs that consume them
-        float af[2][2][4], bf[2][2][4];
-        read_frags<TA, TB, BK>(af[0], bf[0], a_s, b_s, 0, wm, wn, li, hi);
+        float af[2][MI][4], bf[2][2][4];
+        read_frags<TA, TB, BK, MI>(af[0], bf[0], a_s, b_s, 0, wm, wn, li, hi);
 #pragma unroll
         for (int q = 0; q < BK / 8; ++q) {
             const int cq = q & 1;
-            if (q + 1 < BK / 8) read_frags<TA, TB, BK>(af[cq ^ 1], bf[cq ^ 1], a_s, b_s, q + 1, wm, wn, li, hi);
+            if (q + 1 < BK / 8) read_frags<TA, TB, BK, MI>(af[cq ^ 1], bf[cq ^ 1], a_s, b_s, q + 1, wm, wn, li, hi);
             __builtin_amdgcn_sched_barrier(0);  // keep the look-ahead reads ABOVE this group's MFMAs
 #pragma unroll
             for (int s = 0; s < 4; ++s)
 #pragma unroll
-                for (int i = 0; i < 2; ++i)
+                for (int i = 0; i < MI; ++i)
 #pragma unroll
                     for (int j = 0; j < 2; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[cq][i][s], bf[cq][j][s], acc[i][j], 0, 0, 0);
             if (q == 0) {
                 if (kt + 1 < nk) {
-                    store_tile<!TA, BK>(sA + (cur ^ 1) * A_TILE, ra, tid);
-                    store_tile<TB, BK>(sB + (cur ^ 1) * B_TILE, rb, tid);
+                    store_tile<!TA, BK, BM>(sA + (cur ^ 1) * A_TILE, ra, tid);
+                    store_tile<TB, BK, BN>(sB + (cur ^ 1) * B_TILE, rb, tid);
                 }
                 if (kt + 2 < nk) {
-                    load_tile<!TA, BK>(ra, g.A, g.lda, m0, kbeg + (kt + 2) * BK, g.M, kend, tid);
-                    load_tile<TB, BK>(rb, g.B, g.ldb, n0, kbeg + (kt + 2) * BK, g.N, kend, tid);
+                    const int k2 = kbeg + (kt + 2) * BK;
+                    if (k2 + BK <= kend) {      // full k-tile: unguarded fast path
+                        load_tile_fast(ra, a_org + (kt + 2) * a_step, offa);
+                        load_tile_fast(rb, b_org + (kt + 2) * b_step, offb);
+                    } else {                    // ragged last k-tile: guarded, zero-filled
+                        load_tile<!TA, BK, BM>(ra, g.A, g.lda, m0, k2, g.M, kend, tid);
+                        load_tile<TB, BK, BN>(rb, g.B, g.ldb, n0, k2, g.N, kend, tid);
+                    }
                 }
             }
         }
-        __syncthreads();
+        AVSI_LDS_BARRIER();  // LDS visibility only: the tile-(kt+2) global loads stay in flight across it
     }
 
     // epilogue: C/D layout of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
@@ -214,10 +277,10 @@ __global__ __launch_bounds__(256, BK == 16 ? 4 : 2) void gemm_kernel(const GemmA
         bv[j] = (g.bias && col < g.N) ? g.bias[col] : 0.f;
     }
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < MI; ++i) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const int row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+            const int row = m0 + wm * (32 * MI) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
             if (row >= g.M) continue;
             int64_t orow = row;
             if (g.row_map_bp > 0) {  // time-major (t, b) -> batch-major (b, t), padded batch rows dropped
@@ -239,16 +302,25 @@ __global__ __launch_bounds__(256, BK == 16 ? 4 : 2) void gemm_kernel(const GemmA
     }
 }
 
-template <bool TA, bool TB, int BK>
+template <bool TA, bool TB, int BK, int MI>
 int launch(const GemmArgs& g, int splits, hipStream_t st) {
-    constexpr size_t lds = (size_t)2 * ((TA ? Tile<BK>::COL_TILE : Tile<BK>::ROW_TILE) +
-                                        (TB ? Tile<BK>::ROW_TILE : Tile<BK>::COL_TILE)) * 4;
-    static_assert(lds <= (BK == 16 ? 40 : 80) * 1024, "4 (BK=16) / 2 (BK=32) workgroups must fit one CU's 160 KiB LDS");
+    constexpr int BM = 64 * MI;
+    constexpr size_t lds = (size_t)2 * ((TA ? Tile<BK, BM>::COL_TILE : Tile<BK, BM>::ROW_TILE) +
+                                        (TB ? Tile<BK, BN>::ROW_TILE : Tile<BK, BN>::COL_TILE)) * 4;
+    static_assert(lds <= ((BK == 16 && MI == 2) ? 40 : 80) * 1024, "workgroups per CU must fit the 160 KiB LDS");
     if (lds > 64 * 1024)
-        (void)hipFuncSetAttribute((const void*)gemm_kernel<TA, TB, BK>, hipFuncAttributeMaxDynamicSharedMemorySize,
+        (void)hipFuncSetAttribute((const void*)gemm_kernel<TA, TB, BK, MI>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                   (int)lds);
-    hipLaunchKernelGGL((gemm_kernel<TA, TB, BK>), dim3(g.m_blocks * g.n_blocks, 1, splits), dim3(256), lds, st, g);
+    hipLaunchKernelGGL((gemm_kernel<TA, TB, BK, MI>), dim3(g.m_blocks * g.n_blocks, 1, splits), dim3(256), lds, st, g);
     return avsi_launch_status();
+}
+
+template <int BK, int MI>
+int dispatch(const GemmArgs& g, int transA, int transB, int splits, hipStream_t st) {
+    if (!transA && !transB) return launch<false, false, BK, MI>(g, splits, st);
+    if (!transA && transB) return launch<false, true, BK, MI>(g, splits, st);
+    if (transA && !transB) return launch<true, false, BK, MI>(g, splits, st);
+    return launch<true, true, BK, MI>(g, splits, st);
 }
 
 }  // namespace
@@ -277,6 +349,12 @@ int avsi_gemm_launch(int transA, int transB, int M, int N, int K, float alpha, c
     g.M = M, g.N = N, g.K = K;
     g.lda = lda, g.ldb = ldb, g.ldc = ldc;
     g.alpha = alpha, g.beta = beta;
+    // tuning overrides (diagnostic): AVSI_GEMM_BK = 16 | 32, AVSI_GEMM_MI = 2 | 4
+    const char* env_bk = getenv("AVSI_GEMM_BK");
+    const char* env_mi = getenv("AVSI_GEMM_MI");
+    const int bk = env_bk ? atoi(env_bk) : (transB ? 32 : 16);
+    const int mi = env_mi ? atoi(env_mi) : 2;
+    const int BM = 64 * mi;
     g.m_blocks = (int)avsi_ceil_div(M, BM);
     g.n_blocks = (int)avsi_ceil_div(N, BN);
     g.k_split_len = (int)avsi_round_up(avsi_ceil_div(K, splits), 32);
@@ -285,20 +363,8 @@ int avsi_gemm_launch(int transA, int transB, int M, int N, int K, float alpha, c
     // "col" tiles read 4 consecutive x per lane and guard on the first: the ld padding up to a
     // multiple of 4 (checked above) keeps the tail addressable; such lanes feed unstored outputs.
     avsi_clear_error();
-    // k-tile depth: 16 (4 workgroups per CU) wins whenever B is a "col" tile -- measured 125 vs 116
-    // TFLOP/s at K = 512 and 112 vs 93 at K = 264 -- while B^T operands prefer 32 (127 vs 117).
-    const char* env = getenv("AVSI_GEMM_BK");   // tuning override (diagnostic): 16 or 32
-    const int bk = env ? atoi(env) : (transB ? 32 : 16);
-    if (bk == 16) {
-        if (!transA && !transB) return launch<false, false, 16>(g, splits, st);
-        if (!transA && transB) return launch<false, true, 16>(g, splits, st);
-        if (transA && !transB) return launch<true, false, 16>(g, splits, st);
-        return launch<true, true, 16>(g, splits, st);
-    }
-    if (!transA && !transB) return launch<false, false, 32>(g, splits, st);
-    if (!transA && transB) return launch<false, true, 32>(g, splits, st);
-    if (transA && !transB) return launch<true, false, 32>(g, splits, st);
-    return launch<true, true, 32>(g, splits, st);
+    if (mi == 4) return dispatch<16, 4>(g, transA, transB, splits, st);   // 256 x 128 tiles exist with BK = 16 only (LDS)
+    return bk == 16 ? dispatch<16, 2>(g, transA, transB, splits, st) : dispatch<32, 2>(g, transA, transB, splits, st);
 }
 
 extern "C" int avsi_gemm_f32(int transA, int transB, int M, int N, int K, float alpha, const float* A, int64_t lda,
