@@ -75,28 +75,40 @@ __global__ __launch_bounds__(TPB) void frontend_kernel(const avsi_frontend_args 
         const float2 w = *reinterpret_cast<const float2*>(tab + TAB_TW256 + 2 * ((ln * k2) & 255));
         tw[k2] = {w.x, w.y};
     }
-    // ---- per-bin constants of the epilogue (thread <-> bin k = tid)
-    const int k = tid;
-    const float2 wk = *reinterpret_cast<const float2*>(tab + TAB_TW512 + 2 * k);
+    // ---- epilogue mapping: thread <-> 4 consecutive bins (kq) x 4 frames (its wave's quarter of the
+    //      tile): per-bin twiddle / mean / 1/std stay in registers, every global access is 16 B per lane
+    const int kq = tid & 63, fg = tid >> 6;
+    const int k0 = 4 * kq;
     const bool have_norm = a.mean != nullptr;
-    const float mean_k = (have_norm && k < F) ? a.mean[k] : 0.f;
-    const float std_k = (have_norm && k < F) ? a.stdev[k] : 1.f;
+    float wkr[4], wki[4], mean_k[4], istd_k[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const float2 w = *reinterpret_cast<const float2*>(tab + TAB_TW512 + 2 * (k0 + j));
+        wkr[j] = w.x, wki[j] = w.y;
+        mean_k[j] = (have_norm && k0 + j < F) ? a.mean[k0 + j] : 0.f;
+        istd_k[j] = (have_norm && k0 + j < F) ? 1.f / a.stdev[k0 + j] : 1.f;
+    }
     const float mean_n = (have_norm && F > 256) ? a.mean[256] : 0.f;  // Nyquist bin
-    const float std_n = (have_norm && F > 256) ? a.stdev[256] : 1.f;
+    const float istd_n = (have_norm && F > 256) ? 1.f / a.stdev[256] : 1.f;
     const bool want_pow = a.out_logmel != nullptr;
+    const bool full4 = k0 + 3 < F;  // all four bins of this thread are inside the requested slice
 
-    for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
-        const int b = tile / tiles_per_utt;
-        const int t0 = (tile - b * tiles_per_utt) * FR;
-
-        // ---- 1. stage the tile's samples: HBM -> LDS, 16 B per lane, zero past the signal end
-        {
-            const int64_t s0 = (int64_t)t0 * S;
-            const float* src = a.wav + (int64_t)b * a.wav_stride + s0;
-            const int valid = (int)max((int64_t)0, min((int64_t)seg_floats, (int64_t)N - s0));
-            const bool vec = ((reinterpret_cast<uintptr_t>(src) & 15) == 0);
-            for (int i = tid * 4; i < seg_floats; i += TPB * 4) {
-                float4 v;
+    // Software pipeline over tiles: the NEXT tile's samples are fetched into registers while the
+    // current tile is transformed, and the current tile's mask values are fetched before the FFT and
+    // consumed after it, so neither HBM latency sits on the critical path of a tile.
+    constexpr int WR = 8;  // float4 staging registers per thread (covers hop <= 512)
+    float4 wreg[WR];
+    auto fetch_wav = [&](int tl) {
+        const int bb = tl / tiles_per_utt;
+        const int64_t s0 = (int64_t)(tl - bb * tiles_per_utt) * FR * S;
+        const float* src = a.wav + (int64_t)bb * a.wav_stride + s0;
+        const int valid = (int)max((int64_t)0, min((int64_t)seg_floats, (int64_t)N - s0));
+        const bool vec = ((reinterpret_cast<uintptr_t>(src) & 15) == 0);
+#pragma unroll
+        for (int p = 0; p < WR; ++p) {
+            const int i = (p * TPB + tid) * 4;
+            float4 v = {0.f, 0.f, 0.f, 0.f};
+            if (i < seg_floats) {
                 if (vec && i + 3 < valid) {
                     v = *reinterpret_cast<const float4*>(src + i);
                 } else {
@@ -105,10 +117,37 @@ __global__ __launch_bounds__(TPB) void frontend_kernel(const avsi_frontend_args 
                     v.z = i + 2 < valid ? src[i + 2] : 0.f;
                     v.w = i + 3 < valid ? src[i + 3] : 0.f;
                 }
-                *reinterpret_cast<float4*>(s_wav + i) = v;
             }
+            wreg[p] = v;
+        }
+    };
+    if (blockIdx.x < n_tiles) fetch_wav(blockIdx.x);
+
+    for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const int b = tile / tiles_per_utt;
+        const int t0 = (tile - b * tiles_per_utt) * FR;
+
+        // ---- 1. staged samples: registers -> LDS (zero past the signal end), then refill the registers
+#pragma unroll
+        for (int p = 0; p < WR; ++p) {
+            const int i = (p * TPB + tid) * 4;
+            if (i < seg_floats) *reinterpret_cast<float4*>(s_wav + i) = wreg[p];
         }
         __syncthreads();
+        if (tile + (int)gridDim.x < n_tiles) fetch_wav(tile + gridDim.x);
+        float mk[4][4];
+#pragma unroll
+        for (int fi = 0; fi < 4; ++fi) {
+            const int t = t0 + fg * 4 + fi;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) mk[fi][j] = 1.f;
+            if (a.out_feat && a.mask && t < T) {
+                const float* mp = a.mask + (int64_t)b * a.mask_stride_b + (int64_t)t * a.mask_stride_t + k0;
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (k0 + j < F) mk[fi][j] = mp[j];
+            }
+        }
 
         // ---- 2. window + first 16-point FFT (over n2, with n = ln + 16 n2) + twiddle
         cf v[16];
@@ -129,50 +168,73 @@ __global__ __launch_bounds__(TPB) void frontend_kernel(const avsi_frontend_args 
         zf[ln] = v[pos16(0)];
 #pragma unroll
         for (int k2 = 1; k2 < 16; ++k2) zf[k2 * 17 + ln] = cmul(v[pos16(k2)], tw[k2]);
-        __syncthreads();
-
-        // ---- 3. transposition: lane k2 = ln gathers its 16 n1 values
+        // ---- 3. transposition: lane k2 = ln gathers its 16 n1 values.  A frame lives in ONE wave
+        //         (16 consecutive lanes) and a wave's LDS accesses execute in order, so no
+        //         workgroup barrier is needed here -- only the compiler must not reorder.
+        asm volatile("" ::: "memory");
 #pragma unroll
         for (int n1 = 0; n1 < 16; ++n1) v[n1] = zf[ln * 17 + n1];
-        __syncthreads();
+        asm volatile("" ::: "memory");
 
-        // ---- 4. second 16-point FFT (over n1): Z[16 k1 + ln], stored in natural order
+        // ---- 4. second 16-point FFT (over n1): Z[16 k1 + ln], natural order; Z[256] := Z[0]
         fft16(v);
 #pragma unroll
         for (int k1 = 0; k1 < 16; ++k1) zf[16 * k1 + ln] = v[pos16(k1)];
+        if (ln == 0) zf[256] = v[pos16(0)];
         __syncthreads();
 
-        // ---- 5. epilogue, thread <-> bin k: X[k] = E[k] + W512^k O[k]
-        //         E = (Z[k] + conj Z[256-k]) / 2,  O = -j (Z[k] - conj Z[256-k]) / 2
-        const int km = (256 - k) & 255;
-#pragma unroll 4
-        for (int ff = 0; ff < FR; ++ff) {
+        // ---- 5. epilogue: X[k] = E[k] + W512^k O[k],  E = (Z[k] + conj Z[256-k]) / 2,
+        //         O = -j (Z[k] - conj Z[256-k]) / 2
+#pragma unroll
+        for (int fi = 0; fi < 4; ++fi) {
+            const int ff = fg * 4 + fi;
             const int t = t0 + ff;
-            if (t >= T) break;
-            const cf zk = s_z[ff * ZSTRIDE + k], zm = s_z[ff * ZSTRIDE + km];
-            const cf e{0.5f * (zk.r + zm.r), 0.5f * (zk.i - zm.i)};
-            const cf o{0.5f * (zk.i + zm.i), -0.5f * (zk.r - zm.r)};
-            const cf wo = cmul(o, {wk.x, wk.y});
-            const cf x{e.r + wo.r, e.i + wo.i};
-            const float p2 = x.r * x.r + x.i * x.i;
-            if (want_pow) s_pow[ff * PSTRIDE + k] = p2;
-            if (k < F) {
-                if (a.out_stft) {
-                    float* o2 = a.out_stft + (int64_t)b * a.stft_stride_b + (int64_t)t * a.stft_stride_t + 2 * k;
-                    o2[0] = x.r;
-                    o2[1] = x.i;
+            if (t >= T) continue;
+            const cf* zrow = s_z + ff * ZSTRIDE;
+            float xr[4], xi[4], p2[4], sp[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const cf zk = zrow[k0 + j], zm = zrow[256 - k0 - j];
+                const cf e{0.5f * (zk.r + zm.r), 0.5f * (zk.i - zm.i)};
+                const cf o{0.5f * (zk.i + zm.i), -0.5f * (zk.r - zm.r)};
+                xr[j] = e.r + (o.r * wkr[j] - o.i * wki[j]);
+                xi[j] = e.i + (o.r * wki[j] + o.i * wkr[j]);
+                p2[j] = xr[j] * xr[j] + xi[j] * xi[j];
+                float sv = __builtin_amdgcn_sqrtf(p2[j]);
+                if (a.spec_power != 1.f) sv = (a.spec_power == 2.f) ? sv * sv : __powf(sv, a.spec_power);
+                if (a.log_spec) sv = __logf(sv + a.eps);
+                sp[j] = (sv - mean_k[j]) * istd_k[j];
+            }
+            if (want_pow) *reinterpret_cast<float4*>(s_pow + ff * PSTRIDE + k0) = make_float4(p2[0], p2[1], p2[2], p2[3]);
+            if (a.out_stft) {
+                float* o2 = a.out_stft + (int64_t)b * a.stft_stride_b + (int64_t)t * a.stft_stride_t + 2 * k0;
+                if (full4) {
+                    reinterpret_cast<float4*>(o2)[0] = make_float4(xr[0], xi[0], xr[1], xi[1]);
+                    reinterpret_cast<float4*>(o2)[1] = make_float4(xr[2], xi[2], xr[3], xi[3]);
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        if (k0 + j < F) o2[2 * j] = xr[j], o2[2 * j + 1] = xi[j];
                 }
-                if (a.out_spec || a.out_feat) {
-                    float s = __builtin_amdgcn_sqrtf(p2);
-                    if (a.spec_power != 1.f) s = (a.spec_power == 2.f) ? s * s : __powf(s, a.spec_power);
-                    if (a.log_spec) s = __logf(s + a.eps);
-                    if (have_norm) s = (s - mean_k) / std_k;
-                    if (a.out_spec) a.out_spec[(int64_t)b * a.spec_stride_b + (int64_t)t * a.spec_stride_t + k] = s;
-                    if (a.out_feat) {
-                        const float m =
-                            a.mask ? a.mask[(int64_t)b * a.mask_stride_b + (int64_t)t * a.mask_stride_t + k] : 1.f;
-                        a.out_feat[(int64_t)b * a.feat_stride_b + (int64_t)t * a.feat_stride_t + k] = s * m;
-                    }
+            }
+            if (a.out_spec) {
+                float* o1 = a.out_spec + (int64_t)b * a.spec_stride_b + (int64_t)t * a.spec_stride_t + k0;
+                if (full4) {
+                    *reinterpret_cast<float4*>(o1) = make_float4(sp[0], sp[1], sp[2], sp[3]);
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        if (k0 + j < F) o1[j] = sp[j];
+                }
+            }
+            if (a.out_feat) {
+                float* o1 = a.out_feat + (int64_t)b * a.feat_stride_b + (int64_t)t * a.feat_stride_t + k0;
+                if (full4) {
+                    *reinterpret_cast<float4*>(o1) = make_float4(sp[0] * mk[fi][0], sp[1] * mk[fi][1], sp[2] * mk[fi][2], sp[3] * mk[fi][3]);
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        if (k0 + j < F) o1[j] = sp[j] * mk[fi][j];
                 }
             }
         }
@@ -180,24 +242,24 @@ __global__ __launch_bounds__(TPB) void frontend_kernel(const avsi_frontend_args 
         if (tid < FR && t0 + tid < T) {
             const int t = t0 + tid;
             const cf z0 = s_z[tid * ZSTRIDE];
-            const float xr = z0.r - z0.i;  // X[256] = Re Z[0] - Im Z[0], purely real
-            if (want_pow) s_pow[tid * PSTRIDE + 256] = xr * xr;
+            const float xn = z0.r - z0.i;  // X[256] = Re Z[0] - Im Z[0], purely real
+            if (want_pow) s_pow[tid * PSTRIDE + 256] = xn * xn;
             if (F > 256) {
                 if (a.out_stft) {
                     float* o2 = a.out_stft + (int64_t)b * a.stft_stride_b + (int64_t)t * a.stft_stride_t + 512;
-                    o2[0] = xr;
+                    o2[0] = xn;
                     o2[1] = 0.f;
                 }
                 if (a.out_spec || a.out_feat) {
-                    float s = fabsf(xr);
-                    if (a.spec_power != 1.f) s = (a.spec_power == 2.f) ? s * s : __powf(s, a.spec_power);
-                    if (a.log_spec) s = __logf(s + a.eps);
-                    if (have_norm) s = (s - mean_n) / std_n;
-                    if (a.out_spec) a.out_spec[(int64_t)b * a.spec_stride_b + (int64_t)t * a.spec_stride_t + 256] = s;
+                    float sv = fabsf(xn);
+                    if (a.spec_power != 1.f) sv = (a.spec_power == 2.f) ? sv * sv : __powf(sv, a.spec_power);
+                    if (a.log_spec) sv = __logf(sv + a.eps);
+                    sv = (sv - mean_n) * istd_n;
+                    if (a.out_spec) a.out_spec[(int64_t)b * a.spec_stride_b + (int64_t)t * a.spec_stride_t + 256] = sv;
                     if (a.out_feat) {
                         const float m =
                             a.mask ? a.mask[(int64_t)b * a.mask_stride_b + (int64_t)t * a.mask_stride_t + 256] : 1.f;
-                        a.out_feat[(int64_t)b * a.feat_stride_b + (int64_t)t * a.feat_stride_t + 256] = s * m;
+                        a.out_feat[(int64_t)b * a.feat_stride_b + (int64_t)t * a.feat_stride_t + 256] = sv * m;
                     }
                 }
             }
@@ -262,7 +324,7 @@ extern "C" int avsi_frontend_f32(const avsi_frontend_args* args, void* stream) {
     const int nb = nb_need <= 8 ? 8 : (nb_need <= 12 ? 12 : 16);  // template instance actually launched
     const int seg = (int)avsi_round_up((int64_t)(FR - 1) * a.hop + 32 * nb, 4);
     const size_t lds = (size_t)seg * 4 + (size_t)FR * ZSTRIDE * 8 + (a.out_logmel ? (size_t)FR * PSTRIDE * 4 : 0);
-    if (lds > 160 * 1024) return AVSI_ERR_UNSUPPORTED;
+    if (lds > 160 * 1024 || seg > 8 * TPB * 4) return AVSI_ERR_UNSUPPORTED;  // staging registers cover 8192 samples
     const int tiles_per_utt = (int)avsi_ceil_div(a.num_frames, FR);
     const int64_t n_tiles64 = (int64_t)a.batch * tiles_per_utt;
     if (n_tiles64 > INT32_MAX) return AVSI_ERR_UNSUPPORTED;
