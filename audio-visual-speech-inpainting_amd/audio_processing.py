@@ -197,11 +197,10 @@ def _istft_tables(device, frame_len, hop, nfft):
 
 
 def _istft(mode, in0, in1, in2, mean, std, B, T, F, num_samples, sample_rate, window_size, step_size,
-           in_strides, in1_strides=(0, 0), in2_strides=(0, 0)):
+           in_strides, in1_strides=(0, 0), in2_strides=(0, 0), nfft=512):
     _lib.require_cuda(in0, in1, in2, mean, std)
     frame_len = ms_to_samples(window_size, sample_rate)
     hop = ms_to_samples(step_size, sample_rate)
-    nfft = 512
     full = (T - 1) * hop + frame_len
     n_out = full if not num_samples or num_samples <= 0 else min(int(num_samples), full)
     dev = in0.device
@@ -223,12 +222,13 @@ def _istft(mode, in0, in1, in2, mean, std, B, T, F, num_samples, sample_rate, wi
 
 def reconstruct_sources(stfts, num_samples=0, sample_rate=16000, window_size=16, step_size=8):
     """Compute inverse STFT -- reference audio_processing.py:145-157.  stfts complex64 [B, T, F]."""
-    if stfts.dtype != torch.complex64 or (stfts.shape[2] - 1) * 2 != 512:
-        raise _lib.AvsiError("reconstruct_sources needs complex64 [B, T, 257] (fft length 512)")
+    nfft = (stfts.shape[2] - 1) * 2           # tf.contrib.signal.inverse_stft infers the fft length this way
+    if stfts.dtype != torch.complex64 or nfft not in (256, 512):
+        raise _lib.AvsiError("reconstruct_sources needs complex64 [B, T, 257] or [B, T, 129] (fft length 512 / 256)")
     x = torch.view_as_real(stfts.contiguous())
     B, T, F = stfts.shape
     return _istft(0, x, None, None, None, None, B, T, F, num_samples, sample_rate, window_size, step_size,
-                  (x.stride(0), x.stride(1)))
+                  (x.stride(0), x.stride(1)), nfft=nfft)
 
 
 def get_sources(mag_spectrograms, rec_ang_spectrograms, num_samples=48000, sample_rate=16000, window_size=24,
@@ -242,7 +242,7 @@ def get_sources(mag_spectrograms, rec_ang_spectrograms, num_samples=48000, sampl
 
 
 def enhanced_from_prediction(prediction, mean, std, target_stft, masks=None, num_samples=48000, sample_rate=16000,
-                             window_size=24, step_size=12):
+                             window_size=24, step_size=12, n_fft=512):
     """Fused StackedBLSTMModel.enhanced_sources (reference models.py:181-197): waveform of
     exp(prediction*std+mean) with the phase of target_stft*masks (masks=None: oracle phase)."""
     pred = prediction.contiguous()
@@ -251,7 +251,7 @@ def enhanced_from_prediction(prediction, mean, std, target_stft, masks=None, num
     m = None if masks is None else masks.to(torch.float32).contiguous()
     return _istft(2, pred, st, m, None if mean is None else mean.contiguous(), None if std is None else std.contiguous(),
                   B, T, F, num_samples, sample_rate, window_size, step_size, (pred.stride(0), pred.stride(1)),
-                  (st.stride(0), st.stride(1)), (0, 0) if m is None else (m.stride(0), m.stride(1)))
+                  (st.stride(0), st.stride(1)), (0, 0) if m is None else (m.stride(0), m.stride(1)), nfft=n_fft)
 
 
 # ---------------------------------------------------------------------------- per-op API (reference names)

@@ -53,7 +53,7 @@ __global__ void frontend_tables_kernel(float* tab, int frame_len) {
 // NB = number of 32-sample column groups that can hold non-zero window taps = ceil(frame_len/32)
 template <int NB>
 __global__ __launch_bounds__(TPB) void frontend_kernel(const avsi_frontend_args a, const int tiles_per_utt,
-                                                       const int n_tiles, const int seg_floats) {
+                                                       const int n_tiles, const int seg_floats, const int step) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* s_wav = reinterpret_cast<float*>(smem);
     cf* s_z = reinterpret_cast<cf*>(smem + (size_t)seg_floats * 4);
@@ -81,17 +81,24 @@ __global__ __launch_bounds__(TPB) void frontend_kernel(const avsi_frontend_args 
     const int k0 = 4 * kq;
     const bool have_norm = a.mean != nullptr;
     float wkr[4], wki[4], mean_k[4], istd_k[4];
+    // `step` = 512 / nfft: a 256-point transform is read off the even bins of the 512-point one (the
+    // frame is zero-padded to 512, which interpolates the spectrum), so output column = bin / step.
+    bool live[4];
+    int col[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const float2 w = *reinterpret_cast<const float2*>(tab + TAB_TW512 + 2 * (k0 + j));
         wkr[j] = w.x, wki[j] = w.y;
-        mean_k[j] = (have_norm && k0 + j < F) ? a.mean[k0 + j] : 0.f;
-        istd_k[j] = (have_norm && k0 + j < F) ? 1.f / a.stdev[k0 + j] : 1.f;
+        col[j] = (k0 + j) / step;
+        live[j] = ((k0 + j) % step == 0) && col[j] < F;
+        mean_k[j] = (have_norm && live[j]) ? a.mean[col[j]] : 0.f;
+        istd_k[j] = (have_norm && live[j]) ? 1.f / a.stdev[col[j]] : 1.f;
     }
-    const float mean_n = (have_norm && F > 256) ? a.mean[256] : 0.f;  // Nyquist bin
-    const float istd_n = (have_norm && F > 256) ? 1.f / a.stdev[256] : 1.f;
+    const int col_n = 256 / step;                                        // Nyquist bin
+    const float mean_n = (have_norm && F > col_n) ? a.mean[col_n] : 0.f;
+    const float istd_n = (have_norm && F > col_n) ? 1.f / a.stdev[col_n] : 1.f;
     const bool want_pow = a.out_logmel != nullptr;
-    const bool full4 = k0 + 3 < F;  // all four bins of this thread are inside the requested slice
+    const bool full4 = step == 1 && k0 + 3 < F;  // all four bins of this thread are inside the requested slice
 
     // Software pipeline over tiles: the NEXT tile's samples are fetched into registers while the
     // current tile is transformed, and the current tile's mask values are fetched before the FFT and
@@ -142,10 +149,10 @@ __global__ __launch_bounds__(TPB) void frontend_kernel(const avsi_frontend_args 
 #pragma unroll
             for (int j = 0; j < 4; ++j) mk[fi][j] = 1.f;
             if (a.out_feat && a.mask && t < T) {
-                const float* mp = a.mask + (int64_t)b * a.mask_stride_b + (int64_t)t * a.mask_stride_t + k0;
+                const float* mp = a.mask + (int64_t)b * a.mask_stride_b + (int64_t)t * a.mask_stride_t;
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
-                    if (k0 + j < F) mk[fi][j] = mp[j];
+                    if (live[j]) mk[fi][j] = mp[col[j]];
             }
         }
 
@@ -207,34 +214,34 @@ __global__ __launch_bounds__(TPB) void frontend_kernel(const avsi_frontend_args 
             }
             if (want_pow) *reinterpret_cast<float4*>(s_pow + ff * PSTRIDE + k0) = make_float4(p2[0], p2[1], p2[2], p2[3]);
             if (a.out_stft) {
-                float* o2 = a.out_stft + (int64_t)b * a.stft_stride_b + (int64_t)t * a.stft_stride_t + 2 * k0;
+                float* o2 = a.out_stft + (int64_t)b * a.stft_stride_b + (int64_t)t * a.stft_stride_t;
                 if (full4) {
-                    reinterpret_cast<float4*>(o2)[0] = make_float4(xr[0], xi[0], xr[1], xi[1]);
-                    reinterpret_cast<float4*>(o2)[1] = make_float4(xr[2], xi[2], xr[3], xi[3]);
+                    reinterpret_cast<float4*>(o2 + 2 * k0)[0] = make_float4(xr[0], xi[0], xr[1], xi[1]);
+                    reinterpret_cast<float4*>(o2 + 2 * k0)[1] = make_float4(xr[2], xi[2], xr[3], xi[3]);
                 } else {
 #pragma unroll
                     for (int j = 0; j < 4; ++j)
-                        if (k0 + j < F) o2[2 * j] = xr[j], o2[2 * j + 1] = xi[j];
+                        if (live[j]) o2[2 * col[j]] = xr[j], o2[2 * col[j] + 1] = xi[j];
                 }
             }
             if (a.out_spec) {
-                float* o1 = a.out_spec + (int64_t)b * a.spec_stride_b + (int64_t)t * a.spec_stride_t + k0;
+                float* o1 = a.out_spec + (int64_t)b * a.spec_stride_b + (int64_t)t * a.spec_stride_t;
                 if (full4) {
-                    *reinterpret_cast<float4*>(o1) = make_float4(sp[0], sp[1], sp[2], sp[3]);
+                    *reinterpret_cast<float4*>(o1 + k0) = make_float4(sp[0], sp[1], sp[2], sp[3]);
                 } else {
 #pragma unroll
                     for (int j = 0; j < 4; ++j)
-                        if (k0 + j < F) o1[j] = sp[j];
+                        if (live[j]) o1[col[j]] = sp[j];
                 }
             }
             if (a.out_feat) {
-                float* o1 = a.out_feat + (int64_t)b * a.feat_stride_b + (int64_t)t * a.feat_stride_t + k0;
+                float* o1 = a.out_feat + (int64_t)b * a.feat_stride_b + (int64_t)t * a.feat_stride_t;
                 if (full4) {
-                    *reinterpret_cast<float4*>(o1) = make_float4(sp[0] * mk[fi][0], sp[1] * mk[fi][1], sp[2] * mk[fi][2], sp[3] * mk[fi][3]);
+                    *reinterpret_cast<float4*>(o1 + k0) = make_float4(sp[0] * mk[fi][0], sp[1] * mk[fi][1], sp[2] * mk[fi][2], sp[3] * mk[fi][3]);
                 } else {
 #pragma unroll
                     for (int j = 0; j < 4; ++j)
-                        if (k0 + j < F) o1[j] = sp[j] * mk[fi][j];
+                        if (live[j]) o1[col[j]] = sp[j] * mk[fi][j];
                 }
             }
         }
@@ -244,9 +251,9 @@ __global__ __launch_bounds__(TPB) void frontend_kernel(const avsi_frontend_args 
             const cf z0 = s_z[tid * ZSTRIDE];
             const float xn = z0.r - z0.i;  // X[256] = Re Z[0] - Im Z[0], purely real
             if (want_pow) s_pow[tid * PSTRIDE + 256] = xn * xn;
-            if (F > 256) {
+            if (F > col_n) {
                 if (a.out_stft) {
-                    float* o2 = a.out_stft + (int64_t)b * a.stft_stride_b + (int64_t)t * a.stft_stride_t + 512;
+                    float* o2 = a.out_stft + (int64_t)b * a.stft_stride_b + (int64_t)t * a.stft_stride_t + 2 * col_n;
                     o2[0] = xn;
                     o2[1] = 0.f;
                 }
@@ -255,11 +262,11 @@ __global__ __launch_bounds__(TPB) void frontend_kernel(const avsi_frontend_args 
                     if (a.spec_power != 1.f) sv = (a.spec_power == 2.f) ? sv * sv : __powf(sv, a.spec_power);
                     if (a.log_spec) sv = __logf(sv + a.eps);
                     sv = (sv - mean_n) * istd_n;
-                    if (a.out_spec) a.out_spec[(int64_t)b * a.spec_stride_b + (int64_t)t * a.spec_stride_t + 256] = sv;
+                    if (a.out_spec) a.out_spec[(int64_t)b * a.spec_stride_b + (int64_t)t * a.spec_stride_t + col_n] = sv;
                     if (a.out_feat) {
                         const float m =
-                            a.mask ? a.mask[(int64_t)b * a.mask_stride_b + (int64_t)t * a.mask_stride_t + 256] : 1.f;
-                        a.out_feat[(int64_t)b * a.feat_stride_b + (int64_t)t * a.feat_stride_t + 256] = sv * m;
+                            a.mask ? a.mask[(int64_t)b * a.mask_stride_b + (int64_t)t * a.mask_stride_t + col_n] : 1.f;
+                        a.out_feat[(int64_t)b * a.feat_stride_b + (int64_t)t * a.feat_stride_t + col_n] = sv * m;
                     }
                 }
             }
@@ -291,13 +298,13 @@ __global__ __launch_bounds__(TPB) void frontend_kernel(const avsi_frontend_args 
 }  // namespace
 
 extern "C" size_t avsi_frontend_table_floats(int frame_len, int nfft) {
-    if (nfft != 512 || frame_len <= 0 || frame_len > 512) return 0;
+    if ((nfft != 512 && nfft != 256) || frame_len <= 0 || frame_len > nfft) return 0;
     return TAB_FLOATS;
 }
 
 extern "C" int avsi_frontend_init_tables(float* table, int frame_len, int nfft, void* stream) {
     if (!table) return AVSI_ERR_INVALID_ARG;
-    if (nfft != 512 || frame_len <= 0 || frame_len > 512 || (frame_len & 1)) return AVSI_ERR_UNSUPPORTED;
+    if ((nfft != 512 && nfft != 256) || frame_len <= 0 || frame_len > nfft || (frame_len & 1)) return AVSI_ERR_UNSUPPORTED;
     avsi_clear_error();
     hipLaunchKernelGGL(frontend_tables_kernel, dim3(3), dim3(256), 0, (hipStream_t)stream, table, frame_len);
     return avsi_launch_status();
@@ -308,8 +315,11 @@ extern "C" int avsi_frontend_f32(const avsi_frontend_args* args, void* stream) {
     const avsi_frontend_args& a = *args;
     if (!a.wav || !a.table || a.batch <= 0 || a.num_samples <= 0 || a.wav_stride < a.num_samples)
         return AVSI_ERR_INVALID_ARG;
-    if (a.nfft != 512 || a.frame_len <= 0 || a.frame_len > 512 || (a.frame_len & 1) || a.hop <= 0 || (a.hop & 1))
+    if ((a.nfft != 512 && a.nfft != 256) || a.frame_len <= 0 || a.frame_len > a.nfft || (a.frame_len & 1) ||
+        a.hop <= 0 || (a.hop & 1))
         return AVSI_ERR_UNSUPPORTED;
+    if (a.nfft != 512 && a.out_logmel) return AVSI_ERR_UNSUPPORTED;  // mel bands are defined on the 512 grid
+    const int step = 512 / a.nfft;
     const int t_full = (int)avsi_ceil_div(a.num_samples, a.hop);
     if (a.num_frames <= 0 || a.num_frames > t_full) return AVSI_ERR_INVALID_ARG;
     if (a.num_bins <= 0 || a.num_bins > a.nfft / 2 + 1) return AVSI_ERR_INVALID_ARG;
@@ -339,7 +349,7 @@ extern "C" int avsi_frontend_f32(const avsi_frontend_args* args, void* stream) {
         if (lds > 64 * 1024)                                                                                  \
             (void)hipFuncSetAttribute((const void*)frontend_kernel<NBV>, hipFuncAttributeMaxDynamicSharedMemorySize, \
                                       (int)lds);                                                              \
-        hipLaunchKernelGGL(frontend_kernel<NBV>, dim3(grid), dim3(TPB), lds, st, a, tiles_per_utt, n_tiles, seg); \
+        hipLaunchKernelGGL(frontend_kernel<NBV>, dim3(grid), dim3(TPB), lds, st, a, tiles_per_utt, n_tiles, seg, step); \
     } while (0)
     if (nb == 8) AVSI_FE_LAUNCH(8);
     else if (nb == 12) AVSI_FE_LAUNCH(12);

@@ -57,7 +57,7 @@ __global__ void istft_tables_kernel(float* tab, int frame_len, int hop) {
 }
 
 __global__ __launch_bounds__(TPB) void istft_kernel(const avsi_istft_args a, const int tiles_per_utt, const int n_tiles,
-                                                    const int n_hops) {
+                                                    const int n_hops, const int step) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     cf* s_x = reinterpret_cast<cf*>(smem);                             // [FR][XS]   spectrum tile
     cf* s_z = s_x + FR * XS;                                           // [FR][ZSTRIDE] FFT scratch
@@ -83,9 +83,12 @@ __global__ __launch_bounds__(TPB) void istft_kernel(const avsi_istft_args a, con
         for (int ff = 0; ff < FR; ++ff) {
             const int t = t0 + ff;
             const bool live = t >= 0 && t < T;
-            for (int k = tid; k < 257; k += TPB) {
+            for (int kk = tid; kk < 257; kk += TPB) {
+                // `step` = 512 / fft length: a 256-point spectrum sits on the even bins of the 512 grid
+                // (the odd bins are zero), which makes the 512-point inverse 256-periodic and half as large
+                const int k = kk / step;
                 cf x{0.f, 0.f};
-                if (live && k < F) {
+                if (live && (kk % step == 0) && k < F) {
                     const int64_t o = (int64_t)b * a.in_stride_b + (int64_t)t * a.in_stride_t;
                     if (a.mode == 0) {  // complex spectrogram, interleaved
                         x = {a.in0[o + 2 * k], a.in0[o + 2 * k + 1]};
@@ -121,8 +124,8 @@ __global__ __launch_bounds__(TPB) void istft_kernel(const avsi_istft_args a, con
                         }
                     }
                 }
-                if (k == 0 || k == 256) x.i = 0.f;  // irfft ignores the imaginary part of DC / Nyquist
-                s_x[ff * XS + k] = x;
+                if (kk == 0 || kk == 256) x.i = 0.f;  // irfft ignores the imaginary part of DC / Nyquist
+                s_x[ff * XS + kk] = x;
             }
         }
         __syncthreads();
@@ -161,7 +164,8 @@ __global__ __launch_bounds__(TPB) void istft_kernel(const avsi_istft_args a, con
                 const int n = 16 * n1 + ln;
                 const cf z = v[pos16(n1)];
                 const float2 w = *reinterpret_cast<const float2*>(tab + TAB_WIN + 2 * n);
-                *reinterpret_cast<float2*>(ffr + 2 * n) = make_float2(z.r * (1.f / 256.f) * w.x, -z.i * (1.f / 256.f) * w.y);
+                const float sc = (float)step * (1.f / 256.f);
+                *reinterpret_cast<float2*>(ffr + 2 * n) = make_float2(z.r * sc * w.x, -z.i * sc * w.y);
             }
         }
         __syncthreads();
@@ -190,13 +194,13 @@ __global__ __launch_bounds__(TPB) void istft_kernel(const avsi_istft_args a, con
 }  // namespace
 
 extern "C" size_t avsi_istft_table_floats(int frame_len, int hop, int nfft) {
-    if (nfft != 512 || frame_len <= 0 || frame_len > 512 || hop <= 0) return 0;
+    if ((nfft != 512 && nfft != 256) || frame_len <= 0 || frame_len > nfft || hop <= 0) return 0;
     return TAB_FLOATS;
 }
 
 extern "C" int avsi_istft_init_tables(float* table, int frame_len, int hop, int nfft, void* stream) {
     if (!table) return AVSI_ERR_INVALID_ARG;
-    if (nfft != 512 || frame_len <= 0 || frame_len > 512 || (frame_len & 1) || hop <= 0 || hop > frame_len)
+    if ((nfft != 512 && nfft != 256) || frame_len <= 0 || frame_len > nfft || (frame_len & 1) || hop <= 0 || hop > frame_len)
         return AVSI_ERR_UNSUPPORTED;
     avsi_clear_error();
     hipLaunchKernelGGL(istft_tables_kernel, dim3(3), dim3(256), 0, (hipStream_t)stream, table, frame_len, hop);
@@ -210,10 +214,11 @@ extern "C" int avsi_istft_f32(const avsi_istft_args* args, void* stream) {
         return AVSI_ERR_INVALID_ARG;
     if (a.mode < 0 || a.mode > 2 || (a.mode >= 1 && !a.in1)) return AVSI_ERR_INVALID_ARG;
     if ((a.mean == nullptr) != (a.stdev == nullptr)) return AVSI_ERR_INVALID_ARG;
-    if (a.nfft != 512 || a.frame_len <= 0 || a.frame_len > 512 || (a.frame_len & 1) || a.hop <= 0 ||
-        a.hop > a.frame_len || a.frame_len > 2 * a.hop)
+    if ((a.nfft != 512 && a.nfft != 256) || a.frame_len <= 0 || a.frame_len > a.nfft || (a.frame_len & 1) ||
+        a.hop <= 0 || a.hop > a.frame_len || a.frame_len > 2 * a.hop)
         return AVSI_ERR_UNSUPPORTED;  // the 16-frame tile carries ONE halo frame: frame_len <= 2 hop
-    if (a.num_bins <= 0 || a.num_bins > 257) return AVSI_ERR_INVALID_ARG;
+    if (a.num_bins <= 0 || a.num_bins > a.nfft / 2 + 1) return AVSI_ERR_INVALID_ARG;
+    const int step = 512 / a.nfft;
     const int64_t full = (int64_t)(a.num_frames - 1) * a.hop + a.frame_len;
     if (a.num_samples > full) return AVSI_ERR_INVALID_ARG;
     const int n_hops = (int)avsi_ceil_div(a.num_samples, a.hop);
@@ -225,6 +230,6 @@ extern "C" int avsi_istft_f32(const avsi_istft_args* args, void* stream) {
     const int grid = n_tiles < AVSI_NUM_CU * 2 ? n_tiles : AVSI_NUM_CU * 2;
     avsi_clear_error();
     (void)hipFuncSetAttribute((const void*)istft_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(istft_kernel, dim3(grid), dim3(TPB), lds, (hipStream_t)stream, a, tiles_per_utt, n_tiles, n_hops);
+    hipLaunchKernelGGL(istft_kernel, dim3(grid), dim3(TPB), lds, (hipStream_t)stream, a, tiles_per_utt, n_tiles, n_hops, step);
     return avsi_launch_status();
 }

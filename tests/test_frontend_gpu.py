@@ -111,3 +111,25 @@ def test_bad_arguments_raise(ap):
         ap.frontend(w, n_fft=1024, want_spec=True)
     with pytest.raises(avsi_amd._lib.AvsiError):
         ap.frontend(w, num_frames_out=1000, want_spec=True)
+
+
+def test_fft_length_256_unet_geometry(ap):
+    """U-Net front end (models.py:537): 16 ms / 8 ms / n_fft 256 -> 129 bins, sliced to 128."""
+    wav = _wav(2, 16384, 7)
+    w = torch.from_numpy(wav).cuda()
+    got = ap.get_stft(w, window_size=16, step_size=8, n_fft=256).cpu().numpy()
+    ref = OF.get_stft(wav, window_size=16, step_size=8, n_fft=256)
+    assert got.shape == ref.shape == (2, 128, 129)
+    assert np.abs(got - ref).max() / np.abs(ref).max() < 2e-6
+    rng = np.random.default_rng(8)
+    mean, std = rng.normal(5, 1, 128).astype(np.float32), rng.uniform(1, 2, 128).astype(np.float32)
+    masks = (rng.uniform(size=(2, 128, 128)) > 0.2).astype(np.float32)
+    out = ap.frontend(w, window_size=16, step_size=8, n_fft=256, num_bins=128, mean=torch.from_numpy(mean).cuda(),
+                      std=torch.from_numpy(std).cuda(), masks=torch.from_numpy(masks).cuda(), want_spec=True, want_feat=True)
+    spec = (OF.get_spectrogram(ref[:, :, :128], log=True) - mean) / std
+    assert _rms(out['spec'].cpu().numpy(), spec) < 1e-4
+    assert _rms(out['feat'].cpu().numpy(), spec * masks) < 1e-4
+    # inverse: fft length inferred from 129 bins
+    rec = ap.reconstruct_sources(torch.from_numpy(ref.astype(np.complex64)).cuda(), 16384, window_size=16, step_size=8)
+    ref_rec = OF.reconstruct_sources(ref, 16384, window_size=16, step_size=8)
+    assert np.abs(rec.cpu().numpy() - ref_rec).max() < 2e-2
