@@ -80,6 +80,19 @@ PROTOTYPES = {
     "avsi_istft_table_floats": (c_size_t, [c_int, c_int, c_int]),
     "avsi_istft_init_tables": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p]),
     "avsi_istft_f32": (c_int, [POINTER(IstftArgs), c_void_p]),
+    "avsi_im2col_f32": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_int,
+                                c_void_p]),
+    "avsi_col2im_f32": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int,
+                                c_int, c_int, c_void_p]),
+    "avsi_unet_workspace_bytes": (c_size_t, [c_int]),
+    "avsi_colstats_f32": (c_int, [c_void_p, c_int64, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p, c_size_t,
+                                  c_void_p]),
+    "avsi_bn_act_f32": (c_int, [c_void_p, c_int64, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p,
+                                c_void_p]),
+    "avsi_bn_act_bwd_f32": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
+                                    c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "avsi_maxpool2_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "avsi_maxpool2_bwd_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "avsi_spectrogram_f32": (c_int, [c_void_p, c_void_p, c_int64, c_float, c_int, c_float, c_void_p]),
     "avsi_logmel_f32": (c_int, [c_void_p, c_int64, c_int64, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p,
                                 c_float, c_void_p]),

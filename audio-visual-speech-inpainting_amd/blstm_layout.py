@@ -94,6 +94,10 @@ class ParamLayout:
         self.gpacked_size = goff
         self.grad_index = self._build_grad_index()     # ref pos -> gpacked pos
 
+    def signature(self):
+        """Shape signature stored in checkpoints."""
+        return [self.input_dim, self.H, self.num_layers, self.F]
+
     # ------------------------------------------------------------------------------
     def input_row_map(self, li):
         """Padded input column k of layer li -> row of the reference kernel (or -1)."""

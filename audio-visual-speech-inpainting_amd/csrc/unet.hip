@@ -1,0 +1,347 @@
+// Building blocks of the U-Net spectrogram inpainter (reference models.py:519-715 UNetFConvModel,
+// unet_layers.py:6-37 encoder_layer_fconv / decoder_layer_fconv) on gfx950.
+//
+// Activations are NHWC, stored as 2-D [B*H*W rows][C] with row pitch ld (multiple of 4).  A
+// convolution (tf.nn.conv2d, SAME, stride 1) is im2col + the fp32-MFMA GEMM of gemm.hip: the TF
+// filter layout [kh][kw][Cin][Cout] IS the GEMM's B matrix with K ordered (kh, kw, c).  The im2col
+// gather fuses what the decoder does in front of its convolution -- nearest-neighbour 2x
+// up-sampling of the coarse input and the channel concat with the skip connection
+// (tf.keras.layers.UpSampling2D + tf.concat, unet_layers.py:28-29) -- so neither is materialised.
+//   avsi_im2col_f32      [B,H,W,C0] (+ up2x [B,H/2,W/2,C1]) -> col [B*H*W][Kc]
+//   avsi_col2im_f32      gather-form adjoint (deterministic, no atomics), optional accumulate
+//   avsi_colstats_f32    per-channel batch mean and 1/sqrt(var + eps)  (tf.layers.batch_normalization,
+//                        training=True: batch statistics, biased variance, eps 1e-3)
+//   avsi_bn_act_f32      y = act(gamma (x - mean) rstd + beta), act in {none, relu, leaky_relu(0.2)}
+//   avsi_bn_act_bwd_f32  gradient of the above w.r.t. x, gamma, beta (two passes: sums, then apply)
+//   avsi_maxpool2_f32 / avsi_maxpool2_bwd_f32   2x2 / stride 2 max pooling and its gradient
+// All kernels are memory-bound grid-stride loops; the FLOPs live in the GEMMs.
+#include "avsi_common.h"
+
+namespace {
+constexpr int TPB = 256;
+
+inline int grid_for(int64_t items) {
+    int64_t g = avsi_ceil_div(items, TPB);
+    const int64_t cap = (int64_t)AVSI_NUM_CU * 8;
+    return (int)(g < 1 ? 1 : (g > cap ? cap : g));
+}
+
+struct ConvGeom {
+    int B, H, W, C0, ld0, C1, ld1, k, Kc;
+};
+
+__global__ __launch_bounds__(TPB) void im2col_kernel(const float* __restrict__ s0, const float* __restrict__ s1,
+                                                     float* __restrict__ col, const ConvGeom g) {
+    const int Ct = g.C0 + g.C1, p = g.k / 2, H2 = g.H >> 1, W2 = g.W >> 1;
+    const int64_t n = (int64_t)g.B * g.H * g.W * g.Kc;
+    for (int64_t e = (int64_t)blockIdx.x * TPB + threadIdx.x; e < n; e += (int64_t)gridDim.x * TPB) {
+        const int j = (int)(e % g.Kc);
+        int64_t row = e / g.Kc;
+        const int w = (int)(row % g.W);
+        row /= g.W;
+        const int h = (int)(row % g.H), b = (int)(row / g.H);
+        float v = 0.f;
+        if (j < g.k * g.k * Ct) {
+            const int tap = j / Ct, c = j - tap * Ct;
+            const int hh = h + tap / g.k - p, ww = w + tap % g.k - p;
+            if (hh >= 0 && hh < g.H && ww >= 0 && ww < g.W) {
+                if (c < g.C0)
+                    v = s0[(((int64_t)b * g.H + hh) * g.W + ww) * g.ld0 + c];
+                else
+                    v = s1[(((int64_t)b * H2 + (hh >> 1)) * W2 + (ww >> 1)) * g.ld1 + (c - g.C0)];
+            }
+        }
+        col[e] = v;
+    }
+}
+
+// which = 0: gradient of the full-resolution source (channels [0, C0)); which = 1: of the up-sampled one
+__global__ __launch_bounds__(TPB) void col2im_kernel(const float* __restrict__ dcol, float* __restrict__ dst,
+                                                     const ConvGeom g, const int which, const int accumulate) {
+    const int Ct = g.C0 + g.C1, p = g.k / 2;
+    const int Hd = which ? g.H >> 1 : g.H, Wd = which ? g.W >> 1 : g.W;
+    const int Cd = which ? g.C1 : g.C0, ldd = which ? g.ld1 : g.ld0, coff = which ? g.C0 : 0;
+    const int64_t n = (int64_t)g.B * Hd * Wd * ldd;
+    for (int64_t e = (int64_t)blockIdx.x * TPB + threadIdx.x; e < n; e += (int64_t)gridDim.x * TPB) {
+        const int c = (int)(e % ldd);
+        int64_t pix = e / ldd;
+        const int wd = (int)(pix % Wd);
+        pix /= Wd;
+        const int hd = (int)(pix % Hd), b = (int)(pix / Hd);
+        float acc = 0.f;
+        if (c < Cd) {
+            const int reps = which ? 2 : 1;
+            for (int dh = 0; dh < reps; ++dh)
+                for (int dw = 0; dw < reps; ++dw) {
+                    const int h = which ? 2 * hd + dh : hd, w = which ? 2 * wd + dw : wd;
+                    for (int tap = 0; tap < g.k * g.k; ++tap) {
+                        // output pixel (ho, wo) read this input pixel through tap (kh, kw): ho + kh - p = h
+                        const int ho = h - tap / g.k + p, wo = w - tap % g.k + p;
+                        if (ho >= 0 && ho < g.H && wo >= 0 && wo < g.W)
+                            acc += dcol[(((int64_t)b * g.H + ho) * g.W + wo) * g.Kc + tap * Ct + coff + c];
+                    }
+                }
+        }
+        dst[e] = accumulate ? dst[e] + acc : acc;
+    }
+}
+
+// two-stage column reduction of a pair of per-element quantities
+//   MODE 0: (x, x^2)            -> batch-norm statistics
+//   MODE 1: (g, g * xhat), g = dy * act'(gamma xhat + beta)  -> d beta, d gamma
+struct BnArgs {
+    const float* x;
+    const float* dy;
+    const float* mean;
+    const float* rstd;
+    const float* gamma;
+    const float* beta;
+    int64_t R;
+    int C, ld, act, has_bn;
+};
+
+__device__ __forceinline__ float act_grad(float z, int act) {
+    if (act == 1) return z > 0.f ? 1.f : 0.f;
+    if (act == 2) return z > 0.f ? 1.f : 0.2f;
+    return 1.f;
+}
+
+template <int MODE>
+__global__ __launch_bounds__(TPB) void colpair_partial_kernel(const BnArgs a, float* __restrict__ part) {
+    const int c = blockIdx.x * TPB + threadIdx.x;
+    const int64_t chunk = (a.R + gridDim.y - 1) / gridDim.y;
+    const int64_t r0 = (int64_t)blockIdx.y * chunk, r1 = min(a.R, r0 + chunk);
+    if (c >= a.C) return;
+    float s1 = 0.f, s2 = 0.f;
+    float mu = 0.f, rs = 1.f, ga = 1.f, be = 0.f;
+    if (MODE == 1 && a.has_bn) mu = a.mean[c], rs = a.rstd[c], ga = a.gamma[c], be = a.beta[c];
+    for (int64_t r = r0; r < r1; ++r) {
+        const float xv = a.x[r * a.ld + c];
+        if (MODE == 0) {
+            s1 += xv;
+            s2 += xv * xv;
+        } else {
+            const float xh = (xv - mu) * rs;
+            const float g = a.dy[r * a.ld + c] * act_grad(a.has_bn ? ga * xh + be : xv, a.act);
+            s1 += g;
+            s2 += g * xh;
+        }
+    }
+    part[((int64_t)blockIdx.y * 2 + 0) * a.C + c] = s1;
+    part[((int64_t)blockIdx.y * 2 + 1) * a.C + c] = s2;
+}
+
+// MODE 0: out0 = mean, out1 = rstd.  MODE 1: out0 = sum g (d beta), out1 = sum g xhat (d gamma)
+template <int MODE>
+__global__ __launch_bounds__(TPB) void colpair_final_kernel(const float* __restrict__ part, int parts, int C, int64_t R,
+                                                            float eps, float* __restrict__ out0,
+                                                            float* __restrict__ out1) {
+    const int c = blockIdx.x * TPB + threadIdx.x;
+    if (c >= C) return;
+    double s1 = 0.0, s2 = 0.0;
+    for (int p = 0; p < parts; ++p) {
+        s1 += (double)part[((int64_t)p * 2 + 0) * C + c];
+        s2 += (double)part[((int64_t)p * 2 + 1) * C + c];
+    }
+    if (MODE == 0) {
+        const double m = s1 / (double)R;
+        double var = s2 / (double)R - m * m;
+        if (var < 0.0) var = 0.0;
+        out0[c] = (float)m;
+        out1[c] = (float)(1.0 / sqrt(var + (double)eps));
+    } else {
+        out0[c] = (float)s1;
+        out1[c] = (float)s2;
+    }
+}
+
+__global__ __launch_bounds__(TPB) void bn_act_kernel(const BnArgs a, float* __restrict__ y) {
+    const int64_t n = a.R * a.ld;
+    for (int64_t e = (int64_t)blockIdx.x * TPB + threadIdx.x; e < n; e += (int64_t)gridDim.x * TPB) {
+        const int c = (int)(e % a.ld);
+        float v = 0.f;
+        if (c < a.C) {
+            v = a.x[e];
+            if (a.has_bn) v = a.gamma[c] * ((v - a.mean[c]) * a.rstd[c]) + a.beta[c];
+            if (a.act == 1) v = fmaxf(v, 0.f);
+            if (a.act == 2) v = v > 0.f ? v : 0.2f * v;
+        }
+        y[e] = v;
+    }
+}
+
+__global__ __launch_bounds__(TPB) void bn_act_bwd_apply_kernel(const BnArgs a, const float* __restrict__ sum_g,
+                                                               const float* __restrict__ sum_gx,
+                                                               float* __restrict__ dx) {
+    const int64_t n = a.R * a.ld;
+    const float invn = 1.f / (float)a.R;
+    for (int64_t e = (int64_t)blockIdx.x * TPB + threadIdx.x; e < n; e += (int64_t)gridDim.x * TPB) {
+        const int c = (int)(e % a.ld);
+        float v = 0.f;
+        if (c < a.C) {
+            const float xv = a.x[e];
+            if (a.has_bn) {
+                const float rs = a.rstd[c], ga = a.gamma[c];
+                const float xh = (xv - a.mean[c]) * rs;
+                const float g = a.dy[e] * act_grad(ga * xh + a.beta[c], a.act);
+                v = ga * rs * (g - sum_g[c] * invn - xh * sum_gx[c] * invn);
+            } else {
+                v = a.dy[e] * act_grad(xv, a.act);
+            }
+        }
+        dx[e] = v;  // padding columns are written as zeros: dx is a GEMM operand next
+    }
+}
+
+__global__ __launch_bounds__(TPB) void maxpool2_kernel(const float* __restrict__ x, float* __restrict__ y, int B, int H,
+                                                       int W, int C, int ld) {
+    const int H2 = H >> 1, W2 = W >> 1;
+    const int64_t n = (int64_t)B * H2 * W2 * ld;
+    for (int64_t e = (int64_t)blockIdx.x * TPB + threadIdx.x; e < n; e += (int64_t)gridDim.x * TPB) {
+        const int c = (int)(e % ld);
+        int64_t pix = e / ld;
+        const int w2 = (int)(pix % W2);
+        pix /= W2;
+        const int h2 = (int)(pix % H2), b = (int)(pix / H2);
+        float v = 0.f;
+        if (c < C) {
+            const float* p = x + (((int64_t)b * H + 2 * h2) * W + 2 * w2) * ld + c;
+            v = fmaxf(fmaxf(p[0], p[ld]), fmaxf(p[(int64_t)W * ld], p[(int64_t)W * ld + ld]));
+        }
+        y[e] = v;
+    }
+}
+
+__global__ __launch_bounds__(TPB) void maxpool2_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                           float* __restrict__ dx, int B, int H, int W, int C, int ld) {
+    const int H2 = H >> 1, W2 = W >> 1;
+    const int64_t n = (int64_t)B * H2 * W2 * ld;
+    for (int64_t e = (int64_t)blockIdx.x * TPB + threadIdx.x; e < n; e += (int64_t)gridDim.x * TPB) {
+        const int c = (int)(e % ld);
+        int64_t pix = e / ld;
+        const int w2 = (int)(pix % W2);
+        pix /= W2;
+        const int h2 = (int)(pix % H2), b = (int)(pix / H2);
+        const int64_t o = (((int64_t)b * H + 2 * h2) * W + 2 * w2) * ld + c;
+        const int64_t offs[4] = {0, ld, (int64_t)W * ld, (int64_t)W * ld + ld};
+        int best = 0;
+        if (c < C) {
+            float bv = x[o];
+#pragma unroll
+            for (int q = 1; q < 4; ++q) {
+                const float v = x[o + offs[q]];
+                if (v > bv) bv = v, best = q;  // first maximum in row-major window order wins ties
+            }
+        }
+        const float g = c < C ? dy[e] : 0.f;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) dx[o + offs[q]] = (q == best) ? g : 0.f;
+    }
+}
+
+constexpr int MAXPARTS = 256;
+inline int parts_for(int64_t R) {
+    int64_t p = avsi_ceil_div(R, 512);
+    return (int)(p < 1 ? 1 : (p > MAXPARTS ? MAXPARTS : p));
+}
+}  // namespace
+
+static int check_geom(int B, int H, int W, int C0, int ld0, int C1, int ld1, int k, int Kc) {
+    if (B <= 0 || H <= 0 || W <= 0 || C0 < 0 || C1 < 0 || C0 + C1 <= 0 || k < 1 || !(k & 1)) return AVSI_ERR_INVALID_ARG;
+    if (Kc < k * k * (C0 + C1) || (C0 && ld0 < C0) || (C1 && ld1 < C1)) return AVSI_ERR_INVALID_ARG;
+    if (C1 && ((H | W) & 1)) return AVSI_ERR_INVALID_ARG;
+    return AVSI_OK;
+}
+
+extern "C" int avsi_im2col_f32(const float* src0, int C0, int ld0, const float* src1_coarse, int C1, int ld1, int B, int H,
+                               int W, int k, float* col, int Kc, void* stream) {
+    const int rc = check_geom(B, H, W, C0, ld0, C1, ld1, k, Kc);
+    if (rc != AVSI_OK || !col || (C0 && !src0) || (C1 && !src1_coarse)) return rc != AVSI_OK ? rc : AVSI_ERR_INVALID_ARG;
+    const ConvGeom g{B, H, W, C0, ld0, C1, ld1, k, Kc};
+    avsi_clear_error();
+    hipLaunchKernelGGL(im2col_kernel, dim3(grid_for((int64_t)B * H * W * Kc)), dim3(TPB), 0, (hipStream_t)stream, src0,
+                       src1_coarse, col, g);
+    return avsi_launch_status();
+}
+
+extern "C" int avsi_col2im_f32(const float* dcol, int Kc, float* dsrc0, int C0, int ld0, float* dsrc1_coarse, int C1,
+                               int ld1, int B, int H, int W, int k, int accumulate0, int accumulate1, void* stream) {
+    const int rc = check_geom(B, H, W, C0, ld0, C1, ld1, k, Kc);
+    if (rc != AVSI_OK || !dcol) return rc != AVSI_OK ? rc : AVSI_ERR_INVALID_ARG;
+    const ConvGeom g{B, H, W, C0, ld0, C1, ld1, k, Kc};
+    const hipStream_t st = (hipStream_t)stream;
+    avsi_clear_error();
+    if (dsrc0 && C0)
+        hipLaunchKernelGGL(col2im_kernel, dim3(grid_for((int64_t)B * H * W * ld0)), dim3(TPB), 0, st, dcol, dsrc0, g, 0,
+                           accumulate0);
+    if (dsrc1_coarse && C1)
+        hipLaunchKernelGGL(col2im_kernel, dim3(grid_for((int64_t)B * (H / 2) * (W / 2) * ld1)), dim3(TPB), 0, st, dcol,
+                           dsrc1_coarse, g, 1, accumulate1);
+    return avsi_launch_status();
+}
+
+extern "C" size_t avsi_unet_workspace_bytes(int C) { return (size_t)MAXPARTS * 2 * (size_t)C * sizeof(float); }
+
+extern "C" int avsi_colstats_f32(const float* x, int64_t R, int C, int ld, float eps, float* mean, float* rstd,
+                                 void* workspace, size_t workspace_bytes, void* stream) {
+    if (!x || !mean || !rstd || R <= 0 || C <= 0 || ld < C) return AVSI_ERR_INVALID_ARG;
+    if (!workspace || workspace_bytes < avsi_unet_workspace_bytes(C)) return AVSI_ERR_WORKSPACE;
+    BnArgs a{x, nullptr, nullptr, nullptr, nullptr, nullptr, R, C, ld, 0, 0};
+    const int parts = parts_for(R);
+    const hipStream_t st = (hipStream_t)stream;
+    avsi_clear_error();
+    hipLaunchKernelGGL(colpair_partial_kernel<0>, dim3((int)avsi_ceil_div(C, TPB), parts), dim3(TPB), 0, st, a,
+                       (float*)workspace);
+    hipLaunchKernelGGL(colpair_final_kernel<0>, dim3((int)avsi_ceil_div(C, TPB)), dim3(TPB), 0, st,
+                       (const float*)workspace, parts, C, R, eps, mean, rstd);
+    return avsi_launch_status();
+}
+
+extern "C" int avsi_bn_act_f32(const float* x, int64_t R, int C, int ld, const float* mean, const float* rstd,
+                               const float* gamma, const float* beta, int act, float* y, void* stream) {
+    if (!x || !y || R <= 0 || C <= 0 || ld < C || act < 0 || act > 2) return AVSI_ERR_INVALID_ARG;
+    const int has_bn = mean != nullptr;
+    if (has_bn && (!rstd || !gamma || !beta)) return AVSI_ERR_INVALID_ARG;
+    BnArgs a{x, nullptr, mean, rstd, gamma, beta, R, C, ld, act, has_bn};
+    avsi_clear_error();
+    hipLaunchKernelGGL(bn_act_kernel, dim3(grid_for(R * ld)), dim3(TPB), 0, (hipStream_t)stream, a, y);
+    return avsi_launch_status();
+}
+
+extern "C" int avsi_bn_act_bwd_f32(const float* x, const float* dy, int64_t R, int C, int ld, const float* mean,
+                                   const float* rstd, const float* gamma, const float* beta, int act, float* dx,
+                                   float* dgamma, float* dbeta, void* workspace, size_t workspace_bytes, void* stream) {
+    if (!x || !dy || !dx || R <= 0 || C <= 0 || ld < C || act < 0 || act > 2) return AVSI_ERR_INVALID_ARG;
+    const int has_bn = mean != nullptr;
+    if (has_bn && (!rstd || !gamma || !beta || !dgamma || !dbeta)) return AVSI_ERR_INVALID_ARG;
+    if (has_bn && (!workspace || workspace_bytes < avsi_unet_workspace_bytes(C))) return AVSI_ERR_WORKSPACE;
+    BnArgs a{x, dy, mean, rstd, gamma, beta, R, C, ld, act, has_bn};
+    const hipStream_t st = (hipStream_t)stream;
+    avsi_clear_error();
+    if (has_bn) {
+        const int parts = parts_for(R);
+        hipLaunchKernelGGL(colpair_partial_kernel<1>, dim3((int)avsi_ceil_div(C, TPB), parts), dim3(TPB), 0, st, a,
+                           (float*)workspace);
+        hipLaunchKernelGGL(colpair_final_kernel<1>, dim3((int)avsi_ceil_div(C, TPB)), dim3(TPB), 0, st,
+                           (const float*)workspace, parts, C, R, 0.f, dbeta, dgamma);
+    }
+    hipLaunchKernelGGL(bn_act_bwd_apply_kernel, dim3(grid_for(R * ld)), dim3(TPB), 0, st, a, dbeta, dgamma, dx);
+    return avsi_launch_status();
+}
+
+extern "C" int avsi_maxpool2_f32(const float* x, float* y, int B, int H, int W, int C, int ld, void* stream) {
+    if (!x || !y || B <= 0 || H <= 0 || W <= 0 || ((H | W) & 1) || C <= 0 || ld < C) return AVSI_ERR_INVALID_ARG;
+    avsi_clear_error();
+    hipLaunchKernelGGL(maxpool2_kernel, dim3(grid_for((int64_t)B * (H / 2) * (W / 2) * ld)), dim3(TPB), 0,
+                       (hipStream_t)stream, x, y, B, H, W, C, ld);
+    return avsi_launch_status();
+}
+
+extern "C" int avsi_maxpool2_bwd_f32(const float* x, const float* dy, float* dx, int B, int H, int W, int C, int ld,
+                                     void* stream) {
+    if (!x || !dy || !dx || B <= 0 || H <= 0 || W <= 0 || ((H | W) & 1) || C <= 0 || ld < C) return AVSI_ERR_INVALID_ARG;
+    avsi_clear_error();
+    hipLaunchKernelGGL(maxpool2_bwd_kernel, dim3(grid_for((int64_t)B * (H / 2) * (W / 2) * ld)), dim3(TPB), 0,
+                       (hipStream_t)stream, x, dy, dx, B, H, W, C, ld);
+    return avsi_launch_status();
+}

@@ -33,16 +33,17 @@ def _as_device(x, dtype=torch.float32, device=None):
 
 
 class BLSTMVariables:
-    """The trainable variables of one StackedBLSTMModel + optimiser slots, on one GPU.
+    """The trainable variables of one model + optimiser slots, on one GPU.
 
     ``flat`` is the reference-layout buffer (what checkpoints / Adam / all-reduce see);
-    ``packed`` is the kernels' view, refreshed by ``repack()`` after every update."""
+    ``packed`` is the kernels' view, refreshed by ``repack()`` after every update.  Works for any
+    layout object with ref_size / ref_entries / pack_index / grad_index / signature()."""
 
-    def __init__(self, layout, device='cuda', seed=0):
+    def __init__(self, layout, device='cuda', seed=0, init=None):
         _lib.require_cuda()
         self.layout = layout
         self.device = torch.device(device)
-        self.flat = torch.from_numpy(self._tf_default_init(layout, seed)).to(self.device)
+        self.flat = torch.from_numpy((init or self._tf_default_init)(layout, seed)).to(self.device)
         self._pack_index = torch.from_numpy(layout.pack_index).to(self.device)
         self._grad_index = torch.from_numpy(layout.grad_index).to(self.device)
         self.packed = torch.empty(layout.packed_size, dtype=torch.float32, device=self.device)
@@ -93,7 +94,7 @@ class BLSTMVariables:
         flat = self.flat.cpu().numpy()
         arrays = {n: self.layout.ref_view(flat, n) for n, _, _ in self.layout.ref_entries}
         arrays['global_step'] = np.int64(self.global_step)
-        arrays['__layout__'] = np.array([self.layout.input_dim, self.layout.H, self.layout.num_layers, self.layout.F])
+        arrays['__layout__'] = np.array(self.layout.signature())
         if self.adam_m is not None:
             arrays['__adam_m__'] = self.adam_m.cpu().numpy()
         if self.adam_v is not None:
@@ -108,7 +109,7 @@ class BLSTMVariables:
             ck = np.load(fname)
         except Exception as e:
             raise ValueError("%s is not a valid checkpoint (%s)" % (path, e))
-        want = [self.layout.input_dim, self.layout.H, self.layout.num_layers, self.layout.F]
+        want = list(self.layout.signature())
         if '__layout__' not in ck or ck['__layout__'].tolist() != want:
             raise ValueError("%s was saved for a different model shape" % path)
         flat = np.zeros(self.layout.ref_size, dtype=np.float32)
@@ -478,3 +479,6 @@ class StackedBLSTMModel(object):
         return [(n, self.layout.ref_view(self.variables.flat, n)) for n, _, _ in self.layout.ref_entries]
 
     all_vars = train_vars
+
+
+from .unet_model import UNetFConvModel  # noqa: E402,F401  (the reference keeps it in models.py:519-715)

@@ -157,3 +157,57 @@ def adam_tf(param, grad, m, v, step, lr, beta1=0.9, beta2=0.999, eps=1e-8, grad_
     _lib.check(_lib.lib().avsi_adam_tf_f32(_lib.ptr(param), _lib.ptr(grad), _lib.ptr(m), _lib.ptr(v), n, float(lr),
                                            float(beta1), float(beta2), float(eps), int(step), float(grad_scale),
                                            float(l2), _lib.stream_ptr()), "avsi_adam_tf_f32")
+
+
+# ---------------------------------------------------------------------------- U-Net building blocks
+def im2col(src0, c0, src1, c1, B, H, W, k, col, kc):
+    """col[B*H*W, kc] <- patches of src0 [B*H*W, ld0] ++ 2x-up-sampled src1 [B*H/2*W/2, ld1] (avsi_im2col_f32)."""
+    _lib.require_cuda(src0, src1, col)
+    _lib.check(_lib.lib().avsi_im2col_f32(_lib.ptr(src0), int(c0), 0 if src0 is None else src0.stride(0), _lib.ptr(src1),
+                                          int(c1), 0 if src1 is None else src1.stride(0), B, H, W, k, _lib.ptr(col), kc,
+                                          _lib.stream_ptr()), "avsi_im2col_f32")
+    return col
+
+
+def col2im(dcol, kc, dsrc0, c0, dsrc1, c1, B, H, W, k, accumulate0=False, accumulate1=False):
+    _lib.require_cuda(dcol, dsrc0, dsrc1)
+    pitch = lambda t, c: t.stride(0) if t is not None else -(-int(c) // 4) * 4      # a skipped gradient keeps its pitch
+    _lib.check(_lib.lib().avsi_col2im_f32(_lib.ptr(dcol), kc, _lib.ptr(dsrc0), int(c0), pitch(dsrc0, c0),
+                                          _lib.ptr(dsrc1), int(c1), pitch(dsrc1, c1), B, H, W, k, int(accumulate0),
+                                          int(accumulate1), _lib.stream_ptr()), "avsi_col2im_f32")
+
+
+def colstats(x, C, mean, rstd, eps=1e-3):
+    L = _lib.lib()
+    ws = _workspace(x.device, L.avsi_unet_workspace_bytes(C))
+    _lib.check(L.avsi_colstats_f32(_lib.ptr(x), x.shape[0], C, x.stride(0), float(eps), _lib.ptr(mean), _lib.ptr(rstd),
+                                   _lib.ptr(ws), ws.numel() * 4, _lib.stream_ptr()), "avsi_colstats_f32")
+
+
+def bn_act(x, C, y, mean=None, rstd=None, gamma=None, beta=None, act=0):
+    _lib.check(_lib.lib().avsi_bn_act_f32(_lib.ptr(x), x.shape[0], C, x.stride(0), _lib.ptr(mean), _lib.ptr(rstd),
+                                          _lib.ptr(gamma), _lib.ptr(beta), int(act), _lib.ptr(y), _lib.stream_ptr()),
+               "avsi_bn_act_f32")
+    return y
+
+
+def bn_act_bwd(x, dy, C, dx, mean=None, rstd=None, gamma=None, beta=None, act=0, dgamma=None, dbeta=None):
+    L = _lib.lib()
+    ws = _workspace(x.device, L.avsi_unet_workspace_bytes(C))
+    _lib.check(L.avsi_bn_act_bwd_f32(_lib.ptr(x), _lib.ptr(dy), x.shape[0], C, x.stride(0), _lib.ptr(mean),
+                                     _lib.ptr(rstd), _lib.ptr(gamma), _lib.ptr(beta), int(act), _lib.ptr(dx),
+                                     _lib.ptr(dgamma), _lib.ptr(dbeta), _lib.ptr(ws), ws.numel() * 4,
+                                     _lib.stream_ptr()), "avsi_bn_act_bwd_f32")
+    return dx
+
+
+def maxpool2(x, y, B, H, W, C):
+    _lib.check(_lib.lib().avsi_maxpool2_f32(_lib.ptr(x), _lib.ptr(y), B, H, W, C, x.stride(0), _lib.stream_ptr()),
+               "avsi_maxpool2_f32")
+    return y
+
+
+def maxpool2_bwd(x, dy, dx, B, H, W, C):
+    _lib.check(_lib.lib().avsi_maxpool2_bwd_f32(_lib.ptr(x), _lib.ptr(dy), _lib.ptr(dx), B, H, W, C, x.stride(0),
+                                                _lib.stream_ptr()), "avsi_maxpool2_bwd_f32")
+    return dx

@@ -33,8 +33,13 @@ _INPUT_OF = {'a-blstm': 'a', 'v-blstm': 'v', 'av-blstm': 'av'}
 def build_model(config, mean, std, variables=None, is_training=True):
     """Model selection of the drivers (reference training_emb.py:82-92)."""
     kind = config['model']
+    if kind == 'unet':
+        model = net.UNetFConvModel(None, None, None, mean, std, 0.0, config, is_training=is_training,
+                                   variables=variables)
+        model.build_graph(var_scope=kind)
+        return model
     if kind not in _INPUT_OF:
-        print('Model selection must be "a-blstm", "v-blstm" or "av-blstm" on the MI355X path '
+        print('Model selection must be "a-blstm", "v-blstm", "av-blstm" or "unet" on the MI355X path '
               '(got "{:s}"). Closing...'.format(str(kind)))
         sys.exit(1)
     model = net.StackedBLSTMModel(None, None, None, mean, std, 0.0, config, input=_INPUT_OF[kind],

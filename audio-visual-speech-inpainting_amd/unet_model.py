@@ -1,0 +1,417 @@
+"""U-Net spectrogram inpainter on MI355X (host side) -- ``UNetFConvModel`` of the reference
+(``av_speech_inpainting/models.py:519-715`` with ``unet_layers.py:6-37``), BASELINE.json configs[4].
+
+Same constructor signature and attribute names as the reference class.  Front end: 16 ms / 8 ms /
+n_fft 256 (129 bins sliced to ``audio_feat_dim`` = 128), log-magnitude, z-norm, times mask.
+Network: six encoder layers conv(k = 7,5,5,3,3,3; 1-16-32-64-128-128-128) + bias (+ batch norm,
+not on the first) + ReLU + 2x2 max pooling, six decoder layers [2x nearest up-sampling ++ skip]
+conv 3x3 + bias + batch norm + LeakyReLU(0.2), a final 1x1 convolution.  As committed the
+reference encoder never down-samples while its decoder up-samples; the 2x2
+max pooling its channel counts and experiment name ('unet_maxpool') imply is what runs here.
+Batch normalisation always uses batch statistics (the reference never runs UPDATE_OPS and builds
+the model with is_training=True everywhere).
+
+Every convolution is im2col + the fp32-MFMA GEMM (``ops.im2col`` / ``ops.gemm``); its gradients are a
+split-K GEMM (filter) and a GEMM + gather-form col2im (input).  Activations are NHWC
+``[B*H*W][C]`` with the channel pitch padded to a multiple of 4.
+"""
+import math
+import sys
+
+import numpy as np
+import torch
+
+from . import _lib, ops, parallel
+from . import audio_processing as ap
+from .blstm_layout import round_up
+
+ENCODER = [(7, 1, 16, False), (5, 16, 32, True), (5, 32, 64, True), (3, 64, 128, True), (3, 128, 128, True),
+           (3, 128, 128, True)]
+DECODER = [(3, 256, 128), (3, 256, 128), (3, 192, 64), (3, 96, 32), (3, 48, 16), (3, 17, 1)]
+
+
+def layer_specs():
+    """Ordered (name, k, cin, cout, batch_norm, activation) in variable-creation order."""
+    out = [('e%d' % (i + 1), k, ci, co, bn, 1) for i, (k, ci, co, bn) in enumerate(ENCODER)]
+    out += [('d%d' % (i + 1), k, ci, co, True, 2) for i, (k, ci, co) in enumerate(DECODER)]
+    out.append(('out', 1, 1, 1, False, 0))
+    return out
+
+
+class UNetLayout:
+    """Reference variables (w [k,k,cin,cout], b, bn gamma/beta per layer) <-> GEMM-ready packed form
+    (filter as [Kc][ld] with Kc = k*k*cin and ld = cout, both rounded up to 4)."""
+
+    def __init__(self):
+        self.specs = layer_specs()
+        self.ref_entries, self.packed, self.gpacked = [], {}, {}
+        off = poff = 0
+        for name, k, ci, co, bn, _ in self.specs:
+            for vname, shape in ([('w', (k, k, ci, co)), ('b', (co,))]
+                                 + ([('bn/gamma', (co,)), ('bn/beta', (co,))] if bn else [])):
+                self.ref_entries.append(('%s/%s' % (name, vname), shape, off))
+                off += int(np.prod(shape))
+            kc, ld = round_up(k * k * ci, 4), round_up(co, 4)
+            for vname, shape in ([('w', (kc, ld)), ('b', (ld,))] + ([('bn/gamma', (ld,)), ('bn/beta', (ld,))] if bn else [])):
+                self.packed['%s/%s' % (name, vname)] = (poff, shape)
+                poff += round_up(int(np.prod(shape)), 64)
+        self.ref_size, self.packed_size, self.gpacked_size = off, poff, poff
+        self.gpacked = self.packed                       # gradients come out in the packed shapes
+        idx = np.full(self.packed_size, self.ref_size, dtype=np.int64)
+        gi = np.full(self.ref_size, -1, dtype=np.int64)
+        for name, shape, roff in self.ref_entries:
+            poff, pshape = self.packed[name]
+            if name.endswith('/w'):
+                k, _, ci, co = shape
+                rows = np.arange(k * k * ci)[:, None]
+                cols = np.arange(co)[None, :]
+                pos = poff + rows * pshape[1] + cols
+                src = roff + rows * co + cols
+            else:
+                pos = poff + np.arange(shape[0])
+                src = roff + np.arange(shape[0])
+            idx[pos.reshape(-1)] = src.reshape(-1)
+            gi[src.reshape(-1)] = pos.reshape(-1)
+        assert (gi >= 0).all()
+        self.pack_index, self.grad_index = idx, gi
+
+    def signature(self):
+        return [4, self.ref_size, len(self.specs), 0]
+
+    def ref_view(self, flat, name):
+        for n, shape, off in self.ref_entries:
+            if n == name:
+                return flat[off: off + int(np.prod(shape))].reshape(shape)
+        raise KeyError(name)
+
+    def packed_view(self, flat, name):
+        off, shape = self.packed[name]
+        return flat[off: off + int(np.prod(shape))].reshape(shape)
+
+    gpacked_view = packed_view
+
+    def flatten_params(self, params):
+        flat = np.zeros(self.ref_size, dtype=np.float32)
+        for n, _, _ in self.ref_entries:
+            self.ref_view(flat, n)[...] = params[n]
+        return flat
+
+
+def _unet_default_init(layout, seed):
+    """unet_layers.py:7-9,24-26: w ~ truncated_normal(sqrt(2 / (k^2 cout))), b = 0.1; BN gamma 1, beta 0."""
+    rng = np.random.default_rng(seed)
+    flat = np.zeros(layout.ref_size, dtype=np.float32)
+    for name, shape, off in layout.ref_entries:
+        n = int(np.prod(shape))
+        if name.endswith('/w'):
+            sd = math.sqrt(2.0 / (shape[0] * shape[1] * shape[3]))
+            w = rng.normal(0.0, sd, size=n)
+            bad = np.abs(w) > 2 * sd
+            while bad.any():
+                w[bad] = rng.normal(0.0, sd, size=int(bad.sum()))
+                bad = np.abs(w) > 2 * sd
+            flat[off:off + n] = w
+        elif name.endswith('/b'):
+            flat[off:off + n] = 0.1
+        elif name.endswith('/gamma'):
+            flat[off:off + n] = 1.0
+    return flat
+
+
+class UNetFConvModel(object):
+    """
+    Speech inpainting U-Net model with full convolutions (reference models.py:519-715).
+    Input: log-compressed linear spectrogram of corrupted audio.  Output: restored spectrogram.
+    Loss: L1 (target_spectrogram - reconstructed_spectrogram).
+    """
+
+    def __init__(self, sequence_lengths, target_sources, masks, audio_feat_mean, audio_feat_std, dropout_rate, config,
+                 is_training=True, variables=None, seed=0):
+        from .models import BLSTMVariables, _as_device
+        _lib.require_cuda()
+        self._as_device = _as_device
+        self.audio_feat_dim = config['audio_feat_dim']
+        self.audio_len = config['audio_len']
+        self.dropout_rate = dropout_rate
+        self.net_dim = config.get('net_dim')
+        self.optimizer_choice = config['optimizer_type']
+        self.starter_learning_rate = config['starter_learning_rate']
+        self.updating_step = config['lr_updating_steps']
+        self.learning_decay = config['lr_decay']
+        self.is_training = is_training
+        self.batch_size = config.get('batch_size', 1)
+        self.regularization = config['l2']
+        self.var_scope = None
+        self.layout = variables.layout if variables is not None else UNetLayout()
+        self.variables = variables if variables is not None else BLSTMVariables(self.layout, seed=seed,
+                                                                                  init=_unet_default_init)
+        self.device = self.variables.device
+        self._ws, self._cache = {}, {}
+        self.audio_feat_mean = _as_device(audio_feat_mean, device=self.device)
+        self.audio_feat_std = _as_device(audio_feat_std, device=self.device)
+        self.sequence_lengths = None
+        self.feed(sequence_lengths=sequence_lengths, target_sources=target_sources, masks=masks)
+
+    # ------------------------------------------------------------------ feed boundary
+    def feed(self, sequence_lengths=None, target_sources=None, masks=None, audio_feat_mean=None, audio_feat_std=None,
+             **_unused):
+        self._cache = {}
+        if sequence_lengths is not None:
+            self.sequence_lengths = np.asarray(
+                sequence_lengths.cpu() if isinstance(sequence_lengths, torch.Tensor) else sequence_lengths, dtype=np.int64)
+        self.target_sources = self._as_device(target_sources, device=self.device)
+        self.masks = self._as_device(masks, device=self.device)
+        if audio_feat_mean is not None:
+            self.audio_feat_mean = self._as_device(audio_feat_mean, device=self.device)
+        if audio_feat_std is not None:
+            self.audio_feat_std = self._as_device(audio_feat_std, device=self.device)
+
+    def build_graph(self, var_scope=''):
+        self.var_scope = var_scope
+
+    def _buf(self, name, shape, zero=True):
+        key = (name, tuple(shape))
+        t = self._ws.get(key)
+        if t is None:
+            t = torch.zeros(shape, dtype=torch.float32, device=self.device)
+            self._ws[key] = t
+        return t
+
+    def _dims(self):
+        B = int(self.target_sources.shape[0])
+        T = int(self.sequence_lengths.max())
+        F = self.audio_feat_dim
+        if T % 64 or F % 64:
+            raise _lib.AvsiError("the U-Net pools 6 times: frames (%d) and bins (%d) must be multiples of 64" % (T, F))
+        return B, T, F
+
+    # ------------------------------------------------------------------ front end (models.py:536-540)
+    def _frontend(self):
+        c = self._cache
+        if 'x0' in c:
+            return
+        B, T, F = self._dims()
+        m = self.masks[:, :T].contiguous()
+        x0 = self._buf('x0', (B * T * F, 4))                       # [B, T, F, 1] with channel pitch 4
+        fe = ap.frontend(self.target_sources, window_size=16, step_size=8, n_fft=256, num_frames_out=T, num_bins=F,
+                         mean=self.audio_feat_mean, std=self.audio_feat_std, masks=m, want_spec=True, want_feat=True)
+        x0[:, 0] = fe['feat'].reshape(-1)
+        c['target_spec_norm'], c['net_inputs'], c['x0'], c['mask_t'] = fe['spec'], fe['feat'], x0, m
+
+    @property
+    def target_spec_norm(self):
+        self._frontend()
+        return self._cache['target_spec_norm']
+
+    @property
+    def net_inputs(self):
+        self._frontend()
+        return self._cache['net_inputs']
+
+    # ------------------------------------------------------------------ network (models.py:582-607)
+    def _conv_fwd(self, name, k, cout, bn, act, src0, c0, src1, c1, B, H, W):
+        v = self.variables
+        R, kc, ld = B * H * W, round_up(k * k * (c0 + c1), 4), round_up(cout, 4)
+        col = self._buf('col', (self._col_floats,))[: R * kc].view(R, kc)
+        ops.im2col(src0, c0, src1, c1, B, H, W, k, col, kc)
+        conv = self._buf(name + '/conv', (R, ld))
+        ops.gemm(col, v.p(name + '/w'), out=conv, n=cout, bias=v.p(name + '/b'))
+        st = None
+        if bn:
+            st = (self._buf(name + '/mean', (ld,)), self._buf(name + '/rstd', (ld,)))
+            ops.colstats(conv, cout, st[0], st[1])
+        y = self._buf(name + '/act', (R, ld))
+        ops.bn_act(conv, cout, y, *(st or (None, None)), v.p(name + '/bn/gamma') if bn else None,
+                   v.p(name + '/bn/beta') if bn else None, act)
+        self._cache['saved'][name] = dict(k=k, cout=cout, bn=bn, act=act, src0=src0, c0=c0, src1=src1, c1=c1, B=B, H=H,
+                                          W=W, conv=conv, stats=st, y=y, kc=kc, ld=ld)
+        return y
+
+    def _forward(self):
+        c = self._cache
+        if 'pred' in c:
+            return
+        self._frontend()
+        B, T, F = self._dims()
+        self._col_floats = B * T * F * 160                              # largest im2col matrix: d6 (17 ch x 9 taps)
+        c['saved'], c['pool'] = {}, {}
+        h, H, W, ch = c['x0'], T, F, 1
+        skips = [(c['x0'], 1, T, F)]
+        for i, (k, ci, co, bn) in enumerate(ENCODER):
+            name = 'e%d' % (i + 1)
+            y = self._conv_fwd(name, k, co, bn, 1, h, ch, None, 0, B, H, W)
+            pooled = self._buf(name + '/pool', (B * (H // 2) * (W // 2), round_up(co, 4)))
+            ops.maxpool2(y, pooled, B, H, W, co)
+            c['pool'][name] = pooled
+            h, H, W, ch = pooled, H // 2, W // 2, co
+            skips.append((pooled, co, H, W))
+        for i, (k, ci, co) in enumerate(DECODER):
+            name = 'd%d' % (i + 1)
+            skip, cs, Hs, Ws = skips[5 - i]
+            h = self._conv_fwd(name, k, co, True, 2, skip, cs, h, ch, B, Hs, Ws)
+            H, W, ch = Hs, Ws, co
+        logits = self._conv_fwd('out', 1, 1, False, 0, h, 1, None, 0, B, T, F)
+        seq = torch.as_tensor(self.sequence_lengths, device=self.device)
+        rowmask = (torch.arange(T, device=self.device)[None, :] < seq[:, None]).to(torch.float32)
+        c['rowmask'] = rowmask
+        c['inference'] = logits[:, 0].reshape(B, T, F)
+        c['pred'] = (c['inference'] * rowmask[:, :, None]).contiguous()
+
+    @property
+    def inference(self):
+        self._forward()
+        return self._cache['inference']
+
+    @property
+    def prediction(self):
+        self._forward()
+        return self._cache['pred']
+
+    # ------------------------------------------------------------------ loss (models.py:617-634)
+    def _loss(self, want_grad=False):
+        c = self._cache
+        want_grad = want_grad or bool(self.is_training)
+        if 'loss3' in c and (not want_grad or c.get('dpred') is not None):
+            return
+        self._forward()
+        c['loss3'], c['dpred'] = ops.l1_loss(self.target_spec_norm, c['pred'], c['mask_t'], want_grad=want_grad)
+
+    @property
+    def loss_func(self):
+        self._loss()
+        return self._cache['loss3'][0]
+
+    @property
+    def loss_hole(self):
+        self._loss()
+        return self._cache['loss3'][1]
+
+    @property
+    def loss_valid(self):
+        self._loss()
+        return self._cache['loss3'][2]
+
+    @property
+    def reg_loss(self):
+        if self.regularization:
+            return (self.variables.flat.double() ** 2).sum().float() / 2.0
+        return torch.zeros((), device=self.device)
+
+    @property
+    def loss(self):
+        return self.loss_func + self.regularization * self.reg_loss if self.regularization else self.loss_func
+
+    # ------------------------------------------------------------------ gradients / optimiser
+    def _conv_bwd(self, name, dy, gp, dsrc0, acc0, dsrc1, acc1):
+        s, v, lay = self._cache['saved'][name], self.variables, self.layout
+        R, kc, ld, cout = s['B'] * s['H'] * s['W'], s['kc'], s['ld'], s['cout']
+        dconv = self._buf(name + '/dconv', (R, ld))
+        st = s['stats'] or (None, None)
+        ops.bn_act_bwd(s['conv'], dy, cout, dconv, st[0], st[1], v.p(name + '/bn/gamma') if s['bn'] else None,
+                       v.p(name + '/bn/beta') if s['bn'] else None, s['act'],
+                       lay.gpacked_view(gp, name + '/bn/gamma') if s['bn'] else None,
+                       lay.gpacked_view(gp, name + '/bn/beta') if s['bn'] else None)
+        ops.colsum(dconv, lay.gpacked_view(gp, name + '/b'), m=R, n=ld)
+        col = self._buf('col', (self._col_floats,))[: R * kc].view(R, kc)
+        ops.im2col(s['src0'], s['c0'], s['src1'], s['c1'], s['B'], s['H'], s['W'], s['k'], col, kc)
+        ops.gemm_splitk(col, dconv, lay.gpacked_view(gp, name + '/w'), trans_a=True, m=kc, n=ld, k=R,
+                        splits=max(1, min(64, R // 4096)))
+        if dsrc0 is None and dsrc1 is None:
+            return
+        ops.gemm(dconv, v.p(name + '/w'), out=col, trans_b=True, m=R, n=kc, k=ld)          # dcol overwrites col
+        ops.col2im(col, kc, dsrc0, s['c0'], dsrc1, s['c1'], s['B'], s['H'], s['W'], s['k'], acc0, acc1)
+
+    def _backward(self):
+        c = self._cache
+        if 'grads' in c:
+            return c['grads']
+        self._loss(want_grad=True)
+        B, T, F = self._dims()
+        lay, saved = self.layout, c['saved']
+        gp = self._buf('gpacked', (lay.gpacked_size,))
+        dlog = self._buf('dlog', (B * T * F, 4))
+        dlog[:, 0] = (c['dpred'] * c['rowmask'][:, :, None]).reshape(-1)
+        g = {n: self._buf(n + '/dy', saved[n]['y'].shape) for n in saved}       # d loss / d activated output
+        gpool = {n: self._buf(n + '/dpool', c['pool'][n].shape) for n in c['pool']}  # d loss / d pooled encoder outputs
+        self._conv_bwd('out', dlog, gp, g['d6'], False, None, False)
+        prev = None
+        for i in range(5, -1, -1):                                      # d6 .. d1
+            name = 'd%d' % (i + 1)
+            skip_name = 'e%d' % (5 - i) if 5 - i >= 1 else None         # skip source: e5..e1, then the net input
+            dsrc0 = gpool[skip_name] if skip_name else None
+            coarse = g['d%d' % i] if i >= 1 else gpool['e6']             # the up-sampled source: d(i) act, or e6 pooled
+            self._conv_bwd(name, g[name], gp, dsrc0, False, coarse, False)
+        for i in range(5, -1, -1):                                      # e6 .. e1
+            name = 'e%d' % (i + 1)
+            s = saved[name]
+            ops.maxpool2_bwd(s['y'], gpool[name], g[name], s['B'], s['H'], s['W'], s['cout'])
+            dsrc0 = gpool['e%d' % i] if i >= 1 else None                 # e(i) pooled output also fed a decoder: accumulate
+            self._conv_bwd(name, g[name], gp, dsrc0, True, None, False)
+        grads = self.variables.unpack_grads(gp, out=self._buf('grads', (lay.ref_size,)))
+        c['grads'] = grads
+        return grads
+
+    @property
+    def gradients(self):
+        g = self._backward()
+        return g + self.regularization * self.variables.flat if self.regularization else g
+
+    @property
+    def global_step(self):
+        return self.variables.global_step
+
+    @property
+    def learning_rate(self):
+        return self.starter_learning_rate * self.learning_decay ** math.floor(
+            self.variables.global_step / self.updating_step)
+
+    @property
+    def train_op(self):
+        c = self._cache
+        if c.get('trained'):
+            return None
+        g = self._backward()
+        v = self.variables
+        world = parallel.world_size()
+        parallel.all_reduce_sum_(g)
+        step = v.global_step + 1
+        if self.optimizer_choice != 'adam':
+            print('Optimizer must be adam on the MI355X U-Net path. Closing...')
+            sys.exit(1)
+        if v.adam_m is None:
+            v.adam_m, v.adam_v = torch.zeros_like(v.flat), torch.zeros_like(v.flat)
+        ops.adam_tf(v.flat, g, v.adam_m, v.adam_v, step, self.starter_learning_rate, grad_scale=1.0 / world,
+                    l2=float(self.regularization or 0.0))
+        v.global_step = step
+        v.repack()
+        c['trained'] = True
+        return None
+
+    # ------------------------------------------------------------------ waveforms (models.py:664-680)
+    @property
+    def target_stft(self):
+        c = self._cache
+        if 'target_stft' not in c:
+            _, T, F = self._dims()
+            c['target_stft'] = ap.frontend(self.target_sources, window_size=16, step_size=8, n_fft=256,
+                                           num_frames_out=T, num_bins=F, want_stft=True)['stft']
+        return c['target_stft']
+
+    def _enhanced(self, oracle_phase):
+        key = 'enh_oracle' if oracle_phase else 'enh'
+        c = self._cache
+        if key not in c:
+            # the reference calls get_sources with its 24 / 12 ms defaults here (App. B9); the STFT geometry of
+            # this model (16 / 8 ms, n_fft 256) is used instead
+            c[key] = ap.enhanced_from_prediction(self.prediction, self.audio_feat_mean, self.audio_feat_std,
+                                                 self.target_stft, None if oracle_phase else self._cache['mask_t'],
+                                                 num_samples=self.audio_len, window_size=16, step_size=8, n_fft=256)
+        return c[key]
+
+    @property
+    def enhanced_sources(self):
+        return self._enhanced(False)
+
+    @property
+    def enhanced_sources_oracle_phase(self):
+        return self._enhanced(True)

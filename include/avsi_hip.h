@@ -218,6 +218,32 @@ size_t avsi_istft_table_floats(int frame_len, int hop, int nfft);
 int avsi_istft_init_tables(float* table, int frame_len, int hop, int nfft, void* stream);
 int avsi_istft_f32(const avsi_istft_args* args, void* stream);
 
+/* ------------------------------------------------------------------------------------
+ * U-Net building blocks (models.py:519-715 UNetFConvModel, unet_layers.py:6-37).  Activations are
+ * NHWC as 2-D [B*H*W][C] with row pitch ld.  A SAME / stride-1 tf.nn.conv2d is avsi_im2col_f32 +
+ * avsi_gemm_f32 with the TF filter [kh][kw][Cin][Cout] as the B matrix (rows padded to Kc, a
+ * multiple of 4); its gradients are avsi_gemm_splitk_f32 (filter) and avsi_gemm_f32 +
+ * avsi_col2im_f32 (input).  im2col can read a second, half-resolution source through a nearest
+ * 2x up-sampling and appends its channels after src0's (UpSampling2D + concat, unet_layers.py:28-29).
+ * Batch normalisation uses batch statistics (training=True, biased variance, eps = 1e-3);
+ * act: 0 none, 1 relu, 2 leaky_relu(0.2).  Pass mean = null for layers without batch norm.
+ * workspace for the reductions: avsi_unet_workspace_bytes(C).
+ * ------------------------------------------------------------------------------------ */
+int avsi_im2col_f32(const float* src0, int C0, int ld0, const float* src1_coarse, int C1, int ld1,
+                    int B, int H, int W, int k, float* col, int Kc, void* stream);
+int avsi_col2im_f32(const float* dcol, int Kc, float* dsrc0, int C0, int ld0, float* dsrc1_coarse, int C1, int ld1,
+                    int B, int H, int W, int k, int accumulate0, int accumulate1, void* stream);
+size_t avsi_unet_workspace_bytes(int C);
+int avsi_colstats_f32(const float* x, int64_t R, int C, int ld, float eps, float* mean, float* rstd,
+                      void* workspace, size_t workspace_bytes, void* stream);
+int avsi_bn_act_f32(const float* x, int64_t R, int C, int ld, const float* mean, const float* rstd,
+                    const float* gamma, const float* beta, int act, float* y, void* stream);
+int avsi_bn_act_bwd_f32(const float* x, const float* dy, int64_t R, int C, int ld, const float* mean,
+                        const float* rstd, const float* gamma, const float* beta, int act, float* dx,
+                        float* dgamma, float* dbeta, void* workspace, size_t workspace_bytes, void* stream);
+int avsi_maxpool2_f32(const float* x, float* y, int B, int H, int W, int C, int ld, void* stream);
+int avsi_maxpool2_bwd_f32(const float* x, const float* dy, float* dx, int B, int H, int W, int C, int ld, void* stream);
+
 /* Stand-alone forms of the small operators of audio_processing.py (the inpainter itself uses the
  * fused front end).  avsi_spectrogram_f32: out[i] = |stft[i]|^power, log(. + eps) if do_log
  * (:45-56); avsi_logmel_f32: out[r][m] = log(sum_j spec[r][start[m]+j] w[m][j] + eps) (:59-72);

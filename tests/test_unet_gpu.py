@@ -1,0 +1,160 @@
+"""U-Net inpainter (BASELINE configs[4]) on the GPU against the torch-CPU float64 oracle: building-block
+kernels, forward, losses, every gradient, Adam steps and waveform output."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import frontend as OF
+from oracle import unet as OU
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def mods():
+    import avsi_amd
+    from avsi_amd import models, ops
+    return models, ops
+
+
+def _cfg(N):
+    return dict(audio_feat_dim=128, audio_len=N, net_dim=[250, 250, 250], optimizer_type='adam',
+                starter_learning_rate=1e-3, learning_rate=1e-3, lr_updating_steps=10000, lr_decay=1.0, batch_size=2,
+                l2=0.0)
+
+
+def _inputs(B, N, seed):
+    rng = np.random.default_rng(seed)
+    wav = np.clip(np.round(rng.normal(0, 3000, size=(B, N))), -32768, 32767).astype(np.float32)
+    T = N // 128
+    masks = np.ones((B, T, 128), dtype=np.float32)
+    for b in range(B):
+        s = rng.integers(4, T - 20)
+        masks[b, s:s + 12] = 0
+    st = OF.get_stft(wav, window_size=16, step_size=8, n_fft=256)[:, :, :128]
+    spec = OF.get_spectrogram(st, log=True)
+    mean, std = OF.feature_stats(list(spec))
+    return wav, masks, mean.astype(np.float32), std.astype(np.float32), T, spec
+
+
+def test_im2col_col2im_adjoint_and_reference(mods):
+    """im2col vs an explicit numpy gather (incl. the fused 2x up-sampling + concat); col2im is its adjoint."""
+    models, ops = mods
+    rng = np.random.default_rng(0)
+    B, H, W, C0, C1, k = 2, 8, 6, 3, 5, 3
+    a = rng.normal(size=(B, H, W, C0)).astype(np.float32)
+    c = rng.normal(size=(B, H // 2, W // 2, C1)).astype(np.float32)
+    up = c.repeat(2, axis=1).repeat(2, axis=2)
+    cat = np.concatenate([a, up], axis=3)
+    pad = np.pad(cat, [(0, 0), (1, 1), (1, 1), (0, 0)])
+    ref = np.zeros((B, H, W, k * k * (C0 + C1)), dtype=np.float32)
+    for kh in range(k):
+        for kw in range(k):
+            ref[..., (kh * k + kw) * (C0 + C1):(kh * k + kw + 1) * (C0 + C1)] = pad[:, kh:kh + H, kw:kw + W, :]
+    kc = -(-k * k * (C0 + C1) // 4) * 4
+    a4 = torch.zeros(B * H * W, 4, device='cuda'); a4[:, :C0] = torch.from_numpy(a).cuda().view(-1, C0)
+    c8 = torch.zeros(B * (H // 2) * (W // 2), 8, device='cuda'); c8[:, :C1] = torch.from_numpy(c).cuda().view(-1, C1)
+    col = torch.empty(B * H * W, kc, device='cuda')
+    ops.im2col(a4, C0, c8, C1, B, H, W, k, col, kc)
+    got = col.cpu().numpy()
+    np.testing.assert_array_equal(got[:, :k * k * (C0 + C1)], ref.reshape(B * H * W, -1))
+    assert np.all(got[:, k * k * (C0 + C1):] == 0)
+    # adjoint: <im2col(x), y> == <x, col2im(y)>
+    y = torch.randn(B * H * W, kc, device='cuda')
+    d0 = torch.empty_like(a4); d1 = torch.empty_like(c8)
+    ops.col2im(y, kc, d0, C0, d1, C1, B, H, W, k)
+    lhs = float((col.double() * y.double()).sum())
+    rhs = float((a4.double() * d0.double()).sum() + (c8.double() * d1.double()).sum())
+    assert lhs == pytest.approx(rhs, rel=1e-5)
+    d0b = d0.clone()
+    ops.col2im(y, kc, d0b, C0, None, C1, B, H, W, k, accumulate0=True)        # accumulate, second gradient skipped
+    assert torch.allclose(d0b, 2 * d0)
+
+
+def test_bn_act_and_pool_kernels(mods):
+    models, ops = mods
+    rng = np.random.default_rng(1)
+    R, C, ld = 4096, 6, 8
+    x = torch.zeros(R, ld, device='cuda'); x[:, :C] = torch.from_numpy(rng.normal(1.0, 2.0, size=(R, C)).astype(np.float32)).cuda()
+    gamma = torch.zeros(ld, device='cuda'); gamma[:C] = torch.from_numpy(rng.uniform(0.5, 1.5, C).astype(np.float32)).cuda()
+    beta = torch.zeros(ld, device='cuda'); beta[:C] = torch.from_numpy(rng.normal(size=C).astype(np.float32)).cuda()
+    mean, rstd = torch.empty(ld, device='cuda'), torch.empty(ld, device='cuda')
+    ops.colstats(x, C, mean, rstd)
+    xr = x[:, :C].double().cpu()
+    np.testing.assert_allclose(mean[:C].cpu().numpy(), xr.mean(0).numpy(), rtol=1e-5)
+    np.testing.assert_allclose(rstd[:C].cpu().numpy(), (1 / torch.sqrt(xr.var(0, unbiased=False) + 1e-3)).numpy(), rtol=1e-5)
+    for act, fn in ((1, torch.relu), (2, lambda t: torch.nn.functional.leaky_relu(t, 0.2)), (0, lambda t: t)):
+        xt = xr.clone().requires_grad_(True)
+        g_t, b_t = gamma[:C].double().cpu().requires_grad_(True), beta[:C].double().cpu().requires_grad_(True)
+        yt = fn(g_t * (xt - xt.mean(0)) / torch.sqrt(xt.var(0, unbiased=False) + 1e-3) + b_t)
+        dy = torch.from_numpy(rng.normal(size=(R, C))).double()
+        yt.backward(dy)
+        y = torch.empty_like(x)
+        ops.bn_act(x, C, y, mean, rstd, gamma, beta, act)
+        np.testing.assert_allclose(y[:, :C].cpu().numpy(), yt.detach().numpy(), atol=2e-5)
+        dyd = torch.zeros(R, ld, device='cuda'); dyd[:, :C] = dy.float().cuda()
+        dx, dg, db = torch.empty_like(x), torch.empty(ld, device='cuda'), torch.empty(ld, device='cuda')
+        ops.bn_act_bwd(x, dyd, C, dx, mean, rstd, gamma, beta, act, dg, db)
+        np.testing.assert_allclose(dx[:, :C].cpu().numpy(), xt.grad.numpy(), atol=2e-5)
+        np.testing.assert_allclose(dg[:C].cpu().numpy(), g_t.grad.numpy(), rtol=2e-4, atol=1e-3)
+        np.testing.assert_allclose(db[:C].cpu().numpy(), b_t.grad.numpy(), rtol=2e-4, atol=1e-3)
+        assert torch.all(dx[:, C:] == 0)
+    # max pooling and its gradient
+    B, H, W = 2, 8, 4
+    xp = torch.zeros(B * H * W, ld, device='cuda'); xp[:, :C] = torch.randn(B * H * W, C, device='cuda')
+    yp = torch.empty(B * (H // 2) * (W // 2), ld, device='cuda')
+    ops.maxpool2(xp, yp, B, H, W, C)
+    xt = xp[:, :C].cpu().view(B, H, W, C).permute(0, 3, 1, 2).clone().requires_grad_(True)
+    yt = torch.nn.functional.max_pool2d(xt, 2)
+    np.testing.assert_array_equal(yp[:, :C].cpu().view(B, H // 2, W // 2, C).permute(0, 3, 1, 2).numpy(), yt.detach().numpy())
+    dyp = torch.zeros_like(yp); dyp[:, :C] = torch.randn(yp.shape[0], C, device='cuda')
+    yt.backward(dyp[:, :C].cpu().view(B, H // 2, W // 2, C).permute(0, 3, 1, 2))
+    dxp = torch.empty_like(xp)
+    ops.maxpool2_bwd(xp, dyp, dxp, B, H, W, C)
+    np.testing.assert_array_equal(dxp[:, :C].cpu().view(B, H, W, C).permute(0, 3, 1, 2).numpy(), xt.grad.numpy())
+
+
+def test_unet_forward_backward_matches_oracle(mods):
+    models, ops = mods
+    B, N = 2, 8192                       # 64 frames x 128 bins (the reference uses 16384 -> 128 x 128)
+    wav, masks, mean, std, T, _ = _inputs(B, N, 2)
+    seq = np.array([T, T - 3])
+    params = OU.init_params(3)
+    rng = np.random.default_rng(4)
+    for k in params:                      # non-trivial bn parameters and biases
+        if k.endswith('gamma'):
+            params[k] = rng.uniform(0.7, 1.3, params[k].shape).astype(np.float32)
+        elif k.endswith('beta') or k.endswith('/b'):
+            params[k] = rng.normal(0, 0.1, params[k].shape).astype(np.float32)
+    m = models.UNetFConvModel(seq, wav, masks, mean, std, 0.0, _cfg(N))
+    m.variables.load_flat(m.layout.flatten_params(params))
+    x_in = m.net_inputs.cpu().numpy()
+    tgt = m.target_spec_norm.cpu().numpy()
+    st = OF.get_stft(wav, window_size=16, step_size=8, n_fft=256)[:, :, :128]
+    ref_norm = (OF.get_spectrogram(st, log=True) - mean) / std
+    assert np.sqrt(np.mean((tgt - ref_norm) ** 2)) < 1e-4
+    assert np.sqrt(np.mean((x_in - ref_norm * masks) ** 2)) < 1e-4
+    ref = OU.forward_backward(ref_norm * masks, ref_norm, seq, params)
+    pred = m.prediction.cpu().numpy()
+    assert pred.shape == ref['prediction'].shape == (B, T, 128)
+    assert np.sqrt(np.mean((pred - ref['prediction']) ** 2)) < 2e-4
+    assert np.all(pred[1, T - 3:] == 0)
+    assert float(m.loss_func) == pytest.approx(ref['loss_func'], rel=5e-4)
+    got = m.gradients.cpu().numpy().astype(np.float64)
+    for name, shape, off in m.layout.ref_entries:
+        g = got[off:off + int(np.prod(shape))].reshape(shape)
+        r = ref['grads'][name]
+        scale = np.abs(r).max() + 1e-12
+        if name.endswith('/b') and (name[:-2] + '/bn/gamma') in params:
+            assert np.abs(g).max() < 1e-6          # a bias in front of batch norm has zero gradient
+            continue
+        assert np.abs(g - r).max() <= 5e-3 * scale, (name, np.abs(g - r).max(), scale)
+    # three Adam steps reduce the loss and track the oracle's trajectory
+    losses = []
+    for _ in range(3):
+        m.feed(sequence_lengths=seq, target_sources=wav, masks=masks)
+        losses.append(float(m.loss))
+        m.train_op
+    assert losses[2] < losses[0]
+    wavs = m.enhanced_sources_oracle_phase
+    assert wavs.shape == (B, N) and torch.isfinite(wavs).all()
