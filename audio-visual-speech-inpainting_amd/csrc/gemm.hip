@@ -302,6 +302,209 @@ __global__ __launch_bounds__(256, (BK == 16 && MI == 2) ? 4 : 2) void gemm_kerne
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// LDS-DMA variant (128 x 128 x 16 tiles, 3-stage ring).  Operand tiles go global -> LDS with
+// global_load_lds_dwordx4: no VGPR staging, no ds_write, nothing for the waves to wait on but a
+// counted s_waitcnt vmcnt(4) that leaves the NEXT tile's four DMAs in flight across the barrier.
+// Measured against the register-staged loop (M = 524288, N = 2048, TFLOP/s): K=256 115 vs 110,
+// K=512 131 vs 126, K=4096 135 vs 132; A^T B (weight gradients) 32.5 vs 28.5 unsplit.  A B^T is
+// a tie (127.6 vs 128.9) and stays on the register path.  What still separates this from the
+// 148 TFLOP/s the same loop reaches with the DMA issue removed is not latency (dropping the
+// vmcnt wait changes nothing), not HBM traffic (an L2-resident source changes nothing) and not
+// operand data (all-zero inputs change nothing); tools/mfma_f32_lds.hip modes 7/8 reproduce it.
+// The DMA writes LDS linearly (wave-uniform base + lane * 16 B), so the LDS images are unpadded:
+//   "col" tile [16][128]: one instruction = two k-rows; fragment reads are ds_read_b32, lanes along x;
+//   "row" tile [128][16]: one instruction = 16 rows of 64 B; bank conflicts of the ds_read_b128
+//     fragment reads are removed by an XOR swizzle of the 16-byte chunk index with (row >> 2) & 3,
+//     applied on the SOURCE address of each lane (same 64-byte segment, coalescing unchanged) and
+//     on the read address -- never on the LDS destination.
+// Needs the reduction length to be a multiple of 16; other shapes take the register-staged kernel.
+// ------------------------------------------------------------------------------------------
+typedef const __attribute__((address_space(1))) void* gvoid_t;
+typedef __attribute__((address_space(3))) void* lvoid_t;
+
+// One 16-byte-per-lane global -> LDS DMA (LDS address = M0 + lane * 16).  Written as inline asm
+// rather than __builtin_amdgcn_global_load_lds on purpose: for the builtin the compiler cannot
+// prove that later ds_reads do not alias the DMA's destination and puts s_waitcnt vmcnt(0) in
+// front of them, which serialises every tile on the DMA just issued.  The kernel counts vmcnt
+// itself (the DMAs are the only vector-memory operations in its main loop).
+__device__ __forceinline__ void dma16(const float* src, uint32_t lds_byte_addr) {
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(src), "s"(lds_byte_addr) : "memory", "m0");
+}
+
+template <bool TA, bool TB>
+__global__ __launch_bounds__(256, 3) void gemm_dma_kernel(const GemmArgs g) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int BK = 16, BM = 128, TILE = 128 * 16, NST = 3;
+    float* sA = reinterpret_cast<float*>(smem);
+    float* sB = sA + NST * TILE;
+    const uint32_t lds_a = (uint32_t)(uintptr_t)(lvoid_t)smem, lds_b = lds_a + NST * TILE * 4u;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int li = lane & 31, hi = lane >> 5;
+
+    const int nblk = g.m_blocks * g.n_blocks;
+    int bid = blockIdx.x;
+    {
+        const int q = nblk / AVSI_NUM_XCD, r = nblk % AVSI_NUM_XCD;
+        const int xcd = bid % AVSI_NUM_XCD, idx = bid / AVSI_NUM_XCD;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int bm = bid / g.n_blocks, bn = bid - bm * g.n_blocks;
+    const int m0 = bm * BM, n0 = bn * BN;
+    const int kbeg = blockIdx.z * g.k_split_len;
+    const int kend = min(g.K, kbeg + g.k_split_len);
+    const int nk = (kend - kbeg) / BK;
+    float* __restrict__ C = g.C + (int64_t)blockIdx.z * g.c_split_stride;
+
+    // per-lane source offsets (floats, relative to the tile origin) of this wave's two DMA pieces per operand
+    int64_t offa[2], offb[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int p = wave * 2 + j;  // 1-KiB piece of the 8-KiB tile
+        if (!TA) {  // row tile [m][k]
+            const int row = p * 16 + (lane >> 2), cl = (lane & 3) ^ ((row >> 2) & 3);
+            offa[j] = (int64_t)(min(m0 + row, g.M - 1) - m0) * g.lda + cl * 4;
+        } else {    // col tile [k][m]
+            const int x = min(m0 + 4 * (lane & 31), ((g.M + 3) & ~3) - 4) - m0;
+            offa[j] = (int64_t)(2 * p + (lane >> 5)) * g.lda + x;
+        }
+        if (TB) {   // row tile [n][k]
+            const int row = p * 16 + (lane >> 2), cl = (lane & 3) ^ ((row >> 2) & 3);
+            offb[j] = (int64_t)(min(n0 + row, g.N - 1) - n0) * g.ldb + cl * 4;
+        } else {    // col tile [k][n]
+            const int x = min(n0 + 4 * (lane & 31), ((g.N + 3) & ~3) - 4) - n0;
+            offb[j] = (int64_t)(2 * p + (lane >> 5)) * g.ldb + x;
+        }
+    }
+    const float* a_org = TA ? g.A + (int64_t)kbeg * g.lda + m0 : g.A + (int64_t)m0 * g.lda + kbeg;
+    const float* b_org = TB ? g.B + (int64_t)n0 * g.ldb + kbeg : g.B + (int64_t)kbeg * g.ldb + n0;
+    const int64_t a_step = TA ? (int64_t)BK * g.lda : BK, b_step = TB ? BK : (int64_t)BK * g.ldb;
+
+    auto issue = [&](int kt) {
+        const int st = kt % NST;
+        const float* ao = a_org + kt * a_step;
+        const float* bo = b_org + kt * b_step;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            dma16(ao + offa[j], lds_a + (uint32_t)(st * TILE + (wave * 2 + j) * 256) * 4u);
+            dma16(bo + offb[j], lds_b + (uint32_t)(st * TILE + (wave * 2 + j) * 256) * 4u);
+        }
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // fragments of one 8-deep k group (q = 0, 1) of a staged tile pair
+    auto rd = [&](int q, const float* a_s, const float* b_s, float (&a)[2][4], float (&b)[2][4]) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int row = wm * 64 + i * 32 + li;
+            if (!TA) {
+                const float4 v = *reinterpret_cast<const float4*>(a_s + row * 16 + (((2 * q + hi) ^ ((row >> 2) & 3)) << 2));
+                a[i][0] = v.x, a[i][1] = v.y, a[i][2] = v.z, a[i][3] = v.w;
+            } else {
+#pragma unroll
+                for (int s = 0; s < 4; ++s) a[i][s] = a_s[(8 * q + 4 * hi + s) * 128 + row];
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int col = wn * 64 + j * 32 + li;
+            if (TB) {
+                const float4 v = *reinterpret_cast<const float4*>(b_s + col * 16 + (((2 * q + hi) ^ ((col >> 2) & 3)) << 2));
+                b[j][0] = v.x, b[j][1] = v.y, b[j][2] = v.z, b[j][3] = v.w;
+            } else {
+#pragma unroll
+                for (int s = 0; s < 4; ++s) b[j][s] = b_s[(8 * q + 4 * hi + s) * 128 + col];
+            }
+        }
+    };
+    auto mm = [&](const float (&a)[2][4], const float (&b)[2][4]) {
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][s], b[j][s], acc[i][j], 0, 0, 0);
+    };
+
+    if (nk > 0) issue(0);
+    if (nk > 1) issue(1);
+    if (nk > 1)
+        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+
+    float af[2][2][4], bf[2][2][4];
+    for (int kt = 0; kt < nk; ++kt) {
+        // stage (kt+2)%3 was last read (tile kt-1) before the barrier of iteration kt-1
+        if (kt + 2 < nk) issue(kt + 2);
+        const float* a_s = sA + (kt % NST) * TILE;
+        const float* b_s = sB + (kt % NST) * TILE;
+        rd(0, a_s, b_s, af[0], bf[0]);
+        rd(1, a_s, b_s, af[1], bf[1]);
+        mm(af[0], bf[0]);
+        mm(af[1], bf[1]);
+        // tile kt+1 must have landed before anyone reads it; tile kt+2's DMAs (just issued) stay in flight
+        if (kt + 2 < nk)
+            asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+        else
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+    const bool accumulate = g.beta != 0.f;
+    float bv[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int col = n0 + wn * 64 + j * 32 + li;
+        bv[j] = (g.bias && col < g.N) ? g.bias[col] : 0.f;
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+            if (row >= g.M) continue;
+            int64_t orow = row;
+            if (g.row_map_bp > 0) {
+                const int t = row / g.row_map_bp, b = row - t * g.row_map_bp;
+                if (b >= g.row_map_b) continue;
+                orow = (int64_t)b * g.row_map_t + t;
+            }
+            const float rsc = g.row_scale ? g.row_scale[row] : 1.f;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int col = n0 + wn * 64 + j * 32 + li;
+                if (col >= g.N) continue;
+                float* c = C + orow * g.ldc + col;
+                float v = (g.alpha * acc[i][j][r] + bv[j]) * rsc;
+                if (accumulate) v += g.beta * *c;
+                *c = v;
+            }
+        }
+    }
+}
+
+template <bool TA, bool TB>
+int launch_dma(const GemmArgs& g, int splits, hipStream_t st) {
+    constexpr size_t lds = (size_t)2 * 3 * 128 * 16 * 4;   // 48 KiB: three stages of A and B
+    hipLaunchKernelGGL((gemm_dma_kernel<TA, TB>), dim3(g.m_blocks * g.n_blocks, 1, splits), dim3(256), lds, st, g);
+    return avsi_launch_status();
+}
+
 template <bool TA, bool TB, int BK, int MI>
 int launch(const GemmArgs& g, int splits, hipStream_t st) {
     constexpr int BM = 64 * MI;
@@ -363,6 +566,14 @@ int avsi_gemm_launch(int transA, int transB, int M, int N, int K, float alpha, c
     // "col" tiles read 4 consecutive x per lane and guard on the first: the ld padding up to a
     // multiple of 4 (checked above) keeps the tail addressable; such lanes feed unstored outputs.
     avsi_clear_error();
+    const char* env_dma = getenv("AVSI_GEMM_DMA");
+    const bool dma_ok = !(transB && !transA) && (K % 16 == 0) && (g.k_split_len % 16 == 0) && !env_bk && !env_mi && !(env_dma && atoi(env_dma) == 0);
+    if (dma_ok) {
+        if (!transA && !transB) return launch_dma<false, false>(g, splits, st);
+        if (!transA && transB) return launch_dma<false, true>(g, splits, st);
+        if (transA && !transB) return launch_dma<true, false>(g, splits, st);
+        return launch_dma<true, true>(g, splits, st);
+    }
     if (mi == 4) return dispatch<16, 4>(g, transA, transB, splits, st);   // 256 x 128 tiles exist with BK = 16 only (LDS)
     return bk == 16 ? dispatch<16, 2>(g, transA, transB, splits, st) : dispatch<32, 2>(g, transA, transB, splits, st);
 }

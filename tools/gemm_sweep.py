@@ -9,6 +9,11 @@ from avsi_amd import ops
 def t(M, N, K, ta=False, tb=False, reps=5):
     a = torch.randn((K, M) if ta else (M, K), device='cuda')
     b = torch.randn((N, K) if tb else (K, -(-N // 4) * 4), device='cuda')
+    fill = os.environ.get('AVSI_SWEEP_FILL')  # 'zero' / 'const': operand-data dependence of the MFMA rate
+    if fill == 'zero':
+        a.zero_(); b.zero_()
+    elif fill == 'const':
+        a.fill_(1.5); b.fill_(0.75)
     out = torch.empty(M, N, device='cuda')
     ops.gemm(a, b, out=out, trans_a=ta, trans_b=tb, m=M, n=N, k=K)
     torch.cuda.synchronize()

@@ -34,6 +34,18 @@ __global__ __launch_bounds__(256, 2) void k(float* out, int iters, const float4*
                 if (MODE == 4 || MODE == 5) {
                     for (int p = 0; p < 4; ++p) *reinterpret_cast<float4*>(sa + ((p * 64 + (tid >> 2)) % 128) * 36 + 4 * (tid & 3) + 16) = stage[p];
                 }
+                if (MODE == 8) {   // mode 7 with the GEMM's row-tile source pattern: 16 rows x 64 B per instruction, 16-KiB row pitch
+                    for (int p = 0; p < 4; ++p)
+                        __builtin_amdgcn_global_load_lds(
+                            (const __attribute__((address_space(1))) void*)(gsrc + ((((size_t)(blockIdx.x * 8 + wave * 2 + (p & 1)) * 16 + (lane >> 2)) * 1024 + (size_t)(it * 4 + q + (p >> 1)) * 4 + (lane & 3)) & ((1u << 24) - 1))),
+                            (__attribute__((address_space(3))) void*)(sdma + (wave * 4 + p) * 256), 16, 0, 0);
+                }
+                if (MODE == 9) {   // mode 7 with the DMA landing in the arrays the fragment reads use
+                    for (int p = 0; p < 4; ++p)
+                        __builtin_amdgcn_global_load_lds(
+                            (const __attribute__((address_space(1))) void*)(gsrc + (((size_t)(blockIdx.x * 997 + it * 8 + q * 2 + p) * 256 + tid) & ((1u << 24) - 1))),
+                            (__attribute__((address_space(3))) void*)((p < 2 ? sa : sb) + (wave * 2 + (p & 1)) * 256), 16, 0, 0);
+                }
                 if (MODE == 6 || MODE == 7) {   // LDS-DMA: global -> LDS without VGPR staging / ds_write (4 x 1 KiB per wave)
                     for (int p = 0; p < 4; ++p)
                         __builtin_amdgcn_global_load_lds(
@@ -53,8 +65,8 @@ __global__ __launch_bounds__(256, 2) void k(float* out, int iters, const float4*
 #pragma unroll
                     for (int j = 0; j < 2; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[MODE == 0 ? 0 : cq][i][s], bf[MODE == 0 ? 0 : cq][j][s], acc[i][j], 0, 0, 0);
-            if (MODE >= 3 && MODE != 7 && (q & 1) == 1) __syncthreads();
-            if (MODE == 7 && (q & 1) == 1) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            if (MODE >= 3 && MODE < 7 && (q & 1) == 1) __syncthreads();
+            if (MODE >= 7 && (q & 1) == 1) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
         }
     }
     float sum = 0.f;
@@ -79,6 +91,6 @@ template <int MODE> void run(float* d, int blocks, const float4* g) {
 int main() {
     float* d; (void)hipMalloc(&d, 2048 * 256 * 4);
     float4* g; (void)hipMalloc(&g, (size_t)(1u << 24) * 16); (void)hipMemset(g, 0, (size_t)(1u << 24) * 16);
-    for (int blocks : {256, 512, 1024}) { run<0>(d, blocks, g); run<1>(d, blocks, g); run<3>(d, blocks, g); run<4>(d, blocks, g); run<5>(d, blocks, g); run<6>(d, blocks, g); run<7>(d, blocks, g); }
+    for (int blocks : {256, 512, 1024}) { run<0>(d, blocks, g); run<1>(d, blocks, g); run<3>(d, blocks, g); run<4>(d, blocks, g); run<5>(d, blocks, g); run<6>(d, blocks, g); run<7>(d, blocks, g); run<8>(d, blocks, g); run<9>(d, blocks, g); }
     return 0;
 }
