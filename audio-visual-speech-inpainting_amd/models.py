@@ -14,6 +14,7 @@ padded to a multiple of 32 (whole MFMA row tiles) and channels padded (257 -> 26
 250 -> 256 hidden units per direction); padded hidden units are exactly zero by construction.
 """
 import math
+import os
 import sys
 
 import numpy as np
@@ -102,8 +103,32 @@ class BLSTMVariables:
         np.savez(path + '.npz', **arrays)
         return path + '.npz'
 
+    def save_tf(self, prefix, scope):
+        """Write a TensorFlow tensor-bundle checkpoint (``prefix.index`` / ``.data-00000-of-00001``)
+        with the reference's variable names under variable scope ``scope`` (= config['model'],
+        training.py:82) -- what tf.train.Saver(model.all_vars).save writes (training.py:334-340)."""
+        from . import tf_checkpoint
+        flat = self.flat.cpu().numpy()
+        m = self.adam_m.cpu().numpy() if self.adam_m is not None else None
+        v = self.adam_v.cpu().numpy() if self.adam_v is not None else None
+        return tf_checkpoint.write_bundle(prefix, tf_checkpoint.export_variables(
+            self.layout, flat, scope, m, v, self.global_step))
+
+    def restore_tf(self, prefix):
+        """Load a TensorFlow tensor-bundle checkpoint written by the reference (or by save_tf)."""
+        from . import tf_checkpoint
+        flat, m, v, step = tf_checkpoint.import_variables(tf_checkpoint.read_bundle(prefix), self.layout)
+        self.load_flat(flat)
+        self.global_step = step
+        self.adam_m = torch.from_numpy(m).to(self.device) if m is not None else None
+        self.adam_v = torch.from_numpy(v).to(self.device) if v is not None else None
+
     def restore(self, path):
-        """Load a checkpoint written by save(); ValueError if it is not one (reference: exit(2))."""
+        """Load a checkpoint: ``<path>.npz`` written by save(), or -- when ``<path>.index`` exists --
+        a TensorFlow tensor bundle.  ValueError if it is neither (reference: exit(2))."""
+        from . import tf_checkpoint
+        if not path.endswith('.npz') and not os.path.isfile(path + '.npz') and tf_checkpoint.is_bundle(path):
+            return self.restore_tf(path)
         fname = path if path.endswith('.npz') else path + '.npz'
         try:
             ck = np.load(fname)

@@ -48,10 +48,17 @@ def build_model(config, mean, std, variables=None, is_training=True):
     return model
 
 
-def train(config_file):
+def train(config_file, checkpoint_format=None):
     """
     Train the speech inpainting model.
+
+    checkpoint_format: 'npz' (default) or 'tf' -- TensorFlow tensor bundles under the reference's
+    variable names, readable by tf.train.Saver (also selectable with AVSI_CHECKPOINT_FORMAT).
+    Restoring (``model_ckp``) accepts either format.
     """
+    checkpoint_format = checkpoint_format or os.environ.get('AVSI_CHECKPOINT_FORMAT', 'npz')
+    if checkpoint_format not in ('npz', 'tf'):
+        raise ValueError("checkpoint_format must be 'npz' or 'tf', got %r" % (checkpoint_format,))
     config = check_trainconfiguration(load_configfile(config_file))
     rank, world = parallel.init()
     chief = rank == 0
@@ -81,6 +88,11 @@ def train(config_file):
     audio_feat_std = np.load(config['audio_feat_std'])
     model = build_model(config, audio_feat_mean, audio_feat_std)
     print('Model building done.')
+
+    def save_checkpoint(prefix):
+        if checkpoint_format == 'tf':
+            return model.variables.save_tf(prefix, config['model'])
+        return model.variables.save(prefix)
 
     if chief:
         os.makedirs(checkpoints_dir, exist_ok=True)
@@ -185,7 +197,7 @@ def train(config_file):
                 print('Step[{:7d}] Loss[{:3.5f}|{:3.5f}] LR[{:.6f}] Epoch training time[{:.2f}]'.format(
                     tot_step, train_avg_loss, train_avg_loss_fn, lr, time() - epoch_start_time))
             if chief and n_step % 1000 == 0:
-                print('Model checkpoint saved in file %s' % model.variables.save(os.path.join(checkpoints_dir, 'ckpt')))
+                print('Model checkpoint saved in file %s' % save_checkpoint(os.path.join(checkpoints_dir, 'ckpt')))
 
         if chief:
             print('Start validation set evaluation...')
@@ -220,7 +232,7 @@ def train(config_file):
                 val_avg_loss, best_val_loss, best_val_checkpoint[0], best_val_checkpoint[1]))
         if best_val_checkpoint == (0, 0) or val_avg_loss < best_val_loss:
             if chief:
-                print('Model saved in file %s' % model.variables.save(os.path.join(checkpoints_dir, 'sinet')))
+                print('Model saved in file %s' % save_checkpoint(os.path.join(checkpoints_dir, 'sinet')))
             best_val_checkpoint = (epoch_counter, tot_step)
             best_val_loss = val_avg_loss
             cneg_epochs = 0

@@ -1,0 +1,304 @@
+"""TensorFlow tensor-bundle checkpoints without TensorFlow.
+
+No TensorFlow here and no checkpoint in the reference: these tests pin the codec by (1) round trips,
+(2) the protobuf runtime's own view of BundleHeaderProto / BundleEntryProto, (3) an index file
+assembled byte by byte in the test, independently of the writer, (4) corruption detection and
+(5) the variable-name mapping of SURVEY App. C."""
+import os
+import struct
+
+import numpy as np
+import pytest
+
+import avsi_amd  # noqa: F401
+from avsi_amd import tf_checkpoint as tc
+from avsi_amd.blstm_layout import ParamLayout
+from avsi_amd.tfrecord_io import masked_crc32c
+
+
+def test_table_round_trip_many_blocks(tmp_path):
+    rng = np.random.default_rng(0)
+    keys = sorted({('scope/layer_%03d/var_%d' % (rng.integers(0, 200), rng.integers(0, 50))).encode() for _ in range(2000)})
+    items = [(k, bytes(rng.integers(0, 256, size=int(rng.integers(0, 40)), dtype=np.uint8))) for k in keys]
+    p = str(tmp_path / 't.index')
+    tc.write_table(p, items, block_size=512)          # dozens of data blocks, restarts every 16 entries
+    assert tc.read_table(p) == items
+    raw = open(p, 'rb').read()
+    assert raw[-8:] == bytes.fromhex('57fb808b247547db')   # LevelDB kTableMagicNumber, little endian
+    # prefix compression really happened: the file is smaller than the keys + values alone
+    assert len(raw) < sum(len(k) + len(v) for k, v in items)
+
+
+def test_table_rejects_unsorted_keys(tmp_path):
+    with pytest.raises(ValueError):
+        tc.write_table(str(tmp_path / 't'), [(b'b', b''), (b'a', b'')])
+
+
+def test_bundle_round_trip(tmp_path):
+    rng = np.random.default_rng(1)
+    v = {'m/kernel': rng.standard_normal((7, 12)).astype(np.float32), 'm/bias': np.zeros(12, np.float32),
+         'm/Variable': np.array(41, dtype=np.int32), 'm/beta1_power': np.array(0.9 ** 42, dtype=np.float32),
+         'm/steps64': np.arange(5, dtype=np.int64), 'm/empty': np.zeros((0, 3), np.float32)}
+    prefix = str(tmp_path / 'sinet')
+    assert tc.write_bundle(prefix, v) == prefix
+    assert tc.is_bundle(prefix) and os.path.isfile(prefix + '.data-00000-of-00001')
+    assert 'model_checkpoint_path: "sinet"' in open(str(tmp_path / 'checkpoint')).read()
+    got = tc.read_bundle(prefix)
+    assert sorted(got) == sorted(v)
+    for k in v:
+        assert got[k].dtype == v[k].dtype and got[k].shape == v[k].shape
+        np.testing.assert_array_equal(got[k], v[k])
+    listed = {n: (s, d) for n, s, d in tc.list_variables(prefix)}
+    assert listed['m/kernel'] == ((7, 12), np.dtype('float32')) and listed['m/Variable'] == ((), np.dtype('int32'))
+
+
+def _bundle_messages():
+    """BundleHeaderProto / BundleEntryProto / TensorShapeProto / VersionDef declared to the protobuf runtime."""
+    pb = pytest.importorskip('google.protobuf')
+    from google.protobuf import descriptor_pb2, descriptor_pool, message_factory
+    f = descriptor_pb2.FileDescriptorProto(name='avsi_bundle_test.proto', package='avsitest', syntax='proto3')
+    T = descriptor_pb2.FieldDescriptorProto
+
+    def msg(name, fields):
+        m = f.message_type.add(name=name)
+        for fname, num, typ, label, tname in fields:
+            fd = m.field.add(name=fname, number=num, type=typ, label=label)
+            if tname:
+                fd.type_name = '.avsitest.' + tname
+        return m
+    msg('Dim', [('size', 1, T.TYPE_INT64, T.LABEL_OPTIONAL, None), ('name', 2, T.TYPE_STRING, T.LABEL_OPTIONAL, None)])
+    msg('Shape', [('dim', 2, T.TYPE_MESSAGE, T.LABEL_REPEATED, 'Dim'), ('unknown_rank', 3, T.TYPE_BOOL, T.LABEL_OPTIONAL, None)])
+    msg('VersionDef', [('producer', 1, T.TYPE_INT32, T.LABEL_OPTIONAL, None), ('min_consumer', 2, T.TYPE_INT32, T.LABEL_OPTIONAL, None)])
+    msg('Header', [('num_shards', 1, T.TYPE_INT32, T.LABEL_OPTIONAL, None), ('endianness', 2, T.TYPE_INT32, T.LABEL_OPTIONAL, None),
+                   ('version', 3, T.TYPE_MESSAGE, T.LABEL_OPTIONAL, 'VersionDef')])
+    msg('Entry', [('dtype', 1, T.TYPE_INT32, T.LABEL_OPTIONAL, None), ('shape', 2, T.TYPE_MESSAGE, T.LABEL_OPTIONAL, 'Shape'),
+                  ('shard_id', 3, T.TYPE_INT32, T.LABEL_OPTIONAL, None), ('offset', 4, T.TYPE_INT64, T.LABEL_OPTIONAL, None),
+                  ('size', 5, T.TYPE_INT64, T.LABEL_OPTIONAL, None), ('crc32c', 6, T.TYPE_FIXED32, T.LABEL_OPTIONAL, None)])
+    pool = descriptor_pool.DescriptorPool()
+    pool.Add(f)
+    get = getattr(message_factory, 'GetMessageClass', None)
+    cls = (lambda n: get(pool.FindMessageTypeByName('avsitest.' + n))) if get else (
+        lambda n: message_factory.MessageFactory(pool).GetPrototype(pool.FindMessageTypeByName('avsitest.' + n)))
+    return cls('Header'), cls('Entry')
+
+
+def test_bundle_protos_agree_with_protobuf_runtime():
+    Header, Entry = _bundle_messages()
+    h = Header()
+    h.ParseFromString(tc._encode_header(1))
+    assert h.num_shards == 1 and h.endianness == 0 and h.version.producer == 1
+    e = Entry()
+    e.ParseFromString(tc._encode_entry(tc.DT_FLOAT, (500, 257), 0, 4096, 500 * 257 * 4, 0xdeadbeef))
+    assert (e.dtype, [d.size for d in e.shape.dim], e.shard_id, e.offset, e.size, e.crc32c) == (
+        1, [500, 257], 0, 4096, 514000, 0xdeadbeef)
+    # and the other way: a message serialised by the runtime decodes to the same fields
+    e2 = Entry(dtype=3, shard_id=2, offset=7, size=4, crc32c=5)
+    d = tc._decode_entry(e2.SerializeToString())
+    assert (d['dtype'], d['shape'], d['shard_id'], d['offset'], d['size'], d['crc32c']) == (3, [], 2, 7, 4, 5)
+    e3 = Entry(dtype=1, size=24)
+    e3.shape.dim.add(size=2)
+    e3.shape.dim.add(size=3)
+    assert tc._decode_entry(e3.SerializeToString())['shape'] == [2, 3]
+
+
+def _vi(n):
+    out = bytearray()
+    while True:
+        b = n & 0x7f
+        n >>= 7
+        out.append(b | (0x80 if n else 0))
+        if not n:
+            return bytes(out)
+
+
+def test_reads_hand_assembled_bundle(tmp_path):
+    """An index file built here byte by byte (two data blocks, shared-prefix keys), not by write_table."""
+    a = np.array([1.5, -2.0, 3.25], dtype='<f4')
+    b = np.array([[7, 8]], dtype='<i4')
+    data = a.tobytes() + b.tobytes()
+    prefix = str(tmp_path / 'ckpt')
+    open(prefix + '.data-00000-of-00001', 'wb').write(data)
+    header = b'\x08\x01' + b'\x1a\x02\x08\x01'                                  # num_shards=1, version{producer=1}
+    ent_a = (b'\x08\x01' + b'\x12\x04' + b'\x12\x02\x08\x03' + b'\x28\x0c' +     # DT_FLOAT, shape{dim{size 3}}, size 12
+             b'\x35' + struct.pack('<I', masked_crc32c(a.tobytes())))
+    ent_b = (b'\x08\x03' + b'\x12\x08' + b'\x12\x02\x08\x01' + b'\x12\x02\x08\x02' + b'\x20\x0c' + b'\x28\x08' +
+             b'\x35' + struct.pack('<I', masked_crc32c(b.tobytes())))           # DT_INT32, [1,2], offset 12, size 8
+
+    def entry(shared, suffix, value):
+        return _vi(shared) + _vi(len(suffix)) + _vi(len(value)) + suffix + value
+
+    def block(entries, restarts):
+        body = b''.join(entries) + b''.join(struct.pack('<I', r) for r in restarts) + struct.pack('<I', len(restarts))
+        return body, body + b'\x00' + struct.pack('<I', masked_crc32c(body + b'\x00'))
+
+    e0 = entry(0, b'', header)
+    e1 = entry(0, b'net/var_a', ent_a)
+    blk1, raw1 = block([e0, e1], [0])
+    e2 = entry(0, b'net/var_b', ent_b)
+    blk2, raw2 = block([e2], [0])
+    meta, rawm = block([], [0])
+    off2 = len(raw1)
+    offm = off2 + len(raw2)
+    idx_entries = [entry(0, b'net/var_a', _vi(0) + _vi(len(blk1))), entry(0, b'net/var_b', _vi(off2) + _vi(len(blk2)))]
+    idx, rawi = block(idx_entries, [0, len(idx_entries[0])])
+    offi = offm + len(rawm)
+    footer = _vi(offm) + _vi(len(meta)) + _vi(offi) + _vi(len(idx))
+    footer += b'\x00' * (40 - len(footer)) + bytes.fromhex('57fb808b247547db')
+    open(prefix + '.index', 'wb').write(raw1 + raw2 + rawm + rawi + footer)
+    got = tc.read_bundle(prefix)
+    assert sorted(got) == ['net/var_a', 'net/var_b']
+    np.testing.assert_array_equal(got['net/var_a'], a)
+    np.testing.assert_array_equal(got['net/var_b'], b)
+    # the writer produces a file the same reader decodes to the same content
+    tc.write_bundle(str(tmp_path / 'again'), got, write_state=False)
+    again = tc.read_bundle(str(tmp_path / 'again'))
+    np.testing.assert_array_equal(again['net/var_b'], b)
+
+
+def test_corruption_is_detected(tmp_path):
+    prefix = str(tmp_path / 'c')
+    tc.write_bundle(prefix, {'x': np.arange(64, dtype=np.float32)})
+    dpath = prefix + '.data-00000-of-00001'
+    raw = bytearray(open(dpath, 'rb').read())
+    raw[17] ^= 0x40
+    open(dpath, 'wb').write(bytes(raw))
+    with pytest.raises(tc.CheckpointError, match='checksum'):
+        tc.read_bundle(prefix)
+    assert tc.read_bundle(prefix, verify=False)['x'].shape == (64,)
+    tc.write_bundle(prefix, {'x': np.arange(64, dtype=np.float32)})
+    raw = bytearray(open(prefix + '.index', 'rb').read())
+    raw[3] ^= 0x01
+    open(prefix + '.index', 'wb').write(bytes(raw))
+    with pytest.raises(tc.CheckpointError):
+        tc.read_bundle(prefix)
+    open(prefix + '.index', 'wb').write(b'not a table')
+    with pytest.raises(tc.CheckpointError):
+        tc.read_bundle(prefix)
+    with pytest.raises(tc.CheckpointError):
+        tc.read_bundle(str(tmp_path / 'missing'))
+    os.remove(dpath)
+    tc.write_table(prefix + '.index', [(b'', tc._encode_header(1)), (b'x', tc._encode_entry(1, (4,), 0, 0, 16, 0))])
+    with pytest.raises(tc.CheckpointError):
+        tc.read_bundle(prefix)
+
+
+def _layout():
+    return ParamLayout(9, net_dim=(6, 6), audio_feat_dim=5)
+
+
+def test_variable_names_follow_the_reference_scoping():
+    lay = _layout()
+    names = tc.tf_variable_names(lay, 'av-blstm')
+    assert names['cell_1/bw/kernel'] == ('av-blstm/cudnn_lstm/stack_bidirectional_rnn/cell_1/bidirectional_rnn/bw/'
+                                         'cudnn_compatible_lstm_cell/kernel')
+    assert names['logits/weights'] == 'av-blstm/logits/weights' and names['logits/biases'] == 'av-blstm/logits/biases'
+    assert len(names) == len(lay.ref_entries)
+
+
+def test_export_import_round_trip(tmp_path):
+    lay = _layout()
+    rng = np.random.default_rng(2)
+    flat = rng.standard_normal(lay.ref_size).astype(np.float32)
+    m = rng.standard_normal(lay.ref_size).astype(np.float32)
+    v = rng.random(lay.ref_size).astype(np.float32)
+    prefix = str(tmp_path / 'sinet')
+    tc.write_bundle(prefix, tc.export_variables(lay, flat, 'a-blstm', m, v, global_step=123))
+    bundle = tc.read_bundle(prefix)
+    assert bundle['a-blstm/Variable'] == 123
+    np.testing.assert_allclose(bundle['a-blstm/beta1_power'], 0.9 ** 124, rtol=1e-6)
+    f2, m2, v2, step = tc.import_variables(bundle, lay)
+    np.testing.assert_array_equal(f2, flat)
+    np.testing.assert_array_equal(m2, m)
+    np.testing.assert_array_equal(v2, v)
+    assert step == 123
+    # weights-only checkpoint (a CudnnLSTM-trained model keeps its slots in the opaque layout)
+    weights_only = {k: a for k, a in bundle.items() if not k.endswith(('/Adam', '/Adam_1'))}
+    weights_only['a-blstm/cudnn_lstm/opaque_kernel/Adam'] = np.zeros(17, np.float32)
+    f3, m3, v3, _ = tc.import_variables(weights_only, lay)
+    np.testing.assert_array_equal(f3, flat)
+    assert m3 is None and v3 is None
+    # a different enclosing scope (e.g. the two-step model's inner scope) still maps by suffix
+    rescoped = {('outer/' + k): a for k, a in weights_only.items()}
+    np.testing.assert_array_equal(tc.import_variables(rescoped, lay)[0], flat)
+
+
+def test_import_errors():
+    lay = _layout()
+    flat = np.zeros(lay.ref_size, np.float32)
+    bundle = tc.export_variables(lay, flat, 's')
+    bad = dict(bundle)
+    del bad['s/logits/biases']
+    with pytest.raises(tc.CheckpointError, match='lacks'):
+        tc.import_variables(bad, lay)
+    bad = dict(bundle)
+    bad['s/logits/weights'] = np.zeros((3, 3), np.float32)
+    with pytest.raises(tc.CheckpointError, match='shape'):
+        tc.import_variables(bad, lay)
+
+
+def test_unet_variable_names():
+    from avsi_amd.unet_model import UNetLayout
+    lay = UNetLayout()
+    rng = np.random.default_rng(3)
+    flat = rng.standard_normal(lay.ref_size).astype(np.float32)
+    bundle, k, j = {}, 0, 0
+    for name, ksz, ci, co, bn, _ in lay.specs:          # creation order: w, b, (batch_normalization*)
+        sfx = '' if k == 0 else '_%d' % k
+        bundle['unet/w' + sfx] = np.array(lay.ref_view(flat, name + '/w'))
+        bundle['unet/b' + sfx] = np.array(lay.ref_view(flat, name + '/b'))
+        if bn:
+            bsfx = '' if j == 0 else '_%d' % j
+            for v in ('gamma', 'beta'):
+                bundle['unet/batch_normalization%s/%s' % (bsfx, v)] = np.array(lay.ref_view(flat, '%s/bn/%s' % (name, v)))
+            bundle['unet/batch_normalization%s/moving_mean' % bsfx] = np.zeros(co, np.float32)
+            j += 1
+        k += 1
+    f2, _, _, _ = tc.import_variables(bundle, lay)
+    np.testing.assert_array_equal(f2, flat)
+
+
+def test_unet_export_names_round_trip():
+    from avsi_amd.unet_model import UNetLayout
+    lay = UNetLayout()
+    flat = np.random.default_rng(4).standard_normal(lay.ref_size).astype(np.float32)
+    bundle = tc.export_variables(lay, flat, 'unet')
+    assert 'unet/w' in bundle and 'unet/w_12' in bundle and 'unet/batch_normalization_9/gamma' in bundle
+    np.testing.assert_array_equal(tc.import_variables(bundle, lay)[0], flat)
+
+
+@pytest.mark.gpu
+def test_model_save_tf_restore(tmp_path):
+    """A model saved as a TensorFlow bundle restores (weights, Adam slots, step) into a fresh model
+    through the ordinary restore() path the drivers use, and predicts the same."""
+    import torch
+    from avsi_amd import models
+    cfg = {'audio_feat_dim': 257, 'audio_len': 48000, 'net_dim': [250, 250, 250], 'optimizer_type': 'adam',
+           'starter_learning_rate': 1e-3, 'lr_updating_steps': 1000, 'lr_decay': 1.0, 'batch_size': 3, 'l2': 0.0}
+    rng = np.random.default_rng(5)
+    B, T = 3, 250
+    wav = np.clip(np.round(rng.normal(0, 3000, (B, 48000))), -32768, 32767).astype(np.float32)
+    mask = np.ones((B, T, 257), np.float32)
+    mask[:, 100:133] = 0
+    mean, std = rng.normal(0, 1, 257).astype(np.float32), (1 + rng.random(257)).astype(np.float32)
+    seq = np.full(B, T, np.int32)
+
+    def make(seed):
+        m = models.StackedBLSTMModel(seq, wav, mask, mean, std, 0.0, cfg, input='a', is_training=True,
+                                     variables=models.BLSTMVariables(models.ParamLayout(257), seed=seed))
+        m.build_graph('a-blstm')
+        return m
+    m1 = make(0)
+    m1.train_op          # one Adam step so that slots and global_step exist
+    prefix = str(tmp_path / 'sinet')
+    assert m1.variables.save_tf(prefix, 'a-blstm') == prefix
+    names = dict((n, s) for n, s, _ in tc.list_variables(prefix))
+    k0 = 'a-blstm/cudnn_lstm/stack_bidirectional_rnn/cell_0/bidirectional_rnn/fw/cudnn_compatible_lstm_cell/kernel'
+    assert names[k0] == (507, 1000) and names[k0 + '/Adam_1'] == (507, 1000) and names['a-blstm/logits/weights'] == (500, 257)
+    m2 = make(1)
+    m2.variables.restore(prefix)
+    assert m2.variables.global_step == m1.variables.global_step == 1
+    assert torch.equal(m2.variables.flat, m1.variables.flat)
+    assert torch.equal(m2.variables.adam_m, m1.variables.adam_m) and torch.equal(m2.variables.adam_v, m1.variables.adam_v)
+    m1.feed(seq, wav, mask)
+    m2.feed(seq, wav, mask)
+    assert torch.equal(torch.as_tensor(m1.prediction), torch.as_tensor(m2.prediction))
