@@ -28,7 +28,14 @@ def packed_gate_col(direction, gate, unit):
 
 
 class ParamLayout:
-    def __init__(self, input_dim, net_dim=(250, 250, 250), audio_feat_dim=257):
+    """``side = (layer, dim)`` declares a per-utterance side input (a speaker embedding) that the
+    reference concatenates, tiled over time, to the input of BLSTM layer ``layer``
+    (models.py:848-851,1205-1209 for layer 0; :905-906,1247-1249 after ``integration_layer``
+    layers).  Its rows of the TF kernel sit between the layer's input rows and the recurrent rows;
+    the kernels never see the tiled tensor -- the rows are packed apart as ``we`` [dim_p, 2048] and
+    enter the gate pre-activations as a per-utterance bias (see StackedBLSTMModel._forward)."""
+
+    def __init__(self, input_dim, net_dim=(250, 250, 250), audio_feat_dim=257, side=None):
         net_dim = tuple(int(h) for h in net_dim)
         if len(set(net_dim)) != 1 or net_dim[0] > HP or net_dim[0] < 1:
             raise ValueError("the gfx950 BLSTM kernels need equal layer sizes <= %d, got %r" % (HP, net_dim))
@@ -37,6 +44,10 @@ class ParamLayout:
         self.num_layers = len(net_dim)
         self.F = F = int(audio_feat_dim)
         self.ldp = round_up(F, 4)                      # padded row pitch of the projection matrix
+        self.side = None if side is None else (int(side[0]), int(side[1]))
+        if self.side is not None and not (0 <= self.side[0] < self.num_layers and self.side[1] > 0):
+            raise ValueError("side input must name an existing layer and a positive width, got %r" % (side,))
+        self.side_p = round_up(self.side[1], 8) if self.side else 0
 
         # ---- reference layout
         self.ref_entries = []                          # (name, shape, offset)
@@ -45,8 +56,9 @@ class ParamLayout:
         d = self.input_dim
         for li in range(self.num_layers):
             self.in_dims.append(d)
+            e = self.side_dim(li)
             for dname in ('fw', 'bw'):
-                for vname, shape in (('kernel', (d + H, 4 * H)), ('bias', (4 * H,))):
+                for vname, shape in (('kernel', (d + e + H, 4 * H)), ('bias', (4 * H,))):
                     self.ref_entries.append(('cell_%d/%s/%s' % (li, dname, vname), shape, off))
                     off += int(np.prod(shape))
             d = 2 * H
@@ -71,6 +83,8 @@ class ParamLayout:
             alloc('b%d' % li, (2 * GP,))
             alloc('wh%d' % li, (2 * WH_FLOATS,))
             alloc('whb%d' % li, (2 * WH_FLOATS,))      # same numbers, fragment order of dz . Wh^T (BPTT)
+            if self.side_dim(li):
+                alloc('we', (self.side_p, 2 * GP))
         alloc('pw', (2 * HP, self.ldp))
         alloc('pb', (self.ldp,))
         self.packed_size = poff
@@ -89,6 +103,8 @@ class ParamLayout:
             galloc('dwx%d' % li, (self.kp[li], 2 * GP))
             galloc('db%d' % li, (2 * GP,))
             galloc('dwh%d' % li, (2, HP, GP))
+            if self.side_dim(li):
+                galloc('dwe', (self.side_p, 2 * GP))
         galloc('dpw', (2 * HP, self.ldp))
         galloc('dpb', (self.ldp,))
         self.gpacked_size = goff
@@ -96,7 +112,10 @@ class ParamLayout:
 
     def signature(self):
         """Shape signature stored in checkpoints."""
-        return [self.input_dim, self.H, self.num_layers, self.F]
+        return [self.input_dim, self.H, self.num_layers, self.F] + (list(self.side) if self.side else [])
+
+    def side_dim(self, li):
+        return self.side[1] if self.side is not None and self.side[0] == li else 0
 
     # ------------------------------------------------------------------------------
     def input_row_map(self, li):
@@ -115,7 +134,8 @@ class ParamLayout:
         idx = np.full(self.packed_size, Z, dtype=np.int64)
         u = np.arange(H)
         for li in range(self.num_layers):
-            D = self.in_dims[li]
+            E = self.side_dim(li)
+            D = self.in_dims[li] + E                                    # first recurrent row of the TF kernel
             rmap = self.input_row_map(li)
             wx_off, (kp, _) = self.packed['wx%d' % li]
             b_off, _ = self.packed['b%d' % li]
@@ -130,6 +150,11 @@ class ParamLayout:
                     src = k_off + rmap[rows][:, None] * (4 * H) + (g * H + u)[None, :]
                     idx[wx_off + rows[:, None] * (2 * GP) + cols[None, :]] = src
                     idx[b_off + cols] = bias_off + g * H + u
+                    if E:
+                        we_off, _ = self.packed['we']
+                        er = np.arange(E)
+                        idx[we_off + er[:, None] * (2 * GP) + cols[None, :]] = (
+                            k_off + (self.in_dims[li] + er)[:, None] * (4 * H) + (g * H + u)[None, :])
                     # recurrent kernel in fragment order [d][w][q][g][lane][s]
                     w_, q_, lane_, s_ = np.meshgrid(np.arange(8), np.arange(32), np.arange(64), np.arange(4),
                                                     indexing='ij')
@@ -168,10 +193,12 @@ class ParamLayout:
         gi = np.full(self.ref_size, -1, dtype=np.int64)
         u = np.arange(H)
         for li in range(self.num_layers):
-            D = self.in_dims[li]
+            E = self.side_dim(li)
+            Dm = self.in_dims[li]
+            D = Dm + E
             rmap = self.input_row_map(li)
-            krows = np.nonzero(rmap >= 0)[0]                       # padded k for reference rows 0..D-1 (in order)
-            assert (rmap[krows] == np.arange(D)).all()
+            krows = np.nonzero(rmap >= 0)[0]                       # padded k for reference rows 0..Dm-1 (in order)
+            assert (rmap[krows] == np.arange(Dm)).all()
             dwx_off, _ = self.gpacked['dwx%d' % li]
             db_off, _ = self.gpacked['db%d' % li]
             dwh_off, _ = self.gpacked['dwh%d' % li]
@@ -181,8 +208,12 @@ class ParamLayout:
                 for g in range(4):
                     cols = packed_gate_col(d, g, u)
                     lcols = packed_gate_col(0, g, u)
-                    gi[k_off + np.arange(D)[:, None] * (4 * H) + (g * H + u)[None, :]] = (
+                    gi[k_off + np.arange(Dm)[:, None] * (4 * H) + (g * H + u)[None, :]] = (
                         dwx_off + krows[:, None] * (2 * GP) + cols[None, :])
+                    if E:
+                        dwe_off, _ = self.gpacked['dwe']
+                        gi[k_off + (Dm + np.arange(E))[:, None] * (4 * H) + (g * H + u)[None, :]] = (
+                            dwe_off + np.arange(E)[:, None] * (2 * GP) + cols[None, :])
                     gi[k_off + (D + np.arange(H))[:, None] * (4 * H) + (g * H + u)[None, :]] = (
                         dwh_off + (d * HP + np.arange(H))[:, None] * GP + lcols[None, :])
                     gi[bias_off + g * H + u] = db_off + cols

@@ -159,8 +159,14 @@ class StackedBLSTMModel(object):
     """
 
     def __init__(self, sequence_lengths, target_sources, masks, audio_feat_mean, audio_feat_std, dropout_rate, config,
-                 audio_features=None, video_features=None, input='a', is_training=True, variables=None, seed=0):
+                 audio_features=None, video_features=None, input='a', is_training=True, variables=None, seed=0,
+                 side=None, blend=False):
+        """``side`` / ``blend`` are the hooks the model variants of this module use (not reference
+        arguments): ``side = (layer, dim)`` adds a per-utterance side input (speaker embedding,
+        see ParamLayout) delivered by ``_side_input()``; ``blend`` selects the variants'
+        prediction (known bins restored) and loss (loss_hole)."""
         _lib.require_cuda()
+        self.blend = bool(blend)
         self.audio_feat_dim = config['audio_feat_dim']
         self.audio_len = config['audio_len']
         self.video_feat_dim = config.get('video_feat_dim', 136)
@@ -185,7 +191,9 @@ class StackedBLSTMModel(object):
         in_dim = {'a': self.audio_feat_dim, 'v': self.video_feat_dim,
                   'av': self.audio_feat_dim + self.video_feat_dim}[input]
         self.layout = variables.layout if variables is not None else ParamLayout(in_dim, self.net_dim,
-                                                                                 self.audio_feat_dim)
+                                                                                 self.audio_feat_dim, side=side)
+        if side is not None and self.layout.side != (int(side[0]), int(side[1])):
+            raise ValueError("variables were built for side input %r, model needs %r" % (self.layout.side, tuple(side)))
         if self.layout.input_dim != in_dim:
             raise ValueError("variables were built for input dim %d, model needs %d" % (self.layout.input_dim, in_dim))
         self.variables = variables if variables is not None else BLSTMVariables(self.layout, seed=seed)
@@ -288,7 +296,20 @@ class StackedBLSTMModel(object):
         c['reserve'] = []
         for li in range(self.num_layers):
             kp = self.layout.kp[li]
-            ops.gemm(x.view(T * Bp, kp), v.p('wx%d' % li), out=xproj.view(T * Bp, 2 * GP), bias=v.p('b%d' % li))
+            if self.layout.side_dim(li):
+                # tile(side) . W_side is the same row for every frame of an utterance: one small GEMM
+                # [Bp, E] . [E, 2048] (+ bias), broadcast over time, and the layer GEMM accumulates
+                # onto it -- the tiled [B, T, E] tensor of the reference is never formed
+                E = self.layout.side_dim(li)
+                sp = self._buf('side_p', (Bp, self.layout.side_p), zero=True)
+                sp[:B, :E] = self._side_input()
+                eb = self._buf('side_bias', (Bp, 2 * GP))
+                ops.gemm(sp, v.p('we'), out=eb, bias=v.p('b%d' % li))
+                xproj.copy_(eb.unsqueeze(0).expand(T, Bp, 2 * GP))
+                ops.gemm(x.view(T * Bp, kp), v.p('wx%d' % li), out=xproj.view(T * Bp, 2 * GP), beta=1.0)
+                c['side_p'] = sp
+            else:
+                ops.gemm(x.view(T * Bp, kp), v.p('wx%d' % li), out=xproj.view(T * Bp, 2 * GP), bias=v.p('b%d' % li))
             hout = self._buf('h%d' % li, (T, Bp, 2 * HP))
             resv = self._buf('resv%d' % li, (T, Bp, 2, 5, HP)) if keep else None
             ops.blstm_rec_fwd(xproj, v.p('wh%d' % li), hout, resv, self.rows_per_wg)
@@ -306,6 +327,22 @@ class StackedBLSTMModel(object):
         c['row_scale'] = row_scale
         c['pred'] = pred
         c['kept'] = keep
+        if self.blend:
+            # prediction = seq_mask * (target * mask + logits * (1 - mask)); loss_func = loss_hole
+            tgt = self.target_spec_norm
+            mask = self.masks[:, :T].contiguous()
+            rs_bm = row_scale[:, :B].t().contiguous()
+            out3, dlog = ops.l1_loss_blend(tgt, pred, mask, rs_bm, want_grad=keep)
+            c['loss3'] = torch.stack([out3[1], out3[1], out3[2]])
+            c['dpred'] = dlog
+
+    # ---------------------------------------------------------------- side input hooks (variants)
+    def _side_input(self):
+        """[B, side_dim] device tensor concatenated (tiled over time) to the side layer's input."""
+        raise NotImplementedError("this model declares a side input but does not provide it")
+
+    def _side_backward(self, dside):
+        """Receives d loss / d side input [B, side_dim]; models whose side input is trainable override."""
 
     @property
     def inference(self):
@@ -334,6 +371,8 @@ class StackedBLSTMModel(object):
         if 'loss3' in c and (not want_grad or c.get('dpred') is not None):
             return
         self._forward(keep=want_grad)
+        if self.blend:
+            return      # computed with the prediction
         tgt = self.target_spec_norm
         mask = self.masks[:, :tgt.shape[1]].contiguous()
         out3, dpred = ops.l1_loss(tgt, c['pred'], mask, want_grad=want_grad)
@@ -428,6 +467,15 @@ class StackedBLSTMModel(object):
             x = c['layer_in'][li].view(M, kp)
             ops.gemm_splitk(x, dz2, lay.gpacked_view(gp, 'dwx%d' % li), trans_a=True, m=kp, n=2 * GP, k=M, splits=splits)
             ops.colsum(dz2, lay.gpacked_view(gp, 'db%d' % li), m=M, n=2 * GP)
+            if lay.side_dim(li):
+                # the side input saw every frame's dz: sum over time first, then two small GEMMs
+                E = lay.side_dim(li)
+                dsb = self._buf('dside_bias', (Bp, 2 * GP))
+                ops.colsum(dz.view(T, Bp * 2 * GP), dsb.view(-1), m=T, n=Bp * 2 * GP)
+                ops.gemm(c['side_p'], dsb, out=lay.gpacked_view(gp, 'dwe'), trans_a=True, m=lay.side_p, n=2 * GP, k=Bp)
+                dside = self._buf('dside', (Bp, lay.side_p))
+                ops.gemm(dsb, v.p('we'), out=dside, trans_b=True, m=Bp, n=lay.side_p, k=2 * GP)
+                self._side_backward(dside[:B, :E])
             # dWh[d] = H_prev^T . dZ_d : fw pairs h[t-1] with dz[t], bw pairs h[t+1] with dz[t]
             hout = self._ws[('h%d' % li, (T, Bp, 2 * HP))].view(M, 2 * HP)
             dwh = lay.gpacked_view(gp, 'dwh%d' % li)

@@ -83,6 +83,34 @@ def l1_loss(target, pred, mask, want_grad=False, grad_scale=None):
     return out3, dpred
 
 
+def l1_loss_blend(target, pred_inout, mask, row_scale=None, want_grad=False):
+    """Speaker-embedding variants: blends the known bins into ``pred_inout`` IN PLACE
+    (seq_mask * logits -> prediction) and returns (out3, dlogits) for loss_func = loss_hole."""
+    _lib.require_cuda(target, pred_inout, mask)
+    L = _lib.lib()
+    for x in (target, pred_inout, mask):
+        if x.dtype != torch.float32 or not x.is_contiguous():
+            raise _lib.AvsiError("l1_loss_blend operands must be contiguous float32")
+    n, row_len = target.numel(), target.shape[-1]
+    if pred_inout.numel() != n or mask.numel() != n:
+        raise _lib.AvsiError("l1_loss_blend: size mismatch")
+    if row_scale is not None and (row_scale.dtype != torch.float32 or not row_scale.is_contiguous()
+                                  or row_scale.numel() != n // row_len):
+        raise _lib.AvsiError("l1_loss_blend: row_scale must be contiguous float32 with one value per row")
+    dev = target.device
+    ws = _LOSS_WS.get(dev.index)
+    need = L.avsi_l1_loss_workspace_bytes(n)
+    if ws is None or ws.numel() * 4 < need:
+        ws = torch.empty((need + 3) // 4, dtype=torch.float32, device=dev)
+        _LOSS_WS[dev.index] = ws
+    out4 = torch.empty(4, dtype=torch.float32, device=dev)
+    dlog = torch.empty_like(pred_inout) if want_grad else None
+    _lib.check(L.avsi_l1_loss_blend_f32(_lib.ptr(target), _lib.ptr(pred_inout), _lib.ptr(mask), _lib.ptr(row_scale),
+                                        row_len, n, _lib.ptr(out4), _lib.ptr(dlog), _lib.ptr(ws), ws.numel() * 4,
+                                        _lib.stream_ptr()), "avsi_l1_loss_blend_f32")
+    return out4[:3], dlog
+
+
 _WS = {}
 
 

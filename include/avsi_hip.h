@@ -141,6 +141,20 @@ int avsi_l1_loss_f32(const float* target, const float* pred, const float* mask, 
                      float* out3, float* dpred, float grad_scale, void* workspace,
                      size_t workspace_bytes, void* stream);
 
+/* Loss of the speaker-embedding model variants (reference models.py:1006-1029 StackedBLSTMSSNNModel,
+ * :1367-1394 StackedBLSTMEmbeddingModel): the prediction keeps the known bins,
+ *   prediction = seq_mask * (target * mask + logits * (1 - mask)),
+ * and the training loss is loss_hole.  pred_inout [n] holds seq_mask * logits on entry (the
+ * projection GEMM's row-scale epilogue) and the prediction on return; row_scale [n / row_len] is the
+ * sequence mask per (utterance, frame) row of row_len bins, or null for all ones.
+ *   out4[0..2] as avsi_l1_loss_f32 (taken on the prediction), out4[3] = 1 / sum(1 - mask);
+ *   dlogits (optional) [n] = sign(prediction - target) (1 - mask)^2 / sum(1 - mask)
+ *   = d loss_hole / d logits up to the sequence mask the caller folds in afterwards.
+ * workspace: avsi_l1_loss_workspace_bytes(n) bytes. */
+int avsi_l1_loss_blend_f32(const float* target, float* pred_inout, const float* mask,
+                           const float* row_scale, int row_len, int64_t n, float* out4,
+                           float* dlogits, void* workspace, size_t workspace_bytes, void* stream);
+
 /* Split-K form of avsi_gemm_f32 for reductions over very many rows (weight gradients
  * dW = X^T . dZ over all T*Bp rows): K is cut into `splits` chunks, partial [M,N] slabs go to
  * `workspace` (avsi_gemm_splitk_workspace_bytes), then are summed in chunk order (deterministic,

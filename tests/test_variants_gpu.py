@@ -1,0 +1,145 @@
+"""Model variants on the GPU against the literal torch-float64 restatement in
+oracle/variants.py: embedding model (side input at layer 0 and after layer 1), two-step model."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import blstm as OB
+from oracle import frontend as OF
+from oracle import variants as OV
+
+pytestmark = pytest.mark.gpu
+
+
+def _config(**kw):
+    cfg = dict(audio_feat_dim=257, video_feat_dim=136, audio_len=2880, net_dim=[250, 250, 250],
+               optimizer_type='adam', starter_learning_rate=1e-3, lr_updating_steps=10000, lr_decay=1.0,
+               batch_size=3, l2=0.0, integration_layer=0)
+    cfg.update(kw)
+    return cfg
+
+
+def _inputs(B, N, seed, ragged=False):
+    rng = np.random.default_rng(seed)
+    wav = np.clip(np.round(rng.normal(0, 3000, size=(B, N))), -32768, 32767).astype(np.float32)
+    T = -(-N // 192)
+    masks = np.ones((B, T, 257), dtype=np.float32)
+    for b in range(B):
+        s = rng.integers(0, T - 4)
+        masks[b, s:s + 4] = 0
+    spec = OF.get_spectrogram(OF.get_stft(wav, window_size=24, step_size=12), log=True)
+    mean, std = OF.feature_stats(list(spec))
+    video = rng.normal(size=(B, T, 136)).astype(np.float32)
+    seq = np.full(B, T, np.int32)
+    if ragged:
+        seq[1] = T - 3
+    return wav, masks, mean.astype(np.float32), std.astype(np.float32), video, seq, T
+
+
+def _flat_grads(layout, g):
+    return layout.flatten_oracle_params({'layers': g['layers'], 'proj': g['proj']}).astype(np.float64)
+
+
+@pytest.mark.parametrize('int_layer,input_type', [(0, 'a'), (1, 'av'), (2, 'a')])
+def test_embedding_model_forward_backward(int_layer, input_type):
+    import avsi_amd  # noqa: F401
+    from avsi_amd import models
+    from avsi_amd.blstm_layout import ParamLayout
+    from avsi_amd.model_variants import StackedBLSTMEmbeddingModel
+    B, N, E = 3, 2880, 512
+    wav, masks, mean, std, video, seq, T = _inputs(B, N, 10 + int_layer, ragged=True)
+    rng = np.random.default_rng(5)
+    emb = rng.normal(0, 1, size=(B, E)).astype(np.float32)
+    D = 257 if input_type == 'a' else 393
+    params = OV.init_variant_params(3, D, int_layer, E)
+    layout = ParamLayout(D, (250, 250, 250), 257, side=(int_layer, E))
+    assert layout.ref_size == sum(int(np.prod(v.shape)) for _, v in OB.flatten_params(params))
+    variables = models.BLSTMVariables(layout)
+    variables.load_flat(layout.flatten_oracle_params(params))
+    cfg = _config(integration_layer=int_layer, audio_len=N)
+    vid = video if input_type == 'av' else None
+    m = StackedBLSTMEmbeddingModel(seq, wav, masks, mean, std, 0.0, cfg, video_features=vid, embeddings=emb,
+                                   input=input_type, is_training=True, variables=variables)
+    m.build_graph('a-blstm-emb')
+    tp = OV.params_to_torch(params)
+    ref = OV.variant_forward(wav, masks, mean, std, seq, tp, int_layer, embeddings=emb, video=vid, input_type=input_type)
+    ref['loss'].backward()
+    pred = m.prediction.cpu().numpy()
+    np.testing.assert_allclose(pred, ref['prediction'].detach().numpy(), rtol=2e-4, atol=2e-4)
+    # the known bins are restored exactly, frames beyond an utterance's length are zero
+    tn = m.target_spec_norm.cpu().numpy()
+    keep = masks[:, :T] == 1
+    keep[1, seq[1]:] = False
+    np.testing.assert_array_equal(pred[keep], tn[keep])
+    assert np.all(pred[1, seq[1]:] == 0)
+    for name in ('loss', 'loss_func', 'loss_hole', 'loss_valid'):
+        np.testing.assert_allclose(float(getattr(m, name)), float(ref[name].detach()), rtol=1e-4, err_msg=name)
+    g = m.gradients.cpu().numpy().astype(np.float64)
+    gref = _flat_grads(layout, OV.grads_to_numpy(tp))
+    scale = np.abs(gref).max()
+    np.testing.assert_allclose(g, gref, rtol=2e-3, atol=2e-5 * scale)
+    # the side rows of the kernel did receive a gradient
+    k = layout.ref_view(g, 'cell_%d/fw/kernel' % int_layer)
+    d_in = D if int_layer == 0 else 500
+    assert np.abs(k[d_in:d_in + E]).max() > 0
+    # one Adam step moves every variable by about lr
+    before = variables.flat.clone()
+    m.train_op
+    step = (variables.flat - before).abs()
+    assert float(step.max()) <= 1.01e-3 and float((step > 0).float().mean()) > 0.95
+
+
+def test_embedding_model_requires_embeddings():
+    import avsi_amd  # noqa: F401
+    from avsi_amd import _lib
+    from avsi_amd.model_variants import StackedBLSTMEmbeddingModel
+    wav, masks, mean, std, video, seq, T = _inputs(2, 1920, 1)
+    m = StackedBLSTMEmbeddingModel(seq, wav, masks, mean, std, 0.0, _config(audio_len=1920), input='a', is_training=False)
+    with pytest.raises(_lib.AvsiError):
+        m.prediction
+    with pytest.raises(ValueError):
+        m.feed_embeddings(np.zeros((2, 7), np.float32))
+
+
+def test_two_steps_model():
+    import avsi_amd  # noqa: F401
+    from avsi_amd import models
+    from avsi_amd.blstm_layout import ParamLayout
+    from avsi_amd.model_variants import StackedBLSTM2StepsModel
+    B, N = 3, 2880
+    wav, masks, mean, std, video, seq, T = _inputs(B, N, 21)
+    pv = OB.init_params(7, 136)
+    pav = OB.init_params(8, 393)
+    lv, lav = ParamLayout(136), ParamLayout(393)
+    vv, vav = models.BLSTMVariables(lv), models.BLSTMVariables(lav)
+    vv.load_flat(lv.flatten_oracle_params(pv))
+    vav.load_flat(lav.flatten_oracle_params(pav))
+    cfg = _config(audio_len=N)
+    m = StackedBLSTM2StepsModel(seq, wav, masks, mean, std, 0.0, cfg, video, is_training=True, variables=vav,
+                                video_variables=vv)
+    m.build_graph('av-blstm-twosteps')
+    # oracle: two plain models chained (models.py:255-263)
+    f1 = OB.model_forward(wav, masks, mean, std, seq, pv, video=video, input_type='v', dtype=np.float64)
+    x2 = np.concatenate([f1['prediction'], video.astype(np.float64)], axis=2)
+    p2 = OB.cast_params(pav, np.float64)
+    logits2, rnn2, caches2 = OB.inference(x2, p2, True)
+    pred2 = OB.prediction(logits2, seq)
+    np.testing.assert_allclose(m.video_prediction.cpu().numpy(), f1['prediction'], rtol=2e-4, atol=2e-4)
+    np.testing.assert_allclose(m.prediction.cpu().numpy(), pred2, rtol=5e-4, atol=5e-4)
+    l2 = OB.losses(f1['target_spec_norm'], pred2, masks.astype(np.float64))
+    np.testing.assert_allclose(float(m.loss), l2['loss'], rtol=1e-4)
+    fwd = {'params': p2, 'target_spec_norm': f1['target_spec_norm'], 'prediction': pred2, 'rnn_outputs': rnn2,
+           'caches': caches2}
+    gref = lav.flatten_oracle_params(OB.model_backward(fwd, masks, seq)).astype(np.float64)
+    g = m.gradients.cpu().numpy().astype(np.float64)
+    np.testing.assert_allclose(g, gref, rtol=3e-3, atol=3e-5 * np.abs(gref).max())
+    # train_op updates the audio-visual network only
+    v_before, av_before = vv.flat.clone(), vav.flat.clone()
+    m.train_op
+    assert torch.equal(vv.flat, v_before) and not torch.equal(vav.flat, av_before)
+    assert m.global_step == 1
+    # a new feed re-chains the two steps
+    m.feed(seq, wav * 0.5, masks, video)
+    f1b = OB.model_forward(wav * 0.5, masks, mean, std, seq, pv, video=video, input_type='v', dtype=np.float64)
+    np.testing.assert_allclose(m.video_prediction.cpu().numpy(), f1b['prediction'], rtol=2e-4, atol=2e-4)
+    assert m.prediction.shape == (B, T, 257)
