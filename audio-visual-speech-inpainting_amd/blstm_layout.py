@@ -33,9 +33,15 @@ class ParamLayout:
     (models.py:848-851,1205-1209 for layer 0; :905-906,1247-1249 after ``integration_layer``
     layers).  Its rows of the TF kernel sit between the layer's input rows and the recurrent rows;
     the kernels never see the tiled tensor -- the rows are packed apart as ``we`` [dim_p, 2048] and
-    enter the gate pre-activations as a per-utterance bias (see StackedBLSTMModel._forward)."""
+    enter the gate pre-activations as a per-utterance bias (see StackedBLSTMModel._forward).
 
-    def __init__(self, input_dim, net_dim=(250, 250, 250), audio_feat_dim=257, side=None):
+    ``mlp = width`` adds the speaker-embedding network of StackedBLSTMSSNNModel
+    (models.py:803-810): ``speaker_embedding/weights_1 [2F, width]``, ``biases_1``, ``weights_2 [width,
+    width]``, ``biases_2``, ``weights_3``, ``biases_3``.  Packed: ``mw1a`` / ``mw1b`` = the feature and
+    the delta-feature halves of weights_1 (rows padded to the model's time-major input pitch so the
+    GEMM reads the input buffer in place), ``mw2``, ``mw3``, ``mb1..3``."""
+
+    def __init__(self, input_dim, net_dim=(250, 250, 250), audio_feat_dim=257, side=None, mlp=None, mlp_in_pitch=None):
         net_dim = tuple(int(h) for h in net_dim)
         if len(set(net_dim)) != 1 or net_dim[0] > HP or net_dim[0] < 1:
             raise ValueError("the gfx950 BLSTM kernels need equal layer sizes <= %d, got %r" % (HP, net_dim))
@@ -48,6 +54,10 @@ class ParamLayout:
         if self.side is not None and not (0 <= self.side[0] < self.num_layers and self.side[1] > 0):
             raise ValueError("side input must name an existing layer and a positive width, got %r" % (side,))
         self.side_p = round_up(self.side[1], 8) if self.side else 0
+        self.mlp = int(mlp) if mlp else 0
+        self.mlp_in_pitch = int(mlp_in_pitch or round_up(F, 8))
+        if self.mlp and (self.mlp % 8 or self.mlp_in_pitch < F):
+            raise ValueError("speaker-embedding width must be a multiple of 8 and its input pitch >= %d" % F)
 
         # ---- reference layout
         self.ref_entries = []                          # (name, shape, offset)
@@ -66,6 +76,12 @@ class ParamLayout:
         off += 2 * H * F
         self.ref_entries.append(('logits/biases', (F,), off))
         off += F
+        if self.mlp:
+            W = self.mlp
+            for name, shape in (('weights_1', (2 * F, W)), ('biases_1', (W,)), ('weights_2', (W, W)), ('biases_2', (W,)),
+                                ('weights_3', (W, W)), ('biases_3', (W,))):
+                self.ref_entries.append(('speaker_embedding/' + name, shape, off))
+                off += int(np.prod(shape))
         self.ref_size = off
         self._ref_off = {n: o for n, _, o in self.ref_entries}
 
@@ -87,6 +103,13 @@ class ParamLayout:
                 alloc('we', (self.side_p, 2 * GP))
         alloc('pw', (2 * HP, self.ldp))
         alloc('pb', (self.ldp,))
+        self._mlp_shapes = []
+        if self.mlp:
+            W, P = self.mlp, self.mlp_in_pitch
+            self._mlp_shapes = [('mw1a', (P, W)), ('mw1b', (P, W)), ('mb1', (W,)), ('mw2', (W, W)), ('mb2', (W,)),
+                                ('mw3', (W, W)), ('mb3', (W,))]
+            for name, shape in self._mlp_shapes:
+                alloc(name, shape)
         self.packed_size = poff
 
         self.pack_index = self._build_pack_index()     # packed pos -> ref pos (ref_size = zero slot)
@@ -107,12 +130,21 @@ class ParamLayout:
                 galloc('dwe', (self.side_p, 2 * GP))
         galloc('dpw', (2 * HP, self.ldp))
         galloc('dpb', (self.ldp,))
+        for name, shape in self._mlp_shapes:
+            galloc('d' + name, shape)
         self.gpacked_size = goff
         self.grad_index = self._build_grad_index()     # ref pos -> gpacked pos
 
     def signature(self):
         """Shape signature stored in checkpoints."""
-        return [self.input_dim, self.H, self.num_layers, self.F] + (list(self.side) if self.side else [])
+        return ([self.input_dim, self.H, self.num_layers, self.F] + (list(self.side) if self.side else [])
+                + ([-self.mlp] if self.mlp else []))
+
+    def _mlp_map(self):
+        """[(packed name, reference name, row offset in the reference matrix, rows)] of the dense MLP entries."""
+        F, W = self.F, self.mlp
+        return [('mw1a', 'weights_1', 0, F), ('mw1b', 'weights_1', F, F), ('mb1', 'biases_1', 0, 0),
+                ('mw2', 'weights_2', 0, W), ('mb2', 'biases_2', 0, 0), ('mw3', 'weights_3', 0, W), ('mb3', 'biases_3', 0, 0)]
 
     def side_dim(self, li):
         return self.side[1] if self.side is not None and self.side[0] == li else 0
@@ -185,6 +217,17 @@ class ParamLayout:
         idx[pw_off + rows[:, None] * self.ldp + c[None, :]] = (
             self._ref_off['logits/weights'] + rmap[rows][:, None] * F + c[None, :])
         idx[pb_off + c] = self._ref_off['logits/biases'] + c
+        if self.mlp:
+            W = self.mlp
+            w = np.arange(W)
+            for pname, rname, r0, rows in self._mlp_map():
+                poff, _ = self.packed[pname]
+                roff = self._ref_off['speaker_embedding/' + rname]
+                if rows:
+                    r = np.arange(rows)
+                    idx[poff + r[:, None] * W + w[None, :]] = roff + (r0 + r)[:, None] * W + w[None, :]
+                else:
+                    idx[poff + w] = roff + w
         return idx
 
     def _build_grad_index(self):
@@ -224,6 +267,17 @@ class ParamLayout:
         gi[self._ref_off['logits/weights'] + np.arange(2 * H)[:, None] * F + c[None, :]] = (
             dpw_off + prow[:, None] * self.ldp + c[None, :])
         gi[self._ref_off['logits/biases'] + c] = dpb_off + c
+        if self.mlp:
+            W = self.mlp
+            w = np.arange(W)
+            for pname, rname, r0, rows in self._mlp_map():
+                goff, _ = self.gpacked['d' + pname]
+                roff = self._ref_off['speaker_embedding/' + rname]
+                if rows:
+                    r = np.arange(rows)
+                    gi[roff + (r0 + r)[:, None] * W + w[None, :]] = goff + r[:, None] * W + w[None, :]
+                else:
+                    gi[roff + w] = goff + w
         assert (gi >= 0).all()
         return gi
 
@@ -252,6 +306,8 @@ class ParamLayout:
                 self.ref_view(flat, 'cell_%d/%s/bias' % (li, dname))[...] = layer[dname]['bias']
         self.ref_view(flat, 'logits/weights')[...] = params['proj']['weights']
         self.ref_view(flat, 'logits/biases')[...] = params['proj']['biases']
+        for k, v in params.get('mlp', {}).items():
+            self.ref_view(flat, 'speaker_embedding/' + k)[...] = v
         return flat
 
     def unflatten_to_oracle_params(self, flat):

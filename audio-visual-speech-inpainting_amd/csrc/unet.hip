@@ -103,6 +103,7 @@ struct BnArgs {
 __device__ __forceinline__ float act_grad(float z, int act) {
     if (act == 1) return z > 0.f ? 1.f : 0.f;
     if (act == 2) return z > 0.f ? 1.f : 0.2f;
+    if (act == 3) return z > 0.f ? 1.f : 0.3f;
     return 1.f;
 }
 
@@ -165,6 +166,7 @@ __global__ __launch_bounds__(TPB) void bn_act_kernel(const BnArgs a, float* __re
             if (a.has_bn) v = a.gamma[c] * ((v - a.mean[c]) * a.rstd[c]) + a.beta[c];
             if (a.act == 1) v = fmaxf(v, 0.f);
             if (a.act == 2) v = v > 0.f ? v : 0.2f * v;
+            if (a.act == 3) v = v > 0.f ? v : 0.3f * v;
         }
         y[e] = v;
     }
@@ -299,7 +301,7 @@ extern "C" int avsi_colstats_f32(const float* x, int64_t R, int C, int ld, float
 
 extern "C" int avsi_bn_act_f32(const float* x, int64_t R, int C, int ld, const float* mean, const float* rstd,
                                const float* gamma, const float* beta, int act, float* y, void* stream) {
-    if (!x || !y || R <= 0 || C <= 0 || ld < C || act < 0 || act > 2) return AVSI_ERR_INVALID_ARG;
+    if (!x || !y || R <= 0 || C <= 0 || ld < C || act < 0 || act > 3) return AVSI_ERR_INVALID_ARG;
     const int has_bn = mean != nullptr;
     if (has_bn && (!rstd || !gamma || !beta)) return AVSI_ERR_INVALID_ARG;
     BnArgs a{x, nullptr, mean, rstd, gamma, beta, R, C, ld, act, has_bn};
@@ -311,7 +313,7 @@ extern "C" int avsi_bn_act_f32(const float* x, int64_t R, int C, int ld, const f
 extern "C" int avsi_bn_act_bwd_f32(const float* x, const float* dy, int64_t R, int C, int ld, const float* mean,
                                    const float* rstd, const float* gamma, const float* beta, int act, float* dx,
                                    float* dgamma, float* dbeta, void* workspace, size_t workspace_bytes, void* stream) {
-    if (!x || !dy || !dx || R <= 0 || C <= 0 || ld < C || act < 0 || act > 2) return AVSI_ERR_INVALID_ARG;
+    if (!x || !dy || !dx || R <= 0 || C <= 0 || ld < C || act < 0 || act > 3) return AVSI_ERR_INVALID_ARG;
     const int has_bn = mean != nullptr;
     if (has_bn && (!rstd || !gamma || !beta || !dgamma || !dbeta)) return AVSI_ERR_INVALID_ARG;
     if (has_bn && (!workspace || workspace_bytes < avsi_unet_workspace_bytes(C))) return AVSI_ERR_WORKSPACE;

@@ -21,7 +21,7 @@ from scipy.io import wavfile
 from . import parallel
 from .config_utils import check_trainconfiguration, load_configfile
 from .dataset_reader import DataManager, OutOfRangeError
-from .training import build_model
+from .training import EMBEDDING_SIZE, build_model, unpack_batch, uses_embeddings
 
 
 def infer(model_path, data_path_test, audio_path, out_file_prefix, norm=True, oracle_phase=False, batch_size=1):
@@ -29,7 +29,8 @@ def infer(model_path, data_path_test, audio_path, out_file_prefix, norm=True, or
     rank, world = parallel.init()
 
     dm = DataManager(num_audio_samples=config['audio_len'], audio_feat_size=config['audio_feat_dim'],
-                     video_feat_size=config['video_feat_dim'], buffer_size=4000, mode='fixed')
+                     video_feat_size=config['video_feat_dim'], buffer_size=4000, mode='fixed',
+                     embedding_size=EMBEDDING_SIZE if uses_embeddings(config) else None)
     test_files = sorted(glob(os.path.join(data_path_test, '*.tfrecord')))
     _, test_it = dm.get_iterator(dm.get_dataset(test_files, shuffle=False), batch_size=batch_size, n_epochs=1,
                                  drop_remainder=False, shard=(rank, world))
@@ -58,12 +59,12 @@ def infer(model_path, data_path_test, audio_path, out_file_prefix, norm=True, or
     print('Starting inference on dataset: {:s}'.format(data_path_test))
     while True:
         try:
-            test_length, _, test_target_audio, test_sample_path, _, test_video, test_mask = test_it.get_next()
+            feed, test_sample_path = unpack_batch(test_it.get_next(), uses_embeddings(config))
+            test_length = feed['sequence_lengths']
         except OutOfRangeError:
             print('done.')
             break
-        model.feed(sequence_lengths=test_length, target_sources=test_target_audio, video_features=test_video,
-                   masks=test_mask)
+        model.feed(**feed)
         enhanced = model.enhanced_sources_oracle_phase if oracle_phase else model.enhanced_sources
         loss = float(model.loss)
         enhanced = enhanced.cpu().numpy()

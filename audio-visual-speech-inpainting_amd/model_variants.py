@@ -18,9 +18,21 @@ embedding model with ``integration_layer >= 1`` the second BLSTM is fed ``net_in
 the concatenation it has just built (models.py:1276-1281), so the first BLSTM and the embedding are
 dead code there; this build implements the training (CudnnLSTM) branch's dataflow (:1236-1259) for
 both.  Variable names follow the ``integration_layer = 0`` scoping (``cudnn_lstm/...cell_<l>``).
+
+* ``StackedBLSTMSSNNModel``       reference models.py:718-1118 -- the speaker embedding is computed
+  from the masked audio features by a 3-layer MLP (514 -> 200 -> 200 -> 200, leaky_relu 0.3) over
+  every frame, masked by ``masks[:, :, 0]`` and averaged with ``sum / (count + 1)`` (:800-838); it
+  trains end to end.  Here the MLP runs on the time-major input buffer in place (the
+  [features, delta] concatenation is two accumulating GEMMs), and because its last layer is linear
+  the masked time average is taken BEFORE it: ``mean_t(w_t (a_t W3 + b3)) = (sum_t w_t a_t) W3 +
+  (sum_t w_t) b3`` -- a [B, 200] x [200, 200] GEMM instead of a [B T, 200] x [200, 200] one.
 """
-from . import _lib
-from .models import StackedBLSTMModel, _as_device
+import torch
+
+from . import _lib, ops
+from . import audio_processing as ap
+from .blstm_layout import ParamLayout, round_up
+from .models import BLSTMVariables, StackedBLSTMModel, _as_device
 
 
 class StackedBLSTMEmbeddingModel(StackedBLSTMModel):
@@ -56,6 +68,48 @@ class StackedBLSTMEmbeddingModel(StackedBLSTMModel):
         return self.embeddings
 
 
+class TwoStepVariables(object):
+    """What the drivers' tf.train.Saver sees of the two-step model: both networks
+    (training_emb.py:122-125).  npz checkpoints are a pair (``<path>.npz`` for the audio-visual
+    network, ``<path>.vnet.npz`` for the video one); a TensorFlow bundle holds both variable scopes."""
+
+    def __init__(self, av, video):
+        self.av, self.video = av, video
+
+    def __getattr__(self, name):            # flat, layout, global_step, adam_m, ... of the trained network
+        return getattr(self.av, name)
+
+    def save(self, path):
+        self.video.save(path + '.vnet')
+        return self.av.save(path)
+
+    def save_tf(self, prefix, scope=None):
+        from . import tf_checkpoint as tc
+        cpu = lambda t: t.cpu().numpy() if t is not None else None
+        merged = tc.export_variables(self.video.layout, cpu(self.video.flat), 'v-blstm')
+        del merged['v-blstm/Variable']
+        merged.update(tc.export_variables(self.av.layout, cpu(self.av.flat), 'av-blstm-twosteps', cpu(self.av.adam_m),
+                                          cpu(self.av.adam_v), self.av.global_step))
+        return tc.write_bundle(prefix, merged)
+
+    def restore(self, path):
+        import os
+        from . import tf_checkpoint as tc
+        if not path.endswith('.npz') and not os.path.isfile(path + '.npz') and tc.is_bundle(path):
+            bundle = tc.read_bundle(path)
+            for var, scope in ((self.video, 'v-blstm'), (self.av, 'av-blstm-twosteps')):
+                flat, m, v, step = tc.import_variables(bundle, var.layout, scope=scope)
+                var.load_flat(flat)
+                var.global_step = step
+                var.adam_m = torch.from_numpy(m).to(var.device) if m is not None else None
+                var.adam_v = torch.from_numpy(v).to(var.device) if v is not None else None
+            return
+        self.av.restore(path)
+        base = path[:-4] if path.endswith('.npz') else path
+        if os.path.isfile(base + '.vnet.npz'):
+            self.video.restore(base + '.vnet')
+
+
 class StackedBLSTM2StepsModel(object):
     """2-steps speech inpainting BLSTM model (reference models.py:240-317).
 
@@ -78,7 +132,7 @@ class StackedBLSTM2StepsModel(object):
                                           dropout_rate, config, audio_features=None, video_features=video_features,
                                           input='av', is_training=is_training, variables=variables, seed=seed + 1)
         self.av_model.build_graph(var_scope='av-blstm-twosteps')
-        self.variables = self.av_model.variables
+        self.variables = TwoStepVariables(self.av_model.variables, self.video_model.variables)
         self.video_variables = self.video_model.variables
         self.device = self.av_model.device
         self.var_scope = None
@@ -111,3 +165,114 @@ class StackedBLSTM2StepsModel(object):
                     'all_vars', 'train_vars', 'gradients', 'net_inputs', 'target_stft', 'sequence_lengths'):
             return getattr(self._chain(), name)
         raise AttributeError(name)
+
+
+class StackedBLSTMSSNNModel(StackedBLSTMModel):
+    """Speech inpainting BLSTM model with SSNN (reference models.py:718-1118)."""
+    EMB = 200    # models.py:804-809
+
+    def __init__(self, sequence_lengths, target_sources, masks, audio_feat_mean, audio_feat_std, dropout_rate, config,
+                 audio_features=None, video_features=None, input='a', is_training=True, variables=None, seed=0):
+        self.int_layer = int(config.get('integration_layer', 0))
+        F = config['audio_feat_dim']
+        in_dim = {'a': F, 'v': config.get('video_feat_dim', 136), 'av': F + config.get('video_feat_dim', 136)}[input]
+        # the MLP reads the audio features where the network input holds them (pitch = input pitch);
+        # the video-only model keeps them in a buffer of their own
+        pitch = round_up(F, 8) if input == 'v' else round_up(in_dim, 8)
+        if variables is None:
+            layout = ParamLayout(in_dim, config['net_dim'], F, side=(self.int_layer, self.EMB), mlp=self.EMB,
+                                 mlp_in_pitch=pitch)
+            variables = BLSTMVariables(layout, seed=seed)
+        elif variables.layout.mlp != self.EMB or variables.layout.mlp_in_pitch != pitch:
+            raise ValueError("variables were not built for the SSNN model (mlp=%d, pitch=%d)" % (self.EMB, pitch))
+        super().__init__(sequence_lengths, target_sources, masks, audio_feat_mean, audio_feat_std, dropout_rate, config,
+                         audio_features=audio_features, video_features=video_features, input=input,
+                         is_training=is_training, variables=variables, seed=seed,
+                         side=(self.int_layer, self.EMB), blend=True)
+
+    # ------------------------------------------------------------------ forward (models.py:800-838)
+    def _feat_tm(self):
+        """Time-major [T][Bp][pitch] buffer whose first F columns are the masked audio features."""
+        c = self._cache
+        self._frontend()
+        if self.input_type != 'v':
+            return c['x0']
+        if 'ssnn_feat' not in c:
+            B, T, Bp = self._dims()
+            P = self.layout.mlp_in_pitch
+            buf = self._buf('ssnn_feat', (T, Bp, P), zero=True)
+            if self.fed_audio_features is not None:
+                buf[:, :B, :self.audio_feat_dim] = self.fed_audio_features[:, :T].transpose(0, 1)
+            else:
+                ap.frontend(self.target_sources, window_size=24, step_size=12, n_fft=512, num_frames_out=T,
+                            num_bins=self.audio_feat_dim, mean=self.audio_feat_mean, std=self.audio_feat_std,
+                            masks=self.masks, want_spec=False, want_feat=True, time_major=True, feat_cols=P,
+                            _feat_out=buf)
+            c['ssnn_feat'] = buf
+        return c['ssnn_feat']
+
+    def _side_input(self):
+        c = self._cache
+        B, T, Bp = self._dims()
+        if 'spk' in c:
+            return c['spk'][:B]
+        v, W, P = self.variables, self.EMB, self.layout.mlp_in_pitch
+        M = T * Bp
+        feat = self._feat_tm()
+        delta = self._buf('ssnn_delta', (T, Bp, P))
+        # regression deltas run along time; in time-major storage every (utterance, bin) is a "bin"
+        _lib.check(_lib.lib().avsi_delta_f32(_lib.ptr(feat), _lib.ptr(delta), 1, T, Bp * P, 2, _lib.stream_ptr()),
+                   "avsi_delta_f32")
+        l1 = self._buf('ssnn_l1', (M, W))
+        ops.gemm(feat.view(M, P), v.p('mw1a'), out=l1, bias=v.p('mb1'))
+        ops.gemm(delta.view(M, P), v.p('mw1b'), out=l1, beta=1.0)
+        a1 = ops.bn_act(l1, W, self._buf('ssnn_a1', (M, W)), act=3)
+        l2 = self._buf('ssnn_l2', (M, W))
+        ops.gemm(a1, v.p('mw2'), out=l2, bias=v.p('mb2'))
+        a2 = ops.bn_act(l2, W, self._buf('ssnn_a2', (M, W)), act=3)
+        # frame weights w[t][b] = mask[b][t][0] / (sum_t mask[b][t][0] + 1); zero for padded rows
+        m0 = self.masks[:, :T, 0]
+        w = self._buf('ssnn_w', (T, Bp), zero=True)
+        w[:, :B] = (m0 / (m0.sum(dim=1, keepdim=True) + 1.0)).t()
+        a2w = self._buf('ssnn_a2w', (T, Bp, W))
+        ops.relayout_rows(a2, a2w, Bp, T, W, W, (W, Bp * W), (W, Bp * W), row_scale=w, scale_strides=(1, Bp))
+        S = self._buf('ssnn_S', (Bp, W))
+        ops.colsum(a2w.view(T, Bp * W), S.view(-1), m=T, n=Bp * W)
+        cw = w.sum(dim=0)
+        spk = self._buf('ssnn_spk', (Bp, W))
+        ops.gemm(S, v.p('mw3'), out=spk)
+        spk.addcmul_(cw[:, None], v.p('mb3')[None, :])
+        c.update(ssnn=(feat, delta, l1, a1, l2, w, S, cw), spk=spk)
+        return spk[:B]
+
+    @property
+    def speaker_embedding(self):
+        self._frontend()
+        return self._side_input()
+
+    # ------------------------------------------------------------------ backward
+    def _side_backward(self, dside, gp):
+        c, v, lay, W, P = self._cache, self.variables, self.layout, self.EMB, self.layout.mlp_in_pitch
+        B, T, Bp = self._dims()
+        M = T * Bp
+        feat, delta, l1, a1, l2, w, S, cw = c['ssnn']
+        g = lambda name: lay.gpacked_view(gp, name)
+        demb = self._buf('ssnn_demb', (Bp, W), zero=True)
+        demb[:B] = dside
+        ops.gemm(S, demb, out=g('dmw3'), trans_a=True, m=W, n=W, k=Bp)
+        g('dmb3').copy_((cw[:, None] * demb).sum(dim=0))
+        dS = self._buf('ssnn_dS', (Bp, W))
+        ops.gemm(demb, v.p('mw3'), out=dS, trans_b=True, m=Bp, n=W, k=W)
+        # d a2[t][b][:] = w[t][b] dS[b][:]  (broadcast over time: source time stride 0)
+        da2 = self._buf('ssnn_da2', (T, Bp, W))
+        ops.relayout_rows(dS, da2, Bp, T, W, W, (W, 0), (W, Bp * W), row_scale=w, scale_strides=(1, Bp))
+        splits = max(1, min(64, M // 4096))
+        dl2 = ops.bn_act_bwd(l2, da2.view(M, W), W, self._buf('ssnn_dl2', (M, W)), act=3)
+        ops.gemm_splitk(a1, dl2, g('dmw2'), trans_a=True, m=W, n=W, k=M, splits=splits)
+        ops.colsum(dl2, g('dmb2'), m=M, n=W)
+        da1 = self._buf('ssnn_da1', (M, W))
+        ops.gemm(dl2, v.p('mw2'), out=da1, trans_b=True, m=M, n=W, k=W)
+        dl1 = ops.bn_act_bwd(l1, da1, W, self._buf('ssnn_dl1', (M, W)), act=3)
+        ops.gemm_splitk(feat.view(M, P), dl1, g('dmw1a'), trans_a=True, m=P, n=W, k=M, splits=splits)
+        ops.gemm_splitk(delta.view(M, P), dl1, g('dmw1b'), trans_a=True, m=P, n=W, k=M, splits=splits)
+        ops.colsum(dl1, g('dmb1'), m=M, n=W)

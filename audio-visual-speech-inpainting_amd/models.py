@@ -64,8 +64,10 @@ class BLSTMVariables:
             if name.endswith('/kernel'):
                 lim = math.sqrt(6.0 / (shape[0] + shape[1]))
                 flat[off:off + n] = rng.uniform(-lim, lim, size=n)
-            elif name == 'logits/weights':
-                sd = 1.0 / math.sqrt(float(shape[0]))
+            elif name == 'logits/weights' or name.startswith('speaker_embedding/weights_'):
+                # logits: stddev 1/sqrt(2H) (models.py:119); speaker-embedding MLP: 1/sqrt(F) for
+                # weights_1 [2F, W], 1/sqrt(W) for the square ones (models.py:804-808)
+                sd = 1.0 / math.sqrt(float(shape[0] // 2 if name.endswith('weights_1') else shape[0]))
                 w = rng.normal(0.0, sd, size=n)
                 bad = np.abs(w) > 2 * sd
                 while bad.any():
@@ -341,8 +343,9 @@ class StackedBLSTMModel(object):
         """[B, side_dim] device tensor concatenated (tiled over time) to the side layer's input."""
         raise NotImplementedError("this model declares a side input but does not provide it")
 
-    def _side_backward(self, dside):
-        """Receives d loss / d side input [B, side_dim]; models whose side input is trainable override."""
+    def _side_backward(self, dside, gp):
+        """Receives d loss / d side input [B, side_dim] and the packed gradient buffer; models whose
+        side input is trainable override and add their gradients to ``gp``."""
 
     @property
     def inference(self):
@@ -475,7 +478,7 @@ class StackedBLSTMModel(object):
                 ops.gemm(c['side_p'], dsb, out=lay.gpacked_view(gp, 'dwe'), trans_a=True, m=lay.side_p, n=2 * GP, k=Bp)
                 dside = self._buf('dside', (Bp, lay.side_p))
                 ops.gemm(dsb, v.p('we'), out=dside, trans_b=True, m=Bp, n=lay.side_p, k=2 * GP)
-                self._side_backward(dside[:B, :E])
+                self._side_backward(dside[:B, :E], gp)
             # dWh[d] = H_prev^T . dZ_d : fw pairs h[t-1] with dz[t], bw pairs h[t+1] with dz[t]
             hout = self._ws[('h%d' % li, (T, Bp, 2 * HP))].view(M, 2 * HP)
             dwh = lay.gpacked_view(gp, 'dwh%d' % li)

@@ -319,16 +319,24 @@ _LOGITS_RE = re.compile(r'(?:^|/)logits/(weights|biases)$')
 _STEP_RE = re.compile(r'(?:^|/)(Variable|global_step)$')
 _UNET_RE = re.compile(r'(?:^|/)(w|b)(?:_(\d+))?$')
 _BN_RE = re.compile(r'(?:^|/)batch_normalization(?:_(\d+))?/(gamma|beta)$')
+_SPK_RE = re.compile(r'(?:^|/)speaker_embedding/((?:weights|biases)_[123])$')
 
 
-def _local_name(tf_name, unet_specs=None):
-    """TF variable name -> this build's reference-layout entry name (None if it is not a model weight)."""
+def _local_name(tf_name, unet_specs=None, side_layer=0):
+    """TF variable name -> this build's reference-layout entry name (None if it is not a model weight).
+    The speaker-embedding models with ``integration_layer >= 1`` keep two stacks, ``blstm_1`` and
+    ``blstm_2``, each numbering its cells from 0 (models.py:882-901): blstm_2's cell l is layer
+    ``integration_layer + l`` here."""
     m = _CELL_RE.search(tf_name)
     if m:
-        return 'cell_%d/%s/%s' % (int(m.group(1)), m.group(2), m.group(3))
+        li = int(m.group(1)) + (side_layer if '/blstm_2/' in '/' + tf_name else 0)
+        return 'cell_%d/%s/%s' % (li, m.group(2), m.group(3))
     m = _LOGITS_RE.search(tf_name)
     if m:
         return 'logits/' + m.group(1)
+    m = _SPK_RE.search(tf_name)
+    if m:
+        return 'speaker_embedding/' + m.group(1)
     if unet_specs is not None:
         m = _UNET_RE.search(tf_name)
         if m:   # tf.Variable(name='w') is uniquified in creation order: w, w_1, w_2, ... (unet_layers.py:8-9,24-25)
@@ -356,18 +364,23 @@ def tf_variable_names(layout, scope):
                     out['%s/bn/%s' % (spec[0], v)] = '%s/batch_normalization%s/%s' % (scope, '_%d' % j if j else '', v)
                 j += 1
         return out
+    side_layer = layout.side[0] if getattr(layout, 'side', None) else 0
     for name, _, _ in layout.ref_entries:
         m = re.match(r'cell_(\d+)/(fw|bw)/(kernel|bias)$', name)
         if m:
-            out[name] = '%s/cudnn_lstm/stack_bidirectional_rnn/cell_%s/bidirectional_rnn/%s/cudnn_compatible_lstm_cell/%s' % (
-                scope, m.group(1), m.group(2), m.group(3))
-        elif name.startswith('logits/'):
-            out[name] = '%s/%s' % (scope, name)
+            li, stack = int(m.group(1)), 'cudnn_lstm'
+            if side_layer:      # two stacks around the integration point (models.py:882-901)
+                stack, li = ('blstm_1/cudnn_lstm', li) if li < side_layer else ('blstm_2/cudnn_lstm', li - side_layer)
+            out[name] = '%s/%s/stack_bidirectional_rnn/cell_%d/bidirectional_rnn/%s/cudnn_compatible_lstm_cell/%s' % (
+                scope, stack, li, m.group(2), m.group(3))
+        else:
+            out[name] = '%s/%s' % (scope, name)      # logits/*, speaker_embedding/*
     return out
 
 
-def import_variables(bundle, layout):
-    """Map a bundle ({tf name: array}) onto ``layout``.
+def import_variables(bundle, layout, scope=None):
+    """Map a bundle ({tf name: array}) onto ``layout``; ``scope`` restricts the match to names
+    under that variable scope (the two-step model keeps two networks in one checkpoint).
 
     Returns (flat parameters, adam_m or None, adam_v or None, global_step).  Optimiser slots are
     taken only when every variable has its ``/Adam`` and ``/Adam_1`` slot in the canonical
@@ -375,6 +388,9 @@ def import_variables(bundle, layout):
     weights import, the slots do not).  CheckpointError if a model variable is missing or has the
     wrong shape."""
     specs = getattr(layout, 'specs', None)
+    side_layer = layout.side[0] if getattr(layout, 'side', None) else 0
+    if scope is not None:
+        bundle = {k: a for k, a in bundle.items() if ('/' + k).find('/' + scope + '/') >= 0}
     flat = np.zeros(layout.ref_size, dtype=np.float32)
     slots = {'Adam': np.zeros(layout.ref_size, dtype=np.float32), 'Adam_1': np.zeros(layout.ref_size, dtype=np.float32)}
     seen, seen_slot = set(), {'Adam': set(), 'Adam_1': set()}
@@ -387,7 +403,7 @@ def import_variables(bundle, layout):
             if tf_name.endswith('/' + s):
                 slot, base = s, tf_name[:-len(s) - 1]
                 break
-        local = _local_name(base, specs)
+        local = _local_name(base, specs, side_layer)
         if local is None or local not in shapes:
             if slot is None and _STEP_RE.search(tf_name) and arr.ndim == 0 and arr.dtype.kind in 'iu':
                 step = int(arr)

@@ -28,24 +28,52 @@ from .config_utils import check_trainconfiguration, load_configfile
 from .dataset_reader import DataManager, OutOfRangeError
 
 _INPUT_OF = {'a-blstm': 'a', 'v-blstm': 'v', 'av-blstm': 'av'}
+EMBEDDING_SIZE = 512           # training_emb.py:71
+
+
+def uses_embeddings(config):
+    """Models fed with the external speaker embedding stored in the TFRecords (training_emb.py:102-110)."""
+    return str(config['model']).endswith('-emb')
 
 
 def build_model(config, mean, std, variables=None, is_training=True):
-    """Model selection of the drivers (reference training_emb.py:82-92)."""
-    kind = config['model']
+    """Model selection of the drivers (reference training_emb.py:78-117, inference.py:63-85)."""
+    from . import model_variants as mv
+    kind = str(config['model'])
     if kind == 'unet':
         model = net.UNetFConvModel(None, None, None, mean, std, 0.0, config, is_training=is_training,
                                    variables=variables)
-        model.build_graph(var_scope=kind)
-        return model
-    if kind not in _INPUT_OF:
-        print('Model selection must be "a-blstm", "v-blstm", "av-blstm" or "unet" on the MI355X path '
-              '(got "{:s}"). Closing...'.format(str(kind)))
+    elif kind == 'av-blstm-twosteps':
+        model = mv.StackedBLSTM2StepsModel(None, None, None, mean, std, 0.0, config, None, is_training=is_training,
+                                           variables=variables)
+    elif kind in _INPUT_OF:
+        model = net.StackedBLSTMModel(None, None, None, mean, std, 0.0, config, input=_INPUT_OF[kind],
+                                      variables=variables, is_training=is_training)
+    elif kind[:-5] in _INPUT_OF and kind.endswith('-ssnn'):
+        model = mv.StackedBLSTMSSNNModel(None, None, None, mean, std, 0.0, config, input=_INPUT_OF[kind[:-5]],
+                                         variables=variables, is_training=is_training)
+    elif kind[:-4] in _INPUT_OF and kind.endswith('-emb'):
+        model = mv.StackedBLSTMEmbeddingModel(None, None, None, mean, std, 0.0, config, input=_INPUT_OF[kind[:-4]],
+                                              variables=variables, is_training=is_training)
+    else:
+        print('Model selection must be "a-blstm", "v-blstm", "av-blstm" (optionally with "-ssnn" or "-emb"), '
+              '"av-blstm-twosteps" or "unet" (got "{:s}"). Closing...'.format(kind))
         sys.exit(1)
-    model = net.StackedBLSTMModel(None, None, None, mean, std, 0.0, config, input=_INPUT_OF[kind],
-                                  variables=variables, is_training=is_training)
     model.build_graph(var_scope=kind)
     return model
+
+
+def unpack_batch(batch, with_embeddings):
+    """Reader tuple -> feed kwargs (+ sample paths).  Reference: training_emb.py:238-249."""
+    if with_embeddings:
+        length, _, audio, emb, paths, _, video, mask = batch
+    else:
+        length, _, audio, paths, _, video, mask = batch
+        emb = None
+    feed = dict(sequence_lengths=length, target_sources=audio, video_features=video, masks=mask)
+    if with_embeddings:
+        feed['embeddings'] = emb
+    return feed, paths
 
 
 def train(config_file, checkpoint_format=None):
@@ -74,7 +102,8 @@ def train(config_file, checkpoint_format=None):
 
     def manager():
         return DataManager(num_audio_samples=config['audio_len'], audio_feat_size=feat_dim,
-                           video_feat_size=config['video_feat_dim'], buffer_size=4000, mode='fixed')
+                           video_feat_size=config['video_feat_dim'], buffer_size=4000, mode='fixed',
+                           embedding_size=EMBEDDING_SIZE if uses_embeddings(config) else None)
     train_files = sorted(glob(os.path.join(data_path_train, '*.tfrecord')))
     random.Random(0 if world > 1 else None).shuffle(train_files)      # same order on every rank
     train_dm, val_dm = manager(), manager()
@@ -126,6 +155,13 @@ def train(config_file, checkpoint_format=None):
         '## Approximated number of steps per epoch: {:d}'.format(n_steps_epoch),
         '## Number of training epochs: {:d}'.format(config['max_n_epochs']),
     ]
+    if config.get('model_ckp_vnet') and hasattr(model, 'video_variables'):      # training_emb.py:162-168
+        try:
+            model.video_variables.restore(config['model_ckp_vnet'])
+            print('Visual model variables restored.')
+        except ValueError:
+            print('{:s} is not a valid checkpoint. Closing...'.format(config['model_ckp_vnet']))
+            sys.exit(2)
     if config['model_ckp']:
         try:
             model.variables.restore(config['model_ckp'])
@@ -162,7 +198,7 @@ def train(config_file, checkpoint_format=None):
         nframe_sum = 0
         while True:
             try:
-                length_batch, _, audio_batch, _, _, video_batch, mask_batch = train_it.get_next()
+                feed, _ = unpack_batch(train_it.get_next(), uses_embeddings(config))
             except OutOfRangeError:
                 if chief:
                     print('Completed epoch {:d} at step {:d} --> Training loss: {:3.5f} - {:3.5f}'.format(
@@ -173,8 +209,7 @@ def train(config_file, checkpoint_format=None):
                 break
             n_step += 1
             tot_step += 1
-            model.feed(sequence_lengths=length_batch, target_sources=audio_batch, video_features=video_batch,
-                       masks=mask_batch)
+            model.feed(**feed)
             loss, loss_fn, lr = float(model.loss), float(model.loss_func), model.learning_rate
             model.train_op
             if np.isnan(loss):
@@ -183,7 +218,7 @@ def train(config_file, checkpoint_format=None):
             if np.isinf(loss):
                 print('GOT INSTABILITY: loss is inf. Leaving...')
                 sys.exit(1)
-            frames = np.count_nonzero(mask_batch == 0)
+            frames = np.count_nonzero(feed['masks'] == 0)
             if n_step == 1:
                 nframe_sum = frames // feat_dim
                 train_avg_loss, train_avg_loss_fn = loss, loss_fn
@@ -207,14 +242,13 @@ def train(config_file, checkpoint_format=None):
         nframe_sum = 0
         while True:
             try:
-                length_batch, _, audio_batch, _, _, video_batch, mask_batch = val_it.get_next()
+                feed, _ = unpack_batch(val_it.get_next(), uses_embeddings(config))
             except OutOfRangeError:
                 break
             n_step += 1
-            model.feed(sequence_lengths=length_batch, target_sources=audio_batch, video_features=video_batch,
-                       masks=mask_batch)
+            model.feed(**feed)
             loss = float(model.loss_func)
-            frames = np.count_nonzero(mask_batch == 0)
+            frames = np.count_nonzero(feed['masks'] == 0)
             if n_step == 1:
                 nframe_sum = frames // feat_dim
                 val_avg_loss = loss

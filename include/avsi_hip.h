@@ -240,7 +240,8 @@ int avsi_istft_f32(const avsi_istft_args* args, void* stream);
  * avsi_col2im_f32 (input).  im2col can read a second, half-resolution source through a nearest
  * 2x up-sampling and appends its channels after src0's (UpSampling2D + concat, unet_layers.py:28-29).
  * Batch normalisation uses batch statistics (training=True, biased variance, eps = 1e-3);
- * act: 0 none, 1 relu, 2 leaky_relu(0.2).  Pass mean = null for layers without batch norm.
+ * act: 0 none, 1 relu, 2 leaky_relu(0.2), 3 leaky_relu(0.3) (the speaker-embedding MLP,
+ * models.py:822-824).  Pass mean = null for layers without batch norm.
  * workspace for the reductions: avsi_unet_workspace_bytes(C).
  * ------------------------------------------------------------------------------------ */
 int avsi_im2col_f32(const float* src0, int C0, int ld0, const float* src1_coarse, int C1, int ld1,

@@ -10,7 +10,7 @@ pytestmark = pytest.mark.gpu
 N, T = 3840, 20
 
 
-def _make_dataset(root, n, seed):
+def _make_dataset(root, n, seed, embeddings=False):
     import avsi_amd  # noqa: F401
     from avsi_amd import tfrecord_io as tio
     os.makedirs(root, exist_ok=True)
@@ -22,7 +22,8 @@ def _make_dataset(root, n, seed):
         s = rng.integers(2, T - 6)
         mask[s:s + 4] = 0
         video = rng.normal(size=(T, 136)).astype(np.float32)
-        rec = tio.serialize_sample_fixed(T, 3, wav, video, mask, np.zeros(50), "clip_%03d" % i)
+        emb = rng.normal(size=512).astype(np.float32) if embeddings else None
+        rec = tio.serialize_sample_fixed(T, 3, wav, video, mask, np.zeros(50), "clip_%03d" % i, embedding=emb)
         tio.write_records(os.path.join(root, "data_%05d.tfrecord" % (i + 1)), [rec])
     np.save(os.path.join(root, "seq_lengths.npy"), np.full(n, T))
 
@@ -113,3 +114,57 @@ def test_infer_writes_int16_wavs(experiment, oracle_phase, capsys):
         rate, wav = wavfile.read(str(audio_out / ("clip_%03d" % i) / "enhanced" / "av_exp0.wav"))
         assert rate == 16000 and wav.dtype == np.int16 and wav.shape == (T * 192,)
         assert np.abs(wav).max() > 0
+
+
+@pytest.mark.parametrize("model_name,fmt", [("a-blstm-emb", "npz"), ("av-blstm-ssnn", "tf"), ("av-blstm-twosteps", "tf"),
+                                            ("av-blstm-twosteps", "npz")])
+def test_variant_models_train_and_infer(experiment, tmp_path, model_name, fmt, capsys):
+    """The model variants through the same drivers: TFRecords (with the embedding context feature
+    for *-emb) -> train() -> checkpoint in either format -> infer() -> WAVs."""
+    import torch
+    from avsi_amd import inference, training
+    base, data0, cfg0 = experiment
+    data = str(tmp_path / "tfrecords")
+    emb = model_name.endswith('-emb')
+    _make_dataset(os.path.join(data, "training-set"), 8, 0, emb)
+    _make_dataset(os.path.join(data, "validation-set"), 4, 1, emb)
+    _make_dataset(os.path.join(data, "test-set"), 3, 2, emb)
+    exp = tmp_path / "logs" / "exp"
+    text = open(cfg0).read().replace("model = av-blstm", "model = %s" % model_name)
+    text = text.replace("root_folder = %s" % data0, "root_folder = %s" % data)
+    text = text.replace("exp_folder = %s" % (base / "logs" / "av_exp0"), "exp_folder = %s" % exp)
+    text = text.replace("max_n_epochs = 3", "max_n_epochs = 2") + "integration_layer = 1\n"
+    cfg = tmp_path / "v.config"
+    cfg.write_text(text)
+    model = training.train(str(cfg), checkpoint_format=fmt)
+    assert model.global_step == 4
+    net = exp / "netmodel"
+    if fmt == 'tf':
+        from avsi_amd import tf_checkpoint as tc
+        names = [n for n, _, _ in tc.list_variables(str(net / "sinet"))]
+        if model_name == 'av-blstm-ssnn':
+            assert 'av-blstm-ssnn/speaker_embedding/weights_1' in names
+            assert any('/blstm_2/cudnn_lstm/stack_bidirectional_rnn/cell_1/' in n for n in names)
+            assert any('/blstm_1/cudnn_lstm/stack_bidirectional_rnn/cell_0/' in n for n in names)
+        else:
+            assert any(n.startswith('v-blstm/cudnn_lstm/') for n in names)
+            assert any(n.startswith('av-blstm-twosteps/cudnn_lstm/') and n.endswith('/Adam_1') for n in names)
+    else:
+        assert (net / "sinet.npz").is_file()
+        assert (net / "sinet.vnet.npz").is_file() == (model_name == 'av-blstm-twosteps')
+    audio_out = tmp_path / "audio"
+    loss = inference.infer(str(net), os.path.join(data, "test-set"), str(audio_out), "exp", norm=True,
+                           oracle_phase=False, batch_size=2)
+    assert np.isfinite(loss)
+    for i in range(3):
+        rate, wav = wavfile.read(str(audio_out / ("clip_%03d" % i) / "enhanced" / "exp.wav"))
+        assert rate == 16000 and wav.dtype == np.int16 and wav.shape == (T * 192,) and np.abs(wav).max() > 0
+    # the restored model is the trained one
+    from avsi_amd.config_utils import check_trainconfiguration, load_configfile
+    config = check_trainconfiguration(load_configfile(str(net / "config.txt")))
+    m2 = training.build_model(config, np.load(str(net / "audio_features_mean.npy")),
+                              np.load(str(net / "audio_features_std.npy")), is_training=False)
+    m2.variables.restore(str(net / "sinet"))
+    assert m2.variables.global_step in (2, 4)
+    if model_name == 'av-blstm-twosteps':
+        assert torch.equal(m2.video_variables.flat, model.video_variables.flat)

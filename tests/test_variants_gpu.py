@@ -143,3 +143,48 @@ def test_two_steps_model():
     f1b = OB.model_forward(wav * 0.5, masks, mean, std, seq, pv, video=video, input_type='v', dtype=np.float64)
     np.testing.assert_allclose(m.video_prediction.cpu().numpy(), f1b['prediction'], rtol=2e-4, atol=2e-4)
     assert m.prediction.shape == (B, T, 257)
+
+
+@pytest.mark.parametrize('int_layer,input_type', [(0, 'a'), (1, 'av'), (0, 'v')])
+def test_ssnn_model_forward_backward(int_layer, input_type):
+    import avsi_amd  # noqa: F401
+    from avsi_amd import models
+    from avsi_amd.blstm_layout import ParamLayout, round_up
+    from avsi_amd.model_variants import StackedBLSTMSSNNModel
+    B, N, E = 3, 2880, 200
+    wav, masks, mean, std, video, seq, T = _inputs(B, N, 30 + int_layer, ragged=True)
+    D = {'a': 257, 'av': 393, 'v': 136}[input_type]
+    params = OV.init_variant_params(4, D, int_layer, E, mlp=True)
+    pitch = round_up(257 if input_type == 'v' else D, 8)
+    layout = ParamLayout(D, (250, 250, 250), 257, side=(int_layer, E), mlp=E, mlp_in_pitch=pitch)
+    variables = models.BLSTMVariables(layout)
+    variables.load_flat(layout.flatten_oracle_params(params))
+    cfg = _config(integration_layer=int_layer, audio_len=N)
+    vid = video if input_type != 'a' else None
+    m = StackedBLSTMSSNNModel(seq, wav, masks, mean, std, 0.0, cfg, video_features=vid, input=input_type,
+                              is_training=True, variables=variables)
+    m.build_graph(input_type + '-blstm-ssnn')
+    tp = OV.params_to_torch(params)
+    ref = OV.variant_forward(wav, masks, mean, std, seq, tp, int_layer, video=vid, input_type=input_type)
+    ref['loss'].backward()
+    np.testing.assert_allclose(m.speaker_embedding.cpu().numpy(), ref['speaker_embedding'].detach().numpy(),
+                               rtol=2e-4, atol=2e-5)
+    np.testing.assert_allclose(m.prediction.cpu().numpy(), ref['prediction'].detach().numpy(), rtol=2e-4, atol=2e-4)
+    np.testing.assert_allclose(float(m.loss), float(ref['loss'].detach()), rtol=1e-4)
+    g = m.gradients.cpu().numpy().astype(np.float64)
+    gn = OV.grads_to_numpy(tp)
+    gref = layout.flatten_oracle_params(gn).astype(np.float64)
+    np.testing.assert_allclose(g, gref, rtol=2e-3, atol=2e-5 * np.abs(gref).max())
+    # the MLP's own gradients, separately (they are small next to the BLSTM's)
+    for k in ('weights_1', 'biases_1', 'weights_2', 'biases_2', 'weights_3', 'biases_3'):
+        got, want = layout.ref_view(g, 'speaker_embedding/' + k), gn['mlp'][k]
+        assert np.abs(want).max() > 0
+        np.testing.assert_allclose(got, want, rtol=5e-3, atol=5e-4 * np.abs(want).max(), err_msg=k)
+    before = variables.flat.clone()
+    m.train_op
+    assert float((variables.flat - before).abs().max()) <= 1.01e-3
+    # TF-style default initialisation covers the MLP (truncated normal, zero biases)
+    fresh = models.BLSTMVariables(layout, seed=1)
+    w1 = layout.ref_view(fresh.flat.cpu().numpy(), 'speaker_embedding/weights_1')
+    assert 0.5 / np.sqrt(257) < w1.std() < 1.0 / np.sqrt(257) and np.abs(w1).max() <= 2.0 / np.sqrt(257) + 1e-6
+    assert np.all(layout.ref_view(fresh.flat.cpu().numpy(), 'speaker_embedding/biases_2') == 0)
