@@ -2,8 +2,9 @@
 
 Sub-commands, flags, defaults and dispatch follow the reference CLI
 (``av_speech_inpainting/speech_inpainting_main.py:18-257``).  The sub-commands that run the hot
-path are implemented (``audio_preprocessing``, ``masking``, ``training``, ``inference``); the
-reference's offline data preparation, ASR and evaluation sub-commands are accepted by the parser
+path and the data preparation around it are implemented (``dataset_generator``,
+``tfrecords_generator``, ``audio_preprocessing``, ``masking``, ``training``, ``inference``); the
+reference's landmark extraction, ASR and evaluation sub-commands are accepted by the parser
 (same flags) but exit with a message: they are outside the scope of this package.
 Unlike the reference, ``training`` runs the plain a/v/av-BLSTM trainer.
 """
@@ -21,7 +22,7 @@ def build_parser():
     sub = parser.add_subparsers(dest='subparser_name')
     on = dict(action='store_const', const=True, default=False)
 
-    p = sub.add_parser('dataset_generator', description='Generate masks dataset (not part of this package).')
+    p = sub.add_parser('dataset_generator', description='Generate masks dataset. Files are saved in <dest_dir>.')
     _flag(p, '-ca', '--clean_audio_dir', required=True)
     _flag(p, '-bs', '--speaker_ids', nargs='+', type=int, required=True)
     _flag(p, '-d', '--dest_dir', required=True)
@@ -59,7 +60,8 @@ def build_parser():
     _flag(p, '-sp', '--shape_predictor', required=True)
     _flag(p, '-e', '--ext', required=True, default='mpg')
 
-    p = sub.add_parser('tfrecords_generator', description='TFRecord creation from WAV/landmark folders (not part of this package).')
+    p = sub.add_parser('tfrecords_generator', description='TFRecord creation from the sample folders of dataset_generator.')
+    _flag(p, '--embeddings', help='also store <sample>/vgg_embeddings/target.npy (the *-emb models)', **on)
     _flag(p, '-m', '--mode', default='fixed', choices=['fixed', 'var'])
     _flag(p, '-a', '--dataset_dir', required=True)
     _flag(p, '-d', '--dest_dir', required=True)
@@ -130,14 +132,21 @@ def build_parser():
     return parser
 
 
-OUT_OF_SCOPE = ('dataset_generator', 'video_preprocessing', 'tfrecords_generator', 'tfrecords_grouping', 'training_asr',
+OUT_OF_SCOPE = ('video_preprocessing', 'tfrecords_grouping', 'training_asr',
                 'inference_model_generation', 'inference_asr', 'inference_siasr', 'evaluation')
 
 
 def main(argv=None):
     args = build_parser().parse_args(argv)
     cmd = args.subparser_name
-    if cmd == 'audio_preprocessing':
+    if cmd == 'dataset_generator':
+        from .dataset_generator import create_syn_dataset
+        create_syn_dataset(args.clean_audio_dir, args.dest_dir, args.speaker_ids, args.num_samples, args.audio_length,
+                           args.num_max_intr, args.mask_coverage_mean, args.mask_coverage_std, args.ext)
+    elif cmd == 'tfrecords_generator':
+        from .tfrecord_utils import create_dataset
+        create_dataset(args.dataset_dir, args.dest_dir, args.dict_file, args.mode, args.embeddings)
+    elif cmd == 'audio_preprocessing':
         from .audio_feat_preprocessing import compute_mean_std_features
         compute_mean_std_features(args.audio_dir, args.file_prefix, args.out_prefix, args.type, args.sample_rate,
                                   args.fft_size, args.window_size, args.step_size, args.preemph, args.num_mel_bins,

@@ -1,0 +1,175 @@
+"""Data preparation around the hot path: gap-mask generator, audio-visual sync,
+sample folders -> TFRecords.  The label helpers are pinned by goldens produced by the reference's
+own functions (tests/golden/make_labels_golden.py); the rest by properties and independent checks
+(the reference modules need pydub / a SciPy that still has interp2d)."""
+import json
+import os
+import random
+
+import numpy as np
+import pytest
+from scipy.io import wavfile
+
+import avsi_amd  # noqa: F401
+from avsi_amd import av_sync, dataset_generator as dg, tfrecord_io, tfrecord_utils as tu
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+
+
+# ------------------------------------------------------------------ masks
+@pytest.mark.parametrize('n_max', [1, 2, 4])
+def test_intrusion_masks_properties(n_max):
+    random.seed(7)
+    for _ in range(300):
+        mask, cov, n = dg.get_intrusions_mask(257, 250, 400 / 3000, 100 / 3000, n_max)
+        assert mask.shape == (250, 257) and set(np.unique(mask)) <= {0.0, 1.0}
+        assert 1 <= n <= n_max
+        rows = mask[:, 0]
+        assert np.all(mask == rows[:, None])                      # whole frames are masked
+        assert cov <= 0.8 + 1e-12 and cov >= 3 * n / 250 - 0.5 / 250
+        masked = int((rows == 0).sum())
+        assert masked <= int(round(cov * 250))                    # gaps may overlap / run off the end, never exceed
+        if n == 1:
+            assert masked == int(round(cov * 250))
+            runs = np.flatnonzero(np.diff(np.concatenate([[1], rows, [1]])))
+            assert len(runs) == 2                                 # one contiguous gap
+
+
+def test_intrusion_mask_rng_trace_single_gap(monkeypatch):
+    """n_max_intr = 1 draws exactly: randint(1, 1), gauss(mean, std), randint(0, T - gap)."""
+    calls = []
+    monkeypatch.setattr(random, 'randint', lambda a, b: calls.append(('randint', a, b)) or (1 if len(calls) == 1 else 37))
+    monkeypatch.setattr(random, 'gauss', lambda m, s: calls.append(('gauss', m, s)) or 0.1337)
+    monkeypatch.setattr(random, 'shuffle', lambda x: calls.append(('shuffle', tuple(x))))
+    mask, cov, n = dg.get_intrusions_mask(257, 250, 0.1333, 0.0, 1)
+    gap = int(np.around(250 * 0.1337))                            # 33 frames = 400 ms
+    assert calls == [('randint', 1, 1), ('gauss', 0.1333, 0.0), ('shuffle', (gap,)), ('randint', 0, 250 - gap)]
+    assert n == 1 and cov == gap / 250 and np.all(mask[37:37 + gap] == 0) and mask.sum() == (250 - gap) * 257
+
+
+def test_intrusion_mask_is_seed_reproducible_and_coverage_capped():
+    random.seed(30)
+    a = dg.get_intrusions_mask(257, 250, 0.3, 0.1, 3)
+    random.seed(30)
+    b = dg.get_intrusions_mask(257, 250, 0.3, 0.1, 3)
+    assert np.array_equal(a[0], b[0]) and a[1:] == b[1:]
+    random.seed(1)
+    _, cov, _ = dg.get_intrusions_mask(257, 100, 5.0, 0.0, 1)     # asks for 500 % coverage
+    assert cov == 0.8
+
+
+# ------------------------------------------------------------------ sync
+def test_inc_fps_matches_bilinear_spline_and_clamps():
+    from scipy.interpolate import RectBivariateSpline
+    rng = np.random.default_rng(0)
+    frames = rng.normal(size=(75, 136))
+    got = av_sync.inc_fps(frames, 250)
+    assert got.shape == (250, 136)
+    # the regular-grid replacement SciPy names for interp2d(kind='linear')
+    y_inc = np.linspace(0, 75 * (1 - 1 / 250), 250)
+    want = RectBivariateSpline(np.arange(75), np.arange(136), frames, kx=1, ky=1)(np.minimum(y_inc, 74), np.arange(136))
+    np.testing.assert_allclose(got, want, rtol=1e-10, atol=1e-12)
+    np.testing.assert_array_equal(got[0], frames[0])
+    np.testing.assert_allclose(got[-1], frames[-1])              # 74.7 > 74: clamped to the last frame
+    np.testing.assert_allclose(av_sync.inc_fps(frames, 75), frames)
+
+
+def test_sync_rejects_and_pads():
+    mask = np.ones((250, 257))
+    v = np.arange(72 * 136, dtype=np.float64).reshape(72, 136)
+    assert av_sync.sync_audio_visual_features(mask, v[:60], tot_frames=75, min_frames=70) is None
+    assert av_sync.sync_audio_visual_features(mask, v.reshape(-1), tot_frames=75, min_frames=70) is None
+    out = av_sync.sync_audio_visual_features(mask, v, tot_frames=75, min_frames=70)
+    assert out.shape == (250, 136)
+    np.testing.assert_allclose(out[:10], np.tile(v[0], (10, 1)), rtol=1e-12)  # 3 replicated first frames ~ 10 output frames
+    end = av_sync.sync_audio_visual_features(mask, v, tot_frames=75, min_frames=70, pad='end')
+    np.testing.assert_allclose(end[-1], v[0], rtol=1e-12)                # the reference pads the end with the FIRST frame
+
+
+# ------------------------------------------------------------------ labels (reference goldens)
+def test_labels_match_reference_goldens(tmp_path):
+    gold = json.load(open(os.path.join(GOLD, 'labels_golden.json')))
+    path = tmp_path / 'dict.txt'
+    path.write_text(gold['dict_text'])
+    dictionary = tu.load_dictionary(str(path))
+    assert dictionary == gold['dictionary']
+    for case in gold['cases']:
+        assert tu.get_labels(case['transcription'], dictionary).tolist() == case['labels'], case['transcription']
+
+
+def test_motion_vector():
+    x = np.cumsum(np.arange(12, dtype=np.float64).reshape(4, 3), axis=0)
+    mv = tu.get_motion_vector(x, delta=1)
+    assert np.all(mv[0] == 0) and np.array_equal(mv[1:], np.diff(x, axis=0))
+    assert tu.get_motion_vector(x, delta=2).shape == (3, 3)
+    assert tu.get_motion_vector(x, delta=0) is not None and np.array_equal(tu.get_motion_vector(x, delta=0), x)
+
+
+# ------------------------------------------------------------------ folders -> TFRecords -> reader
+def _grid_like(root, n_clips=3, frames=(75, 75, 60)):
+    rng = np.random.default_rng(0)
+    spk = os.path.join(root, 's1')
+    for sub in ('s1_16kHz', 's1.landmarks', 'align'):
+        os.makedirs(os.path.join(spk, sub))
+    for i in range(n_clips):
+        wav = np.clip(np.round(rng.normal(0, 3000, 48000)), -32768, 32767).astype(np.int16)
+        wavfile.write(os.path.join(spk, 's1_16kHz', 'clip%d.wav' % i), 16000, wav)
+        np.save(os.path.join(spk, 's1.landmarks', 'clip%d.npy' % i), rng.normal(size=(frames[i], 68, 2)))
+        open(os.path.join(spk, 'align', 'clip%d.lbl' % i), 'w').write('B,IH,N,SP,AE,T')
+    np.save(os.path.join(spk, 's1.landmarks', 'video_feat_mean.npy'), rng.normal(size=(1, 136)))
+    np.save(os.path.join(spk, 's1.landmarks', 'video_feat_std.npy'), 1 + rng.random((1, 136)))
+    return spk
+
+
+def test_generator_to_tfrecords_to_reader(tmp_path, capsys):
+    from avsi_amd.dataset_reader import DataManager
+    _grid_like(str(tmp_path / 'GRID'))
+    samples = str(tmp_path / 'samples')
+    random.seed(5)
+    covs = dg.create_syn_dataset(str(tmp_path / 'GRID'), os.path.join(samples, 'training-set'), [1], 0, 3000, 1, 400, 0)
+    assert len(covs) == 3 and all(abs(c - 33 / 250) < 1e-12 for c in covs)
+    out = capsys.readouterr().out
+    assert 'Number of generated samples: 3. Total length: 9.00 seconds' in out
+    assert 'True mask coverage mean: 396.00 ms - std: 0.00 ms' in out
+    names = sorted(os.listdir(os.path.join(samples, 'training-set')))
+    assert names == ['s1_clip0_396_1', 's1_clip1_396_1', 's1_clip2_396_1']
+    assert sorted(os.listdir(os.path.join(samples, 'training-set', names[0]))) == [
+        'landmarks.npy', 'mask.npy', 'target.wav', 'transcription.lbl', 'video_feat_mean.npy', 'video_feat_std.npy']
+    for sub in ('validation-set', 'test-set'):
+        os.makedirs(os.path.join(samples, sub))
+    dict_file = tmp_path / 'dict.txt'
+    dict_file.write_text('B IH N\nAE T\nSP\n')
+    counts = tu.create_dataset(samples, str(tmp_path / 'tfr'), str(dict_file))
+    assert counts == [2, 0, 0]                                    # clip2 has 60 landmark frames: skipped
+    assert 'Skipped. Video features corrupted.' in capsys.readouterr().out
+    tdir = str(tmp_path / 'tfr' / 'training-set')
+    assert sorted(os.listdir(tdir)) == ['data_00001.tfrecord', 'data_00002.tfrecord', 'seq_lengths.npy']
+    assert np.load(os.path.join(tdir, 'seq_lengths.npy')).tolist() == [250, 250]
+    dm = DataManager(num_audio_samples=48000)
+    _, it = dm.get_iterator(dm.get_dataset(sorted(os.path.join(tdir, f) for f in os.listdir(tdir) if f.endswith('.tfrecord')),
+                                           shuffle=False), batch_size=2, n_epochs=1)
+    it.initializer()
+    length, lab_len, audio, paths, labels, video, mask = it.get_next()
+    assert length.tolist() == [250, 250] and lab_len.tolist() == [5, 5]
+    assert [p.decode() for p in paths] == ['s1_clip0_396_1', 's1_clip1_396_1']
+    _, wav0 = wavfile.read(os.path.join(samples, 'training-set', 's1_clip0_396_1', 'target.wav'))
+    np.testing.assert_array_equal(audio[0], wav0.astype(np.int32))
+    np.testing.assert_array_equal(mask[0], np.load(os.path.join(samples, 'training-set', 's1_clip0_396_1', 'mask.npy')))
+    assert labels.shape == (2, 50) and labels[0, :6].tolist() == [1.0, 2.0, 3.0, 0.0, 5.0, 0.0]
+    assert video.shape == (2, 250, 136)
+    # video = normalised first difference of the synchronised landmarks; row 0 = -mean / std
+    sd = os.path.join(samples, 'training-set', 's1_clip0_396_1')
+    mean, std = np.load(os.path.join(sd, 'video_feat_mean.npy')).ravel(), np.load(os.path.join(sd, 'video_feat_std.npy')).ravel()
+    np.testing.assert_allclose(video[0, 0], -mean / std, rtol=1e-5)
+    lm = av_sync.inc_fps(np.load(os.path.join(sd, 'landmarks.npy')).reshape(-1, 136), 250)
+    np.testing.assert_allclose(video[0, 1:], (np.diff(lm, axis=0) - mean) / std, rtol=1e-4, atol=1e-5)
+
+
+def test_cli_dataset_generator(tmp_path, capsys):
+    from avsi_amd import speech_inpainting_main as cli
+    _grid_like(str(tmp_path / 'GRID'))
+    random.seed(3)
+    cli.main(['dataset_generator', '-ca', str(tmp_path / 'GRID'), '-bs', '1', '-d', str(tmp_path / 'out'), '-num', '2',
+              '-al', '3000', '-i', '2', '-cm', '800', '-cs', '100'])
+    assert len(os.listdir(str(tmp_path / 'out'))) == 2
+    assert 'Dataset generation completed.' in capsys.readouterr().out
