@@ -332,10 +332,16 @@ __device__ __forceinline__ void dma16(const float* src, uint32_t lds_byte_addr) 
     asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(src), "s"(lds_byte_addr) : "memory", "m0");
 }
 
-template <bool TA, bool TB>
-__global__ __launch_bounds__(256, 3) void gemm_dma_kernel(const GemmArgs g) {
+template <bool TA, bool TB, int BK, int NST>
+__global__ __launch_bounds__(256, BK == 16 ? (NST == 3 ? 3 : 4) : 2) void gemm_dma_kernel(const GemmArgs g) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int BK = 16, BM = 128, TILE = 128 * 16, NST = 3;
+    static_assert((BK == 16 && (NST == 3 || NST == 2)) || (BK == 32 && NST == 2), "tile shapes this kernel was tuned for");
+    constexpr int BM = 128, TILE = 128 * BK;
+    constexpr int PPW = BK / 8;         // 1-KiB DMA pieces per wave and operand tile
+    constexpr int CPR = BK / 4;         // 16-byte chunks per row of a "row" tile
+    constexpr int RPP = 256 / BK;       // rows of a "row" tile per DMA piece
+    // XOR swizzle of the chunk index inside a row: spreads the ds_read_b128 of 8 neighbouring rows over all banks
+    auto swz = [](int row) { return BK == 16 ? (row >> 2) & 3 : row & 7; };
     float* sA = reinterpret_cast<float*>(smem);
     float* sB = sA + NST * TILE;
     const uint32_t lds_a = (uint32_t)(uintptr_t)(lvoid_t)smem, lds_b = lds_a + NST * TILE * 4u;
@@ -360,20 +366,20 @@ __global__ __launch_bounds__(256, 3) void gemm_dma_kernel(const GemmArgs g) {
     const int nk = (kend - kbeg) / BK;
     float* __restrict__ C = g.C + (int64_t)blockIdx.z * g.c_split_stride;
 
-    // per-lane source offsets (floats, relative to the tile origin) of this wave's two DMA pieces per operand
-    int64_t offa[2], offb[2];
+    // per-lane source offsets (floats, relative to the tile origin) of this wave's DMA pieces per operand
+    int64_t offa[PPW], offb[PPW];
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int p = wave * 2 + j;  // 1-KiB piece of the 8-KiB tile
+    for (int j = 0; j < PPW; ++j) {
+        const int p = wave * PPW + j;  // 1-KiB piece of the tile
         if (!TA) {  // row tile [m][k]
-            const int row = p * 16 + (lane >> 2), cl = (lane & 3) ^ ((row >> 2) & 3);
+            const int row = p * RPP + lane / CPR, cl = (lane % CPR) ^ swz(row);
             offa[j] = (int64_t)(min(m0 + row, g.M - 1) - m0) * g.lda + cl * 4;
         } else {    // col tile [k][m]
             const int x = min(m0 + 4 * (lane & 31), ((g.M + 3) & ~3) - 4) - m0;
             offa[j] = (int64_t)(2 * p + (lane >> 5)) * g.lda + x;
         }
         if (TB) {   // row tile [n][k]
-            const int row = p * 16 + (lane >> 2), cl = (lane & 3) ^ ((row >> 2) & 3);
+            const int row = p * RPP + lane / CPR, cl = (lane % CPR) ^ swz(row);
             offb[j] = (int64_t)(min(n0 + row, g.N - 1) - n0) * g.ldb + cl * 4;
         } else {    // col tile [k][n]
             const int x = min(n0 + 4 * (lane & 31), ((g.N + 3) & ~3) - 4) - n0;
@@ -389,9 +395,9 @@ __global__ __launch_bounds__(256, 3) void gemm_dma_kernel(const GemmArgs g) {
         const float* ao = a_org + kt * a_step;
         const float* bo = b_org + kt * b_step;
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            dma16(ao + offa[j], lds_a + (uint32_t)(st * TILE + (wave * 2 + j) * 256) * 4u);
-            dma16(bo + offb[j], lds_b + (uint32_t)(st * TILE + (wave * 2 + j) * 256) * 4u);
+        for (int j = 0; j < PPW; ++j) {
+            dma16(ao + offa[j], lds_a + (uint32_t)(st * TILE + (wave * PPW + j) * 256) * 4u);
+            dma16(bo + offb[j], lds_b + (uint32_t)(st * TILE + (wave * PPW + j) * 256) * 4u);
         }
     };
 
@@ -403,13 +409,13 @@ __global__ __launch_bounds__(256, 3) void gemm_dma_kernel(const GemmArgs g) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    // fragments of one 8-deep k group (q = 0, 1) of a staged tile pair
+    // fragments of one 8-deep k group (q < BK / 8) of a staged tile pair
     auto rd = [&](int q, const float* a_s, const float* b_s, float (&a)[2][4], float (&b)[2][4]) {
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int row = wm * 64 + i * 32 + li;
             if (!TA) {
-                const float4 v = *reinterpret_cast<const float4*>(a_s + row * 16 + (((2 * q + hi) ^ ((row >> 2) & 3)) << 2));
+                const float4 v = *reinterpret_cast<const float4*>(a_s + row * BK + (((2 * q + hi) ^ swz(row)) << 2));
                 a[i][0] = v.x, a[i][1] = v.y, a[i][2] = v.z, a[i][3] = v.w;
             } else {
 #pragma unroll
@@ -420,7 +426,7 @@ __global__ __launch_bounds__(256, 3) void gemm_dma_kernel(const GemmArgs g) {
         for (int j = 0; j < 2; ++j) {
             const int col = wn * 64 + j * 32 + li;
             if (TB) {
-                const float4 v = *reinterpret_cast<const float4*>(b_s + col * 16 + (((2 * q + hi) ^ ((col >> 2) & 3)) << 2));
+                const float4 v = *reinterpret_cast<const float4*>(b_s + col * BK + (((2 * q + hi) ^ swz(col)) << 2));
                 b[j][0] = v.x, b[j][1] = v.y, b[j][2] = v.z, b[j][3] = v.w;
             } else {
 #pragma unroll
@@ -438,27 +444,33 @@ __global__ __launch_bounds__(256, 3) void gemm_dma_kernel(const GemmArgs g) {
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][s], b[j][s], acc[i][j], 0, 0, 0);
     };
 
+    // ring of NST stages: tiles kt+1 .. kt+NST-1 are in flight / landed while tile kt is computed
+    constexpr int PPT = 2 * PPW;        // DMA instructions per wave and k-tile
     if (nk > 0) issue(0);
-    if (nk > 1) issue(1);
-    if (nk > 1)
-        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    if (NST == 3 && nk > 1) issue(1);
+    if (NST == 3 && nk > 1)
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPT) : "memory");
     else
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
 
     float af[2][2][4], bf[2][2][4];
     for (int kt = 0; kt < nk; ++kt) {
-        // stage (kt+2)%3 was last read (tile kt-1) before the barrier of iteration kt-1
-        if (kt + 2 < nk) issue(kt + 2);
+        // the stage being refilled was last read (tile kt-1) before the barrier of iteration kt-1
+        if (kt + NST - 1 < nk) issue(kt + NST - 1);
         const float* a_s = sA + (kt % NST) * TILE;
         const float* b_s = sB + (kt % NST) * TILE;
-        rd(0, a_s, b_s, af[0], bf[0]);
-        rd(1, a_s, b_s, af[1], bf[1]);
-        mm(af[0], bf[0]);
-        mm(af[1], bf[1]);
-        // tile kt+1 must have landed before anyone reads it; tile kt+2's DMAs (just issued) stay in flight
-        if (kt + 2 < nk)
-            asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int h = 0; h < BK / 16; ++h) {
+            rd(2 * h, a_s, b_s, af[0], bf[0]);
+            rd(2 * h + 1, a_s, b_s, af[1], bf[1]);
+            mm(af[0], bf[0]);
+            mm(af[1], bf[1]);
+        }
+        // tile kt+1 must have landed before anyone reads it; with three stages tile kt+2's DMAs (just
+        // issued) stay in flight across the barrier
+        if (NST == 3 && kt + 2 < nk)
+            asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(PPT) : "memory");
         else
             asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
@@ -501,7 +513,17 @@ __global__ __launch_bounds__(256, 3) void gemm_dma_kernel(const GemmArgs g) {
 template <bool TA, bool TB>
 int launch_dma(const GemmArgs& g, int splits, hipStream_t st) {
     constexpr size_t lds = (size_t)2 * 3 * 128 * 16 * 4;   // 48 KiB: three stages of A and B
-    hipLaunchKernelGGL((gemm_dma_kernel<TA, TB>), dim3(g.m_blocks * g.n_blocks, 1, splits), dim3(256), lds, st, g);
+    if (getenv("AVSI_GEMM_DMA") && atoi(getenv("AVSI_GEMM_DMA")) == 2 && g.k_split_len % 32 == 0 && g.K % 32 == 0) {
+        hipLaunchKernelGGL((gemm_dma_kernel<TA, TB, 32, 2>), dim3(g.m_blocks * g.n_blocks, 1, splits), dim3(256),
+                           2 * 2 * 128 * 32 * 4, st, g);
+        return avsi_launch_status();
+    }
+    if (getenv("AVSI_GEMM_DMA") && atoi(getenv("AVSI_GEMM_DMA")) == 3) {
+        hipLaunchKernelGGL((gemm_dma_kernel<TA, TB, 16, 2>), dim3(g.m_blocks * g.n_blocks, 1, splits), dim3(256),
+                           2 * 2 * 128 * 16 * 4, st, g);
+        return avsi_launch_status();
+    }
+    hipLaunchKernelGGL((gemm_dma_kernel<TA, TB, 16, 3>), dim3(g.m_blocks * g.n_blocks, 1, splits), dim3(256), lds, st, g);
     return avsi_launch_status();
 }
 
