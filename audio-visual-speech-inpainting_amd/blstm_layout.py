@@ -22,6 +22,12 @@ def round_up(a, b):
     return -(-a // b) * b
 
 
+def input_pitch(dim):
+    """Padded width of a network-input row: a multiple of 16 so that every input-projection GEMM
+    qualifies for the LDS-DMA kernel (reduction length % 16 == 0)."""
+    return round_up(dim, 16)
+
+
 def packed_gate_col(direction, gate, unit):
     """Column of (direction, gate, hidden unit) inside the 2048-wide packed gate row."""
     return direction * GP + (unit // 32) * 128 + gate * 32 + unit % 32
@@ -55,7 +61,7 @@ class ParamLayout:
             raise ValueError("side input must name an existing layer and a positive width, got %r" % (side,))
         self.side_p = round_up(self.side[1], 8) if self.side else 0
         self.mlp = int(mlp) if mlp else 0
-        self.mlp_in_pitch = int(mlp_in_pitch or round_up(F, 8))
+        self.mlp_in_pitch = int(mlp_in_pitch or input_pitch(F))
         if self.mlp and (self.mlp % 8 or self.mlp_in_pitch < F):
             raise ValueError("speaker-embedding width must be a multiple of 8 and its input pitch >= %d" % F)
 
@@ -86,7 +92,7 @@ class ParamLayout:
         self._ref_off = {n: o for n, _, o in self.ref_entries}
 
         # ---- packed layout
-        self.kp = [round_up(self.input_dim, 8)] + [2 * HP] * (self.num_layers - 1)
+        self.kp = [input_pitch(self.input_dim)] + [2 * HP] * (self.num_layers - 1)
         self.packed = {}                               # name -> (offset, shape)
         poff = 0
 

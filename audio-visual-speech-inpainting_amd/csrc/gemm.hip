@@ -54,7 +54,29 @@ struct GemmArgs {
     int m_blocks, n_blocks;
     int k_split_len;       // reduction length handled per blockIdx.z (multiple of BK)
     int64_t c_split_stride;  // elements between per-split partial outputs (0 = no split)
+    int n_group;           // N-blocks per column group of the block -> tile order (see tile_of_block)
 };
+
+// Block -> tile map.  Two things are arranged here:
+//  * XCD awareness: hardware deals workgroups round-robin to the 8 XCDs (blocks b and b+8 share
+//    an XCD and its L2), so the linear tile order is cut into 8 contiguous ranges, one per XCD;
+//  * column groups: the linear order is (column group, M-block, N-block inside the group).  While
+//    an XCD walks down the M-blocks of one group, the group's slice of B (K x n_group*128 floats,
+//    sized by the host to about half an L2) stays resident and every A panel is read once by the
+//    n_group workgroups that run side by side.  With the plain (M-block, N-block) order the whole
+//    of B (4 MiB for the 512 x 2048 layer kernel = one L2) was evicted by the A / C streams and
+//    re-fetched through the fabric by almost every M-block: 39.5 GB per launch against 4.2 GB of A.
+__device__ __forceinline__ void tile_of_block(const GemmArgs& g, int bid, int& bm, int& bn) {
+    const int nblk = g.m_blocks * g.n_blocks;
+    const int q = nblk / AVSI_NUM_XCD, r = nblk % AVSI_NUM_XCD;
+    const int xcd = bid % AVSI_NUM_XCD, idx = bid / AVSI_NUM_XCD;
+    const int lin = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    const int per_group = g.m_blocks * g.n_group;
+    const int grp = lin / per_group, rem = lin - grp * per_group;
+    const int width = min(g.n_group, g.n_blocks - grp * g.n_group);
+    bm = rem / width;
+    bn = grp * g.n_group + (rem - bm * width);
+}
 
 // Global -> registers for one operand tile.  ROWK: memory is [x][k] (k contiguous), else [k][x].
 template <bool ROWK, int BK, int XT>
@@ -180,15 +202,8 @@ __global__ __launch_bounds__(256, (BK == 16 && MI == 2) ? 4 : 2) void gemm_kerne
     const int wm = wave >> 1, wn = wave & 1;
     const int li = lane & 31, hi = lane >> 5;
 
-    // XCD-aware, bijective block -> tile map (blocks b and b+8 share an XCD)
-    const int nblk = g.m_blocks * g.n_blocks;
-    int bid = blockIdx.x;
-    {
-        const int q = nblk / AVSI_NUM_XCD, r = nblk % AVSI_NUM_XCD;
-        const int xcd = bid % AVSI_NUM_XCD, idx = bid / AVSI_NUM_XCD;
-        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-    }
-    const int bm = bid / g.n_blocks, bn = bid - bm * g.n_blocks;
+    int bm, bn;
+    tile_of_block(g, blockIdx.x, bm, bn);
     const int m0 = bm * BM, n0 = bn * BN;
     const int kbeg = blockIdx.z * g.k_split_len;
     const int kend = min(g.K, kbeg + g.k_split_len);
@@ -352,14 +367,8 @@ __global__ __launch_bounds__(256, BK == 16 ? (NST == 3 ? 3 : 4) : 2) void gemm_d
     const int wm = wave >> 1, wn = wave & 1;
     const int li = lane & 31, hi = lane >> 5;
 
-    const int nblk = g.m_blocks * g.n_blocks;
-    int bid = blockIdx.x;
-    {
-        const int q = nblk / AVSI_NUM_XCD, r = nblk % AVSI_NUM_XCD;
-        const int xcd = bid % AVSI_NUM_XCD, idx = bid / AVSI_NUM_XCD;
-        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-    }
-    const int bm = bid / g.n_blocks, bn = bid - bm * g.n_blocks;
+    int bm, bn;
+    tile_of_block(g, blockIdx.x, bm, bn);
     const int m0 = bm * BM, n0 = bn * BN;
     const int kbeg = blockIdx.z * g.k_split_len;
     const int kend = min(g.K, kbeg + g.k_split_len);
@@ -584,6 +593,15 @@ int avsi_gemm_launch(int transA, int transB, int M, int N, int K, float alpha, c
     g.n_blocks = (int)avsi_ceil_div(N, BN);
     g.k_split_len = (int)avsi_round_up(avsi_ceil_div(K, splits), 32);
     g.c_split_stride = splits > 1 ? c_split_stride : 0;
+    {   // column-group width: the group's slice of op(B), k_split_len x (n_group * 128) floats, should fill about half of
+        // one XCD's 4 MiB L2
+        const char* env_ng = getenv("AVSI_GEMM_NGROUP");
+        const int64_t slice_bytes_per_block = (int64_t)g.k_split_len * BN * 4;
+        int ng = (int)((2 << 20) / (slice_bytes_per_block > 0 ? slice_bytes_per_block : 1));
+        if (ng < 4) ng = 4;      // narrower groups re-read A more often than they save on B
+        if (env_ng) ng = atoi(env_ng);
+        g.n_group = ng < 1 ? 1 : (ng > g.n_blocks ? g.n_blocks : ng);
+    }
     if ((int64_t)g.m_blocks * g.n_blocks > INT32_MAX) return AVSI_ERR_UNSUPPORTED;
     // "col" tiles read 4 consecutive x per lane and guard on the first: the ld padding up to a
     // multiple of 4 (checked above) keeps the tail addressable; such lanes feed unstored outputs.

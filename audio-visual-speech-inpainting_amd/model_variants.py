@@ -31,7 +31,7 @@ import torch
 
 from . import _lib, ops
 from . import audio_processing as ap
-from .blstm_layout import ParamLayout, round_up
+from .blstm_layout import ParamLayout, input_pitch
 from .models import BLSTMVariables, StackedBLSTMModel, _as_device
 
 
@@ -178,7 +178,7 @@ class StackedBLSTMSSNNModel(StackedBLSTMModel):
         in_dim = {'a': F, 'v': config.get('video_feat_dim', 136), 'av': F + config.get('video_feat_dim', 136)}[input]
         # the MLP reads the audio features where the network input holds them (pitch = input pitch);
         # the video-only model keeps them in a buffer of their own
-        pitch = round_up(F, 8) if input == 'v' else round_up(in_dim, 8)
+        pitch = input_pitch(F if input == 'v' else in_dim)
         if variables is None:
             layout = ParamLayout(in_dim, config['net_dim'], F, side=(self.int_layer, self.EMB), mlp=self.EMB,
                                  mlp_in_pitch=pitch)

@@ -10,7 +10,7 @@ replaces them for the next batch, and reading an attribute runs the gfx950 kerne
 it (results are cached until the next ``feed()``).
 
 Device data layout: activations are TIME-MAJOR ``[T][Bp][C]`` with the batch
-padded to a multiple of 32 (whole MFMA row tiles) and channels padded (257 -> 264 inputs,
+padded to a multiple of 32 (whole MFMA row tiles) and channels padded (257 -> 272 inputs,
 250 -> 256 hidden units per direction); padded hidden units are exactly zero by construction.
 """
 import math

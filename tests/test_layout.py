@@ -15,8 +15,8 @@ def _packed(layout, params):
 def test_sizes_match_reference_param_counts():
     assert ParamLayout(257).ref_size == 4148757
     assert ParamLayout(393).ref_size == 4420757
-    assert ParamLayout(257).kp == [264, 512, 512]
-    assert ParamLayout(136).kp == [136, 512, 512]
+    assert ParamLayout(257).kp == [272, 512, 512]
+    assert ParamLayout(136).kp == [144, 512, 512]
 
 
 def test_roundtrip_flat_oracle_params():

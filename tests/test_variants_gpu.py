@@ -149,13 +149,13 @@ def test_two_steps_model():
 def test_ssnn_model_forward_backward(int_layer, input_type):
     import avsi_amd  # noqa: F401
     from avsi_amd import models
-    from avsi_amd.blstm_layout import ParamLayout, round_up
+    from avsi_amd.blstm_layout import ParamLayout, input_pitch
     from avsi_amd.model_variants import StackedBLSTMSSNNModel
     B, N, E = 3, 2880, 200
     wav, masks, mean, std, video, seq, T = _inputs(B, N, 30 + int_layer, ragged=True)
     D = {'a': 257, 'av': 393, 'v': 136}[input_type]
     params = OV.init_variant_params(4, D, int_layer, E, mlp=True)
-    pitch = round_up(257 if input_type == 'v' else D, 8)
+    pitch = input_pitch(257 if input_type == 'v' else D)
     layout = ParamLayout(D, (250, 250, 250), 257, side=(int_layer, E), mlp=E, mlp_in_pitch=pitch)
     variables = models.BLSTMVariables(layout)
     variables.load_flat(layout.flatten_oracle_params(params))
