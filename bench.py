@@ -113,9 +113,26 @@ def cpu_baseline(torch, model, wav, masks, mean, std, sample, cpu_batch):
         cores = len(os.sched_getaffinity(0))
     except AttributeError:
         cores = os.cpu_count()
+    # best-case CPU line: the same network shape through torch's fused CPU LSTM (oneDNN),
+    # random weights, network only (no front end) -- an upper bound for what a CPU port could reach
+    fused = None
+    try:
+        with torch.no_grad():
+            F = model.audio_feat_dim
+            net = torch.nn.LSTM(F, 250, num_layers=3, bidirectional=True, batch_first=True)
+            proj = torch.nn.Linear(500, F)
+            x = torch.randn(sample, T_FRAMES, F)
+            proj(net(x[:cpu_batch])[0])
+            t1 = time.perf_counter()
+            for i in range(0, sample, cpu_batch):
+                proj(net(x[i:i + cpu_batch])[0])
+            fused = {"value": sample / (time.perf_counter() - t1), "unit": "utterances/s",
+                     "threads": torch.get_num_threads(), "what": "torch.nn.LSTM + Linear forward, float32, batches of %d" % cpu_batch}
+    except Exception as e:   # a reported extra, never a reason to lose the bench line
+        fused = {"error": str(e)[:200]}
     return {"value": sample / dt, "unit": "utterances/s", "cores": cores, "kind": "port",
             "sample": "%d utterances in batches of %d, float32 numpy oracle (per-step loop), %.1f s"
-                      % (sample, cpu_batch, dt)}, rms
+                      % (sample, cpu_batch, dt), "best_case_fused_cpu": fused}, rms
 
 
 def profiled_traffic(kernel_key, batch):
@@ -259,7 +276,7 @@ def main():
                                 "ms_per_step": t_fe / args.steps},
         }
         cpu, rms = (None, None)
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:     # the CPU leg is reported at N = 1 only
             cpu, rms = cpu_baseline(torch, model, wav, masks, mean, std, min(args.cpu_sample, B), 32)
         line = {
             "metric": "masked utterances/sec (inference: front end + 3xBLSTM-250 forward + projection + L1 loss)",
