@@ -1,0 +1,232 @@
+// Small-batch form of the recurrent half of one bidirectional LSTM layer (same maths, layouts and
+// packed operands as blstm_fwd.hip; reference models.py:95-115).
+//
+// blstm_fwd.hip is batch-stationary: one workgroup owns 32 / 64 utterances of a direction and
+// streams the 1 MiB recurrent kernel from L2 every step.  At the reference's own batch sizes
+// (8 for training, 32 for inference: blstm.config:8, inference.sh:7) that is two workgroups on a
+// 256-CU chip and 37 us per time step, all of it latency: 512 dependent-free MFMAs per wave plus a
+// 128 KiB fragment stream per wave and step.  Here a (32-utterance tile, direction) pair is spread
+// over S = 4 or 8 workgroups ("weight-stationary"):
+//   - workgroup m of the group owns 8 / S of the eight 32-unit slices of the hidden state (all four
+//     gates of those units); inside it the reduction over h_{t-1} is split over S waves per slice.
+//     Every wave keeps ITS piece of Wh (32 / S k-groups x 4 gates = 64 or 128 VGPRs) in registers
+//     for all T steps: after the first step no weight is ever loaded again;
+//   - per step a wave issues 64 (S = 8) or 128 (S = 4) MFMAs on h_{t-1} fragments read straight
+//     from global memory (the previous step's hout rows, L2-resident), parks its partial
+//     32 x 128 tile in LDS, and after one workgroup barrier the 512 lanes finish 2 (4) cells each:
+//     sum of the S partials + hoisted input projection, LSTM cell, c_t in registers;
+//   - the S workgroups exchange h_t through hout itself: device-coherent (sc1) stores, one atomic
+//     increment of the group's step counter once they have completed, and the consumers spin on
+//     that counter before they read hout[t] with device-coherent loads.  Members of a group are
+//     placed S blocks of 8 apart so that they share an XCD.  The spin is bounded: a group that does not see its peers within ~2^22 polls marks
+//     the status word, stops waiting and runs to the end, so the grid always drains.
+// The launch needs all S members of a group resident together; groups are contiguous windows of
+// 8 S block ids and the kernel uses one workgroup per CU, so in-order dispatch guarantees that for
+// any grid (and the host only selects this kernel when the whole grid fits the chip anyway).
+#include "avsi_common.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int HP = 256, GP = 4 * HP;
+constexpr int PSTRIDE = 36;                          // LDS pitch of one unit's 32 rows (+4: conflict-free b128)
+constexpr int PART_FLOATS = 8 * 4 * 32 * PSTRIDE;    // [wave][gate][unit][row]
+constexpr unsigned SPIN_LIMIT = 1u << 22;
+
+struct CoopArgs {
+    const float* xproj;
+    const float* whp;
+    float* hout;
+    float* resv;
+    unsigned* sync;    // [0] status, [1 + group] step counters
+    int T, Bp, ngroups;
+};
+
+__device__ __forceinline__ float sigmoidf_fast(float x) { return __builtin_amdgcn_rcpf(1.f + __expf(-x)); }
+__device__ __forceinline__ float tanhf_fast(float x) { return 2.f * __builtin_amdgcn_rcpf(1.f + __expf(-2.f * x)) - 1.f; }
+
+// 16-byte load that is coherent at device scope (four relaxed agent-scope atomic loads: the
+// compiler emits them with the sc1 bit and, being atomics, never merges them with cached ones)
+__device__ __forceinline__ float4 coherent_load4(const float* p) {
+    float4 v;
+    v.x = __hip_atomic_load(p + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    v.y = __hip_atomic_load(p + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    v.z = __hip_atomic_load(p + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    v.w = __hip_atomic_load(p + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return v;
+}
+
+template <int S, bool SAVE>
+__global__ __launch_bounds__(512, 2) void blstm_rec_fwd_coop_kernel(const CoopArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* part = reinterpret_cast<float*>(smem);
+    __shared__ int dead;                              // this workgroup gave up waiting (status word set)
+
+    constexpr int UG = 8 / S;                         // 32-unit slices per workgroup
+    constexpr int QPW = 32 / S;                       // 8-wide k groups per wave
+    constexpr int CPL = 2 * UG;                       // (row, unit) cells finished per lane
+
+    // block -> (group, member): members of a group are 8 block ids apart (same XCD)
+    const int xcd = blockIdx.x % AVSI_NUM_XCD, kk = blockIdx.x / AVSI_NUM_XCD;
+    const int member = kk % S;
+    const int group = (kk / S) * AVSI_NUM_XCD + xcd;
+    if (group >= a.ngroups) return;
+    const int dir = group & 1;
+    const int b0 = (group >> 1) * 32;
+    const int T = a.T, Bp = a.Bp;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int v = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 31, hi = lane >> 5;
+    const int ugl = v / S, ks = v % S;                // slice of this wave, its part of the reduction
+    const int wq = member * UG + ugl;                 // slice index 0..7 in the packed layouts
+    if (tid == 0) dead = 0;
+
+    // ---- this wave's piece of Wh, once: whp [2][8 w][32 q][4 g][64 lane][4 s]
+    float4 wreg[QPW][4];
+    {
+        const float4* wp = reinterpret_cast<const float4*>(a.whp) + (size_t)(dir * 8 + wq) * (32 * 4 * 64) + lane;
+#pragma unroll
+        for (int q = 0; q < QPW; ++q)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) wreg[q][g] = wp[((ks * QPW + q) * 4 + g) * 64];
+    }
+
+    // ---- finishing role of this lane: unit fu of slice (member * UG + c / 2), rows frow, frow + 1
+    const int fu = tid & 31, frow = (tid >> 5) * 2;
+    float cstate[CPL];
+#pragma unroll
+    for (int c = 0; c < CPL; ++c) cstate[c] = 0.f;
+
+    unsigned* ctr = a.sync + 1 + group;
+    __syncthreads();
+
+    for (int step = 0; step < T; ++step) {
+        const int t = dir ? (T - 1 - step) : step;
+        const int tprev = dir ? t + 1 : t - 1;
+        const size_t row0 = (size_t)t * Bp + b0;
+
+        // hoisted input projection of this lane's cells (in flight during the wait and the MFMAs)
+        float xz[CPL][4];
+#pragma unroll
+        for (int c = 0; c < CPL; ++c)
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+                xz[c][g] = a.xproj[(row0 + frow + (c & 1)) * (2 * GP) + dir * GP + (member * UG + (c >> 1)) * 128 + g * 32 + fu];
+
+        f32x16 acc[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[g][r] = 0.f;
+
+        if (step > 0) {
+            // ---- wait until all S members have published h of the previous step
+            if (tid == 0 && !dead) {
+                const unsigned want = (unsigned)S * (unsigned)step;
+                unsigned polls = 0;
+                while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
+                    __builtin_amdgcn_s_sleep(2);
+                    if (++polls > SPIN_LIMIT) {
+                        dead = 1;
+                        atomicExch(a.sync, 1u);
+                        break;
+                    }
+                }
+            }
+            __syncthreads();
+
+            // ---- partial z = h_{t-1}[:, k range of this wave] . Wh piece.  The h exchange uses
+            //      device-coherent accesses (sc1: served at the memory side, not from a possibly stale
+            //      L1 / other XCD's L2) instead of cache-wide acquire / release fences, whose cost
+            //      (L2 write-back + invalidate per workgroup and step) grew with the number of groups.
+            const float* hp = a.hout + ((size_t)tprev * Bp + b0 + li) * (2 * HP) + dir * HP + 4 * hi;
+            float4 af[QPW];
+#pragma unroll
+            for (int q = 0; q < QPW; ++q) af[q] = coherent_load4(hp + 8 * (ks * QPW + q));
+#pragma unroll
+            for (int q = 0; q < QPW; ++q)
+#pragma unroll
+                for (int s = 0; s < 4; ++s)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const float av = s == 0 ? af[q].x : s == 1 ? af[q].y : s == 2 ? af[q].z : af[q].w;
+                        const float bv = s == 0 ? wreg[q][g].x : s == 1 ? wreg[q][g].y : s == 2 ? wreg[q][g].z : wreg[q][g].w;
+                        acc[g] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[g], 0, 0, 0);
+                    }
+        }
+
+        // ---- park the partial tile: part[v][g][unit li][row], rows (r&3) + 8 (r>>2) + 4 hi
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                *reinterpret_cast<float4*>(part + ((v * 4 + g) * 32 + li) * PSTRIDE + 8 * j + 4 * hi) =
+                    make_float4(acc[g][4 * j], acc[g][4 * j + 1], acc[g][4 * j + 2], acc[g][4 * j + 3]);
+        __syncthreads();
+
+        // ---- finish this lane's cells
+#pragma unroll
+        for (int c = 0; c < CPL; ++c) {
+            const int slice = c >> 1, r = frow + (c & 1);
+            float z[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                float s = xz[c][g];
+#pragma unroll
+                for (int k = 0; k < S; ++k) s += part[(((slice * S + k) * 4 + g) * 32 + fu) * PSTRIDE + r];
+                z[g] = s;
+            }
+            const float ig = sigmoidf_fast(z[0]), jg = tanhf_fast(z[1]), fg = sigmoidf_fast(z[2]), og = sigmoidf_fast(z[3]);
+            const float cn = fg * cstate[c] + ig * jg;
+            cstate[c] = cn;
+            const float hn = og * tanhf_fast(cn);
+            const int unit = (member * UG + slice) * 32 + fu;
+            __hip_atomic_store(a.hout + (row0 + r) * (2 * HP) + dir * HP + unit, hn, __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
+            if (SAVE) {
+                float* rv = a.resv + (row0 + r) * (2 * 5 * HP) + dir * 5 * HP + unit;
+                rv[0 * HP] = ig, rv[1 * HP] = jg, rv[2 * HP] = fg, rv[3 * HP] = og, rv[4 * HP] = cn;
+            }
+        }
+
+        // ---- publish: every wave waits for its own (write-through) stores, then one increment per workgroup
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();      // also: nobody overwrites `part` before all cells of this step are read
+        if (tid == 0) __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
+template <int S, bool SAVE>
+int launch_coop(const CoopArgs& a, hipStream_t st) {
+    const size_t lds = (size_t)PART_FLOATS * sizeof(float);
+    (void)hipFuncSetAttribute((const void*)blstm_rec_fwd_coop_kernel<S, SAVE>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)lds);
+    const int blocks = (int)avsi_ceil_div(a.ngroups, AVSI_NUM_XCD) * AVSI_NUM_XCD * S;
+    hipLaunchKernelGGL((blstm_rec_fwd_coop_kernel<S, SAVE>), dim3(blocks), dim3(512), lds, st, a);
+    return avsi_launch_status();
+}
+
+}  // namespace
+
+extern "C" size_t avsi_blstm_rec_fwd_coop_workspace_bytes(int Bp) {
+    return (size_t)(1 + 2 * (Bp > 0 ? Bp / 32 : 0)) * sizeof(unsigned);
+}
+
+extern "C" int avsi_blstm_rec_fwd_coop_f32(const float* xproj, const float* whp, float* hout, float* reserve, int T, int Bp,
+                                           int split, void* workspace, size_t workspace_bytes, void* stream) {
+    if (!xproj || !whp || !hout || T <= 0 || Bp <= 0 || (Bp & 31)) return AVSI_ERR_INVALID_ARG;
+    if (split != 4 && split != 8) return AVSI_ERR_INVALID_ARG;
+    if (!workspace || workspace_bytes < avsi_blstm_rec_fwd_coop_workspace_bytes(Bp)) return AVSI_ERR_WORKSPACE;
+    const int ngroups = 2 * (Bp / 32);
+    // every member of a group must be resident while its peers wait for it: one workgroup per CU
+    if ((int64_t)avsi_ceil_div(ngroups, AVSI_NUM_XCD) * AVSI_NUM_XCD * split > AVSI_NUM_CU) return AVSI_ERR_UNSUPPORTED;
+    const hipStream_t st = (hipStream_t)stream;
+    avsi_clear_error();
+    if (hipMemsetAsync(workspace, 0, avsi_blstm_rec_fwd_coop_workspace_bytes(Bp), st) != hipSuccess) return AVSI_ERR_LAUNCH;
+    CoopArgs a{xproj, whp, hout, reserve, (unsigned*)workspace, T, Bp, ngroups};
+    if (split == 8) return reserve ? launch_coop<8, true>(a, st) : launch_coop<8, false>(a, st);
+    return reserve ? launch_coop<4, true>(a, st) : launch_coop<4, false>(a, st);
+}

@@ -342,9 +342,10 @@ typedef __attribute__((address_space(3))) void* lvoid_t;
 // rather than __builtin_amdgcn_global_load_lds on purpose: for the builtin the compiler cannot
 // prove that later ds_reads do not alias the DMA's destination and puts s_waitcnt vmcnt(0) in
 // front of them, which serialises every tile on the DMA just issued.  The kernel counts vmcnt
-// itself (the DMAs are the only vector-memory operations in its main loop).
+// itself (the DMAs are the only vector-memory operations in its main loop).  M0 is a reserved
+// register the compiler does not allocate; nothing else in this kernel uses it.
 __device__ __forceinline__ void dma16(const float* src, uint32_t lds_byte_addr) {
-    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(src), "s"(lds_byte_addr) : "memory", "m0");
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(src), "s"(lds_byte_addr) : "memory");
 }
 
 template <bool TA, bool TB, int BK, int NST>

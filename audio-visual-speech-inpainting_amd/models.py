@@ -319,6 +319,8 @@ class StackedBLSTMModel(object):
             c['reserve'].append(resv)
             x = hout
         c['rnn_out'] = x
+        if not self.rows_per_wg and ops.coop_split(Bp):
+            ops.coop_check(self.device)      # small batches: the cooperative kernel's bounded waits held
         # prediction = sequence_mask * (rnn_out . W + b), stored batch-major [B, T, F]
         seq = torch.as_tensor(self.sequence_lengths, device=self.device)
         row_scale = self._buf('row_scale', (T, Bp), zero=True)

@@ -3,6 +3,7 @@
 No arithmetic happens here: each wrapper validates layout, passes raw device pointers and the
 current stream to libavsi_hip.so, and returns the output tensor."""
 import ctypes
+import os
 
 import torch
 
@@ -38,8 +39,9 @@ def gemm(a, b, out=None, trans_a=False, trans_b=False, m=None, n=None, k=None, a
     return out
 
 
-def blstm_rec_fwd(xproj, whp, hout, reserve=None, rows_per_wg=0):
-    """All T steps of both directions of one layer (avsi_blstm_rec_fwd_f32).
+def blstm_rec_fwd(xproj, whp, hout, reserve=None, rows_per_wg=0, split=None):
+    """All T steps of both directions of one layer (avsi_blstm_rec_fwd_f32, or its small-batch
+    cooperative form avsi_blstm_rec_fwd_coop_f32: `split` 4 / 8 forces it, 0 forbids it, None = by Bp).
     xproj [T, Bp, 2048], whp [2 * 262144], hout [T, Bp, 512], reserve [T, Bp, 2, 5, 256] or None."""
     _lib.require_cuda(xproj, whp, hout, reserve)
     T, Bp = xproj.shape[0], xproj.shape[1]
@@ -49,10 +51,44 @@ def blstm_rec_fwd(xproj, whp, hout, reserve=None, rows_per_wg=0):
         raise _lib.AvsiError("blstm_rec_fwd: bad operand shapes")
     if reserve is not None and (tuple(reserve.shape) != (T, Bp, 2, 5, 256) or not reserve.is_contiguous()):
         raise _lib.AvsiError("blstm_rec_fwd: bad reserve shape")
+    split = coop_split(Bp) if (rows_per_wg == 0 and split is None) else int(split or 0)
+    if split:
+        L = _lib.lib()
+        need = L.avsi_blstm_rec_fwd_coop_workspace_bytes(Bp)
+        ws = _COOP_WS.get(xproj.device.index)
+        if ws is None or ws.numel() * 4 < need:
+            ws = torch.zeros((need + 3) // 4, dtype=torch.int32, device=xproj.device)
+            _COOP_WS[xproj.device.index] = ws
+            _COOP_STICKY.setdefault(xproj.device.index, torch.zeros(1, dtype=torch.int32, device=xproj.device))
+        _lib.check(L.avsi_blstm_rec_fwd_coop_f32(_lib.ptr(xproj), _lib.ptr(whp), _lib.ptr(hout), _lib.ptr(reserve), T, Bp,
+                                                 split, _lib.ptr(ws), ws.numel() * 4, _lib.stream_ptr()),
+                   "avsi_blstm_rec_fwd_coop_f32")
+        _COOP_STICKY[xproj.device.index].bitwise_or_(ws[:1])     # keeps a failure visible across later launches
+        return hout
     _lib.check(_lib.lib().avsi_blstm_rec_fwd_f32(_lib.ptr(xproj), _lib.ptr(whp), _lib.ptr(hout), _lib.ptr(reserve),
                                                  T, Bp, int(rows_per_wg), _lib.stream_ptr()),
                "avsi_blstm_rec_fwd_f32")
     return hout
+
+
+_COOP_WS, _COOP_STICKY = {}, {}
+
+
+def coop_split(Bp):
+    """Workgroups per (32-utterance tile, direction) of the small-batch recurrent kernel, 0 = use the
+    batch-stationary kernels.  The cooperative grid must be resident on the 256 CUs at once."""
+    if os.environ.get('AVSI_REC_COOP', '1') == '0':
+        return 0
+    return 8 if Bp <= 512 else (4 if Bp <= 1024 else 0)
+
+
+def coop_check(device=None):
+    """Raise if a cooperative recurrent launch on `device` ever gave up waiting for its peer
+    workgroups (its outputs are then invalid).  Synchronises with the device."""
+    idx = torch.cuda.current_device() if device is None else torch.device(device).index
+    st = _COOP_STICKY.get(idx)
+    if st is not None and int(st.item()) != 0:
+        raise _lib.AvsiError("cooperative recurrent kernel timed out waiting for a peer workgroup; results are invalid")
 
 
 _LOSS_WS = {}

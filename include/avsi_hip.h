@@ -141,6 +141,19 @@ int avsi_l1_loss_f32(const float* target, const float* pred, const float* mask, 
                      float* out3, float* dpred, float grad_scale, void* workspace,
                      size_t workspace_bytes, void* stream);
 
+/* Small-batch form of avsi_blstm_rec_fwd_f32 (same operands and results): every (32-utterance
+ * tile, direction) pair is spread over `split` = 4 or 8 workgroups that keep their piece of the
+ * recurrent kernel in registers for all T steps and exchange h_t through hout with a per-step
+ * counter in `workspace` (avsi_blstm_rec_fwd_coop_workspace_bytes(Bp) bytes, zeroed by the call).
+ * The whole grid must be resident: AVSI_ERR_UNSUPPORTED unless ceil8(2 Bp / 32) * split <= 256
+ * (Bp <= 512 for split 8, <= 1024 for split 4).  After the stream has drained, word 0 of the
+ * workspace is 0; a non-zero value means a workgroup stopped waiting for its peers (bounded spin)
+ * and the outputs are invalid. */
+size_t avsi_blstm_rec_fwd_coop_workspace_bytes(int Bp);
+int avsi_blstm_rec_fwd_coop_f32(const float* xproj, const float* whp, float* hout, float* reserve,
+                                int T, int Bp, int split, void* workspace, size_t workspace_bytes,
+                                void* stream);
+
 /* Loss of the speaker-embedding model variants (reference models.py:1006-1029 StackedBLSTMSSNNModel,
  * :1367-1394 StackedBLSTMEmbeddingModel): the prediction keeps the known bins,
  *   prediction = seq_mask * (target * mask + logits * (1 - mask)),

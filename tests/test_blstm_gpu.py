@@ -149,3 +149,34 @@ def test_feed_reuses_model_and_variables(mods):
     assert not torch.allclose(p1, p2)
     m.feed(sequence_lengths=np.full(2, T), target_sources=wav, masks=masks)
     assert torch.equal(m.prediction, p1)                            # deterministic, bitwise
+
+
+@pytest.mark.parametrize("Bp,split,save", [(32, 8, False), (64, 8, True), (512, 8, False), (1024, 4, True), (96, 4, False)])
+def test_cooperative_small_batch_kernel_matches_batch_stationary(Bp, split, save):
+    """avsi_blstm_rec_fwd_coop_f32 (weights resident in registers, h exchanged through hout with a
+    per-step counter) against avsi_blstm_rec_fwd_f32 on the same operands: same maths, different
+    summation order of the 256-long reduction."""
+    import torch
+    import avsi_amd  # noqa: F401
+    from avsi_amd import ops
+    T = 37
+    g = torch.Generator(device='cuda')
+    g.manual_seed(Bp + split)
+    xproj = torch.randn(T, Bp, 2048, generator=g, device='cuda')
+    whp = torch.randn(2 * 262144, generator=g, device='cuda') * 0.05
+    outs = []
+    for sp in (0, split):
+        hout = torch.full((T, Bp, 512), 7.0, device='cuda')
+        resv = torch.full((T, Bp, 2, 5, 256), 7.0, device='cuda') if save else None
+        ops.blstm_rec_fwd(xproj, whp, hout, resv, split=sp)
+        outs.append((hout, resv))
+    ops.coop_check()
+    np.testing.assert_allclose(outs[1][0].cpu().numpy(), outs[0][0].cpu().numpy(), rtol=0, atol=2e-5)
+    if save:
+        np.testing.assert_allclose(outs[1][1].cpu().numpy(), outs[0][1].cpu().numpy(), rtol=0, atol=5e-5)
+    assert ops.coop_split(32) == 8 and ops.coop_split(1024) == 4 and ops.coop_split(2048) == 0
+    # the launch refuses grids that could not be co-resident
+    from avsi_amd import _lib
+    with pytest.raises(_lib.AvsiError):
+        big = torch.zeros(2, 2048, 2048, device='cuda')
+        ops.blstm_rec_fwd(big, whp, torch.zeros(2, 2048, 512, device='cuda'), None, split=8)
