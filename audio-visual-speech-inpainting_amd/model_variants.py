@@ -266,7 +266,7 @@ class StackedBLSTMSSNNModel(StackedBLSTMModel):
         # d a2[t][b][:] = w[t][b] dS[b][:]  (broadcast over time: source time stride 0)
         da2 = self._buf('ssnn_da2', (T, Bp, W))
         ops.relayout_rows(dS, da2, Bp, T, W, W, (W, 0), (W, Bp * W), row_scale=w, scale_strides=(1, Bp))
-        splits = max(1, min(64, M // 4096))
+        splits = ops.splitk_for(M)
         dl2 = ops.bn_act_bwd(l2, da2.view(M, W), W, self._buf('ssnn_dl2', (M, W)), act=3)
         ops.gemm_splitk(a1, dl2, g('dmw2'), trans_a=True, m=W, n=W, k=M, splits=splits)
         ops.colsum(dl2, g('dmb2'), m=M, n=W)

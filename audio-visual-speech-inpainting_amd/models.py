@@ -459,7 +459,7 @@ class StackedBLSTMModel(object):
                           row_scale=c['row_scale'], scale_strides=(1, Bp))
         dlog2 = dlog.view(M, ldp)
         h_top = c['rnn_out'].view(M, 2 * HP)
-        splits = max(1, min(64, M // 4096))
+        splits = ops.splitk_for(M)
         ops.gemm_splitk(h_top, dlog2, lay.gpacked_view(gp, 'dpw'), trans_a=True, m=2 * HP, n=ldp, k=M, splits=splits)
         ops.colsum(dlog2, lay.gpacked_view(gp, 'dpb'), m=M, n=ldp)
         dh = self._buf('dh', (T, Bp, 2 * HP))

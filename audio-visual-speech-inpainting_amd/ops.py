@@ -159,6 +159,13 @@ def _workspace(dev, nbytes):
     return ws
 
 
+def splitk_for(rows):
+    """Reduction slabs for a weight-gradient GEMM over `rows` = T * Bp rows: long reductions get 64
+    slabs of >= 4096 rows; short ones (small batches) are still cut into ~1024-row slabs so that the
+    few output tiles (4 x 16 for a 512 x 2048 gradient) spread over the chip."""
+    return max(1, min(64, rows // 4096)) if rows >= 65536 else max(1, min(16, rows // 1024))
+
+
 def gemm_splitk(a, b, out, trans_a=False, trans_b=False, m=None, n=None, k=None, alpha=1.0, splits=16):
     """out[M, N] (contiguous) = alpha * op(A) . op(B), reduction split into `splits` slabs
     (avsi_gemm_splitk_f32).  For weight gradients: K = all T * Bp rows."""
