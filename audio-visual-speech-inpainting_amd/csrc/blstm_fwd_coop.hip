@@ -46,15 +46,22 @@ struct CoopArgs {
 __device__ __forceinline__ float sigmoidf_fast(float x) { return __builtin_amdgcn_rcpf(1.f + __expf(-x)); }
 __device__ __forceinline__ float tanhf_fast(float x) { return 2.f * __builtin_amdgcn_rcpf(1.f + __expf(-2.f * x)) - 1.f; }
 
-// 16-byte load that is coherent at device scope (four relaxed agent-scope atomic loads: the
-// compiler emits them with the sc1 bit and, being atomics, never merges them with cached ones)
-__device__ __forceinline__ float4 coherent_load4(const float* p) {
-    float4 v;
-    v.x = __hip_atomic_load(p + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    v.y = __hip_atomic_load(p + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    v.z = __hip_atomic_load(p + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    v.w = __hip_atomic_load(p + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    return v;
+// 16-byte loads that are coherent at device scope (sc0 sc1: served at the memory side, never from
+// this CU's L1 or a stale line of the XCD's L2).  Inline asm because the only portable spelling --
+// relaxed agent-scope atomic loads -- exists per dword (4 x the instructions and 4 x the address
+// VALU work; the BPTT kernel reads 16 fragments per lane and step).  The compiler does not know
+// these loads are in flight, so a batch is closed by coherent_wait(): one s_waitcnt, after which
+// every loaded value is passed through an empty asm so that no consumer can be scheduled before it.
+typedef float v4f __attribute__((ext_vector_type(4)));
+// byte_off: a constant after unrolling -- one address register pair serves a whole batch
+__device__ __forceinline__ void coherent_load4_issue(v4f& dst, const float* p, int byte_off) {
+    asm volatile("global_load_dwordx4 %0, %1, off offset:%2 sc0 sc1" : "=v"(dst) : "v"(p), "i"(byte_off) : "memory");
+}
+template <int N>
+__device__ __forceinline__ void coherent_wait(v4f (&v)[N]) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int i = 0; i < N; ++i) asm volatile("" : "+v"(v[i]));
 }
 
 template <int S, bool SAVE>
@@ -108,13 +115,17 @@ __global__ __launch_bounds__(512, 2) void blstm_rec_fwd_coop_kernel(const CoopAr
         const int tprev = dir ? t + 1 : t - 1;
         const size_t row0 = (size_t)t * Bp + b0;
 
-        // hoisted input projection of this lane's cells (in flight during the wait and the MFMAs)
+        // hoisted input projection of this lane's cells: in flight during the wait and the MFMAs
+        // (S = 8), or fetched while the partial tiles are parked (S = 4, whose weights leave no room)
         float xz[CPL][4];
+        auto load_xz = [&]() {
 #pragma unroll
-        for (int c = 0; c < CPL; ++c)
+            for (int c = 0; c < CPL; ++c)
 #pragma unroll
-            for (int g = 0; g < 4; ++g)
-                xz[c][g] = a.xproj[(row0 + frow + (c & 1)) * (2 * GP) + dir * GP + (member * UG + (c >> 1)) * 128 + g * 32 + fu];
+                for (int g = 0; g < 4; ++g)
+                    xz[c][g] = a.xproj[(row0 + frow + (c & 1)) * (2 * GP) + dir * GP + (member * UG + (c >> 1)) * 128 + g * 32 + fu];
+        };
+        if (S == 8) load_xz();
 
         f32x16 acc[4];
 #pragma unroll
@@ -143,19 +154,25 @@ __global__ __launch_bounds__(512, 2) void blstm_rec_fwd_coop_kernel(const CoopAr
             //      L1 / other XCD's L2) instead of cache-wide acquire / release fences, whose cost
             //      (L2 write-back + invalidate per workgroup and step) grew with the number of groups.
             const float* hp = a.hout + ((size_t)tprev * Bp + b0 + li) * (2 * HP) + dir * HP + 4 * hi;
-            float4 af[QPW];
+            // fragments in batches of 4 (the weights already hold 64 / 128 registers)
 #pragma unroll
-            for (int q = 0; q < QPW; ++q) af[q] = coherent_load4(hp + 8 * (ks * QPW + q));
+            for (int c0 = 0; c0 < QPW; c0 += 4) {
+                v4f af[4];
 #pragma unroll
-            for (int q = 0; q < QPW; ++q)
+                for (int q = 0; q < 4; ++q) coherent_load4_issue(af[q], hp + 8 * ks * QPW, 32 * (c0 + q));
+                coherent_wait(af);
 #pragma unroll
-                for (int s = 0; s < 4; ++s)
+                for (int q = 0; q < 4; ++q)
 #pragma unroll
-                    for (int g = 0; g < 4; ++g) {
-                        const float av = s == 0 ? af[q].x : s == 1 ? af[q].y : s == 2 ? af[q].z : af[q].w;
-                        const float bv = s == 0 ? wreg[q][g].x : s == 1 ? wreg[q][g].y : s == 2 ? wreg[q][g].z : wreg[q][g].w;
-                        acc[g] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[g], 0, 0, 0);
-                    }
+                    for (int s = 0; s < 4; ++s)
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) {
+                            const float4 b = wreg[c0 + q][g];
+                            const float av = s == 0 ? af[q].x : s == 1 ? af[q].y : s == 2 ? af[q].z : af[q].w;
+                            const float bv = s == 0 ? b.x : s == 1 ? b.y : s == 2 ? b.z : b.w;
+                            acc[g] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[g], 0, 0, 0);
+                        }
+            }
         }
 
         // ---- park the partial tile: part[v][g][unit li][row], rows (r&3) + 8 (r>>2) + 4 hi
@@ -165,6 +182,7 @@ __global__ __launch_bounds__(512, 2) void blstm_rec_fwd_coop_kernel(const CoopAr
             for (int j = 0; j < 4; ++j)
                 *reinterpret_cast<float4*>(part + ((v * 4 + g) * 32 + li) * PSTRIDE + 8 * j + 4 * hi) =
                     make_float4(acc[g][4 * j], acc[g][4 * j + 1], acc[g][4 * j + 2], acc[g][4 * j + 3]);
+        if (S != 8) load_xz();
         __syncthreads();
 
         // ---- finish this lane's cells
@@ -229,4 +247,169 @@ extern "C" int avsi_blstm_rec_fwd_coop_f32(const float* xproj, const float* whp,
     CoopArgs a{xproj, whp, hout, reserve, (unsigned*)workspace, T, Bp, ngroups};
     if (split == 8) return reserve ? launch_coop<8, true>(a, st) : launch_coop<8, false>(a, st);
     return reserve ? launch_coop<4, true>(a, st) : launch_coop<4, false>(a, st);
+}
+
+// ==========================================================================================
+// Cooperative BPTT (small batches): the gradient of the kernel above, same decomposition.
+//   dh = dH_out[t] + dz_next . Wh^T   reduces over the 1024 packed gate columns of the step
+// processed just before.  Workgroup m of a group owns 8 / S of the 32-unit slices of dh; inside
+// it the 1024-long reduction is split over S waves per slice (128 / S k-groups of 8 each), whose
+// piece of Wh^T (whbT fragment order of blstm_bwd.hip) stays in registers for all T steps.  The
+// group exchanges dz through the dz output buffer itself (device-coherent stores / loads + the
+// same per-step counter protocol); every lane then finishes two (four) cells: sum of the S
+// partials, gate gradients from the forward reserve, dc_next in registers.
+// ==========================================================================================
+namespace {
+
+struct CoopBwdArgs {
+    const float* dhout;
+    const float* resv;
+    const float* whbT;
+    float* dz;
+    unsigned* sync;
+    int T, Bp, ngroups;
+};
+
+constexpr int BPART_FLOATS = 8 * 32 * PSTRIDE;      // [wave][unit][row]
+
+template <int S>
+__global__ __launch_bounds__(512, 2) void blstm_rec_bwd_coop_kernel(const CoopBwdArgs a) {
+    __shared__ __attribute__((aligned(16))) float part[BPART_FLOATS];
+    __shared__ int dead;
+    constexpr int UG = 8 / S;
+    constexpr int QPW = 128 / S;                       // k groups of 8 (packed gate columns) per wave
+    constexpr int CPL = 2 * UG;
+
+    const int xcd = blockIdx.x % AVSI_NUM_XCD, kk = blockIdx.x / AVSI_NUM_XCD;
+    const int member = kk % S;
+    const int group = (kk / S) * AVSI_NUM_XCD + xcd;
+    if (group >= a.ngroups) return;
+    const int dir = group & 1;
+    const int b0 = (group >> 1) * 32;
+    const int T = a.T, Bp = a.Bp;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int v = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 31, hi = lane >> 5;
+    const int ugl = v / S, ks = v % S;
+    const int wq = member * UG + ugl;
+    if (tid == 0) dead = 0;
+
+    // this wave's piece of Wh^T: whbT [2][8 w][128 q][64 lane][4 s]
+    float4 wreg[QPW];
+    {
+        const float4* wb = reinterpret_cast<const float4*>(a.whbT) + (size_t)(dir * 8 + wq) * (128 * 64) + lane;
+#pragma unroll
+        for (int q = 0; q < QPW; ++q) wreg[q] = wb[(ks * QPW + q) * 64];
+    }
+
+    const int fu = tid & 31, frow = (tid >> 5) * 2;
+    float dcn[CPL];
+#pragma unroll
+    for (int c = 0; c < CPL; ++c) dcn[c] = 0.f;
+    unsigned* ctr = a.sync + 1 + group;
+    __syncthreads();
+
+    for (int s = 0; s < T; ++s) {
+        const int t = dir ? s : (T - 1 - s);             // fw walks T-1 .. 0, bw walks 0 .. T-1
+        const int tnext = dir ? t - 1 : t + 1;           // the step processed just before this one
+        const int tp = dir ? t + 1 : t - 1;              // forward-previous step (owner of c_prev)
+        const bool has_prev = dir ? (t + 1 < T) : (t > 0);
+        const size_t row0 = (size_t)t * Bp + b0;
+
+        // inputs of this lane's cells (in flight during the wait and the MFMAs)
+        float dh[CPL], gi[CPL], gj[CPL], gf[CPL], go[CPL], cc[CPL], cp[CPL];
+#pragma unroll
+        for (int c = 0; c < CPL; ++c) {
+            const int unit = (member * UG + (c >> 1)) * 32 + fu;
+            const size_t row = row0 + frow + (c & 1);
+            const float* rv = a.resv + row * (2 * 5 * HP) + dir * 5 * HP + unit;
+            dh[c] = a.dhout[row * (2 * HP) + dir * HP + unit];
+            gi[c] = rv[0 * HP], gj[c] = rv[1 * HP], gf[c] = rv[2 * HP], go[c] = rv[3 * HP], cc[c] = rv[4 * HP];
+            cp[c] = has_prev ? a.resv[((size_t)tp * Bp + b0 + frow + (c & 1)) * (2 * 5 * HP) + dir * 5 * HP + 4 * HP + unit] : 0.f;
+        }
+
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        if (s > 0) {
+            if (tid == 0 && !dead) {
+                const unsigned want = (unsigned)S * (unsigned)s;
+                unsigned polls = 0;
+                while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
+                    __builtin_amdgcn_s_sleep(2);
+                    if (++polls > SPIN_LIMIT) {
+                        dead = 1;
+                        atomicExch(a.sync, 1u);
+                        break;
+                    }
+                }
+            }
+            __syncthreads();
+            const float* zp = a.dz + ((size_t)tnext * Bp + b0 + li) * (2 * GP) + dir * GP + 4 * hi;
+            // fragments in batches of 8 (the weights already hold 64 / 128 registers)
+#pragma unroll
+            for (int c0 = 0; c0 < QPW; c0 += 8) {
+                v4f af[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) coherent_load4_issue(af[q], zp + 8 * ks * QPW, 32 * (c0 + q));
+                coherent_wait(af);
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const float4 b = wreg[c0 + q];
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[q].x, b.x, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[q].y, b.y, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[q].z, b.z, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[q].w, b.w, acc, 0, 0, 0);
+                }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            *reinterpret_cast<float4*>(part + (v * 32 + li) * PSTRIDE + 8 * j + 4 * hi) =
+                make_float4(acc[4 * j], acc[4 * j + 1], acc[4 * j + 2], acc[4 * j + 3]);
+        __syncthreads();
+
+#pragma unroll
+        for (int c = 0; c < CPL; ++c) {
+            const int slice = c >> 1, r = frow + (c & 1);
+            float d = dh[c];
+#pragma unroll
+            for (int k = 0; k < S; ++k) d += part[((slice * S + k) * 32 + fu) * PSTRIDE + r];
+            const float ig = gi[c], jg = gj[c], fg = gf[c], og = go[c];
+            const float tc = 2.f * __builtin_amdgcn_rcpf(1.f + __expf(-2.f * cc[c])) - 1.f;
+            const float dc = d * og * (1.f - tc * tc) + dcn[c];
+            dcn[c] = dc * fg;
+            float* zo = a.dz + (row0 + r) * (2 * GP) + dir * GP + (member * UG + slice) * 128 + fu;
+            __hip_atomic_store(zo + 0, dc * jg * ig * (1.f - ig), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(zo + 32, dc * ig * (1.f - jg * jg), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(zo + 64, dc * cp[c] * fg * (1.f - fg), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(zo + 96, d * tc * og * (1.f - og), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
+}  // namespace
+
+extern "C" int avsi_blstm_rec_bwd_coop_f32(const float* dhout, const float* reserve, const float* whbT, float* dz, int T,
+                                           int Bp, int split, void* workspace, size_t workspace_bytes, void* stream) {
+    if (!dhout || !reserve || !whbT || !dz || T <= 0 || Bp <= 0 || (Bp & 31)) return AVSI_ERR_INVALID_ARG;
+    if (split != 4 && split != 8) return AVSI_ERR_INVALID_ARG;
+    if (!workspace || workspace_bytes < avsi_blstm_rec_fwd_coop_workspace_bytes(Bp)) return AVSI_ERR_WORKSPACE;
+    const int ngroups = 2 * (Bp / 32);
+    const int blocks = (int)avsi_ceil_div(ngroups, AVSI_NUM_XCD) * AVSI_NUM_XCD * split;
+    if (blocks > AVSI_NUM_CU) return AVSI_ERR_UNSUPPORTED;
+    const hipStream_t st = (hipStream_t)stream;
+    avsi_clear_error();
+    if (hipMemsetAsync(workspace, 0, avsi_blstm_rec_fwd_coop_workspace_bytes(Bp), st) != hipSuccess) return AVSI_ERR_LAUNCH;
+    CoopBwdArgs a{dhout, reserve, whbT, dz, (unsigned*)workspace, T, Bp, ngroups};
+    if (split == 8)
+        hipLaunchKernelGGL(blstm_rec_bwd_coop_kernel<8>, dim3(blocks), dim3(512), 0, st, a);
+    else
+        hipLaunchKernelGGL(blstm_rec_bwd_coop_kernel<4>, dim3(blocks), dim3(512), 0, st, a);
+    return avsi_launch_status();
 }

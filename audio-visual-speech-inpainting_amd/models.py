@@ -492,6 +492,8 @@ class StackedBLSTMModel(object):
                 dwh.zero_()
             if li > 0:
                 ops.gemm(dz2, v.p('wx%d' % li), out=dh.view(M, 2 * HP), trans_b=True, m=M, n=2 * HP, k=2 * GP)
+        if ops.coop_split(Bp):
+            ops.coop_check(self.device)
         grads = v.unpack_grads(gp, out=self._buf('grads', (lay.ref_size,)))
         c['grads'] = grads
         return grads

@@ -54,12 +54,7 @@ def blstm_rec_fwd(xproj, whp, hout, reserve=None, rows_per_wg=0, split=None):
     split = coop_split(Bp) if (rows_per_wg == 0 and split is None) else int(split or 0)
     if split:
         L = _lib.lib()
-        need = L.avsi_blstm_rec_fwd_coop_workspace_bytes(Bp)
-        ws = _COOP_WS.get(xproj.device.index)
-        if ws is None or ws.numel() * 4 < need:
-            ws = torch.zeros((need + 3) // 4, dtype=torch.int32, device=xproj.device)
-            _COOP_WS[xproj.device.index] = ws
-            _COOP_STICKY.setdefault(xproj.device.index, torch.zeros(1, dtype=torch.int32, device=xproj.device))
+        ws = _coop_ws(xproj.device, Bp)
         _lib.check(L.avsi_blstm_rec_fwd_coop_f32(_lib.ptr(xproj), _lib.ptr(whp), _lib.ptr(hout), _lib.ptr(reserve), T, Bp,
                                                  split, _lib.ptr(ws), ws.numel() * 4, _lib.stream_ptr()),
                    "avsi_blstm_rec_fwd_coop_f32")
@@ -72,6 +67,16 @@ def blstm_rec_fwd(xproj, whp, hout, reserve=None, rows_per_wg=0, split=None):
 
 
 _COOP_WS, _COOP_STICKY = {}, {}
+
+
+def _coop_ws(device, Bp):
+    need = _lib.lib().avsi_blstm_rec_fwd_coop_workspace_bytes(Bp)
+    ws = _COOP_WS.get(device.index)
+    if ws is None or ws.numel() * 4 < need:
+        ws = torch.zeros((need + 3) // 4, dtype=torch.int32, device=device)
+        _COOP_WS[device.index] = ws
+    _COOP_STICKY.setdefault(device.index, torch.zeros(1, dtype=torch.int32, device=device))
+    return ws
 
 
 def coop_split(Bp):
@@ -184,8 +189,9 @@ def gemm_splitk(a, b, out, trans_a=False, trans_b=False, m=None, n=None, k=None,
     return out
 
 
-def blstm_rec_bwd(dhout, reserve, whbt, dz):
-    """BPTT through the recurrence of one layer (avsi_blstm_rec_bwd_f32).
+def blstm_rec_bwd(dhout, reserve, whbt, dz, split=None):
+    """BPTT through the recurrence of one layer (avsi_blstm_rec_bwd_f32, or the small-batch cooperative
+    avsi_blstm_rec_bwd_coop_f32: `split` 4 / 8 forces it, 0 forbids it, None = by Bp).
     dhout [T, Bp, 512], reserve [T, Bp, 2, 5, 256], whbt [2 * 262144] -> dz [T, Bp, 2048]."""
     _lib.require_cuda(dhout, reserve, whbt, dz)
     T, Bp = dhout.shape[0], dhout.shape[1]
@@ -193,6 +199,14 @@ def blstm_rec_bwd(dhout, reserve, whbt, dz):
           and tuple(dz.shape) == (T, Bp, 2048) and whbt.numel() == 2 * 262144)
     if not ok or not (dhout.is_contiguous() and reserve.is_contiguous() and dz.is_contiguous() and whbt.is_contiguous()):
         raise _lib.AvsiError("blstm_rec_bwd: bad operand shapes / strides")
+    split = coop_split(Bp) if split is None else int(split)
+    if split:
+        ws = _coop_ws(dhout.device, Bp)
+        _lib.check(_lib.lib().avsi_blstm_rec_bwd_coop_f32(_lib.ptr(dhout), _lib.ptr(reserve), _lib.ptr(whbt), _lib.ptr(dz),
+                                                          T, Bp, split, _lib.ptr(ws), ws.numel() * 4, _lib.stream_ptr()),
+                   "avsi_blstm_rec_bwd_coop_f32")
+        _COOP_STICKY[dhout.device.index].bitwise_or_(ws[:1])
+        return dz
     _lib.check(_lib.lib().avsi_blstm_rec_bwd_f32(_lib.ptr(dhout), _lib.ptr(reserve), _lib.ptr(whbt), _lib.ptr(dz),
                                                  T, Bp, _lib.stream_ptr()), "avsi_blstm_rec_bwd_f32")
     return dz

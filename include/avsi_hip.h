@@ -154,6 +154,13 @@ int avsi_blstm_rec_fwd_coop_f32(const float* xproj, const float* whp, float* hou
                                 int T, int Bp, int split, void* workspace, size_t workspace_bytes,
                                 void* stream);
 
+/* Small-batch form of avsi_blstm_rec_bwd_f32 (same operands and results), the gradient of the
+ * cooperative forward above: same group / split / workspace / residency rules, dz doubles as the
+ * exchange buffer between the workgroups of a group. */
+int avsi_blstm_rec_bwd_coop_f32(const float* dhout, const float* reserve, const float* whbT, float* dz,
+                                int T, int Bp, int split, void* workspace, size_t workspace_bytes,
+                                void* stream);
+
 /* Loss of the speaker-embedding model variants (reference models.py:1006-1029 StackedBLSTMSSNNModel,
  * :1367-1394 StackedBLSTMEmbeddingModel): the prediction keeps the known bins,
  *   prediction = seq_mask * (target * mask + logits * (1 - mask)),

@@ -180,3 +180,26 @@ def test_cooperative_small_batch_kernel_matches_batch_stationary(Bp, split, save
     with pytest.raises(_lib.AvsiError):
         big = torch.zeros(2, 2048, 2048, device='cuda')
         ops.blstm_rec_fwd(big, whp, torch.zeros(2, 2048, 512, device='cuda'), None, split=8)
+
+
+@pytest.mark.parametrize("Bp,split", [(32, 8), (256, 8), (1024, 4), (64, 4)])
+def test_cooperative_bptt_matches_batch_stationary(Bp, split):
+    import torch
+    import avsi_amd  # noqa: F401
+    from avsi_amd import ops
+    T = 29
+    g = torch.Generator(device='cuda')
+    g.manual_seed(Bp * 3 + split)
+    dh = torch.randn(T, Bp, 512, generator=g, device='cuda')
+    resv = torch.rand(T, Bp, 2, 5, 256, generator=g, device='cuda') * 0.9 + 0.05      # activated gates in (0, 1)
+    resv[:, :, :, 1] = resv[:, :, :, 1] * 2 - 1                                        # j in (-1, 1)
+    resv[:, :, :, 4] = torch.randn(T, Bp, 2, 256, generator=g, device='cuda')          # c
+    whbt = torch.randn(2 * 262144, generator=g, device='cuda') * 0.05
+    outs = []
+    for sp in (0, split):
+        dz = torch.full((T, Bp, 2048), 7.0, device='cuda')
+        ops.blstm_rec_bwd(dh, resv, whbt, dz, split=sp)
+        outs.append(dz.cpu().numpy())
+    ops.coop_check()
+    scale = np.abs(outs[0]).max()
+    np.testing.assert_allclose(outs[1], outs[0], rtol=0, atol=2e-6 * scale)
