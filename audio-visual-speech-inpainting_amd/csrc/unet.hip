@@ -55,6 +55,33 @@ __global__ __launch_bounds__(TPB) void im2col_kernel(const float* __restrict__ s
     }
 }
 
+// 16-byte form for layers whose channel counts are multiples of 4 (every layer but the three with a
+// 1-channel operand): a group of 4 consecutive k never straddles a tap or the source boundary.
+__global__ __launch_bounds__(TPB) void im2col4_kernel(const float* __restrict__ s0, const float* __restrict__ s1,
+                                                      float* __restrict__ col, const ConvGeom g) {
+    const int Ct = g.C0 + g.C1, p = g.k / 2, H2 = g.H >> 1, W2 = g.W >> 1, K4 = g.Kc >> 2;
+    const int64_t n = (int64_t)g.B * g.H * g.W * K4;
+    for (int64_t e = (int64_t)blockIdx.x * TPB + threadIdx.x; e < n; e += (int64_t)gridDim.x * TPB) {
+        const int j = (int)(e % K4) * 4;
+        int64_t row = e / K4;
+        const int w = (int)(row % g.W);
+        row /= g.W;
+        const int h = (int)(row % g.H), b = (int)(row / g.H);
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (j < g.k * g.k * Ct) {
+            const int tap = j / Ct, c = j - tap * Ct;
+            const int hh = h + tap / g.k - p, ww = w + tap % g.k - p;
+            if (hh >= 0 && hh < g.H && ww >= 0 && ww < g.W) {
+                if (c < g.C0)
+                    v = *reinterpret_cast<const float4*>(s0 + (((int64_t)b * g.H + hh) * g.W + ww) * g.ld0 + c);
+                else
+                    v = *reinterpret_cast<const float4*>(s1 + (((int64_t)b * H2 + (hh >> 1)) * W2 + (ww >> 1)) * g.ld1 + (c - g.C0));
+            }
+        }
+        reinterpret_cast<float4*>(col)[e] = v;
+    }
+}
+
 // which = 0: gradient of the full-resolution source (channels [0, C0)); which = 1: of the up-sampled one
 __global__ __launch_bounds__(TPB) void col2im_kernel(const float* __restrict__ dcol, float* __restrict__ dst,
                                                      const ConvGeom g, const int which, const int accumulate) {
@@ -107,29 +134,56 @@ __device__ __forceinline__ float act_grad(float z, int act) {
     return 1.f;
 }
 
+// Rows are read whole with 16-byte loads: thread t owns the float4 column group t % (ld / 4) of rows
+// t / (ld / 4), + TPB / (ld / 4), ...; the row-threads of a column group are then summed through LDS.
 template <int MODE>
 __global__ __launch_bounds__(TPB) void colpair_partial_kernel(const BnArgs a, float* __restrict__ part) {
-    const int c = blockIdx.x * TPB + threadIdx.x;
+    __shared__ float red[2][TPB * 4];
+    const int q4 = a.ld >> 2;                              // float4 groups per row (<= 64: ld <= 256)
+    const int rp = TPB / q4;                               // rows per pass
+    const int cq = threadIdx.x % q4, rl = threadIdx.x / q4;
     const int64_t chunk = (a.R + gridDim.y - 1) / gridDim.y;
     const int64_t r0 = (int64_t)blockIdx.y * chunk, r1 = min(a.R, r0 + chunk);
-    if (c >= a.C) return;
-    float s1 = 0.f, s2 = 0.f;
-    float mu = 0.f, rs = 1.f, ga = 1.f, be = 0.f;
-    if (MODE == 1 && a.has_bn) mu = a.mean[c], rs = a.rstd[c], ga = a.gamma[c], be = a.beta[c];
-    for (int64_t r = r0; r < r1; ++r) {
-        const float xv = a.x[r * a.ld + c];
-        if (MODE == 0) {
-            s1 += xv;
-            s2 += xv * xv;
-        } else {
-            const float xh = (xv - mu) * rs;
-            const float g = a.dy[r * a.ld + c] * act_grad(a.has_bn ? ga * xh + be : xv, a.act);
-            s1 += g;
-            s2 += g * xh;
+    float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+    float mu[4] = {0.f, 0.f, 0.f, 0.f}, rs[4] = {1.f, 1.f, 1.f, 1.f}, ga[4] = {1.f, 1.f, 1.f, 1.f}, be[4] = {0.f, 0.f, 0.f, 0.f};
+    if (MODE == 1 && a.has_bn)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int c = 4 * cq + k;
+            if (c < a.C) mu[k] = a.mean[c], rs[k] = a.rstd[c], ga[k] = a.gamma[c], be[k] = a.beta[c];
         }
+    if (rl < rp)
+        for (int64_t r = r0 + rl; r < r1; r += rp) {
+            const float4 xv4 = *reinterpret_cast<const float4*>(a.x + r * a.ld + 4 * cq);
+            const float xv[4] = {xv4.x, xv4.y, xv4.z, xv4.w};
+            if (MODE == 0) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) s1[k] += xv[k], s2[k] += xv[k] * xv[k];
+            } else {
+                const float4 dy4 = *reinterpret_cast<const float4*>(a.dy + r * a.ld + 4 * cq);
+                const float dy[4] = {dy4.x, dy4.y, dy4.z, dy4.w};
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const float xh = (xv[k] - mu[k]) * rs[k];
+                    const float g = dy[k] * act_grad(a.has_bn ? ga[k] * xh + be[k] : xv[k], a.act);
+                    s1[k] += g, s2[k] += g * xh;
+                }
+            }
+        }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) red[0][threadIdx.x * 4 + k] = s1[k], red[1][threadIdx.x * 4 + k] = s2[k];
+    __syncthreads();
+    // thread c < C sums the rp row-threads of its channel (fixed order: deterministic)
+    const int c = threadIdx.x;
+    if (c < a.C) {
+        float t1 = 0.f, t2 = 0.f;
+        for (int j = 0; j < rp; ++j) {
+            const int src = (j * q4 + (c >> 2)) * 4 + (c & 3);
+            t1 += red[0][src], t2 += red[1][src];
+        }
+        part[((int64_t)blockIdx.y * 2 + 0) * a.C + c] = t1;
+        part[((int64_t)blockIdx.y * 2 + 1) * a.C + c] = t2;
     }
-    part[((int64_t)blockIdx.y * 2 + 0) * a.C + c] = s1;
-    part[((int64_t)blockIdx.y * 2 + 1) * a.C + c] = s2;
 }
 
 // MODE 0: out0 = mean, out1 = rstd.  MODE 1: out0 = sum g (d beta), out1 = sum g xhat (d gamma)
@@ -261,8 +315,15 @@ extern "C" int avsi_im2col_f32(const float* src0, int C0, int ld0, const float* 
     if (rc != AVSI_OK || !col || (C0 && !src0) || (C1 && !src1_coarse)) return rc != AVSI_OK ? rc : AVSI_ERR_INVALID_ARG;
     const ConvGeom g{B, H, W, C0, ld0, C1, ld1, k, Kc};
     avsi_clear_error();
-    hipLaunchKernelGGL(im2col_kernel, dim3(grid_for((int64_t)B * H * W * Kc)), dim3(TPB), 0, (hipStream_t)stream, src0,
-                       src1_coarse, col, g);
+    const bool vec4 = !(C0 & 3) && !(C1 & 3) && !(ld0 & 3) && !(ld1 & 3) && !(Kc & 3) &&
+                      !((reinterpret_cast<uintptr_t>(src0) | reinterpret_cast<uintptr_t>(src1_coarse) |
+                         reinterpret_cast<uintptr_t>(col)) & 15);
+    if (vec4)
+        hipLaunchKernelGGL(im2col4_kernel, dim3(grid_for((int64_t)B * H * W * (Kc / 4))), dim3(TPB), 0, (hipStream_t)stream,
+                           src0, src1_coarse, col, g);
+    else
+        hipLaunchKernelGGL(im2col_kernel, dim3(grid_for((int64_t)B * H * W * Kc)), dim3(TPB), 0, (hipStream_t)stream, src0,
+                           src1_coarse, col, g);
     return avsi_launch_status();
 }
 
@@ -287,12 +348,13 @@ extern "C" size_t avsi_unet_workspace_bytes(int C) { return (size_t)MAXPARTS * 2
 extern "C" int avsi_colstats_f32(const float* x, int64_t R, int C, int ld, float eps, float* mean, float* rstd,
                                  void* workspace, size_t workspace_bytes, void* stream) {
     if (!x || !mean || !rstd || R <= 0 || C <= 0 || ld < C) return AVSI_ERR_INVALID_ARG;
+    if ((ld & 3) || ld > 256 || (reinterpret_cast<uintptr_t>(x) & 15)) return AVSI_ERR_UNSUPPORTED;
     if (!workspace || workspace_bytes < avsi_unet_workspace_bytes(C)) return AVSI_ERR_WORKSPACE;
     BnArgs a{x, nullptr, nullptr, nullptr, nullptr, nullptr, R, C, ld, 0, 0};
     const int parts = parts_for(R);
     const hipStream_t st = (hipStream_t)stream;
     avsi_clear_error();
-    hipLaunchKernelGGL(colpair_partial_kernel<0>, dim3((int)avsi_ceil_div(C, TPB), parts), dim3(TPB), 0, st, a,
+    hipLaunchKernelGGL(colpair_partial_kernel<0>, dim3(1, parts), dim3(TPB), 0, st, a,
                        (float*)workspace);
     hipLaunchKernelGGL(colpair_final_kernel<0>, dim3((int)avsi_ceil_div(C, TPB)), dim3(TPB), 0, st,
                        (const float*)workspace, parts, C, R, eps, mean, rstd);
@@ -317,12 +379,14 @@ extern "C" int avsi_bn_act_bwd_f32(const float* x, const float* dy, int64_t R, i
     const int has_bn = mean != nullptr;
     if (has_bn && (!rstd || !gamma || !beta || !dgamma || !dbeta)) return AVSI_ERR_INVALID_ARG;
     if (has_bn && (!workspace || workspace_bytes < avsi_unet_workspace_bytes(C))) return AVSI_ERR_WORKSPACE;
+    if (has_bn && ((ld & 3) || ld > 256 || ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(dy)) & 15)))
+        return AVSI_ERR_UNSUPPORTED;
     BnArgs a{x, dy, mean, rstd, gamma, beta, R, C, ld, act, has_bn};
     const hipStream_t st = (hipStream_t)stream;
     avsi_clear_error();
     if (has_bn) {
         const int parts = parts_for(R);
-        hipLaunchKernelGGL(colpair_partial_kernel<1>, dim3((int)avsi_ceil_div(C, TPB), parts), dim3(TPB), 0, st, a,
+        hipLaunchKernelGGL(colpair_partial_kernel<1>, dim3(1, parts), dim3(TPB), 0, st, a,
                            (float*)workspace);
         hipLaunchKernelGGL(colpair_final_kernel<1>, dim3((int)avsi_ceil_div(C, TPB)), dim3(TPB), 0, st,
                            (const float*)workspace, parts, C, R, 0.f, dbeta, dgamma);
