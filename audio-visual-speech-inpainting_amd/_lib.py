@@ -107,6 +107,10 @@ PROTOTYPES = {
                                             c_void_p]),
     "avsi_blstm_rec_bwd_coop_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_size_t,
                                             c_void_p]),
+    "avsi_conv2d_f32": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_int,
+                                c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p]),
+    "avsi_conv2d_thin_f32": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_int,
+                                     c_void_p, c_int, c_void_p, c_int, c_void_p]),
     "avsi_l1_loss_blend_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int64, c_void_p, c_void_p,
                                        c_void_p, c_size_t, c_void_p]),
 }

@@ -55,6 +55,12 @@ struct GemmArgs {
     int k_split_len;       // reduction length handled per blockIdx.z (multiple of BK)
     int64_t c_split_stride;  // elements between per-split partial outputs (0 = no split)
     int n_group;           // N-blocks per column group of the block -> tile order (see tile_of_block)
+    // implicit-GEMM convolution (gemm_dma_kernel<.., CONV = true>): A is never materialised, its rows are
+    // gathered from one or two NHWC activations (tf.nn.conv2d SAME / stride 1 over concat(src0, up2x(src1)))
+    const float* conv_s0;
+    const float* conv_s1;
+    const float* conv_zeros;   // >= 64 bytes of zeros: the source of out-of-image taps
+    int cH, cW, cC0, cld0, cC1, cld1, ck;
 };
 
 // Block -> tile map.  Two things are arranged here:
@@ -348,10 +354,11 @@ __device__ __forceinline__ void dma16(const float* src, uint32_t lds_byte_addr) 
     asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(src), "s"(lds_byte_addr) : "memory");
 }
 
-template <bool TA, bool TB, int BK, int NST>
+template <bool TA, bool TB, int BK, int NST, bool CONV = false>
 __global__ __launch_bounds__(256, BK == 16 ? (NST == 3 ? 3 : 4) : 2) void gemm_dma_kernel(const GemmArgs g) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     static_assert((BK == 16 && (NST == 3 || NST == 2)) || (BK == 32 && NST == 2), "tile shapes this kernel was tuned for");
+    static_assert(!CONV || (!TA && !TB && BK == 16), "the implicit-GEMM gather is written for A . B with 16-deep tiles");
     constexpr int BM = 128, TILE = 128 * BK;
     constexpr int PPW = BK / 8;         // 1-KiB DMA pieces per wave and operand tile
     constexpr int CPR = BK / 4;         // 16-byte chunks per row of a "row" tile
@@ -396,6 +403,22 @@ __global__ __launch_bounds__(256, BK == 16 ? (NST == 3 ? 3 : 4) : 2) void gemm_d
             offb[j] = (int64_t)(2 * p + (lane >> 5)) * g.ldb + x;
         }
     }
+    // implicit GEMM: output pixel (b, h, w) of this lane's rows, and its 16-byte chunk inside a 16-deep k tile
+    int cvh[PPW], cvw[PPW], cvb[PPW], cvcl[PPW];
+    bool cvok[PPW];
+    if (CONV) {
+#pragma unroll
+        for (int j = 0; j < PPW; ++j) {
+            const int row = (wave * PPW + j) * RPP + lane / CPR;
+            const int m = m0 + row;
+            cvok[j] = m < g.M;
+            const int mm = cvok[j] ? m : 0;
+            cvw[j] = mm % g.cW;
+            cvh[j] = (mm / g.cW) % g.cH;
+            cvb[j] = mm / (g.cW * g.cH);
+            cvcl[j] = ((lane % CPR) ^ swz(row)) * 4;
+        }
+    }
     const float* a_org = TA ? g.A + (int64_t)kbeg * g.lda + m0 : g.A + (int64_t)m0 * g.lda + kbeg;
     const float* b_org = TB ? g.B + (int64_t)n0 * g.ldb + kbeg : g.B + (int64_t)kbeg * g.ldb + n0;
     const int64_t a_step = TA ? (int64_t)BK * g.lda : BK, b_step = TB ? BK : (int64_t)BK * g.ldb;
@@ -404,9 +427,31 @@ __global__ __launch_bounds__(256, BK == 16 ? (NST == 3 ? 3 : 4) : 2) void gemm_d
         const int st = kt % NST;
         const float* ao = a_org + kt * a_step;
         const float* bo = b_org + kt * b_step;
+        // implicit GEMM: the whole k tile lies in one filter tap and one source (channel counts % 16 == 0)
+        int cdh = 0, cdw = 0, cc = 0;
+        bool from0 = true;
+        if (CONV) {
+            const int Ct = g.cC0 + g.cC1, k0 = kbeg + kt * BK;
+            const int tap = k0 / Ct;
+            cc = k0 - tap * Ct;
+            cdh = tap / g.ck - g.ck / 2, cdw = tap % g.ck - g.ck / 2;
+            from0 = cc < g.cC0;
+        }
 #pragma unroll
         for (int j = 0; j < PPW; ++j) {
-            dma16(ao + offa[j], lds_a + (uint32_t)(st * TILE + (wave * PPW + j) * 256) * 4u);
+            const float* asrc = ao + offa[j];
+            if (CONV) {
+                const int hh = cvh[j] + cdh, ww = cvw[j] + cdw;
+                const bool ok = cvok[j] && hh >= 0 && hh < g.cH && ww >= 0 && ww < g.cW;
+                if (!ok)
+                    asrc = g.conv_zeros + cvcl[j];
+                else if (from0)
+                    asrc = g.conv_s0 + (((int64_t)cvb[j] * g.cH + hh) * g.cW + ww) * g.cld0 + cc + cvcl[j];
+                else
+                    asrc = g.conv_s1 + (((int64_t)cvb[j] * (g.cH >> 1) + (hh >> 1)) * (g.cW >> 1) + (ww >> 1)) * g.cld1 +
+                           (cc - g.cC0) + cvcl[j];
+            }
+            dma16(asrc, lds_a + (uint32_t)(st * TILE + (wave * PPW + j) * 256) * 4u);
             dma16(bo + offb[j], lds_b + (uint32_t)(st * TILE + (wave * PPW + j) * 256) * 4u);
         }
     };
@@ -572,7 +617,7 @@ int avsi_gemm_launch(int transA, int transB, int M, int N, int K, float alpha, c
     if (transA ? (lda < avsi_round_up(M, 4)) : (lda < K)) return AVSI_ERR_INVALID_ARG;
     if (transB ? (ldb < K) : (ldb < avsi_round_up(N, 4))) return AVSI_ERR_INVALID_ARG;
     if (ldc < N || splits < 1) return AVSI_ERR_INVALID_ARG;
-    GemmArgs g;
+    GemmArgs g{};
     g.A = A, g.B = B, g.C = C;
     g.bias = ep ? ep->bias : nullptr;
     g.row_scale = ep ? ep->row_scale : nullptr;
@@ -617,6 +662,38 @@ int avsi_gemm_launch(int transA, int transB, int M, int N, int K, float alpha, c
     }
     if (mi == 4) return dispatch<16, 4>(g, transA, transB, splits, st);   // 256 x 128 tiles exist with BK = 16 only (LDS)
     return bk == 16 ? dispatch<16, 2>(g, transA, transB, splits, st) : dispatch<32, 2>(g, transA, transB, splits, st);
+}
+
+// Convolution as an implicit GEMM: out[(b,h,w)][n] = bias[n] + sum_{tap,c} in(b, h+dh, w+dw, c) filter[(tap, c)][n].
+extern "C" int avsi_conv2d_f32(const float* src0, int C0, int ld0, const float* src1_coarse, int C1, int ld1, int B, int H,
+                               int W, int k, const float* filter, int ldf, const float* bias, int Cout, float* out,
+                               int ldo, const float* zeros64, void* stream) {
+    if (!filter || !out || !zeros64 || B <= 0 || H <= 0 || W <= 0 || k < 1 || !(k & 1) || Cout <= 0 || C0 < 0 || C1 < 0)
+        return AVSI_ERR_INVALID_ARG;
+    if ((C0 && !src0) || (C1 && !src1_coarse) || ldf < Cout || ldo < Cout || (C0 && ld0 < C0) || (C1 && ld1 < C1))
+        return AVSI_ERR_INVALID_ARG;
+    // a 16-deep k tile must sit inside one tap of one source; 16-byte gathers
+    if ((C0 & 15) || (C1 & 15) || C0 + C1 < 16 || (ld0 & 3) || (ld1 & 3) || (ldf & 3) || (C1 && ((H | W) & 1)))
+        return AVSI_ERR_UNSUPPORTED;
+    if ((reinterpret_cast<uintptr_t>(src0) | reinterpret_cast<uintptr_t>(src1_coarse) | reinterpret_cast<uintptr_t>(filter) |
+         reinterpret_cast<uintptr_t>(zeros64)) & 15)
+        return AVSI_ERR_UNSUPPORTED;
+    const int64_t M64 = (int64_t)B * H * W;
+    if (M64 > INT32_MAX) return AVSI_ERR_UNSUPPORTED;
+    GemmArgs g{};
+    g.A = zeros64, g.B = filter, g.C = out, g.bias = bias, g.row_scale = nullptr;
+    g.M = (int)M64, g.N = Cout, g.K = k * k * (C0 + C1);
+    g.lda = 0, g.ldb = ldf, g.ldc = ldo;
+    g.alpha = 1.f, g.beta = 0.f;
+    g.m_blocks = (int)avsi_ceil_div(g.M, 128), g.n_blocks = (int)avsi_ceil_div(Cout, BN);
+    g.k_split_len = g.K, g.c_split_stride = 0, g.n_group = g.n_blocks;
+    g.conv_s0 = src0, g.conv_s1 = src1_coarse, g.conv_zeros = zeros64;
+    g.cH = H, g.cW = W, g.cC0 = C0, g.cld0 = ld0, g.cC1 = C1, g.cld1 = ld1, g.ck = k;
+    if ((int64_t)g.m_blocks * g.n_blocks > INT32_MAX) return AVSI_ERR_UNSUPPORTED;
+    avsi_clear_error();
+    hipLaunchKernelGGL((gemm_dma_kernel<false, false, 16, 3, true>), dim3(g.m_blocks * g.n_blocks), dim3(256),
+                       (size_t)2 * 3 * 128 * 16 * 4, (hipStream_t)stream, g);
+    return avsi_launch_status();
 }
 
 extern "C" int avsi_gemm_f32(int transA, int transB, int M, int N, int K, float alpha, const float* A, int64_t lda,

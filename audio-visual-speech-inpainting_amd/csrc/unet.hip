@@ -82,6 +82,70 @@ __global__ __launch_bounds__(TPB) void im2col4_kernel(const float* __restrict__ 
     }
 }
 
+// Direct convolution for the three thin full-resolution layers of the U-Net (1 -> 16 channels 7x7,
+// 1 + 16 -> 1 channels 3x3 over [skip, up2x(coarse)], 1 -> 1 channel 1x1): no MFMA shape fits a
+// reduction of 49 / 153 / 1, and as im2col + GEMM they were 60 % of an inference step (the im2col
+// matrix of the 17-channel layer alone is 5 GB at batch 512).  One thread per output pixel, lanes
+// along W; the loops are fully unrolled, so the filter taps are wave-uniform scalar loads and every
+// multiply-add has an SGPR operand.
+template <int K, int C0, int C1, int COUT>
+__global__ __launch_bounds__(TPB) void direct_conv_kernel(const float* __restrict__ s0, int ld0, const float* __restrict__ s1,
+                                                          int ld1, const float* __restrict__ filt, int ldf,
+                                                          const float* __restrict__ bias, float* __restrict__ out, int ldo,
+                                                          int B, int H, int W) {
+    constexpr int P = K / 2, CT = C0 + C1;
+    const int H2 = H >> 1, W2 = W >> 1;
+    const int64_t n = (int64_t)B * H * W;
+    for (int64_t e = (int64_t)blockIdx.x * TPB + threadIdx.x; e < n; e += (int64_t)gridDim.x * TPB) {
+        const int w = (int)(e % W);
+        const int64_t bh = e / W;
+        const int h = (int)(bh % H), b = (int)(bh / H);
+        float acc[COUT];
+#pragma unroll
+        for (int o = 0; o < COUT; ++o) acc[o] = bias ? bias[o] : 0.f;
+#pragma unroll
+        for (int dh = 0; dh < K; ++dh) {
+            const int hh = h + dh - P;
+#pragma unroll
+            for (int dw = 0; dw < K; ++dw) {
+                const int ww = w + dw - P;
+                const bool ok = hh >= 0 && hh < H && ww >= 0 && ww < W;
+                const float* wt = filt + (int64_t)((dh * K + dw) * CT) * ldf;
+                if (C0 > 0) {
+                    const float* px = s0 + (((int64_t)b * H + hh) * W + ww) * ld0;
+#pragma unroll
+                    for (int c = 0; c < C0; ++c) {
+                        const float xv = ok ? px[c] : 0.f;
+#pragma unroll
+                        for (int o = 0; o < COUT; ++o) acc[o] += xv * wt[c * ldf + o];
+                    }
+                }
+                if (C1 > 0) {
+                    const float* px = s1 + (((int64_t)b * H2 + (hh >> 1)) * W2 + (ww >> 1)) * ld1;
+#pragma unroll
+                    for (int c4 = 0; c4 < C1; c4 += 4) {
+                        float4 xv = make_float4(0.f, 0.f, 0.f, 0.f);
+                        if (ok) xv = *reinterpret_cast<const float4*>(px + c4);
+                        const float xs[4] = {xv.x, xv.y, xv.z, xv.w};
+#pragma unroll
+                        for (int q = 0; q < 4; ++q)
+#pragma unroll
+                            for (int o = 0; o < COUT; ++o) acc[o] += xs[q] * wt[(C0 + c4 + q) * ldf + o];
+                    }
+                }
+            }
+        }
+        float* op = out + e * ldo;
+        if (COUT % 4 == 0) {
+#pragma unroll
+            for (int o = 0; o < COUT; o += 4) *reinterpret_cast<float4*>(op + o) = make_float4(acc[o], acc[o + 1], acc[o + 2], acc[o + 3]);
+        } else {
+#pragma unroll
+            for (int o = 0; o < COUT; ++o) op[o] = acc[o];
+        }
+    }
+}
+
 // which = 0: gradient of the full-resolution source (channels [0, C0)); which = 1: of the up-sampled one
 __global__ __launch_bounds__(TPB) void col2im_kernel(const float* __restrict__ dcol, float* __restrict__ dst,
                                                      const ConvGeom g, const int which, const int accumulate) {
@@ -324,6 +388,32 @@ extern "C" int avsi_im2col_f32(const float* src0, int C0, int ld0, const float* 
     else
         hipLaunchKernelGGL(im2col_kernel, dim3(grid_for((int64_t)B * H * W * Kc)), dim3(TPB), 0, (hipStream_t)stream, src0,
                            src1_coarse, col, g);
+    return avsi_launch_status();
+}
+
+extern "C" int avsi_conv2d_thin_f32(const float* src0, int C0, int ld0, const float* src1_coarse, int C1, int ld1, int B, int H,
+                                    int W, int k, const float* filter, int ldf, const float* bias, int Cout, float* out,
+                                    int ldo, void* stream) {
+    if (!filter || !out || B <= 0 || H <= 0 || W <= 0 || (C0 && !src0) || (C1 && !src1_coarse) || ldf < Cout || ldo < Cout ||
+        (C0 && ld0 < C0) || (C1 && ld1 < C1))
+        return AVSI_ERR_INVALID_ARG;
+    if ((C1 && (((H | W) & 1) || (ld1 & 3) || (reinterpret_cast<uintptr_t>(src1_coarse) & 15))) ||
+        ((Cout & 3) == 0 && ((ldo & 3) || (reinterpret_cast<uintptr_t>(out) & 15))))
+        return AVSI_ERR_UNSUPPORTED;
+    const dim3 grid(grid_for((int64_t)B * H * W)), block(TPB);
+    const hipStream_t st = (hipStream_t)stream;
+    avsi_clear_error();
+    if (k == 7 && C0 == 1 && C1 == 0 && Cout == 16)
+        hipLaunchKernelGGL((direct_conv_kernel<7, 1, 0, 16>), grid, block, 0, st, src0, ld0, src1_coarse, ld1, filter, ldf, bias,
+                           out, ldo, B, H, W);
+    else if (k == 3 && C0 == 1 && C1 == 16 && Cout == 1)
+        hipLaunchKernelGGL((direct_conv_kernel<3, 1, 16, 1>), grid, block, 0, st, src0, ld0, src1_coarse, ld1, filter, ldf, bias,
+                           out, ldo, B, H, W);
+    else if (k == 1 && C0 == 1 && C1 == 0 && Cout == 1)
+        hipLaunchKernelGGL((direct_conv_kernel<1, 1, 0, 1>), grid, block, 0, st, src0, ld0, src1_coarse, ld1, filter, ldf, bias,
+                           out, ldo, B, H, W);
+    else
+        return AVSI_ERR_UNSUPPORTED;
     return avsi_launch_status();
 }
 

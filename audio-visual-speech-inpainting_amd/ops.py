@@ -245,6 +245,44 @@ def adam_tf(param, grad, m, v, step, lr, beta1=0.9, beta2=0.999, eps=1e-8, grad_
 
 
 # ---------------------------------------------------------------------------- U-Net building blocks
+_ZEROS = {}
+
+
+def conv2d_supported(c0, c1):
+    """Layers the implicit-GEMM convolution takes (avsi_conv2d_f32): channel counts multiples of 16."""
+    return c0 % 16 == 0 and c1 % 16 == 0 and c0 + c1 >= 16
+
+
+def conv2d(src0, c0, src1, c1, B, H, W, k, filt, bias, out, cout):
+    """out [B*H*W, ld] = conv2d(concat(src0, up2x(src1)), filt [k*k*(c0+c1), ldf]) + bias, no im2col matrix."""
+    _lib.require_cuda(src0, src1, filt, out)
+    z = _ZEROS.get(out.device.index)
+    if z is None:
+        z = _ZEROS[out.device.index] = torch.zeros(64, dtype=torch.float32, device=out.device)
+    _lib.check(_lib.lib().avsi_conv2d_f32(_lib.ptr(src0), c0, src0.stride(0) if src0 is not None else 0, _lib.ptr(src1), c1,
+                                          src1.stride(0) if src1 is not None else 0, B, H, W, k, _lib.ptr(filt),
+                                          filt.stride(0), _lib.ptr(bias), cout, _lib.ptr(out), out.stride(0), _lib.ptr(z),
+                                          _lib.stream_ptr()), "avsi_conv2d_f32")
+    return out
+
+
+_THIN = {(7, 1, 0, 16), (3, 1, 16, 1), (1, 1, 0, 1)}
+
+
+def conv2d_thin_supported(k, c0, c1, cout):
+    return (k, c0, c1, cout) in _THIN
+
+
+def conv2d_thin(src0, c0, src1, c1, B, H, W, k, filt, bias, out, cout):
+    """Direct convolution of the thin full-resolution U-Net layers (avsi_conv2d_thin_f32)."""
+    _lib.require_cuda(src0, src1, filt, out)
+    _lib.check(_lib.lib().avsi_conv2d_thin_f32(_lib.ptr(src0), c0, src0.stride(0) if src0 is not None else 0, _lib.ptr(src1),
+                                               c1, src1.stride(0) if src1 is not None else 0, B, H, W, k, _lib.ptr(filt),
+                                               filt.stride(0), _lib.ptr(bias), cout, _lib.ptr(out), out.stride(0),
+                                               _lib.stream_ptr()), "avsi_conv2d_thin_f32")
+    return out
+
+
 def im2col(src0, c0, src1, c1, B, H, W, k, col, kc):
     """col[B*H*W, kc] <- patches of src0 [B*H*W, ld0] ++ 2x-up-sampled src1 [B*H/2*W/2, ld1] (avsi_im2col_f32)."""
     _lib.require_cuda(src0, src1, col)

@@ -212,10 +212,16 @@ class UNetFConvModel(object):
     def _conv_fwd(self, name, k, cout, bn, act, src0, c0, src1, c1, B, H, W):
         v = self.variables
         R, kc, ld = B * H * W, round_up(k * k * (c0 + c1), 4), round_up(cout, 4)
-        col = self._buf('col', (self._col_floats,))[: R * kc].view(R, kc)
-        ops.im2col(src0, c0, src1, c1, B, H, W, k, col, kc)
         conv = self._buf(name + '/conv', (R, ld))
-        ops.gemm(col, v.p(name + '/w'), out=conv, n=cout, bias=v.p(name + '/b'))
+        if ops.conv2d_supported(c0, c1):
+            # implicit GEMM: the operand rows are gathered from the activations by the GEMM's DMA loads
+            ops.conv2d(src0, c0, src1, c1, B, H, W, k, v.p(name + '/w'), v.p(name + '/b'), conv, cout)
+        elif ops.conv2d_thin_supported(k, c0, c1, cout):
+            ops.conv2d_thin(src0, c0, src1, c1, B, H, W, k, v.p(name + '/w'), v.p(name + '/b'), conv, cout)
+        else:
+            col = self._buf('col', (self._col_floats,))[: R * kc].view(R, kc)
+            ops.im2col(src0, c0, src1, c1, B, H, W, k, col, kc)
+            ops.gemm(col, v.p(name + '/w'), out=conv, n=cout, bias=v.p(name + '/b'))
         st = None
         if bn:
             st = (self._buf(name + '/mean', (ld,)), self._buf(name + '/rstd', (ld,)))

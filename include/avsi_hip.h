@@ -264,6 +264,21 @@ int avsi_istft_f32(const avsi_istft_args* args, void* stream);
  * models.py:822-824).  Pass mean = null for layers without batch norm.
  * workspace for the reductions: avsi_unet_workspace_bytes(C).
  * ------------------------------------------------------------------------------------ */
+/* Convolution as an implicit GEMM (no im2col matrix): out [B*H*W][ldo] = conv2d(concat(src0,
+ * up2x(src1_coarse)), filter [k*k*(C0+C1)][ldf]) + bias, SAME padding, stride 1.  The operand rows
+ * are gathered by the GEMM kernel's LDS-DMA loads straight from the NHWC activations; taps outside
+ * the image read `zeros64` (>= 64 bytes of zeros, 16-byte aligned, caller-owned).  Needs C0 and C1
+ * to be multiples of 16 (every 16-deep reduction tile then lies in one tap of one source) --
+ * AVSI_ERR_UNSUPPORTED otherwise: use avsi_im2col_f32 + avsi_gemm_f32 for those layers. */
+int avsi_conv2d_f32(const float* src0, int C0, int ld0, const float* src1_coarse, int C1, int ld1,
+                    int B, int H, int W, int k, const float* filter, int ldf, const float* bias,
+                    int Cout, float* out, int ldo, const float* zeros64, void* stream);
+/* Direct form for the thin full-resolution layers no MFMA shape fits: (k, C0, C1, Cout) in
+ * {(7, 1, 0, 16), (3, 1, 16, 1), (1, 1, 0, 1)} (unet_layers.py / models.py:592,605,607);
+ * AVSI_ERR_UNSUPPORTED for anything else. */
+int avsi_conv2d_thin_f32(const float* src0, int C0, int ld0, const float* src1_coarse, int C1, int ld1,
+                         int B, int H, int W, int k, const float* filter, int ldf, const float* bias,
+                         int Cout, float* out, int ldo, void* stream);
 int avsi_im2col_f32(const float* src0, int C0, int ld0, const float* src1_coarse, int C1, int ld1,
                     int B, int H, int W, int k, float* col, int Kc, void* stream);
 int avsi_col2im_f32(const float* dcol, int Kc, float* dsrc0, int C0, int ld0, float* dsrc1_coarse, int C1, int ld1,

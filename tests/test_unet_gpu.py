@@ -158,3 +158,56 @@ def test_unet_forward_backward_matches_oracle(mods):
     assert losses[2] < losses[0]
     wavs = m.enhanced_sources_oracle_phase
     assert wavs.shape == (B, N) and torch.isfinite(wavs).all()
+
+
+@pytest.mark.parametrize("c0,c1,k,cout,B,H,W", [(16, 0, 5, 32, 2, 12, 10), (32, 64, 3, 32, 3, 8, 16), (128, 128, 3, 128, 1, 4, 6),
+                                                (16, 32, 3, 16, 2, 128, 8)])
+def test_implicit_gemm_conv_matches_im2col_gemm(c0, c1, k, cout, B, H, W):
+    """avsi_conv2d_f32 (operand rows gathered by the GEMM's DMA loads) against im2col + GEMM."""
+    import torch
+    import avsi_amd  # noqa: F401
+    from avsi_amd import ops
+    g = torch.Generator(device='cuda')
+    g.manual_seed(c0 + c1 + k)
+    R = B * H * W
+    src0 = torch.randn(R, c0 + 4, generator=g, device='cuda')                        # pitch > channels on purpose
+    src1 = torch.randn(B * (H // 2) * (W // 2), c1, generator=g, device='cuda') if c1 else None
+    kc = k * k * (c0 + c1)
+    filt = torch.randn(kc, cout, generator=g, device='cuda') * 0.1
+    bias = torch.randn(cout, generator=g, device='cuda')
+    col = torch.empty(R, kc, device='cuda')
+    ops.im2col(src0, c0, src1, c1, B, H, W, k, col, kc)
+    want = torch.empty(R, cout, device='cuda')
+    ops.gemm(col, filt, out=want, n=cout, bias=bias)
+    got = torch.full((R, cout), 7.0, device='cuda')
+    assert ops.conv2d_supported(c0, c1)
+    ops.conv2d(src0, c0, src1, c1, B, H, W, k, filt, bias, got, cout)
+    np.testing.assert_allclose(got.cpu().numpy(), want.cpu().numpy(), rtol=1e-5, atol=1e-4)
+    assert not ops.conv2d_supported(1, 16) and not ops.conv2d_supported(0, 0)
+
+
+@pytest.mark.parametrize("k,c0,c1,cout", [(7, 1, 0, 16), (3, 1, 16, 1), (1, 1, 0, 1)])
+def test_thin_direct_conv_matches_im2col_gemm(k, c0, c1, cout):
+    import torch
+    import avsi_amd  # noqa: F401
+    from avsi_amd import ops
+    g = torch.Generator(device='cuda')
+    g.manual_seed(k * 10 + cout)
+    B, H, W = 3, 20, 14
+    R = B * H * W
+    ld = 4
+    src0 = torch.randn(R, ld, generator=g, device='cuda')
+    src1 = torch.randn(B * (H // 2) * (W // 2), c1, generator=g, device='cuda') if c1 else None
+    kc = -(-(k * k * (c0 + c1)) // 4) * 4
+    ldf = -(-cout // 4) * 4
+    filt = torch.zeros(kc, ldf, device='cuda')
+    filt[:k * k * (c0 + c1), :cout] = torch.randn(k * k * (c0 + c1), cout, generator=g, device='cuda') * 0.2
+    bias = torch.randn(ldf, generator=g, device='cuda')
+    col = torch.empty(R, kc, device='cuda')
+    ops.im2col(src0, c0, src1, c1, B, H, W, k, col, kc)
+    want = torch.zeros(R, ldf, device='cuda')
+    ops.gemm(col, filt, out=want, n=cout, bias=bias)
+    got = torch.zeros(R, ldf, device='cuda')
+    assert ops.conv2d_thin_supported(k, c0, c1, cout) and not ops.conv2d_thin_supported(3, 1, 0, 16)
+    ops.conv2d_thin(src0, c0, src1, c1, B, H, W, k, filt, bias, got, cout)
+    np.testing.assert_allclose(got[:, :cout].cpu().numpy(), want[:, :cout].cpu().numpy(), rtol=1e-5, atol=1e-5)
