@@ -11,8 +11,10 @@ max pooling its channel counts and experiment name ('unet_maxpool') imply is wha
 Batch normalisation always uses batch statistics (the reference never runs UPDATE_OPS and builds
 the model with is_training=True everywhere).
 
-Every convolution is im2col + the fp32-MFMA GEMM (``ops.im2col`` / ``ops.gemm``); its gradients are a
-split-K GEMM (filter) and a GEMM + gather-form col2im (input).  Activations are NHWC
+Forward convolutions: implicit GEMM on the fp32-MFMA GEMM kernel for the layers whose channel
+counts are multiples of 16 (``ops.conv2d``), direct kernels for the three thin full-resolution
+layers (``ops.conv2d_thin``), im2col + GEMM otherwise; gradients are a split-K GEMM over the
+im2col matrix (filter) and a GEMM + gather-form col2im (input).  Activations are NHWC
 ``[B*H*W][C]`` with the channel pitch padded to a multiple of 4.
 """
 import math
