@@ -41,6 +41,7 @@ struct CoopArgs {
     float* resv;
     unsigned* sync;    // [0] status, [1 + group] step counters
     int T, Bp, ngroups;
+    int tile0;         // first 32-utterance tile of this launch (large batches run in resident-sized chunks)
 };
 
 __device__ __forceinline__ float sigmoidf_fast(float x) { return __builtin_amdgcn_rcpf(1.f + __expf(-x)); }
@@ -80,7 +81,7 @@ __global__ __launch_bounds__(512, 2) void blstm_rec_fwd_coop_kernel(const CoopAr
     const int group = (kk / S) * AVSI_NUM_XCD + xcd;
     if (group >= a.ngroups) return;
     const int dir = group & 1;
-    const int b0 = (group >> 1) * 32;
+    const int b0 = (a.tile0 + (group >> 1)) * 32;
     const int T = a.T, Bp = a.Bp;
 
     const int tid = threadIdx.x;
@@ -107,7 +108,7 @@ __global__ __launch_bounds__(512, 2) void blstm_rec_fwd_coop_kernel(const CoopAr
 #pragma unroll
     for (int c = 0; c < CPL; ++c) cstate[c] = 0.f;
 
-    unsigned* ctr = a.sync + 1 + group;
+    unsigned* ctr = a.sync + 1 + 2 * a.tile0 + group;
     __syncthreads();
 
     for (int step = 0; step < T; ++step) {
@@ -233,20 +234,31 @@ extern "C" size_t avsi_blstm_rec_fwd_coop_workspace_bytes(int Bp) {
     return (size_t)(1 + 2 * (Bp > 0 ? Bp / 32 : 0)) * sizeof(unsigned);
 }
 
+// Tiles per launch: the whole launch must be resident (one workgroup per CU)
+static int coop_tiles_per_launch(int split) { return (AVSI_NUM_CU / split / AVSI_NUM_XCD) * AVSI_NUM_XCD / 2; }
+
 extern "C" int avsi_blstm_rec_fwd_coop_f32(const float* xproj, const float* whp, float* hout, float* reserve, int T, int Bp,
                                            int split, void* workspace, size_t workspace_bytes, void* stream) {
     if (!xproj || !whp || !hout || T <= 0 || Bp <= 0 || (Bp & 31)) return AVSI_ERR_INVALID_ARG;
     if (split != 4 && split != 8) return AVSI_ERR_INVALID_ARG;
     if (!workspace || workspace_bytes < avsi_blstm_rec_fwd_coop_workspace_bytes(Bp)) return AVSI_ERR_WORKSPACE;
-    const int ngroups = 2 * (Bp / 32);
-    // every member of a group must be resident while its peers wait for it: one workgroup per CU
-    if ((int64_t)avsi_ceil_div(ngroups, AVSI_NUM_XCD) * AVSI_NUM_XCD * split > AVSI_NUM_CU) return AVSI_ERR_UNSUPPORTED;
     const hipStream_t st = (hipStream_t)stream;
     avsi_clear_error();
     if (hipMemsetAsync(workspace, 0, avsi_blstm_rec_fwd_coop_workspace_bytes(Bp), st) != hipSuccess) return AVSI_ERR_LAUNCH;
-    CoopArgs a{xproj, whp, hout, reserve, (unsigned*)workspace, T, Bp, ngroups};
-    if (split == 8) return reserve ? launch_coop<8, true>(a, st) : launch_coop<8, false>(a, st);
-    return reserve ? launch_coop<4, true>(a, st) : launch_coop<4, false>(a, st);
+    // every member of a group must be resident while its peers wait for it: batches beyond one chip-full of
+    // groups run as consecutive launches over tile ranges
+    const int tiles = Bp / 32, per = coop_tiles_per_launch(split);
+    for (int tile0 = 0; tile0 < tiles; tile0 += per) {
+        const int nt = tiles - tile0 < per ? tiles - tile0 : per;
+        CoopArgs a{xproj, whp, hout, reserve, (unsigned*)workspace, T, Bp, 2 * nt, tile0};
+        int rc;
+        if (split == 8)
+            rc = reserve ? launch_coop<8, true>(a, st) : launch_coop<8, false>(a, st);
+        else
+            rc = reserve ? launch_coop<4, true>(a, st) : launch_coop<4, false>(a, st);
+        if (rc != AVSI_OK) return rc;
+    }
+    return AVSI_OK;
 }
 
 // ==========================================================================================
@@ -268,6 +280,7 @@ struct CoopBwdArgs {
     float* dz;
     unsigned* sync;
     int T, Bp, ngroups;
+    int tile0;
 };
 
 constexpr int BPART_FLOATS = 8 * 32 * PSTRIDE;      // [wave][unit][row]
@@ -285,7 +298,7 @@ __global__ __launch_bounds__(512, 2) void blstm_rec_bwd_coop_kernel(const CoopBw
     const int group = (kk / S) * AVSI_NUM_XCD + xcd;
     if (group >= a.ngroups) return;
     const int dir = group & 1;
-    const int b0 = (group >> 1) * 32;
+    const int b0 = (a.tile0 + (group >> 1)) * 32;
     const int T = a.T, Bp = a.Bp;
 
     const int tid = threadIdx.x;
@@ -308,7 +321,7 @@ __global__ __launch_bounds__(512, 2) void blstm_rec_bwd_coop_kernel(const CoopBw
     float dcn[CPL];
 #pragma unroll
     for (int c = 0; c < CPL; ++c) dcn[c] = 0.f;
-    unsigned* ctr = a.sync + 1 + group;
+    unsigned* ctr = a.sync + 1 + 2 * a.tile0 + group;
     __syncthreads();
 
     for (int s = 0; s < T; ++s) {
@@ -400,16 +413,20 @@ extern "C" int avsi_blstm_rec_bwd_coop_f32(const float* dhout, const float* rese
     if (!dhout || !reserve || !whbT || !dz || T <= 0 || Bp <= 0 || (Bp & 31)) return AVSI_ERR_INVALID_ARG;
     if (split != 4 && split != 8) return AVSI_ERR_INVALID_ARG;
     if (!workspace || workspace_bytes < avsi_blstm_rec_fwd_coop_workspace_bytes(Bp)) return AVSI_ERR_WORKSPACE;
-    const int ngroups = 2 * (Bp / 32);
-    const int blocks = (int)avsi_ceil_div(ngroups, AVSI_NUM_XCD) * AVSI_NUM_XCD * split;
-    if (blocks > AVSI_NUM_CU) return AVSI_ERR_UNSUPPORTED;
     const hipStream_t st = (hipStream_t)stream;
     avsi_clear_error();
     if (hipMemsetAsync(workspace, 0, avsi_blstm_rec_fwd_coop_workspace_bytes(Bp), st) != hipSuccess) return AVSI_ERR_LAUNCH;
-    CoopBwdArgs a{dhout, reserve, whbT, dz, (unsigned*)workspace, T, Bp, ngroups};
-    if (split == 8)
-        hipLaunchKernelGGL(blstm_rec_bwd_coop_kernel<8>, dim3(blocks), dim3(512), 0, st, a);
-    else
-        hipLaunchKernelGGL(blstm_rec_bwd_coop_kernel<4>, dim3(blocks), dim3(512), 0, st, a);
-    return avsi_launch_status();
+    const int tiles = Bp / 32, per = coop_tiles_per_launch(split);
+    for (int tile0 = 0; tile0 < tiles; tile0 += per) {
+        const int nt = tiles - tile0 < per ? tiles - tile0 : per;
+        CoopBwdArgs a{dhout, reserve, whbT, dz, (unsigned*)workspace, T, Bp, 2 * nt, tile0};
+        const int blocks = (int)avsi_ceil_div(2 * nt, AVSI_NUM_XCD) * AVSI_NUM_XCD * split;
+        if (split == 8)
+            hipLaunchKernelGGL(blstm_rec_bwd_coop_kernel<8>, dim3(blocks), dim3(512), 0, st, a);
+        else
+            hipLaunchKernelGGL(blstm_rec_bwd_coop_kernel<4>, dim3(blocks), dim3(512), 0, st, a);
+        const int rc = avsi_launch_status();
+        if (rc != AVSI_OK) return rc;
+    }
+    return AVSI_OK;
 }

@@ -84,7 +84,7 @@ def coop_split(Bp):
     batch-stationary kernels.  The cooperative grid must be resident on the 256 CUs at once."""
     if os.environ.get('AVSI_REC_COOP', '1') == '0':
         return 0
-    return 8 if Bp <= 512 else (4 if Bp <= 1024 else 0)
+    return 8 if Bp <= 512 else (4 if Bp <= 2048 else 0)      # 1024 < Bp <= 2048: two resident-sized launches
 
 
 def coop_check(device=None):

@@ -145,8 +145,8 @@ int avsi_l1_loss_f32(const float* target, const float* pred, const float* mask, 
  * tile, direction) pair is spread over `split` = 4 or 8 workgroups that keep their piece of the
  * recurrent kernel in registers for all T steps and exchange h_t through hout with a per-step
  * counter in `workspace` (avsi_blstm_rec_fwd_coop_workspace_bytes(Bp) bytes, zeroed by the call).
- * The whole grid must be resident: AVSI_ERR_UNSUPPORTED unless ceil8(2 Bp / 32) * split <= 256
- * (Bp <= 512 for split 8, <= 1024 for split 4).  After the stream has drained, word 0 of the
+ * A launch must be wholly resident (one workgroup per CU), so batches beyond 512 (split 8) /
+ * 1024 (split 4) utterances run as consecutive launches over tile ranges.  After the stream has drained, word 0 of the
  * workspace is 0; a non-zero value means a workgroup stopped waiting for its peers (bounded spin)
  * and the outputs are invalid. */
 size_t avsi_blstm_rec_fwd_coop_workspace_bytes(int Bp);

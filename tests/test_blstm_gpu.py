@@ -151,7 +151,8 @@ def test_feed_reuses_model_and_variables(mods):
     assert torch.equal(m.prediction, p1)                            # deterministic, bitwise
 
 
-@pytest.mark.parametrize("Bp,split,save", [(32, 8, False), (64, 8, True), (512, 8, False), (1024, 4, True), (96, 4, False)])
+@pytest.mark.parametrize("Bp,split,save", [(32, 8, False), (64, 8, True), (512, 8, False), (1024, 4, True), (96, 4, False),
+                                           (1056, 4, False), (544, 8, True)])   # the last two: more than one resident-sized launch
 def test_cooperative_small_batch_kernel_matches_batch_stationary(Bp, split, save):
     """avsi_blstm_rec_fwd_coop_f32 (weights resident in registers, h exchanged through hout with a
     per-step counter) against avsi_blstm_rec_fwd_f32 on the same operands: same maths, different
@@ -174,15 +175,10 @@ def test_cooperative_small_batch_kernel_matches_batch_stationary(Bp, split, save
     np.testing.assert_allclose(outs[1][0].cpu().numpy(), outs[0][0].cpu().numpy(), rtol=0, atol=2e-5)
     if save:
         np.testing.assert_allclose(outs[1][1].cpu().numpy(), outs[0][1].cpu().numpy(), rtol=0, atol=5e-5)
-    assert ops.coop_split(32) == 8 and ops.coop_split(1024) == 4 and ops.coop_split(2048) == 0
-    # the launch refuses grids that could not be co-resident
-    from avsi_amd import _lib
-    with pytest.raises(_lib.AvsiError):
-        big = torch.zeros(2, 2048, 2048, device='cuda')
-        ops.blstm_rec_fwd(big, whp, torch.zeros(2, 2048, 512, device='cuda'), None, split=8)
+    assert ops.coop_split(32) == 8 and ops.coop_split(1024) == 4 and ops.coop_split(2048) == 4 and ops.coop_split(4096) == 0
 
 
-@pytest.mark.parametrize("Bp,split", [(32, 8), (256, 8), (1024, 4), (64, 4)])
+@pytest.mark.parametrize("Bp,split", [(32, 8), (256, 8), (1024, 4), (64, 4), (1088, 4)])
 def test_cooperative_bptt_matches_batch_stationary(Bp, split):
     import torch
     import avsi_amd  # noqa: F401
