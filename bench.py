@@ -135,6 +135,71 @@ def cpu_baseline(torch, model, wav, masks, mean, std, sample, cpu_batch):
                       % (sample, cpu_batch, dt), "best_case_fused_cpu": fused}, rms
 
 
+def bench_unet(args, torch, dist, rank, world, device):
+    """configs[4]: U-Net spectrogram inpainter (UNetFConvModel), inference, mixed 100-1600 ms gap masks."""
+    import avsi_amd  # noqa: F401
+    from avsi_amd import models, ops
+    from avsi_amd import audio_processing as ap_mod
+    B, N, T, F = args.batch, 16384, 128, 128
+    cfg = dict(audio_feat_dim=F, audio_len=N, net_dim=[H, H, H], optimizer_type='adam', starter_learning_rate=1e-3,
+               lr_updating_steps=10000, lr_decay=1.0, batch_size=B, l2=0.0)
+    g = torch.Generator(device=device)
+    g.manual_seed(4321 + rank)
+    wav = torch.clamp(torch.round(torch.randn(B, N, generator=g, device=device) * 3000.0), -32768, 32767)
+    # one whole-frame gap per clip, 100 / 200 / 400 / 800 ms at 8 ms frames (1600 ms exceeds the 0.8 coverage cap of a 1 s clip)
+    lens = torch.tensor([12, 25, 50, 100], device=device)[torch.randint(0, 4, (B,), generator=g, device=device)]
+    starts = (torch.rand(B, generator=g, device=device) * (T - lens).float()).long()
+    t = torch.arange(T, device=device)[None, :]
+    masks = torch.ones(B, T, F, device=device)
+    masks[(t >= starts[:, None]) & (t < (starts + lens)[:, None])] = 0.0
+    spec = ap_mod.frontend(wav[:min(B, 256)], window_size=16, step_size=8, n_fft=256, num_bins=F, want_spec=True)['spec']
+    mean, std = spec.mean(dim=(0, 1)), spec.std(dim=(0, 1), unbiased=False)
+    seq = np.full(B, T)
+    model = models.UNetFConvModel(seq, wav, masks, mean, std, 0.0, cfg, is_training=False, seed=7)
+    timer = KernelTimer(torch)
+    for name in ("conv2d", "conv2d_thin", "colstats", "bn_act", "maxpool2"):
+        setattr(ops, name, timer.wrap(name, getattr(ops, name)))
+
+    def step():
+        model.feed(sequence_lengths=seq, target_sources=wav, masks=masks)
+        _ = model.prediction
+        return model.loss_func
+
+    for _ in range(args.warmup):
+        step()
+    timer.events.clear()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+    if rank == 0:
+        totals = timer.totals()
+        flops = 0.52e9 * B * args.steps                      # 2 k^2 Cin Cout H W over the 13 layers, per clip
+        print(json.dumps({
+            "metric": "spectrogram clips/sec (U-Net inference: front end + 13 conv layers + L1 loss)",
+            "value": B * world * args.steps / elapsed, "unit": "clips/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "configs[4]: U-Net (fconv) spectrogram inpainter, 1.024 s 16 kHz clips, 128 x 128 log-spectrogram, "
+                                   "one 100-800 ms gap", "per_gpu_batch": B, "global_batch": B * world,
+                       "parallelism": "dp%d" % world},
+            "loss_func": float(loss), "algorithmic_TFLOP/s": flops / elapsed / 1e12,
+            "kernel_ms_per_step": {k: v[0] / args.steps for k, v in totals.items()}}))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def profiled_traffic(kernel_key, batch):
     """HBM bytes per launch from the committed PMC passes (profiles/r*_traffic_b<batch>.json: FETCH_SIZE and
     WRITE_SIZE collected in separate rocprofv3 --pmc runs of this same command, gfx950 correction
@@ -162,8 +227,9 @@ def main():
     ap.add_argument("--rows-per-wg", type=int, default=0)
     ap.add_argument("--cpu-sample", type=int, default=384, help="utterances timed on the CPU oracle (~15 s)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--mode", choices=["infer", "train"], default="infer",
-                    help="infer = headline workload (configs[1]); train = configs[2]: AV model, fwd + BPTT + Adam")
+    ap.add_argument("--mode", choices=["infer", "train", "unet"], default="infer",
+                    help="infer = headline workload (configs[1]); train = configs[2]: AV model, fwd + BPTT + Adam; "
+                         "unet = configs[4]: U-Net spectrogram inpainter inference (use --batch 32 .. 512)")
     args = ap.parse_args()
 
     import torch
@@ -182,6 +248,9 @@ def main():
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+
+    if args.mode == "unet":
+        return bench_unet(args, torch, dist, rank, world, device)
 
     B = args.batch
     cfg = dict(audio_feat_dim=F_BINS, video_feat_dim=136, audio_len=N_SAMPLES, net_dim=[H, H, H],
