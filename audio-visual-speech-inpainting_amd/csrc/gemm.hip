@@ -354,30 +354,36 @@ __device__ __forceinline__ void dma16(const float* src, uint32_t lds_byte_addr) 
     asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(src), "s"(lds_byte_addr) : "memory");
 }
 
-template <bool TA, bool TB, int BK, int NST, bool CONV = false>
+template <bool TA, bool TB, int BK, int NST, bool CONV = false, int BNT = 128>
 __global__ __launch_bounds__(256, BK == 16 ? (NST == 3 ? 3 : 4) : 2) void gemm_dma_kernel(const GemmArgs g) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     static_assert((BK == 16 && (NST == 3 || NST == 2)) || (BK == 32 && NST == 2), "tile shapes this kernel was tuned for");
     static_assert(!CONV || (!TA && !TB && BK == 16), "the implicit-GEMM gather is written for A . B with 16-deep tiles");
-    constexpr int BM = 128, TILE = 128 * BK;
+    static_assert(BNT == 128 || ((BNT == 64 || BNT == 32) && !TA && !TB && BK == 16 && NST == 3),
+                  "narrow N tiles (convolutions with 16 .. 64 output channels) exist for the A . B 16-deep form");
+    // wave grid WM x WN, each wave TM x TN MFMA tiles: 128 x 128 = (2 x 2) x (2 x 2), 128 x 64 = (2 x 2) x (2 x 1),
+    // 128 x 32 = (4 x 1) x (1 x 1)
+    constexpr int WN = BNT == 32 ? 1 : 2, TN = BNT == 128 ? 2 : 1, TM = BNT == 32 ? 1 : 2;
+    constexpr int BM = 128, TILE = 128 * BK, TILEB = BNT * BK;
+    constexpr int PPWB = BNT == 128 ? BK / 8 : 1;   // B pieces per wave (the 2 pieces of a 32-wide tile are issued twice)
     constexpr int PPW = BK / 8;         // 1-KiB DMA pieces per wave and operand tile
     constexpr int CPR = BK / 4;         // 16-byte chunks per row of a "row" tile
     constexpr int RPP = 256 / BK;       // rows of a "row" tile per DMA piece
     // XOR swizzle of the chunk index inside a row: spreads the ds_read_b128 of 8 neighbouring rows over all banks
     auto swz = [](int row) { return BK == 16 ? (row >> 2) & 3 : row & 7; };
     float* sA = reinterpret_cast<float*>(smem);
-    float* sB = sA + NST * TILE;
+    float* sB = sA + NST * TILE;   // NST stages of TILEB floats
     const uint32_t lds_a = (uint32_t)(uintptr_t)(lvoid_t)smem, lds_b = lds_a + NST * TILE * 4u;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave / WN, wn = wave % WN;
     const int li = lane & 31, hi = lane >> 5;
 
     int bm, bn;
     tile_of_block(g, blockIdx.x, bm, bn);
-    const int m0 = bm * BM, n0 = bn * BN;
+    const int m0 = bm * BM, n0 = bn * BNT;
     const int kbeg = blockIdx.z * g.k_split_len;
     const int kend = min(g.K, kbeg + g.k_split_len);
     const int nk = (kend - kbeg) / BK;
@@ -385,6 +391,7 @@ __global__ __launch_bounds__(256, BK == 16 ? (NST == 3 ? 3 : 4) : 2) void gemm_d
 
     // per-lane source offsets (floats, relative to the tile origin) of this wave's DMA pieces per operand
     int64_t offa[PPW], offb[PPW];
+    const int pb0 = BNT == 128 ? wave * PPW : (BNT == 64 ? wave : (wave & 1));   // first B piece of this wave
 #pragma unroll
     for (int j = 0; j < PPW; ++j) {
         const int p = wave * PPW + j;  // 1-KiB piece of the tile
@@ -398,9 +405,10 @@ __global__ __launch_bounds__(256, BK == 16 ? (NST == 3 ? 3 : 4) : 2) void gemm_d
         if (TB) {   // row tile [n][k]
             const int row = p * RPP + lane / CPR, cl = (lane % CPR) ^ swz(row);
             offb[j] = (int64_t)(min(n0 + row, g.N - 1) - n0) * g.ldb + cl * 4;
-        } else {    // col tile [k][n]
-            const int x = min(n0 + 4 * (lane & 31), ((g.N + 3) & ~3) - 4) - n0;
-            offb[j] = (int64_t)(2 * p + (lane >> 5)) * g.ldb + x;
+        } else if (j < PPWB) {    // col tile [k][n]: one piece = 256 / BNT k-rows of BNT floats
+            constexpr int XQ = BNT / 4;
+            const int x = min(n0 + 4 * (lane % XQ), ((g.N + 3) & ~3) - 4) - n0;
+            offb[j] = (int64_t)((pb0 + j) * (256 / BNT) + lane / XQ) * g.ldb + x;
         }
     }
     // implicit GEMM: output pixel (b, h, w) of this lane's rows, and its 16-byte chunk inside a 16-deep k tile
@@ -452,23 +460,23 @@ __global__ __launch_bounds__(256, BK == 16 ? (NST == 3 ? 3 : 4) : 2) void gemm_d
                            (cc - g.cC0) + cvcl[j];
             }
             dma16(asrc, lds_a + (uint32_t)(st * TILE + (wave * PPW + j) * 256) * 4u);
-            dma16(bo + offb[j], lds_b + (uint32_t)(st * TILE + (wave * PPW + j) * 256) * 4u);
+            if (j < PPWB) dma16(bo + offb[j], lds_b + (uint32_t)(st * TILEB + (pb0 + j) * 256) * 4u);
         }
     };
 
-    f32x16 acc[2][2];
+    f32x16 acc[TM][TN];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < TN; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     // fragments of one 8-deep k group (q < BK / 8) of a staged tile pair
-    auto rd = [&](int q, const float* a_s, const float* b_s, float (&a)[2][4], float (&b)[2][4]) {
+    auto rd = [&](int q, const float* a_s, const float* b_s, float (&a)[TM][4], float (&b)[TN][4]) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int row = wm * 64 + i * 32 + li;
+        for (int i = 0; i < TM; ++i) {
+            const int row = wm * (32 * TM) + i * 32 + li;
             if (!TA) {
                 const float4 v = *reinterpret_cast<const float4*>(a_s + row * BK + (((2 * q + hi) ^ swz(row)) << 2));
                 a[i][0] = v.x, a[i][1] = v.y, a[i][2] = v.z, a[i][3] = v.w;
@@ -478,29 +486,29 @@ __global__ __launch_bounds__(256, BK == 16 ? (NST == 3 ? 3 : 4) : 2) void gemm_d
             }
         }
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int col = wn * 64 + j * 32 + li;
+        for (int j = 0; j < TN; ++j) {
+            const int col = wn * (32 * TN) + j * 32 + li;
             if (TB) {
                 const float4 v = *reinterpret_cast<const float4*>(b_s + col * BK + (((2 * q + hi) ^ swz(col)) << 2));
                 b[j][0] = v.x, b[j][1] = v.y, b[j][2] = v.z, b[j][3] = v.w;
             } else {
 #pragma unroll
-                for (int s = 0; s < 4; ++s) b[j][s] = b_s[(8 * q + 4 * hi + s) * 128 + col];
+                for (int s = 0; s < 4; ++s) b[j][s] = b_s[(8 * q + 4 * hi + s) * BNT + col];
             }
         }
     };
-    auto mm = [&](const float (&a)[2][4], const float (&b)[2][4]) {
+    auto mm = [&](const float (&a)[TM][4], const float (&b)[TN][4]) {
 #pragma unroll
         for (int s = 0; s < 4; ++s)
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+            for (int i = 0; i < TM; ++i)
 #pragma unroll
-                for (int j = 0; j < 2; ++j)
+                for (int j = 0; j < TN; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][s], b[j][s], acc[i][j], 0, 0, 0);
     };
 
     // ring of NST stages: tiles kt+1 .. kt+NST-1 are in flight / landed while tile kt is computed
-    constexpr int PPT = 2 * PPW;        // DMA instructions per wave and k-tile
+    constexpr int PPT = PPW + PPWB;     // DMA instructions per wave and k-tile
     if (nk > 0) issue(0);
     if (NST == 3 && nk > 1) issue(1);
     if (NST == 3 && nk > 1)
@@ -509,12 +517,12 @@ __global__ __launch_bounds__(256, BK == 16 ? (NST == 3 ? 3 : 4) : 2) void gemm_d
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
 
-    float af[2][2][4], bf[2][2][4];
+    float af[2][TM][4], bf[2][TN][4];
     for (int kt = 0; kt < nk; ++kt) {
         // the stage being refilled was last read (tile kt-1) before the barrier of iteration kt-1
         if (kt + NST - 1 < nk) issue(kt + NST - 1);
         const float* a_s = sA + (kt % NST) * TILE;
-        const float* b_s = sB + (kt % NST) * TILE;
+        const float* b_s = sB + (kt % NST) * TILEB;
 #pragma unroll
         for (int h = 0; h < BK / 16; ++h) {
             rd(2 * h, a_s, b_s, af[0], bf[0]);
@@ -533,17 +541,17 @@ __global__ __launch_bounds__(256, BK == 16 ? (NST == 3 ? 3 : 4) : 2) void gemm_d
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
     const bool accumulate = g.beta != 0.f;
-    float bv[2];
+    float bv[TN];
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int col = n0 + wn * 64 + j * 32 + li;
+    for (int j = 0; j < TN; ++j) {
+        const int col = n0 + wn * (32 * TN) + j * 32 + li;
         bv[j] = (g.bias && col < g.N) ? g.bias[col] : 0.f;
     }
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < TM; ++i) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const int row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+            const int row = m0 + wm * (32 * TM) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
             if (row >= g.M) continue;
             int64_t orow = row;
             if (g.row_map_bp > 0) {
@@ -553,8 +561,8 @@ __global__ __launch_bounds__(256, BK == 16 ? (NST == 3 ? 3 : 4) : 2) void gemm_d
             }
             const float rsc = g.row_scale ? g.row_scale[row] : 1.f;
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const int col = n0 + wn * 64 + j * 32 + li;
+            for (int j = 0; j < TN; ++j) {
+                const int col = n0 + wn * (32 * TN) + j * 32 + li;
                 if (col >= g.N) continue;
                 float* c = C + orow * g.ldc + col;
                 float v = (g.alpha * acc[i][j][r] + bv[j]) * rsc;
@@ -685,14 +693,21 @@ extern "C" int avsi_conv2d_f32(const float* src0, int C0, int ld0, const float* 
     g.M = (int)M64, g.N = Cout, g.K = k * k * (C0 + C1);
     g.lda = 0, g.ldb = ldf, g.ldc = ldo;
     g.alpha = 1.f, g.beta = 0.f;
-    g.m_blocks = (int)avsi_ceil_div(g.M, 128), g.n_blocks = (int)avsi_ceil_div(Cout, BN);
+    const int bnt = Cout <= 32 ? 32 : (Cout <= 64 ? 64 : 128);      // N tile: narrow layers do not pay for 128 columns
+    g.m_blocks = (int)avsi_ceil_div(g.M, 128), g.n_blocks = (int)avsi_ceil_div(Cout, bnt);
     g.k_split_len = g.K, g.c_split_stride = 0, g.n_group = g.n_blocks;
     g.conv_s0 = src0, g.conv_s1 = src1_coarse, g.conv_zeros = zeros64;
     g.cH = H, g.cW = W, g.cC0 = C0, g.cld0 = ld0, g.cC1 = C1, g.cld1 = ld1, g.ck = k;
     if ((int64_t)g.m_blocks * g.n_blocks > INT32_MAX) return AVSI_ERR_UNSUPPORTED;
     avsi_clear_error();
-    hipLaunchKernelGGL((gemm_dma_kernel<false, false, 16, 3, true>), dim3(g.m_blocks * g.n_blocks), dim3(256),
-                       (size_t)2 * 3 * 128 * 16 * 4, (hipStream_t)stream, g);
+    const dim3 grid(g.m_blocks * g.n_blocks), block(256);
+    const hipStream_t st = (hipStream_t)stream;
+    if (bnt == 32)
+        hipLaunchKernelGGL((gemm_dma_kernel<false, false, 16, 3, true, 32>), grid, block, (size_t)3 * (128 + 32) * 16 * 4, st, g);
+    else if (bnt == 64)
+        hipLaunchKernelGGL((gemm_dma_kernel<false, false, 16, 3, true, 64>), grid, block, (size_t)3 * (128 + 64) * 16 * 4, st, g);
+    else
+        hipLaunchKernelGGL((gemm_dma_kernel<false, false, 16, 3, true, 128>), grid, block, (size_t)3 * (128 + 128) * 16 * 4, st, g);
     return avsi_launch_status();
 }
 

@@ -161,7 +161,8 @@ def test_unet_forward_backward_matches_oracle(mods):
 
 
 @pytest.mark.parametrize("c0,c1,k,cout,B,H,W", [(16, 0, 5, 32, 2, 12, 10), (32, 64, 3, 32, 3, 8, 16), (128, 128, 3, 128, 1, 4, 6),
-                                                (16, 32, 3, 16, 2, 128, 8)])
+                                                (16, 32, 3, 16, 2, 128, 8), (32, 0, 5, 64, 2, 16, 12), (64, 128, 3, 64, 1, 16, 16),
+                                                (16, 0, 3, 40, 1, 9, 7)])
 def test_implicit_gemm_conv_matches_im2col_gemm(c0, c1, k, cout, B, H, W):
     """avsi_conv2d_f32 (operand rows gathered by the GEMM's DMA loads) against im2col + GEMM."""
     import torch
