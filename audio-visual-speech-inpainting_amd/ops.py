@@ -70,11 +70,14 @@ _COOP_WS, _COOP_STICKY = {}, {}
 
 
 def _coop_ws(device, Bp):
+    """Step counters of the cooperative kernels: one buffer per (device, stream) -- launches on one
+    stream run in order and may share it, launches on different streams may overlap and must not."""
     need = _lib.lib().avsi_blstm_rec_fwd_coop_workspace_bytes(Bp)
-    ws = _COOP_WS.get(device.index)
+    key = (device.index, _lib.stream_ptr().value)
+    ws = _COOP_WS.get(key)
     if ws is None or ws.numel() * 4 < need:
         ws = torch.zeros((need + 3) // 4, dtype=torch.int32, device=device)
-        _COOP_WS[device.index] = ws
+        _COOP_WS[key] = ws
     _COOP_STICKY.setdefault(device.index, torch.zeros(1, dtype=torch.int32, device=device))
     return ws
 
@@ -110,11 +113,11 @@ def l1_loss(target, pred, mask, want_grad=False, grad_scale=None):
     if pred.numel() != n or mask.numel() != n:
         raise _lib.AvsiError("l1_loss: size mismatch")
     dev = target.device
-    ws = _LOSS_WS.get(dev.index)
+    ws = _LOSS_WS.get((dev.index, _lib.stream_ptr().value))
     need = L.avsi_l1_loss_workspace_bytes(n)
     if ws is None or ws.numel() * 4 < need:
         ws = torch.empty((need + 3) // 4, dtype=torch.float32, device=dev)
-        _LOSS_WS[dev.index] = ws
+        _LOSS_WS[(dev.index, _lib.stream_ptr().value)] = ws
     out3 = torch.empty(3, dtype=torch.float32, device=dev)
     dpred = torch.empty_like(pred) if want_grad else None
     gs = (1.0 / n) if grad_scale is None else float(grad_scale)
@@ -139,11 +142,11 @@ def l1_loss_blend(target, pred_inout, mask, row_scale=None, want_grad=False):
                                   or row_scale.numel() != n // row_len):
         raise _lib.AvsiError("l1_loss_blend: row_scale must be contiguous float32 with one value per row")
     dev = target.device
-    ws = _LOSS_WS.get(dev.index)
+    ws = _LOSS_WS.get((dev.index, _lib.stream_ptr().value))
     need = L.avsi_l1_loss_workspace_bytes(n)
     if ws is None or ws.numel() * 4 < need:
         ws = torch.empty((need + 3) // 4, dtype=torch.float32, device=dev)
-        _LOSS_WS[dev.index] = ws
+        _LOSS_WS[(dev.index, _lib.stream_ptr().value)] = ws
     out4 = torch.empty(4, dtype=torch.float32, device=dev)
     dlog = torch.empty_like(pred_inout) if want_grad else None
     _lib.check(L.avsi_l1_loss_blend_f32(_lib.ptr(target), _lib.ptr(pred_inout), _lib.ptr(mask), _lib.ptr(row_scale),
@@ -156,11 +159,13 @@ _WS = {}
 
 
 def _workspace(dev, nbytes):
-    """One growing scratch buffer per device (split-K slabs, column-sum partials)."""
-    ws = _WS.get(dev.index)
+    """One growing scratch buffer per (device, stream) (split-K slabs, column-sum partials): work on
+    one stream is ordered and can share it, concurrent streams each get their own."""
+    key = (dev.index, _lib.stream_ptr().value)
+    ws = _WS.get(key)
     if ws is None or ws.numel() * 4 < nbytes:
         ws = torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=dev)
-        _WS[dev.index] = ws
+        _WS[key] = ws
     return ws
 
 
