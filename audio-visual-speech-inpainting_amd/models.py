@@ -555,6 +555,22 @@ class StackedBLSTMModel(object):
             self.variables.global_step / self.updating_step)
 
     @property
+    def summaries(self):
+        """The tensors the reference hands to TensorBoard (models.py:199-218), as a dict of device
+        tensors for the first 10 utterances: spectrogram images [n, F, T, 1] flipped upside down
+        (frequency up), the mask likewise, peak-normalised target / enhanced audio [n, samples]."""
+        n = 10
+
+        def image(x):
+            return x[:n].transpose(1, 2).flip(1).unsqueeze(3)
+        T = self.prediction.shape[1]
+        tgt, enh = self.target_sources[:n], self.enhanced_sources[:n]
+        return {'Target_spectrogram': image(self.target_spec_norm), 'Enhanced_spectrogram': image(self.prediction),
+                'Mask': image(self.masks[:, :T]),
+                'Target_audio': tgt / tgt.abs().amax(dim=1, keepdim=True),
+                'Enhanced_audio': enh / enh.abs().amax(dim=1, keepdim=True)}
+
+    @property
     def train_vars(self):
         return [(n, self.layout.ref_view(self.variables.flat, n)) for n, _, _ in self.layout.ref_entries]
 

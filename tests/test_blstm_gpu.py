@@ -199,3 +199,14 @@ def test_cooperative_bptt_matches_batch_stationary(Bp, split):
     ops.coop_check()
     scale = np.abs(outs[0]).max()
     np.testing.assert_allclose(outs[1], outs[0], rtol=0, atol=2e-6 * scale)
+
+
+def test_summaries_hold_the_tensorboard_tensors(mods):
+    models, ops, bl = mods
+    wav, masks, mean, std, video, T = _inputs(3, 3840, 5)
+    m = models.StackedBLSTMModel(np.full(3, T), wav, masks, mean, std, 0.0, _config(audio_len=3840), input='a', is_training=False)
+    s = m.summaries
+    assert set(s) == {'Target_spectrogram', 'Enhanced_spectrogram', 'Mask', 'Target_audio', 'Enhanced_audio'}
+    assert tuple(s['Target_spectrogram'].shape) == (3, 257, T, 1) and tuple(s['Mask'].shape) == (3, 257, T, 1)
+    np.testing.assert_array_equal(s['Mask'][0, :, :, 0].cpu().numpy()[::-1], masks[0].T)       # flipped upside down
+    assert abs(float(s['Enhanced_audio'].abs().amax(dim=1)[0]) - 1.0) < 1e-6 and tuple(s['Target_audio'].shape) == (3, 3840)
