@@ -146,6 +146,55 @@ __global__ __launch_bounds__(TPB) void direct_conv_kernel(const float* __restric
     }
 }
 
+// After the input-gradient convolution (dX of concat(src0, up2x(src1)) as one [R][C0 + C1] matrix):
+// channels [0, C0) go to the full-resolution source, channels [C0, C0 + C1) are summed over each 2x2
+// block into the coarse source (the adjoint of nearest-neighbour up-sampling); "=" or "+=" per target.
+__global__ __launch_bounds__(TPB) void split_sumpool_kernel(const float* __restrict__ dx, int ldx, float* __restrict__ d0,
+                                                            int C0, int ld0, int acc0, float* __restrict__ d1, int C1,
+                                                            int ld1, int acc1, int B, int H, int W) {
+    const int q0 = d0 ? ld0 >> 2 : 0, q1 = d1 ? ld1 >> 2 : 0;
+    const int H2 = H >> 1, W2 = W >> 1;
+    const int64_t n0 = (int64_t)B * H * W * q0, n1 = (int64_t)B * H2 * W2 * q1;
+    for (int64_t e = (int64_t)blockIdx.x * TPB + threadIdx.x; e < n0 + n1; e += (int64_t)gridDim.x * TPB) {
+        if (e < n0) {
+            const int c = (int)(e % q0) * 4;
+            const int64_t px = e / q0;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (c < C0) v = *reinterpret_cast<const float4*>(dx + px * ldx + c);
+            float4* o = reinterpret_cast<float4*>(d0 + px * ld0 + c);
+            if (acc0) {
+                const float4 p = *o;
+                v.x += p.x, v.y += p.y, v.z += p.z, v.w += p.w;
+            }
+            *o = v;
+        } else {
+            const int64_t e1 = e - n0;
+            const int c = (int)(e1 % q1) * 4;
+            int64_t px = e1 / q1;
+            const int w2 = (int)(px % W2);
+            px /= W2;
+            const int h2 = (int)(px % H2), b = (int)(px / H2);
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (c < C1) {
+#pragma unroll
+                for (int dh = 0; dh < 2; ++dh)
+#pragma unroll
+                    for (int dw = 0; dw < 2; ++dw) {
+                        const float4 t = *reinterpret_cast<const float4*>(
+                            dx + (((int64_t)b * H + 2 * h2 + dh) * W + 2 * w2 + dw) * ldx + C0 + c);
+                        v.x += t.x, v.y += t.y, v.z += t.z, v.w += t.w;
+                    }
+            }
+            float4* o = reinterpret_cast<float4*>(d1 + (((int64_t)b * H2 + h2) * W2 + w2) * ld1 + c);
+            if (acc1) {
+                const float4 p = *o;
+                v.x += p.x, v.y += p.y, v.z += p.z, v.w += p.w;
+            }
+            *o = v;
+        }
+    }
+}
+
 // which = 0: gradient of the full-resolution source (channels [0, C0)); which = 1: of the up-sampled one
 __global__ __launch_bounds__(TPB) void col2im_kernel(const float* __restrict__ dcol, float* __restrict__ dst,
                                                      const ConvGeom g, const int which, const int accumulate) {
@@ -414,6 +463,22 @@ extern "C" int avsi_conv2d_thin_f32(const float* src0, int C0, int ld0, const fl
                            out, ldo, B, H, W);
     else
         return AVSI_ERR_UNSUPPORTED;
+    return avsi_launch_status();
+}
+
+extern "C" int avsi_split_sumpool_f32(const float* dx, int ldx, float* dsrc0, int C0, int ld0, int accumulate0,
+                                      float* dsrc1_coarse, int C1, int ld1, int accumulate1, int B, int H, int W,
+                                      void* stream) {
+    if (!dx || B <= 0 || H <= 0 || W <= 0 || C0 < 0 || C1 < 0 || ldx < C0 + C1 || (!dsrc0 && !dsrc1_coarse))
+        return AVSI_ERR_INVALID_ARG;
+    if ((dsrc0 && ld0 < C0) || (dsrc1_coarse && (ld1 < C1 || ((H | W) & 1)))) return AVSI_ERR_INVALID_ARG;
+    if ((C0 & 3) || (C1 & 3) || (ldx & 3) || (dsrc0 && (ld0 & 3)) || (dsrc1_coarse && (ld1 & 3)) ||
+        ((reinterpret_cast<uintptr_t>(dx) | reinterpret_cast<uintptr_t>(dsrc0) | reinterpret_cast<uintptr_t>(dsrc1_coarse)) & 15))
+        return AVSI_ERR_UNSUPPORTED;
+    const int64_t n = (dsrc0 ? (int64_t)B * H * W * (ld0 >> 2) : 0) + (dsrc1_coarse ? (int64_t)B * (H >> 1) * (W >> 1) * (ld1 >> 2) : 0);
+    avsi_clear_error();
+    hipLaunchKernelGGL(split_sumpool_kernel, dim3(grid_for(n)), dim3(TPB), 0, (hipStream_t)stream, dx, ldx, dsrc0, C0, ld0,
+                       accumulate0, dsrc1_coarse, C1, ld1, accumulate1, B, H, W);
     return avsi_launch_status();
 }
 

@@ -297,6 +297,15 @@ def im2col(src0, c0, src1, c1, B, H, W, k, col, kc):
     return col
 
 
+def split_sumpool(dx, dsrc0, c0, acc0, dsrc1, c1, acc1, B, H, W):
+    """dX of concat(src0, up2x(src1)) [B*H*W, c0 + c1] -> (+)= dsrc0 and (+)= 2x2-summed dsrc1 (avsi_split_sumpool_f32)."""
+    _lib.require_cuda(dx, dsrc0, dsrc1)
+    _lib.check(_lib.lib().avsi_split_sumpool_f32(_lib.ptr(dx), dx.stride(0), _lib.ptr(dsrc0), int(c0),
+                                                 dsrc0.stride(0) if dsrc0 is not None else 0, int(acc0), _lib.ptr(dsrc1),
+                                                 int(c1), dsrc1.stride(0) if dsrc1 is not None else 0, int(acc1), B, H, W,
+                                                 _lib.stream_ptr()), "avsi_split_sumpool_f32")
+
+
 def col2im(dcol, kc, dsrc0, c0, dsrc1, c1, B, H, W, k, accumulate0=False, accumulate1=False):
     _lib.require_cuda(dcol, dsrc0, dsrc1)
     pitch = lambda t, c: t.stride(0) if t is not None else -(-int(c) // 4) * 4      # a skipped gradient keeps its pitch

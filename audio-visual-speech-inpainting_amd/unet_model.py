@@ -148,7 +148,7 @@ class UNetFConvModel(object):
         self.variables = variables if variables is not None else BLSTMVariables(self.layout, seed=seed,
                                                                                   init=_unet_default_init)
         self.device = self.variables.device
-        self._ws, self._cache = {}, {}
+        self._ws, self._cache, self._flip_idx = {}, {}, {}
         self.audio_feat_mean = _as_device(audio_feat_mean, device=self.device)
         self.audio_feat_std = _as_device(audio_feat_std, device=self.device)
         self.sequence_lengths = None
@@ -242,6 +242,7 @@ class UNetFConvModel(object):
         self._frontend()
         B, T, F = self._dims()
         self._col_floats = B * T * F * 160                              # largest im2col matrix: d6 (17 ch x 9 taps)
+        self._dx_floats = B * T * F * 16                                # >= the largest [R][C0 + C1] input gradient (d5: 64 x 64 x 48)
         c['saved'], c['pool'] = {}, {}
         h, H, W, ch = c['x0'], T, F, 1
         skips = [(c['x0'], 1, T, F)]
@@ -326,8 +327,28 @@ class UNetFConvModel(object):
                         splits=max(1, min(64, R // 4096)))
         if dsrc0 is None and dsrc1 is None:
             return
+        if cout % 16 == 0 and s['c0'] % 4 == 0 and s['c1'] % 4 == 0:
+            # dX = conv2d(dY, tap-flipped transposed filter): implicit GEMM again, then split / 2x2-sum into the sources
+            ct = s['c0'] + s['c1']
+            dxc = self._buf('dxcat', (self._dx_floats,))[: R * ct].view(R, ct)
+            ops.conv2d(dconv, cout, None, 0, s['B'], s['H'], s['W'], s['k'], self._flipped_filter(name, s), None, dxc, ct)
+            ops.split_sumpool(dxc, dsrc0, s['c0'], acc0, dsrc1, s['c1'], acc1, s['B'], s['H'], s['W'])
+            return
         ops.gemm(dconv, v.p(name + '/w'), out=col, trans_b=True, m=R, n=kc, k=ld)          # dcol overwrites col
         ops.col2im(col, kc, dsrc0, s['c0'], dsrc1, s['c1'], s['B'], s['H'], s['W'], s['k'], acc0, acc1)
+
+    def _flipped_filter(self, name, s):
+        """[k*k*cout][ct] filter of the input-gradient convolution: Wt[(tap', n)][c] = W[(k*k-1-tap'), c][n]."""
+        k, cout, ct, ld = s['k'], s['cout'], s['c0'] + s['c1'], s['ld']
+        idx = self._flip_idx.get(name)
+        if idx is None:
+            tap = np.arange(k * k)[:, None, None]
+            n = np.arange(cout)[None, :, None]
+            c = np.arange(ct)[None, None, :]
+            src = ((k * k - 1 - tap) * ct + c) * ld + n                      # position inside the packed [kc][ld] filter
+            idx = torch.from_numpy(src.reshape(k * k * cout, ct).astype(np.int64)).to(self.device)
+            self._flip_idx[name] = idx
+        return self.variables.p(name + '/w').reshape(-1)[idx]
 
     def _backward(self):
         c = self._cache

@@ -279,6 +279,14 @@ int avsi_conv2d_f32(const float* src0, int C0, int ld0, const float* src1_coarse
 int avsi_conv2d_thin_f32(const float* src0, int C0, int ld0, const float* src1_coarse, int C1, int ld1,
                          int B, int H, int W, int k, const float* filter, int ldf, const float* bias,
                          int Cout, float* out, int ldo, void* stream);
+/* Second half of the input gradient of a convolution computed as an implicit GEMM (dX of
+ * concat(src0, up2x(src1)) = avsi_conv2d_f32 of dY with the tap-flipped, transposed filter, one
+ * [B*H*W][C0 + C1] matrix): channels [0, C0) are copied / added to dsrc0, channels [C0, C0 + C1)
+ * are summed over every 2x2 block into dsrc1_coarse (adjoint of the nearest up-sampling).  Either
+ * target may be null.  Channel counts and pitches must be multiples of 4. */
+int avsi_split_sumpool_f32(const float* dx, int ldx, float* dsrc0, int C0, int ld0, int accumulate0,
+                           float* dsrc1_coarse, int C1, int ld1, int accumulate1, int B, int H, int W,
+                           void* stream);
 int avsi_im2col_f32(const float* src0, int C0, int ld0, const float* src1_coarse, int C1, int ld1,
                     int B, int H, int W, int k, float* col, int Kc, void* stream);
 int avsi_col2im_f32(const float* dcol, int Kc, float* dsrc0, int C0, int ld0, float* dsrc1_coarse, int C1, int ld1,
