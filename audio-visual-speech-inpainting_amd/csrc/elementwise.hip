@@ -50,6 +50,33 @@ __global__ __launch_bounds__(TPB) void colsum_partial_kernel(const float* __rest
     part[(int64_t)blockIdx.y * N + col] = (s0 + s1) + (s2 + s3);
 }
 
+// Narrow matrices (ld <= 256: bias gradients of the U-Net layers, 16 .. 128 channels): with one
+// thread per column only ld threads of a block work.  Here rows are read whole with 16-byte loads
+// (thread t: float4 column group t % (ld / 4), rows t / (ld / 4) + i * TPB / (ld / 4)) and the
+// row-threads of a column are summed through LDS in a fixed order.
+__global__ __launch_bounds__(TPB) void colsum_narrow_kernel(const float* __restrict__ x, int ld, int64_t M, int N,
+                                                            float* __restrict__ part) {
+    __shared__ float red[TPB * 4];
+    const int q4 = ld >> 2, rp = TPB / q4;
+    const int cq = threadIdx.x % q4, rl = threadIdx.x / q4;
+    const int64_t chunk = (M + gridDim.y - 1) / gridDim.y;
+    const int64_t r0 = (int64_t)blockIdx.y * chunk, r1 = min(M, r0 + chunk);
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (rl < rp)
+        for (int64_t r = r0 + rl; r < r1; r += rp) {
+            const float4 v = *reinterpret_cast<const float4*>(x + r * ld + 4 * cq);
+            s.x += v.x, s.y += v.y, s.z += v.z, s.w += v.w;
+        }
+    *reinterpret_cast<float4*>(red + threadIdx.x * 4) = s;
+    __syncthreads();
+    const int c = threadIdx.x;
+    if (c < N) {
+        float t = 0.f;
+        for (int j = 0; j < rp; ++j) t += red[(j * q4 + (c >> 2)) * 4 + (c & 3)];
+        part[(int64_t)blockIdx.y * N + c] = t;
+    }
+}
+
 __global__ __launch_bounds__(TPB) void sum_slabs_kernel(const float* __restrict__ slabs, int64_t n, int count,
                                                         int64_t stride, float* __restrict__ out, float alpha) {
     for (int64_t i = (int64_t)blockIdx.x * TPB + threadIdx.x; i < n; i += (int64_t)gridDim.x * TPB) {
@@ -126,8 +153,11 @@ extern "C" int avsi_colsum_f32(const float* x, int64_t ld, int64_t M, int N, flo
     if (parts < 1) parts = 1;
     const hipStream_t st = (hipStream_t)stream;
     avsi_clear_error();
-    hipLaunchKernelGGL(colsum_partial_kernel, dim3((int)avsi_ceil_div(N, TPB), (int)parts), dim3(TPB), 0, st, x, ld, M,
-                       N, (float*)workspace);
+    if (ld <= 256 && !(ld & 3) && !(reinterpret_cast<uintptr_t>(x) & 15))
+        hipLaunchKernelGGL(colsum_narrow_kernel, dim3(1, (int)parts), dim3(TPB), 0, st, x, (int)ld, M, N, (float*)workspace);
+    else
+        hipLaunchKernelGGL(colsum_partial_kernel, dim3((int)avsi_ceil_div(N, TPB), (int)parts), dim3(TPB), 0, st, x, ld, M,
+                           N, (float*)workspace);
     hipLaunchKernelGGL(sum_slabs_kernel, dim3(grid_for(N, TPB)), dim3(TPB), 0, st, (const float*)workspace, (int64_t)N,
                        (int)parts, (int64_t)N, out, 1.f);
     return avsi_launch_status();
