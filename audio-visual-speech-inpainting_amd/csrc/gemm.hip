@@ -358,7 +358,7 @@ template <bool TA, bool TB, int BK, int NST, bool CONV = false, int BNT = 128>
 __global__ __launch_bounds__(256, BK == 16 ? (NST == 3 ? 3 : 4) : 2) void gemm_dma_kernel(const GemmArgs g) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     static_assert((BK == 16 && (NST == 3 || NST == 2)) || (BK == 32 && NST == 2), "tile shapes this kernel was tuned for");
-    static_assert(!CONV || (!TA && !TB && BK == 16), "the implicit-GEMM gather is written for A . B with 16-deep tiles");
+    static_assert(!CONV || (!TB && BK == 16), "the implicit-GEMM gathers are written for A . B and A^T . B with 16-deep tiles");
     static_assert(BNT == 128 || ((BNT == 64 || BNT == 32) && !TA && !TB && BK == 16 && NST == 3),
                   "narrow N tiles (convolutions with 16 .. 64 output channels) exist for the A . B 16-deep form");
     // wave grid WM x WN, each wave TM x TN MFMA tiles: 128 x 128 = (2 x 2) x (2 x 2), 128 x 64 = (2 x 2) x (2 x 1),
@@ -414,7 +414,7 @@ __global__ __launch_bounds__(256, BK == 16 ? (NST == 3 ? 3 : 4) : 2) void gemm_d
     // implicit GEMM: output pixel (b, h, w) of this lane's rows, and its 16-byte chunk inside a 16-deep k tile
     int cvh[PPW], cvw[PPW], cvb[PPW], cvcl[PPW];
     bool cvok[PPW];
-    if (CONV) {
+    if (CONV && !TA) {
 #pragma unroll
         for (int j = 0; j < PPW; ++j) {
             const int row = (wave * PPW + j) * RPP + lane / CPR;
@@ -427,6 +427,18 @@ __global__ __launch_bounds__(256, BK == 16 ? (NST == 3 ? 3 : 4) : 2) void gemm_d
             cvcl[j] = ((lane % CPR) ^ swz(row)) * 4;
         }
     }
+    // filter-gradient form (A^T . B, A = the im2col matrix, reduction over pixels): this lane's 4 columns
+    // m = (tap, c .. c+3) are fixed for the whole kernel, the pixel changes with the k row
+    int wt_dh = 0, wt_dw = 0, wt_c = 0;
+    bool wt_ok = false, wt_from0 = true;
+    if (CONV && TA) {
+        const int Ct = g.cC0 + g.cC1, m = m0 + 4 * (lane & 31);
+        wt_ok = m < g.M;
+        const int tap = wt_ok ? m / Ct : 0;
+        wt_c = wt_ok ? m - tap * Ct : 0;
+        wt_dh = tap / g.ck - g.ck / 2, wt_dw = tap % g.ck - g.ck / 2;
+        wt_from0 = wt_c < g.cC0;
+    }
     const float* a_org = TA ? g.A + (int64_t)kbeg * g.lda + m0 : g.A + (int64_t)m0 * g.lda + kbeg;
     const float* b_org = TB ? g.B + (int64_t)n0 * g.ldb + kbeg : g.B + (int64_t)kbeg * g.ldb + n0;
     const int64_t a_step = TA ? (int64_t)BK * g.lda : BK, b_step = TB ? BK : (int64_t)BK * g.ldb;
@@ -438,7 +450,7 @@ __global__ __launch_bounds__(256, BK == 16 ? (NST == 3 ? 3 : 4) : 2) void gemm_d
         // implicit GEMM: the whole k tile lies in one filter tap and one source (channel counts % 16 == 0)
         int cdh = 0, cdw = 0, cc = 0;
         bool from0 = true;
-        if (CONV) {
+        if (CONV && !TA) {
             const int Ct = g.cC0 + g.cC1, k0 = kbeg + kt * BK;
             const int tap = k0 / Ct;
             cc = k0 - tap * Ct;
@@ -448,7 +460,20 @@ __global__ __launch_bounds__(256, BK == 16 ? (NST == 3 ? 3 : 4) : 2) void gemm_d
 #pragma unroll
         for (int j = 0; j < PPW; ++j) {
             const float* asrc = ao + offa[j];
-            if (CONV) {
+            if (CONV && TA) {
+                const int px = kbeg + kt * BK + 2 * (wave * PPW + j) + (lane >> 5);     // pixel of this lane's k row
+                const int w = px % g.cW, h = (px / g.cW) % g.cH, b = px / (g.cW * g.cH);
+                const int hh = h + wt_dh, ww = w + wt_dw;
+                const bool ok = wt_ok && px < kend && hh >= 0 && hh < g.cH && ww >= 0 && ww < g.cW;
+                if (!ok)
+                    asrc = g.conv_zeros;
+                else if (wt_from0)
+                    asrc = g.conv_s0 + (((int64_t)b * g.cH + hh) * g.cW + ww) * g.cld0 + wt_c;
+                else
+                    asrc = g.conv_s1 + (((int64_t)b * (g.cH >> 1) + (hh >> 1)) * (g.cW >> 1) + (ww >> 1)) * g.cld1 +
+                           (wt_c - g.cC0);
+            }
+            if (CONV && !TA) {
                 const int hh = cvh[j] + cdh, ww = cvw[j] + cdw;
                 const bool ok = cvok[j] && hh >= 0 && hh < g.cH && ww >= 0 && ww < g.cW;
                 if (!ok)
@@ -709,6 +734,55 @@ extern "C" int avsi_conv2d_f32(const float* src0, int C0, int ld0, const float* 
     else
         hipLaunchKernelGGL((gemm_dma_kernel<false, false, 16, 3, true, 128>), grid, block, (size_t)3 * (128 + 128) * 16 * 4, st, g);
     return avsi_launch_status();
+}
+
+// Filter gradient of the convolution as an implicit GEMM: dW[(tap, c)][n] = sum over pixels of
+// in(b, h+dh, w+dw, c) dY[(b,h,w)][n], i.e. im2col^T . dY without the im2col matrix; the reduction over
+// the B*H*W pixels is cut into `splits` slabs summed in order (deterministic), like avsi_gemm_splitk_f32.
+int avsi_sum_slabs_launch(const float* slabs, int64_t n, int count, int64_t stride, float* out, float alpha,
+                          hipStream_t st);
+
+extern "C" size_t avsi_conv2d_wgrad_workspace_bytes(int C0, int C1, int k, int Cout, int splits) {
+    if (splits < 1 || k < 1 || Cout <= 0 || C0 + C1 <= 0) return 0;
+    return (size_t)splits * (size_t)(k * k * (C0 + C1)) * (size_t)((Cout + 3) & ~3) * sizeof(float);
+}
+
+extern "C" int avsi_conv2d_wgrad_f32(const float* src0, int C0, int ld0, const float* src1_coarse, int C1, int ld1, int B,
+                                     int H, int W, int k, const float* dy, int ldy, int Cout, float* dw, int ldw,
+                                     int splits, const float* zeros64, void* workspace, size_t workspace_bytes,
+                                     void* stream) {
+    if (!dy || !dw || !zeros64 || B <= 0 || H <= 0 || W <= 0 || k < 1 || !(k & 1) || Cout <= 0 || C0 < 0 || C1 < 0 || splits < 1)
+        return AVSI_ERR_INVALID_ARG;
+    if ((C0 && !src0) || (C1 && !src1_coarse) || ldy < Cout || ldw != ((Cout + 3) & ~3) || (C0 && ld0 < C0) || (C1 && ld1 < C1))
+        return AVSI_ERR_INVALID_ARG;
+    // a lane's 4 consecutive columns must stay inside one tap of one source; 16-byte gathers
+    if ((C0 & 3) || (C1 & 3) || C0 + C1 < 4 || (ld0 & 3) || (ld1 & 3) || (ldy & 3) || (C1 && ((H | W) & 1)))
+        return AVSI_ERR_UNSUPPORTED;
+    if ((reinterpret_cast<uintptr_t>(src0) | reinterpret_cast<uintptr_t>(src1_coarse) | reinterpret_cast<uintptr_t>(dy) |
+         reinterpret_cast<uintptr_t>(zeros64)) & 15)
+        return AVSI_ERR_UNSUPPORTED;
+    if (!workspace || workspace_bytes < avsi_conv2d_wgrad_workspace_bytes(C0, C1, k, Cout, splits)) return AVSI_ERR_WORKSPACE;
+    const int64_t R = (int64_t)B * H * W;
+    if (R > INT32_MAX || (R & 15)) return AVSI_ERR_UNSUPPORTED;     // whole 16-pixel reduction tiles
+    const int Kc = k * k * (C0 + C1);
+    GemmArgs g{};
+    g.A = zeros64, g.B = dy, g.C = (float*)workspace, g.bias = nullptr, g.row_scale = nullptr;
+    g.M = Kc, g.N = Cout, g.K = (int)R;
+    g.lda = 0, g.ldb = ldy, g.ldc = ldw;
+    g.alpha = 1.f, g.beta = 0.f;
+    g.m_blocks = (int)avsi_ceil_div(Kc, 128), g.n_blocks = (int)avsi_ceil_div(Cout, BN);
+    g.k_split_len = (int)avsi_round_up(avsi_ceil_div(R, splits), 32);
+    g.c_split_stride = (int64_t)Kc * ldw;
+    g.n_group = g.n_blocks;
+    g.conv_s0 = src0, g.conv_s1 = src1_coarse, g.conv_zeros = zeros64;
+    g.cH = H, g.cW = W, g.cC0 = C0, g.cld0 = ld0, g.cC1 = C1, g.cld1 = ld1, g.ck = k;
+    const hipStream_t st = (hipStream_t)stream;
+    avsi_clear_error();
+    hipLaunchKernelGGL((gemm_dma_kernel<true, false, 16, 3, true, 128>), dim3(g.m_blocks * g.n_blocks, 1, splits), dim3(256),
+                       (size_t)2 * 3 * 128 * 16 * 4, st, g);
+    const int rc = avsi_launch_status();
+    if (rc != AVSI_OK) return rc;
+    return avsi_sum_slabs_launch((const float*)workspace, (int64_t)Kc * ldw, splits, (int64_t)Kc * ldw, dw, 1.f, st);
 }
 
 extern "C" int avsi_gemm_f32(int transA, int transB, int M, int N, int K, float alpha, const float* A, int64_t lda,

@@ -297,6 +297,25 @@ def im2col(src0, c0, src1, c1, B, H, W, k, col, kc):
     return col
 
 
+def conv2d_wgrad_supported(c0, c1, rows):
+    return c0 % 4 == 0 and c1 % 4 == 0 and c0 + c1 >= 4 and rows % 16 == 0
+
+
+def conv2d_wgrad(src0, c0, src1, c1, B, H, W, k, dy, cout, dw, splits):
+    """dw [k*k*(c0+c1), ld] = im2col(concat(src0, up2x(src1)))^T . dy, no im2col matrix (avsi_conv2d_wgrad_f32)."""
+    _lib.require_cuda(src0, src1, dy, dw)
+    L = _lib.lib()
+    z = _ZEROS.get(dw.device.index)
+    if z is None:
+        z = _ZEROS[dw.device.index] = torch.zeros(64, dtype=torch.float32, device=dw.device)
+    ws = _workspace(dw.device, L.avsi_conv2d_wgrad_workspace_bytes(c0, c1, k, cout, splits))
+    _lib.check(L.avsi_conv2d_wgrad_f32(_lib.ptr(src0), c0, src0.stride(0) if src0 is not None else 0, _lib.ptr(src1), c1,
+                                       src1.stride(0) if src1 is not None else 0, B, H, W, k, _lib.ptr(dy), dy.stride(0),
+                                       cout, _lib.ptr(dw), dw.stride(0), int(splits), _lib.ptr(z), _lib.ptr(ws),
+                                       ws.numel() * 4, _lib.stream_ptr()), "avsi_conv2d_wgrad_f32")
+    return dw
+
+
 def split_sumpool(dx, dsrc0, c0, acc0, dsrc1, c1, acc1, B, H, W):
     """dX of concat(src0, up2x(src1)) [B*H*W, c0 + c1] -> (+)= dsrc0 and (+)= 2x2-summed dsrc1 (avsi_split_sumpool_f32)."""
     _lib.require_cuda(dx, dsrc0, dsrc1)

@@ -321,10 +321,17 @@ class UNetFConvModel(object):
                        lay.gpacked_view(gp, name + '/bn/gamma') if s['bn'] else None,
                        lay.gpacked_view(gp, name + '/bn/beta') if s['bn'] else None)
         ops.colsum(dconv, lay.gpacked_view(gp, name + '/b'), m=R, n=ld)
-        col = self._buf('col', (self._col_floats,))[: R * kc].view(R, kc)
-        ops.im2col(s['src0'], s['c0'], s['src1'], s['c1'], s['B'], s['H'], s['W'], s['k'], col, kc)
-        ops.gemm_splitk(col, dconv, lay.gpacked_view(gp, name + '/w'), trans_a=True, m=kc, n=ld, k=R,
-                        splits=max(1, min(64, R // 4096)))
+        # reduction slabs: enough workgroups (output tiles x slabs ~ 1024) even when the filter is one 128 x 128 tile
+        tiles = -(-kc // 128) * -(-ld // 128)
+        splits = max(1, min(R // 2048, max(64, 1024 // tiles)))
+        implicit_w = ops.conv2d_wgrad_supported(s['c0'], s['c1'], R)
+        if implicit_w:
+            ops.conv2d_wgrad(s['src0'], s['c0'], s['src1'], s['c1'], s['B'], s['H'], s['W'], s['k'], dconv, cout,
+                             lay.gpacked_view(gp, name + '/w'), splits)
+        else:
+            col = self._buf('col', (self._col_floats,))[: R * kc].view(R, kc)
+            ops.im2col(s['src0'], s['c0'], s['src1'], s['c1'], s['B'], s['H'], s['W'], s['k'], col, kc)
+            ops.gemm_splitk(col, dconv, lay.gpacked_view(gp, name + '/w'), trans_a=True, m=kc, n=ld, k=R, splits=splits)
         if dsrc0 is None and dsrc1 is None:
             return
         if cout % 16 == 0 and s['c0'] % 4 == 0 and s['c1'] % 4 == 0:
@@ -334,7 +341,8 @@ class UNetFConvModel(object):
             ops.conv2d(dconv, cout, None, 0, s['B'], s['H'], s['W'], s['k'], self._flipped_filter(name, s), None, dxc, ct)
             ops.split_sumpool(dxc, dsrc0, s['c0'], acc0, dsrc1, s['c1'], acc1, s['B'], s['H'], s['W'])
             return
-        ops.gemm(dconv, v.p(name + '/w'), out=col, trans_b=True, m=R, n=kc, k=ld)          # dcol overwrites col
+        col = self._buf('col', (self._col_floats,))[: R * kc].view(R, kc)
+        ops.gemm(dconv, v.p(name + '/w'), out=col, trans_b=True, m=R, n=kc, k=ld)          # d(im2col matrix)
         ops.col2im(col, kc, dsrc0, s['c0'], dsrc1, s['c1'], s['B'], s['H'], s['W'], s['k'], acc0, acc1)
 
     def _flipped_filter(self, name, s):

@@ -287,6 +287,16 @@ int avsi_conv2d_thin_f32(const float* src0, int C0, int ld0, const float* src1_c
 int avsi_split_sumpool_f32(const float* dx, int ldx, float* dsrc0, int C0, int ld0, int accumulate0,
                            float* dsrc1_coarse, int C1, int ld1, int accumulate1, int B, int H, int W,
                            void* stream);
+/* Filter gradient of the same convolution, again without the im2col matrix:
+ *   dw [k*k*(C0+C1)][ldw] = im2col(concat(src0, up2x(src1)))^T . dy [B*H*W][ldy]
+ * (ldw = Cout rounded up to 4).  The reduction over the pixels is cut into `splits` slabs in
+ * `workspace` (avsi_conv2d_wgrad_workspace_bytes) and summed in order.  Needs C0, C1 multiples of 4
+ * and B*H*W a multiple of 16; AVSI_ERR_UNSUPPORTED otherwise. */
+size_t avsi_conv2d_wgrad_workspace_bytes(int C0, int C1, int k, int Cout, int splits);
+int avsi_conv2d_wgrad_f32(const float* src0, int C0, int ld0, const float* src1_coarse, int C1, int ld1,
+                          int B, int H, int W, int k, const float* dy, int ldy, int Cout, float* dw, int ldw,
+                          int splits, const float* zeros64, void* workspace, size_t workspace_bytes,
+                          void* stream);
 int avsi_im2col_f32(const float* src0, int C0, int ld0, const float* src1_coarse, int C1, int ld1,
                     int B, int H, int W, int k, float* col, int Kc, void* stream);
 int avsi_col2im_f32(const float* dcol, int Kc, float* dsrc0, int C0, int ld0, float* dsrc1_coarse, int C1, int ld1,

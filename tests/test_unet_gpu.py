@@ -212,3 +212,28 @@ def test_thin_direct_conv_matches_im2col_gemm(k, c0, c1, cout):
     assert ops.conv2d_thin_supported(k, c0, c1, cout) and not ops.conv2d_thin_supported(3, 1, 0, 16)
     ops.conv2d_thin(src0, c0, src1, c1, B, H, W, k, filt, bias, got, cout)
     np.testing.assert_allclose(got[:, :cout].cpu().numpy(), want[:, :cout].cpu().numpy(), rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize("c0,c1,k,cout,B,H,W,splits", [(16, 0, 5, 32, 2, 12, 8, 3), (32, 64, 3, 32, 3, 8, 16, 1), (128, 128, 3, 128, 1, 4, 4, 2),
+                                                       (16, 32, 3, 16, 2, 64, 8, 5), (4, 0, 3, 7, 1, 8, 8, 1)])
+def test_implicit_filter_gradient_matches_im2col_gemm(c0, c1, k, cout, B, H, W, splits):
+    import torch
+    import avsi_amd  # noqa: F401
+    from avsi_amd import ops
+    g = torch.Generator(device='cuda')
+    g.manual_seed(c0 + c1 + k + 1)
+    R = B * H * W
+    src0 = torch.randn(R, c0 + 4, generator=g, device='cuda')
+    src1 = torch.randn(B * (H // 2) * (W // 2), c1, generator=g, device='cuda') if c1 else None
+    kc, ld = k * k * (c0 + c1), -(-cout // 4) * 4
+    dy = torch.zeros(R, ld, device='cuda')
+    dy[:, :cout] = torch.randn(R, cout, generator=g, device='cuda')
+    col = torch.empty(R, kc, device='cuda')
+    ops.im2col(src0, c0, src1, c1, B, H, W, k, col, kc)
+    want = torch.empty(kc, ld, device='cuda')
+    ops.gemm_splitk(col, dy, want, trans_a=True, m=kc, n=ld, k=R, splits=splits)
+    got = torch.full((kc, ld), 7.0, device='cuda')
+    assert ops.conv2d_wgrad_supported(c0, c1, R) and not ops.conv2d_wgrad_supported(1, 16, R)
+    ops.conv2d_wgrad(src0, c0, src1, c1, B, H, W, k, dy, cout, got, splits)
+    scale = want.abs().max().item()
+    np.testing.assert_allclose(got[:, :cout].cpu().numpy(), want[:, :cout].cpu().numpy(), rtol=1e-4, atol=1e-5 * scale)
