@@ -116,6 +116,11 @@ PROTOTYPES = {
     "avsi_conv2d_wgrad_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int]),
     "avsi_conv2d_wgrad_f32": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p,
                                       c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "avsi_conv2d_thin_wgrad_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int, c_int, c_int]),
+    "avsi_conv2d_thin_wgrad_f32": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p,
+                                           c_int, c_int, c_void_p, c_int, c_void_p, c_size_t, c_void_p]),
+    "avsi_conv2d_thin_dx_coarse_f32": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int,
+                                               c_void_p]),
     "avsi_l1_loss_blend_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int64, c_void_p, c_void_p,
                                        c_void_p, c_size_t, c_void_p]),
 }

@@ -146,6 +146,118 @@ __global__ __launch_bounds__(TPB) void direct_conv_kernel(const float* __restric
     }
 }
 
+// Filter gradient of the thin layers, direct form: dW[(tap, c)][n] = sum over pixels of in(p + off(tap), c) dY[p][n].
+// blockIdx.y = filter row dh (K rows), so a thread keeps K * CT * COUT accumulators; pixels are
+// grid-strided, lanes along W.  Per block: wave shuffle tree, LDS across the 4 waves, one partial
+// row per block in `part` [gridDim.x][K*K*CT*COUT]; the caller sums the rows in order (deterministic).
+template <int K, int C0, int C1, int COUT>
+__global__ __launch_bounds__(TPB) void thin_wgrad_kernel(const float* __restrict__ s0, int ld0, const float* __restrict__ s1,
+                                                         int ld1, const float* __restrict__ dy, int ldy,
+                                                         float* __restrict__ part, int B, int H, int W) {
+    constexpr int P = K / 2, CT = C0 + C1, NA = K * CT * COUT;
+    __shared__ float red[TPB / 64][NA];
+    const int dh = blockIdx.y;
+    const int H2 = H >> 1, W2 = W >> 1;
+    const int64_t n = (int64_t)B * H * W;
+    float acc[NA];
+#pragma unroll
+    for (int i = 0; i < NA; ++i) acc[i] = 0.f;
+    for (int64_t e = (int64_t)blockIdx.x * TPB + threadIdx.x; e < n; e += (int64_t)gridDim.x * TPB) {
+        const int w = (int)(e % W);
+        const int64_t bh = e / W;
+        const int h = (int)(bh % H), b = (int)(bh / H);
+        float g[COUT];
+#pragma unroll
+        for (int o = 0; o < COUT; ++o) g[o] = dy[e * ldy + o];
+        const int hh = h + dh - P;
+        if (hh < 0 || hh >= H) continue;
+#pragma unroll
+        for (int dw = 0; dw < K; ++dw) {
+            const int ww = w + dw - P;
+            const bool ok = ww >= 0 && ww < W;
+            if (C0 > 0) {
+                const float* px = s0 + (((int64_t)b * H + hh) * W + ww) * ld0;
+#pragma unroll
+                for (int c = 0; c < C0; ++c) {
+                    const float xv = ok ? px[c] : 0.f;
+#pragma unroll
+                    for (int o = 0; o < COUT; ++o) acc[(dw * CT + c) * COUT + o] += xv * g[o];
+                }
+            }
+            if (C1 > 0) {
+                const float* px = s1 + (((int64_t)b * H2 + (hh >> 1)) * W2 + (ww >> 1)) * ld1;
+#pragma unroll
+                for (int c4 = 0; c4 < C1; c4 += 4) {
+                    float4 xv = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (ok) xv = *reinterpret_cast<const float4*>(px + c4);
+                    const float xs[4] = {xv.x, xv.y, xv.z, xv.w};
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+#pragma unroll
+                        for (int o = 0; o < COUT; ++o) acc[(dw * CT + C0 + c4 + q) * COUT + o] += xs[q] * g[o];
+                }
+            }
+        }
+    }
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+        float v = acc[i];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+        if (lane == 0) red[wv][i] = v;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < NA; i += TPB) {
+        float v = 0.f;
+        for (int q = 0; q < TPB / 64; ++q) v += red[q][i];
+        part[(int64_t)blockIdx.x * (K * NA) + dh * NA + i] = v;
+    }
+}
+
+// Input gradient of the 1 + 16 -> 1 layer w.r.t. its up-sampled source: every coarse pixel collects the
+// 2x2 fine pixels it was copied to, each through the 9 taps (adjoint of up2x followed by the 3x3 conv).
+__global__ __launch_bounds__(TPB) void thin_dx_coarse_kernel(const float* __restrict__ dy, int ldy, const float* __restrict__ filt,
+                                                             int ldf, float* __restrict__ d1, int ld1, int accumulate, int B,
+                                                             int H, int W) {
+    constexpr int K = 3, C0 = 1, C1 = 16, CT = 17;
+    const int H2 = H >> 1, W2 = W >> 1;
+    const int64_t n = (int64_t)B * H2 * W2;
+    for (int64_t e = (int64_t)blockIdx.x * TPB + threadIdx.x; e < n; e += (int64_t)gridDim.x * TPB) {
+        const int w2 = (int)(e % W2);
+        const int64_t bh = e / W2;
+        const int h2 = (int)(bh % H2), b = (int)(bh / H2);
+        float acc[C1];
+#pragma unroll
+        for (int c = 0; c < C1; ++c) acc[c] = 0.f;
+#pragma unroll
+        for (int fh = 0; fh < 2; ++fh)
+#pragma unroll
+            for (int fw = 0; fw < 2; ++fw)
+#pragma unroll
+                for (int dh = 0; dh < K; ++dh)
+#pragma unroll
+                    for (int dw = 0; dw < K; ++dw) {
+                        // fine pixel (2 h2 + fh, 2 w2 + fw) was read by output pixel p = fine - off(tap)
+                        const int ph = 2 * h2 + fh - (dh - 1), pw = 2 * w2 + fw - (dw - 1);
+                        const float g = (ph >= 0 && ph < H && pw >= 0 && pw < W) ? dy[(((int64_t)b * H + ph) * W + pw) * ldy] : 0.f;
+                        const float* wt = filt + (int64_t)((dh * K + dw) * CT + C0) * ldf;
+#pragma unroll
+                        for (int c = 0; c < C1; ++c) acc[c] += g * wt[c * ldf];
+                    }
+        float* o = d1 + e * ld1;
+#pragma unroll
+        for (int c = 0; c < C1; c += 4) {
+            float4 v = make_float4(acc[c], acc[c + 1], acc[c + 2], acc[c + 3]);
+            if (accumulate) {
+                const float4 p = *reinterpret_cast<const float4*>(o + c);
+                v.x += p.x, v.y += p.y, v.z += p.z, v.w += p.w;
+            }
+            *reinterpret_cast<float4*>(o + c) = v;
+        }
+    }
+}
+
 // After the input-gradient convolution (dX of concat(src0, up2x(src1)) as one [R][C0 + C1] matrix):
 // channels [0, C0) go to the full-resolution source, channels [C0, C0 + C1) are summed over each 2x2
 // block into the coarse source (the adjoint of nearest-neighbour up-sampling); "=" or "+=" per target.
@@ -463,6 +575,65 @@ extern "C" int avsi_conv2d_thin_f32(const float* src0, int C0, int ld0, const fl
                            out, ldo, B, H, W);
     else
         return AVSI_ERR_UNSUPPORTED;
+    return avsi_launch_status();
+}
+
+int avsi_sum_slabs_launch(const float* slabs, int64_t n, int count, int64_t stride, float* out, float alpha, hipStream_t st);
+
+static int thin_wgrad_blocks(int64_t pixels) {
+    const int64_t want = avsi_ceil_div(pixels, (int64_t)TPB * 8);
+    return (int)(want < 1 ? 1 : (want > 512 ? 512 : want));
+}
+
+extern "C" size_t avsi_conv2d_thin_wgrad_workspace_bytes(int C0, int C1, int k, int Cout, int B, int H, int W) {
+    return (size_t)thin_wgrad_blocks((int64_t)B * H * W) * (size_t)(k * k * (C0 + C1) * Cout) * sizeof(float);
+}
+
+// dw [k*k*(C0+C1)][ldw] for the thin layers (same (k, C0, C1, Cout) set as avsi_conv2d_thin_f32); Cout == ldw or Cout == 1
+extern "C" int avsi_conv2d_thin_wgrad_f32(const float* src0, int C0, int ld0, const float* src1_coarse, int C1, int ld1, int B,
+                                          int H, int W, int k, const float* dy, int ldy, int Cout, float* dw, int ldw,
+                                          void* workspace, size_t workspace_bytes, void* stream) {
+    if (!dy || !dw || B <= 0 || H <= 0 || W <= 0 || (C0 && !src0) || (C1 && !src1_coarse) || ldy < Cout || ldw < Cout)
+        return AVSI_ERR_INVALID_ARG;
+    if (!workspace || workspace_bytes < avsi_conv2d_thin_wgrad_workspace_bytes(C0, C1, k, Cout, B, H, W)) return AVSI_ERR_WORKSPACE;
+    if (C1 && (((H | W) & 1) || (ld1 & 3) || (reinterpret_cast<uintptr_t>(src1_coarse) & 15))) return AVSI_ERR_UNSUPPORTED;
+    const int blocks = thin_wgrad_blocks((int64_t)B * H * W);
+    const int na = k * k * (C0 + C1) * Cout;
+    const hipStream_t st = (hipStream_t)stream;
+    float* part = (float*)workspace;
+    avsi_clear_error();
+    if (k == 7 && C0 == 1 && C1 == 0 && Cout == 16)
+        hipLaunchKernelGGL((thin_wgrad_kernel<7, 1, 0, 16>), dim3(blocks, 7), dim3(TPB), 0, st, src0, ld0, src1_coarse, ld1, dy, ldy,
+                           part, B, H, W);
+    else if (k == 3 && C0 == 1 && C1 == 16 && Cout == 1)
+        hipLaunchKernelGGL((thin_wgrad_kernel<3, 1, 16, 1>), dim3(blocks, 3), dim3(TPB), 0, st, src0, ld0, src1_coarse, ld1, dy, ldy,
+                           part, B, H, W);
+    else if (k == 1 && C0 == 1 && C1 == 0 && Cout == 1)
+        hipLaunchKernelGGL((thin_wgrad_kernel<1, 1, 0, 1>), dim3(blocks, 1), dim3(TPB), 0, st, src0, ld0, src1_coarse, ld1, dy, ldy,
+                           part, B, H, W);
+    else
+        return AVSI_ERR_UNSUPPORTED;
+    int rc = avsi_launch_status();
+    if (rc != AVSI_OK) return rc;
+    if (ldw == Cout) return avsi_sum_slabs_launch(part, na, blocks, na, dw, 1.f, st);
+    // Cout = 1 stored with pitch ldw: sum into a dense vector behind the partials, then scatter
+    if (Cout != 1) return AVSI_ERR_UNSUPPORTED;
+    rc = avsi_sum_slabs_launch(part, na, blocks, na, part, 1.f, st);      // in place: row 0 receives the sum of all rows
+    if (rc != AVSI_OK) return rc;
+    if (hipMemsetAsync(dw, 0, (size_t)na * ldw * sizeof(float), st) != hipSuccess) return AVSI_ERR_LAUNCH;
+    if (hipMemcpy2DAsync(dw, (size_t)ldw * sizeof(float), part, sizeof(float), sizeof(float), na, hipMemcpyDeviceToDevice, st) !=
+        hipSuccess)
+        return AVSI_ERR_LAUNCH;
+    return AVSI_OK;
+}
+
+extern "C" int avsi_conv2d_thin_dx_coarse_f32(const float* dy, int ldy, const float* filter, int ldf, float* dsrc1_coarse, int ld1,
+                                              int accumulate, int B, int H, int W, void* stream) {
+    if (!dy || !filter || !dsrc1_coarse || B <= 0 || H <= 0 || W <= 0 || ldy < 1 || ldf < 1 || ld1 < 16) return AVSI_ERR_INVALID_ARG;
+    if (((H | W) & 1) || (ld1 & 3) || (reinterpret_cast<uintptr_t>(dsrc1_coarse) & 15)) return AVSI_ERR_UNSUPPORTED;
+    avsi_clear_error();
+    hipLaunchKernelGGL(thin_dx_coarse_kernel, dim3(grid_for((int64_t)B * (H / 2) * (W / 2))), dim3(TPB), 0, (hipStream_t)stream, dy,
+                       ldy, filter, ldf, dsrc1_coarse, ld1, accumulate, B, H, W);
     return avsi_launch_status();
 }
 

@@ -316,6 +316,27 @@ def conv2d_wgrad(src0, c0, src1, c1, B, H, W, k, dy, cout, dw, splits):
     return dw
 
 
+def conv2d_thin_wgrad(src0, c0, src1, c1, B, H, W, k, dy, cout, dw):
+    """Direct filter gradient of a thin layer (avsi_conv2d_thin_wgrad_f32)."""
+    _lib.require_cuda(src0, src1, dy, dw)
+    L = _lib.lib()
+    ws = _workspace(dw.device, L.avsi_conv2d_thin_wgrad_workspace_bytes(c0, c1, k, cout, B, H, W))
+    _lib.check(L.avsi_conv2d_thin_wgrad_f32(_lib.ptr(src0), c0, src0.stride(0) if src0 is not None else 0, _lib.ptr(src1), c1,
+                                            src1.stride(0) if src1 is not None else 0, B, H, W, k, _lib.ptr(dy), dy.stride(0),
+                                            cout, _lib.ptr(dw), dw.stride(0), _lib.ptr(ws), ws.numel() * 4, _lib.stream_ptr()),
+               "avsi_conv2d_thin_wgrad_f32")
+    return dw
+
+
+def conv2d_thin_dx_coarse(dy, filt, dsrc1, accumulate, B, H, W):
+    """Gradient of the 1 + 16 -> 1 layer w.r.t. its up-sampled source (avsi_conv2d_thin_dx_coarse_f32)."""
+    _lib.require_cuda(dy, filt, dsrc1)
+    _lib.check(_lib.lib().avsi_conv2d_thin_dx_coarse_f32(_lib.ptr(dy), dy.stride(0), _lib.ptr(filt), filt.stride(0),
+                                                         _lib.ptr(dsrc1), dsrc1.stride(0), int(accumulate), B, H, W,
+                                                         _lib.stream_ptr()), "avsi_conv2d_thin_dx_coarse_f32")
+    return dsrc1
+
+
 def split_sumpool(dx, dsrc0, c0, acc0, dsrc1, c1, acc1, B, H, W):
     """dX of concat(src0, up2x(src1)) [B*H*W, c0 + c1] -> (+)= dsrc0 and (+)= 2x2-summed dsrc1 (avsi_split_sumpool_f32)."""
     _lib.require_cuda(dx, dsrc0, dsrc1)

@@ -325,6 +325,16 @@ class UNetFConvModel(object):
         tiles = -(-kc // 128) * -(-ld // 128)
         splits = max(1, min(R // 2048, max(64, 1024 // tiles)))
         implicit_w = ops.conv2d_wgrad_supported(s['c0'], s['c1'], R)
+        if ops.conv2d_thin_supported(s['k'], s['c0'], s['c1'], cout):
+            # the thin full-resolution layers: direct kernels for the filter gradient and the one input gradient needed
+            ops.conv2d_thin_wgrad(s['src0'], s['c0'], s['src1'], s['c1'], s['B'], s['H'], s['W'], s['k'], dconv, cout,
+                                  lay.gpacked_view(gp, name + '/w'))
+            if dsrc0 is not None:        # 'out' (1 x 1, one channel): dX = w dY, the forward kernel itself
+                assert s['k'] == 1 and not acc0
+                ops.conv2d_thin(dconv, 1, None, 0, s['B'], s['H'], s['W'], 1, v.p(name + '/w'), None, dsrc0, 1)
+            if dsrc1 is not None:
+                ops.conv2d_thin_dx_coarse(dconv, v.p(name + '/w'), dsrc1, acc1, s['B'], s['H'], s['W'])
+            return
         if implicit_w:
             ops.conv2d_wgrad(s['src0'], s['c0'], s['src1'], s['c1'], s['B'], s['H'], s['W'], s['k'], dconv, cout,
                              lay.gpacked_view(gp, name + '/w'), splits)

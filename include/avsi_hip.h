@@ -297,6 +297,15 @@ int avsi_conv2d_wgrad_f32(const float* src0, int C0, int ld0, const float* src1_
                           int B, int H, int W, int k, const float* dy, int ldy, int Cout, float* dw, int ldw,
                           int splits, const float* zeros64, void* workspace, size_t workspace_bytes,
                           void* stream);
+/* Backward of the thin layers (same (k, C0, C1, Cout) set as avsi_conv2d_thin_f32), direct form:
+ * filter gradient dw [k*k*(C0+C1)][ldw] (per-block partials in `workspace`, summed in order), and
+ * for the 1 + 16 -> 1 layer the gradient w.r.t. its up-sampled 16-channel source. */
+size_t avsi_conv2d_thin_wgrad_workspace_bytes(int C0, int C1, int k, int Cout, int B, int H, int W);
+int avsi_conv2d_thin_wgrad_f32(const float* src0, int C0, int ld0, const float* src1_coarse, int C1, int ld1,
+                               int B, int H, int W, int k, const float* dy, int ldy, int Cout, float* dw, int ldw,
+                               void* workspace, size_t workspace_bytes, void* stream);
+int avsi_conv2d_thin_dx_coarse_f32(const float* dy, int ldy, const float* filter, int ldf, float* dsrc1_coarse,
+                                   int ld1, int accumulate, int B, int H, int W, void* stream);
 int avsi_im2col_f32(const float* src0, int C0, int ld0, const float* src1_coarse, int C1, int ld1,
                     int B, int H, int W, int k, float* col, int Kc, void* stream);
 int avsi_col2im_f32(const float* dcol, int Kc, float* dsrc0, int C0, int ld0, float* dsrc1_coarse, int C1, int ld1,
