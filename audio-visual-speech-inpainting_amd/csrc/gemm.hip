@@ -54,6 +54,7 @@ struct GemmArgs {
     int m_blocks, n_blocks;
     int k_split_len;       // reduction length handled per blockIdx.z (multiple of BK)
     int64_t c_split_stride;  // elements between per-split partial outputs (0 = no split)
+    int bnt;               // N tile width chosen by the host (128, or 64 for A . B with a narrow last tile)
     int n_group;           // N-blocks per column group of the block -> tile order (see tile_of_block)
     // implicit-GEMM convolution (gemm_dma_kernel<.., CONV = true>): A is never materialised, its rows are
     // gathered from one or two NHWC activations (tf.nn.conv2d SAME / stride 1 over concat(src0, up2x(src1)))
@@ -611,6 +612,11 @@ int launch_dma(const GemmArgs& g, int splits, hipStream_t st) {
                            2 * 2 * 128 * 16 * 4, st, g);
         return avsi_launch_status();
     }
+    if (!TA && !TB && g.bnt == 64) {
+        hipLaunchKernelGGL((gemm_dma_kernel<false, false, 16, 3, false, 64>), dim3(g.m_blocks * g.n_blocks, 1, splits), dim3(256),
+                           (size_t)3 * (128 + 64) * 16 * 4, st, g);
+        return avsi_launch_status();
+    }
     hipLaunchKernelGGL((gemm_dma_kernel<TA, TB, 16, 3>), dim3(g.m_blocks * g.n_blocks, 1, splits), dim3(256), lds, st, g);
     return avsi_launch_status();
 }
@@ -669,8 +675,14 @@ int avsi_gemm_launch(int transA, int transB, int M, int N, int K, float alpha, c
     const int mi = env_mi ? atoi(env_mi) : 2;
     const int BM = 64 * mi;
     g.m_blocks = (int)avsi_ceil_div(M, BM);
-    g.n_blocks = (int)avsi_ceil_div(N, BN);
+    // A . B whose last 128-wide tile would be at most half full and that is narrow enough for the tail to matter
+    // (the 257-bin projection: 5 x 64 instead of 3 x 128 columns of MFMA work)
     g.k_split_len = (int)avsi_round_up(avsi_ceil_div(K, splits), 32);
+    const char* env_dma = getenv("AVSI_GEMM_DMA");
+    const bool dma_ok = !(transB && !transA) && (K % 16 == 0) && (g.k_split_len % 16 == 0) && !env_bk && !env_mi &&
+                        !(env_dma && atoi(env_dma) == 0);
+    g.bnt = (dma_ok && !transA && !transB && N < 1024 && ((N - 1) % BN) < 64 && !(env_dma && atoi(env_dma) > 1)) ? 64 : BN;
+    g.n_blocks = (int)avsi_ceil_div(N, g.bnt);
     g.c_split_stride = splits > 1 ? c_split_stride : 0;
     {   // column-group width: the group's slice of op(B), k_split_len x (n_group * 128) floats, should fill about half of
         // one XCD's 4 MiB L2
@@ -685,8 +697,6 @@ int avsi_gemm_launch(int transA, int transB, int M, int N, int K, float alpha, c
     // "col" tiles read 4 consecutive x per lane and guard on the first: the ld padding up to a
     // multiple of 4 (checked above) keeps the tail addressable; such lanes feed unstored outputs.
     avsi_clear_error();
-    const char* env_dma = getenv("AVSI_GEMM_DMA");
-    const bool dma_ok = !(transB && !transA) && (K % 16 == 0) && (g.k_split_len % 16 == 0) && !env_bk && !env_mi && !(env_dma && atoi(env_dma) == 0);
     if (dma_ok) {
         if (!transA && !transB) return launch_dma<false, false>(g, splits, st);
         if (!transA && transB) return launch_dma<false, true>(g, splits, st);
