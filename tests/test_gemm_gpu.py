@@ -69,3 +69,38 @@ def test_rejects_unaligned(ops):
     b = torch.zeros(6, 8, device='cuda')
     with pytest.raises(avsi_amd._lib.AvsiError):
         ops.gemm(a, b)                       # K = 6 is not a multiple of 4
+
+
+def test_randomised_shapes_and_options(ops):
+    """80 seeded random cases over the dispatch space: DMA / register-staged kernels, 64-wide tail tiles,
+    column-group tile order, transposes, bias, alpha / beta, split-K."""
+    rng = np.random.default_rng(2024)
+    worst = 0.0
+    for case in range(80):
+        ta, tb = bool(rng.integers(2)), bool(rng.integers(2))
+        M = int(rng.choice([1, 31, 128, 129, 700, 2500]))
+        N = int(rng.choice([1, 33, 64, 65, 200, 257, 300, 1100]))
+        K = int(rng.choice([8, 16, 48, 264, 272, 512, 1040]))
+        A = rng.normal(size=(M, K)).astype(np.float32)
+        B = rng.normal(size=(K, N)).astype(np.float32)
+        a_store = _pad_cols(A.T.copy(), -(-M // 4) * 4) if ta else A
+        b_store = B.T.copy() if tb else _pad_cols(B, -(-N // 4) * 4)
+        a_t, b_t = torch.from_numpy(a_store).cuda(), torch.from_numpy(b_store).cuda()
+        ref = A.astype(np.float64) @ B.astype(np.float64)
+        mode = case % 3
+        if mode == 0:       # plain + bias
+            bias = rng.normal(size=N).astype(np.float32)
+            got = ops.gemm(a_t, b_t, trans_a=ta, trans_b=tb, m=M, n=N, k=K, bias=torch.from_numpy(bias).cuda())
+            ref = ref + bias
+        elif mode == 1:     # alpha / beta accumulate
+            C0 = rng.normal(size=(M, N)).astype(np.float32)
+            got = torch.from_numpy(C0.copy()).cuda()
+            ops.gemm(a_t, b_t, out=got, trans_a=ta, trans_b=tb, m=M, n=N, k=K, alpha=-0.75, beta=1.0)
+            ref = -0.75 * ref + C0
+        else:               # split-K (contiguous [M, N] output)
+            got = torch.full((M, N), 7.0, device='cuda')
+            ops.gemm_splitk(a_t, b_t, got, trans_a=ta, trans_b=tb, m=M, n=N, k=K, splits=int(rng.choice([1, 2, 5])))
+        err = np.abs(got.cpu().numpy()[:, :N] - ref).max() / (1e-6 * K * 4 + 1e-5)
+        worst = max(worst, err)
+        assert err < 2.0, (case, ta, tb, M, N, K, mode, err)
+    assert worst > 0
