@@ -360,8 +360,8 @@ __global__ __launch_bounds__(256, BK == 16 ? (NST == 3 ? 3 : 4) : 2) void gemm_d
     extern __shared__ __attribute__((aligned(16))) char smem[];
     static_assert((BK == 16 && (NST == 3 || NST == 2)) || (BK == 32 && NST == 2), "tile shapes this kernel was tuned for");
     static_assert(!CONV || (!TB && BK == 16), "the implicit-GEMM gathers are written for A . B and A^T . B with 16-deep tiles");
-    static_assert(BNT == 128 || ((BNT == 64 || BNT == 32) && !TA && !TB && BK == 16 && NST == 3),
-                  "narrow N tiles (convolutions with 16 .. 64 output channels) exist for the A . B 16-deep form");
+    static_assert(BNT == 128 || ((BNT == 64 || BNT == 32) && !TB && BK == 16 && NST == 3),
+                  "narrow N tiles (convolutions with 16 .. 64 output channels) exist for the 16-deep forms with B as [k][n]");
     // wave grid WM x WN, each wave TM x TN MFMA tiles: 128 x 128 = (2 x 2) x (2 x 2), 128 x 64 = (2 x 2) x (2 x 1),
     // 128 x 32 = (4 x 1) x (1 x 1)
     constexpr int WN = BNT == 32 ? 1 : 2, TN = BNT == 128 ? 2 : 1, TM = BNT == 32 ? 1 : 2;
@@ -780,7 +780,8 @@ extern "C" int avsi_conv2d_wgrad_f32(const float* src0, int C0, int ld0, const f
     g.M = Kc, g.N = Cout, g.K = (int)R;
     g.lda = 0, g.ldb = ldy, g.ldc = ldw;
     g.alpha = 1.f, g.beta = 0.f;
-    g.m_blocks = (int)avsi_ceil_div(Kc, 128), g.n_blocks = (int)avsi_ceil_div(Cout, BN);
+    const int bnt = Cout <= 32 ? 32 : (Cout <= 64 ? 64 : 128);
+    g.m_blocks = (int)avsi_ceil_div(Kc, 128), g.n_blocks = (int)avsi_ceil_div(Cout, bnt);
     g.k_split_len = (int)avsi_round_up(avsi_ceil_div(R, splits), 32);
     g.c_split_stride = (int64_t)Kc * ldw;
     g.n_group = g.n_blocks;
@@ -788,8 +789,13 @@ extern "C" int avsi_conv2d_wgrad_f32(const float* src0, int C0, int ld0, const f
     g.cH = H, g.cW = W, g.cC0 = C0, g.cld0 = ld0, g.cC1 = C1, g.cld1 = ld1, g.ck = k;
     const hipStream_t st = (hipStream_t)stream;
     avsi_clear_error();
-    hipLaunchKernelGGL((gemm_dma_kernel<true, false, 16, 3, true, 128>), dim3(g.m_blocks * g.n_blocks, 1, splits), dim3(256),
-                       (size_t)2 * 3 * 128 * 16 * 4, st, g);
+    const dim3 grid(g.m_blocks * g.n_blocks, 1, splits), block(256);
+    if (bnt == 32)
+        hipLaunchKernelGGL((gemm_dma_kernel<true, false, 16, 3, true, 32>), grid, block, (size_t)3 * (128 + 32) * 16 * 4, st, g);
+    else if (bnt == 64)
+        hipLaunchKernelGGL((gemm_dma_kernel<true, false, 16, 3, true, 64>), grid, block, (size_t)3 * (128 + 64) * 16 * 4, st, g);
+    else
+        hipLaunchKernelGGL((gemm_dma_kernel<true, false, 16, 3, true, 128>), grid, block, (size_t)3 * (128 + 128) * 16 * 4, st, g);
     const int rc = avsi_launch_status();
     if (rc != AVSI_OK) return rc;
     return avsi_sum_slabs_launch((const float*)workspace, (int64_t)Kc * ldw, splits, (int64_t)Kc * ldw, dw, 1.f, st);
