@@ -18,7 +18,7 @@ from glob import glob
 import numpy as np
 from scipy.io import wavfile
 
-from . import parallel
+from . import ops, parallel
 from .config_utils import check_trainconfiguration, load_configfile
 from .dataset_reader import DataManager, OutOfRangeError
 from .training import EMBEDDING_SIZE, build_model, unpack_batch, uses_embeddings
@@ -67,6 +67,7 @@ def infer(model_path, data_path_test, audio_path, out_file_prefix, norm=True, or
         model.feed(**feed)
         enhanced = model.enhanced_sources_oracle_phase if oracle_phase else model.enhanced_sources
         loss = float(model.loss)
+        ops.coop_check()
         enhanced = enhanced.cpu().numpy()
         for wav, sample_dir, seq_len in zip(enhanced, test_sample_path, test_length):
             out_dir = os.path.join(audio_path, sample_dir.decode(), 'enhanced')

@@ -217,6 +217,9 @@ class StackedBLSTMModel(object):
             self.sequence_lengths = np.asarray(
                 sequence_lengths.cpu() if isinstance(sequence_lengths, torch.Tensor) else sequence_lengths,
                 dtype=np.int64)
+            # on the device once per feed: a host-to-device copy issued later, behind the recurrent kernels
+            # of the stream, would block the host until they finish (pageable memory)
+            self._seq_dev = torch.as_tensor(self.sequence_lengths, device=self.device)
         self.target_sources = _as_device(target_sources, device=self.device)
         self.masks = _as_device(masks, device=self.device)
         self.video_features = _as_device(video_features, device=self.device)
@@ -320,9 +323,9 @@ class StackedBLSTMModel(object):
             x = hout
         c['rnn_out'] = x
         if not self.rows_per_wg and ops.coop_split(Bp):
-            ops.coop_check(self.device)      # small batches: the cooperative kernel's bounded waits held
+            ops.coop_poll(self.device)       # small batches: a bounded wait that gave up surfaces here, without a sync
         # prediction = sequence_mask * (rnn_out . W + b), stored batch-major [B, T, F]
-        seq = torch.as_tensor(self.sequence_lengths, device=self.device)
+        seq = self._seq_dev
         row_scale = self._buf('row_scale', (T, Bp), zero=True)
         row_scale[:, :B] = (torch.arange(T, device=self.device)[:, None] < seq[None, :]).to(torch.float32)
         pred = torch.empty((B, T, self.audio_feat_dim), dtype=torch.float32, device=self.device)
@@ -493,7 +496,7 @@ class StackedBLSTMModel(object):
             if li > 0:
                 ops.gemm(dz2, v.p('wx%d' % li), out=dh.view(M, 2 * HP), trans_b=True, m=M, n=2 * HP, k=2 * GP)
         if ops.coop_split(Bp):
-            ops.coop_check(self.device)
+            ops.coop_poll(self.device)
         grads = v.unpack_grads(gp, out=self._buf('grads', (lay.ref_size,)))
         c['grads'] = grads
         return grads

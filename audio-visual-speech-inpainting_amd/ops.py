@@ -58,7 +58,7 @@ def blstm_rec_fwd(xproj, whp, hout, reserve=None, rows_per_wg=0, split=None):
         _lib.check(L.avsi_blstm_rec_fwd_coop_f32(_lib.ptr(xproj), _lib.ptr(whp), _lib.ptr(hout), _lib.ptr(reserve), T, Bp,
                                                  split, _lib.ptr(ws), ws.numel() * 4, _lib.stream_ptr()),
                    "avsi_blstm_rec_fwd_coop_f32")
-        _COOP_STICKY[xproj.device.index].bitwise_or_(ws[:1])     # keeps a failure visible across later launches
+        _coop_after_launch(xproj.device, ws)
         return hout
     _lib.check(_lib.lib().avsi_blstm_rec_fwd_f32(_lib.ptr(xproj), _lib.ptr(whp), _lib.ptr(hout), _lib.ptr(reserve),
                                                  T, Bp, int(rows_per_wg), _lib.stream_ptr()),
@@ -66,7 +66,8 @@ def blstm_rec_fwd(xproj, whp, hout, reserve=None, rows_per_wg=0, split=None):
     return hout
 
 
-_COOP_WS, _COOP_STICKY = {}, {}
+_COOP_WS, _COOP_STICKY, _COOP_HOST = {}, {}, {}      # all keyed by (device index, stream)
+_COOP_MSG = "cooperative recurrent kernel timed out waiting for a peer workgroup; results are invalid"
 
 
 def _coop_ws(device, Bp):
@@ -78,8 +79,20 @@ def _coop_ws(device, Bp):
     if ws is None or ws.numel() * 4 < need:
         ws = torch.zeros((need + 3) // 4, dtype=torch.int32, device=device)
         _COOP_WS[key] = ws
-    _COOP_STICKY.setdefault(device.index, torch.zeros(1, dtype=torch.int32, device=device))
+    if key not in _COOP_STICKY:
+        _COOP_STICKY[key] = torch.zeros(1, dtype=torch.int32, device=device)
+        _COOP_HOST[key] = (torch.zeros(1, dtype=torch.int32).pin_memory(), torch.cuda.Event())
     return ws
+
+
+def _coop_after_launch(device, ws):
+    """Fold the launch's status word into the stream's sticky flag (so a failure stays visible across
+    later launches, which zero the workspace) and queue its asynchronous copy to pinned host memory."""
+    key = (device.index, _lib.stream_ptr().value)
+    _COOP_STICKY[key].bitwise_or_(ws[:1])
+    host, event = _COOP_HOST[key]
+    host.copy_(_COOP_STICKY[key], non_blocking=True)
+    event.record()
 
 
 def coop_split(Bp):
@@ -90,13 +103,23 @@ def coop_split(Bp):
     return 8 if Bp <= 512 else (4 if Bp <= 2048 else 0)      # 1024 < Bp <= 2048: two resident-sized launches
 
 
+def coop_poll(device=None):
+    """Non-blocking form of coop_check: raises if a failure has ALREADY been observed on the host
+    (the flag travels asynchronously behind every cooperative launch).  Never synchronises, so
+    independent small batches can be in flight on several streams."""
+    idx = torch.cuda.current_device() if device is None else torch.device(device).index
+    for (dev, _), (host, event) in _COOP_HOST.items():
+        if dev == idx and event.query() and int(host[0]) != 0:
+            raise _lib.AvsiError(_COOP_MSG)
+
+
 def coop_check(device=None):
     """Raise if a cooperative recurrent launch on `device` ever gave up waiting for its peer
     workgroups (its outputs are then invalid).  Synchronises with the device."""
     idx = torch.cuda.current_device() if device is None else torch.device(device).index
-    st = _COOP_STICKY.get(idx)
-    if st is not None and int(st.item()) != 0:
-        raise _lib.AvsiError("cooperative recurrent kernel timed out waiting for a peer workgroup; results are invalid")
+    flags = [st for (dev, _), st in _COOP_STICKY.items() if dev == idx]
+    if flags and int(torch.stack(flags).max().item()) != 0:
+        raise _lib.AvsiError(_COOP_MSG)
 
 
 _LOSS_WS = {}
@@ -210,7 +233,7 @@ def blstm_rec_bwd(dhout, reserve, whbt, dz, split=None):
         _lib.check(_lib.lib().avsi_blstm_rec_bwd_coop_f32(_lib.ptr(dhout), _lib.ptr(reserve), _lib.ptr(whbt), _lib.ptr(dz),
                                                           T, Bp, split, _lib.ptr(ws), ws.numel() * 4, _lib.stream_ptr()),
                    "avsi_blstm_rec_bwd_coop_f32")
-        _COOP_STICKY[dhout.device.index].bitwise_or_(ws[:1])
+        _coop_after_launch(dhout.device, ws)
         return dz
     _lib.check(_lib.lib().avsi_blstm_rec_bwd_f32(_lib.ptr(dhout), _lib.ptr(reserve), _lib.ptr(whbt), _lib.ptr(dz),
                                                  T, Bp, _lib.stream_ptr()), "avsi_blstm_rec_bwd_f32")

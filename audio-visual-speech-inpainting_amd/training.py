@@ -23,7 +23,7 @@ from time import time
 import numpy as np
 
 from . import models as net
-from . import parallel
+from . import ops, parallel
 from .config_utils import check_trainconfiguration, load_configfile
 from .dataset_reader import DataManager, OutOfRangeError
 
@@ -211,6 +211,7 @@ def train(config_file, checkpoint_format=None):
             tot_step += 1
             model.feed(**feed)
             loss, loss_fn, lr = float(model.loss), float(model.loss_func), model.learning_rate
+            ops.coop_check()                # the float() above synchronised; a cooperative-kernel timeout aborts here
             model.train_op
             if np.isnan(loss):
                 print('GOT INSTABILITY: loss is NaN. Leaving...')
