@@ -52,7 +52,7 @@ __global__ void frontend_tables_kernel(float* tab, int frame_len) {
 
 // NB = number of 32-sample column groups that can hold non-zero window taps = ceil(frame_len/32)
 template <int NB>
-__global__ __launch_bounds__(TPB) void frontend_kernel(const avsi_frontend_args a, const int tiles_per_utt,
+__global__ __launch_bounds__(TPB, 2) void frontend_kernel(const avsi_frontend_args a, const int tiles_per_utt,
                                                        const int n_tiles, const int seg_floats, const int step) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* s_wav = reinterpret_cast<float*>(smem);
@@ -65,16 +65,15 @@ __global__ __launch_bounds__(TPB) void frontend_kernel(const avsi_frontend_args 
     const int S = a.hop, N = a.num_samples, T = a.num_frames, F = a.num_bins;
     const float* __restrict__ tab = a.table;
 
-    // ---- per-lane constants of the FFT phase
-    float2 win[NB];
-#pragma unroll
-    for (int b = 0; b < NB; ++b) win[b] = *reinterpret_cast<const float2*>(tab + TAB_WIN + 2 * ln + 32 * b);
-    cf tw[16];
-#pragma unroll
-    for (int k2 = 1; k2 < 16; ++k2) {
-        const float2 w = *reinterpret_cast<const float2*>(tab + TAB_TW256 + 2 * ((ln * k2) & 255));
-        tw[k2] = {w.x, w.y};
+    // ---- per-lane constants of the FFT phase live in LDS ([index][lane], conflict-free float2 reads):
+    //      as registers they were 54 VGPRs of a kernel that needed 317 and therefore ran one wave per SIMD
+    __shared__ float2 s_win[16][16], s_tw[16][16];
+    {
+        const int i = tid >> 4, l = tid & 15;     // 256 threads = 16 x 16 entries each
+        s_win[i][l] = i < NB ? *reinterpret_cast<const float2*>(tab + TAB_WIN + 2 * l + 32 * i) : make_float2(0.f, 0.f);
+        s_tw[i][l] = *reinterpret_cast<const float2*>(tab + TAB_TW256 + 2 * ((l * i) & 255));
     }
+    __syncthreads();
     // ---- epilogue mapping: thread <-> 4 consecutive bins (kq) x 4 frames (its wave's quarter of the
     //      tile): per-bin twiddle / mean / 1/std stay in registers, every global access is 16 B per lane
     const int kq = tid & 63, fg = tid >> 6;
@@ -164,7 +163,8 @@ __global__ __launch_bounds__(TPB) void frontend_kernel(const avsi_frontend_args 
             for (int n2 = 0; n2 < 16; ++n2) {
                 if (n2 < NB) {
                     const float2 x = *reinterpret_cast<const float2*>(fr + 32 * n2);
-                    v[n2] = {x.x * win[n2].x, x.y * win[n2].y};
+                    const float2 wn = s_win[n2][ln];
+                    v[n2] = {x.x * wn.x, x.y * wn.y};
                 } else {
                     v[n2] = {0.f, 0.f};
                 }
@@ -174,7 +174,10 @@ __global__ __launch_bounds__(TPB) void frontend_kernel(const avsi_frontend_args 
         cf* zf = s_z + f * ZSTRIDE;
         zf[ln] = v[pos16(0)];
 #pragma unroll
-        for (int k2 = 1; k2 < 16; ++k2) zf[k2 * 17 + ln] = cmul(v[pos16(k2)], tw[k2]);
+        for (int k2 = 1; k2 < 16; ++k2) {
+            const float2 w = s_tw[k2][ln];
+            zf[k2 * 17 + ln] = cmul(v[pos16(k2)], cf{w.x, w.y});
+        }
         // ---- 3. transposition: lane k2 = ln gathers its 16 n1 values.  A frame lives in ONE wave
         //         (16 consecutive lanes) and a wave's LDS accesses execute in order, so no
         //         workgroup barrier is needed here -- only the compiler must not reorder.
@@ -339,7 +342,8 @@ extern "C" int avsi_frontend_f32(const avsi_frontend_args* args, void* stream) {
     const int64_t n_tiles64 = (int64_t)a.batch * tiles_per_utt;
     if (n_tiles64 > INT32_MAX) return AVSI_ERR_UNSUPPORTED;
     const int n_tiles = (int)n_tiles64;
-    const int wg_per_cu = (int)(160 * 1024 / lds) > 4 ? 4 : (int)(160 * 1024 / lds);
+    // resident workgroups per CU: two by registers (256 VGPRs at 256 threads), fewer if the LDS tile is large
+    const int wg_per_cu = (int)(156 * 1024 / lds) > 2 ? 2 : ((int)(156 * 1024 / lds) < 1 ? 1 : (int)(156 * 1024 / lds));
     const int grid = n_tiles < AVSI_NUM_CU * wg_per_cu ? n_tiles : AVSI_NUM_CU * wg_per_cu;
     const hipStream_t st = (hipStream_t)stream;
     avsi_clear_error();
