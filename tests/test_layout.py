@@ -130,3 +130,49 @@ def test_projection_padding():
     np.testing.assert_array_equal(pw[:250, :257], p['proj']['weights'][:250])
     np.testing.assert_array_equal(pw[256:506, :257], p['proj']['weights'][250:])
     assert np.all(pw[250:256] == 0) and np.all(pw[506:] == 0) and np.all(pw[:, 257:] == 0)
+
+
+def test_side_input_and_mlp_layouts():
+    """The variants' layouts: side rows of the TF kernel are packed apart ('we'), the recurrent rows move
+    behind them, the speaker-embedding MLP gets dense entries; every parameter has exactly one packed copy
+    (two for the recurrent kernels) and one gradient slot."""
+    E, W = 24, 40
+    for side_layer in (0, 1, 2):
+        lay = ParamLayout(257, (250, 250, 250), 257, side=(side_layer, E), mlp=W, mlp_in_pitch=272)
+        base = ParamLayout(257)
+        assert lay.ref_size == base.ref_size + 2 * E * 1000 + (2 * 257 * W + W) + 2 * (W * W + W)
+        flat = np.arange(1, lay.ref_size + 1, dtype=np.float64)
+        packed = np.concatenate([flat, [0.0]])[lay.pack_index]
+        rec = 3 * 2 * 250 * 1000
+        assert np.count_nonzero(packed) == lay.ref_size + rec
+        # side rows: kernel rows [D, D + E) of the side layer, both directions, land in 'we'
+        D = 257 if side_layer == 0 else 500
+        we = lay.packed_view(packed, 'we')
+        kf = lay.ref_view(flat, 'cell_%d/fw/kernel' % side_layer)
+        kb = lay.ref_view(flat, 'cell_%d/bw/kernel' % side_layer)
+        assert kf.shape == (D + E + 250, 1000)
+        g, u = 3, 77
+        assert we[5, packed_gate_col(0, g, u)] == kf[D + 5, g * 250 + u]
+        assert we[E - 1, packed_gate_col(1, g, u)] == kb[D + E - 1, g * 250 + u]
+        assert np.all(we[E:] == 0)
+        # recurrent rows start behind the side rows: compare against the no-side layout's packed Wh
+        p0 = O.init_params(3, 257)
+        fl0 = base.flatten_oracle_params(p0)
+        wh0 = np.concatenate([fl0, [0.0]])[base.pack_index]
+        k_with_side = np.insert(p0['layers'][side_layer]['fw']['kernel'], [D] * E, 7.0, axis=0)
+        p1 = {'layers': [dict(l) for l in p0['layers']], 'proj': p0['proj'],
+              'mlp': {'weights_1': np.ones((514, W)), 'biases_1': np.ones(W), 'weights_2': np.ones((W, W)), 'biases_2': np.ones(W),
+                      'weights_3': np.ones((W, W)), 'biases_3': np.ones(W)}}
+        p1['layers'][side_layer] = {'fw': {'kernel': k_with_side, 'bias': p0['layers'][side_layer]['fw']['bias']},
+                                    'bw': {'kernel': np.insert(p0['layers'][side_layer]['bw']['kernel'], [D] * E, 7.0, axis=0),
+                                           'bias': p0['layers'][side_layer]['bw']['bias']}}
+        pk1 = np.concatenate([lay.flatten_oracle_params(p1), [0.0]])[lay.pack_index]
+        for name in ('wh%d' % side_layer, 'whb%d' % side_layer, 'wx%d' % side_layer):
+            np.testing.assert_array_equal(lay.packed_view(pk1, name), base.packed_view(wh0, name))
+        # MLP halves: weights_1 rows [0, F) -> mw1a, [F, 2F) -> mw1b, padded rows zero
+        w1 = lay.ref_view(flat, 'speaker_embedding/weights_1')
+        assert np.array_equal(lay.packed_view(packed, 'mw1a')[:257], w1[:257]) and np.all(lay.packed_view(packed, 'mw1a')[257:] == 0)
+        assert np.array_equal(lay.packed_view(packed, 'mw1b')[:257], w1[257:])
+        # gradient slots: a bijection
+        assert len(np.unique(lay.grad_index)) == lay.ref_size and lay.grad_index.max() < lay.gpacked_size
+        assert lay.signature() == [257, 250, 3, 257, side_layer, E, -W]
