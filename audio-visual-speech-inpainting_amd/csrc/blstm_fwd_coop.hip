@@ -18,7 +18,10 @@
 //   - the S workgroups exchange h_t through hout itself: device-coherent (sc1) stores, one atomic
 //     increment of the group's step counter once they have completed, and the consumers spin on
 //     that counter before they read hout[t] with device-coherent loads.  Members of a group are
-//     placed S blocks of 8 apart so that they share an XCD.  The spin is bounded: a group that does not see its peers within ~2^22 polls marks
+//     placed S blocks of 8 apart (round-robin dispatch then tends to put them on one XCD), but that
+//     is a locality hint only: nothing is assumed about placement -- an experiment with L2-scope
+//     (sc0) atomics between the members never saw its peers' increments, so every exchange uses
+//     device scope.  The spin is bounded: a group that does not see its peers within ~2^22 polls marks
 //     the status word, stops waiting and runs to the end, so the grid always drains.
 // The launch needs all S members of a group resident together; groups are contiguous windows of
 // 8 S block ids and the kernel uses one workgroup per CU, so in-order dispatch guarantees that for
