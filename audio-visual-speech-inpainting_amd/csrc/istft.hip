@@ -59,73 +59,103 @@ __global__ void istft_tables_kernel(float* tab, int frame_len, int hop) {
 __global__ __launch_bounds__(TPB) void istft_kernel(const avsi_istft_args a, const int tiles_per_utt, const int n_tiles,
                                                     const int n_hops, const int step) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    // s_x (spectrum tile) and s_z (FFT transposition scratch) share storage: s_x is dead once every lane has
+    // gathered its 16 inputs of the first FFT stage (barrier below).  With frames kept at their true length this
+    // is 59 KB per workgroup instead of 100 KB: two workgroups per CU.
     cf* s_x = reinterpret_cast<cf*>(smem);                             // [FR][XS]   spectrum tile
-    cf* s_z = s_x + FR * XS;                                           // [FR][ZSTRIDE] FFT scratch
-    float* s_f = reinterpret_cast<float*>(s_z + FR * ZSTRIDE);         // [FR][512]  windowed frames
+    cf* s_z = s_x;                                                     // [FR][ZSTRIDE] FFT scratch (aliases s_x)
+    float* s_f = reinterpret_cast<float*>(s_x + FR * ZSTRIDE);         // [FR][fs]   windowed frames
+    __shared__ float2 s_tw[16][16];                                    // per-lane twiddles of the 16 x 16 FFT: [k2][lane]
 
     const int tid = threadIdx.x, f = tid >> 4, ln = tid & 15;
     const int S = a.hop, L = a.frame_len, T = a.num_frames, F = a.num_bins;
+    const int fs = (L + 3) & ~3;                                       // pitch of a windowed frame in LDS
     const float* __restrict__ tab = a.table;
-    cf tw[16];
-#pragma unroll
-    for (int k2 = 1; k2 < 16; ++k2) {
-        const float2 w = *reinterpret_cast<const float2*>(tab + TAB_TW256 + 2 * ((ln * k2) & 255));
-        tw[k2] = {w.x, w.y};
-    }
+    s_tw[tid >> 4][tid & 15] = *reinterpret_cast<const float2*>(tab + TAB_TW256 + 2 * (((tid & 15) * (tid >> 4)) & 255));
     const bool have_norm = a.mean != nullptr;
+
+    // one spectrum element from the raw loaded values (r0 .. r3 as loaded by `fetch` below)
+    auto make_x = [&](int kk, float r0, float r1, float r2, float r3, float mean_k, float std_k) -> cf {
+        cf x{0.f, 0.f};
+        if (a.mode == 0) {          // complex spectrogram, interleaved
+            x = {r0, r1};
+        } else if (a.mode == 1) {   // magnitude + phase planes
+            float sn, cs;
+            __sincosf(r1, &sn, &cs);
+            x = {r0 * cs, r0 * sn};
+        } else {                    // fused enhanced_sources: r0 = prediction, (r1, r2) = target STFT, r3 = mask
+            float m = r0;
+            if (have_norm) m = m * std_k + mean_k;
+            m = __expf(m);
+            if (a.in2) {
+                // models.py:186 casts the mask to complex64 and takes a FULL complex product
+                // (a + bj)(m + 0j) = (a m - b 0) + (a 0 + b m) j; in a gap the signed zeros
+                // decide tf.angle = atan2: (-0, +0) -> pi, everything else -> 0.  Kept as is.
+                const float zero = 0.f;
+                const float pr = r1 * r3 - r2 * zero, pi = r1 * zero + r2 * r3;
+                const float r = sqrtf(pr * pr + pi * pi);
+                if (r > 0.f)
+                    x = {m * (pr / r), m * (pi / r)};
+                else
+                    x = {(__builtin_signbitf(pr) && !__builtin_signbitf(pi)) ? -m : m, 0.f};
+            } else {
+                const float r = sqrtf(r1 * r1 + r2 * r2);
+                if (r > 0.f)
+                    x = {m * (r1 / r), m * (r2 / r)};
+                else
+                    x = {__builtin_signbitf(r1) && !__builtin_signbitf(r2) ? -m : m, 0.f};  // atan2(+0,-0) = pi
+            }
+        }
+        if (kk == 0 || kk == 256) x.i = 0.f;  // irfft ignores the imaginary part of DC / Nyquist
+        return x;
+    };
+    auto fetch = [&](int b, int t, int k, float& r0, float& r1, float& r2, float& r3) {
+        const int64_t o = (int64_t)b * a.in_stride_b + (int64_t)t * a.in_stride_t;
+        if (a.mode == 0) {
+            r0 = a.in0[o + 2 * k], r1 = a.in0[o + 2 * k + 1];
+        } else if (a.mode == 1) {
+            r0 = a.in0[o + k], r1 = a.in1[o + k];
+        } else {
+            r0 = a.in0[o + k];
+            const int64_t os = (int64_t)b * a.in1_stride_b + (int64_t)t * a.in1_stride_t;
+            r1 = a.in1[os + 2 * k], r2 = a.in1[os + 2 * k + 1];
+            if (a.in2) r3 = a.in2[(int64_t)b * a.in2_stride_b + (int64_t)t * a.in2_stride_t + k];
+        }
+    };
+    __syncthreads();
 
     for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
         const int b = tile / tiles_per_utt;
         const int h0 = (tile - b * tiles_per_utt) * (FR - 1);  // first output hop of the tile
         const int t0 = h0 - 1;                                  // first frame (halo)
 
-        // ---- 1. spectrum tile -> LDS (thread <-> bin, coalesced rows), assembling X on the fly
-        for (int ff = 0; ff < FR; ++ff) {
-            const int t = t0 + ff;
-            const bool live = t >= 0 && t < T;
-            for (int kk = tid; kk < 257; kk += TPB) {
-                // `step` = 512 / fft length: a 256-point spectrum sits on the even bins of the 512 grid
-                // (the odd bins are zero), which makes the 512-point inverse 256-periodic and half as large
-                const int k = kk / step;
-                cf x{0.f, 0.f};
-                if (live && (kk % step == 0) && k < F) {
-                    const int64_t o = (int64_t)b * a.in_stride_b + (int64_t)t * a.in_stride_t;
-                    if (a.mode == 0) {  // complex spectrogram, interleaved
-                        x = {a.in0[o + 2 * k], a.in0[o + 2 * k + 1]};
-                    } else if (a.mode == 1) {  // magnitude + phase planes
-                        float sn, cs;
-                        __sincosf(a.in1[o + k], &sn, &cs);
-                        const float m = a.in0[o + k];
-                        x = {m * cs, m * sn};
-                    } else {  // fused enhanced_sources: in0 = prediction, in1 = target STFT (complex), in2 = mask
-                        float m = a.in0[o + k];
-                        if (have_norm) m = m * a.stdev[k] + a.mean[k];
-                        m = __expf(m);
-                        const int64_t os = (int64_t)b * a.in1_stride_b + (int64_t)t * a.in1_stride_t;
-                        const float sr = a.in1[os + 2 * k], si = a.in1[os + 2 * k + 1];
-                        if (a.in2) {
-                            // models.py:186 casts the mask to complex64 and takes a FULL complex product
-                            // (a + bj)(m + 0j) = (a m - b 0) + (a 0 + b m) j; in a gap the signed zeros
-                            // decide tf.angle = atan2: (-0, +0) -> pi, everything else -> 0.  Kept as is.
-                            const float mk = a.in2[(int64_t)b * a.in2_stride_b + (int64_t)t * a.in2_stride_t + k];
-                            const float zero = 0.f;
-                            const float pr = sr * mk - si * zero, pi = sr * zero + si * mk;
-                            const float r = sqrtf(pr * pr + pi * pi);
-                            if (r > 0.f)
-                                x = {m * (pr / r), m * (pi / r)};
-                            else
-                                x = {(__builtin_signbitf(pr) && !__builtin_signbitf(pi)) ? -m : m, 0.f};
-                        } else {
-                            const float r = sqrtf(sr * sr + si * si);
-                            if (r > 0.f)
-                                x = {m * (sr / r), m * (si / r)};
-                            else
-                                x = {__builtin_signbitf(sr) && !__builtin_signbitf(si) ? -m : m, 0.f};  // atan2(+0,-0) = pi
-                        }
-                    }
-                }
-                if (kk == 0 || kk == 256) x.i = 0.f;  // irfft ignores the imaginary part of DC / Nyquist
-                s_x[ff * XS + kk] = x;
+        // ---- 1. spectrum tile -> LDS (thread <-> bin, coalesced rows), assembling X on the fly.  All 16 frames'
+        //         loads are issued before anything is computed (they used to be consumed frame by frame, one
+        //         memory latency per frame); `step` = 512 / fft length: a 256-point spectrum sits on the even
+        //         bins of the 512 grid (the odd bins are zero), which makes the 512-point inverse 256-periodic.
+        {
+            const int kk = tid, k = kk / step;
+            const bool kok = (kk % step == 0) && k < F;
+            const float mean_k = (have_norm && kok) ? a.mean[k] : 0.f, std_k = (have_norm && kok) ? a.stdev[k] : 1.f;
+            float r0[FR], r1[FR], r2[FR], r3[FR];
+#pragma unroll
+            for (int ff = 0; ff < FR; ++ff) {
+                const int t = t0 + ff;
+                r0[ff] = r1[ff] = r2[ff] = 0.f, r3[ff] = 1.f;
+                if (kok && t >= 0 && t < T) fetch(b, t, k, r0[ff], r1[ff], r2[ff], r3[ff]);
+            }
+#pragma unroll
+            for (int ff = 0; ff < FR; ++ff) {
+                const int t = t0 + ff;
+                s_x[ff * XS + kk] = (kok && t >= 0 && t < T) ? make_x(kk, r0[ff], r1[ff], r2[ff], r3[ff], mean_k, std_k) : cf{0.f, 0.f};
+            }
+            if (tid < FR) {     // the Nyquist column: one frame per thread
+                const int t = t0 + tid, kn = 256 / step;
+                const bool ok = (256 % step == 0) && kn < F && t >= 0 && t < T;
+                float q0 = 0.f, q1 = 0.f, q2 = 0.f, q3 = 1.f;
+                if (ok) fetch(b, t, kn, q0, q1, q2, q3);
+                s_x[tid * XS + 256] = ok ? make_x(256, q0, q1, q2, q3, have_norm ? a.mean[kn] : 0.f, have_norm ? a.stdev[kn] : 1.f)
+                                         : cf{0.f, 0.f};
             }
         }
         __syncthreads();
@@ -147,10 +177,14 @@ __global__ __launch_bounds__(TPB) void istft_kernel(const avsi_istft_args a, con
             }
         }
         fft16(v);
+        __syncthreads();        // every lane has read its s_x inputs: the storage becomes s_z
         cf* zf = s_z + f * ZSTRIDE;
         zf[ln] = v[pos16(0)];
 #pragma unroll
-        for (int n2 = 1; n2 < 16; ++n2) zf[n2 * 17 + ln] = cmul(v[pos16(n2)], tw[n2]);
+        for (int n2 = 1; n2 < 16; ++n2) {
+            const float2 w = s_tw[n2][ln];
+            zf[n2 * 17 + ln] = cmul(v[pos16(n2)], cf{w.x, w.y});
+        }
         __syncthreads();
 #pragma unroll
         for (int k1 = 0; k1 < 16; ++k1) v[k1] = zf[ln * 17 + k1];
@@ -158,14 +192,14 @@ __global__ __launch_bounds__(TPB) void istft_kernel(const avsi_istft_args a, con
         fft16(v);
         // ---- 3. z[16 n1 + ln] = conj(.) / 256 -> x[2n], x[2n+1]; synthesis window; store frame
         {
-            float* ffr = s_f + f * 512;
+            float* ffr = s_f + f * fs;
 #pragma unroll
             for (int n1 = 0; n1 < 16; ++n1) {
                 const int n = 16 * n1 + ln;
                 const cf z = v[pos16(n1)];
                 const float2 w = *reinterpret_cast<const float2*>(tab + TAB_WIN + 2 * n);
                 const float sc = (float)step * (1.f / 256.f);
-                *reinterpret_cast<float2*>(ffr + 2 * n) = make_float2(z.r * sc * w.x, -z.i * sc * w.y);
+                if (2 * n < L) *reinterpret_cast<float2*>(ffr + 2 * n) = make_float2(z.r * sc * w.x, -z.i * sc * w.y);
             }
         }
         __syncthreads();
@@ -183,7 +217,7 @@ __global__ __launch_bounds__(TPB) void istft_kernel(const avsi_istft_args a, con
             for (int c = 0; c < cover; ++c) {
                 const int ff = hop_i + 1 - c;  // frame index inside the tile (frame t = h - c)
                 const int off = r + c * S;
-                if (ff >= 0 && off < L) acc += s_f[ff * 512 + off];
+                if (ff >= 0 && off < L) acc += s_f[ff * fs + off];
             }
             a.out[(int64_t)b * a.out_stride_b + n] = acc;
         }
@@ -225,7 +259,7 @@ extern "C" int avsi_istft_f32(const avsi_istft_args* args, void* stream) {
     const int tiles_per_utt = (int)avsi_ceil_div(n_hops, FR - 1);
     const int64_t n_tiles64 = (int64_t)a.batch * tiles_per_utt;
     if (n_tiles64 > INT32_MAX) return AVSI_ERR_UNSUPPORTED;
-    const size_t lds = (size_t)FR * XS * 8 + (size_t)FR * ZSTRIDE * 8 + (size_t)FR * 512 * 4;
+    const size_t lds = (size_t)FR * ZSTRIDE * 8 + (size_t)FR * ((a.frame_len + 3) & ~3) * 4;     // ZSTRIDE >= XS: shared storage
     const int n_tiles = (int)n_tiles64;
     const int grid = n_tiles < AVSI_NUM_CU * 2 ? n_tiles : AVSI_NUM_CU * 2;
     avsi_clear_error();
