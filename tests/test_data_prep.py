@@ -173,3 +173,25 @@ def test_cli_dataset_generator(tmp_path, capsys):
               '-al', '3000', '-i', '2', '-cm', '800', '-cs', '100'])
     assert len(os.listdir(str(tmp_path / 'out'))) == 2
     assert 'Dataset generation completed.' in capsys.readouterr().out
+
+
+def test_intrusion_mask_properties_hypothesis():
+    """Property-based form (hypothesis): for any seed, frame count and coverage request, gaps are whole
+    frames, the coverage respects the 0.8 cap and the requested minimum, and a single gap is contiguous."""
+    hyp = pytest.importorskip('hypothesis')
+    from hypothesis import given, settings, strategies as st
+
+    @settings(max_examples=150, deadline=None)
+    @given(seed=st.integers(0, 2 ** 31 - 1), spec_len=st.integers(40, 400), mean=st.floats(0.0, 1.5), std=st.floats(0.0, 0.5))
+    def check(seed, spec_len, mean, std):
+        random.seed(seed)
+        mask, cov, n = dg.get_intrusions_mask(7, spec_len, mean, std, 1)
+        assert mask.shape == (spec_len, 7) and n == 1
+        rows = mask[:, 0]
+        assert np.all(mask == rows[:, None]) and set(np.unique(rows)) <= {0.0, 1.0}
+        masked = int((rows == 0).sum())
+        # the 0.8 cap applies to the request; the realised coverage is that rounded to whole frames
+        assert masked == int(np.around(spec_len * cov)) and (3 - 0.5) / spec_len <= cov <= 0.8 + 0.5 / spec_len
+        edges = np.flatnonzero(np.diff(np.concatenate([[1.0], rows, [1.0]])))
+        assert len(edges) == 2
+    check()
