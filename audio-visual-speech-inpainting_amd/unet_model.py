@@ -158,9 +158,26 @@ class UNetFConvModel(object):
     def feed(self, sequence_lengths=None, target_sources=None, masks=None, audio_feat_mean=None, audio_feat_std=None,
              **_unused):
         self._cache = {}
+        graph = getattr(self, '_graph', None)
         if sequence_lengths is not None:
-            self.sequence_lengths = np.asarray(
-                sequence_lengths.cpu() if isinstance(sequence_lengths, torch.Tensor) else sequence_lengths, dtype=np.int64)
+            lens = np.asarray(sequence_lengths.cpu() if isinstance(sequence_lengths, torch.Tensor) else sequence_lengths,
+                              dtype=np.int64)
+            if graph is not None and (lens.shape != self.sequence_lengths.shape or int(lens.max()) != int(self.sequence_lengths.max())):
+                raise _lib.AvsiError("the captured graph was built for another batch / frame count: call release_graph() first")
+            self.sequence_lengths = lens
+            if graph is not None:
+                self._seq_dev.copy_(torch.as_tensor(lens))
+            else:
+                self._seq_dev = torch.as_tensor(lens, device=self.device)
+        if graph is not None:
+            # replay mode: new data goes INTO the buffers the graph reads; results are those of the replay
+            if target_sources is not None:
+                self.target_sources.copy_(self._as_device(target_sources, device=self.device))
+            if masks is not None:
+                self.masks.copy_(self._as_device(masks, device=self.device))
+            graph.replay()
+            self._cache = dict(self._graph_cache)
+            return
         self.target_sources = self._as_device(target_sources, device=self.device)
         self.masks = self._as_device(masks, device=self.device)
         if audio_feat_mean is not None:
@@ -170,6 +187,39 @@ class UNetFConvModel(object):
 
     def build_graph(self, var_scope=''):
         self.var_scope = var_scope
+
+    # ------------------------------------------------------------------ HIP graph of the inference step
+    def capture_graph(self):
+        """Capture front end -> 13 layers -> prediction -> loss (about 70 launches) into one HIP graph
+        (torch.cuda.CUDAGraph).  At the reference's batch of 32 a step is launch-bound -- the kernels
+        take about half of the 1.5 ms -- so replaying one graph per feed() instead of issuing every
+        launch from Python is what is left to gain there.  After capture, feed() copies the new clips
+        into the captured input buffers and replays; batch size and frame count are fixed until
+        release_graph().  Inference only (training updates the packed weights between steps, which a
+        graph would have to re-capture)."""
+        if self.is_training:
+            raise _lib.AvsiError("capture_graph() is for inference models")
+        if self.target_sources is None or self.masks is None or self.sequence_lengths is None:
+            raise _lib.AvsiError("feed() the model once before capture_graph()")
+        self.release_graph()
+        self.target_sources, self.masks = self.target_sources.clone(), self.masks.clone()
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):               # warm-up: every workspace and table exists before capture
+            for _ in range(2):
+                self._cache = {}
+                self._loss()
+        torch.cuda.current_stream().wait_stream(side)
+        self._cache = {}
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            self._loss()
+        self._graph, self._graph_cache = graph, dict(self._cache)
+        graph.replay()
+        return graph
+
+    def release_graph(self):
+        self._graph, self._graph_cache = None, None
 
     def _buf(self, name, shape, zero=True):
         key = (name, tuple(shape))
@@ -260,7 +310,7 @@ class UNetFConvModel(object):
             h = self._conv_fwd(name, k, co, True, 2, skip, cs, h, ch, B, Hs, Ws)
             H, W, ch = Hs, Ws, co
         logits = self._conv_fwd('out', 1, 1, False, 0, h, 1, None, 0, B, T, F)
-        seq = torch.as_tensor(self.sequence_lengths, device=self.device)
+        seq = self._seq_dev
         rowmask = (torch.arange(T, device=self.device)[None, :] < seq[:, None]).to(torch.float32)
         c['rowmask'] = rowmask
         c['inference'] = logits[:, 0].reshape(B, T, F)

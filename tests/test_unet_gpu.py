@@ -237,3 +237,34 @@ def test_implicit_filter_gradient_matches_im2col_gemm(c0, c1, k, cout, B, H, W, 
     ops.conv2d_wgrad(src0, c0, src1, c1, B, H, W, k, dy, cout, got, splits)
     scale = want.abs().max().item()
     np.testing.assert_allclose(got[:, :cout].cpu().numpy(), want[:, :cout].cpu().numpy(), rtol=1e-4, atol=1e-5 * scale)
+
+
+def test_captured_hip_graph_replays_the_inference_step(mods):
+    """capture_graph(): one HIP graph per feed() instead of ~70 launches; same numbers as the eager path."""
+    import torch
+    from avsi_amd import _lib, models
+    B, N = 4, 16384
+    cfg = dict(audio_feat_dim=128, audio_len=N, net_dim=[250, 250, 250], optimizer_type='adam', starter_learning_rate=1e-3,
+               lr_updating_steps=10000, lr_decay=1.0, batch_size=B, l2=0.0)
+    g = torch.Generator(device='cuda')
+    g.manual_seed(3)
+    wavs = [torch.round(torch.randn(B, N, generator=g, device='cuda') * 3000) for _ in range(3)]
+    masks = torch.ones(B, 128, 128, device='cuda')
+    masks[:, 30:55] = 0
+    seq = np.full(B, 128)
+    mean, std = torch.zeros(128, device='cuda') + 6, torch.ones(128, device='cuda') * 2
+    eager = models.UNetFConvModel(seq, wavs[0], masks, mean, std, 0.0, cfg, is_training=False, seed=2)
+    want = []
+    for w in wavs:
+        eager.feed(seq, w, masks)
+        want.append((eager.prediction.clone(), float(eager.loss_func)))
+    m = models.UNetFConvModel(seq, wavs[0], masks, mean, std, 0.0, cfg, is_training=False, variables=eager.variables)
+    m.capture_graph()
+    for w, (pred, loss) in zip(wavs[::-1], want[::-1]):          # different order: results follow the fed data
+        m.feed(seq, w, masks)
+        assert torch.equal(m.prediction, pred) and float(m.loss_func) == loss
+    with pytest.raises(_lib.AvsiError):
+        m.feed(np.full(B - 1, 128), wavs[0][:B - 1], masks[:B - 1])
+    m.release_graph()
+    m.feed(np.full(B - 1, 128), wavs[0][:B - 1], masks[:B - 1])
+    assert m.prediction.shape == (B - 1, 128, 128)
