@@ -1,0 +1,44 @@
+"""bench.py prints ONE JSON line with the fields the driver reads (small batches here; the defaults are the
+BASELINE configuration)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(*args):
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *args], capture_output=True, text=True, timeout=600,
+                         cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+def test_default_mode_line():
+    d = _run("--batch", "256", "--steps", "2", "--warmup", "1", "--cpu-sample", "32")
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 2 and d["warmup"] == 1 and d["higher_is_better"] is True
+    assert d["scaling"] == "weak" and d["vs_baseline"] is None and d["dtype"] == "f32" and d["data"] == "synthetic"
+    assert "workload" in d["config"] and "model" not in d["config"]
+    r = d["roofline"]
+    assert r["bound"] in ("hbm", "mfma") and r["unit"] in ("GB/s", "TFLOP/s") and 0 < r["frac"] < 1
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9 and r["avg_launch_ms"] > 0
+    c = d["cpu_baseline"]
+    assert c["kind"] == "port" and c["value"] > 0 and c["cores"] >= 1 and "sample" in c
+    assert d["logmel_rms_vs_cpu_oracle"] < 1e-3                  # the BASELINE parity bar, checked in the bench itself
+    assert abs(d["value"] - 256 * 2 / (d["ms_per_step"] * 2e-3)) < 1e-6 * d["value"]
+
+
+def test_train_and_unet_modes():
+    t = _run("--mode", "train", "--batch", "64", "--steps", "1", "--warmup", "1")
+    assert t["unit"] == "utterances/s" and t["value"] > 0 and "blstm_rec_bwd" in t["kernel_ms_per_step"]
+    u = _run("--mode", "unet", "--batch", "64", "--steps", "2", "--warmup", "1")
+    assert u["unit"] == "clips/s" and u["value"] > 0 and u["vs_baseline"] is None
