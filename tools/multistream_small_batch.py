@@ -1,3 +1,4 @@
+"""Independent small batches on several streams (serving pattern): python tools/multistream_small_batch.py [streams]"""
 import sys, time
 sys.path.insert(0, '/root/repo')
 import numpy as np, torch
@@ -23,7 +24,7 @@ def round_():
     for s, m in zip(streams, ms):
         with torch.cuda.stream(s):
             m.feed(seq, wav, masks)
-            outs.append(m._forward_async() if hasattr(m, '_forward_async') else m.prediction)
+            outs.append(m.prediction)
     return outs
 for _ in range(2): round_()
 torch.cuda.synchronize(); t0 = time.perf_counter()
