@@ -9,7 +9,7 @@ from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int32, c_int6
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libavsi_hip.so")
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 AVSI_OK = 0
 
@@ -123,6 +123,11 @@ PROTOTYPES = {
                                                c_void_p]),
     "avsi_l1_loss_blend_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int64, c_void_p, c_void_p,
                                        c_void_p, c_size_t, c_void_p]),
+    "avsi_ctc_loss_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
+    "avsi_ctc_loss_f32": (c_int, [c_void_p, c_int64, c_int64, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p,
+                                  c_int, c_float, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "avsi_ctc_beam_search_host_f32": (c_int, [c_void_p, c_int64, c_int64, c_int, c_int, c_int, c_void_p, c_int, c_int,
+                                              c_void_p, c_int, c_void_p, c_void_p]),
 }
 
 _lib = None

@@ -5,6 +5,8 @@ current stream to libavsi_hip.so, and returns the output tensor."""
 import ctypes
 import os
 
+import numpy as np
+
 import torch
 
 from . import _lib
@@ -176,6 +178,73 @@ def l1_loss_blend(target, pred_inout, mask, row_scale=None, want_grad=False):
                                         row_len, n, _lib.ptr(out4), _lib.ptr(dlog), _lib.ptr(ws), ws.numel() * 4,
                                         _lib.stream_ptr()), "avsi_l1_loss_blend_f32")
     return out4[:3], dlog
+
+
+_CTC_WS = {}
+
+
+def ctc_loss(logits, labels, labels_lengths, sequence_lengths, grad_scale=1.0, want_grad=False, max_label_len=None):
+    """tf.nn.ctc_loss on un-normalised ``logits`` [B, T, C] (last dim contiguous; blank = C - 1):
+    returns (loss [B], grad or None) with grad = grad_scale * d loss[b] / d logits (avsi_ctc_loss_f32).
+    ``labels`` int32 [B, Lp], ``labels_lengths`` / ``sequence_lengths`` int32 [B], all on the device."""
+    _lib.require_cuda(logits, labels, labels_lengths, sequence_lengths)
+    L = _lib.lib()
+    if logits.dtype != torch.float32 or logits.dim() != 3 or logits.stride(2) != 1:
+        raise _lib.AvsiError("ctc_loss: logits must be float32 [B, T, C] with contiguous classes")
+    for x in (labels, labels_lengths, sequence_lengths):
+        if x.dtype != torch.int32 or not x.is_contiguous():
+            raise _lib.AvsiError("ctc_loss: labels and lengths must be contiguous int32")
+    B, T, C = logits.shape
+    Lp = labels.shape[1]
+    Lmax = Lp if max_label_len is None else int(max_label_len)
+    need = L.avsi_ctc_loss_workspace_bytes(B, T, Lmax)
+    if not need:
+        raise _lib.AvsiError("ctc_loss: labellings longer than 127 are not supported")
+    key = (logits.device.index, _lib.stream_ptr().value)
+    ws = _CTC_WS.get(key)
+    if ws is None or ws.numel() * 4 < need:
+        ws = torch.empty((need + 3) // 4, dtype=torch.float32, device=logits.device)
+        _CTC_WS[key] = ws
+    loss = torch.empty(B, dtype=torch.float32, device=logits.device)
+    grad = torch.empty_strided(logits.shape, logits.stride(), dtype=torch.float32, device=logits.device) if want_grad else None
+    _lib.check(L.avsi_ctc_loss_f32(_lib.ptr(logits), logits.stride(0), logits.stride(1), B, T, C, _lib.ptr(labels), Lp,
+                                   _lib.ptr(labels_lengths), _lib.ptr(sequence_lengths), Lmax, float(grad_scale),
+                                   _lib.ptr(loss), _lib.ptr(grad), _lib.ptr(ws), ws.numel() * 4, _lib.stream_ptr()),
+               "avsi_ctc_loss_f32")
+    return loss, grad
+
+
+def ctc_beam_search(logits, sequence_lengths, beam_width=20, merge_repeated=True):
+    """tf.nn.ctc_beam_search_decoder(top_paths=1) on the host (avsi_ctc_beam_search_host_f32): ``logits``
+    [B, T, C] (a device tensor is copied to the host), -> (decoded int32 [B, max_len] padded with -1,
+    lengths int32 [B], log_prob float32 [B]) as numpy arrays."""
+    x = logits.detach().to('cpu', torch.float32).contiguous().numpy() if isinstance(logits, torch.Tensor) \
+        else np.ascontiguousarray(logits, dtype=np.float32)
+    B, T, C = x.shape
+    seq = np.ascontiguousarray(np.asarray(sequence_lengths.cpu() if isinstance(sequence_lengths, torch.Tensor)
+                                          else sequence_lengths), dtype=np.int32)
+    dec = np.empty((B, T), dtype=np.int32)
+    dlen = np.empty(B, dtype=np.int32)
+    lp = np.empty(B, dtype=np.float32)
+    _lib.check(_lib.lib().avsi_ctc_beam_search_host_f32(x.ctypes.data, T * C, C, B, T, C, seq.ctypes.data, int(beam_width),
+                                                        int(bool(merge_repeated)), dec.ctypes.data, T, dlen.ctypes.data,
+                                                        lp.ctypes.data), "avsi_ctc_beam_search_host_f32")
+    return dec[:, :max(int(dlen.max()), 0)], dlen, lp
+
+
+def edit_distance(hyp, truth, normalize=True):
+    """tf.edit_distance for one pair of label sequences (host bookkeeping of the `per` diagnostic)."""
+    hyp, truth = list(hyp), list(truth)
+    d = list(range(len(truth) + 1))
+    for i, h in enumerate(hyp, 1):
+        prev, d[0] = d[0], i
+        for j, t in enumerate(truth, 1):
+            prev, d[j] = d[j], min(d[j] + 1, d[j - 1] + 1, prev + (h != t))
+    if not normalize:
+        return float(d[-1])
+    if not truth:
+        return float('inf') if hyp else 0.0
+    return d[-1] / len(truth)
 
 
 _WS = {}

@@ -175,6 +175,36 @@ int avsi_l1_loss_blend_f32(const float* target, float* pred_inout, const float* 
                            const float* row_scale, int row_len, int64_t n, float* out4,
                            float* dlogits, void* workspace, size_t workspace_bytes, void* stream);
 
+/* CTC head of the multi-task models (reference models.py:1944-1964 StackedBLSTMSSNNCTCLossModel.loss,
+ * :1634-1654 StackedBLSTMCTCLossModel.loss): tf.nn.ctc_loss(labels, logits, sequence_length,
+ * preprocess_collapse_repeated=False, ctc_merge_repeated=True) and its gradient.
+ *   logits [B][T][C] un-normalised (softmax is applied inside, like TF), element (b, t, k) at
+ *          b*ld_b + t*ld_t + k; the blank label is C - 1;
+ *   labels int32 [B][label_pitch], row b's first label_len[b] entries (the dense form the reference
+ *          feeds, ctc_label_dense_to_sparse :1760); max_label_len >= every label_len[b] (<= 127);
+ *   seq_len int32 [B]: frames t >= seq_len[b] are ignored and get zero gradient;
+ *   loss [B] = -log p(labels_b | logits_b); +inf (and a zero gradient row) when the labelling does not
+ *          fit into seq_len[b] frames (TF raises instead -- the trainers stop on an infinite loss);
+ *   grad (optional, same strides as logits) = grad_scale * d loss[b] / d logits[b]
+ *          = grad_scale * (softmax - posterior of the labelling's states per class).
+ * Out-of-range labels are clamped into [0, C-1] (the host mirror rejects them before the call).
+ * workspace: avsi_ctc_loss_workspace_bytes (0 = unsupported sizes) -- the alpha / beta tables.
+ * AVSI_ERR_UNSUPPORTED if T * (2 max_label_len + 1) floats do not fit the CU's LDS. */
+size_t avsi_ctc_loss_workspace_bytes(int B, int T, int max_label_len);
+int avsi_ctc_loss_f32(const float* logits, int64_t ld_b, int64_t ld_t, int B, int T, int C,
+                      const int32_t* labels, int label_pitch, const int32_t* label_len,
+                      const int32_t* seq_len, int max_label_len, float grad_scale, float* loss, float* grad,
+                      void* workspace, size_t workspace_bytes, void* stream);
+
+/* Host helper (no GPU work; HOST pointers): tf.nn.ctc_beam_search_decoder(logits, seq_len, beam_width,
+ * top_paths=1, merge_repeated) of the reference's `decoding` / `per` diagnostics (models.py:1934-1942,
+ * 2026-2031) -- TensorFlow runs this decoder on the CPU too.  decoded int32 [B][decoded_pitch >= T]
+ * padded with -1 (tf.sparse.to_dense(default_value=-1)), decoded_len [B], log_prob [B] (optional) =
+ * log probability of the returned labelling under the beam. */
+int avsi_ctc_beam_search_host_f32(const float* logits, int64_t ld_b, int64_t ld_t, int B, int T, int C,
+                                  const int32_t* seq_len, int beam_width, int merge_repeated,
+                                  int32_t* decoded, int decoded_pitch, int32_t* decoded_len, float* log_prob);
+
 /* Split-K form of avsi_gemm_f32 for reductions over very many rows (weight gradients
  * dW = X^T . dZ over all T*Bp rows): K is cut into `splits` chunks, partial [M,N] slabs go to
  * `workspace` (avsi_gemm_splitk_workspace_bytes), then are summed in chunk order (deterministic,

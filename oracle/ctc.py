@@ -172,6 +172,11 @@ def beam_search_one(logits, beam_width=20, merge_repeated=True):
                     if len(leaves) == beam_width:
                         del leaves[bottom().labels]
                     leaves[key] = c
+                elif key in entries:
+                    # a prefix pushed out of the beam earlier in this step and found again as a child that
+                    # does not make it back: TF deactivates the node (oldp.Reset()), so it spawns nothing
+                    # when its own turn comes
+                    entries[key].o_blank = entries[key].o_label = entries[key].o_total = NEG_INF
         entries = leaves
     best = max(entries.values(), key=lambda e: e.n_total)
     out = list(best.labels)
