@@ -45,9 +45,16 @@ class ParamLayout:
     (models.py:803-810): ``speaker_embedding/weights_1 [2F, width]``, ``biases_1``, ``weights_2 [width,
     width]``, ``biases_2``, ``weights_3``, ``biases_3``.  Packed: ``mw1a`` / ``mw1b`` = the feature and
     the delta-feature halves of weights_1 (rows padded to the model's time-major input pitch so the
-    GEMM reads the input buffer in place), ``mw2``, ``mw3``, ``mb1..3``."""
+    GEMM reads the input buffer in place), ``mw2``, ``mw3``, ``mb1..3``.
 
-    def __init__(self, input_dim, net_dim=(250, 250, 250), audio_feat_dim=257, side=None, mlp=None, mlp_in_pitch=None):
+    ``asr = num_classes`` adds the second head of the multi-task CTC models (models.py:1903-1916):
+    ``asr/weights [2H, num_classes]``, ``asr/biases``; the inpainting head keeps the internal names
+    ``logits/*`` (its TF scope there is ``inpainting/``, see tf_checkpoint).  Packed, the two heads
+    share ``pw`` / ``pb``: the asr columns start at ``asr_col`` = F rounded up to 4, so both heads
+    are column windows of one matrix and the backward pass treats them as one projection."""
+
+    def __init__(self, input_dim, net_dim=(250, 250, 250), audio_feat_dim=257, side=None, mlp=None, mlp_in_pitch=None,
+                 asr=None):
         net_dim = tuple(int(h) for h in net_dim)
         if len(set(net_dim)) != 1 or net_dim[0] > HP or net_dim[0] < 1:
             raise ValueError("the gfx950 BLSTM kernels need equal layer sizes <= %d, got %r" % (HP, net_dim))
@@ -55,7 +62,11 @@ class ParamLayout:
         self.H = H = net_dim[0]
         self.num_layers = len(net_dim)
         self.F = F = int(audio_feat_dim)
-        self.ldp = round_up(F, 4)                      # padded row pitch of the projection matrix
+        self.asr = int(asr) if asr else 0
+        if self.asr and self.asr < 2:
+            raise ValueError("the asr head needs at least one label and the blank, got %r classes" % (asr,))
+        self.asr_col = round_up(F, 4) if self.asr else 0
+        self.ldp = round_up(self.asr_col + self.asr, 4) if self.asr else round_up(F, 4)   # row pitch of the projection matrix
         self.side = None if side is None else (int(side[0]), int(side[1]))
         if self.side is not None and not (0 <= self.side[0] < self.num_layers and self.side[1] > 0):
             raise ValueError("side input must name an existing layer and a positive width, got %r" % (side,))
@@ -82,6 +93,11 @@ class ParamLayout:
         off += 2 * H * F
         self.ref_entries.append(('logits/biases', (F,), off))
         off += F
+        if self.asr:
+            self.ref_entries.append(('asr/weights', (2 * H, self.asr), off))
+            off += 2 * H * self.asr
+            self.ref_entries.append(('asr/biases', (self.asr,), off))
+            off += self.asr
         if self.mlp:
             W = self.mlp
             for name, shape in (('weights_1', (2 * F, W)), ('biases_1', (W,)), ('weights_2', (W, W)), ('biases_2', (W,)),
@@ -144,7 +160,7 @@ class ParamLayout:
     def signature(self):
         """Shape signature stored in checkpoints."""
         return ([self.input_dim, self.H, self.num_layers, self.F] + (list(self.side) if self.side else [])
-                + ([-self.mlp] if self.mlp else []))
+                + ([-self.mlp] if self.mlp else []) + ([-100000 - self.asr] if self.asr else []))
 
     def _mlp_map(self):
         """[(packed name, reference name, row offset in the reference matrix, rows)] of the dense MLP entries."""
@@ -223,6 +239,11 @@ class ParamLayout:
         idx[pw_off + rows[:, None] * self.ldp + c[None, :]] = (
             self._ref_off['logits/weights'] + rmap[rows][:, None] * F + c[None, :])
         idx[pb_off + c] = self._ref_off['logits/biases'] + c
+        if self.asr:
+            a = np.arange(self.asr)
+            idx[pw_off + rows[:, None] * self.ldp + (self.asr_col + a)[None, :]] = (
+                self._ref_off['asr/weights'] + rmap[rows][:, None] * self.asr + a[None, :])
+            idx[pb_off + self.asr_col + a] = self._ref_off['asr/biases'] + a
         if self.mlp:
             W = self.mlp
             w = np.arange(W)
@@ -273,6 +294,11 @@ class ParamLayout:
         gi[self._ref_off['logits/weights'] + np.arange(2 * H)[:, None] * F + c[None, :]] = (
             dpw_off + prow[:, None] * self.ldp + c[None, :])
         gi[self._ref_off['logits/biases'] + c] = dpb_off + c
+        if self.asr:
+            a = np.arange(self.asr)
+            gi[self._ref_off['asr/weights'] + np.arange(2 * H)[:, None] * self.asr + a[None, :]] = (
+                dpw_off + prow[:, None] * self.ldp + (self.asr_col + a)[None, :])
+            gi[self._ref_off['asr/biases'] + a] = dpb_off + self.asr_col + a
         if self.mlp:
             W = self.mlp
             w = np.arange(W)
@@ -312,6 +338,9 @@ class ParamLayout:
                 self.ref_view(flat, 'cell_%d/%s/bias' % (li, dname))[...] = layer[dname]['bias']
         self.ref_view(flat, 'logits/weights')[...] = params['proj']['weights']
         self.ref_view(flat, 'logits/biases')[...] = params['proj']['biases']
+        if 'asr' in params:
+            self.ref_view(flat, 'asr/weights')[...] = params['asr']['weights']
+            self.ref_view(flat, 'asr/biases')[...] = params['asr']['biases']
         for k, v in params.get('mlp', {}).items():
             self.ref_view(flat, 'speaker_embedding/' + k)[...] = v
         return flat

@@ -27,6 +27,7 @@ both.  Variable names follow the ``integration_layer = 0`` scoping (``cudnn_lstm
   the masked time average is taken BEFORE it: ``mean_t(w_t (a_t W3 + b3)) = (sum_t w_t a_t) W3 +
   (sum_t w_t) b3`` -- a [B, 200] x [200, 200] GEMM instead of a [B T, 200] x [200, 200] one.
 """
+import numpy as np
 import torch
 
 from . import _lib, ops
@@ -276,3 +277,136 @@ class StackedBLSTMSSNNModel(StackedBLSTMModel):
         ops.gemm_splitk(feat.view(M, P), dl1, g('dmw1a'), trans_a=True, m=P, n=W, k=M, splits=splits)
         ops.gemm_splitk(delta.view(M, P), dl1, g('dmw1b'), trans_a=True, m=P, n=W, k=M, splits=splits)
         ops.colsum(dl1, g('dmb1'), m=M, n=W)
+
+
+class StackedBLSTMSSNNCTCLossModel(StackedBLSTMSSNNModel):
+    """Multi-task model: speech inpainting + phone recognition with a CTC loss (reference
+    models.py:1741-2047; the model the shipped ``blstm_ctc.config`` trains, ``v-blstm-ssnn-ctc``).
+
+    A plain stacked BLSTM with two heads on its output: ``inpainting`` (prediction and loss_hole as in
+    the embedding variants) and ``asr`` (``num_asr_labels + 1`` classes, the last one blank);
+    ``loss_func = loss_hole + ctc_loss * mean_b CTC_b``.  The class also creates the speaker-embedding
+    MLP variables and ``speaker_embedding`` can be fetched, but -- as in the reference, :1874-1918 --
+    nothing of it reaches ``inference``: those variables get no gradient.
+
+    Here both heads are column windows of ONE packed projection matrix (ParamLayout ``asr``), so the
+    backward pass is the plain model's with a wider d-logits buffer; the CTC loss and its gradient come
+    from avsi_ctc_loss_f32, ``decoding`` / ``per`` run the beam search (width 20) on the host like TF."""
+    WITH_MLP = True
+
+    def __init__(self, sequence_lengths, labels_lengths, target_sources, masks, labels, audio_feat_mean, audio_feat_std,
+                 dropout_rate, config, audio_features=None, video_features=None, input='a', apply_mask=False,
+                 is_training=True, variables=None, seed=0):
+        self.num_classes = int(config['num_asr_labels'])         # blank included (config_utils adds it)
+        self.ctc_loss_weight = float(config['ctc_loss'])
+        self.int_layer = 0
+        F = config['audio_feat_dim']
+        in_dim = {'a': F, 'v': config.get('video_feat_dim', 136), 'av': F + config.get('video_feat_dim', 136)}[input]
+        pitch = input_pitch(F if input == 'v' else in_dim)
+        if variables is None:
+            layout = ParamLayout(in_dim, config['net_dim'], F, asr=self.num_classes, mlp=self.EMB if self.WITH_MLP else None,
+                                 mlp_in_pitch=pitch if self.WITH_MLP else None)
+            variables = BLSTMVariables(layout, seed=seed)
+        elif variables.layout.asr != self.num_classes or bool(variables.layout.mlp) != self.WITH_MLP:
+            raise ValueError("variables were not built for this multi-task model (asr=%d)" % self.num_classes)
+        self.labels = self.labels_lengths = None
+        StackedBLSTMModel.__init__(self, sequence_lengths, target_sources, masks, audio_feat_mean, audio_feat_std,
+                                   dropout_rate, config, audio_features=audio_features, video_features=video_features,
+                                   input=input, is_training=is_training, variables=variables, seed=seed, blend=True)
+        self.feed_labels(labels, labels_lengths)
+
+    # ------------------------------------------------------------------ feed boundary
+    def feed_labels(self, labels, labels_lengths):
+        """Dense labels float/int [B, L] + labels_lengths [B] (training_ctc.py:68-73; the model keeps the
+        first labels_lengths[b] entries of row b, ctc_label_dense_to_sparse :1760).  Labels outside
+        [0, num_classes - 1) raise ValueError (TensorFlow: InvalidArgumentError)."""
+        self._cache = {}
+        if labels is None or labels_lengths is None:
+            self.labels = self.labels_lengths = None
+            return
+        lab = np.asarray(labels.cpu() if isinstance(labels, torch.Tensor) else labels)
+        lens = np.asarray(labels_lengths.cpu() if isinstance(labels_lengths, torch.Tensor) else labels_lengths).astype(np.int64)
+        if lab.ndim != 2 or lens.shape != (lab.shape[0],) or (lens < 0).any() or (lens > lab.shape[1]).any():
+            raise ValueError("labels must be [batch, L] with 0 <= labels_lengths <= L")
+        lab = lab.astype(np.int32)                              # tf.cast(..., tf.int32) :1760
+        used = np.arange(lab.shape[1])[None, :] < lens[:, None]
+        if used.any() and (lab[used].min() < 0 or lab[used].max() >= self.num_classes - 1):
+            raise ValueError("labels must lie in [0, %d)" % (self.num_classes - 1))
+        self.labels, self.labels_lengths = lab, lens.astype(np.int32)
+        self._labels_dev = torch.as_tensor(self.labels, device=self.device)
+        self._lab_len_dev = torch.as_tensor(self.labels_lengths, device=self.device)
+
+    def feed(self, sequence_lengths=None, target_sources=None, masks=None, video_features=None, audio_features=None,
+             audio_feat_mean=None, audio_feat_std=None, labels=None, labels_lengths=None):
+        StackedBLSTMModel.feed(self, sequence_lengths, target_sources, masks, video_features, audio_features,
+                               audio_feat_mean, audio_feat_std)
+        if sequence_lengths is not None:
+            self._seq_dev32 = self._seq_dev.to(torch.int32)
+        if labels is not None:
+            self.feed_labels(labels, labels_lengths)
+
+    # ------------------------------------------------------------------ loss (models.py:1944-1964)
+    def _extra_loss(self, want_grad):
+        c = self._cache
+        if self.labels is None:
+            # prediction-only use (the `infer` driver feeds no labels): loss_func stays loss_hole
+            if want_grad:
+                raise _lib.AvsiError("the multi-task model needs `labels` and `labels_lengths` to be fed for training")
+            c['ctc_loss'] = None
+            return
+        logits = c['asr_logits']
+        B = logits.shape[0]
+        if self.labels.shape[0] != B:
+            raise ValueError("labels are for %d utterances, the batch has %d" % (self.labels.shape[0], B))
+        per_utt, dasr = ops.ctc_loss(logits, self._labels_dev, self._lab_len_dev, self._seq_dev32,
+                                     grad_scale=self.ctc_loss_weight / B, want_grad=want_grad,
+                                     max_label_len=max(int(self.labels_lengths.max()), 1))
+        c['ctc_loss'] = per_utt.mean()
+        c['dasr'] = dasr
+        l3 = c['loss3']
+        c['loss3'] = torch.stack([l3[1] + self.ctc_loss_weight * c['ctc_loss'], l3[1], l3[2]])
+
+    @property
+    def ctc_loss(self):
+        self._loss()
+        return self._cache['ctc_loss']
+
+    @property
+    def inference(self):
+        """(inpainting head, asr logits [B, T, num_classes]) -- models.py:1903-1918; the first is the
+        prediction (the raw logits of the known bins are not materialised, as in the base class)."""
+        self._forward()
+        return self._cache['pred'], self._cache['asr_logits']
+
+    # ------------------------------------------------------------------ diagnostics (models.py:1934-1942, 2026-2031)
+    def _decode(self):
+        c = self._cache
+        if 'decoded' not in c:
+            self._forward()
+            c['decoded'] = ops.ctc_beam_search(c['asr_logits'], self.sequence_lengths, beam_width=20)
+        return c['decoded']
+
+    @property
+    def decoding(self):
+        """Dense int32 [B, longest] padded with -1 (tf.sparse.to_dense(default_value=-1)), numpy."""
+        return self._decode()[0]
+
+    @property
+    def per(self):
+        """Normalised edit distance of every decoded sequence to its labels (tf.edit_distance), numpy [B]."""
+        dec, dlen, _ = self._decode()
+        if self.labels is None:
+            raise _lib.AvsiError("`per` needs the labels to be fed")
+        return np.array([ops.edit_distance(dec[b, :dlen[b]], self.labels[b, :self.labels_lengths[b]])
+                         for b in range(len(dlen))], dtype=np.float32)
+
+
+class StackedBLSTMCTCLossModel(StackedBLSTMSSNNCTCLossModel):
+    """reference models.py:1475-1739.  There, ``inference`` concatenates ``self.speaker_embedding``,
+    which the class never defines (:1565-1566): the reference cannot build this
+    model.  Provided here as the multi-task model without the (unused) speaker-embedding variables."""
+    WITH_MLP = False
+
+    @property
+    def speaker_embedding(self):
+        raise AttributeError("StackedBLSTMCTCLossModel has no speaker embedding (reference models.py:1565)")

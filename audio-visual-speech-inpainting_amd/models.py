@@ -64,7 +64,7 @@ class BLSTMVariables:
             if name.endswith('/kernel'):
                 lim = math.sqrt(6.0 / (shape[0] + shape[1]))
                 flat[off:off + n] = rng.uniform(-lim, lim, size=n)
-            elif name == 'logits/weights' or name.startswith('speaker_embedding/weights_'):
+            elif name in ('logits/weights', 'asr/weights') or name.startswith('speaker_embedding/weights_'):
                 # logits: stddev 1/sqrt(2H) (models.py:119); speaker-embedding MLP: 1/sqrt(F) for
                 # weights_1 [2F, W], 1/sqrt(W) for the square ones (models.py:804-808)
                 sd = 1.0 / math.sqrt(float(shape[0] // 2 if name.endswith('weights_1') else shape[0]))
@@ -334,6 +334,13 @@ class StackedBLSTMModel(object):
         c['row_scale'] = row_scale
         c['pred'] = pred
         c['kept'] = keep
+        if self.layout.asr:
+            # second head (models.py:1910-1916): the asr columns of the same packed matrix, no sequence mask
+            lay = self.layout
+            asr = torch.empty((B, T, lay.asr), dtype=torch.float32, device=self.device)
+            ops.gemm(x.view(T * Bp, 2 * HP), v.p('pw')[:, lay.asr_col:lay.asr_col + lay.asr], out=asr.view(B * T, lay.asr),
+                     n=lay.asr, bias=v.p('pb')[lay.asr_col:lay.asr_col + lay.asr], row_map=(Bp, T, B))
+            c['asr_logits'] = asr
         if self.blend:
             # prediction = seq_mask * (target * mask + logits * (1 - mask)); loss_func = loss_hole
             tgt = self.target_spec_norm
@@ -342,6 +349,11 @@ class StackedBLSTMModel(object):
             out3, dlog = ops.l1_loss_blend(tgt, pred, mask, rs_bm, want_grad=keep)
             c['loss3'] = torch.stack([out3[1], out3[1], out3[2]])
             c['dpred'] = dlog
+            self._extra_loss(keep)
+
+    def _extra_loss(self, want_grad):
+        """Hook of the multi-task variants: add further loss terms to ``_cache['loss3'][0]`` and leave
+        the gradient of extra heads' logits in ``_cache['dasr']`` [B, T, classes]."""
 
     # ---------------------------------------------------------------- side input hooks (variants)
     def _side_input(self):
@@ -460,6 +472,9 @@ class StackedBLSTMModel(object):
         dlog = self._buf('dlog', (T, Bp, ldp), zero=True)
         ops.relayout_rows(c['dpred'], dlog, B, T, F, ldp, (T * F, F), (ldp, Bp * ldp),
                           row_scale=c['row_scale'], scale_strides=(1, Bp))
+        if lay.asr:
+            ops.relayout_rows(c['dasr'], dlog.view(-1)[lay.asr_col:], B, T, lay.asr, ldp - lay.asr_col,
+                              (T * lay.asr, lay.asr), (ldp, Bp * ldp))
         dlog2 = dlog.view(M, ldp)
         h_top = c['rnn_out'].view(M, 2 * HP)
         splits = ops.splitk_for(M)

@@ -315,7 +315,8 @@ def write_bundle(prefix, variables, write_state=True):
 
 # ------------------------------------------------------------------------------- variable mapping
 _CELL_RE = re.compile(r'(?:^|/)cell_(\d+)/bidirectional_rnn/(fw|bw)/[^/]+/(kernel|bias)$')
-_LOGITS_RE = re.compile(r'(?:^|/)logits/(weights|biases)$')
+_LOGITS_RE = re.compile(r'(?:^|/)(?:logits|inpainting)/(weights|biases)$')    # multi-task models: scope 'inpainting'
+_ASR_RE = re.compile(r'(?:^|/)asr/(weights|biases)$')
 _STEP_RE = re.compile(r'(?:^|/)(Variable|global_step)$')
 _UNET_RE = re.compile(r'(?:^|/)(w|b)(?:_(\d+))?$')
 _BN_RE = re.compile(r'(?:^|/)batch_normalization(?:_(\d+))?/(gamma|beta)$')
@@ -334,6 +335,9 @@ def _local_name(tf_name, unet_specs=None, side_layer=0):
     m = _LOGITS_RE.search(tf_name)
     if m:
         return 'logits/' + m.group(1)
+    m = _ASR_RE.search(tf_name)
+    if m:
+        return 'asr/' + m.group(1)
     m = _SPK_RE.search(tf_name)
     if m:
         return 'speaker_embedding/' + m.group(1)
@@ -373,8 +377,10 @@ def tf_variable_names(layout, scope):
                 stack, li = ('blstm_1/cudnn_lstm', li) if li < side_layer else ('blstm_2/cudnn_lstm', li - side_layer)
             out[name] = '%s/%s/stack_bidirectional_rnn/cell_%d/bidirectional_rnn/%s/cudnn_compatible_lstm_cell/%s' % (
                 scope, stack, li, m.group(2), m.group(3))
+        elif getattr(layout, 'asr', 0) and name.startswith('logits/'):
+            out[name] = '%s/inpainting/%s' % (scope, name[7:])   # two heads: inpainting/ and asr/ (models.py:1903-1916)
         else:
-            out[name] = '%s/%s' % (scope, name)      # logits/*, speaker_embedding/*
+            out[name] = '%s/%s' % (scope, name)      # logits/*, asr/*, speaker_embedding/*
     return out
 
 

@@ -31,6 +31,8 @@ def params_to_torch(params, grad=True):
            'proj': {k: _t(params['proj'][k], grad) for k in ('weights', 'biases')}}
     if 'mlp' in params:
         out['mlp'] = {k: _t(v, grad) for k, v in params['mlp'].items()}
+    if 'asr' in params:
+        out['asr'] = {k: _t(v, grad) for k, v in params['asr'].items()}
     return out
 
 
@@ -40,6 +42,8 @@ def grads_to_numpy(tp):
          'proj': {k: tp['proj'][k].grad.numpy() for k in ('weights', 'biases')}}
     if 'mlp' in tp:
         g['mlp'] = {k: v.grad.numpy() for k, v in tp['mlp'].items()}
+    if 'asr' in tp:
+        g['asr'] = {k: v.grad.numpy() for k, v in tp['asr'].items()}
     return g
 
 
@@ -146,3 +150,39 @@ def init_variant_params(seed, input_dim, side_layer, side_dim, net_dim=(250, 250
                          'weights_3': rng.normal(0, 1 / np.sqrt(side_dim), size=(side_dim, side_dim)).astype(np.float32),
                          'biases_3': rng.normal(0, 0.1, size=side_dim).astype(np.float32)}
     return params
+
+
+
+def ctc_multitask_forward(wav, masks, mean, std, seq_len, tparams, labels, labels_lengths, ctc_weight, video=None,
+                          input_type='a'):
+    """StackedBLSTMSSNNCTCLossModel (reference av_speech_inpainting/models.py:1741-2047): a plain stacked
+    BLSTM with two heads on its output -- ``inpainting`` (prediction / loss_hole as in the embedding
+    variants, :1921-1931) and ``asr`` (un-masked logits over num_asr_labels + 1 classes, :1910-1916) --
+    and ``loss_func = loss_hole + ctc_loss_weight * mean_b ctc_loss_b`` (:1944-1955).  The speaker-embedding
+    MLP the class also builds (:1830-1871) feeds nothing and is left out.  ``tparams['asr']`` holds the
+    second head.  The CTC term is torch's ctc_loss in float64 (tests/test_oracle_ctc.py shows it equal to
+    oracle.ctc's explicit recursions, which restate tf.nn.ctc_loss)."""
+    norm, feats, T = frontend(wav, masks, mean, std, seq_len)
+    m = _t(masks)[:, :T]
+    if input_type == 'a':
+        x = feats
+    elif input_type == 'v':
+        x = _t(video)[:, :T]
+    else:
+        x = torch.cat([feats, _t(video)[:, :T]], dim=2)
+    rnn = blstm_stack(x, tparams['layers'])
+    B = rnn.shape[0]
+    flat = rnn.reshape(B * T, -1)
+    logits = (flat @ tparams['proj']['weights'] + tparams['proj']['biases']).reshape(B, T, -1)
+    asr = (flat @ tparams['asr']['weights'] + tparams['asr']['biases']).reshape(B, T, -1)
+    seq = _t(OB.sequence_mask(seq_len, T, np.float64))[:, :, None]
+    pred = seq * (norm * m + logits * (1 - m))
+    loss_hole = ((norm - pred).abs() * (1 - m)).sum() / (1 - m).sum()
+    C = asr.shape[2]
+    ctc = torch.nn.functional.ctc_loss(torch.log_softmax(asr, dim=2).transpose(0, 1),
+                                       torch.as_tensor(np.asarray(labels)).long(),
+                                       torch.as_tensor(np.asarray(seq_len)).long(),
+                                       torch.as_tensor(np.asarray(labels_lengths)).long(), blank=C - 1,
+                                       reduction='none').mean()
+    return {'prediction': pred, 'asr_logits': asr, 'loss_hole': loss_hole, 'ctc_loss': ctc,
+            'loss_func': loss_hole + ctc_weight * ctc}

@@ -188,3 +188,107 @@ def test_ssnn_model_forward_backward(int_layer, input_type):
     w1 = layout.ref_view(fresh.flat.cpu().numpy(), 'speaker_embedding/weights_1')
     assert 0.5 / np.sqrt(257) < w1.std() < 1.0 / np.sqrt(257) and np.abs(w1).max() <= 2.0 / np.sqrt(257) + 1e-6
     assert np.all(layout.ref_view(fresh.flat.cpu().numpy(), 'speaker_embedding/biases_2') == 0)
+
+
+def _ctc_labels(B, T, C, rng, Lp=50):
+    lab_len = rng.integers(1, 6, size=B).astype(np.int32)
+    labels = np.zeros((B, Lp), dtype=np.float32)
+    for b in range(B):
+        labels[b, :lab_len[b]] = rng.integers(0, C - 1, size=lab_len[b])
+    return labels, lab_len
+
+
+@pytest.mark.parametrize('input_type,with_mlp', [('a', True), ('av', False)])
+def test_ctc_multitask_model_forward_backward(input_type, with_mlp):
+    """Both heads, loss_func = loss_hole + ctc_loss * mean CTC, gradient w.r.t. every variable
+    (the unused speaker-embedding variables of the SSNN class get exactly zero)."""
+    import avsi_amd  # noqa: F401
+    from avsi_amd import models
+    from avsi_amd.blstm_layout import ParamLayout, input_pitch
+    from avsi_amd import model_variants as mv
+    B, N, C, W = 3, 2880, 34, 0.05
+    wav, masks, mean, std, video, seq, T = _inputs(B, N, 31, ragged=True)
+    rng = np.random.default_rng(8)
+    labels, lab_len = _ctc_labels(B, T, C, rng)
+    D = 257 if input_type == 'a' else 393
+    params = OV.init_variant_params(4, D, None, 0)
+    params['asr'] = {'weights': rng.normal(0, 1 / np.sqrt(500), size=(500, C)).astype(np.float32),
+                     'biases': rng.normal(0, 0.1, size=C).astype(np.float32)}
+    layout = ParamLayout(D, (250, 250, 250), 257, asr=C, mlp=200 if with_mlp else None,
+                         mlp_in_pitch=input_pitch(D) if with_mlp else None)
+    variables = models.BLSTMVariables(layout, seed=2)            # MLP variables: random, must not matter
+    flat = variables.flat.cpu().numpy()
+    base = layout.flatten_oracle_params(params)
+    known = base != 0
+    flat[known] = base[known]
+    for name in ('logits/biases', 'asr/biases'):
+        layout.ref_view(flat, name)[...] = layout.ref_view(base, name)
+    for li in range(3):
+        for d in ('fw', 'bw'):
+            layout.ref_view(flat, 'cell_%d/%s/bias' % (li, d))[...] = layout.ref_view(base, 'cell_%d/%s/bias' % (li, d))
+    variables.load_flat(flat)
+    cfg = _config(audio_len=N, num_asr_labels=C, ctc_loss=W)
+    vid = video if input_type == 'av' else None
+    cls = mv.StackedBLSTMSSNNCTCLossModel if with_mlp else mv.StackedBLSTMCTCLossModel
+    m = cls(seq, lab_len, wav, masks, labels, mean, std, 0.0, cfg, video_features=vid, input=input_type,
+            is_training=True, variables=variables)
+    m.build_graph('a-blstm-ssnn-ctc')
+    tp = OV.params_to_torch(params)
+    ref = OV.ctc_multitask_forward(wav, masks, mean, std, seq, tp, labels, lab_len, W, video=vid, input_type=input_type)
+    ref['loss_func'].backward()
+    pred, asr = m.inference
+    np.testing.assert_allclose(pred.cpu().numpy(), ref['prediction'].detach().numpy(), rtol=2e-4, atol=2e-4)
+    np.testing.assert_allclose(asr.cpu().numpy(), ref['asr_logits'].detach().numpy(), rtol=2e-4, atol=2e-4)
+    np.testing.assert_allclose(float(m.loss_hole), float(ref['loss_hole'].detach()), rtol=1e-4)
+    np.testing.assert_allclose(float(m.ctc_loss), float(ref['ctc_loss'].detach()), rtol=2e-4)
+    np.testing.assert_allclose(float(m.loss_func), float(ref['loss_func'].detach()), rtol=2e-4)
+    np.testing.assert_allclose(float(m.loss), float(ref['loss_func'].detach()), rtol=2e-4)
+    g = m.gradients.cpu().numpy().astype(np.float64)
+    go = OV.grads_to_numpy(tp)
+    gref = layout.flatten_oracle_params({'layers': go['layers'], 'proj': go['proj'], 'asr': go['asr']}).astype(np.float64)
+    scale = np.abs(gref).max()
+    np.testing.assert_allclose(g, gref, rtol=2e-3, atol=2e-5 * scale)
+    if with_mlp:
+        for n_, shape, off in layout.ref_entries:
+            if n_.startswith('speaker_embedding/'):
+                assert not g[off:off + int(np.prod(shape))].any()
+        assert tuple(m.speaker_embedding.shape) == (B, 200)
+    # diagnostics: beam search on the host equals the oracle's decoder on the same logits
+    from oracle import ctc as OC
+    outs, _ = OC.beam_search(asr.cpu().numpy(), seq, beam_width=20)
+    dec = m.decoding
+    for b in range(B):
+        got = [int(v) for v in dec[b] if v >= 0]
+        assert got == outs[b]
+        want_per = OC.edit_distance(outs[b], labels[b, :lab_len[b]].astype(int).tolist())
+        assert abs(float(m.per[b]) - want_per) < 1e-6
+    # one optimiser step moves both heads, leaves the unused variables alone
+    before = m.variables.flat.clone()
+    m.train_op
+    after = m.variables.flat
+    for n_, shape, off in layout.ref_entries:
+        moved = bool((after[off:off + int(np.prod(shape))] != before[off:off + int(np.prod(shape))]).any())
+        assert moved == (not n_.startswith('speaker_embedding/')), n_
+
+
+def test_ctc_model_predicts_without_labels_and_rejects_bad_ones():
+    import avsi_amd  # noqa: F401
+    from avsi_amd import _lib
+    from avsi_amd import model_variants as mv
+    B, N, C = 2, 2880, 34
+    wav, masks, mean, std, video, seq, T = _inputs(B, N, 32)
+    cfg = _config(audio_len=N, num_asr_labels=C, ctc_loss=0.001)
+    m = mv.StackedBLSTMSSNNCTCLossModel(seq, None, wav, masks, None, mean, std, 0.0, cfg, input='a', is_training=False)
+    pred = m.prediction
+    keep = masks[:, :T] == 1
+    np.testing.assert_array_equal(pred.cpu().numpy()[keep], m.target_spec_norm.cpu().numpy()[keep])
+    assert np.isfinite(float(m.loss_hole)) and m.ctc_loss is None
+    assert m.enhanced_sources.shape == (B, N)
+    with pytest.raises(ValueError):
+        m.feed_labels(np.full((B, 4), C - 1.0, np.float32), np.full(B, 2))     # the blank is not a label
+    with pytest.raises(ValueError):
+        m.feed_labels(np.zeros((B, 4), np.float32), np.full(B, 5))
+    m.is_training = True
+    m.feed(seq, wav, masks)
+    with pytest.raises(_lib.AvsiError):
+        m.loss_func
