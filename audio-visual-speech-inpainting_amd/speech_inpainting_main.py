@@ -6,7 +6,9 @@ path and the data preparation around it are implemented (``dataset_generator``,
 ``tfrecords_generator``, ``audio_preprocessing``, ``masking``, ``training``, ``inference``); the
 reference's landmark extraction, ASR and evaluation sub-commands are accepted by the parser
 (same flags) but exit with a message: they are outside the scope of this package.
-Unlike the reference, ``training`` runs the plain a/v/av-BLSTM trainer.
+``training`` serves every model name of the reference's bound trainer (training_ctc.py:78-131): the
+plain, ``-ssnn``, ``-emb``, two-step and U-Net models follow training_emb.py, the ``-ctc`` ones training_ctc.py
+(the reference's own ``training`` only works for the latter).
 """
 import argparse
 import sys

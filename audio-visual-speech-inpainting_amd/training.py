@@ -2,7 +2,9 @@
 
 ``train(config_file)`` follows the reference trainer for the plain a/v/av-BLSTM models
 (``av_speech_inpainting/training_emb.py:23-383``, the internally consistent copy of
-``training.py``): same config keys, same directory contract
+``training.py``) and, for the multi-task ``*-ctc`` models, ``training_ctc.py:23-425`` (the
+trainer the reference CLI binds to ``training``; its extra loss terms, PER columns and its choice of
+the inpainting loss for model selection are kept): same config keys, same directory contract
 (``<exp_folder>/netmodel/{config.txt, audio_features_mean.npy, audio_features_std.npy, sinet*,
 ckpt*}``, ``<exp_folder>/training_log.txt``), same console / log line formats, NaN/Inf abort with
 exit code 1, bad checkpoint with exit code 2, best-on-validation checkpoint ``sinet``, periodic
@@ -31,6 +33,11 @@ _INPUT_OF = {'a-blstm': 'a', 'v-blstm': 'v', 'av-blstm': 'av'}
 EMBEDDING_SIZE = 512           # training_emb.py:71
 
 
+def is_ctc(config):
+    """Multi-task models with the CTC head (training_ctc.py:110-127)."""
+    return str(config['model']).endswith('-ctc')
+
+
 def uses_embeddings(config):
     """Models fed with the external speaker embedding stored in the TFRecords (training_emb.py:102-110)."""
     return str(config['model']).endswith('-emb')
@@ -55,24 +62,35 @@ def build_model(config, mean, std, variables=None, is_training=True):
     elif kind[:-4] in _INPUT_OF and kind.endswith('-emb'):
         model = mv.StackedBLSTMEmbeddingModel(None, None, None, mean, std, 0.0, config, input=_INPUT_OF[kind[:-4]],
                                               variables=variables, is_training=is_training)
+    elif kind.endswith('-ssnn-ctc') and kind[:-9] in _INPUT_OF:
+        model = mv.StackedBLSTMSSNNCTCLossModel(None, None, None, None, None, mean, std, 0.0, config,
+                                                input=_INPUT_OF[kind[:-9]], variables=variables, is_training=is_training)
+    elif kind.endswith('-ctc') and kind[:-4] in _INPUT_OF:
+        # the reference class cannot be built; see model_variants.StackedBLSTMCTCLossModel
+        model = mv.StackedBLSTMCTCLossModel(None, None, None, None, None, mean, std, 0.0, config,
+                                            input=_INPUT_OF[kind[:-4]], variables=variables, is_training=is_training)
     else:
-        print('Model selection must be "a-blstm", "v-blstm", "av-blstm" (optionally with "-ssnn" or "-emb"), '
+        print('Model selection must be "a-blstm", "v-blstm", "av-blstm" (optionally with "-ssnn", "-emb", "-ctc" or '
+              '"-ssnn-ctc"), '
               '"av-blstm-twosteps" or "unet" (got "{:s}"). Closing...'.format(kind))
         sys.exit(1)
     model.build_graph(var_scope=kind)
     return model
 
 
-def unpack_batch(batch, with_embeddings):
-    """Reader tuple -> feed kwargs (+ sample paths).  Reference: training_emb.py:238-249."""
+def unpack_batch(batch, with_embeddings, with_labels=False):
+    """Reader tuple -> feed kwargs (+ sample paths).  Reference: training_emb.py:238-249,
+    training_ctc.py:260-275 (labels and their lengths for the multi-task models)."""
     if with_embeddings:
-        length, _, audio, emb, paths, _, video, mask = batch
+        length, lab_len, audio, emb, paths, labels, video, mask = batch
     else:
-        length, _, audio, paths, _, video, mask = batch
+        length, lab_len, audio, paths, labels, video, mask = batch
         emb = None
     feed = dict(sequence_lengths=length, target_sources=audio, video_features=video, masks=mask)
     if with_embeddings:
         feed['embeddings'] = emb
+    if with_labels:
+        feed['labels'], feed['labels_lengths'] = labels, lab_len
     return feed, paths
 
 
@@ -113,6 +131,7 @@ def train(config_file, checkpoint_format=None):
     _, val_it = val_dm.get_iterator(val_dm.get_dataset(val_files, shuffle=False), batch_size=config['batch_size'],
                                     n_epochs=1, shard=(rank, world))
 
+    ctc = is_ctc(config)
     audio_feat_mean = np.load(config['audio_feat_mean'])
     audio_feat_std = np.load(config['audio_feat_std'])
     model = build_model(config, audio_feat_mean, audio_feat_std)
@@ -145,6 +164,7 @@ def train(config_file, checkpoint_format=None):
         '## Starter learning rate: {:.6f}'.format(config['starter_learning_rate']),
         '## Learning rate update steps: {:d}'.format(config['lr_updating_steps']),
         '## Learning rate decay: {:.6f}'.format(config['lr_decay']),
+    ] + (['## CTC-loss coefficient: {:.6f}'.format(config['ctc_loss'])] if ctc else []) + [
         '## L2 regularization coefficient: {:.6f}'.format(config['l2']),
         '## Dropout rate (no dropout if 0): {:.6f}'.format(config['dropout_rate']),
         '## Training dataset: {:s}'.format(data_path_train),
@@ -172,7 +192,8 @@ def train(config_file, checkpoint_format=None):
     else:
         log.write('\n'.join(header) + '\n')
         log.write('## Approximated total number of steps: {:d}\n'.format(n_steps))
-        log.write('\nEpoch\tLR\tTraining loss\tValidation loss\t[TIME]\n')
+        log.write('\nEpoch\tLR\tTraining loss\tTraining PER \tValidation loss\tValidation PER[TIME]\n' if ctc else
+                  '\nEpoch\tLR\tTraining loss\tValidation loss\t[TIME]\n')
     if chief:
         print('')
         print('\n'.join(header))
@@ -185,8 +206,31 @@ def train(config_file, checkpoint_format=None):
     cneg_epochs = 0
     train_start_time = time()
     lr = model.learning_rate
-    train_avg_loss = train_avg_loss_fn = val_avg_loss = float('nan')
+    # running means weighted by the number of gap frames: [loss, loss_func] for the plain models
+    # (training_emb.py:252-253), [loss, loss_hole, ctc_loss, PER] for the multi-task ones (training_ctc.py:293-306)
+    n_avg = 4 if ctc else 2
+    train_avg = [float('nan')] * n_avg
+    val_avg = [float('nan')] * n_avg
     epoch_duration = 0.0
+
+    def fetch(training):
+        """The reference's fetch list for one batch, as floats."""
+        if ctc:
+            vals = [float(model.loss), float(model.loss_hole), float(model.ctc_loss), float(np.mean(model.per))]
+        elif training:
+            vals = [float(model.loss), float(model.loss_func)]
+        else:
+            vals = [float(model.loss_func)] * 2
+        ops.coop_check()                # the float() above synchronised; a cooperative-kernel timeout aborts here
+        return vals
+
+    def accumulate(avg, vals, nframe_sum, frames, first):
+        if first:
+            return list(vals), frames // feat_dim
+        prev = nframe_sum
+        nframe_sum += frames // feat_dim
+        # reference: (avg * prev + value * count // dim) / total, floor division included
+        return [(a * prev + v * frames // feat_dim) / nframe_sum for a, v in zip(avg, vals)], nframe_sum
 
     for _ in range(config['max_n_epochs']):
         epoch_counter += 1
@@ -198,11 +242,15 @@ def train(config_file, checkpoint_format=None):
         nframe_sum = 0
         while True:
             try:
-                feed, _ = unpack_batch(train_it.get_next(), uses_embeddings(config))
+                feed, _ = unpack_batch(train_it.get_next(), uses_embeddings(config), ctc)
             except OutOfRangeError:
                 if chief:
-                    print('Completed epoch {:d} at step {:d} --> Training loss: {:3.5f} - {:3.5f}'.format(
-                        epoch_counter, tot_step, train_avg_loss, train_avg_loss_fn))
+                    if ctc:
+                        print('Completed epoch {:d} at step {:d} --> Training loss: {:3.5f} - {:3.5f} - {:3.5f}; PER: {:3.5f}'
+                              .format(epoch_counter, tot_step, *train_avg))
+                    else:
+                        print('Completed epoch {:d} at step {:d} --> Training loss: {:3.5f} - {:3.5f}'.format(
+                            epoch_counter, tot_step, *train_avg))
                 epoch_duration = time() - epoch_start_time
                 if chief:
                     print('Epoch training time (seconds) = {:.6f}'.format(epoch_duration))
@@ -210,28 +258,22 @@ def train(config_file, checkpoint_format=None):
             n_step += 1
             tot_step += 1
             model.feed(**feed)
-            loss, loss_fn, lr = float(model.loss), float(model.loss_func), model.learning_rate
-            ops.coop_check()                # the float() above synchronised; a cooperative-kernel timeout aborts here
+            vals, lr = fetch(True), model.learning_rate
             model.train_op
-            if np.isnan(loss):
+            if np.isnan(vals[0]):
                 print('GOT INSTABILITY: loss is NaN. Leaving...')
                 sys.exit(1)
-            if np.isinf(loss):
+            if np.isinf(vals[0]):
                 print('GOT INSTABILITY: loss is inf. Leaving...')
                 sys.exit(1)
-            frames = np.count_nonzero(feed['masks'] == 0)
-            if n_step == 1:
-                nframe_sum = frames // feat_dim
-                train_avg_loss, train_avg_loss_fn = loss, loss_fn
-            else:
-                prev = nframe_sum
-                nframe_sum += frames // feat_dim
-                # reference :252-253: (avg * prev + value * count // dim) / total, floor division included
-                train_avg_loss = (train_avg_loss * prev + loss * frames // feat_dim) / nframe_sum
-                train_avg_loss_fn = (train_avg_loss_fn * prev + loss_fn * frames // feat_dim) / nframe_sum
+            train_avg, nframe_sum = accumulate(train_avg, vals, nframe_sum, np.count_nonzero(feed['masks'] == 0), n_step == 1)
             if chief and (n_step % 200 == 0 or n_step == 1):
-                print('Step[{:7d}] Loss[{:3.5f}|{:3.5f}] LR[{:.6f}] Epoch training time[{:.2f}]'.format(
-                    tot_step, train_avg_loss, train_avg_loss_fn, lr, time() - epoch_start_time))
+                if ctc:
+                    print('Step[{:7d}] Loss[{:3.5f}|{:3.5f}|{:3.5f}] PER[{:.5f}] LR[{:.6f}] Epoch training time[{:.2f}]'.format(
+                        tot_step, train_avg[0], train_avg[1], train_avg[2], train_avg[3], lr, time() - epoch_start_time))
+                else:
+                    print('Step[{:7d}] Loss[{:3.5f}|{:3.5f}] LR[{:.6f}] Epoch training time[{:.2f}]'.format(
+                        tot_step, train_avg[0], train_avg[1], lr, time() - epoch_start_time))
             if chief and n_step % 1000 == 0:
                 print('Model checkpoint saved in file %s' % save_checkpoint(os.path.join(checkpoints_dir, 'ckpt')))
 
@@ -243,28 +285,26 @@ def train(config_file, checkpoint_format=None):
         nframe_sum = 0
         while True:
             try:
-                feed, _ = unpack_batch(val_it.get_next(), uses_embeddings(config))
+                feed, _ = unpack_batch(val_it.get_next(), uses_embeddings(config), ctc)
             except OutOfRangeError:
                 break
             n_step += 1
             model.feed(**feed)
-            loss = float(model.loss_func)
-            frames = np.count_nonzero(feed['masks'] == 0)
-            if n_step == 1:
-                nframe_sum = frames // feat_dim
-                val_avg_loss = loss
-            else:
-                prev = nframe_sum
-                nframe_sum += frames // feat_dim
-                val_avg_loss = (val_avg_loss * prev + loss * frames // feat_dim) / nframe_sum
+            val_avg, nframe_sum = accumulate(val_avg, fetch(False), nframe_sum, np.count_nonzero(feed['masks'] == 0),
+                                             n_step == 1)
             if chief and (n_step % 200 == 0 or n_step == 1):
-                print('Step[{:7d}] Loss[{:3.5f}]'.format(n_step, val_avg_loss))
+                print('Step[{:7d}] Loss[{:3.5f}]'.format(n_step, val_avg[1]))
         model.is_training = True
-        (val_avg_loss,) = parallel.all_reduce_mean_scalars([val_avg_loss])
+        val_avg = list(parallel.all_reduce_mean_scalars(val_avg))
+        val_avg_loss = val_avg[1]          # model selection: loss_func (plain) / the inpainting loss (training_ctc.py:383-392)
         if chief:
             print('done.')
-            print('Validation loss: {:3.5f}. Best loss so far {:2.5f} [Epoch {:d} (step {:d})]'.format(
-                val_avg_loss, best_val_loss, best_val_checkpoint[0], best_val_checkpoint[1]))
+            if ctc:
+                print('Validation loss: {:3.5f}; PER: {:3.5f}. Best loss so far {:2.5f} [Epoch {:d} (step {:d})]'.format(
+                    val_avg_loss, val_avg[3], best_val_loss, best_val_checkpoint[0], best_val_checkpoint[1]))
+            else:
+                print('Validation loss: {:3.5f}. Best loss so far {:2.5f} [Epoch {:d} (step {:d})]'.format(
+                    val_avg_loss, best_val_loss, best_val_checkpoint[0], best_val_checkpoint[1]))
         if best_val_checkpoint == (0, 0) or val_avg_loss < best_val_loss:
             if chief:
                 print('Model saved in file %s' % save_checkpoint(os.path.join(checkpoints_dir, 'sinet')))
@@ -275,8 +315,13 @@ def train(config_file, checkpoint_format=None):
             cneg_epochs += 1
         if chief:
             print('')
-        log.write('{:d}\t{:.6f}\t{:.6f}|{:.6f}\t{:.6f}\t[{:.2f}]\n'.format(
-            epoch_counter, lr, train_avg_loss, train_avg_loss_fn, val_avg_loss, epoch_duration))
+        if ctc:
+            log.write('{:d}\t{:.6f}\t{:.6f}|{:.6f}|{:.6f}\t{:.6f}\t{:.6f}|{:.6f}|{:.6f}\t{:.6f}\t[{:.2f}]\n'.format(
+                epoch_counter, lr, train_avg[0], train_avg[1], train_avg[2], train_avg[3], val_avg[0], val_avg[1], val_avg[2],
+                val_avg[3], epoch_duration))
+        else:
+            log.write('{:d}\t{:.6f}\t{:.6f}|{:.6f}\t{:.6f}\t[{:.2f}]\n'.format(
+                epoch_counter, lr, train_avg[0], train_avg[1], val_avg_loss, epoch_duration))
         log.flush()
         if cneg_epochs >= config['n_earlystop_epochs']:
             break

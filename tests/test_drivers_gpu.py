@@ -168,3 +168,43 @@ def test_variant_models_train_and_infer(experiment, tmp_path, model_name, fmt, c
     assert m2.variables.global_step in (2, 4)
     if model_name == 'av-blstm-twosteps':
         assert torch.equal(m2.video_variables.flat, model.video_variables.flat)
+
+
+def test_ctc_multitask_model_trains_and_infers(experiment, tmp_path, capsys):
+    """The multi-task model of the shipped blstm_ctc.config through the drivers (reference
+    training_ctc.py): three-part loss and PER columns in the console and the log, model selection on the
+    inpainting loss, TF checkpoint with both heads, inference without labels."""
+    from avsi_amd import inference, training
+    from avsi_amd import tf_checkpoint as tc
+    base, data, cfg0 = experiment
+    exp = tmp_path / "logs" / "ctc_exp"
+    text = open(cfg0).read().replace("model = av-blstm", "model = v-blstm-ssnn-ctc")
+    text = text.replace("exp_folder = %s" % (base / "logs" / "av_exp0"), "exp_folder = %s" % exp)
+    text = text.replace("max_n_epochs = 3", "max_n_epochs = 2") + "num_asr_labels = 33\nctc_loss = 0.001\n"
+    cfg = tmp_path / "ctc.config"
+    cfg.write_text(text)
+    model = training.train(str(cfg), checkpoint_format='tf')
+    out = capsys.readouterr().out
+    assert model.global_step == 6 and model.num_classes == 34
+    assert "## CTC-loss coefficient: 0.001000" in out
+    step = [l for l in out.splitlines() if l.startswith("Step[      1] Loss[")][0]
+    assert step.count("|") == 2 and "PER[" in step
+    assert "; PER: " in out and "Validation loss: " in out
+    log = (exp / "training_log.txt").read_text().splitlines()
+    assert "Epoch\tLR\tTraining loss\tTraining PER \tValidation loss\tValidation PER[TIME]" in log
+    rows = [l.split("\t") for l in log if l[:1].isdigit()]
+    assert len(rows) == 2 and len(rows[0]) == 7 and rows[0][2].count("|") == 2 and rows[0][4].count("|") == 2
+    total, ipt, ctc = (float(v) for v in rows[0][2].split("|"))
+    # (the reference's running means floor-divide value * frames by the feature size, so the three
+    # columns are only approximately consistent with each other)
+    assert ctc > 0 and ipt > 0 and abs(total - (ipt + 0.001 * ctc)) < 0.1 * total
+    names = [n for n, _, _ in tc.list_variables(str(exp / "netmodel" / "sinet"))]
+    for want in ("v-blstm-ssnn-ctc/inpainting/weights", "v-blstm-ssnn-ctc/asr/weights", "v-blstm-ssnn-ctc/asr/biases",
+                 "v-blstm-ssnn-ctc/speaker_embedding/weights_3", "v-blstm-ssnn-ctc/asr/weights/Adam"):
+        assert want in names, want
+    audio_out = tmp_path / "audio"
+    loss = inference.infer(str(exp / "netmodel"), os.path.join(data, "test-set"), str(audio_out), "ctc", norm=True,
+                           oracle_phase=False, batch_size=2)
+    assert np.isfinite(loss)
+    rate, wav = wavfile.read(str(audio_out / "clip_000" / "enhanced" / "ctc.wav"))
+    assert rate == 16000 and wav.dtype == np.int16 and wav.shape == (T * 192,)

@@ -176,3 +176,29 @@ def test_side_input_and_mlp_layouts():
         # gradient slots: a bijection
         assert len(np.unique(lay.grad_index)) == lay.ref_size and lay.grad_index.max() < lay.gpacked_size
         assert lay.signature() == [257, 250, 3, 257, side_layer, E, -W]
+
+
+def test_asr_head_shares_the_packed_projection():
+    """Multi-task CTC models: the asr columns start at F rounded up to 4 inside the same packed matrix."""
+    lay = ParamLayout(257, asr=34)
+    assert lay.ref_size == ParamLayout(257).ref_size + 500 * 34 + 34
+    assert (lay.asr_col, lay.ldp) == (260, 296)
+    assert lay.packed['pw'][1] == (2 * HP, 296) and lay.gpacked['dpw'][1] == (2 * HP, 296)
+    flat = np.arange(1, lay.ref_size + 1, dtype=np.float64)
+    pw = lay.packed_view(np.concatenate([flat, [0.0]])[lay.pack_index], 'pw')
+    wa = lay.ref_view(flat, 'asr/weights')
+    wi = lay.ref_view(flat, 'logits/weights')
+    np.testing.assert_array_equal(pw[:250, 260:294], wa[:250])
+    np.testing.assert_array_equal(pw[HP:HP + 250, 260:294], wa[250:])
+    np.testing.assert_array_equal(pw[:250, :257], wi[:250])
+    assert not pw[:, 257:260].any() and not pw[:, 294:].any() and not pw[250:HP].any()
+    pb = lay.packed_view(np.concatenate([flat, [0.0]])[lay.pack_index], 'pb')
+    np.testing.assert_array_equal(pb[260:294], lay.ref_view(flat, 'asr/biases'))
+    # gradient index: a bijection onto distinct slots, asr entries inside dpw / dpb
+    assert len(np.unique(lay.grad_index)) == lay.ref_size
+    off, shape = lay.gpacked['dpw']
+    gi = lay.ref_view(lay.grad_index, 'asr/weights')
+    assert gi[0, 0] == off + 260 and gi[250, 3] == off + HP * 296 + 263
+    assert lay.signature()[-1] == -100034
+    with np.testing.assert_raises(ValueError):
+        ParamLayout(257, asr=1)

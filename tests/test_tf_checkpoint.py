@@ -302,3 +302,21 @@ def test_model_save_tf_restore(tmp_path):
     m1.feed(seq, wav, mask)
     m2.feed(seq, wav, mask)
     assert torch.equal(torch.as_tensor(m1.prediction), torch.as_tensor(m2.prediction))
+
+
+def test_multitask_heads_names_and_round_trip(tmp_path):
+    """Two heads of the CTC models: TF scopes inpainting/ and asr/ (reference models.py:1903-1916)."""
+    lay = ParamLayout(9, net_dim=(6, 6), audio_feat_dim=5, asr=4, mlp=8, mlp_in_pitch=16)
+    names = tc.tf_variable_names(lay, 'v-blstm-ssnn-ctc')
+    assert names['logits/weights'] == 'v-blstm-ssnn-ctc/inpainting/weights'
+    assert names['logits/biases'] == 'v-blstm-ssnn-ctc/inpainting/biases'
+    assert names['asr/weights'] == 'v-blstm-ssnn-ctc/asr/weights'
+    assert names['speaker_embedding/weights_1'] == 'v-blstm-ssnn-ctc/speaker_embedding/weights_1'
+    rng = np.random.default_rng(3)
+    flat = rng.standard_normal(lay.ref_size).astype(np.float32)
+    prefix = str(tmp_path / 'sinet')
+    tc.write_bundle(prefix, tc.export_variables(lay, flat, 'v-blstm-ssnn-ctc', global_step=7))
+    f2, m2, v2, step = tc.import_variables(tc.read_bundle(prefix), lay)
+    np.testing.assert_array_equal(f2, flat)
+    assert m2 is None and step == 7
+    assert lay.ref_view(f2, 'asr/weights').shape == (12, 4)
