@@ -12,6 +12,7 @@ LIB_PATH = os.path.join(_HERE, "csrc", "libavsi_hip.so")
 ABI_VERSION = 3
 
 AVSI_OK = 0
+AVSI_ERR_INVALID_ARG, AVSI_ERR_UNSUPPORTED, AVSI_ERR_LAUNCH, AVSI_ERR_WORKSPACE = -1, -2, -3, -4
 
 
 class AvsiError(RuntimeError):
@@ -126,6 +127,10 @@ PROTOTYPES = {
     "avsi_ctc_loss_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
     "avsi_ctc_loss_f32": (c_int, [c_void_p, c_int64, c_int64, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p,
                                   c_int, c_float, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "avsi_sequence_example_shape_host": (c_int, [c_void_p, c_size_t, c_void_p]),
+    "avsi_sequence_example_decode_fixed_host": (c_int, [c_void_p, c_size_t, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
+                                                        c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p,
+                                                        c_void_p]),
     "avsi_ctc_beam_search_host_f32": (c_int, [c_void_p, c_int64, c_int64, c_int, c_int, c_int, c_void_p, c_int, c_int,
                                               c_void_p, c_int, c_void_p, c_void_p]),
 }

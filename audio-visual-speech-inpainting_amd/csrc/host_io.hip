@@ -1,7 +1,8 @@
 // Host-side helper of the TFRecord reader/writer (no device code): CRC-32C (Castagnoli), the
 // checksum of the TFRecord framing that TensorFlow's C++ RecordReader/RecordWriter computes
 // (the reference reads its datasets through tf.data.TFRecordDataset, dataset_reader.py:24).
-// Slicing-by-8, ~1-2 GB/s per core; tables built once, thread-safe via static initialisation.
+// SSE4.2 crc32 instruction when the CPU has it (~8 GB/s per core), else slicing-by-8 (~1-2 GB/s); tables built
+// once, thread-safe via static initialisation.
 #include <stddef.h>
 #include <stdint.h>
 
@@ -20,9 +21,27 @@ struct Crc32cTables {
             for (int s = 1; s < 8; ++s) t[s][i] = (t[s - 1][i] >> 8) ^ t[0][t[s - 1][i] & 0xFF];
     }
 };
+__attribute__((target("sse4.2"))) uint32_t crc32c_hw(const uint8_t* p, size_t n, uint32_t c) {
+    uint64_t c64 = c;
+    while (n && (reinterpret_cast<uintptr_t>(p) & 7)) {
+        c64 = __builtin_ia32_crc32qi((uint32_t)c64, *p++);
+        --n;
+    }
+    while (n >= 8) {
+        uint64_t v;
+        __builtin_memcpy(&v, p, 8);
+        c64 = __builtin_ia32_crc32di(c64, v);
+        p += 8;
+        n -= 8;
+    }
+    while (n--) c64 = __builtin_ia32_crc32qi((uint32_t)c64, *p++);
+    return (uint32_t)c64;
+}
 }  // namespace
 
 extern "C" uint32_t avsi_crc32c(const void* data, size_t n, uint32_t seed) {
+    static const bool have_hw = __builtin_cpu_supports("sse4.2");
+    if (have_hw) return ~crc32c_hw(static_cast<const uint8_t*>(data), n, ~seed);
     static const Crc32cTables T;
     const uint8_t* p = static_cast<const uint8_t*>(data);
     uint32_t c = ~seed;

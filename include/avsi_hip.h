@@ -367,6 +367,26 @@ int avsi_delta_f32(const float* x, float* y, int64_t B, int T, int F, int N, voi
  * stores masked CRC-32C values of the length and payload of every record. */
 uint32_t avsi_crc32c(const void* data, size_t n, uint32_t seed);
 
+/* Host helpers (no GPU work; HOST pointers; re-entrant): the native half of the TFRecord reader.  The
+ * reference parses its samples inside TensorFlow's C++ input pipeline
+ * (tf.parse_single_sequence_example over the 'fixed' schema, dataset_reader.py:62-79, with the
+ * `embedding` context feature in dataset_reader_emb.py:63-81; writer tfrecord_utils.py:19-41).
+ * avsi_sequence_example_shape_host: shape5 = {target_audio_wav samples, embedding size, mask frames,
+ *   video_features frames, labels entries} of one serialized tf.train.SequenceExample.
+ * avsi_sequence_example_decode_fixed_host: parses one record straight into (one row of) the caller's
+ *   batch arrays: lengths2 = {sequence_length, labels_length}; wav_i32 [num_audio_samples] = the float
+ *   samples truncated toward zero (tf.to_int32); embedding [embedding_size] (0 = not read); sample_path
+ *   as a NUL-terminated string; labels [num_labels]; video [num_video_frames][video_feat_size];
+ *   mask [num_frames][audio_feat_size].  AVSI_ERR_INVALID_ARG for a malformed record or a missing
+ *   feature, AVSI_ERR_UNSUPPORTED when its sizes differ from the ones passed (ragged batch). */
+int avsi_sequence_example_shape_host(const void* buf, size_t n, int64_t* shape5);
+int avsi_sequence_example_decode_fixed_host(const void* buf, size_t n, int num_audio_samples,
+                                            int audio_feat_size, int video_feat_size, int embedding_size,
+                                            int num_frames, int num_video_frames, int num_labels,
+                                            int32_t* lengths2, int32_t* wav_i32, float* embedding,
+                                            char* sample_path, int sample_path_cap, float* labels,
+                                            float* video, float* mask);
+
 #ifdef __cplusplus
 }
 #endif

@@ -175,3 +175,80 @@ def test_embedding_reader_and_rank_sharding(tmp_path):
     assert len(b0[0]) == 8 and b0[0][3].shape == (2, 512)
     got = [p for b in (b0[0], b1[0], b0[1]) for p in b[4]]
     assert got == [t[6] for t in truth]
+
+
+@pytest.mark.parametrize("with_emb", [False, True])
+def test_native_decoder_equals_python_parser(tmp_path, with_emb):
+    """avsi_sequence_example_decode_fixed_host (what the iterator uses) against read_data_format_fixed, the
+    pure-Python statement of the schema: same dtypes, shapes and bits, batch by batch."""
+    files, _ = _write_dataset(tmp_path, 5, with_emb=with_emb)
+    dm = dr.DataManager(2304, 257, 136, buffer_size=4, embedding_size=512 if with_emb else None)
+    ds = dm.get_dataset(files, shuffle=False)
+    _, fast = dm.get_iterator(ds, batch_size=2, n_epochs=2)
+    _, slow = dm.get_iterator(ds, batch_size=2, n_epochs=2, native=False, prefetch=0)
+    nb = 0
+    for a, b in zip(fast, slow):
+        nb += 1
+        assert len(a) == len(b) == (8 if with_emb else 7)
+        for x, y in zip(a, b):
+            assert x.dtype == y.dtype and x.shape == y.shape
+            assert (x == y).all()
+    assert nb == 5                                          # 10 examples over two epochs, batches of 2
+
+
+def test_native_decoder_handles_unpacked_lists_missing_video_and_bad_records():
+    """Wire-format corners: unpacked float lists (legal protobuf), a sample without video features,
+    ragged batches and truncated records."""
+    rec, t = _sample(3)
+    dm = dr.DataManager(2304, 257, 136)
+    # re-encode the mask frames with UNPACKED floats (field 1, wire type 5 per value)
+    def unpacked_feature(row):
+        body = b''.join(tio._varint((1 << 3) | 5) + struct.pack('<f', v) for v in row)
+        return tio._ld(2, body)
+    ctx, lists = tio.decode_sequence_example(rec)
+    fl = tio._encode_map({'mask': lists['mask']}, lambda steps: b''.join(tio._ld(1, unpacked_feature(s)) for s in steps))
+    fl += tio._encode_map({'labels': lists['labels']}, lambda steps: b''.join(tio._ld(1, tio.encode_feature(s)) for s in steps))
+    novideo = tio._ld(1, tio._encode_map({k: (v if not isinstance(v, list) else v[0]) for k, v in ctx.items()},
+                                         tio.encode_feature)) + tio._ld(2, fl)
+    out = dm.decode_batch([novideo])
+    ref = dm.read_data_format_fixed(novideo)
+    assert out[5].shape == (1, 0, 136) and ref[5].shape == (0, 136)
+    np.testing.assert_array_equal(out[6][0], t[4])
+    np.testing.assert_array_equal(out[2][0], np.trunc(t[2]).astype(np.int32))
+    # ragged batch: second record has another number of frames
+    other, _ = _sample(4, T=9)
+    with pytest.raises(ValueError, match="sizes of the first"):
+        dm.decode_batch([rec, other])
+    with pytest.raises(ValueError, match="malformed"):
+        dm.decode_batch([rec[:len(rec) // 2]])
+    with pytest.raises(ValueError, match="expected 100"):
+        dr.DataManager(100, 257, 136).decode_batch([rec])
+    with pytest.raises(ValueError):
+        dr.DataManager(2304, 200, 136).decode_batch([rec])          # mask width mismatch
+    with pytest.raises(ValueError):
+        dr.DataManager(2304, 257, 136, embedding_size=512).decode_batch([rec])   # no embedding in the record
+
+
+def test_prefetcher_propagates_errors_and_rewinds(tmp_path):
+    files, truth = _write_dataset(tmp_path, 6)
+    dm = dr.DataManager(2304, 257, 136, buffer_size=2)
+    ds = dm.get_dataset(files, shuffle=False)
+    _, it = dm.get_iterator(ds, batch_size=2, n_epochs=1, prefetch=3)
+    first = it.get_next()
+    it.initializer()                                        # rewind while the background thread is ahead
+    again = it.get_next()
+    assert (first[2] == again[2]).all() and list(first[3]) == list(again[3])
+    assert sum(1 for _ in it) == 2
+    with pytest.raises(dr.OutOfRangeError):
+        it.get_next()
+    with pytest.raises(dr.OutOfRangeError):                 # stays exhausted
+        it.get_next()
+    # a corrupted file surfaces as the reader's IOError on the consumer's thread
+    raw = bytearray(open(files[3], "rb").read())
+    raw[100] ^= 0xFF
+    open(files[3], "wb").write(bytes(raw))
+    _, bad = dm.get_iterator(dm.get_dataset(files, shuffle=False), batch_size=2, n_epochs=1)
+    assert len(bad.get_next()[0]) == 2
+    with pytest.raises(IOError):
+        bad.get_next()
+        bad.get_next()
