@@ -221,6 +221,155 @@ __global__ __launch_bounds__(512, 2) void blstm_rec_fwd_coop_kernel(const CoopAr
     }
 }
 
+// Finer split for the smallest batches (S = 16 or 32 workgroups per (tile, direction)): at S = 8 the 128
+// MFMAs per SIMD and step are 3.2 us of an 7.7 us step, and a batch of 32 .. 256 utterances leaves most of the
+// chip idle, so the slice of a workgroup shrinks to UW = 256 / S = 16 or 8 hidden units.  Its 4 x UW gate
+// columns form NT = 2 or 1 MFMA column tiles (gates (i, j) and (f, o) of 16 units, or all four gates of 8
+// units -- the B fragments are gathered accordingly from the same packed Wh, once); the eight waves split
+// the reduction as before (4 k-groups each), so a wave issues 16 NT MFMAs per step instead of 64.
+template <int NT, bool SAVE>
+__global__ __launch_bounds__(512, 2) void blstm_rec_fwd_coop_fine_kernel(const CoopArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* part = reinterpret_cast<float*>(smem);      // [wave][tile][column][row]
+    __shared__ int dead;
+    constexpr int S = 32 / NT;                         // members per group
+    constexpr int UW = 256 / S;                        // hidden units of this workgroup
+    constexpr int NG = 32 / UW;                        // gates per column tile
+    constexpr int PER = S / 8;                         // members per 32-unit slice
+    constexpr int QPW = 4;
+
+    const int xcd = blockIdx.x % AVSI_NUM_XCD, kk = blockIdx.x / AVSI_NUM_XCD;
+    const int member = kk % S;
+    const int group = (kk / S) * AVSI_NUM_XCD + xcd;
+    if (group >= a.ngroups) return;
+    const int dir = group & 1;
+    const int b0 = (a.tile0 + (group >> 1)) * 32;
+    const int T = a.T, Bp = a.Bp;
+    const int w = member / PER, u0 = (member % PER) * UW;   // slice and first unit inside it
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int ks = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 31, hi = lane >> 5;
+    if (tid == 0) dead = 0;
+
+    // this wave's piece of Wh: column li of tile tl = gate tl * NG + li / UW, unit u0 + li % UW
+    float4 wreg[QPW][NT];
+    {
+        const float4* wp = reinterpret_cast<const float4*>(a.whp) + (size_t)(dir * 8 + w) * (32 * 4 * 64);
+#pragma unroll
+        for (int q = 0; q < QPW; ++q)
+#pragma unroll
+            for (int tl = 0; tl < NT; ++tl)
+                wreg[q][tl] = wp[((ks * QPW + q) * 4 + tl * NG + li / UW) * 64 + hi * 32 + u0 + li % UW];
+    }
+
+    // finishing role: one cell (row frow, unit fu) per lane; with UW = 8 the upper half of the block idles
+    const int fu = tid % UW, frow = tid / UW;
+    const bool fin = frow < 32;
+    float cstate = 0.f;
+
+    unsigned* ctr = a.sync + 1 + 2 * a.tile0 + group;
+    __syncthreads();
+
+    for (int step = 0; step < T; ++step) {
+        const int t = dir ? (T - 1 - step) : step;
+        const int tprev = dir ? t + 1 : t - 1;
+        const size_t row0 = (size_t)t * Bp + b0;
+
+        float xz[4];
+        if (fin)
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+                xz[g] = a.xproj[(row0 + frow) * (2 * GP) + dir * GP + w * 128 + g * 32 + u0 + fu];
+
+        f32x16 acc[NT];
+#pragma unroll
+        for (int tl = 0; tl < NT; ++tl)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[tl][r] = 0.f;
+
+        if (step > 0) {
+            if (tid == 0 && !dead) {
+                const unsigned want = (unsigned)S * (unsigned)step;
+                unsigned polls = 0;
+                while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
+                    __builtin_amdgcn_s_sleep(1);
+                    if (++polls > SPIN_LIMIT) {
+                        dead = 1;
+                        atomicExch(a.sync, 1u);
+                        break;
+                    }
+                }
+            }
+            __syncthreads();
+            const float* hp = a.hout + ((size_t)tprev * Bp + b0 + li) * (2 * HP) + dir * HP + 4 * hi;
+            v4f af[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) coherent_load4_issue(af[q], hp + 8 * ks * QPW, 32 * q);
+            coherent_wait(af);
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int s = 0; s < 4; ++s)
+#pragma unroll
+                    for (int tl = 0; tl < NT; ++tl) {
+                        const float4 b = wreg[q][tl];
+                        const float av = s == 0 ? af[q].x : s == 1 ? af[q].y : s == 2 ? af[q].z : af[q].w;
+                        const float bv = s == 0 ? b.x : s == 1 ? b.y : s == 2 ? b.z : b.w;
+                        acc[tl] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[tl], 0, 0, 0);
+                    }
+        }
+
+        // park the partial tiles: part[ks][tile][column li][row], rows (r&3) + 8 (r>>2) + 4 hi
+#pragma unroll
+        for (int tl = 0; tl < NT; ++tl)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                *reinterpret_cast<float4*>(part + ((ks * NT + tl) * 32 + li) * PSTRIDE + 8 * j + 4 * hi) =
+                    make_float4(acc[tl][4 * j], acc[tl][4 * j + 1], acc[tl][4 * j + 2], acc[tl][4 * j + 3]);
+        __syncthreads();
+
+        if (fin) {
+            float z[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                float sum = xz[g];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) sum += part[((k * NT + g / NG) * 32 + (g % NG) * UW + fu) * PSTRIDE + frow];
+                z[g] = sum;
+            }
+            const float ig = sigmoidf_fast(z[0]), jg = tanhf_fast(z[1]), fg = sigmoidf_fast(z[2]), og = sigmoidf_fast(z[3]);
+            const float cn = fg * cstate + ig * jg;
+            cstate = cn;
+            const float hn = og * tanhf_fast(cn);
+            const int unit = w * 32 + u0 + fu;
+            __hip_atomic_store(a.hout + (row0 + frow) * (2 * HP) + dir * HP + unit, hn, __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
+            if (SAVE) {
+                float* rv = a.resv + (row0 + frow) * (2 * 5 * HP) + dir * 5 * HP + unit;
+                rv[0 * HP] = ig, rv[1 * HP] = jg, rv[2 * HP] = fg, rv[3 * HP] = og, rv[4 * HP] = cn;
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
+template <int NT, bool SAVE>
+int launch_coop_fine(const CoopArgs& a, hipStream_t st) {
+    constexpr int S = 32 / NT;
+    // > half of the CU's LDS on purpose: one workgroup per CU, so the members of a group spread over S CUs
+    const size_t lds = 96 * 1024;
+    static_assert((size_t)8 * NT * 32 * PSTRIDE * sizeof(float) <= 96 * 1024, "partial tiles must fit");
+    (void)hipFuncSetAttribute((const void*)blstm_rec_fwd_coop_fine_kernel<NT, SAVE>,
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    const int blocks = (int)avsi_ceil_div(a.ngroups, AVSI_NUM_XCD) * AVSI_NUM_XCD * S;
+    hipLaunchKernelGGL((blstm_rec_fwd_coop_fine_kernel<NT, SAVE>), dim3(blocks), dim3(512), lds, st, a);
+    return avsi_launch_status();
+}
+
 template <int S, bool SAVE>
 int launch_coop(const CoopArgs& a, hipStream_t st) {
     const size_t lds = (size_t)PART_FLOATS * sizeof(float);
@@ -243,7 +392,7 @@ static int coop_tiles_per_launch(int split) { return (AVSI_NUM_CU / split / AVSI
 extern "C" int avsi_blstm_rec_fwd_coop_f32(const float* xproj, const float* whp, float* hout, float* reserve, int T, int Bp,
                                            int split, void* workspace, size_t workspace_bytes, void* stream) {
     if (!xproj || !whp || !hout || T <= 0 || Bp <= 0 || (Bp & 31)) return AVSI_ERR_INVALID_ARG;
-    if (split != 4 && split != 8) return AVSI_ERR_INVALID_ARG;
+    if (split != 4 && split != 8 && split != 16 && split != 32) return AVSI_ERR_INVALID_ARG;
     if (!workspace || workspace_bytes < avsi_blstm_rec_fwd_coop_workspace_bytes(Bp)) return AVSI_ERR_WORKSPACE;
     const hipStream_t st = (hipStream_t)stream;
     avsi_clear_error();
@@ -255,7 +404,11 @@ extern "C" int avsi_blstm_rec_fwd_coop_f32(const float* xproj, const float* whp,
         const int nt = tiles - tile0 < per ? tiles - tile0 : per;
         CoopArgs a{xproj, whp, hout, reserve, (unsigned*)workspace, T, Bp, 2 * nt, tile0};
         int rc;
-        if (split == 8)
+        if (split == 32)
+            rc = reserve ? launch_coop_fine<1, true>(a, st) : launch_coop_fine<1, false>(a, st);
+        else if (split == 16)
+            rc = reserve ? launch_coop_fine<2, true>(a, st) : launch_coop_fine<2, false>(a, st);
+        else if (split == 8)
             rc = reserve ? launch_coop<8, true>(a, st) : launch_coop<8, false>(a, st);
         else
             rc = reserve ? launch_coop<4, true>(a, st) : launch_coop<4, false>(a, st);
@@ -409,22 +562,153 @@ __global__ __launch_bounds__(512, 2) void blstm_rec_bwd_coop_kernel(const CoopBw
     }
 }
 
+// Finer split of the BPTT kernel (S = 16: a workgroup owns 16 units of dh), the counterpart of
+// blstm_rec_fwd_coop_fine_kernel.  A 32x32x2 tile would leave half its columns empty, so this kernel uses
+// v_mfma_f32_16x16x4_f32 (same rate: 64 flop / cycle / SIMD): two 16-row tiles x 16 units, the eight waves
+// split the 1024 packed gate columns (128 each); a lane's float4 of dz covers four consecutive columns, used
+// as the k-slices of four MFMAs, and its 32 weights Wh[unit][those columns] are gathered once from the same
+// whbT operand.  64 short MFMAs per wave and step instead of 64 long ones.
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+__global__ __launch_bounds__(512, 2) void blstm_rec_bwd_coop_fine_kernel(const CoopBwdArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem_b[];
+    float* part = reinterpret_cast<float*>(smem_b);    // [wave][unit 16][row 32 (+4 pad)]
+    __shared__ int dead;
+    constexpr int S = 16, UW = 16;
+
+    const int xcd = blockIdx.x % AVSI_NUM_XCD, kk = blockIdx.x / AVSI_NUM_XCD;
+    const int member = kk % S;
+    const int group = (kk / S) * AVSI_NUM_XCD + xcd;
+    if (group >= a.ngroups) return;
+    const int dir = group & 1;
+    const int b0 = (a.tile0 + (group >> 1)) * 32;
+    const int T = a.T, Bp = a.Bp;
+    const int w = member >> 1, u0 = (member & 1) * UW;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int ks = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l16 = lane & 15, kq = lane >> 4;
+    if (tid == 0) dead = 0;
+
+    // Wh[unit 32 w + u0 + l16][packed column ks * 128 + 16 j + 4 kq + s] out of whbT [2][8 w][128 q][64 lane][4 s]
+    float wreg[8][4];
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) {
+            const int c = ks * 128 + 16 * j + 4 * kq + s4;
+            wreg[j][s4] = a.whbT[((((size_t)(dir * 8 + w) * 128 + (c >> 3)) * 64 + ((c & 7) >> 2) * 32 + u0 + l16) << 2) + (c & 3)];
+        }
+
+    const int fu = tid & 15, frow = tid >> 4;          // one cell per lane
+    const int unit = w * 32 + u0 + fu;
+    float dcn = 0.f;
+    unsigned* ctr = a.sync + 1 + 2 * a.tile0 + group;
+    __syncthreads();
+
+    for (int s = 0; s < T; ++s) {
+        const int t = dir ? s : (T - 1 - s);
+        const int tnext = dir ? t - 1 : t + 1;
+        const int tp = dir ? t + 1 : t - 1;
+        const bool has_prev = dir ? (t + 1 < T) : (t > 0);
+        const size_t row0 = (size_t)t * Bp + b0;
+
+        const size_t row = row0 + frow;
+        const float* rv = a.resv + row * (2 * 5 * HP) + dir * 5 * HP + unit;
+        const float dh = a.dhout[row * (2 * HP) + dir * HP + unit];
+        const float ig = rv[0 * HP], jg = rv[1 * HP], fg = rv[2 * HP], og = rv[3 * HP], cc = rv[4 * HP];
+        const float cp = has_prev ? a.resv[((size_t)tp * Bp + b0 + frow) * (2 * 5 * HP) + dir * 5 * HP + 4 * HP + unit] : 0.f;
+
+        f32x4 acc[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[i][r] = 0.f;
+        if (s > 0) {
+            if (tid == 0 && !dead) {
+                const unsigned want = (unsigned)S * (unsigned)s;
+                unsigned polls = 0;
+                while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
+                    __builtin_amdgcn_s_sleep(1);
+                    if (++polls > SPIN_LIMIT) {
+                        dead = 1;
+                        atomicExch(a.sync, 1u);
+                        break;
+                    }
+                }
+            }
+            __syncthreads();
+            // rows l16 and 16 + l16 of the tile, columns ks * 128 + 16 j + 4 kq .. + 3
+            const float* zp = a.dz + ((size_t)tnext * Bp + b0 + l16) * (2 * GP) + dir * GP + ks * 128 + 4 * kq;
+            const float* zq = zp + (size_t)16 * (2 * GP);
+            // (starting the MFMAs on the first loads while the rest is still landing -- staged vmcnt waits -- was slower)
+            v4f a0[8], a1[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) coherent_load4_issue(a0[j], zp, 64 * j);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) coherent_load4_issue(a1[j], zq, 64 * j);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                asm volatile("" : "+v"(a0[j]));
+                asm volatile("" : "+v"(a1[j]));
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+#pragma unroll
+                for (int s4 = 0; s4 < 4; ++s4) {
+                    const float x0 = s4 == 0 ? a0[j].x : s4 == 1 ? a0[j].y : s4 == 2 ? a0[j].z : a0[j].w;
+                    const float x1 = s4 == 0 ? a1[j].x : s4 == 1 ? a1[j].y : s4 == 2 ? a1[j].z : a1[j].w;
+                    acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(x0, wreg[j][s4], acc[0], 0, 0, 0);
+                    acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(x1, wreg[j][s4], acc[1], 0, 0, 0);
+                }
+        }
+        // D: lane holds rows 4 kq .. 4 kq + 3 of column (unit) l16
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+            *reinterpret_cast<float4*>(part + (ks * UW + l16) * PSTRIDE + 16 * i + 4 * kq) =
+                make_float4(acc[i][0], acc[i][1], acc[i][2], acc[i][3]);
+        __syncthreads();
+
+        float d = dh;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) d += part[(k * UW + fu) * PSTRIDE + frow];
+        const float tc = 2.f * __builtin_amdgcn_rcpf(1.f + __expf(-2.f * cc)) - 1.f;
+        const float dc = d * og * (1.f - tc * tc) + dcn;
+        dcn = dc * fg;
+        float* zo = a.dz + row * (2 * GP) + dir * GP + w * 128 + u0 + fu;
+        __hip_atomic_store(zo + 0, dc * jg * ig * (1.f - ig), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(zo + 32, dc * ig * (1.f - jg * jg), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(zo + 64, dc * cp * fg * (1.f - fg), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(zo + 96, d * tc * og * (1.f - og), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
 }  // namespace
 
 extern "C" int avsi_blstm_rec_bwd_coop_f32(const float* dhout, const float* reserve, const float* whbT, float* dz, int T,
                                            int Bp, int split, void* workspace, size_t workspace_bytes, void* stream) {
     if (!dhout || !reserve || !whbT || !dz || T <= 0 || Bp <= 0 || (Bp & 31)) return AVSI_ERR_INVALID_ARG;
-    if (split != 4 && split != 8) return AVSI_ERR_INVALID_ARG;
+    if (split != 4 && split != 8 && split != 16) return AVSI_ERR_INVALID_ARG;
     if (!workspace || workspace_bytes < avsi_blstm_rec_fwd_coop_workspace_bytes(Bp)) return AVSI_ERR_WORKSPACE;
     const hipStream_t st = (hipStream_t)stream;
     avsi_clear_error();
     if (hipMemsetAsync(workspace, 0, avsi_blstm_rec_fwd_coop_workspace_bytes(Bp), st) != hipSuccess) return AVSI_ERR_LAUNCH;
+    if (split == 16)
+        (void)hipFuncSetAttribute((const void*)blstm_rec_bwd_coop_fine_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  96 * 1024);
     const int tiles = Bp / 32, per = coop_tiles_per_launch(split);
     for (int tile0 = 0; tile0 < tiles; tile0 += per) {
         const int nt = tiles - tile0 < per ? tiles - tile0 : per;
         CoopBwdArgs a{dhout, reserve, whbT, dz, (unsigned*)workspace, T, Bp, 2 * nt, tile0};
         const int blocks = (int)avsi_ceil_div(2 * nt, AVSI_NUM_XCD) * AVSI_NUM_XCD * split;
-        if (split == 8)
+        if (split == 16)     // 96 KiB of LDS requested on purpose: one workgroup per CU (it uses 18 KiB)
+            hipLaunchKernelGGL(blstm_rec_bwd_coop_fine_kernel, dim3(blocks), dim3(512), 96 * 1024, st, a);
+        else if (split == 8)
             hipLaunchKernelGGL(blstm_rec_bwd_coop_kernel<8>, dim3(blocks), dim3(512), 0, st, a);
         else
             hipLaunchKernelGGL(blstm_rec_bwd_coop_kernel<4>, dim3(blocks), dim3(512), 0, st, a);

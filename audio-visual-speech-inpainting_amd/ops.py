@@ -97,11 +97,17 @@ def _coop_after_launch(device, ws):
     event.record()
 
 
-def coop_split(Bp):
-    """Workgroups per (32-utterance tile, direction) of the small-batch recurrent kernel, 0 = use the
-    batch-stationary kernels.  The cooperative grid must be resident on the 256 CUs at once."""
+def coop_split(Bp, backward=False):
+    """Workgroups per (32-utterance tile, direction) of the small-batch recurrent kernels, 0 = use the
+    batch-stationary kernels.  The cooperative grid must be resident on the 256 CUs at once, and the
+    fewer utterances there are, the finer the hidden state is cut (measured per layer, T = 250:
+    Bp = 32: 1.81 ms at 8, 1.04 at 16, 0.83 at 32; Bp = 256: 1.89 / 1.37 / 2.78)."""
     if os.environ.get('AVSI_REC_COOP', '1') == '0':
         return 0
+    if Bp <= 64 and not backward:
+        return 32
+    if Bp <= 256:
+        return 16
     return 8 if Bp <= 512 else (4 if Bp <= 2048 else 0)      # 1024 < Bp <= 2048: two resident-sized launches
 
 
@@ -296,7 +302,7 @@ def blstm_rec_bwd(dhout, reserve, whbt, dz, split=None):
           and tuple(dz.shape) == (T, Bp, 2048) and whbt.numel() == 2 * 262144)
     if not ok or not (dhout.is_contiguous() and reserve.is_contiguous() and dz.is_contiguous() and whbt.is_contiguous()):
         raise _lib.AvsiError("blstm_rec_bwd: bad operand shapes / strides")
-    split = coop_split(Bp) if split is None else int(split)
+    split = coop_split(Bp, backward=True) if split is None else int(split)
     if split:
         ws = _coop_ws(dhout.device, Bp)
         _lib.check(_lib.lib().avsi_blstm_rec_bwd_coop_f32(_lib.ptr(dhout), _lib.ptr(reserve), _lib.ptr(whbt), _lib.ptr(dz),
