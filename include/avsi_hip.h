@@ -142,11 +142,11 @@ int avsi_l1_loss_f32(const float* target, const float* pred, const float* mask, 
                      size_t workspace_bytes, void* stream);
 
 /* Small-batch form of avsi_blstm_rec_fwd_f32 (same operands and results): every (32-utterance
- * tile, direction) pair is spread over `split` = 4 or 8 workgroups that keep their piece of the
+ * tile, direction) pair is spread over `split` = 4, 8, 16 or 32 workgroups that keep their piece of the
  * recurrent kernel in registers for all T steps and exchange h_t through hout with a per-step
  * counter in `workspace` (avsi_blstm_rec_fwd_coop_workspace_bytes(Bp) bytes, zeroed by the call).
- * A launch must be wholly resident (one workgroup per CU), so batches beyond 512 (split 8) /
- * 1024 (split 4) utterances run as consecutive launches over tile ranges.  After the stream has drained, word 0 of the
+ * A launch must be wholly resident (one workgroup per CU), so batches beyond 128 (split 32) / 256 (16) /
+ * 512 (8) / 1024 (4) utterances run as consecutive launches over tile ranges.  After the stream has drained, word 0 of the
  * workspace is 0; a non-zero value means a workgroup stopped waiting for its peers (bounded spin)
  * and the outputs are invalid. */
 size_t avsi_blstm_rec_fwd_coop_workspace_bytes(int Bp);
@@ -155,7 +155,7 @@ int avsi_blstm_rec_fwd_coop_f32(const float* xproj, const float* whp, float* hou
                                 void* stream);
 
 /* Small-batch form of avsi_blstm_rec_bwd_f32 (same operands and results), the gradient of the
- * cooperative forward above: same group / split / workspace / residency rules, dz doubles as the
+ * cooperative forward above: same group / split (4, 8 or 16) / workspace / residency rules, dz doubles as the
  * exchange buffer between the workgroups of a group. */
 int avsi_blstm_rec_bwd_coop_f32(const float* dhout, const float* reserve, const float* whbT, float* dz,
                                 int T, int Bp, int split, void* workspace, size_t workspace_bytes,
