@@ -382,8 +382,9 @@ int launch_coop(const CoopArgs& a, hipStream_t st) {
 
 }  // namespace
 
+// word 0: status, then step counters: one per (tile, direction), two for the half-tile BPTT kernel
 extern "C" size_t avsi_blstm_rec_fwd_coop_workspace_bytes(int Bp) {
-    return (size_t)(1 + 2 * (Bp > 0 ? Bp / 32 : 0)) * sizeof(unsigned);
+    return (size_t)(1 + 4 * (Bp > 0 ? Bp / 32 : 0)) * sizeof(unsigned);
 }
 
 // Tiles per launch: the whole launch must be resident (one workgroup per CU)
@@ -570,18 +571,23 @@ __global__ __launch_bounds__(512, 2) void blstm_rec_bwd_coop_kernel(const CoopBw
 // whbT operand.  64 short MFMAs per wave and step instead of 64 long ones.
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+// RH = 2: the 32 utterances of a tile are two independent halves of 16 with 16 workgroups each (32 per
+// (tile, direction)): one MFMA row tile and half the dz rows per workgroup.
+template <int RH>
 __global__ __launch_bounds__(512, 2) void blstm_rec_bwd_coop_fine_kernel(const CoopBwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem_b[];
     float* part = reinterpret_cast<float*>(smem_b);    // [wave][unit 16][row 32 (+4 pad)]
     __shared__ int dead;
-    constexpr int S = 16, UW = 16;
+    constexpr int S = 16, UW = 16;                      // members that exchange with each other, units per member
+    constexpr int NR = 2 / RH;                         // 16-row MFMA tiles per workgroup
 
     const int xcd = blockIdx.x % AVSI_NUM_XCD, kk = blockIdx.x / AVSI_NUM_XCD;
-    const int member = kk % S;
-    const int group = (kk / S) * AVSI_NUM_XCD + xcd;
+    const int mem_all = kk % (S * RH);
+    const int member = mem_all % S, half = mem_all / S;
+    const int group = (kk / (S * RH)) * AVSI_NUM_XCD + xcd;
     if (group >= a.ngroups) return;
     const int dir = group & 1;
-    const int b0 = (a.tile0 + (group >> 1)) * 32;
+    const int b0 = (a.tile0 + (group >> 1)) * 32 + half * 16;
     const int T = a.T, Bp = a.Bp;
     const int w = member >> 1, u0 = (member & 1) * UW;
 
@@ -601,10 +607,11 @@ __global__ __launch_bounds__(512, 2) void blstm_rec_bwd_coop_fine_kernel(const C
             wreg[j][s4] = a.whbT[((((size_t)(dir * 8 + w) * 128 + (c >> 3)) * 64 + ((c & 7) >> 2) * 32 + u0 + l16) << 2) + (c & 3)];
         }
 
-    const int fu = tid & 15, frow = tid >> 4;          // one cell per lane
+    const int fu = tid & 15, frow = tid >> 4;          // one cell per lane (RH = 2: the upper half of the block idles)
+    const bool fin = frow < 16 * NR;
     const int unit = w * 32 + u0 + fu;
     float dcn = 0.f;
-    unsigned* ctr = a.sync + 1 + 2 * a.tile0 + group;
+    unsigned* ctr = a.sync + 1 + RH * (2 * a.tile0 + group) + half;
     __syncthreads();
 
     for (int s = 0; s < T; ++s) {
@@ -614,15 +621,18 @@ __global__ __launch_bounds__(512, 2) void blstm_rec_bwd_coop_fine_kernel(const C
         const bool has_prev = dir ? (t + 1 < T) : (t > 0);
         const size_t row0 = (size_t)t * Bp + b0;
 
-        const size_t row = row0 + frow;
+        const size_t row = row0 + (fin ? frow : 0);
         const float* rv = a.resv + row * (2 * 5 * HP) + dir * 5 * HP + unit;
-        const float dh = a.dhout[row * (2 * HP) + dir * HP + unit];
-        const float ig = rv[0 * HP], jg = rv[1 * HP], fg = rv[2 * HP], og = rv[3 * HP], cc = rv[4 * HP];
-        const float cp = has_prev ? a.resv[((size_t)tp * Bp + b0 + frow) * (2 * 5 * HP) + dir * 5 * HP + 4 * HP + unit] : 0.f;
+        float dh = 0.f, ig = 0.f, jg = 0.f, fg = 0.f, og = 0.f, cc = 0.f, cp = 0.f;
+        if (fin) {
+            dh = a.dhout[row * (2 * HP) + dir * HP + unit];
+            ig = rv[0 * HP], jg = rv[1 * HP], fg = rv[2 * HP], og = rv[3 * HP], cc = rv[4 * HP];
+            cp = has_prev ? a.resv[((size_t)tp * Bp + b0 + frow) * (2 * 5 * HP) + dir * 5 * HP + 4 * HP + unit] : 0.f;
+        }
 
-        f32x4 acc[2];
+        f32x4 acc[NR];
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < NR; ++i)
 #pragma unroll
             for (int r = 0; r < 4; ++r) acc[i][r] = 0.f;
         if (s > 0) {
@@ -646,42 +656,47 @@ __global__ __launch_bounds__(512, 2) void blstm_rec_bwd_coop_fine_kernel(const C
             v4f a0[8], a1[8];
 #pragma unroll
             for (int j = 0; j < 8; ++j) coherent_load4_issue(a0[j], zp, 64 * j);
+            if (NR == 2)
 #pragma unroll
-            for (int j = 0; j < 8; ++j) coherent_load4_issue(a1[j], zq, 64 * j);
+                for (int j = 0; j < 8; ++j) coherent_load4_issue(a1[j], zq, 64 * j);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 asm volatile("" : "+v"(a0[j]));
-                asm volatile("" : "+v"(a1[j]));
+                if (NR == 2) asm volatile("" : "+v"(a1[j]));
             }
 #pragma unroll
             for (int j = 0; j < 8; ++j)
 #pragma unroll
                 for (int s4 = 0; s4 < 4; ++s4) {
                     const float x0 = s4 == 0 ? a0[j].x : s4 == 1 ? a0[j].y : s4 == 2 ? a0[j].z : a0[j].w;
-                    const float x1 = s4 == 0 ? a1[j].x : s4 == 1 ? a1[j].y : s4 == 2 ? a1[j].z : a1[j].w;
                     acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(x0, wreg[j][s4], acc[0], 0, 0, 0);
-                    acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(x1, wreg[j][s4], acc[1], 0, 0, 0);
+                    if (NR == 2) {
+                        const float x1 = s4 == 0 ? a1[j].x : s4 == 1 ? a1[j].y : s4 == 2 ? a1[j].z : a1[j].w;
+                        acc[NR - 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(x1, wreg[j][s4], acc[NR - 1], 0, 0, 0);
+                    }
                 }
         }
         // D: lane holds rows 4 kq .. 4 kq + 3 of column (unit) l16
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < NR; ++i)
             *reinterpret_cast<float4*>(part + (ks * UW + l16) * PSTRIDE + 16 * i + 4 * kq) =
                 make_float4(acc[i][0], acc[i][1], acc[i][2], acc[i][3]);
         __syncthreads();
 
-        float d = dh;
+        if (fin) {
+            float d = dh;
 #pragma unroll
-        for (int k = 0; k < 8; ++k) d += part[(k * UW + fu) * PSTRIDE + frow];
-        const float tc = 2.f * __builtin_amdgcn_rcpf(1.f + __expf(-2.f * cc)) - 1.f;
-        const float dc = d * og * (1.f - tc * tc) + dcn;
-        dcn = dc * fg;
-        float* zo = a.dz + row * (2 * GP) + dir * GP + w * 128 + u0 + fu;
-        __hip_atomic_store(zo + 0, dc * jg * ig * (1.f - ig), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(zo + 32, dc * ig * (1.f - jg * jg), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(zo + 64, dc * cp * fg * (1.f - fg), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(zo + 96, d * tc * og * (1.f - og), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            for (int k = 0; k < 8; ++k) d += part[(k * UW + fu) * PSTRIDE + frow];
+            const float tc = 2.f * __builtin_amdgcn_rcpf(1.f + __expf(-2.f * cc)) - 1.f;
+            const float dc = d * og * (1.f - tc * tc) + dcn;
+            dcn = dc * fg;
+            float* zo = a.dz + row * (2 * GP) + dir * GP + w * 128 + u0 + fu;
+            __hip_atomic_store(zo + 0, dc * jg * ig * (1.f - ig), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(zo + 32, dc * ig * (1.f - jg * jg), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(zo + 64, dc * cp * fg * (1.f - fg), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(zo + 96, d * tc * og * (1.f - og), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (tid == 0) __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -693,21 +708,26 @@ __global__ __launch_bounds__(512, 2) void blstm_rec_bwd_coop_fine_kernel(const C
 extern "C" int avsi_blstm_rec_bwd_coop_f32(const float* dhout, const float* reserve, const float* whbT, float* dz, int T,
                                            int Bp, int split, void* workspace, size_t workspace_bytes, void* stream) {
     if (!dhout || !reserve || !whbT || !dz || T <= 0 || Bp <= 0 || (Bp & 31)) return AVSI_ERR_INVALID_ARG;
-    if (split != 4 && split != 8 && split != 16) return AVSI_ERR_INVALID_ARG;
+    if (split != 4 && split != 8 && split != 16 && split != 32) return AVSI_ERR_INVALID_ARG;
     if (!workspace || workspace_bytes < avsi_blstm_rec_fwd_coop_workspace_bytes(Bp)) return AVSI_ERR_WORKSPACE;
     const hipStream_t st = (hipStream_t)stream;
     avsi_clear_error();
     if (hipMemsetAsync(workspace, 0, avsi_blstm_rec_fwd_coop_workspace_bytes(Bp), st) != hipSuccess) return AVSI_ERR_LAUNCH;
     if (split == 16)
-        (void)hipFuncSetAttribute((const void*)blstm_rec_bwd_coop_fine_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+        (void)hipFuncSetAttribute((const void*)blstm_rec_bwd_coop_fine_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  96 * 1024);
+    if (split == 32)
+        (void)hipFuncSetAttribute((const void*)blstm_rec_bwd_coop_fine_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                   96 * 1024);
     const int tiles = Bp / 32, per = coop_tiles_per_launch(split);
     for (int tile0 = 0; tile0 < tiles; tile0 += per) {
         const int nt = tiles - tile0 < per ? tiles - tile0 : per;
         CoopBwdArgs a{dhout, reserve, whbT, dz, (unsigned*)workspace, T, Bp, 2 * nt, tile0};
         const int blocks = (int)avsi_ceil_div(2 * nt, AVSI_NUM_XCD) * AVSI_NUM_XCD * split;
-        if (split == 16)     // 96 KiB of LDS requested on purpose: one workgroup per CU (it uses 18 KiB)
-            hipLaunchKernelGGL(blstm_rec_bwd_coop_fine_kernel, dim3(blocks), dim3(512), 96 * 1024, st, a);
+        if (split == 32)     // 16 unit slices x 2 row halves
+            hipLaunchKernelGGL(blstm_rec_bwd_coop_fine_kernel<2>, dim3(blocks), dim3(512), 96 * 1024, st, a);
+        else if (split == 16)     // 96 KiB of LDS requested on purpose: one workgroup per CU (it uses 18 KiB)
+            hipLaunchKernelGGL(blstm_rec_bwd_coop_fine_kernel<1>, dim3(blocks), dim3(512), 96 * 1024, st, a);
         else if (split == 8)
             hipLaunchKernelGGL(blstm_rec_bwd_coop_kernel<8>, dim3(blocks), dim3(512), 0, st, a);
         else

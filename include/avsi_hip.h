@@ -155,8 +155,9 @@ int avsi_blstm_rec_fwd_coop_f32(const float* xproj, const float* whp, float* hou
                                 void* stream);
 
 /* Small-batch form of avsi_blstm_rec_bwd_f32 (same operands and results), the gradient of the
- * cooperative forward above: same group / split (4, 8 or 16) / workspace / residency rules, dz doubles as the
- * exchange buffer between the workgroups of a group. */
+ * cooperative forward above: same group / split / workspace / residency rules (split 32 here = 16 slices of
+ * the hidden state x 2 halves of the tile's 32 utterances), dz doubles as the exchange buffer between the
+ * workgroups of a group. */
 int avsi_blstm_rec_bwd_coop_f32(const float* dhout, const float* reserve, const float* whbT, float* dz,
                                 int T, int Bp, int split, void* workspace, size_t workspace_bytes,
                                 void* stream);

@@ -177,11 +177,12 @@ def test_cooperative_small_batch_kernel_matches_batch_stationary(Bp, split, save
     np.testing.assert_allclose(outs[1][0].cpu().numpy(), outs[0][0].cpu().numpy(), rtol=0, atol=2e-5)
     if save:
         np.testing.assert_allclose(outs[1][1].cpu().numpy(), outs[0][1].cpu().numpy(), rtol=0, atol=5e-5)
-    assert ops.coop_split(32) == 32 and ops.coop_split(32, backward=True) == 16 and ops.coop_split(256) == 16
+    assert ops.coop_split(32) == 32 and ops.coop_split(32, backward=True) == 32 and ops.coop_split(256) == 16
+    assert ops.coop_split(256, backward=True) == 8
     assert ops.coop_split(512) == 8 and ops.coop_split(1024) == 4 and ops.coop_split(2048) == 4 and ops.coop_split(4096) == 0
 
 
-@pytest.mark.parametrize("Bp,split", [(32, 8), (256, 8), (1024, 4), (64, 4), (1088, 4), (32, 16), (256, 16), (288, 16)])
+@pytest.mark.parametrize("Bp,split", [(32, 8), (256, 8), (1024, 4), (64, 4), (1088, 4), (32, 16), (256, 16), (288, 16), (32, 32), (128, 32), (160, 32)])
 def test_cooperative_bptt_matches_batch_stationary(Bp, split):
     import torch
     import avsi_amd  # noqa: F401

@@ -13,7 +13,7 @@ for Bp in (32, 64, 128, 256, 512):
     whbt = torch.randn(2 * 262144, device='cuda') * 0.05
     dz = torch.empty(T, Bp, 2048, device='cuda')
     line = []
-    for sp in (0, 4, 8, 16):
+    for sp in (0, 4, 8, 16, 32):
         for _ in range(2):
             ops.blstm_rec_bwd(dh, resv, whbt, dz, split=sp)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
