@@ -107,12 +107,20 @@ def coop_split(Bp, backward=False):
     if backward:
         # BPTT: 16 unit slices x 2 halves of 16 utterances up to four tiles (1.08 ms per layer at Bp = 32
         # against 1.76 at 8), then the 8-way kernel
-        return 32 if Bp <= 128 else (8 if Bp <= 512 else (4 if Bp <= 2048 else 0))
-    if Bp <= 64:
-        return 32
-    if Bp <= 256:
-        return 16
-    return 8 if Bp <= 512 else (4 if Bp <= 2048 else 0)      # 1024 < Bp <= 2048: two resident-sized launches
+        split = 32 if Bp <= 128 else (8 if Bp <= 512 else (4 if Bp <= 2048 else 0))
+    elif Bp <= 64:
+        split = 32
+    elif Bp <= 256:
+        split = 16
+    else:
+        split = 8 if Bp <= 512 else (4 if Bp <= 2048 else 0)      # 1024 < Bp <= 2048: two resident-sized launches
+    # AVSI_COOP_CUS: CUs one cooperative launch may occupy (default: the chip).  Every member of a launch must be
+    # resident together, so a process that keeps several small batches in flight on different streams should
+    # divide the 256 CUs between them (8 streams: 32); the bounded spin catches an over-subscription anyway.
+    budget = int(os.environ.get('AVSI_COOP_CUS', '256'))
+    while split > 4 and 2 * (Bp // 32) * split > budget:
+        split //= 2
+    return split
 
 
 def coop_poll(device=None):

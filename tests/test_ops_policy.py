@@ -1,0 +1,22 @@
+"""Host-side kernel selection of the recurrent layers (pure Python, no GPU work)."""
+import avsi_amd  # noqa: F401
+from avsi_amd import ops
+
+
+def test_cooperative_split_policy(monkeypatch):
+    monkeypatch.delenv('AVSI_COOP_CUS', raising=False)
+    monkeypatch.delenv('AVSI_REC_COOP', raising=False)
+    fwd = {b: ops.coop_split(b) for b in (32, 64, 96, 256, 288, 512, 544, 2048, 2080)}
+    assert fwd == {32: 32, 64: 32, 96: 16, 256: 16, 288: 8, 512: 8, 544: 4, 2048: 4, 2080: 0}
+    bwd = {b: ops.coop_split(b, backward=True) for b in (32, 128, 160, 512, 544, 2048, 4096)}
+    assert bwd == {32: 32, 128: 32, 160: 8, 512: 8, 544: 4, 2048: 4, 4096: 0}
+    # every single-launch choice fits the chip: members = 2 directions x tiles x split <= 256 CUs
+    for b in range(32, 513, 32):
+        for back in (False, True):
+            assert 2 * (b // 32) * ops.coop_split(b, back) <= 256, (b, back)
+    # a process that shares the chip between 8 streams gives each launch 32 CUs
+    monkeypatch.setenv('AVSI_COOP_CUS', '32')
+    assert ops.coop_split(32) == 16 and ops.coop_split(32, backward=True) == 16 and ops.coop_split(64) == 8
+    assert ops.coop_split(256) == 4                        # never below the coarsest cooperative kernel
+    monkeypatch.setenv('AVSI_REC_COOP', '0')
+    assert ops.coop_split(32) == 0

@@ -1,11 +1,12 @@
 """Independent small batches on several streams (serving pattern): python tools/multistream_small_batch.py [streams]"""
 import sys, time
-sys.path.insert(0, '/root/repo')
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 import avsi_amd
 from avsi_amd import models
 from avsi_amd import audio_processing as ap
 B, NS = 32, int(sys.argv[1]) if len(sys.argv) > 1 else 8
+os.environ.setdefault('AVSI_COOP_CUS', str(256 // NS))     # the streams share the chip: no launch may need more than its part
 cfg = dict(audio_feat_dim=257, video_feat_dim=136, audio_len=48000, net_dim=[250, 250, 250], optimizer_type='adam',
            starter_learning_rate=1e-3, lr_updating_steps=10000, lr_decay=1.0, batch_size=B, l2=0.0)
 wav = torch.round(torch.randn(B, 48000, device='cuda') * 3000)
