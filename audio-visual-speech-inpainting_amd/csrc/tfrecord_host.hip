@@ -299,7 +299,8 @@ extern "C" int avsi_sequence_example_decode_fixed_host(const void* buf, size_t n
                     for (int i = 0; i < num_audio_samples; ++i) {
                         float x;
                         memcpy(&x, &tmp[i], 4);
-                        wav_i32[i] = (int32_t)x;
+                        // out-of-range / NaN: what x86's cvttss2si (and so TF's cast on the reference's hosts) returns
+                        wav_i32[i] = (x > -2147483904.f && x < 2147483648.f) ? (int32_t)x : INT32_MIN;
                     }
                     have_wav = true;
                 } else if (key_is(key, "sample_path")) {

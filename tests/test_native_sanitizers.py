@@ -1,0 +1,59 @@
+"""AddressSanitizer + UBSan run of the host-side record decoder (CPU build; the GPU pool has no sanitizers):
+the decoder source is compiled as plain C++ with g++ and fed the valid record plus a few hundred mutations."""
+import os
+import shutil
+import struct
+import subprocess
+
+import numpy as np
+import pytest
+
+import avsi_amd  # noqa: F401
+from avsi_amd import tfrecord_io as tio
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SRC = os.path.join(ROOT, "audio-visual-speech-inpainting_amd", "csrc", "tfrecord_host.hip")
+MAIN = os.path.join(ROOT, "tests", "native", "asan_tfrecord_main.cpp")
+
+
+@pytest.mark.skipif(shutil.which("g++") is None, reason="needs g++")
+def test_decoder_under_address_and_ub_sanitizers(tmp_path):
+    exe = str(tmp_path / "asan_tfrecord")
+    cmd = ["g++", "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=all",
+           "-x", "c++", SRC, MAIN, "-o", exe]
+    build = subprocess.run(cmd, capture_output=True, text=True)
+    if build.returncode != 0 and "sanitize" in build.stderr and "cannot find" in build.stderr:
+        pytest.skip("sanitizer runtime not installed: " + build.stderr.splitlines()[-1])
+    assert build.returncode == 0, build.stderr
+    rng = np.random.default_rng(1)
+    T, N = 12, 2304
+    wav = np.round(rng.normal(0, 3000, N)).astype(np.float32)
+    mask = np.ones((T, 257), np.float32)
+    video = rng.normal(size=(T, 136)).astype(np.float32)
+    rec = tio.serialize_sample_fixed(T, 7, wav, video, mask, np.arange(50, dtype=np.float32), "s01_clip",
+                                     embedding=rng.normal(size=512).astype(np.float32))
+    cases = [rec, b"", rec[:1], rec[:-1]]
+    for trial in range(400):
+        buf = bytearray(rec)
+        kind = trial % 4
+        if kind == 0:
+            buf = buf[:rng.integers(0, len(buf))]
+        elif kind == 1:
+            for _ in range(rng.integers(1, 6)):
+                buf[rng.integers(0, len(buf))] ^= 1 << rng.integers(0, 8)
+        elif kind == 2:
+            buf[rng.integers(0, min(len(buf), 4000))] = rng.integers(0, 256)
+        else:
+            a = rng.integers(0, len(buf))
+            buf[a:a] = bytes(rng.integers(0, 256, size=rng.integers(1, 64), dtype=np.uint8))
+        cases.append(bytes(buf))
+    path = str(tmp_path / "cases.bin")
+    with open(path, "wb") as fh:
+        for c in cases:
+            fh.write(struct.pack("<I", len(c)))
+            fh.write(c)
+    run = subprocess.run([exe, path], capture_output=True, text=True, timeout=120,
+                         env=dict(os.environ, ASAN_OPTIONS="detect_leaks=0"))
+    assert run.returncode == 0, run.stderr[-2000:]
+    ok, rejected = (int(v) for v in run.stdout.split()[1::2])
+    assert ok >= 1 and rejected >= 200 and ok + rejected == len(cases)

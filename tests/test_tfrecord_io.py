@@ -252,3 +252,36 @@ def test_prefetcher_propagates_errors_and_rewinds(tmp_path):
     with pytest.raises(IOError):
         bad.get_next()
         bad.get_next()
+
+
+def test_native_decoder_survives_corrupted_records():
+    """The decoder parses untrusted bytes: truncations, bit flips and random splices of a valid record must
+    end in a clean status (a ValueError here), never in a crash, a hang or an out-of-bounds write."""
+    rec, _ = _sample(5, with_emb=True)
+    dm = dr.DataManager(2304, 257, 136, embedding_size=512)
+    ref = dm.decode_batch([rec])
+    rng = np.random.default_rng(0)
+    outcomes = {'ok': 0, 'rejected': 0}
+    for trial in range(600):
+        buf = bytearray(rec)
+        kind = trial % 4
+        if kind == 0:
+            buf = buf[:rng.integers(0, len(buf))]
+        elif kind == 1:
+            for _ in range(rng.integers(1, 6)):
+                buf[rng.integers(0, len(buf))] ^= 1 << rng.integers(0, 8)
+        elif kind == 2:                                      # corrupt a length / tag byte near the start of a field
+            pos = rng.integers(0, min(len(buf), 4000))
+            buf[pos] = rng.integers(0, 256)
+        else:                                                # splice a random chunk somewhere
+            a, b = sorted(rng.integers(0, len(buf), size=2))
+            buf[a:a] = bytes(rng.integers(0, 256, size=rng.integers(1, 64), dtype=np.uint8))
+            del buf[b:b + rng.integers(0, 64)]
+        try:
+            out = dm.decode_batch([bytes(buf)])
+            outcomes['ok'] += 1
+            assert out[2].shape == ref[2].shape and out[7].shape[2] == 257
+        except ValueError:
+            outcomes['rejected'] += 1
+    assert outcomes['rejected'] > 300 and outcomes['ok'] + outcomes['rejected'] == 600
+    np.testing.assert_array_equal(dm.decode_batch([rec])[2], ref[2])     # and the decoder still works afterwards
