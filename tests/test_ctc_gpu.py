@@ -103,3 +103,11 @@ def test_is_deterministic_and_rejects_unsupported(ops):
     with pytest.raises(avsi_amd._lib.AvsiError):
         big = np.zeros((1, 8, 5), np.float32)
         _run(ops, big, np.zeros((1, 200), np.int32), np.zeros(1, np.int32), np.full(1, 8, np.int32))
+
+
+def test_kernel_against_the_committed_golden(ops):
+    import os
+    g = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'ctc_golden.npz'))
+    loss, grad = _run(ops, g['logits'], g['labels'].astype(np.int32), g['labels_lengths'], g['sequence_lengths'])
+    np.testing.assert_allclose(loss, g['loss'], rtol=2e-4)
+    np.testing.assert_allclose(grad, g['grad'], atol=2e-5)

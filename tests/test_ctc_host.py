@@ -60,3 +60,15 @@ def test_edit_distance_matches_oracle(ops):
         b = rng.integers(0, 5, size=rng.integers(0, 9)).tolist()
         for norm in (True, False):
             assert ops.edit_distance(a, b, norm) == OC.edit_distance(a, b, norm)
+
+
+def test_beam_search_and_per_against_the_golden(ops):
+    import os
+    g = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'ctc_golden.npz'))
+    dec, dlen, lp = ops.ctc_beam_search(g['logits'], g['sequence_lengths'], beam_width=20)
+    np.testing.assert_array_equal(dlen, g['decoded_lengths'])
+    for b in range(len(dlen)):
+        assert dec[b, :dlen[b]].tolist() == g['decoded'][b, :dlen[b]].tolist()
+        per = ops.edit_distance(dec[b, :dlen[b]], g['labels'][b, :g['labels_lengths'][b]].astype(int))
+        assert per == g['per'][b] or abs(per - g['per'][b]) < 1e-12
+    np.testing.assert_allclose(lp, g['log_prob'], atol=2e-3)

@@ -117,3 +117,16 @@ def test_dense_to_sparse_drops_padding():
     lab = np.array([[3, 1, 0, 0], [0, 0, 0, 0]], dtype=np.float32)
     out = OC.dense_to_sparse(lab, [2, 3])
     assert out[0].tolist() == [3, 1] and out[1].tolist() == [0, 0, 0]
+
+
+def test_oracle_reproduces_the_committed_golden():
+    """tests/golden/ctc_golden.npz (made by make_ctc_golden.py): the oracle must not drift."""
+    import os
+    g = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'ctc_golden.npz'))
+    loss, grad = OC.ctc_loss(g['logits'], g['labels'], g['labels_lengths'], g['sequence_lengths'])
+    np.testing.assert_allclose(loss, g['loss'], rtol=1e-12)
+    np.testing.assert_allclose(grad, g['grad'], atol=1e-7)
+    dec, scores = OC.beam_search(g['logits'], g['sequence_lengths'], beam_width=20)
+    for b, d in enumerate(dec):
+        assert d == g['decoded'][b, :g['decoded_lengths'][b]].tolist()
+    np.testing.assert_allclose(scores, g['log_prob'], rtol=1e-12)
