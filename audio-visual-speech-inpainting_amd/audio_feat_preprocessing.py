@@ -14,18 +14,12 @@ from glob import glob
 
 import numpy as np
 import torch
-from scipy import signal
 from scipy.io import wavfile
 
 from . import audio_processing as ap
 
 
-def downsampling(samples, sample_rate, downsample_rate):
-    """FFT resampling to `downsample_rate` (reference audio_processing.py:9-16)."""
-    if sample_rate == downsample_rate:
-        return samples
-    num = int(downsample_rate * (len(samples) / float(sample_rate)))
-    return signal.resample(samples, num)
+downsampling = ap.downsampling       # reference audio_processing.py:9-16, imported there by this module
 
 
 def _features(wavs, type, sample_rate, n_fft, window_size, step_size, preemph, num_mel_bins, num_mfcc, delta):
@@ -100,3 +94,44 @@ def compute_mean_std_features(audio_folder, file_prefix, out_prefix, type='spec'
     np.save(os.path.join(audio_folder, out_prefix + '_std.npy'), feat_std)
     print('Normalization data files saved.')
     return feat_mean, feat_std
+
+
+def save_features(audio_folder, type='spec', sample_rate=16e3, n_fft=512, window_size=25, step_size=10, preemph=0,
+                  num_mel_bins=80, num_mfcc=13, delta=0, file_ext='wav', batch_size=64):
+    """Write ``<file>.npy`` = the features of every ``<audio_folder>/*.<file_ext>`` -- reference
+    audio_feat_preprocessing.py:132-198 (types 'stft' -- complex64 --, 'spec', 'fbanks', 'mfcc'; optional
+    pre-emphasis and deltas).  Files of equal length share a launch of the front-end kernel."""
+    sample_rate = int(sample_rate)
+    files = sorted(glob(os.path.join(audio_folder, '*.' + file_ext)))
+    if type not in ('stft', 'spec', 'fbanks', 'mfcc'):
+        print('Type must be "spec", "fbanks" or "mfcc". Closing...')
+        exit(1)
+    print('Computing and saving features...')
+
+    def flush(group):
+        wavs = [w for _, w in group]
+        if type == 'stft':
+            x = torch.from_numpy(np.stack(wavs).astype(np.float32)).cuda()
+            if preemph > 0:
+                x = ap.preemphasis(x, alpha=preemph)
+            feats = ap.get_stft(x, sample_rate, window_size, step_size, n_fft)
+            if delta > 0:
+                raise ValueError("delta features of a complex STFT are not defined")
+            feats = feats.cpu().numpy()
+        else:
+            feats = _features(wavs, type, sample_rate, n_fft, window_size, step_size, preemph, num_mel_bins, num_mfcc, delta)
+        for (path, _), feat in zip(group, feats):
+            np.save(os.path.splitext(path)[0] + '.npy', feat)
+
+    group, group_len = [], None
+    for path in files:
+        rate, samples = wavfile.read(path)
+        samples = np.asarray(downsampling(samples, rate, sample_rate), dtype=np.float32)
+        if group and (len(samples) != group_len or len(group) == batch_size):
+            flush(group)
+            group = []
+        group.append((path, samples))
+        group_len = len(samples)
+    if group:
+        flush(group)
+    print('done. Audio files processed:', len(files))

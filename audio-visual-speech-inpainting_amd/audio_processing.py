@@ -341,3 +341,56 @@ def preemphasis(sources, alpha=0.95):
     _lib.check(_lib.lib().avsi_preemphasis_f32(_lib.ptr(x), _lib.ptr(out), x.shape[0], x.shape[1], x.stride(0),
                                                float(alpha), _lib.stream_ptr()), "avsi_preemphasis_f32")
     return out
+
+
+def downsampling(samples, sample_rate, downsample_rate):
+    """FFT resampling of one waveform to `downsample_rate` on the host -- reference audio_processing.py:9-16
+    (scipy.signal.resample; offline data preparation, not part of the device path)."""
+    from scipy import signal
+    if sample_rate == downsample_rate:
+        return samples
+    return signal.resample(samples, int(downsample_rate * (len(samples) / float(sample_rate))))
+
+
+def asr_preprocessing(input_sources, type='mfcc', preemph=0.95, num_spec_bins=257, num_mel_bins=80, num_mfccs=13, n_delta=3,
+                      feat_mean=None, feat_std=None, stft_shape=[0, 0, 0], name='features'):
+    """Front end of the recognition branch -- reference audio_processing.py:107-142: pre-emphasis, STFT
+    (25 / 10 ms, the get_stft defaults), then ``type`` = 'spec' (|X| ** 0.3), 'fbanks' (log-mel of the power
+    spectrogram) or 'mfcc'; ``n_delta`` orders of regression deltas appended; normalised with feat_mean /
+    feat_std (feat_mean = the per-utterance mean over time when only feat_std is given).  With preemph <= 0 the
+    reference hits an undefined name; here the sources are used as they are."""
+    sources = preemphasis(input_sources, alpha=preemph) if preemph > 0 else input_sources
+    stfts = get_stft(sources, out_shape=stft_shape)
+    if type == 'spec':
+        features = get_spectrogram(stfts, power=0.3)
+    else:
+        fbanks = get_log_mel_spectrogram(get_spectrogram(stfts, power=2), num_spec_bins=num_spec_bins,
+                                         num_mel_bins=num_mel_bins)
+        if type == 'fbanks':
+            features = fbanks
+        elif type == 'mfcc':
+            features = get_mfcc(fbanks, num_mfccs=num_mfccs)
+        else:
+            raise ValueError("type must be 'spec', 'fbanks' or 'mfcc', got %r" % (type,))
+    if n_delta > 0:
+        features = add_delta_features(features, n_delta=n_delta)
+    if feat_mean is None and feat_std is not None:
+        feat_mean = features.mean(dim=1, keepdim=True)
+    if feat_mean is not None and feat_std is not None:
+        dev = features.device
+        features = (features - torch.as_tensor(feat_mean, dtype=torch.float32, device=dev)) / \
+            torch.as_tensor(feat_std, dtype=torch.float32, device=dev)
+    return features
+
+
+def get_oracle_iam(target_stft, mixed_stft, clip_value=10):
+    """Oracle Ideal Amplitude Mask |target| / |mixed| clipped to [0, clip_value] -- reference :167-173."""
+    iam = get_spectrogram(target_stft) / get_spectrogram(mixed_stft)
+    return torch.clamp(iam, 0, clip_value).to(torch.float32)
+
+
+def get_oracle_ipsm(target_stft, mixed_stft, min_clip_value=0, max_clip_value=10):
+    """Oracle Ideal Phase Sensitive Mask |target| cos(angle(mixed) - angle(target)) / |mixed| -- reference :176-184."""
+    ipsm = get_spectrogram(target_stft) * torch.cos(torch.angle(mixed_stft) - torch.angle(target_stft)) / \
+        get_spectrogram(mixed_stft)
+    return torch.clamp(ipsm, min_clip_value, max_clip_value)

@@ -108,3 +108,67 @@ def test_cli_help_and_out_of_scope_subcommands():
     assert r.returncode == 1 and "not part of the MI355X hot-path package" in r.stdout
     r = run()
     assert r.returncode == 1 and "Bad subcommand name" in r.stdout
+
+
+@pytest.mark.parametrize("ftype", ["mfcc", "fbanks", "spec"])
+def test_asr_preprocessing_matches_oracle_chain(ap, ftype):
+    """asr_preprocessing (audio_processing.py:107-142): the composed recognition front end, with the
+    per-utterance mean normalisation it applies when only feat_std is given."""
+    wav = _wav(2, 16000, 3)
+    n_delta = 2
+    D = {"mfcc": 13, "fbanks": 80, "spec": 257}[ftype] * (n_delta + 1)
+    std = np.linspace(0.5, 2.0, D).astype(np.float32)
+    out = ap.asr_preprocessing(torch.from_numpy(wav).cuda(), type=ftype, n_delta=n_delta, feat_std=std)
+    st = OF.get_stft(OF.preemphasis(wav, 0.95))
+    if ftype == "spec":
+        ref = OF.get_spectrogram(st, power=0.3)
+    else:
+        ref = OF.get_log_mel_spectrogram(OF.get_spectrogram(st, power=2))
+        if ftype == "mfcc":
+            ref = OF.get_mfcc(ref, 13)
+    ref = OF.add_delta_features(ref, n_delta, 2)
+    ref = (ref - ref.mean(axis=1, keepdims=True)) / std
+    assert out.shape == ref.shape == (2, 100, D)
+    assert np.abs(out.cpu().numpy() - ref).max() < 5e-3 * max(1.0, np.abs(ref).max())
+    with pytest.raises(ValueError):
+        ap.asr_preprocessing(torch.from_numpy(wav).cuda(), type='stft')
+    # preemph <= 0: the sources are used as they are (the reference stops on an undefined name, App. B7)
+    plain = ap.asr_preprocessing(torch.from_numpy(wav).cuda(), type='fbanks', preemph=0, n_delta=0)
+    ref_plain = OF.get_log_mel_spectrogram(OF.get_spectrogram(OF.get_stft(wav), power=2))
+    assert np.sqrt(np.mean((plain.cpu().numpy() - ref_plain) ** 2)) < 1e-4
+
+
+def test_oracle_masks_and_downsampling(ap):
+    wav = _wav(2, 9600, 4)
+    noise = _wav(2, 9600, 5)
+    t = ap.get_stft(torch.from_numpy(wav).cuda())
+    m = ap.get_stft(torch.from_numpy(wav + noise).cuda())
+    T, M = OF.get_stft(wav), OF.get_stft(wav + noise)
+    iam = ap.get_oracle_iam(t, m).cpu().numpy()
+    ref_iam = np.clip(np.abs(T) / np.abs(M), 0, 10)
+    np.testing.assert_allclose(iam, ref_iam, rtol=2e-3, atol=2e-4)
+    ipsm = ap.get_oracle_ipsm(t, m).cpu().numpy()
+    ref_ipsm = np.clip(np.abs(T) * np.cos(np.angle(M) - np.angle(T)) / np.abs(M), 0, 10)
+    np.testing.assert_allclose(ipsm, ref_ipsm, rtol=2e-3, atol=2e-3)
+    assert iam.dtype == np.float32 and iam.max() <= 10 and ipsm.min() >= 0
+    x = np.sin(2 * np.pi * 440 * np.arange(50000) / 50000.0)
+    y = ap.downsampling(x, 50000, 16000)
+    assert len(y) == 16000 and ap.downsampling(x, 16000, 16000) is x
+    np.testing.assert_allclose(y[100:-100], np.sin(2 * np.pi * 440 * np.arange(16000) / 16000.0)[100:-100], atol=1e-6)
+
+
+def test_save_features_writes_one_npy_per_wav(ap, tmp_path):
+    from avsi_amd.audio_feat_preprocessing import save_features
+    rng = np.random.default_rng(6)
+    for i, n in enumerate((9600, 9600, 4800)):
+        w = np.clip(np.round(rng.normal(0, 3000, n)), -32768, 32767).astype(np.int16)
+        wavfile.write(str(tmp_path / ("utt%d.wav" % i)), 16000, w)
+    save_features(str(tmp_path), type='fbanks', sample_rate=16000, window_size=24, step_size=12, delta=1)
+    f0, f2 = np.load(str(tmp_path / "utt0.npy")), np.load(str(tmp_path / "utt2.npy"))
+    assert f0.shape == (50, 160) and f2.shape == (25, 160)
+    rate, w0 = wavfile.read(str(tmp_path / "utt0.wav"))
+    ref = OF.add_delta_features(OF.get_log_mel_spectrogram(OF.get_spectrogram(
+        OF.get_stft(w0[None].astype(np.float32), window_size=24, step_size=12), power=2)), 1, 2)[0]
+    assert np.sqrt(np.mean((f0 - ref) ** 2)) < 1e-4
+    save_features(str(tmp_path), type='stft', sample_rate=16000, window_size=24, step_size=12)
+    assert np.load(str(tmp_path / "utt2.npy")).dtype == np.complex64
