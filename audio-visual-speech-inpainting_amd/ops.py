@@ -117,6 +117,9 @@ def coop_split(Bp, backward=False):
     # AVSI_COOP_CUS: CUs one cooperative launch may occupy (default: the chip).  Every member of a launch must be
     # resident together, so a process that keeps several small batches in flight on different streams should
     # divide the 256 CUs between them (8 streams: 32); the bounded spin catches an over-subscription anyway.
+    forced = os.environ.get('AVSI_COOP_SPLIT_BWD' if backward else 'AVSI_COOP_SPLIT_FWD')     # diagnostics
+    if forced and split:
+        return int(forced)
     budget = int(os.environ.get('AVSI_COOP_CUS', '256'))
     while split > 4 and 2 * (Bp // 32) * split > budget:
         split //= 2
