@@ -356,17 +356,18 @@ __device__ __forceinline__ void dma16(const float* src, uint32_t lds_byte_addr) 
 }
 
 template <bool TA, bool TB, int BK, int NST, bool CONV = false, int BNT = 128>
-__global__ __launch_bounds__(256, BK == 16 ? (NST == 3 ? 3 : 4) : 2) void gemm_dma_kernel(const GemmArgs g) {
+__global__ __launch_bounds__(256, BNT == 256 ? 2 : (BK == 16 ? (NST == 3 ? 3 : 4) : 2)) void gemm_dma_kernel(const GemmArgs g) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     static_assert((BK == 16 && (NST == 3 || NST == 2)) || (BK == 32 && NST == 2), "tile shapes this kernel was tuned for");
     static_assert(!CONV || (!TB && BK == 16), "the implicit-GEMM gathers are written for A . B and A^T . B with 16-deep tiles");
-    static_assert(BNT == 128 || ((BNT == 64 || BNT == 32) && !TB && BK == 16 && NST == 3),
-                  "narrow N tiles (convolutions with 16 .. 64 output channels) exist for the 16-deep forms with B as [k][n]");
+    static_assert(BNT == 128 || ((BNT == 64 || BNT == 32 || BNT == 256) && !TB && BK == 16 && NST == 3),
+                  "narrow / wide N tiles exist for the 16-deep forms with B as [k][n]");
     // wave grid WM x WN, each wave TM x TN MFMA tiles: 128 x 128 = (2 x 2) x (2 x 2), 128 x 64 = (2 x 2) x (2 x 1),
     // 128 x 32 = (4 x 1) x (1 x 1)
-    constexpr int WN = BNT == 32 ? 1 : 2, TN = BNT == 128 ? 2 : 1, TM = BNT == 32 ? 1 : 2;
+    // 128 x 256 = (2 x 2) x (2 x 4): half the barriers and a quarter less LDS traffic per MFMA than 128 x 128
+    constexpr int WN = BNT == 32 ? 1 : 2, TN = BNT == 256 ? 4 : (BNT == 128 ? 2 : 1), TM = BNT == 32 ? 1 : 2;
     constexpr int BM = 128, TILE = 128 * BK, TILEB = BNT * BK;
-    constexpr int PPWB = BNT == 128 ? BK / 8 : 1;   // B pieces per wave (the 2 pieces of a 32-wide tile are issued twice)
+    constexpr int PPWB = BNT == 256 ? 4 : (BNT == 128 ? BK / 8 : 1);   // B pieces per wave (the 2 pieces of a 32-wide tile are issued twice)
     constexpr int PPW = BK / 8;         // 1-KiB DMA pieces per wave and operand tile
     constexpr int CPR = BK / 4;         // 16-byte chunks per row of a "row" tile
     constexpr int RPP = 256 / BK;       // rows of a "row" tile per DMA piece
@@ -391,12 +392,14 @@ __global__ __launch_bounds__(256, BK == 16 ? (NST == 3 ? 3 : 4) : 2) void gemm_d
     float* __restrict__ C = g.C + (int64_t)blockIdx.z * g.c_split_stride;
 
     // per-lane source offsets (floats, relative to the tile origin) of this wave's DMA pieces per operand
-    int64_t offa[PPW], offb[PPW];
-    const int pb0 = BNT == 128 ? wave * PPW : (BNT == 64 ? wave : (wave & 1));   // first B piece of this wave
+    constexpr int PPM = PPW > PPWB ? PPW : PPWB;
+    int64_t offa[PPM], offb[PPM];
+    const int pb0 = BNT >= 128 ? wave * PPWB : (BNT == 64 ? wave : (wave & 1));   // first B piece of this wave
 #pragma unroll
-    for (int j = 0; j < PPW; ++j) {
+    for (int j = 0; j < PPM; ++j) {
         const int p = wave * PPW + j;  // 1-KiB piece of the tile
-        if (!TA) {  // row tile [m][k]
+        if (j >= PPW) {
+        } else if (!TA) {  // row tile [m][k]
             const int row = p * RPP + lane / CPR, cl = (lane % CPR) ^ swz(row);
             offa[j] = (int64_t)(min(m0 + row, g.M - 1) - m0) * g.lda + cl * 4;
         } else {    // col tile [k][m]
@@ -488,6 +491,8 @@ __global__ __launch_bounds__(256, BK == 16 ? (NST == 3 ? 3 : 4) : 2) void gemm_d
             dma16(asrc, lds_a + (uint32_t)(st * TILE + (wave * PPW + j) * 256) * 4u);
             if (j < PPWB) dma16(bo + offb[j], lds_b + (uint32_t)(st * TILEB + (pb0 + j) * 256) * 4u);
         }
+#pragma unroll
+        for (int j = PPW; j < PPWB; ++j) dma16(bo + offb[j], lds_b + (uint32_t)(st * TILEB + (pb0 + j) * 256) * 4u);
     };
 
     f32x16 acc[TM][TN];
@@ -573,6 +578,29 @@ __global__ __launch_bounds__(256, BK == 16 ? (NST == 3 ? 3 : 4) : 2) void gemm_d
         const int col = n0 + wn * (32 * TN) + j * 32 + li;
         bv[j] = (g.bias && col < g.N) ? g.bias[col] : 0.f;
     }
+    // Fast path of the 128 x 256 tile (whole tile inside the matrix, plain C = alpha A.B + bias): one 64-bit add per
+    // store instead of the general addressing / masking / row-map code below.  Measured on the three layer GEMMs
+    // of the benchmark step (ms): 128-wide general 84.6 / fast 85.4, 256-wide general 86.1 / fast 82.9 -- so the
+    // narrow tiles keep the general form.
+    if (BNT == 256 && g.row_map_bp == 0 && !g.row_scale && !accumulate && m0 + BM <= g.M && n0 + BNT <= g.N) {
+        float* cw = C + (int64_t)(m0 + wm * (32 * TM) + 4 * hi) * g.ldc + n0 + wn * (32 * TN) + li;
+        const int64_t ld4 = (int64_t)4 * g.ldc;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            float* ci = cw + (int64_t)(i * 32) * g.ldc;
+#pragma unroll
+            for (int rq = 0; rq < 4; ++rq) {                  // rows 8 rq + (0..3)
+                float* cr = ci + 2 * rq * ld4;
+#pragma unroll
+                for (int r3 = 0; r3 < 4; ++r3) {
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) cr[j * 32] = g.alpha * acc[i][j][4 * rq + r3] + bv[j];
+                    cr += g.ldc;
+                }
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
 #pragma unroll
@@ -610,6 +638,14 @@ int launch_dma(const GemmArgs& g, int splits, hipStream_t st) {
     if (getenv("AVSI_GEMM_DMA") && atoi(getenv("AVSI_GEMM_DMA")) == 3) {
         hipLaunchKernelGGL((gemm_dma_kernel<TA, TB, 16, 2>), dim3(g.m_blocks * g.n_blocks, 1, splits), dim3(256),
                            2 * 2 * 128 * 16 * 4, st, g);
+        return avsi_launch_status();
+    }
+    if (!TA && !TB && g.bnt == 256) {
+        constexpr size_t lds256 = (size_t)3 * (128 + 256) * 16 * 4;      // 72 KiB: two workgroups per CU
+        (void)hipFuncSetAttribute((const void*)gemm_dma_kernel<false, false, 16, 3, false, 256>,
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds256);
+        hipLaunchKernelGGL((gemm_dma_kernel<false, false, 16, 3, false, 256>), dim3(g.m_blocks * g.n_blocks, 1, splits), dim3(256),
+                           lds256, st, g);
         return avsi_launch_status();
     }
     if (!TA && !TB && g.bnt == 64) {
@@ -682,12 +718,17 @@ int avsi_gemm_launch(int transA, int transB, int M, int N, int K, float alpha, c
     const bool dma_ok = !(transB && !transA) && (K % 16 == 0) && (g.k_split_len % 16 == 0) && !env_bk && !env_mi &&
                         !(env_dma && atoi(env_dma) == 0);
     g.bnt = (dma_ok && !transA && !transB && N < 1024 && ((N - 1) % BN) < 64 && !(env_dma && atoi(env_dma) > 1)) ? 64 : BN;
+    // wide layer GEMMs (N = 2048): 128 x 256 output tiles, each wave 64 x 128 -- half the barriers and a quarter less
+    // LDS traffic per MFMA (K = 4096: 135 -> 142 TFLOP/s; the 512-deep layer GEMMs gain 2 %).  AVSI_GEMM_BNT=128: diagnostics
+    if (dma_ok && !transA && !transB && g.bnt == BN && N % 256 == 0 && N >= 1024 && splits == 1 &&
+        !(getenv("AVSI_GEMM_BNT") && atoi(getenv("AVSI_GEMM_BNT")) == 128))
+        g.bnt = 256;
     g.n_blocks = (int)avsi_ceil_div(N, g.bnt);
     g.c_split_stride = splits > 1 ? c_split_stride : 0;
     {   // column-group width: the group's slice of op(B), k_split_len x (n_group * 128) floats, should fill about half of
         // one XCD's 4 MiB L2
         const char* env_ng = getenv("AVSI_GEMM_NGROUP");
-        const int64_t slice_bytes_per_block = (int64_t)g.k_split_len * BN * 4;
+        const int64_t slice_bytes_per_block = (int64_t)g.k_split_len * g.bnt * 4;
         int ng = (int)((2 << 20) / (slice_bytes_per_block > 0 ? slice_bytes_per_block : 1));
         if (ng < 4) ng = 4;      // narrower groups re-read A more often than they save on B
         if (env_ng) ng = atoi(env_ng);

@@ -11,7 +11,7 @@ import csv
 import json
 import sys
 
-KERNELS = {'frontend_kernel': 1, 'gemm_dma_kernel<false, false, 16, 3, false, 128>': 3, 'blstm_rec_fwd_pp': 3, 'l1_partial_kernel': 1}
+KERNELS = {'frontend_kernel': 1, 'gemm_dma_kernel<false, false, 16, 3, false, 256>': 3, 'blstm_rec_fwd_pp': 3, 'l1_partial_kernel': 1}
 
 
 def per_kernel(path, counter):
