@@ -640,11 +640,11 @@ int launch_dma(const GemmArgs& g, int splits, hipStream_t st) {
                            2 * 2 * 128 * 16 * 4, st, g);
         return avsi_launch_status();
     }
-    if (!TA && !TB && g.bnt == 256) {
+    if (!TB && g.bnt == 256) {
         constexpr size_t lds256 = (size_t)3 * (128 + 256) * 16 * 4;      // 72 KiB: two workgroups per CU
-        (void)hipFuncSetAttribute((const void*)gemm_dma_kernel<false, false, 16, 3, false, 256>,
+        (void)hipFuncSetAttribute((const void*)gemm_dma_kernel<TA, false, 16, 3, false, 256>,
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds256);
-        hipLaunchKernelGGL((gemm_dma_kernel<false, false, 16, 3, false, 256>), dim3(g.m_blocks * g.n_blocks, 1, splits), dim3(256),
+        hipLaunchKernelGGL((gemm_dma_kernel<TA, false, 16, 3, false, 256>), dim3(g.m_blocks * g.n_blocks, 1, splits), dim3(256),
                            lds256, st, g);
         return avsi_launch_status();
     }
@@ -719,8 +719,9 @@ int avsi_gemm_launch(int transA, int transB, int M, int N, int K, float alpha, c
                         !(env_dma && atoi(env_dma) == 0);
     g.bnt = (dma_ok && !transA && !transB && N < 1024 && ((N - 1) % BN) < 64 && !(env_dma && atoi(env_dma) > 1)) ? 64 : BN;
     // wide layer GEMMs (N = 2048): 128 x 256 output tiles, each wave 64 x 128 -- half the barriers and a quarter less
-    // LDS traffic per MFMA (K = 4096: 135 -> 142 TFLOP/s; the 512-deep layer GEMMs gain 2 %).  AVSI_GEMM_BNT=128: diagnostics
-    if (dma_ok && !transA && !transB && g.bnt == BN && N % 256 == 0 && N >= 1024 && splits == 1 &&
+    // LDS traffic per MFMA (K = 4096: 135 -> 142 TFLOP/s; the 512-deep layer GEMMs gain 2 %, the split-K weight
+    // gradients 6 %), when that still leaves two workgroups per CU.  AVSI_GEMM_BNT=128: diagnostics
+    if (dma_ok && !transB && g.bnt == BN && N % 256 == 0 && N >= 1024 && (int64_t)g.m_blocks * (N / 256) * splits >= 2 * AVSI_NUM_CU &&
         !(getenv("AVSI_GEMM_BNT") && atoi(getenv("AVSI_GEMM_BNT")) == 128))
         g.bnt = 256;
     g.n_blocks = (int)avsi_ceil_div(N, g.bnt);
