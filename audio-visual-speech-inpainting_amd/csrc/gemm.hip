@@ -708,7 +708,8 @@ int avsi_gemm_launch(int transA, int transB, int M, int N, int K, float alpha, c
     const char* env_bk = getenv("AVSI_GEMM_BK");
     const char* env_mi = getenv("AVSI_GEMM_MI");
     const int bk = env_bk ? atoi(env_bk) : (transB ? 32 : 16);
-    const int mi = env_mi ? atoi(env_mi) : 2;
+    // A . B^T over many rows (the dX products of training): 256-row tiles, +2.7 % (129.7 -> 133.2 TFLOP/s)
+    const int mi = env_mi ? atoi(env_mi) : ((transB && !transA && M >= 65536) ? 4 : 2);
     const int BM = 64 * mi;
     g.m_blocks = (int)avsi_ceil_div(M, BM);
     // A . B whose last 128-wide tile would be at most half full and that is narrow enough for the tail to matter
