@@ -214,12 +214,16 @@ class StackedBLSTMModel(object):
         """Replace the fed values (the reference's feed_dict, training.py:67-74) and drop cached results."""
         self._cache = {}
         if sequence_lengths is not None:
-            self.sequence_lengths = np.asarray(
-                sequence_lengths.cpu() if isinstance(sequence_lengths, torch.Tensor) else sequence_lengths,
-                dtype=np.int64)
+            new_len = np.asarray(sequence_lengths.cpu() if isinstance(sequence_lengths, torch.Tensor) else sequence_lengths,
+                                 dtype=np.int64)
             # on the device once per feed: a host-to-device copy issued later, behind the recurrent kernels
-            # of the stream, would block the host until they finish (pageable memory)
-            self._seq_dev = torch.as_tensor(self.sequence_lengths, device=self.device)
+            # of the stream, would block the host until they finish (pageable memory) -- and not at all when the
+            # lengths are the ones already there (every batch of a fixed-length dataset): that copy is the one
+            # point where the host would otherwise wait for the previous step's kernels
+            if self.sequence_lengths is None or not np.array_equal(new_len, self.sequence_lengths) \
+                    or getattr(self, '_seq_dev', None) is None:
+                self.sequence_lengths = new_len
+                self._seq_dev = torch.as_tensor(self.sequence_lengths, device=self.device)
         self.target_sources = _as_device(target_sources, device=self.device)
         self.masks = _as_device(masks, device=self.device)
         self.video_features = _as_device(video_features, device=self.device)
@@ -478,38 +482,68 @@ class StackedBLSTMModel(object):
         dlog2 = dlog.view(M, ldp)
         h_top = c['rnn_out'].view(M, 2 * HP)
         splits = ops.splitk_for(M)
-        ops.gemm_splitk(h_top, dlog2, lay.gpacked_view(gp, 'dpw'), trans_a=True, m=2 * HP, n=ldp, k=M, splits=splits)
-        ops.colsum(dlog2, lay.gpacked_view(gp, 'dpb'), m=M, n=ldp)
+        # Small batches: the BPTT kernels occupy 64 .. 256 CUs and everything on the chain dz_l -> dX -> BPTT_{l-1} is
+        # latency-bound, while the weight gradients of layer l (dWx, dWh, db: split-K GEMMs and column sums over dz_l)
+        # feed nothing on that chain -- they run on a second stream, behind an event, beside the BPTT of the layers
+        # below (dz then needs a buffer per layer).  Measured (ms per step, one stream -> two): B = 8: 11.9 -> 10.4,
+        # B = 32: 11.1 -> 10.3, B = 128: 15.0 -> 15.7, B = 256: 23.2 -> 22.8 -- so only the smallest batches do it.
+        overlap = Bp <= 64 and os.environ.get('AVSI_TRAIN_OVERLAP', '1') != '0'
+        main = torch.cuda.current_stream(self.device)
+        side = main
+        if overlap:
+            if getattr(self, '_side_stream', None) is None:
+                self._side_stream = torch.cuda.Stream(device=self.device)
+            side = self._side_stream
+
+        def on_side(fn):
+            """Run fn on the side stream once everything enqueued on the main stream so far has finished."""
+            if not overlap:
+                return fn()
+            ev = torch.cuda.Event()
+            ev.record(main)
+            side.wait_event(ev)
+            with torch.cuda.stream(side):
+                fn()
+
+        def head_grads():
+            ops.gemm_splitk(h_top, dlog2, lay.gpacked_view(gp, 'dpw'), trans_a=True, m=2 * HP, n=ldp, k=M, splits=splits)
+            ops.colsum(dlog2, lay.gpacked_view(gp, 'dpb'), m=M, n=ldp)
+        on_side(head_grads)
         dh = self._buf('dh', (T, Bp, 2 * HP))
         ops.gemm(dlog2, v.p('pw'), out=dh.view(M, 2 * HP), trans_b=True, m=M, n=2 * HP, k=ldp)
-        dz = self._buf('dz', (T, Bp, 2 * GP))
         for li in range(self.num_layers - 1, -1, -1):
             kp = lay.kp[li]
+            dz = self._buf('dz%d' % li if overlap else 'dz', (T, Bp, 2 * GP))
             ops.blstm_rec_bwd(dh, c['reserve'][li], v.p('whb%d' % li), dz)
             dz2 = dz.view(M, 2 * GP)
-            x = c['layer_in'][li].view(M, kp)
-            ops.gemm_splitk(x, dz2, lay.gpacked_view(gp, 'dwx%d' % li), trans_a=True, m=kp, n=2 * GP, k=M, splits=splits)
-            ops.colsum(dz2, lay.gpacked_view(gp, 'db%d' % li), m=M, n=2 * GP)
-            if lay.side_dim(li):
-                # the side input saw every frame's dz: sum over time first, then two small GEMMs
-                E = lay.side_dim(li)
-                dsb = self._buf('dside_bias', (Bp, 2 * GP))
-                ops.colsum(dz.view(T, Bp * 2 * GP), dsb.view(-1), m=T, n=Bp * 2 * GP)
-                ops.gemm(c['side_p'], dsb, out=lay.gpacked_view(gp, 'dwe'), trans_a=True, m=lay.side_p, n=2 * GP, k=Bp)
-                dside = self._buf('dside', (Bp, lay.side_p))
-                ops.gemm(dsb, v.p('we'), out=dside, trans_b=True, m=Bp, n=lay.side_p, k=2 * GP)
-                self._side_backward(dside[:B, :E], gp)
-            # dWh[d] = H_prev^T . dZ_d : fw pairs h[t-1] with dz[t], bw pairs h[t+1] with dz[t]
-            hout = self._ws[('h%d' % li, (T, Bp, 2 * HP))].view(M, 2 * HP)
-            dwh = lay.gpacked_view(gp, 'dwh%d' % li)
-            if T > 1:
-                Mr = (T - 1) * Bp
-                ops.gemm_splitk(hout[:Mr, :HP], dz2[Bp:, :GP], dwh[0], trans_a=True, m=HP, n=GP, k=Mr, splits=splits)
-                ops.gemm_splitk(hout[Bp:, HP:], dz2[:Mr, GP:], dwh[1], trans_a=True, m=HP, n=GP, k=Mr, splits=splits)
-            else:
-                dwh.zero_()
+
+            def weight_grads(li=li, kp=kp, dz=dz, dz2=dz2):
+                x = c['layer_in'][li].view(M, kp)
+                ops.gemm_splitk(x, dz2, lay.gpacked_view(gp, 'dwx%d' % li), trans_a=True, m=kp, n=2 * GP, k=M, splits=splits)
+                ops.colsum(dz2, lay.gpacked_view(gp, 'db%d' % li), m=M, n=2 * GP)
+                if lay.side_dim(li):
+                    # the side input saw every frame's dz: sum over time first, then two small GEMMs
+                    E = lay.side_dim(li)
+                    dsb = self._buf('dside_bias', (Bp, 2 * GP))
+                    ops.colsum(dz.view(T, Bp * 2 * GP), dsb.view(-1), m=T, n=Bp * 2 * GP)
+                    ops.gemm(c['side_p'], dsb, out=lay.gpacked_view(gp, 'dwe'), trans_a=True, m=lay.side_p, n=2 * GP, k=Bp)
+                    dside = self._buf('dside', (Bp, lay.side_p))
+                    ops.gemm(dsb, v.p('we'), out=dside, trans_b=True, m=Bp, n=lay.side_p, k=2 * GP)
+                    self._side_backward(dside[:B, :E], gp)
+                # dWh[d] = H_prev^T . dZ_d : fw pairs h[t-1] with dz[t], bw pairs h[t+1] with dz[t]
+                hout = self._ws[('h%d' % li, (T, Bp, 2 * HP))].view(M, 2 * HP)
+                dwh = lay.gpacked_view(gp, 'dwh%d' % li)
+                if T > 1:
+                    Mr = (T - 1) * Bp
+                    ops.gemm_splitk(hout[:Mr, :HP], dz2[Bp:, :GP], dwh[0], trans_a=True, m=HP, n=GP, k=Mr, splits=splits)
+                    ops.gemm_splitk(hout[Bp:, HP:], dz2[:Mr, GP:], dwh[1], trans_a=True, m=HP, n=GP, k=Mr, splits=splits)
+                else:
+                    dwh.zero_()
+            on_side(weight_grads)
             if li > 0:
                 ops.gemm(dz2, v.p('wx%d' % li), out=dh.view(M, 2 * HP), trans_b=True, m=M, n=2 * HP, k=2 * GP)
+        if overlap:
+            main.wait_stream(side)
         if ops.coop_split(Bp):
             ops.coop_poll(self.device)
         grads = v.unpack_grads(gp, out=self._buf('grads', (lay.ref_size,)))
