@@ -99,6 +99,60 @@ class Dataset(object):
             yield self.parse(payload)
 
 
+class Batch(tuple):
+    """The batch tuple of the module docstring (numpy arrays).  With ``get_iterator(..., device=...)`` the large
+    arrays have also been copied to the GPU by the prefetch thread: ``device_arrays`` maps positions of the tuple
+    to device tensors, ``ready`` is the event a consuming stream has to wait for (see ``to_device``)."""
+    device_arrays = None
+    ready = None
+    _pinned = None
+
+    def to_device(self, index):
+        """Device tensor of field ``index`` (or None if it was not uploaded), ordered after the upload on the
+        current stream -- no host synchronisation."""
+        import torch
+        if not self.device_arrays or index not in self.device_arrays:
+            return None
+        t = self.device_arrays[index]
+        cur = torch.cuda.current_stream(t.device)
+        cur.wait_event(self.ready)
+        t.record_stream(cur)
+        return t
+
+
+class _Uploader(object):
+    """Copies the bulky fields of a batch (audio, video, mask, embedding) to the GPU from the prefetch thread:
+    pinned staging buffers, asynchronous copies on a stream of its own, one event per batch.  The reference's
+    feed_dict crossing is a synchronous pageable copy per step; this keeps it off the training stream."""
+
+    def __init__(self, device, fields):
+        import torch
+        self.torch = torch
+        self.fields = tuple(fields)         # positions of the batch tuple to upload (negative = from the end)
+        self.device = torch.device(device)
+        if self.device.type == 'cuda' and self.device.index is None:
+            self.device = torch.device('cuda', torch.cuda.current_device())
+        self.stream = None
+
+    def __call__(self, batch):
+        torch = self.torch
+        if self.stream is None:
+            torch.cuda.set_device(self.device)
+            self.stream = torch.cuda.Stream(device=self.device)
+        out = Batch(batch)
+        out.device_arrays, out._pinned = {}, []
+        with torch.cuda.stream(self.stream):
+            for i in sorted(f % len(batch) for f in self.fields):
+                a = batch[i]
+                if isinstance(a, np.ndarray) and a.dtype != object and a.size:
+                    host = torch.from_numpy(np.ascontiguousarray(a)).pin_memory()
+                    out._pinned.append(host)
+                    out.device_arrays[i] = host.to(self.device, non_blocking=True)
+            out.ready = torch.cuda.Event()
+            out.ready.record(self.stream)
+        return out
+
+
 class _Prefetcher(object):
     """Runs a generator on a background thread, `depth` items ahead of the consumer."""
     _END = object()
@@ -145,7 +199,8 @@ class _Prefetcher(object):
 
 
 class BatchIterator(object):
-    def __init__(self, dataset, batch_size, n_epochs, drop_remainder, shard=(0, 1), decode_batch=None, prefetch=2):
+    def __init__(self, dataset, batch_size, n_epochs, drop_remainder, shard=(0, 1), decode_batch=None, prefetch=2,
+                 device=None, upload_fields=(2, -2, -1)):
         self.dataset = dataset
         self.batch_size = int(batch_size)
         self.n_epochs = n_epochs
@@ -153,6 +208,7 @@ class BatchIterator(object):
         self.shard = shard
         self.decode_batch = decode_batch    # list of payloads -> batch tuple (native); None = parse + stack in Python
         self.prefetch = int(prefetch)
+        self.upload = _Uploader(device, upload_fields) if device is not None else None
         self._gen = None
         self.initializer()
 
@@ -172,9 +228,9 @@ class BatchIterator(object):
             epoch += 1
 
     def _make(self, payloads):
-        if self.decode_batch is not None:
-            return self.decode_batch(payloads)
-        return _collate([self.dataset.parse(p) for p in payloads])
+        batch = self.decode_batch(payloads) if self.decode_batch is not None else \
+            _collate([self.dataset.parse(p) for p in payloads])
+        return self.upload(batch) if self.upload is not None else batch
 
     def _batches(self):
         rank, world = self.shard
@@ -236,11 +292,13 @@ class DataManager:
         return Dataset(file_list, shuffle, seed, self.buffer_size, self.read_data_format_fixed)
 
     def get_iterator(self, dataset, batch_size=16, n_epochs=None, drop_remainder=False, shard=(0, 1), native=True,
-                     prefetch=2):
+                     prefetch=2, device=None):
         """`shard=(rank, world)` deals whole batches round-robin to data-parallel ranks.  `native=False`
-        parses with the pure-Python decoder, `prefetch=0` parses on the caller's thread."""
+        parses with the pure-Python decoder, `prefetch=0` parses on the caller's thread, `device` (e.g. 'cuda')
+        also uploads audio / video / mask from the prefetch thread (see `Batch`)."""
         it = BatchIterator(dataset, batch_size, n_epochs, drop_remainder, shard,
-                           decode_batch=self.decode_batch if native else None, prefetch=prefetch)
+                           decode_batch=self.decode_batch if native else None, prefetch=prefetch, device=device,
+                           upload_fields=(2, 3, -2, -1) if self.embedding_size else (2, -2, -1))
         return it, it
 
     def decode_batch(self, payloads):

@@ -32,8 +32,10 @@ def infer(model_path, data_path_test, audio_path, out_file_prefix, norm=True, or
                      video_feat_size=config['video_feat_dim'], buffer_size=4000, mode='fixed',
                      embedding_size=EMBEDDING_SIZE if uses_embeddings(config) else None)
     test_files = sorted(glob(os.path.join(data_path_test, '*.tfrecord')))
+    import torch
     _, test_it = dm.get_iterator(dm.get_dataset(test_files, shuffle=False), batch_size=batch_size, n_epochs=1,
-                                 drop_remainder=False, shard=(rank, world))
+                                 drop_remainder=False, shard=(rank, world),
+                                 device=torch.device('cuda', torch.cuda.current_device()))
 
     if norm:
         audio_feat_mean = np.load(os.path.join(model_path, 'audio_features_mean.npy'))

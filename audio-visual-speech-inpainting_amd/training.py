@@ -86,6 +86,14 @@ def unpack_batch(batch, with_embeddings, with_labels=False):
     else:
         length, lab_len, audio, paths, labels, video, mask = batch
         emb = None
+    if getattr(batch, 'device_arrays', None):
+        # uploaded by the reader's prefetch thread (dataset_reader.Batch): use the device copies, ordered behind
+        # their upload on the current stream
+        n = len(batch)
+        dev = lambda i, host: batch.to_device(i) if i in batch.device_arrays else host
+        audio, video, mask = dev(2, audio), dev(n - 2, video), dev(n - 1, mask)
+        if with_embeddings:
+            emb = dev(3, emb)
     feed = dict(sequence_lengths=length, target_sources=audio, video_features=video, masks=mask)
     if with_embeddings:
         feed['embeddings'] = emb
@@ -122,14 +130,16 @@ def train(config_file, checkpoint_format=None):
         return DataManager(num_audio_samples=config['audio_len'], audio_feat_size=feat_dim,
                            video_feat_size=config['video_feat_dim'], buffer_size=4000, mode='fixed',
                            embedding_size=EMBEDDING_SIZE if uses_embeddings(config) else None)
+    import torch
+    device = torch.device('cuda', torch.cuda.current_device())       # the reader uploads batches from its prefetch thread
     train_files = sorted(glob(os.path.join(data_path_train, '*.tfrecord')))
     random.Random(0 if world > 1 else None).shuffle(train_files)      # same order on every rank
     train_dm, val_dm = manager(), manager()
     _, train_it = train_dm.get_iterator(train_dm.get_dataset(train_files, shuffle=True, seed=1234 if world > 1 else None),
-                                        batch_size=config['batch_size'], n_epochs=1, shard=(rank, world))
+                                        batch_size=config['batch_size'], n_epochs=1, shard=(rank, world), device=device)
     val_files = sorted(glob(os.path.join(data_path_val, '*.tfrecord')))
     _, val_it = val_dm.get_iterator(val_dm.get_dataset(val_files, shuffle=False), batch_size=config['batch_size'],
-                                    n_epochs=1, shard=(rank, world))
+                                    n_epochs=1, shard=(rank, world), device=device)
 
     ctc = is_ctc(config)
     audio_feat_mean = np.load(config['audio_feat_mean'])
@@ -242,7 +252,8 @@ def train(config_file, checkpoint_format=None):
         nframe_sum = 0
         while True:
             try:
-                feed, _ = unpack_batch(train_it.get_next(), uses_embeddings(config), ctc)
+                batch = train_it.get_next()
+                feed, _ = unpack_batch(batch, uses_embeddings(config), ctc)
             except OutOfRangeError:
                 if chief:
                     if ctc:
@@ -266,7 +277,7 @@ def train(config_file, checkpoint_format=None):
             if np.isinf(vals[0]):
                 print('GOT INSTABILITY: loss is inf. Leaving...')
                 sys.exit(1)
-            train_avg, nframe_sum = accumulate(train_avg, vals, nframe_sum, np.count_nonzero(feed['masks'] == 0), n_step == 1)
+            train_avg, nframe_sum = accumulate(train_avg, vals, nframe_sum, np.count_nonzero(batch[-1] == 0), n_step == 1)
             if chief and (n_step % 200 == 0 or n_step == 1):
                 if ctc:
                     print('Step[{:7d}] Loss[{:3.5f}|{:3.5f}|{:3.5f}] PER[{:.5f}] LR[{:.6f}] Epoch training time[{:.2f}]'.format(
@@ -285,12 +296,13 @@ def train(config_file, checkpoint_format=None):
         nframe_sum = 0
         while True:
             try:
-                feed, _ = unpack_batch(val_it.get_next(), uses_embeddings(config), ctc)
+                batch = val_it.get_next()
+                feed, _ = unpack_batch(batch, uses_embeddings(config), ctc)
             except OutOfRangeError:
                 break
             n_step += 1
             model.feed(**feed)
-            val_avg, nframe_sum = accumulate(val_avg, fetch(False), nframe_sum, np.count_nonzero(feed['masks'] == 0),
+            val_avg, nframe_sum = accumulate(val_avg, fetch(False), nframe_sum, np.count_nonzero(batch[-1] == 0),
                                              n_step == 1)
             if chief and (n_step % 200 == 0 or n_step == 1):
                 print('Step[{:7d}] Loss[{:3.5f}]'.format(n_step, val_avg[1]))

@@ -208,3 +208,30 @@ def test_ctc_multitask_model_trains_and_infers(experiment, tmp_path, capsys):
     assert np.isfinite(loss)
     rate, wav = wavfile.read(str(audio_out / "clip_000" / "enhanced" / "ctc.wav"))
     assert rate == 16000 and wav.dtype == np.int16 and wav.shape == (T * 192,)
+
+
+def test_reader_uploads_batches_from_its_prefetch_thread(experiment):
+    """get_iterator(device=...): the bulky fields arrive as device tensors equal to the numpy ones, ordered by
+    an event instead of a host synchronisation; small fields stay on the host."""
+    import torch
+    from avsi_amd.dataset_reader import DataManager
+    from avsi_amd.training import unpack_batch
+    base, data, cfg = experiment
+    files = sorted(os.path.join(data, "training-set", f) for f in os.listdir(os.path.join(data, "training-set"))
+                   if f.endswith(".tfrecord"))
+    dm = DataManager(num_audio_samples=N, audio_feat_size=257, video_feat_size=136)
+    _, it = dm.get_iterator(dm.get_dataset(files, shuffle=False), batch_size=4, n_epochs=1, device='cuda')
+    _, ref = dm.get_iterator(dm.get_dataset(files, shuffle=False), batch_size=4, n_epochs=1)
+    n = 0
+    for b, r in zip(it, ref):
+        n += 1
+        assert sorted(b.device_arrays) == [2, 5, 6]           # audio, video, mask
+        feed, paths = unpack_batch(b, False)
+        assert feed['target_sources'].is_cuda and feed['masks'].is_cuda and isinstance(feed['sequence_lengths'], np.ndarray)
+        torch.cuda.current_stream().synchronize()
+        np.testing.assert_array_equal(feed['target_sources'].cpu().numpy(), r[2])
+        np.testing.assert_array_equal(feed['video_features'].cpu().numpy(), r[5])
+        np.testing.assert_array_equal(feed['masks'].cpu().numpy(), r[6])
+        np.testing.assert_array_equal(b[6], r[6])             # the host copy is still there
+        assert list(paths) == list(r[3])
+    assert n == 3
