@@ -224,13 +224,19 @@ def train(config_file, checkpoint_format=None):
     epoch_duration = 0.0
 
     def fetch(training):
-        """The reference's fetch list for one batch, as floats."""
+        """The reference's fetch list for one batch, still on the device (the CTC diagnostics are host work)."""
         if ctc:
-            vals = [float(model.loss), float(model.loss_hole), float(model.ctc_loss), float(np.mean(model.per))]
-        elif training:
-            vals = [float(model.loss), float(model.loss_func)]
-        else:
-            vals = [float(model.loss_func)] * 2
+            return [float(model.loss), float(model.loss_hole), float(model.ctc_loss), float(np.mean(model.per))]
+        if training:
+            return [model.loss, model.loss_func]
+        return [model.loss_func] * 2
+
+    def resolve(vals):
+        """Device scalars -> floats.  Called one step late in the training loop: reading a loss is a host
+        synchronisation, and doing it right after enqueuing the step would leave the GPU idle while the host
+        prepares the next one (12.3 -> ~9 ms per step of 32 utterances).  The NaN / Inf abort therefore fires one
+        step after the offending batch."""
+        vals = [float(x) for x in vals]
         ops.coop_check()                # the float() above synchronised; a cooperative-kernel timeout aborts here
         return vals
 
@@ -250,11 +256,37 @@ def train(config_file, checkpoint_format=None):
         if chief:
             print('-> Epoch {:d}'.format(epoch_counter))
         nframe_sum = 0
+        pending = None
+
+        def book(vals, frames, n_step, tot_step, lr):
+            """Bookkeeping of one finished training step (reference training_emb.py:244-262)."""
+            nonlocal train_avg, nframe_sum
+            vals = resolve(vals)
+            if np.isnan(vals[0]):
+                print('GOT INSTABILITY: loss is NaN. Leaving...')
+                sys.exit(1)
+            if np.isinf(vals[0]):
+                print('GOT INSTABILITY: loss is inf. Leaving...')
+                sys.exit(1)
+            train_avg, nframe_sum = accumulate(train_avg, vals, nframe_sum, frames, n_step == 1)
+            if chief and (n_step % 200 == 0 or n_step == 1):
+                if ctc:
+                    print('Step[{:7d}] Loss[{:3.5f}|{:3.5f}|{:3.5f}] PER[{:.5f}] LR[{:.6f}] Epoch training time[{:.2f}]'.format(
+                        tot_step, train_avg[0], train_avg[1], train_avg[2], train_avg[3], lr, time() - epoch_start_time))
+                else:
+                    print('Step[{:7d}] Loss[{:3.5f}|{:3.5f}] LR[{:.6f}] Epoch training time[{:.2f}]'.format(
+                        tot_step, train_avg[0], train_avg[1], lr, time() - epoch_start_time))
+            if chief and n_step % 1000 == 0:
+                print('Model checkpoint saved in file %s' % save_checkpoint(os.path.join(checkpoints_dir, 'ckpt')))
+
         while True:
             try:
                 batch = train_it.get_next()
                 feed, _ = unpack_batch(batch, uses_embeddings(config), ctc)
             except OutOfRangeError:
+                if pending is not None:
+                    book(*pending)
+                    pending = None
                 if chief:
                     if ctc:
                         print('Completed epoch {:d} at step {:d} --> Training loss: {:3.5f} - {:3.5f} - {:3.5f}; PER: {:3.5f}'
@@ -271,23 +303,9 @@ def train(config_file, checkpoint_format=None):
             model.feed(**feed)
             vals, lr = fetch(True), model.learning_rate
             model.train_op
-            if np.isnan(vals[0]):
-                print('GOT INSTABILITY: loss is NaN. Leaving...')
-                sys.exit(1)
-            if np.isinf(vals[0]):
-                print('GOT INSTABILITY: loss is inf. Leaving...')
-                sys.exit(1)
-            train_avg, nframe_sum = accumulate(train_avg, vals, nframe_sum, np.count_nonzero(batch[-1] == 0), n_step == 1)
-            if chief and (n_step % 200 == 0 or n_step == 1):
-                if ctc:
-                    print('Step[{:7d}] Loss[{:3.5f}|{:3.5f}|{:3.5f}] PER[{:.5f}] LR[{:.6f}] Epoch training time[{:.2f}]'.format(
-                        tot_step, train_avg[0], train_avg[1], train_avg[2], train_avg[3], lr, time() - epoch_start_time))
-                else:
-                    print('Step[{:7d}] Loss[{:3.5f}|{:3.5f}] LR[{:.6f}] Epoch training time[{:.2f}]'.format(
-                        tot_step, train_avg[0], train_avg[1], lr, time() - epoch_start_time))
-            if chief and n_step % 1000 == 0:
-                print('Model checkpoint saved in file %s' % save_checkpoint(os.path.join(checkpoints_dir, 'ckpt')))
-
+            step_done, pending = pending, (vals, np.count_nonzero(batch[-1] == 0), n_step, tot_step, lr)
+            if step_done is not None:
+                book(*step_done)
         if chief:
             print('Start validation set evaluation...')
         model.is_training = False          # validation: no BPTT reserve, no gradient stream
@@ -302,7 +320,7 @@ def train(config_file, checkpoint_format=None):
                 break
             n_step += 1
             model.feed(**feed)
-            val_avg, nframe_sum = accumulate(val_avg, fetch(False), nframe_sum, np.count_nonzero(batch[-1] == 0),
+            val_avg, nframe_sum = accumulate(val_avg, resolve(fetch(False)), nframe_sum, np.count_nonzero(batch[-1] == 0),
                                              n_step == 1)
             if chief and (n_step % 200 == 0 or n_step == 1):
                 print('Step[{:7d}] Loss[{:3.5f}]'.format(n_step, val_avg[1]))
