@@ -208,6 +208,10 @@ class BatchIterator(object):
         self.decode_batch = decode_batch    # list of payloads -> batch tuple (native); None = parse + stack in Python
         self.prefetch = int(prefetch)
         self.upload = _Uploader(device, upload_fields) if device is not None else None
+        # with a device the consumer works on the uploaded copies, so the host arrays are recycled: a batch's numpy
+        # fields stay valid until prefetch + 2 further batches have been fetched
+        self._arenas = [dict() for _ in range(self.prefetch + 3)] if device is not None else None
+        self._made = 0
         self._gen = None
         self.initializer()
 
@@ -227,8 +231,13 @@ class BatchIterator(object):
             epoch += 1
 
     def _make(self, payloads):
-        batch = self.decode_batch(payloads) if self.decode_batch is not None else \
-            _collate([self.dataset.parse(p) for p in payloads])
+        if self.decode_batch is None:
+            batch = _collate([self.dataset.parse(p) for p in payloads])
+        elif self._arenas is not None:
+            batch = self.decode_batch(payloads, self._arenas[self._made % len(self._arenas)])
+            self._made += 1
+        else:
+            batch = self.decode_batch(payloads)
         return self.upload(batch) if self.upload is not None else batch
 
     def _batches(self):
@@ -300,8 +309,10 @@ class DataManager:
                            upload_fields=(2, 3, -2, -1) if self.embedding_size else (2, -2, -1))
         return it, it
 
-    def decode_batch(self, payloads):
-        """Serialized records -> the batch tuple of the module docstring, parsed natively in parallel."""
+    def decode_batch(self, payloads, arena=None):
+        """Serialized records -> the batch tuple of the module docstring, parsed natively.  ``arena`` (a dict the
+        caller keeps) lets consecutive calls reuse their arrays instead of mapping 19 MB of fresh pages per batch
+        (half of the 0.22 ms per record); the arrays of a call are then only valid until the arena's next use."""
         L = _lib.lib()
         B = len(payloads)
         shape = (ctypes.c_int64 * 5)()
@@ -313,13 +324,20 @@ class DataManager:
         E = int(self.embedding_size or 0)
         if E and n_emb != E:
             raise ValueError("embedding has %d values, expected %d" % (n_emb, E))
+        def alloc(name, shape, dtype):
+            if arena is None:
+                return np.empty(shape, dtype=dtype)
+            a = arena.get(name)
+            if a is None or a.dtype != dtype or a.shape[1:] != tuple(shape[1:]) or a.shape[0] < shape[0]:
+                a = arena[name] = np.empty(shape, dtype=dtype)
+            return a[:shape[0]]
         lengths = np.empty((B, 2), dtype=np.int32)
-        wav = np.empty((B, n_wav), dtype=np.int32)
-        emb = np.empty((B, E), dtype=np.float32) if E else None
+        wav = alloc('wav', (B, n_wav), np.int32)
+        emb = alloc('emb', (B, E), np.float32) if E else None
         paths = ctypes.create_string_buffer(B * 1024)
-        labels = np.empty((B, n_lab), dtype=np.float32)
-        video = np.empty((B, Tv, self.video_feat_size), dtype=np.float32)
-        mask = np.empty((B, T, self.audio_feat_size), dtype=np.float32)
+        labels = alloc('labels', (B, n_lab), np.float32)
+        video = alloc('video', (B, Tv, self.video_feat_size), np.float32)
+        mask = alloc('mask', (B, T, self.audio_feat_size), np.float32)
         paths_addr = ctypes.addressof(paths)
 
         def row(a, i):
