@@ -109,6 +109,13 @@ class ParamLayout:
 
         # ---- packed layout
         self.kp = [input_pitch(self.input_dim)] + [2 * HP] * (self.num_layers - 1)
+        # A padded input column per layer (and of the projection's input) that the training pass sets to 1: its
+        # weight row is zero, so the forward pass is unchanged, and its row of dW = X^T . dZ is the column sum of
+        # dZ -- the bias gradient -- for free inside the weight-gradient GEMM.  -1: no padded column to spare
+        # (input width a multiple of 16), that layer's bias gradient is a separate column sum.
+        self.ones_col = [self.input_dim if self.kp[0] > self.input_dim else -1] + \
+            [H if H < HP else -1] * (self.num_layers - 1)
+        self.ones_col_top = H if H < HP else -1
         self.packed = {}                               # name -> (offset, shape)
         poff = 0
 
@@ -286,19 +293,23 @@ class ParamLayout:
                             dwe_off + np.arange(E)[:, None] * (2 * GP) + cols[None, :])
                     gi[k_off + (D + np.arange(H))[:, None] * (4 * H) + (g * H + u)[None, :]] = (
                         dwh_off + (d * HP + np.arange(H))[:, None] * GP + lcols[None, :])
-                    gi[bias_off + g * H + u] = db_off + cols
+                    if self.ones_col[li] >= 0:
+                        gi[bias_off + g * H + u] = dwx_off + self.ones_col[li] * (2 * GP) + cols
+                    else:
+                        gi[bias_off + g * H + u] = db_off + cols
         dpw_off, _ = self.gpacked['dpw']
         dpb_off, _ = self.gpacked['dpb']
         prow = np.concatenate([np.arange(H), HP + np.arange(H)])
         c = np.arange(F)
         gi[self._ref_off['logits/weights'] + np.arange(2 * H)[:, None] * F + c[None, :]] = (
             dpw_off + prow[:, None] * self.ldp + c[None, :])
-        gi[self._ref_off['logits/biases'] + c] = dpb_off + c
+        top = dpw_off + self.ones_col_top * self.ldp if self.ones_col_top >= 0 else dpb_off
+        gi[self._ref_off['logits/biases'] + c] = top + c
         if self.asr:
             a = np.arange(self.asr)
             gi[self._ref_off['asr/weights'] + np.arange(2 * H)[:, None] * self.asr + a[None, :]] = (
                 dpw_off + prow[:, None] * self.ldp + (self.asr_col + a)[None, :])
-            gi[self._ref_off['asr/biases'] + a] = dpb_off + self.asr_col + a
+            gi[self._ref_off['asr/biases'] + a] = top + self.asr_col + a
         if self.mlp:
             W = self.mlp
             w = np.arange(W)

@@ -324,7 +324,14 @@ class StackedBLSTMModel(object):
             ops.blstm_rec_fwd(xproj, v.p('wh%d' % li), hout, resv, self.rows_per_wg)
             c['layer_in'].append(x)
             c['reserve'].append(resv)
+            if keep and self.layout.ones_col[li] >= 0:
+                # the constant-1 input column of this layer (ParamLayout.ones_col): zero weights forward, bias
+                # gradient inside the dWx GEMM backward.  hout columns are written by the recurrent kernel, so the
+                # fill comes after it (nothing reads the column before the backward pass)
+                x[:, :B, self.layout.ones_col[li]] = 1.0
             x = hout
+        if keep and self.layout.ones_col_top >= 0:
+            x[:, :B, self.layout.ones_col_top] = 1.0
         c['rnn_out'] = x
         if not self.rows_per_wg and ops.coop_split(Bp):
             ops.coop_poll(self.device)       # small batches: a bounded wait that gave up surfaces here, without a sync
@@ -507,7 +514,8 @@ class StackedBLSTMModel(object):
 
         def head_grads():
             ops.gemm_splitk(h_top, dlog2, lay.gpacked_view(gp, 'dpw'), trans_a=True, m=2 * HP, n=ldp, k=M, splits=splits)
-            ops.colsum(dlog2, lay.gpacked_view(gp, 'dpb'), m=M, n=ldp)
+            if lay.ones_col_top < 0:
+                ops.colsum(dlog2, lay.gpacked_view(gp, 'dpb'), m=M, n=ldp)
         on_side(head_grads)
         dh = self._buf('dh', (T, Bp, 2 * HP))
         ops.gemm(dlog2, v.p('pw'), out=dh.view(M, 2 * HP), trans_b=True, m=M, n=2 * HP, k=ldp)
@@ -520,7 +528,8 @@ class StackedBLSTMModel(object):
             def weight_grads(li=li, kp=kp, dz=dz, dz2=dz2):
                 x = c['layer_in'][li].view(M, kp)
                 ops.gemm_splitk(x, dz2, lay.gpacked_view(gp, 'dwx%d' % li), trans_a=True, m=kp, n=2 * GP, k=M, splits=splits)
-                ops.colsum(dz2, lay.gpacked_view(gp, 'db%d' % li), m=M, n=2 * GP)
+                if lay.ones_col[li] < 0:
+                    ops.colsum(dz2, lay.gpacked_view(gp, 'db%d' % li), m=M, n=2 * GP)
                 if lay.side_dim(li):
                     # the side input saw every frame's dz: sum over time first, then two small GEMMs
                     E = lay.side_dim(li)
