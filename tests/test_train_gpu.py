@@ -98,16 +98,21 @@ def test_adam_kernel_matches_tf_form(mods):
     np.testing.assert_allclose(tm.cpu().numpy(), m, rtol=1e-5, atol=1e-7)   # fp32 slots vs float64 oracle
 
 
-@pytest.mark.parametrize("input_type,B,N", [('a', 5, 3840), ('av', 3, 2880), ('a', 34, 1920)])
-def test_gradients_match_oracle(mods, input_type, B, N):
+@pytest.mark.parametrize("input_type,B,N,Dv", [('a', 5, 3840, 136), ('av', 3, 2880, 136), ('a', 34, 1920, 136),
+                                              ('av', 3, 2880, 15)])
+def test_gradients_match_oracle(mods, input_type, B, N, Dv):
+    """Dv = 15 makes the network input 272 wide: no padded column to spare, so layer 0 takes its bias gradient
+    from a column sum instead of the constant-1 column of the weight-gradient GEMM (ParamLayout.ones_col)."""
     models, ops, bl = mods
     wav, masks, mean, std, video, T = _inputs(B, N, 30 + B)
-    D = {'a': 257, 'av': 393}[input_type]
+    video = video[:, :, :Dv]
+    D = {'a': 257, 'av': 257 + Dv}[input_type]
     p = _rand_biases(O.init_params(9, D), 10)
     seq_len = np.full(B, T)
     seq_len[0] = T - 2
-    m = models.StackedBLSTMModel(seq_len, wav, masks, mean, std, 0.0, _config(audio_len=N), video_features=video,
-                                 input=input_type)
+    m = models.StackedBLSTMModel(seq_len, wav, masks, mean, std, 0.0, _config(audio_len=N, video_feat_dim=Dv),
+                                 video_features=video, input=input_type)
+    assert (m.layout.ones_col[0] < 0) == (D % 16 == 0) and m.layout.ones_col[1] == 250
     m.variables.load_flat(m.layout.flatten_oracle_params(p))
     got = m.gradients.cpu().numpy().astype(np.float64)
     fwd = O.model_forward(wav, masks, mean, std, seq_len, p, video=video, input_type=input_type, keep=True)
