@@ -25,9 +25,11 @@ def init(backend=None):
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
-        if backend == "nccl":
-            torch.cuda.set_device(local_rank)
+            # AVSI_DIST_BACKEND=gloo: ranks that share one GPU (tests on a single-GPU box; RCCL refuses two ranks
+            # on one device) -- the gradient all-reduce is then staged through the host
+            backend = os.environ.get("AVSI_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
+        if torch.cuda.is_available():
+            torch.cuda.set_device(local_rank % torch.cuda.device_count())
         dist.init_process_group(backend, rank=rank, world_size=world)
     return rank, world
 
@@ -50,7 +52,12 @@ def shard_range(n, rank_, world):
 def all_reduce_sum_(flat):
     """In-place sum over ranks of one flat buffer (no-op on a single process)."""
     if world_size() > 1:
-        dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+        if flat.is_cuda and dist.get_backend() != 'nccl':
+            host = flat.cpu()
+            dist.all_reduce(host, op=dist.ReduceOp.SUM)
+            flat.copy_(host)
+        else:
+            dist.all_reduce(flat, op=dist.ReduceOp.SUM)
     return flat
 
 

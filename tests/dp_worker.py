@@ -1,0 +1,54 @@
+"""Worker of tests/test_dp_gpu.py: one data-parallel rank (launched by torch.distributed.run) trains the AV model
+for a few steps on ITS half of a fixed batch; rank 0 stores the resulting variables."""
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def make_inputs(B, N=2880):
+    rng = np.random.default_rng(123)
+    wav = np.clip(np.round(rng.normal(0, 3000, size=(B, N))), -32768, 32767).astype(np.float32)
+    T = -(-N // 192)
+    masks = np.ones((B, T, 257), dtype=np.float32)
+    for b in range(B):
+        masks[b, 3 + b % 4: 7 + b % 4] = 0
+    video = rng.normal(size=(B, T, 136)).astype(np.float32)
+    mean = rng.normal(0, 1, size=257).astype(np.float32)
+    std = (1.0 + rng.random(257)).astype(np.float32)
+    return wav, masks, video, mean, std, T
+
+
+def config(N, B):
+    return dict(audio_feat_dim=257, video_feat_dim=136, audio_len=N, net_dim=[250, 250, 250], optimizer_type='adam',
+                starter_learning_rate=1e-3, lr_updating_steps=10000, lr_decay=1.0, batch_size=B, l2=0.0)
+
+
+def run(rank, world, steps, B_global=4):
+    import avsi_amd  # noqa: F401
+    from avsi_amd import models
+    wav, masks, video, mean, std, T = make_inputs(B_global)
+    per = B_global // world
+    sl = slice(rank * per, (rank + 1) * per)
+    m = models.StackedBLSTMModel(np.full(per, T), wav[sl], masks[sl], mean, std, 0.0, config(wav.shape[1], per),
+                                 video_features=video[sl], input='av', seed=7)
+    losses = []
+    for _ in range(steps):
+        m.feed(sequence_lengths=np.full(per, T), target_sources=wav[sl], masks=masks[sl], video_features=video[sl])
+        losses.append(float(m.loss_func))
+        m.train_op
+    return m.variables.flat.cpu().numpy(), losses
+
+
+if __name__ == '__main__':
+    out = sys.argv[1]
+    from avsi_amd import parallel
+    rank, world = parallel.init()
+    flat, losses = run(rank, world, steps=3)
+    np.save(os.path.join(out, 'flat_rank%d.npy' % rank), flat)
+    np.save(os.path.join(out, 'loss_rank%d.npy' % rank), np.array(losses))
+    import torch.distributed as dist
+    dist.barrier()
+    dist.destroy_process_group()
