@@ -180,7 +180,7 @@ def bench_unet(args, torch, dist, rank, world, device):
         dist.barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        tmax = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        tmax = torch.tensor([elapsed], device=device if dist.get_backend() == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
     if rank == 0:
@@ -244,11 +244,18 @@ def main():
     if args.gpus != world:
         if world == 1 and args.gpus > 1:
             sys.exit("bench.py --gpus %d must be launched with torch.distributed.run (one rank per GPU)" % args.gpus)
+    local_rank %= torch.cuda.device_count()        # ranks sharing a GPU (gloo rehearsal) all map onto it
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        # RCCL (backend "nccl") in production; AVSI_DIST_BACKEND=gloo lets several ranks share one GPU to rehearse
+        # the multi-rank path on a single-GPU box (tests/test_bench_contract_gpu.py)
+        backend = os.environ.get("AVSI_DIST_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     if args.mode == "unet":
         return bench_unet(args, torch, dist, rank, world, device)
@@ -305,7 +312,7 @@ def main():
         dist.barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        tmax = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        tmax = torch.tensor([elapsed], device=device if dist.get_backend() == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
     loss_val = float(loss)

@@ -42,3 +42,28 @@ def test_train_and_unet_modes():
     assert t["unit"] == "utterances/s" and t["value"] > 0 and "blstm_rec_bwd" in t["kernel_ms_per_step"]
     u = _run("--mode", "unet", "--batch", "64", "--steps", "2", "--warmup", "1")
     assert u["unit"] == "clips/s" and u["value"] > 0 and u["vs_baseline"] is None
+
+
+@pytest.mark.parametrize("mode", ["infer", "train"])
+def test_multi_rank_launch_as_the_driver_does(mode):
+    """`python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 ... bench.py --gpus 2`: rank 0 alone prints
+    the line, the value is the whole-job aggregate, no CPU baseline leg.  The two ranks share this box's one GPU, so
+    the process group is gloo here (AVSI_DIST_BACKEND); the driver's 8-GPU node uses RCCL."""
+    import socket
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, AVSI_DIST_BACKEND='gloo', HSA_ENABLE_IPC_MODE_LEGACY='0', AVSI_COOP_CUS='128')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+           '--master-port', str(port), os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '2', '--warmup', '1',
+           '--batch', '64', '--mode', mode]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["config"]["global_batch"] == 128
+    assert d["config"]["parallelism"] == "dp2"
+    assert abs(d["value"] - 2 * 64 * 2 / (d["ms_per_step"] * 2e-3)) < 1e-6 * d["value"]
+    assert "cpu_baseline" not in d or d["cpu_baseline"] is None
