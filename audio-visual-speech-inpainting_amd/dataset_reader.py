@@ -199,8 +199,11 @@ class _Prefetcher(object):
 
 class BatchIterator(object):
     def __init__(self, dataset, batch_size, n_epochs, drop_remainder, shard=(0, 1), decode_batch=None, prefetch=2,
-                 device=None, upload_fields=(2, -2, -1)):
+                 device=None, upload_fields=(2, -2, -1), even_rounds=False):
         self.dataset = dataset
+        # data-parallel training does one collective per step: every rank must see the same number of batches, so
+        # batches are dealt in whole rounds of `world` and a last incomplete round (and a short last batch) is dropped
+        self.even_rounds = bool(even_rounds) and shard[1] > 1
         self.batch_size = int(batch_size)
         self.n_epochs = n_epochs
         self.drop_remainder = drop_remainder
@@ -242,15 +245,20 @@ class BatchIterator(object):
 
     def _batches(self):
         rank, world = self.shard
-        batch, index = [], 0
+        batch, index, mine = [], 0, None
         for p in self._payloads():
             batch.append(p)
             if len(batch) == self.batch_size:
                 if index % world == rank:
-                    yield self._make(batch)
+                    mine = batch
+                    if not self.even_rounds:
+                        yield self._make(mine)
                 index += 1
                 batch = []
-        if batch and not self.drop_remainder and index % world == rank:
+                if self.even_rounds and index % world == 0:     # a whole round of `world` batches exists: hand out ours
+                    yield self._make(mine)
+                    mine = None
+        if batch and not self.drop_remainder and not self.even_rounds and index % world == rank:
             yield self._make(batch)
 
     def get_next(self):
@@ -300,13 +308,14 @@ class DataManager:
         return Dataset(file_list, shuffle, seed, self.buffer_size, self.read_data_format_fixed)
 
     def get_iterator(self, dataset, batch_size=16, n_epochs=None, drop_remainder=False, shard=(0, 1), native=True,
-                     prefetch=2, device=None):
+                     prefetch=2, device=None, even_rounds=False):
         """`shard=(rank, world)` deals whole batches round-robin to data-parallel ranks.  `native=False`
         parses with the pure-Python decoder, `prefetch=0` parses on the caller's thread, `device` (e.g. 'cuda')
-        also uploads audio / video / mask from the prefetch thread (see `Batch`)."""
+        also uploads audio / video / mask from the prefetch thread (see `Batch`), `even_rounds` gives every rank the same
+        number of (full) batches -- what a training loop with one collective per step needs."""
         it = BatchIterator(dataset, batch_size, n_epochs, drop_remainder, shard,
                            decode_batch=self.decode_batch if native else None, prefetch=prefetch, device=device,
-                           upload_fields=(2, 3, -2, -1) if self.embedding_size else (2, -2, -1))
+                           upload_fields=(2, 3, -2, -1) if self.embedding_size else (2, -2, -1), even_rounds=even_rounds)
         return it, it
 
     def decode_batch(self, payloads, arena=None):

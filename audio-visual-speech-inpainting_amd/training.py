@@ -136,7 +136,8 @@ def train(config_file, checkpoint_format=None):
     random.Random(0 if world > 1 else None).shuffle(train_files)      # same order on every rank
     train_dm, val_dm = manager(), manager()
     _, train_it = train_dm.get_iterator(train_dm.get_dataset(train_files, shuffle=True, seed=1234 if world > 1 else None),
-                                        batch_size=config['batch_size'], n_epochs=1, shard=(rank, world), device=device)
+                                        batch_size=config['batch_size'], n_epochs=1, shard=(rank, world), device=device,
+                                        even_rounds=True)
     val_files = sorted(glob(os.path.join(data_path_val, '*.tfrecord')))
     _, val_it = val_dm.get_iterator(val_dm.get_dataset(val_files, shuffle=False), batch_size=config['batch_size'],
                                     n_epochs=1, shard=(rank, world), device=device)

@@ -235,3 +235,34 @@ def test_reader_uploads_batches_from_its_prefetch_thread(experiment):
         np.testing.assert_array_equal(b[6], r[6])             # the host copy is still there
         assert list(paths) == list(r[3])
     assert n == 3
+
+
+def test_data_parallel_training_through_the_driver(experiment, tmp_path):
+    """train() under torch.distributed.run with two ranks (sharing this box's GPU: gloo process group): batches are
+    dealt in whole rounds, every rank takes the same number of steps, gradients are all-reduced inside train_op,
+    rank 0 alone writes the log and the checkpoints."""
+    import socket
+    import subprocess
+    import sys
+    base, data, cfg0 = experiment
+    exp = tmp_path / "logs" / "dp_exp"
+    text = open(cfg0).read().replace("exp_folder = %s" % (base / "logs" / "av_exp0"), "exp_folder = %s" % exp)
+    text = text.replace("max_n_epochs = 3", "max_n_epochs = 2")
+    cfg = tmp_path / "dp.config"
+    cfg.write_text(text)
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, AVSI_DIST_BACKEND='gloo', HSA_ENABLE_IPC_MODE_LEGACY='0', AVSI_COOP_CUS='128')
+    here = os.path.dirname(os.path.abspath(__file__))
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+           '--master-port', str(port), os.path.join(here, 'dp_train_worker.py'), str(cfg)]
+    run = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert run.returncode == 0, run.stderr[-3000:]
+    # 12 training samples in batches of 4 = 3 batches = one whole round of two + one left over (dropped): one step per epoch
+    assert 'RANK 0 STEPS 2' in run.stdout and 'RANK 1 STEPS 2' in run.stdout
+    log = (exp / "training_log.txt").read_text().splitlines()
+    assert len([l for l in log if l[:1].isdigit()]) == 2 and log[0] == "+-- EXPERIMENT NAME - dp_exp --+"
+    assert (exp / "netmodel" / "sinet.npz").is_file()
+    assert run.stdout.count('+---- Done training: epoch limit reached ----+') == 1      # rank 0 only

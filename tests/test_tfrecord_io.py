@@ -285,3 +285,22 @@ def test_native_decoder_survives_corrupted_records():
             outcomes['rejected'] += 1
     assert outcomes['rejected'] > 300 and outcomes['ok'] + outcomes['rejected'] == 600
     np.testing.assert_array_equal(dm.decode_batch([rec])[2], ref[2])     # and the decoder still works afterwards
+
+
+def test_even_rounds_give_every_rank_the_same_number_of_batches(tmp_path):
+    """7 samples, batches of 2, two ranks: 3 full batches + 1 short one.  A training loop does one collective per
+    step, so with even_rounds each rank gets exactly one batch (round 0) and the rest of the epoch is dropped;
+    without it rank 0 would get two and rank 1 one -- and rank 0 would wait for ever."""
+    files, truth = _write_dataset(tmp_path, 7)
+    dm = dr.DataManager(2304, 257, 136, buffer_size=2)
+    ds = dm.get_dataset(files, shuffle=False)
+    got = []
+    for rank in (0, 1):
+        _, it = dm.get_iterator(ds, batch_size=2, n_epochs=1, shard=(rank, 2), even_rounds=True)
+        got.append([list(b[3]) for b in it])
+    assert [len(g) for g in got] == [1, 1]
+    assert got[0][0] == [truth[0][6], truth[1][6]] and got[1][0] == [truth[2][6], truth[3][6]]
+    _, plain = dm.get_iterator(ds, batch_size=2, n_epochs=1, shard=(0, 2))
+    assert [len(b[0]) for b in plain] == [2, 2]            # batches 0 and 2 (the short one, index 3, is rank 1's)
+    _, single = dm.get_iterator(ds, batch_size=2, n_epochs=1, even_rounds=True)
+    assert [len(b[0]) for b in single] == [2, 2, 2, 1]     # one process: nothing to even out
