@@ -80,6 +80,8 @@ def infer(model_path, data_path_test, audio_path, out_file_prefix, norm=True, or
         total_samples += len(test_length)
         print('Written {:d} enhanced wavs. Total samples written so far {:d}.'.format(len(test_length), total_samples))
 
-    (mean_loss,) = parallel.all_reduce_mean_scalars([float(np.mean(loss_list)) if loss_list else 0.0])
+    # np.mean over the batches of ALL ranks (reference inference.py:170), whatever share of them each rank had
+    tot, cnt = parallel.all_reduce_sum_scalars([float(np.sum(loss_list)), float(len(loss_list))])
+    mean_loss = tot / cnt if cnt else 0.0
     print('Loss hole: {:.5}'.format(mean_loss))
     return mean_loss

@@ -69,3 +69,13 @@ def all_reduce_mean_scalars(values):
     t = torch.tensor(list(values), dtype=torch.float64, device=dev)
     dist.all_reduce(t, op=dist.ReduceOp.SUM)
     return (t / world_size()).tolist()
+
+
+def all_reduce_sum_scalars(values):
+    """Sum over ranks of a few python floats; returns a list of floats."""
+    if world_size() == 1:
+        return list(values)
+    dev = 'cuda' if dist.get_backend() == 'nccl' else 'cpu'
+    t = torch.tensor(list(values), dtype=torch.float64, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return t.tolist()

@@ -326,7 +326,11 @@ def train(config_file, checkpoint_format=None):
             if chief and (n_step % 200 == 0 or n_step == 1):
                 print('Step[{:7d}] Loss[{:3.5f}]'.format(n_step, val_avg[1]))
         model.is_training = True
-        val_avg = list(parallel.all_reduce_mean_scalars(val_avg))
+        if world > 1:
+            # combine the ranks' frame-weighted means (a rank may have seen no validation batch at all)
+            w = float(nframe_sum) if n_step else 0.0
+            sums = parallel.all_reduce_sum_scalars([a * w if n_step else 0.0 for a in val_avg] + [w])
+            val_avg = [v / sums[-1] if sums[-1] > 0 else float('nan') for v in sums[:-1]]
         val_avg_loss = val_avg[1]          # model selection: loss_func (plain) / the inpainting loss (training_ctc.py:383-392)
         if chief:
             print('done.')

@@ -89,3 +89,24 @@ def test_single_process_helpers_are_noops():
     assert parallel.world_size() == 1 and parallel.rank() == 0
     assert torch.equal(parallel.all_reduce_sum_(t.clone()), t)
     assert parallel.all_reduce_mean_scalars([1.5, 2.5]) == [1.5, 2.5]
+
+
+def _sum_worker(rank, world, port, out):
+    import os
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import avsi_amd  # noqa: F401
+    from avsi_amd import parallel
+    parallel.init(backend="gloo")
+    # rank 1 saw no batch at all: frame-weighted means combine to rank 0's value, not to half of it
+    vals, frames = ([0.5, 0.25], 40.0) if rank == 0 else ([float('nan'), float('nan')], 0.0)
+    sums = parallel.all_reduce_sum_scalars([v * frames if frames else 0.0 for v in vals] + [frames])
+    if rank == 0:
+        np.save(out, np.array([s / sums[-1] for s in sums[:-1]]))
+    import torch.distributed as dist
+    dist.destroy_process_group()
+
+
+def test_weighted_combination_ignores_ranks_without_batches(tmp_path):
+    out = str(tmp_path / "sums.npy")
+    mp.spawn(_sum_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    np.testing.assert_allclose(np.load(out), [0.5, 0.25])
