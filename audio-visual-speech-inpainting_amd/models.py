@@ -502,6 +502,18 @@ class StackedBLSTMModel(object):
                 self._side_stream = torch.cuda.Stream(device=self.device)
             side = self._side_stream
 
+        # Data parallel (train_op sets _reduce_in_backward): the packed gradient buffer is all-reduced in buckets --
+        # one per layer, started right behind that layer's weight-gradient kernels, and the head at the end -- so
+        # the collectives of the upper layers run while the BPTT of the lower ones is still going
+        reduce = bool(getattr(self, '_reduce_in_backward', False)) and parallel.world_size() > 1
+        works = []
+
+        def reduce_from(name, upto=None):
+            if reduce:
+                lo = lay.gpacked[name][0]
+                hi = lay.gpacked_size if upto is None else lay.gpacked[upto][0]
+                works.append(parallel.all_reduce_sum_async(gp[lo:hi]))
+
         def on_side(fn):
             """Run fn on the side stream once everything enqueued on the main stream so far has finished."""
             if not overlap:
@@ -548,11 +560,17 @@ class StackedBLSTMModel(object):
                     ops.gemm_splitk(hout[Bp:, HP:], dz2[:Mr, GP:], dwh[1], trans_a=True, m=HP, n=GP, k=Mr, splits=splits)
                 else:
                     dwh.zero_()
+                reduce_from('dwx%d' % li, 'dwx%d' % (li + 1) if li + 1 < self.num_layers else 'dpw')
             on_side(weight_grads)
             if li > 0:
                 ops.gemm(dz2, v.p('wx%d' % li), out=dh.view(M, 2 * HP), trans_b=True, m=M, n=2 * HP, k=2 * GP)
         if overlap:
             main.wait_stream(side)
+        reduce_from('dpw')                       # projection head (+ the speaker-embedding MLP of the SSNN variant)
+        for w in works:
+            if w is not None:
+                w.wait()
+        c['grads_reduced'] = reduce
         if ops.coop_split(Bp):
             ops.coop_poll(self.device)
         grads = v.unpack_grads(gp, out=self._buf('grads', (lay.ref_size,)))
@@ -576,10 +594,16 @@ class StackedBLSTMModel(object):
         c = self._cache
         if c.get('trained'):
             return None
-        g = self._backward()
+        self._reduce_in_backward = 'grads' not in c
+        try:
+            g = self._backward()
+        finally:
+            self._reduce_in_backward = False
         v = self.variables
         world = parallel.world_size()
-        parallel.all_reduce_sum_(g)
+        if not c.get('grads_reduced'):
+            parallel.all_reduce_sum_(g)          # gradients were fetched (unreduced) before train_op: one flat all-reduce
+            c['grads_reduced'] = world > 1
         step = v.global_step + 1
         l2 = float(self.regularization or 0.0)
         if self.optimizer_choice == 'adam':

@@ -1,8 +1,9 @@
 """Single-node data parallelism: one process per GPU, torch.distributed over RCCL (backend "nccl"
 on ROCm) for the GPUs, gloo for CPU-side tests.
 
-The hot path shards by utterance: inference needs no data-path collective; training needs ONE
-all-reduce per step over the flat reference-layout gradient buffer (4.15 M / 4.42 M floats).
+The hot path shards by utterance: inference needs no data-path collective; training all-reduces the
+gradients once per step (4.15 M / 4.42 M floats), in per-layer buckets of the packed gradient buffer that
+overlap with the backward pass (StackedBLSTMModel._backward).
 The loss is a mean over B*T*F, so summing per-rank gradients and dividing by the world size
 reproduces the single-GPU gradient of the global batch when ranks hold equal batches.
 """
@@ -79,3 +80,16 @@ def all_reduce_sum_scalars(values):
     t = torch.tensor(list(values), dtype=torch.float64, device=dev)
     dist.all_reduce(t, op=dist.ReduceOp.SUM)
     return t.tolist()
+
+
+def all_reduce_sum_async(flat):
+    """Start the in-place sum over ranks of one buffer and return a handle to wait() on (None when there is nothing
+    to wait for).  With RCCL the collective runs on the communicator's stream, ordered after the work already
+    enqueued on the current stream: called right after the kernels that produced `flat`, it overlaps with whatever
+    the caller enqueues next (the BPTT of the layers below)."""
+    if world_size() == 1:
+        return None
+    if flat.is_cuda and dist.get_backend() == 'nccl':
+        return dist.all_reduce(flat, op=dist.ReduceOp.SUM, async_op=True)
+    all_reduce_sum_(flat)
+    return None
