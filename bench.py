@@ -48,22 +48,38 @@ def algorithmic_flops(batch, input_dim=257):
 
 class KernelTimer:
     """HIP-event pairs on the launch stream (torch's current stream is the stream the C ABI
-    launches on), grouped by kernel name."""
+    launches on), grouped by kernel name.  Events come from a pool that reset() fills OUTSIDE the timed
+    region: creating a few thousand events inside it (70 launches per U-Net step) stalls the host for ~50 ms
+    once the runtime has to grow its event pool."""
 
     def __init__(self, torch):
         self.torch = torch
         self.events = {}
+        self.pool = []
+
+    def _event(self):
+        return self.pool.pop() if self.pool else self.torch.cuda.Event(enable_timing=True)
 
     def wrap(self, name, fn):
         def timed(*a, **kw):
-            s = self.torch.cuda.Event(enable_timing=True)
-            e = self.torch.cuda.Event(enable_timing=True)
+            s, e = self._event(), self._event()
             s.record()
             out = fn(*a, **kw)
             e.record()
             self.events.setdefault(name, []).append((s, e))
             return out
         return timed
+
+    def reset(self, steps, warmup):
+        """After the warm-up: recycle its events and create what `steps` timed steps will need on top."""
+        used = sum(len(v) for v in self.events.values())
+        for v in self.events.values():
+            for s, e in v:
+                self.pool += [s, e]
+        self.events.clear()
+        need = 2 * (used // max(warmup, 1) + 8) * steps
+        while len(self.pool) < need:
+            self.pool.append(self.torch.cuda.Event(enable_timing=True))
 
     def totals(self):
         return {k: (sum(s.elapsed_time(e) for s, e in v), len(v)) for k, v in self.events.items()}
@@ -168,7 +184,7 @@ def bench_unet(args, torch, dist, rank, world, device):
 
     for _ in range(args.warmup):
         step()
-    timer.events.clear()
+    timer.reset(args.steps, args.warmup)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -300,7 +316,7 @@ def main():
 
     for _ in range(args.warmup):
         step()
-    timer.events.clear()
+    timer.reset(args.steps, args.warmup)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
