@@ -196,11 +196,24 @@ def _istft_tables(device, frame_len, hop, nfft):
     return tab
 
 
+def enclosing_power_of_two(n):
+    """2 ** ceil(log2(n)): the fft length tf.contrib.signal.inverse_stft uses when none is given."""
+    return 1 << max(0, int(n) - 1).bit_length()
+
+
 def _istft(mode, in0, in1, in2, mean, std, B, T, F, num_samples, sample_rate, window_size, step_size,
-           in_strides, in1_strides=(0, 0), in2_strides=(0, 0), nfft=512):
+           in_strides, in1_strides=(0, 0), in2_strides=(0, 0), nfft=None):
+    """``nfft=None`` follows TF 1.x: fft length = enclosing power of two of the frame length (the reference never
+    passes one, audio_processing.py:149-151), and irfft crops / zero-pads the bin axis to nfft / 2 + 1 -- the
+    kernel reads ``min(F, nfft / 2 + 1)`` bins of each row and treats the rest of the grid as zero."""
     _lib.require_cuda(in0, in1, in2, mean, std)
     frame_len = ms_to_samples(window_size, sample_rate)
     hop = ms_to_samples(step_size, sample_rate)
+    if nfft is None:
+        nfft = enclosing_power_of_two(frame_len)
+    if nfft not in (256, 512):
+        raise _lib.AvsiError("inverse STFT: fft length %d (frame of %d samples) is not 256 or 512" % (nfft, frame_len))
+    F = min(F, nfft // 2 + 1)
     full = (T - 1) * hop + frame_len
     n_out = full if not num_samples or num_samples <= 0 else min(int(num_samples), full)
     dev = in0.device
@@ -222,13 +235,12 @@ def _istft(mode, in0, in1, in2, mean, std, B, T, F, num_samples, sample_rate, wi
 
 def reconstruct_sources(stfts, num_samples=0, sample_rate=16000, window_size=16, step_size=8):
     """Compute inverse STFT -- reference audio_processing.py:145-157.  stfts complex64 [B, T, F]."""
-    nfft = (stfts.shape[2] - 1) * 2           # tf.contrib.signal.inverse_stft infers the fft length this way
-    if stfts.dtype != torch.complex64 or nfft not in (256, 512):
-        raise _lib.AvsiError("reconstruct_sources needs complex64 [B, T, 257] or [B, T, 129] (fft length 512 / 256)")
+    if stfts.dtype != torch.complex64 or stfts.dim() != 3:
+        raise _lib.AvsiError("reconstruct_sources needs complex64 [B, T, F]")
     x = torch.view_as_real(stfts.contiguous())
     B, T, F = stfts.shape
     return _istft(0, x, None, None, None, None, B, T, F, num_samples, sample_rate, window_size, step_size,
-                  (x.stride(0), x.stride(1)), nfft=nfft)
+                  (x.stride(0), x.stride(1)))
 
 
 def get_sources(mag_spectrograms, rec_ang_spectrograms, num_samples=48000, sample_rate=16000, window_size=24,

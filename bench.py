@@ -12,7 +12,9 @@ inpainter on 3 s / 16 kHz clips with one 400 ms gap each.
 
 For N > 1 launch with torch.distributed.run (one rank per GPU); utterances are sharded across
 ranks with no data-path collective (weak scaling: per-GPU batch fixed).  Rank 0 prints ONE JSON
-line.  `roofline` is measured live with HIP events on the launch stream around the dominant
+line.  Its `also` block reports the sizes the reference and BASELINE.json name (inference at 100 and
+32 utterances, AV training at 32 utterances per GPU -- with the gradient all-reduce when N > 1), each
+with its own ms_per_step, measured after the headline.  `roofline` is measured live with HIP events on the launch stream around the dominant
 kernel; `cpu_baseline` times the CPU oracle (a numpy port of the reference graph) on a bounded
 sample of the same workload on this node's host cores.
 """
@@ -99,56 +101,72 @@ def synth_batch(torch, batch, seed, device):
     return wav, masks
 
 
-def cpu_baseline(torch, model, wav, masks, mean, std, sample, cpu_batch):
+def cpu_baseline(torch, model, wav, masks, mean, std, sample, pred_gpu):
     """Time the CPU oracle (float32 numpy, explicit per-step loop = the reference's
-    stack_bidirectional_dynamic_rnn schedule) on `sample` utterances of the same workload, and
-    use its output as the checker for the GPU result on those utterances."""
+    stack_bidirectional_dynamic_rnn schedule) on `sample` utterances of the same workload, in batches of 32
+    (scripts/inference.sh:7) and of 8 (scripts/config/blstm.config:8), and use its output as the checker for
+    `pred_gpu`: the first `sample` rows of the prediction of the LAST TIMED step (so the kernels that are
+    checked are the kernels that were timed)."""
     from oracle import blstm as OB
     from oracle import frontend as OF
     params = model.layout.unflatten_to_oracle_params(model.variables.flat.cpu().numpy())
     w = wav[:sample].cpu().numpy()
     m = masks[:sample].cpu().numpy()
     mean_h, std_h = mean.cpu().numpy(), std.cpu().numpy()
-    seq = np.full(cpu_batch, T_FRAMES)
-    OB.model_forward(w[:cpu_batch], m[:cpu_batch], mean_h, std_h, seq, params, dtype=np.float32)   # warm-up
-    preds = []
-    t0 = time.perf_counter()
-    for i in range(0, sample, cpu_batch):
-        out = OB.model_forward(w[i:i + cpu_batch], m[i:i + cpu_batch], mean_h, std_h,
-                               np.full(len(w[i:i + cpu_batch]), T_FRAMES), params, dtype=np.float32)
-        preds.append(out['prediction'])
-    dt = time.perf_counter() - t0
-    pred_cpu = np.concatenate(preds).astype(np.float64)
-    # checker: reconstructed log-mel RMS, GPU vs CPU oracle, on the sample
-    model.feed(sequence_lengths=np.full(sample, T_FRAMES), target_sources=wav[:sample], masks=masks[:sample])
-    pred_gpu = model.prediction.cpu().numpy().astype(np.float64)
+    OB.model_forward(w[:8], m[:8], mean_h, std_h, np.full(8, T_FRAMES), params, dtype=np.float32)   # warm-up
+
+    def run(n, cpu_batch):
+        preds = []
+        t0 = time.perf_counter()
+        for i in range(0, n, cpu_batch):
+            out = OB.model_forward(w[i:i + cpu_batch], m[i:i + cpu_batch], mean_h, std_h,
+                                   np.full(len(w[i:i + cpu_batch]), T_FRAMES), params, dtype=np.float32)
+            preds.append(out['prediction'])
+        return np.concatenate(preds), time.perf_counter() - t0
+
+    pred32, dt32 = run(sample, 32)
+    n8 = max(8, (sample // 3) // 8 * 8)
+    _, dt8 = run(n8, 8)
+    pred_cpu = pred32.astype(np.float64)
     lm_cpu = OF.logmel_of_prediction(pred_cpu, mean_h, std_h)
-    lm_gpu = OF.logmel_of_prediction(pred_gpu, mean_h, std_h)
+    lm_gpu = OF.logmel_of_prediction(pred_gpu.astype(np.float64), mean_h, std_h)
     rms = float(np.sqrt(np.mean((lm_cpu - lm_gpu) ** 2)))
     try:
         cores = len(os.sched_getaffinity(0))
     except AttributeError:
         cores = os.cpu_count()
-    # best-case CPU line (SURVEY 8d): the same network shape through torch's fused CPU LSTM (oneDNN),
-    # random weights, network only (no front end) -- an upper bound for what a CPU port could reach
+    # best-case CPU line (SURVEY 8d): the same network shape through torch's fused CPU LSTM (oneDNN), random
+    # weights, network only (no front end) -- an upper bound for what a CPU port could reach.  Threads pinned to
+    # the physical share of this process (an unpinned run on a 128-thread host was SLOWER than the numpy loop:
+    # oversubscription), whole sample as one batch per call.
     fused = None
     try:
+        threads_before = torch.get_num_threads()
+        torch.set_num_threads(max(1, min(cores, 32)))
         with torch.no_grad():
             F = model.audio_feat_dim
             net = torch.nn.LSTM(F, 250, num_layers=3, bidirectional=True, batch_first=True)
             proj = torch.nn.Linear(500, F)
             x = torch.randn(sample, T_FRAMES, F)
-            proj(net(x[:cpu_batch])[0])
-            t1 = time.perf_counter()
-            for i in range(0, sample, cpu_batch):
-                proj(net(x[i:i + cpu_batch])[0])
-            fused = {"value": sample / (time.perf_counter() - t1), "unit": "utterances/s",
-                     "threads": torch.get_num_threads(), "what": "torch.nn.LSTM + Linear forward, float32, batches of %d" % cpu_batch}
+            best = None
+            for fb in (32, 128):
+                proj(net(x[:fb])[0])
+                t1 = time.perf_counter()
+                for i in range(0, sample, fb):
+                    proj(net(x[i:i + fb])[0])
+                rate = sample / (time.perf_counter() - t1)
+                if best is None or rate > best[0]:
+                    best = (rate, fb)
+            fused = {"value": best[0], "unit": "utterances/s", "threads": torch.get_num_threads(),
+                     "what": "torch.nn.LSTM + Linear forward, float32, batches of %d (best of 32 / 128)" % best[1]}
+        torch.set_num_threads(threads_before)
     except Exception as e:   # a reported extra, never a reason to lose the bench line
         fused = {"error": str(e)[:200]}
-    return {"value": sample / dt, "unit": "utterances/s", "cores": cores, "kind": "port",
-            "sample": "%d utterances in batches of %d, float32 numpy oracle (per-step loop), %.1f s"
-                      % (sample, cpu_batch, dt), "best_case_fused_cpu": fused}, rms
+    return {"value": sample / dt32, "unit": "utterances/s", "cores": cores, "kind": "port",
+            "sample": "%d utterances in batches of 32, float32 numpy oracle (per-step loop), %.1f s" % (sample, dt32),
+            "batch_8": {"value": n8 / dt8, "unit": "utterances/s",
+                        "sample": "%d utterances in batches of 8, %.1f s" % (n8, dt8)},
+            "best_case_fused_cpu": fused}, rms
 
 
 def bench_unet(args, torch, dist, rank, world, device):
@@ -218,21 +236,79 @@ def bench_unet(args, torch, dist, rank, world, device):
 
 
 def profiled_traffic(kernel_key, batch):
-    """HBM bytes per launch from the committed PMC passes (profiles/r*_traffic_b<batch>.json: FETCH_SIZE and
-    WRITE_SIZE collected in separate rocprofv3 --pmc runs of this same command, gfx950 correction
-    applied there).  None when no profile exists for this batch size."""
+    """(HBM bytes per launch, provenance) from the committed PMC passes (profiles/r*_traffic_b<batch>.json:
+    FETCH_SIZE and WRITE_SIZE collected in separate rocprofv3 --pmc runs of this same command, gfx950 correction
+    applied there; counters cannot be read from inside the process that is being timed).  The provenance names
+    the file and the git commit the profile was taken at, so a stale figure is visible as such.  (None, None)
+    when no profile exists for this batch size."""
     import glob
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic_b%d.json" % batch)))
     if not files:
-        return None
+        return None, None
     try:
-        k = json.load(open(files[-1]))["kernels"]
-        for name, v in k.items():
+        prof = json.load(open(files[-1]))
+        for name, v in prof["kernels"].items():
             if name in kernel_key or kernel_key in name:
-                return v["hbm_bytes_per_launch_avg"]
+                return v["hbm_bytes_per_launch_avg"], {"file": "profiles/" + os.path.basename(files[-1]),
+                                                       "commit": prof.get("commit"), "collected": prof.get("collected")}
     except Exception:
-        return None
-    return None
+        return None, None
+    return None, None
+
+
+def time_steps(torch, step, steps, warmup):
+    """ms per step of `step()` on the current device (single rank: the named-workload entries of `also`)."""
+    for _ in range(warmup):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / steps * 1e3
+
+
+def named_workloads(torch, models, ops, model, cfg, mean, std, device, rank, world):
+    """The sizes the reference and BASELINE.json name, next to the headline batch: inference on the 100 clips of
+    configs[0/1] as ONE batch and at the reference's inference batch of 32 (scripts/inference.sh:7), and the AV
+    training step at 32 utterances per GPU (configs[3]: global batch 256 over 8 GPUs; under torch.distributed this
+    entry includes the bucketed RCCL all-reduce of the gradients).  Each entry has its own ms_per_step."""
+    out = {}
+    for name, b in (("infer_b100", 100), ("infer_b32", 32)):
+        wav, masks = synth_batch(torch, b, 4321 + rank, device)
+        seq = np.full(b, T_FRAMES)
+        m = models.StackedBLSTMModel(seq, wav, masks, mean, std, 0.0, dict(cfg, batch_size=b, rows_per_wg=0), input='a',
+                                     is_training=False, variables=model.variables)
+
+        def step(m=m, seq=seq, wav=wav, masks=masks):
+            m.feed(sequence_lengths=seq, target_sources=wav, masks=masks)
+            _ = m.prediction
+            return m.loss_func
+        ms = time_steps(torch, step, 30, 5)
+        ops.coop_check(device)
+        out[name] = {"workload": "configs[1] inference, %d utterances per step per GPU" % b, "per_gpu_batch": b,
+                     "ms_per_step": ms, "value": b * world / ms * 1e3, "unit": "utterances/s"}
+    b = 32
+    wav, masks = synth_batch(torch, b, 8765 + rank, device)
+    gv = torch.Generator(device=device)
+    gv.manual_seed(199 + rank)
+    video = torch.randn(b, T_FRAMES, 136, generator=gv, device=device)
+    seq = np.full(b, T_FRAMES)
+    mt = models.StackedBLSTMModel(seq, wav, masks, mean, std, 0.0, dict(cfg, batch_size=b, rows_per_wg=0),
+                                  video_features=video, input='av', seed=7, is_training=True)
+
+    def tstep():
+        mt.feed(sequence_lengths=seq, target_sources=wav, masks=masks, video_features=video)
+        loss = mt.loss_func
+        mt.train_op
+        return loss
+    ms = time_steps(torch, tstep, 30, 5)
+    ops.coop_check(device)
+    out["train_b32"] = {"workload": "configs[2]/[3] AV training step (forward + BPTT + %sTF-Adam), 32 utterances per GPU"
+                                    % ("RCCL gradient all-reduce + " if world > 1 else ""),
+                        "per_gpu_batch": b, "global_batch": b * world, "ms_per_step": ms,
+                        "value": b * world / ms * 1e3, "unit": "utterances/s"}
+    return out
 
 
 def main():
@@ -244,6 +320,8 @@ def main():
     ap.add_argument("--rows-per-wg", type=int, default=0)
     ap.add_argument("--cpu-sample", type=int, default=384, help="utterances timed on the CPU oracle (~15 s)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-also", action="store_true", help="skip the named-workload entries (`also` block)")
+    ap.add_argument("--also-timeout", type=int, default=240)
     ap.add_argument("--mode", choices=["infer", "train", "unet"], default="infer",
                     help="infer = headline workload (configs[1]); train = configs[2]: AV model, fwd + BPTT + Adam; "
                          "unet = configs[4]: U-Net spectrogram inpainter inference (use --batch 32 .. 512)")
@@ -298,6 +376,7 @@ def main():
                                      input='av' if train else 'a', seed=7, is_training=train)   # same weights on all ranks
 
     timer = KernelTimer(torch)
+    untimed = (ops.gemm, ops.blstm_rec_fwd, ap_mod.frontend)
     ops.gemm = timer.wrap("gemm_dma_kernel", ops.gemm)
     ops.blstm_rec_fwd = timer.wrap("blstm_rec_fwd_kernel", ops.blstm_rec_fwd)
     ap_mod.frontend = timer.wrap("frontend_kernel", ap_mod.frontend)
@@ -332,6 +411,7 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
     loss_val = float(loss)
+    ops.coop_check(device)
 
     totals = timer.totals()
     if rank == 0 and train:
@@ -363,13 +443,15 @@ def main():
         proj_tf = proj * args.steps / (t_proj * 1e-3) / 1e12
         fe_gbs = 706000.0 * B * n_fe / (t_fe * 1e-3) / 1e9
         if t_rec >= t_gemm:
+            traffic, traffic_src = profiled_traffic("blstm_rec_fwd", B)
             roof = {"kernel": "blstm_rec_fwd_kernel", "bound": "mfma", "achieved": rec_tf,
                     "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": rec_tf / FP32_MFMA_PEAK_TFLOPS,
-                    "traffic": profiled_traffic("blstm_rec_fwd", B), "avg_launch_ms": t_rec / n_rec}
+                    "traffic": traffic, "traffic_source": traffic_src, "avg_launch_ms": t_rec / n_rec}
         else:
+            traffic, traffic_src = profiled_traffic("gemm_dma_kernel", B)
             roof = {"kernel": "gemm_dma_kernel<false, false, 16, 3, false, 256>", "bound": "mfma", "achieved": gemm_tf,
                     "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": gemm_tf / FP32_MFMA_PEAK_TFLOPS,
-                    "traffic": profiled_traffic("gemm_dma_kernel", B), "avg_launch_ms": t_gemm / n_gemm}
+                    "traffic": traffic, "traffic_source": traffic_src, "avg_launch_ms": t_gemm / n_gemm}
         roof["others"] = {
             "blstm_rec_fwd_kernel": {"TFLOP/s": rec_tf, "ms_per_step": t_rec / args.steps},
             "gemm_dma_kernel": {"TFLOP/s": gemm_tf, "ms_per_step": t_gemm / args.steps},
@@ -379,7 +461,10 @@ def main():
         }
         cpu, rms = (None, None)
         if not args.no_cpu_baseline and world == 1:     # the CPU leg is reported at N = 1 only
-            cpu, rms = cpu_baseline(torch, model, wav, masks, mean, std, min(args.cpu_sample, B), 32)
+            sample = min(args.cpu_sample, B)
+            # `model` still holds the results of the last TIMED step: its prediction rows are what gets checked
+            pred_timed = model.prediction[:sample].cpu().numpy()
+            cpu, rms = cpu_baseline(torch, model, wav, masks, mean, std, sample, pred_timed)
         line = {
             "metric": "masked utterances/sec (inference: front end + 3xBLSTM-250 forward + projection + L1 loss)",
             "value": B * world * args.steps / elapsed,
@@ -396,6 +481,30 @@ def main():
             "roofline": roof,
             "cpu_baseline": cpu,
         }
+    if not train and not args.no_also:
+        # The named workloads run AFTER the headline measurement is complete.  Their training entry is the first
+        # code of this repository to issue RCCL collectives from inside the backward pass on real multi-GPU
+        # hardware; a watchdog makes sure a stall there cannot cost the headline line: when it fires, rank 0 prints
+        # the line it already has (with the reason in `also`) and every rank leaves.
+        import threading
+
+        def give_up():
+            if rank == 0:
+                line["also"] = {"error": "named workloads did not finish within %d s" % args.also_timeout}
+                print(json.dumps(line), flush=True)
+            os._exit(0)
+        dog = threading.Timer(args.also_timeout, give_up)
+        dog.daemon = True
+        dog.start()
+        ops.gemm, ops.blstm_rec_fwd, ap_mod.frontend = untimed      # no per-call events in the small-batch entries
+        try:
+            also = named_workloads(torch, models, ops, model, cfg, mean, std, device, rank, world)
+        except Exception as e:        # never a reason to lose the headline
+            also = {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
+        dog.cancel()
+        if rank == 0:
+            line["also"] = also
+    if rank == 0 and not train:
         print(json.dumps(line))
     if world > 1:
         dist.barrier()

@@ -1,6 +1,7 @@
 """Oracle: STFT / log-spectrogram / log-mel / MFCC / inverse-STFT front end (numpy).
 
-TEST INFRASTRUCTURE ONLY (see oracle/__init__.py).  PARITY UNPINNED.
+TEST INFRASTRUCTURE ONLY (see oracle/__init__.py).  STFT / |.| / inverse STFT are PINNED by the reference's
+own docs/files/*/masked.wav (tests/test_ref_docs_golden.py); mel / MFCC / deltas remain unpinned.
 
 Restates, op for op, the TensorFlow-1.x semantics behind the reference's
 ``av_speech_inpainting/audio_processing.py``.
@@ -162,13 +163,23 @@ def inverse_stft_window(frame_length, frame_step, dtype=np.float64):
     return (w / denom).astype(dtype)
 
 
-def inverse_stft(stfts, frame_length, frame_step, dtype=np.float64):
+def enclosing_power_of_two(n):
+    """tf.contrib.signal (spectral_ops._enclosing_power_of_two): 2 ** ceil(log2(n))."""
+    return 1 << max(0, int(n) - 1).bit_length()
+
+
+def inverse_stft(stfts, frame_length, frame_step, dtype=np.float64, fft_length=None):
     """tf.contrib.signal.inverse_stft (audio_processing.py:149-151; App. A.6).
 
-    complex [B, T, F] -> real [B, (T-1) step + frame_length]."""
+    complex [B, T, F] -> real [B, (T-1) step + frame_length].  ``fft_length=None`` is TF 1.x's default: the
+    enclosing power of two of ``frame_length`` -- NOT (F - 1) * 2 -- and ``irfft`` crops (or zero-pads) the
+    bin axis to fft_length // 2 + 1.  So the reference's 384 / 192 call transforms 257 bins at 512 points, and
+    ``reconstruct_sources`` with its 16 / 8 ms default on a 257-bin spectrogram uses the first 129 bins at 256."""
     X = np.asarray(stfts)
     B, T, F = X.shape
-    nfft = (F - 1) * 2
+    nfft = enclosing_power_of_two(frame_length) if fft_length is None else int(fft_length)
+    nb = nfft // 2 + 1
+    X = X[..., :nb] if F >= nb else np.pad(X, [[0, 0], [0, 0], [0, nb - F]])
     frames = np.fft.irfft(X, n=nfft, axis=-1).astype(dtype)[..., :frame_length]
     if frames.shape[-1] < frame_length:       # fft shorter than frame: TF pads with zeros
         frames = np.pad(frames, [[0, 0], [0, 0], [0, frame_length - frames.shape[-1]]])

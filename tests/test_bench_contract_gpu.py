@@ -33,7 +33,14 @@ def test_default_mode_line():
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9 and r["avg_launch_ms"] > 0
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["value"] > 0 and c["cores"] >= 1 and "sample" in c
+    assert c["batch_8"]["value"] > 0 and "batches of 8" in c["batch_8"]["sample"]          # 8 and 32
     assert d["logmel_rms_vs_cpu_oracle"] < 1e-3                  # the BASELINE parity bar, checked in the bench itself
+    # the sizes the reference and BASELINE.json name, each with its own ms_per_step
+    also = d["also"]
+    assert "error" not in also, also
+    for k, b in (("infer_b100", 100), ("infer_b32", 32), ("train_b32", 32)):
+        assert also[k]["per_gpu_batch"] == b and also[k]["ms_per_step"] > 0
+        assert abs(also[k]["value"] - b / also[k]["ms_per_step"] * 1e3) < 1e-6 * also[k]["value"]
     assert abs(d["value"] - 256 * 2 / (d["ms_per_step"] * 2e-3)) < 1e-6 * d["value"]
 
 
@@ -67,3 +74,6 @@ def test_multi_rank_launch_as_the_driver_does(mode):
     assert d["config"]["parallelism"] == "dp2"
     assert abs(d["value"] - 2 * 64 * 2 / (d["ms_per_step"] * 2e-3)) < 1e-6 * d["value"]
     assert "cpu_baseline" not in d or d["cpu_baseline"] is None
+    if mode == "infer":
+        assert "error" not in d["also"], d["also"]
+        assert d["also"]["train_b32"]["global_batch"] == 64 and d["also"]["train_b32"]["ms_per_step"] > 0

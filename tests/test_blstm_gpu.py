@@ -89,7 +89,58 @@ def test_recurrent_kernel_single_layer(mods, rows_per_wg):
                 np.testing.assert_allclose(r[t, :B, d, gi, :H], ref, atol=3e-5)
 
 
-@pytest.mark.parametrize("input_type,B,N", [('a', 4, 48000), ('av', 3, 9600), ('v', 2, 9600), ('a', 33, 3840)])
+@pytest.mark.parametrize("rows_per_wg,B", [(64, 70), (32, 37)])
+def test_recurrent_kernel_inference_form_full_length(mods, rows_per_wg, B):
+    """The kernel the benchmark times -- blstm_rec_fwd_pp_kernel<false>: 64 utterances per workgroup, NO reserve
+    (inference), all T = 250 steps -- against the oracle's per-step loop (reference models.py:106-115).  B = 70
+    gives one full and one partial 64-row workgroup per direction."""
+    models, ops, bl = mods
+    H, D, T = 250, 257, 250
+    Bp = -(-B // 32) * 32
+    lay = bl.ParamLayout(D, (H,), 257)
+    p = _rand_biases(O.init_params(13, D, (H,), 257), 14)
+    flat = lay.flatten_oracle_params(p)
+    packed = torch.from_numpy(np.concatenate([flat, [0]]).astype(np.float32)[lay.pack_index]).cuda()
+    rng = np.random.default_rng(15)
+    x = rng.normal(size=(B, T, D)).astype(np.float32)
+    xp = torch.zeros(T, Bp, lay.kp[0], device='cuda')
+    xp[:, :B, :D] = torch.from_numpy(x).cuda().transpose(0, 1)
+    xproj = ops.gemm(xp.view(T * Bp, -1), lay.packed_view(packed, 'wx0'), bias=lay.packed_view(packed, 'b0'))
+    hout = torch.full((T, Bp, 512), 9.0, device='cuda')
+    ops.blstm_rec_fwd(xproj.view(T, Bp, 2048), lay.packed_view(packed, 'wh0'), hout, None, rows_per_wg)
+    got = hout.cpu().numpy()
+    p64 = O.cast_params(p, np.float64)
+    fw = O.lstm_direction(x.astype(np.float64), p64['layers'][0]['fw']['kernel'], p64['layers'][0]['fw']['bias'], False)
+    bw = O.lstm_direction(x.astype(np.float64), p64['layers'][0]['bw']['kernel'], p64['layers'][0]['bw']['bias'], True)
+    np.testing.assert_allclose(got[:, :B, :H].transpose(1, 0, 2), fw, atol=3e-5)
+    np.testing.assert_allclose(got[:, :B, 256:256 + H].transpose(1, 0, 2), bw, atol=3e-5)
+    assert np.all(got[:, :, H:256] == 0) and np.all(got[:, :, 256 + H:] == 0)
+
+
+def test_model_forward_bench_kernels_match_oracle(mods):
+    """Whole model through the kernels of the B = 8192 benchmark step at a size the oracle finishes in seconds:
+    rows_per_wg = 64 forces blstm_rec_fwd_pp_kernel<false> (is_training=False: no reserve), and B = 64, T = 250
+    gives the layer GEMMs M = 16000 rows -> 125 row blocks x 8 = 1000 >= 512 tiles -> the 128 x 256 tile."""
+    models, ops, bl = mods
+    B, N = 64, 48000
+    wav, masks, mean, std, video, T = _inputs(B, N, 77)
+    p = _rand_biases(O.init_params(17, 257), 18)
+    seq_len = np.full(B, T)
+    m = models.StackedBLSTMModel(seq_len, wav, masks, mean, std, 0.0, _config(audio_len=N, rows_per_wg=64), input='a',
+                                 is_training=False)
+    m.variables.load_flat(m.layout.flatten_oracle_params(p))
+    ref = O.model_forward(wav, masks, mean, std, seq_len, p)
+    pred = m.prediction.cpu().numpy()
+    assert m._cache['reserve'] == [None, None, None]
+    assert _rms(pred, ref['prediction']) < 1e-4
+    assert np.abs(pred - ref['prediction']).max() < 2e-3
+    lm_ref = OF.logmel_of_prediction(ref['prediction'], mean, std)
+    lm_got = OF.logmel_of_prediction(pred.astype(np.float64), mean, std)
+    assert _rms(lm_got, lm_ref) < 1e-3
+    assert float(m.loss_func) == pytest.approx(ref['loss_func'], rel=2e-4)
+
+
+@pytest.mark.parametrize("input_type,B,N", [('a', 33, 48000), ('av', 3, 9600), ('v', 2, 9600), ('a', 33, 3840)])
 def test_model_forward_matches_oracle(mods, input_type, B, N):
     models, ops, bl = mods
     wav, masks, mean, std, video, T = _inputs(B, N, 10 + B)

@@ -104,3 +104,39 @@ def test_randomised_shapes_and_options(ops):
         worst = max(worst, err)
         assert err < 2.0, (case, ta, tb, M, N, K, mode, err)
     assert worst > 0
+
+
+@pytest.mark.parametrize("M,K", [(8192, 272), (8192, 512), (16384, 272), (16384, 512), (8192 + 40, 512)])
+def test_wide_tile_layer_gemm_matches_numpy(ops, M, K):
+    """The kernel the benchmark times: gemm_dma_kernel<false, false, 16, 3, false, 256> (128 x 256 tiles, short
+    epilogue) is selected for A.B with N % 256 == 0, N >= 1024 and m_blocks * (N / 256) >= 512, i.e. from 8192 rows
+    at N = 2048 -- the layer input projections x . Wx + b of the stacked BLSTM (reference models.py:95-115).
+    M = 8232 adds a partial last row tile (general epilogue of the same kernel)."""
+    N = 2048
+    rng = np.random.default_rng(M + K)
+    A = rng.normal(size=(M, K)).astype(np.float32)
+    B = rng.normal(size=(K, N)).astype(np.float32)
+    bias = rng.normal(size=N).astype(np.float32)
+    got = ops.gemm(torch.from_numpy(A).cuda(), torch.from_numpy(B).cuda(), bias=torch.from_numpy(bias).cuda())
+    ref = A.astype(np.float64) @ B.astype(np.float64) + bias
+    assert got.shape == (M, N)
+    assert np.abs(got.cpu().numpy() - ref).max() < 2e-6 * K * 4
+    # accumulate form (the speaker-embedding variants: beta = 1 onto a broadcast bias) takes the general epilogue
+    C0 = rng.normal(size=(M, N)).astype(np.float32)
+    acc = torch.from_numpy(C0.copy()).cuda()
+    ops.gemm(torch.from_numpy(A).cuda(), torch.from_numpy(B).cuda(), out=acc, beta=1.0)
+    assert np.abs(acc.cpu().numpy() - (ref - bias + C0)).max() < 2e-6 * K * 4
+
+
+@pytest.mark.parametrize("Mk,rows,splits", [(512, 16384, 16), (272, 32768, 32), (400, 20000, 16)])
+def test_wide_tile_split_k_weight_gradient_matches_numpy(ops, Mk, rows, splits):
+    """dWx = X^T . dZ of training (the gradient of models.py:95-115): A^T . B, N = 2048, reduction over all T * Bp
+    rows cut into slabs; m_blocks * 8 * splits >= 512 selects the 128 x 256 tile of the DMA kernel."""
+    rng = np.random.default_rng(rows + Mk)
+    X = rng.normal(size=(rows, Mk)).astype(np.float32)
+    dZ = rng.normal(size=(rows, 2048)).astype(np.float32)
+    out = torch.full((Mk, 2048), 7.0, device='cuda')
+    ops.gemm_splitk(torch.from_numpy(X).cuda(), torch.from_numpy(dZ).cuda(), out, trans_a=True, m=Mk, n=2048, k=rows,
+                    splits=splits)
+    ref = X.astype(np.float64).T @ dZ.astype(np.float64)
+    assert np.abs(out.cpu().numpy() - ref).max() < 2e-6 * rows * 4 * 0.05 + 1e-3   # random-sign sums grow ~sqrt(K)

@@ -74,3 +74,17 @@ def test_enhanced_sources_fused_matches_oracle(ap, oracle_phase):
     assert got.shape == (B, N)
     assert np.sqrt(np.mean((got - ref) ** 2)) < 1e-4 * np.abs(ref).max()
     assert np.abs(got - ref).max() < 1e-3 * np.abs(ref).max()
+
+
+@pytest.mark.parametrize("bins,ws,ss", [(257, 16, 8), (128, 16, 8), (129, 16, 8), (200, 24, 12)])
+def test_fft_length_follows_the_frame_length_not_the_bin_count(ap, bins, ws, ss):
+    """tf.contrib.signal.inverse_stft(fft_length=None): enclosing power of two of the frame length, bins cropped /
+    zero-padded to fit -- e.g. reconstruct_sources' own 16 / 8 ms default on a 257-bin spectrogram is a 256-point
+    transform of bins 0..128 (reference audio_processing.py:145-151)."""
+    rng = np.random.default_rng(12)
+    X = (rng.normal(size=(2, 21, bins)) + 1j * rng.normal(size=(2, 21, bins))) * 100
+    ref = OF.reconstruct_sources(X, 0, window_size=ws, step_size=ss)
+    got = ap.reconstruct_sources(torch.from_numpy(X.astype(np.complex64)).cuda(), 0, window_size=ws, step_size=ss)
+    got = got.cpu().numpy()
+    assert got.shape == ref.shape
+    assert np.abs(got - ref).max() < 1e-5 * np.abs(ref).max() + 1e-4

@@ -114,6 +114,30 @@ def test_istft_roundtrip_anchor():
                                atol=1e-7)
 
 
+def test_inverse_stft_fft_length_is_enclosing_power_of_two_of_the_frame():
+    """TF 1.x inverse_stft(fft_length=None) -> _enclosing_power_of_two(frame_length), and irfft crops / pads the
+    bins to fft_length / 2 + 1.  Checked against torch.fft.irfft + explicit overlap-add for the two cases where
+    this differs from (F - 1) * 2: the 16 / 8 ms default of reconstruct_sources on a 257-bin spectrogram
+    (audio_processing.py:145) and a sliced 128-bin U-Net spectrogram."""
+    import torch
+    assert [F.enclosing_power_of_two(n) for n in (1, 2, 3, 256, 257, 384, 512)] == [1, 2, 4, 256, 512, 512, 512]
+    rng = np.random.default_rng(11)
+    for bins, L, S, nfft in ((257, 256, 128, 256), (128, 256, 128, 256), (257, 384, 192, 512), (100, 384, 192, 512)):
+        X = rng.normal(size=(2, 9, bins)) + 1j * rng.normal(size=(2, 9, bins))
+        y = F.inverse_stft(X, L, S)
+        nb = nfft // 2 + 1
+        Xc = np.zeros((2, 9, nb), dtype=complex)
+        Xc[..., :min(bins, nb)] = X[..., :nb]
+        fr = torch.fft.irfft(torch.from_numpy(Xc), n=nfft, dim=-1).numpy()[..., :L] * F.inverse_stft_window(L, S)
+        ref = np.zeros((2, 8 * S + L))
+        for t in range(9):
+            ref[:, t * S: t * S + L] += fr[:, t]
+        np.testing.assert_allclose(y, ref, atol=1e-12)
+    # the default call on 257 bins is a 256-point transform of bins 0..128
+    X = rng.normal(size=(1, 5, 257)) + 1j * rng.normal(size=(1, 5, 257))
+    np.testing.assert_allclose(F.reconstruct_sources(X), F.reconstruct_sources(X[..., :129]), atol=0)
+
+
 def test_feature_stats():
     rng = np.random.default_rng(5)
     feats = [rng.normal(2.0, 3.0, size=(40, 5)) for _ in range(4)]
