@@ -111,7 +111,8 @@ def frontend(sources, sample_rate=16000, window_size=24, step_size=12, n_fft=512
     F = n_fft // 2 + 1 if num_bins is None else int(num_bins)
 
     a = _lib.FrontendArgs()
-    a.wav, a.batch, a.num_samples, a.wav_stride = _lib.ptr(sources), B, N, sources.stride(0)
+    # a size-1 batch axis can carry any stride (numpy's newaxis gives 0): the pitch is then irrelevant
+    a.wav, a.batch, a.num_samples, a.wav_stride = _lib.ptr(sources), B, N, sources.stride(0) if B > 1 else N
     a.frame_len, a.hop, a.nfft, a.num_frames, a.num_bins = frame_len, hop, n_fft, T, F
     tab = _tables(dev, frame_len, n_fft)
     a.table = _lib.ptr(tab)
@@ -350,7 +351,8 @@ def preemphasis(sources, alpha=0.95):
     if x.stride(1) != 1:
         x = x.contiguous()
     out = torch.empty(x.shape, dtype=torch.float32, device=x.device)
-    _lib.check(_lib.lib().avsi_preemphasis_f32(_lib.ptr(x), _lib.ptr(out), x.shape[0], x.shape[1], x.stride(0),
+    _lib.check(_lib.lib().avsi_preemphasis_f32(_lib.ptr(x), _lib.ptr(out), x.shape[0], x.shape[1],
+                                               x.stride(0) if x.shape[0] > 1 else x.shape[1],
                                                float(alpha), _lib.stream_ptr()), "avsi_preemphasis_f32")
     return out
 

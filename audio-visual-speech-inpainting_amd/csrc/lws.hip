@@ -1,0 +1,596 @@
+// LWS ("local weighted sums") phase reconstruction on gfx950 -- the phase refinement the reference's `infer`
+// applies to every enhanced waveform when --oracle_phase is not given (inference.py:119,141-154, through the
+// third-party `lws` package: lws.lws(384, 192, fftsize=512, mode='speech')).
+//
+// The package is neither vendored in the reference nor installable here; this file implements the published
+// algorithm (Le Roux, Kameoka, Ono, Sagayama, DAFx-10 and ASJ 2010) under the conventions written down in
+// oracle/lws.py -- the two are compared in tests/test_lws_gpu.py.  UNPINNED against the package itself.
+//
+// Four kernels:
+//   lws_stft_kernel     sqrt-Hann (symmetric) analysis window zero-padded to the FFT length, 'perfectrec' padding
+//   lws_stitch_kernel   the reference's mask stitching before / after the iterations (inference.py:143-153)
+//   lws_sweeps_kernel   all "no future" / online / batch sweeps of one utterance, in place
+//   lws_istft_*         inverse FFT with the perfect-reconstruction synthesis window, overlap-add, un-pad
+//
+// lws_sweeps_kernel is where the time goes.  A sweep visits the bins of the spectrogram in raster order IN PLACE:
+// S[m,k] <- A[m,k] t/|t| with t the truncated consistency sum over rows m-1, m, m+1 and |p| <= L bins, for bins whose
+// magnitude exceeds the sweep's threshold.  That order is strictly sequential along k inside a frame (the
+// row-0 taps p < 0 were updated a moment ago) but only there: the taps of rows m-1, m+1 and the row-0 taps p > 0
+// are known before the frame starts.  So a frame is two phases: (1) 64 lanes compute the 27 "known" taps of all
+// 257 bins in parallel from an LDS ring of three spectrogram rows, (2) ONE lane per utterance runs the 5-tap
+// recurrence over k with the last five updated bins in registers.  A workgroup is a single wave that owns U
+// utterances (lane u < U runs the recurrence of utterance u), so there are no workgroup barriers, and thousands
+// of such waves fill the chip: the recurrences are latency-bound, and independent waves on a SIMD hide each other.
+#include <math.h>
+
+#include "avsi_common.h"
+
+namespace {
+
+constexpr int NF = 512;          // FFT length = frame length of the (zero-padded) windows
+constexpr int KB = NF / 2 + 1;   // 257 bins
+constexpr int LMAX = 5;          // truncation of the consistency sum in frequency
+constexpr int NP = 2 * LMAX + 1;
+constexpr int RS = KB + 2 * LMAX + 1;  // complex entries per LDS row (mirror images either side; 268)
+constexpr int PS = KB + 3;             // 260
+constexpr int MAX_SWEEPS = 256;
+
+constexpr int TAB_AWIN = 0, TAB_SWIN = NF, TAB_FLOATS = 2 * NF;
+
+struct LwsWeights {       // alpha_q(p), q = -1, 0, +1, p = -L .. L   (re, im)
+    float w[3][NP][2];
+    int phase_step;       // 8 R / N ... the consistency phase factor is exp(-2 pi j (k + p) q R / N); R / N = phase_step / 64
+};
+
+struct LwsSchedule {
+    int n;
+    float rel[MAX_SWEEPS];            // threshold relative to the mean magnitude of the utterance
+    unsigned char past_only[MAX_SWEEPS];
+};
+
+// ---------------------------------------------------------------------------------------------- windows (host, double)
+void host_windows(int frame_len, int hop, int nfft, double* awin, double* swin) {
+    // sqrt of the symmetric Hann window, synthesis window awin / sum_q awin(n + q R)^2, both zero-padded
+    // symmetrically to nfft (oracle/lws.py LWS.__init__)
+    const int lo = (nfft - frame_len) / 2;
+    for (int i = 0; i < nfft; ++i) awin[i] = swin[i] = 0.0;
+    const int Q = (frame_len + hop - 1) / hop;
+    for (int i = 0; i < frame_len; ++i) awin[lo + i] = sqrt(0.5 * (1.0 - cos(2.0 * M_PI * i / (frame_len - 1))));
+    for (int i = 0; i < frame_len; ++i) {
+        double den = 0.0;
+        for (int q = 0; q < Q; ++q) {
+            const int j = i % hop + q * hop;
+            if (j < frame_len) den += awin[lo + j] * awin[lo + j];
+        }
+        swin[lo + i] = awin[lo + i] / den;
+    }
+}
+
+bool host_weights(int frame_len, int hop, int nfft, int L, LwsWeights& W) {
+    double awin[NF], swin[NF];
+    host_windows(frame_len, hop, nfft, awin, swin);
+    // rows |q| >= 2 must vanish (the windows' supports do not overlap): frame_len <= 2 hop
+    for (int q = -1; q <= 1; ++q)
+        for (int p = -LMAX; p <= LMAX; ++p) {
+            double re = 0.0, im = 0.0;
+            if (p >= -L && p <= L)
+                for (int n = 0; n < nfft; ++n) {
+                    const int s = n - q * hop;
+                    if (s < 0 || s >= nfft) continue;
+                    const double pr = awin[n] * swin[s], ph = 2.0 * M_PI * p * n / nfft;
+                    re += pr * cos(ph), im += pr * sin(ph);
+                }
+            W.w[q + 1][p + LMAX][0] = (float)(re / nfft), W.w[q + 1][p + LMAX][1] = (float)(im / nfft);
+        }
+    W.phase_step = 64 * hop / nfft;
+    return true;
+}
+
+__global__ void lws_tables_kernel(float* tab, int frame_len, int hop, int nfft) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= NF) return;
+    const int lo = (nfft - frame_len) / 2;
+    auto aw = [&](int j) -> double { return sqrt(0.5 * (1.0 - cospi(2.0 * j / (frame_len - 1)))); };
+    double a = 0.0, s = 0.0;
+    const int j = i - lo;
+    if (i < nfft && j >= 0 && j < frame_len) {
+        a = aw(j);
+        double den = 0.0;
+        for (int jj = j % hop; jj < frame_len; jj += hop) den += aw(jj) * aw(jj);
+        s = a / den;
+    }
+    tab[TAB_AWIN + i] = (float)a;
+    tab[TAB_SWIN + i] = (float)s;
+}
+
+// ---------------------------------------------------------------------------------------------- 512-point FFT in LDS
+__device__ __forceinline__ int bitrev9(int x) { return (int)(__brev((unsigned)x) >> 23); }
+
+// radix-2 decimation in time over s[512] (bit-reversed input order), 256 threads
+__device__ __forceinline__ void fft512(float2* s, const float2* tw, int tid) {
+#pragma unroll
+    for (int st = 0; st < 9; ++st) {
+        const int half = 1 << st;
+        const int j = tid & (half - 1), i0 = ((tid >> st) << (st + 1)) + j, i1 = i0 + half;
+        const float2 w = tw[j << (8 - st)];
+        __syncthreads();
+        const float2 a = s[i0], b = s[i1];
+        const float2 t = make_float2(b.x * w.x - b.y * w.y, b.x * w.y + b.y * w.x);
+        s[i0] = make_float2(a.x + t.x, a.y + t.y);
+        s[i1] = make_float2(a.x - t.x, a.y - t.y);
+    }
+    __syncthreads();
+}
+
+__device__ __forceinline__ void fill_twiddles(float2* tw, int tid) {
+    float sn, cs;
+    sincospif(-2.f * (float)tid / 512.f, &sn, &cs);
+    tw[tid] = make_float2(cs, sn);
+}
+
+// spec [B][M][257] complex <- frames of the padded signal
+__global__ __launch_bounds__(256) void lws_stft_kernel(const float* __restrict__ wav, int64_t wav_stride, int num_samples,
+                                                       const float* __restrict__ tab, int hop, float2* __restrict__ spec,
+                                                       int M) {
+    __shared__ float2 s[NF], tw[256];
+    const int tid = threadIdx.x, m = blockIdx.x, b = blockIdx.y;
+    fill_twiddles(tw, tid);
+    const int64_t t0 = (int64_t)m * hop - (NF - hop);       // 'perfectrec': N - R zeros in front
+    for (int n = tid; n < NF; n += 256) {
+        const int64_t t = t0 + n;
+        const float x = (t >= 0 && t < num_samples) ? wav[(int64_t)b * wav_stride + t] : 0.f;
+        s[bitrev9(n)] = make_float2(x * tab[TAB_AWIN + n], 0.f);
+    }
+    fft512(s, tw, tid);
+    float2* out = spec + ((int64_t)b * M + m) * KB;
+    for (int k = tid; k < KB; k += 256) out[k] = s[k];
+}
+
+// frames [B][M][512] <- swin . irfft(spec)
+__global__ __launch_bounds__(256) void lws_istft_frames_kernel(const float2* __restrict__ spec, const float* __restrict__ tab,
+                                                               float* __restrict__ frames, int M) {
+    __shared__ float2 s[NF], tw[256];
+    const int tid = threadIdx.x, m = blockIdx.x, b = blockIdx.y;
+    fill_twiddles(tw, tid);
+    const float2* in = spec + ((int64_t)b * M + m) * KB;
+    // x[n] = Re FFT(conj Xfull)[n] / N, Xfull[k] = X[k] (k <= 256), conj X[512 - k] above; irfft drops Im of DC / Nyquist
+    for (int k = tid; k < NF; k += 256) {
+        float2 v;
+        if (k <= 256) {
+            v = in[k];
+            v.y = (k == 0 || k == 256) ? 0.f : -v.y;
+        } else {
+            v = in[NF - k];
+        }
+        s[bitrev9(k)] = v;
+    }
+    fft512(s, tw, tid);
+    float* out = frames + ((int64_t)b * M + m) * NF;
+    for (int n = tid; n < NF; n += 256) out[n] = s[n].x * (1.f / NF) * tab[TAB_SWIN + n];
+}
+
+__global__ void lws_ola_kernel(const float* __restrict__ frames, int M, int hop, float* __restrict__ out, int64_t out_stride,
+                               int out_samples) {
+    const int b = blockIdx.y;
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= out_samples) return;
+    const int tp = t + (NF - hop);
+    int m1 = tp / hop;
+    int m0 = (tp - NF + hop) / hop;       // ceil((tp - N + 1) / R) for tp - N + 1 > 0
+    if (tp - NF + 1 <= 0) m0 = 0;
+    if (m1 > M - 1) m1 = M - 1;
+    float acc = 0.f;
+    for (int m = m0; m <= m1; ++m) acc += frames[((int64_t)b * M + m) * NF + (tp - m * hop)];
+    out[(int64_t)b * out_stride + t] = acc;
+}
+
+// inference.py:143-153.  ref == null: "pre"  S <- |S| exp(j angle(S) mask_adj)
+//                        ref != null: "post" S <- |S| exp(j (angle(ref) + angle(S) (1 - mask_adj)))
+// mask_adj = mask on [0, mask_frames) x [0, mask_bins), zero elsewhere.
+__global__ void lws_stitch_kernel(float2* __restrict__ spec, const float2* __restrict__ ref, const float* __restrict__ mask,
+                                  int64_t msb, int64_t mst, int mask_frames, int mask_bins, int M, int64_t total) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int k = (int)(i % KB);
+    const int m = (int)((i / KB) % M);
+    const int64_t b = i / ((int64_t)KB * M);
+    const float mk = (mask && m < mask_frames && k < mask_bins) ? mask[b * msb + (int64_t)m * mst + k] : 0.f;
+    const float2 s = spec[i];
+    const float mag = sqrtf(s.x * s.x + s.y * s.y);
+    float ang;
+    if (!ref) {
+        if (mk == 1.f) return;                        // phase kept
+        ang = atan2f(s.y, s.x) * mk;
+    } else {
+        const float2 r = ref[i];
+        if (mk == 1.f) {                              // known phase restored: |S| e^{j angle(ref)}
+            const float rm = sqrtf(r.x * r.x + r.y * r.y);
+            spec[i] = rm > 0.f ? make_float2(mag * (r.x / rm), mag * (r.y / rm)) : make_float2(mag, 0.f);
+            return;
+        }
+        ang = atan2f(r.y, r.x) + atan2f(s.y, s.x) * (1.f - mk);
+    }
+    float sn, cs;
+    sincosf(ang, &sn, &cs);
+    spec[i] = make_float2(mag * cs, mag * sn);
+}
+
+// ---------------------------------------------------------------------------------------------- the sweeps
+__device__ __forceinline__ float2 cmadd(float2 acc, float2 w, float2 x) {
+    return make_float2(fmaf(w.x, x.x, fmaf(-w.y, x.y, acc.x)), fmaf(w.x, x.y, fmaf(w.y, x.x, acc.y)));
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+    return v;
+}
+
+template <int U>
+__global__ __launch_bounds__(64) void lws_sweeps_kernel(float2* __restrict__ spec, int B, int M, const LwsWeights W,
+                                                        const LwsSchedule sched) {
+    __shared__ float2 s_row[U][3][RS];   // ring of spectrogram rows m-1, m, m+1 with mirror images: entry j <-> bin j - LMAX
+    __shared__ float2 s_p[U][PS];        // phase-1 partial sums
+    __shared__ float s_amp[U][PS];       // magnitudes of row m
+    const int lane = threadIdx.x;
+    const int b0 = blockIdx.x * U;
+    const int nu = min(U, B - b0);
+
+    // per-lane taps: bin k = lane + 64 i has (k + p) mod 64 = (lane + p) mod 64 for every i, and the phase factor
+    // exp(-2 pi j (k + p) q R / N) has period 64 in k + p (host checks 64 R / N integer)
+    float2 wm[NP], wp[NP], w0[NP];
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+        const int kk = (lane + p - LMAX) & 63;
+        float sn, cs;
+        sincospif(2.f * (float)((kk * W.phase_step) & 63) / 64.f, &sn, &cs);       // e^{+2 pi j (k+p) R/N}: row q = -1
+        const float2 am = make_float2(W.w[0][p][0], W.w[0][p][1]), ap = make_float2(W.w[2][p][0], W.w[2][p][1]);
+        wm[p] = make_float2(am.x * cs - am.y * sn, am.x * sn + am.y * cs);
+        wp[p] = make_float2(ap.x * cs + ap.y * sn, -ap.x * sn + ap.y * cs);         // conjugate factor: row q = +1
+        w0[p] = make_float2(W.w[1][p][0], W.w[1][p][1]);
+    }
+
+    // mean and max magnitude per utterance (thresholds are relative to the mean; a sweep whose threshold is above
+    // the max touches nothing)
+    float mean_u[U], max_u[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        float sum = 0.f, mx = 0.f;
+        if (u < nu) {
+            const float2* sp = spec + (int64_t)(b0 + u) * M * KB;
+            for (int i = lane; i < M * KB; i += 64) {
+                const float2 v = sp[i];
+                const float a = sqrtf(v.x * v.x + v.y * v.y);
+                sum += a, mx = fmaxf(mx, a);
+            }
+        }
+        mean_u[u] = wave_sum(sum) / (float)(M * KB);
+        max_u[u] = wave_max(mx);
+    }
+
+    auto load_row = [&](int u, int m, float2 (&r)[5]) {      // global -> registers (zeros outside the spectrogram)
+        const bool ok = u < nu && m >= 0 && m < M;
+        const float2* src = spec + ((int64_t)(b0 + u) * M + (ok ? m : 0)) * KB;
+#pragma unroll
+        for (int i = 0; i < 5; ++i) {
+            const int k = lane + 64 * i;
+            r[i] = (ok && k < KB) ? src[k] : make_float2(0.f, 0.f);
+        }
+    };
+    auto store_row = [&](int u, int slot, const float2 (&r)[5]) {      // registers -> LDS row (bins only)
+#pragma unroll
+        for (int i = 0; i < 5; ++i) {
+            const int k = lane + 64 * i;
+            if (k < KB) s_row[u][slot][k + LMAX] = r[i];
+        }
+    };
+    auto mirror_row = [&](int u, int slot) {      // mirror images below DC and above Nyquist
+        if (lane >= 1 && lane <= LMAX) {
+            const float2 lo = s_row[u][slot][LMAX + lane], hi = s_row[u][slot][LMAX + 256 - lane];
+            s_row[u][slot][LMAX - lane] = make_float2(lo.x, -lo.y);
+            s_row[u][slot][LMAX + 256 + lane] = make_float2(hi.x, -hi.y);
+        }
+    };
+
+    for (int sw = 0; sw < sched.n; ++sw) {
+        float thr[U];
+        bool any_u = false;
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            thr[u] = sched.rel[sw] * mean_u[u];
+            any_u |= (u < nu) && (max_u[u] > thr[u]);
+        }
+        if (!any_u) continue;       // wave-uniform
+        const bool past_only = sched.past_only[sw] != 0;
+
+        // ring: slot (m + 3) % 3 holds row m
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            float2 r[5];
+            load_row(u, -1, r);
+            store_row(u, 2, r);
+            load_row(u, 0, r);
+            store_row(u, 0, r);
+            load_row(u, 1, r);
+            store_row(u, 1, r);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            mirror_row(u, 0);
+            mirror_row(u, 1);
+            mirror_row(u, 2);
+        }
+        __syncthreads();
+
+        for (int m = 0; m < M; ++m) {
+            const int sc = m % 3, sp_ = (m + 2) % 3, sn_ = (m + 1) % 3;   // cur, prev, next
+            // prefetch row m + 2 (lands in the slot of row m - 1 after this frame)
+            float2 pre[U][5];
+#pragma unroll
+            for (int u = 0; u < U; ++u) load_row(u, m + 2, pre[u]);
+
+            // magnitudes of row m, and is any bin above the threshold?
+            bool frame_active = false;
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                bool act = false;
+#pragma unroll
+                for (int i = 0; i < 5; ++i) {
+                    const int k = lane + 64 * i;
+                    if (k < KB) {
+                        const float2 v = s_row[u][sc][k + LMAX];
+                        const float a = sqrtf(v.x * v.x + v.y * v.y);
+                        s_amp[u][k] = a;
+                        act |= (u < nu) && (a > thr[u]);
+                    }
+                }
+                frame_active |= act;
+            }
+            frame_active = __any(frame_active);
+
+            if (frame_active) {
+                // ---- phase 1: the taps that are known before the frame starts
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+#pragma unroll
+                    for (int i = 0; i < 5; ++i) {
+                        const int k = lane + 64 * i;
+                        if (k < KB) {
+                            float2 acc = make_float2(0.f, 0.f);
+                            const float2* rp = &s_row[u][sp_][k];        // entry k + p + LMAX, p = -LMAX ..
+                            const float2* rn = &s_row[u][sn_][k];
+                            const float2* rc = &s_row[u][sc][k];
+#pragma unroll
+                            for (int p = 0; p < NP; ++p) acc = cmadd(acc, wm[p], rp[p]);
+                            if (!past_only) {
+#pragma unroll
+                                for (int p = 0; p < NP; ++p) acc = cmadd(acc, wp[p], rn[p]);
+#pragma unroll
+                                for (int p = LMAX + 1; p < NP; ++p)
+                                    if (k + p - LMAX <= 256) acc = cmadd(acc, w0[p], rc[p]);
+                            }
+                            s_p[u][k] = acc;
+                        }
+                    }
+                }
+                __syncthreads();
+                if (past_only) {
+                    // "no future" pass: rows q < 0 only, no dependence inside the frame
+#pragma unroll
+                    for (int u = 0; u < U; ++u) {
+#pragma unroll
+                        for (int i = 0; i < 5; ++i) {
+                            const int k = lane + 64 * i;
+                            if (k < KB) {
+                                const float2 t = s_p[u][k];
+                                const float a = s_amp[u][k], n2 = t.x * t.x + t.y * t.y;
+                                if (u < nu && a > thr[u] && n2 > 0.f) {
+                                    const float sc_ = a * rsqrtf(n2);
+                                    s_row[u][sc][k + LMAX] = make_float2(t.x * sc_, t.y * sc_);
+                                }
+                            }
+                        }
+                    }
+                } else if (lane < nu) {
+                    // ---- phase 2: the in-frame recurrence, one lane per utterance
+                    const int u = lane;
+                    float2* row = s_row[u][sc];
+                    const float th = thr[0 + 0 * u];       // thr[] is lane-uniform per u: select below
+                    float thu = th;
+#pragma unroll
+                    for (int uu = 1; uu < U; ++uu) thu = (u == uu) ? thr[uu] : thu;
+                    const float2 c1 = make_float2(W.w[1][LMAX - 1][0], W.w[1][LMAX - 1][1]);
+                    const float2 c2 = make_float2(W.w[1][LMAX - 2][0], W.w[1][LMAX - 2][1]);
+                    const float2 c3 = make_float2(W.w[1][LMAX - 3][0], W.w[1][LMAX - 3][1]);
+                    const float2 c4 = make_float2(W.w[1][LMAX - 4][0], W.w[1][LMAX - 4][1]);
+                    const float2 c5 = make_float2(W.w[1][LMAX - 5][0], W.w[1][LMAX - 5][1]);
+                    // edge bins: every row-0 tap that may have changed in this sweep is read back from the row
+                    auto edge_bin = [&](int k) {
+                        const float a = s_amp[u][k];
+                        if (!(a > thu)) return;
+                        float2 t = s_p[u][k];
+                        t = cmadd(t, c1, row[k - 1 + LMAX]);
+                        t = cmadd(t, c2, row[k - 2 + LMAX]);
+                        t = cmadd(t, c3, row[k - 3 + LMAX]);
+                        t = cmadd(t, c4, row[k - 4 + LMAX]);
+                        t = cmadd(t, c5, row[k - 5 + LMAX]);
+                        for (int p = 1; p <= LMAX; ++p)
+                            if (k + p > 256) t = cmadd(t, make_float2(W.w[1][LMAX + p][0], W.w[1][LMAX + p][1]), row[k + p + LMAX]);
+                        const float n2 = t.x * t.x + t.y * t.y;
+                        if (n2 > 0.f) {
+                            const float sc_ = a * rsqrtf(n2);
+                            const float2 v = make_float2(t.x * sc_, t.y * sc_);
+                            row[k + LMAX] = v;
+                            if (k >= 1 && k <= LMAX) row[LMAX - k] = make_float2(v.x, -v.y);
+                            if (k >= 256 - LMAX && k <= 255) row[LMAX + 512 - k] = make_float2(v.x, -v.y);
+                        }
+                    };
+                    for (int k = 0; k < LMAX; ++k) edge_bin(k);
+                    float2 s1 = row[LMAX - 1 + LMAX], s2 = row[LMAX - 2 + LMAX], s3 = row[LMAX - 3 + LMAX],
+                           s4 = row[LMAX - 4 + LMAX], s5 = row[LMAX - 5 + LMAX];
+                    float2 pn = s_p[u][LMAX], on = row[LMAX + LMAX];
+                    float an = s_amp[u][LMAX];
+                    for (int k = LMAX; k <= 256 - LMAX - 1; ++k) {
+                        const float2 pk = pn, old = on;
+                        const float a = an;
+                        pn = s_p[u][k + 1], on = row[k + 1 + LMAX], an = s_amp[u][k + 1];    // next bin's operands, off the chain
+                        float2 t = cmadd(pk, c5, s5);
+                        t = cmadd(t, c4, s4);
+                        t = cmadd(t, c3, s3);
+                        t = cmadd(t, c2, s2);
+                        t = cmadd(t, c1, s1);
+                        const float n2 = t.x * t.x + t.y * t.y;
+                        const bool upd = (a > thu) && (n2 > 0.f);
+                        const float sc_ = a * rsqrtf(n2);
+                        const float2 v = upd ? make_float2(t.x * sc_, t.y * sc_) : old;
+                        if (upd) row[k + LMAX] = v;
+                        s5 = s4, s4 = s3, s3 = s2, s2 = s1, s1 = v;
+                    }
+                    for (int k = 256 - LMAX; k <= 256; ++k) edge_bin(k);
+                }
+                __syncthreads();
+                // refresh the mirror images of row m (it becomes row m - 1 of the next frame) and write it back
+#pragma unroll
+                for (int u = 0; u < U; ++u) mirror_row(u, sc);
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    if (u < nu) {
+                        float2* dst = spec + ((int64_t)(b0 + u) * M + m) * KB;
+#pragma unroll
+                        for (int i = 0; i < 5; ++i) {
+                            const int k = lane + 64 * i;
+                            if (k < KB) dst[k] = s_row[u][sc][k + LMAX];
+                        }
+                    }
+                }
+            }
+            __syncthreads();
+            // row m + 2 replaces row m - 1
+#pragma unroll
+            for (int u = 0; u < U; ++u) store_row(u, sp_, pre[u]);
+            __syncthreads();
+#pragma unroll
+            for (int u = 0; u < U; ++u) mirror_row(u, sp_);
+            __syncthreads();
+        }
+    }
+}
+
+bool geometry_ok(int frame_len, int hop, int nfft) {
+    return nfft == NF && frame_len >= 4 && frame_len <= nfft && hop > 0 && hop <= frame_len && frame_len <= 2 * hop &&
+           ((nfft - frame_len) / 2 + frame_len <= nfft) && (64 * hop) % nfft == 0;
+}
+
+}  // namespace
+
+extern "C" int avsi_lws_num_frames(int num_samples, int hop, int nfft) {
+    if (num_samples <= 0 || hop <= 0 || nfft < hop) return 0;
+    const int64_t padded = (int64_t)num_samples + 2 * (int64_t)(nfft - hop);
+    const int64_t m = (padded - nfft + hop - 1) / hop + 1;
+    return m < 1 ? 1 : (int)m;
+}
+
+extern "C" size_t avsi_lws_table_floats(int frame_len, int hop, int nfft) {
+    return geometry_ok(frame_len, hop, nfft) ? (size_t)TAB_FLOATS : 0;
+}
+
+extern "C" int avsi_lws_init_tables(float* table, int frame_len, int hop, int nfft, void* stream) {
+    if (!table) return AVSI_ERR_INVALID_ARG;
+    if (!geometry_ok(frame_len, hop, nfft)) return AVSI_ERR_UNSUPPORTED;
+    avsi_clear_error();
+    hipLaunchKernelGGL(lws_tables_kernel, dim3(2), dim3(256), 0, (hipStream_t)stream, table, frame_len, hop, nfft);
+    return avsi_launch_status();
+}
+
+extern "C" int avsi_lws_stft_f32(const float* wav, int64_t wav_stride, int batch, int num_samples, const float* table, int hop,
+                                 int nfft, float* spec, int num_frames, void* stream) {
+    if (!wav || !table || !spec || batch <= 0 || num_samples <= 0 || (batch > 1 && wav_stride < num_samples))
+        return AVSI_ERR_INVALID_ARG;
+    if (nfft != NF || hop <= 0 || hop > nfft) return AVSI_ERR_UNSUPPORTED;
+    if (num_frames != avsi_lws_num_frames(num_samples, hop, nfft) || batch > 65535) return AVSI_ERR_INVALID_ARG;
+    avsi_clear_error();
+    hipLaunchKernelGGL(lws_stft_kernel, dim3(num_frames, batch), dim3(256), 0, (hipStream_t)stream, wav, wav_stride, num_samples,
+                       table, hop, reinterpret_cast<float2*>(spec), num_frames);
+    return avsi_launch_status();
+}
+
+extern "C" int avsi_lws_stitch_f32(float* spec, const float* ref, const float* mask, int64_t mask_stride_b,
+                                   int64_t mask_stride_t, int mask_frames, int mask_bins, int batch, int num_frames, int nfft,
+                                   void* stream) {
+    if (!spec || batch <= 0 || num_frames <= 0 || (mask && (mask_frames < 0 || mask_bins < 0))) return AVSI_ERR_INVALID_ARG;
+    if (nfft != NF) return AVSI_ERR_UNSUPPORTED;
+    const int64_t total = (int64_t)batch * num_frames * KB;
+    avsi_clear_error();
+    hipLaunchKernelGGL(lws_stitch_kernel, dim3((unsigned)avsi_ceil_div(total, 256)), dim3(256), 0, (hipStream_t)stream,
+                       reinterpret_cast<float2*>(spec), reinterpret_cast<const float2*>(ref), mask, mask_stride_b, mask_stride_t,
+                       mask_frames, mask_bins, num_frames, total);
+    return avsi_launch_status();
+}
+
+extern "C" int avsi_lws_run_f32(float* spec, int batch, int num_frames, int frame_len, int hop, int nfft, int L,
+                                int nofuture_iterations, float nofuture_alpha, int online_iterations, float online_alpha,
+                                int batch_iterations, float batch_alpha, float batch_beta, float batch_gamma,
+                                int utterances_per_wave, void* stream) {
+    if (!spec || batch <= 0 || num_frames <= 0 || L < 1 || nofuture_iterations < 0 || online_iterations < 0 ||
+        batch_iterations < 0)
+        return AVSI_ERR_INVALID_ARG;
+    if (!geometry_ok(frame_len, hop, nfft) || L > LMAX ||
+        nofuture_iterations + online_iterations + batch_iterations > MAX_SWEEPS)
+        return AVSI_ERR_UNSUPPORTED;
+    LwsWeights W;
+    host_weights(frame_len, hop, nfft, L, W);
+    LwsSchedule S;
+    S.n = 0;
+    for (int i = 0; i < nofuture_iterations; ++i) S.rel[S.n] = nofuture_alpha, S.past_only[S.n++] = 1;
+    for (int i = 0; i < online_iterations; ++i) S.rel[S.n] = online_alpha, S.past_only[S.n++] = 0;
+    for (int i = 0; i < batch_iterations; ++i)
+        S.rel[S.n] = (float)(batch_alpha * exp(-(double)batch_beta * pow((double)i, (double)batch_gamma))), S.past_only[S.n++] = 0;
+    for (int i = S.n; i < MAX_SWEEPS; ++i) S.rel[i] = 0.f, S.past_only[i] = 0;
+    if (S.n == 0) return AVSI_OK;
+    // utterances per wave: 4 fills the recurrence lanes four-fold at 38 KB of LDS per wave (4 waves per CU); small
+    // batches take fewer so that the waves spread over the chip
+    int U = utterances_per_wave;
+    if (U == 0) U = batch >= 4 * 4 * AVSI_NUM_CU ? 4 : (batch >= 2 * 4 * AVSI_NUM_CU ? 2 : 1);
+    avsi_clear_error();
+    float2* sp = reinterpret_cast<float2*>(spec);
+    const hipStream_t st = (hipStream_t)stream;
+    if (U == 4)
+        hipLaunchKernelGGL((lws_sweeps_kernel<4>), dim3((batch + 3) / 4), dim3(64), 0, st, sp, batch, num_frames, W, S);
+    else if (U == 2)
+        hipLaunchKernelGGL((lws_sweeps_kernel<2>), dim3((batch + 1) / 2), dim3(64), 0, st, sp, batch, num_frames, W, S);
+    else if (U == 1)
+        hipLaunchKernelGGL((lws_sweeps_kernel<1>), dim3(batch), dim3(64), 0, st, sp, batch, num_frames, W, S);
+    else
+        return AVSI_ERR_INVALID_ARG;
+    return avsi_launch_status();
+}
+
+extern "C" size_t avsi_lws_istft_workspace_bytes(int batch, int num_frames, int nfft) {
+    if (batch <= 0 || num_frames <= 0 || nfft != NF) return 0;
+    return (size_t)batch * num_frames * NF * sizeof(float);
+}
+
+extern "C" int avsi_lws_istft_f32(const float* spec, int batch, int num_frames, const float* table, int hop, int nfft,
+                                  float* out, int64_t out_stride, int out_samples, void* workspace, size_t workspace_bytes,
+                                  void* stream) {
+    if (!spec || !table || !out || batch <= 0 || num_frames <= 0 || out_samples <= 0 || batch > 65535) return AVSI_ERR_INVALID_ARG;
+    if (nfft != NF || hop <= 0 || hop > nfft) return AVSI_ERR_UNSUPPORTED;
+    const int64_t avail = (int64_t)(num_frames - 1) * hop + nfft - 2 * (int64_t)(nfft - hop);
+    if (out_samples > avail || (batch > 1 && out_stride < out_samples)) return AVSI_ERR_INVALID_ARG;
+    if (!workspace || workspace_bytes < avsi_lws_istft_workspace_bytes(batch, num_frames, nfft)) return AVSI_ERR_WORKSPACE;
+    avsi_clear_error();
+    const hipStream_t st = (hipStream_t)stream;
+    float* frames = static_cast<float*>(workspace);
+    hipLaunchKernelGGL(lws_istft_frames_kernel, dim3(num_frames, batch), dim3(256), 0, st, reinterpret_cast<const float2*>(spec),
+                       table, frames, num_frames);
+    hipLaunchKernelGGL(lws_ola_kernel, dim3((unsigned)avsi_ceil_div(out_samples, 256), batch), dim3(256), 0, st, frames, num_frames,
+                       hop, out, out_stride, out_samples);
+    return avsi_launch_status();
+}

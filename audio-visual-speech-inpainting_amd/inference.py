@@ -7,9 +7,9 @@
 ``seq_len * 192`` samples.
 
 Phase: ``oracle_phase=True`` uses the target phase everywhere; otherwise the phase of the masked
-target STFT (zero inside gaps).  The reference then refines the gap phase with the ``lws``
-package (inference.py:141-154); ``lws`` is a third-party C extension outside this path, so the
-masked-phase reconstruction -- the input of that refinement -- is what gets written.
+target STFT (zero inside gaps), whose gap frames are then refined by LWS phase reconstruction exactly
+as the reference does with the ``lws`` package (inference.py:119,141-154) -- here ``avsi_amd.lws``,
+the gfx950 implementation of the published algorithm (see that module: unpinned against the package).
 """
 import os
 import sys
@@ -19,6 +19,7 @@ import numpy as np
 from scipy.io import wavfile
 
 from . import ops, parallel
+from . import lws as lws_mod
 from .config_utils import check_trainconfiguration, load_configfile
 from .dataset_reader import DataManager, OutOfRangeError
 from .training import EMBEDDING_SIZE, build_model, unpack_batch, uses_embeddings
@@ -56,6 +57,9 @@ def infer(model_path, data_path_test, audio_path, out_file_prefix, norm=True, or
         sys.exit(2)
     print('done.\n')
 
+    # LWS module initialization (reference inference.py:119)
+    lws_processor = lws_mod.lws(384, 192, fftsize=512, mode='speech')
+
     total_samples = 0
     loss_list = []
     print('Starting inference on dataset: {:s}'.format(data_path_test))
@@ -70,6 +74,9 @@ def infer(model_path, data_path_test, audio_path, out_file_prefix, norm=True, or
         enhanced = model.enhanced_sources_oracle_phase if oracle_phase else model.enhanced_sources
         loss = float(model.loss)
         ops.coop_check()
+        if not oracle_phase:
+            # Reconstruct phase with LWS algorithm (reference inference.py:141-154), whole batch on the device
+            enhanced = lws_processor.refine_enhanced(enhanced, model.masks, num_samples=enhanced.shape[1])
         enhanced = enhanced.cpu().numpy()
         for wav, sample_dir, seq_len in zip(enhanced, test_sample_path, test_length):
             out_dir = os.path.join(audio_path, sample_dir.decode(), 'enhanced')

@@ -1,0 +1,162 @@
+"""LWS ("local weighted sums") phase reconstruction on MI355X (host side).
+
+The reference refines the gap phases of every enhanced waveform with the third-party ``lws`` package when
+``--oracle_phase`` is not given (``av_speech_inpainting/inference.py:119,141-154``):
+
+    lws_processor = lws.lws(384, 192, fftsize=512, mode='speech')
+    stft = lws_processor.stft(enhanced) ... rec_stft = lws_processor.run_lws(...) ... lws_processor.istft(...)
+
+``lws`` here mirrors that class -- same constructor arguments and the ``stft`` / ``run_lws`` / ``istft`` methods --
+on top of the gfx950 kernels of ``csrc/lws.hip`` (C ABI ``avsi_lws_*``); arrays may be numpy (host in, host out,
+like the package) or torch device tensors, single ``[n]`` / ``[M, F]`` or batched along a leading axis.
+``refine_enhanced`` is the whole of inference.py:141-154 for a batch, without leaving the device.
+
+The package itself is not part of the reference tree and not installable here: the kernels implement the published
+algorithm under the conventions written down in ``oracle/lws.py`` (UNPINNED against the package).
+"""
+import numpy as np
+import torch
+
+from . import _lib
+
+_TABLES = {}
+
+
+def _table(device, fsize, fshift, fftsize):
+    key = (device.index, fsize, fshift, fftsize)
+    tab = _TABLES.get(key)
+    if tab is None:
+        L = _lib.lib()
+        n = L.avsi_lws_table_floats(fsize, fshift, fftsize)
+        if n == 0:
+            raise _lib.AvsiError("unsupported LWS geometry: window %d, shift %d, fft %d" % (fsize, fshift, fftsize))
+        tab = torch.empty(n, dtype=torch.float32, device=device)
+        _lib.check(L.avsi_lws_init_tables(_lib.ptr(tab), fsize, fshift, fftsize, _lib.stream_ptr()), "avsi_lws_init_tables")
+        _TABLES[key] = tab
+    return tab
+
+
+class lws(object):
+    """``lws.lws(awin_or_fsize, fshift, L=5, ..., mode=None, fftsize=None)`` of the package, window LENGTH form
+    (the reference passes 384; a custom analysis window is not supported)."""
+
+    def __init__(self, awin_or_fsize, fshift, L=5, swin=None, look_ahead=3, nofuture_iterations=0, nofuture_alpha=1,
+                 online_iterations=0, online_alpha=1, batch_iterations=100, batch_alpha=100, batch_beta=0.1, batch_gamma=1,
+                 symmetric_win=True, mode=None, fftsize=None, utterances_per_wave=0):
+        if not isinstance(awin_or_fsize, (int, np.integer)) or swin is not None or not symmetric_win:
+            raise _lib.AvsiError("lws: only the window-length form with the default sqrt-Hann windows is implemented")
+        if mode == 'speech':
+            look_ahead, nofuture_iterations, nofuture_alpha = 3, 1, 1
+            online_iterations, online_alpha, batch_iterations, batch_alpha = 1, 1, 100, 100
+        elif mode == 'music':
+            look_ahead, nofuture_iterations, nofuture_alpha = 3, 1, 1
+            online_iterations, online_alpha, batch_iterations, batch_alpha = 10, 1, 100, 100
+        elif mode is not None:
+            raise ValueError("mode must be None, 'speech' or 'music'")
+        self.fsize, self.fshift, self.L = int(awin_or_fsize), int(fshift), int(L)
+        self.fftsize = int(fftsize) if fftsize else self.fsize
+        self.look_ahead = look_ahead
+        self.nofuture_iterations, self.nofuture_alpha = int(nofuture_iterations), float(nofuture_alpha)
+        self.online_iterations, self.online_alpha = int(online_iterations), float(online_alpha)
+        self.batch_iterations = int(batch_iterations)
+        self.batch_alpha, self.batch_beta, self.batch_gamma = float(batch_alpha), float(batch_beta), float(batch_gamma)
+        self.utterances_per_wave = int(utterances_per_wave)
+        if _lib.lib().avsi_lws_table_floats(self.fsize, self.fshift, self.fftsize) == 0:
+            raise _lib.AvsiError("unsupported LWS geometry: window %d, shift %d, fft %d" % (self.fsize, self.fshift, self.fftsize))
+
+    # ------------------------------------------------------------------------------------------------ helpers
+    @staticmethod
+    def _to_device(x, dtype):
+        host = not isinstance(x, torch.Tensor)
+        t = torch.as_tensor(np.asarray(x)) if host else x
+        _lib.require_cuda()
+        return t.to(device='cuda', dtype=dtype), host
+
+    def num_frames(self, num_samples):
+        return _lib.lib().avsi_lws_num_frames(int(num_samples), self.fshift, self.fftsize)
+
+    # ------------------------------------------------------------------------------------------------ package API
+    def stft(self, x):
+        """waveform [n] or [B, n] -> complex64 [M, F] or [B, M, F] (numpy in -> numpy out)."""
+        w, host = self._to_device(x, torch.float32)
+        single = w.dim() == 1
+        w = (w[None] if single else w).contiguous()
+        B, n = w.shape
+        M, F = self.num_frames(n), self.fftsize // 2 + 1
+        spec = torch.empty((B, M, F, 2), dtype=torch.float32, device=w.device)
+        tab = _table(w.device, self.fsize, self.fshift, self.fftsize)
+        _lib.check(_lib.lib().avsi_lws_stft_f32(_lib.ptr(w), n, B, n, _lib.ptr(tab), self.fshift, self.fftsize, _lib.ptr(spec),
+                                                M, _lib.stream_ptr()), "avsi_lws_stft_f32")
+        out = torch.view_as_complex(spec)
+        out = out[0] if single else out
+        return out.cpu().numpy() if host else out
+
+    def _as_spec(self, S):
+        s, host = self._to_device(S, torch.complex64)
+        single = s.dim() == 2
+        s = torch.view_as_real((s[None] if single else s).contiguous().clone())
+        if s.shape[2] != self.fftsize // 2 + 1:
+            raise _lib.AvsiError("spectrogram must have %d bins" % (self.fftsize // 2 + 1))
+        return s, host, single
+
+    def run_lws(self, S):
+        """complex spectrogram (magnitudes kept, phases = starting point) -> complex spectrogram."""
+        s, host, single = self._as_spec(S)
+        self._run(s)
+        out = torch.view_as_complex(s)
+        out = out[0] if single else out
+        return out.cpu().numpy() if host else out
+
+    def _run(self, s):
+        B, M = s.shape[0], s.shape[1]
+        _lib.check(_lib.lib().avsi_lws_run_f32(_lib.ptr(s), B, M, self.fsize, self.fshift, self.fftsize, self.L,
+                                               self.nofuture_iterations, self.nofuture_alpha, self.online_iterations,
+                                               self.online_alpha, self.batch_iterations, self.batch_alpha, self.batch_beta,
+                                               self.batch_gamma, self.utterances_per_wave, _lib.stream_ptr()), "avsi_lws_run_f32")
+
+    def istft(self, S, num_samples=None):
+        """complex [M, F] or [B, M, F] -> waveform (front / back padding removed; ``num_samples`` truncates)."""
+        s, host, single = self._as_spec(S)
+        out = self._istft(s, num_samples)
+        out = out[0] if single else out
+        return out.cpu().numpy() if host else out
+
+    def _istft(self, s, num_samples=None):
+        B, M = s.shape[0], s.shape[1]
+        avail = (M - 1) * self.fshift + self.fftsize - 2 * (self.fftsize - self.fshift)
+        n = avail if num_samples is None else min(int(num_samples), avail)
+        L = _lib.lib()
+        ws = torch.empty(L.avsi_lws_istft_workspace_bytes(B, M, self.fftsize) // 4, dtype=torch.float32, device=s.device)
+        out = torch.empty((B, n), dtype=torch.float32, device=s.device)
+        tab = _table(s.device, self.fsize, self.fshift, self.fftsize)
+        _lib.check(L.avsi_lws_istft_f32(_lib.ptr(s), B, M, _lib.ptr(tab), self.fshift, self.fftsize, _lib.ptr(out), n, n,
+                                        _lib.ptr(ws), ws.numel() * 4, _lib.stream_ptr()), "avsi_lws_istft_f32")
+        return out
+
+    # ------------------------------------------------------------------------------------------------ inference.py:141-154
+    def refine_enhanced(self, enhanced, masks, num_samples=None):
+        """The reference's per-utterance block, batched on the device: ``enhanced`` [B, n] (output of
+        ``enhanced_sources``: masked target phase, zero phase inside the gaps), ``masks`` [B, T, F] ->
+        [B, num_samples or all] with the gap phases replaced by LWS estimates."""
+        _lib.require_cuda(enhanced, masks)
+        w = enhanced.to(torch.float32).contiguous()
+        m = masks.to(torch.float32)
+        if m.stride(2) != 1:
+            m = m.contiguous()
+        B, n = w.shape
+        M, F = self.num_frames(n), self.fftsize // 2 + 1
+        L = _lib.lib()
+        tab = _table(w.device, self.fsize, self.fshift, self.fftsize)
+        init = torch.empty((B, M, F, 2), dtype=torch.float32, device=w.device)
+        _lib.check(L.avsi_lws_stft_f32(_lib.ptr(w), n, B, n, _lib.ptr(tab), self.fshift, self.fftsize, _lib.ptr(init), M,
+                                       _lib.stream_ptr()), "avsi_lws_stft_f32")
+        msb = m.stride(0) if B > 1 else m.shape[1] * m.stride(1)
+        # mag_spec * exp(1j * ang_spec): phases kept where the mask is one, zero in the gaps
+        _lib.check(L.avsi_lws_stitch_f32(_lib.ptr(init), None, _lib.ptr(m), msb, m.stride(1), m.shape[1], m.shape[2], B, M,
+                                         self.fftsize, _lib.stream_ptr()), "avsi_lws_stitch_f32")
+        rec = init.clone()
+        self._run(rec)
+        # rec_mag * exp(1j * (ang_spec + rec_ang * (1 - mask_adj)))
+        _lib.check(L.avsi_lws_stitch_f32(_lib.ptr(rec), _lib.ptr(init), _lib.ptr(m), msb, m.stride(1), m.shape[1], m.shape[2],
+                                         B, M, self.fftsize, _lib.stream_ptr()), "avsi_lws_stitch_f32")
+        return self._istft(rec, num_samples)

@@ -284,6 +284,42 @@ int avsi_istft_init_tables(float* table, int frame_len, int hop, int nfft, void*
 int avsi_istft_f32(const avsi_istft_args* args, void* stream);
 
 /* ------------------------------------------------------------------------------------
+ * LWS ("local weighted sums") phase reconstruction: the refinement `infer` applies to every enhanced waveform
+ * when --oracle_phase is not given (inference.py:119,141-154), there through the third-party `lws` package
+ * (lws.lws(384, 192, fftsize=512, mode='speech'): .stft / .run_lws / .istft).  The package is not part of the
+ * reference tree; these entry points implement the published algorithm (Le Roux et al., DAFx-10 / ASJ 2010) under
+ * the conventions written down in oracle/lws.py.  UNPINNED against the package.
+ *   spectrograms are [B][num_frames][nfft/2+1][2] floats (complex, contiguous), num_frames =
+ *   avsi_lws_num_frames(num_samples, hop, nfft) ('perfectrec' padding: nfft - hop zeros either side);
+ *   windows: sqrt of the symmetric Hann window of frame_len samples, zero-padded symmetrically to nfft,
+ *   and its perfect-reconstruction synthesis window (table from avsi_lws_init_tables).
+ *   Supported geometry: nfft = 512, hop <= frame_len <= 2 hop, 64 hop / nfft integer.
+ *   avsi_lws_stft_f32    lws.stft   (inference.py:143)
+ *   avsi_lws_stitch_f32  ref = null: S <- |S| exp(j angle(S) mask_adj)                       (inference.py:144-147)
+ *                        ref given:  S <- |S| exp(j (angle(ref) + angle(S) (1 - mask_adj)))  (inference.py:149-152)
+ *                        mask_adj = mask [B][mask_frames][mask_bins] (element strides), zero outside it
+ *   avsi_lws_run_f32     lws.run_lws (inference.py:148): nofuture / online / batch sweeps in place; thresholds
+ *                        alpha exp(-beta j^gamma) relative to the mean magnitude of each utterance;
+ *                        utterances_per_wave 0 = chosen from the batch (1, 2 or 4)
+ *   avsi_lws_istft_f32   lws.istft  (inference.py:153): out [B][out_samples], out_samples <=
+ *                        (num_frames - 1) hop + nfft - 2 (nfft - hop); workspace from avsi_lws_istft_workspace_bytes
+ * ------------------------------------------------------------------------------------ */
+int avsi_lws_num_frames(int num_samples, int hop, int nfft);
+size_t avsi_lws_table_floats(int frame_len, int hop, int nfft);
+int avsi_lws_init_tables(float* table, int frame_len, int hop, int nfft, void* stream);
+int avsi_lws_stft_f32(const float* wav, int64_t wav_stride, int batch, int num_samples, const float* table, int hop,
+                      int nfft, float* spec, int num_frames, void* stream);
+int avsi_lws_stitch_f32(float* spec, const float* ref, const float* mask, int64_t mask_stride_b, int64_t mask_stride_t,
+                        int mask_frames, int mask_bins, int batch, int num_frames, int nfft, void* stream);
+int avsi_lws_run_f32(float* spec, int batch, int num_frames, int frame_len, int hop, int nfft, int L,
+                     int nofuture_iterations, float nofuture_alpha, int online_iterations, float online_alpha,
+                     int batch_iterations, float batch_alpha, float batch_beta, float batch_gamma,
+                     int utterances_per_wave, void* stream);
+size_t avsi_lws_istft_workspace_bytes(int batch, int num_frames, int nfft);
+int avsi_lws_istft_f32(const float* spec, int batch, int num_frames, const float* table, int hop, int nfft, float* out,
+                       int64_t out_stride, int out_samples, void* workspace, size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------
  * U-Net building blocks (models.py:519-715 UNetFConvModel, unet_layers.py:6-37).  Activations are
  * NHWC as 2-D [B*H*W][C] with row pitch ld.  A SAME / stride-1 tf.nn.conv2d is avsi_im2col_f32 +
  * avsi_gemm_f32 with the TF filter [kh][kw][Cin][Cout] as the B matrix (rows padded to Kc, a

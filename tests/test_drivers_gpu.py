@@ -116,6 +116,30 @@ def test_infer_writes_int16_wavs(experiment, oracle_phase, capsys):
         assert np.abs(wav).max() > 0
 
 
+def test_infer_default_phase_is_lws_refined(experiment, monkeypatch):
+    """oracle_phase=False (the reference's default, inference.py:141-154): every batch goes through LWS phase
+    reconstruction, and what is written is its output."""
+    from avsi_amd import inference
+    from avsi_amd import lws as lws_mod
+    base, data, cfg = experiment
+    net = base / "logs" / "av_exp0" / "netmodel"
+    seen = []
+    orig = lws_mod.lws.refine_enhanced
+
+    def spy(self, enhanced, masks, num_samples=None):
+        out = orig(self, enhanced, masks, num_samples)
+        seen.append((enhanced.cpu().numpy(), out.cpu().numpy()))
+        return out
+    monkeypatch.setattr(lws_mod.lws, "refine_enhanced", spy)
+    audio_out = base / "audio_lws"
+    inference.infer(str(net), os.path.join(data, "test-set"), str(audio_out), "p", norm=True, oracle_phase=False, batch_size=5)
+    assert len(seen) == 1 and seen[0][0].shape == (5, N)
+    before, after = seen[0]
+    assert after.shape == before.shape and not np.allclose(before, after)
+    _, wav = wavfile.read(str(audio_out / "clip_000" / "enhanced" / "p.wav"))
+    assert np.array_equal(wav, after[0][: T * 192].astype(np.int16))
+
+
 @pytest.mark.parametrize("model_name,fmt", [("a-blstm-emb", "npz"), ("av-blstm-ssnn", "tf"), ("av-blstm-twosteps", "tf"),
                                             ("av-blstm-twosteps", "npz")])
 def test_variant_models_train_and_infer(experiment, tmp_path, model_name, fmt, capsys):

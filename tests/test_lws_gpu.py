@@ -1,0 +1,108 @@
+"""LWS phase reconstruction on the GPU (csrc/lws.hip through avsi_amd.lws) against the float64 oracle
+(oracle/lws.py), plus size-independent properties at the reference's full clip length.  Both sides implement the same
+written definition of the published algorithm; neither is pinned against the `lws` package (not installable here)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import lws as OL
+
+pytestmark = pytest.mark.gpu
+
+
+def _speechlike(n, seed):
+    rng = np.random.default_rng(seed)
+    t = np.arange(n)
+    f0 = 180 + 40 * np.sin(2 * np.pi * 2.0 * t / 16000)
+    x = sum(2000 / h * np.sin(2 * np.pi * h * np.cumsum(f0) / 16000) for h in range(1, 9))
+    return (x * (0.6 + 0.4 * np.sin(2 * np.pi * 4 * t / 16000)) + rng.normal(0, 100, n)).astype(np.float32)
+
+
+@pytest.fixture(scope="module")
+def L():
+    import avsi_amd  # noqa: F401
+    from avsi_amd import lws
+    return lws
+
+
+def test_stft_and_istft_match_oracle(L):
+    p = L.lws(384, 192, fftsize=512, mode='speech')
+    o = OL.LWS(384, 192, fftsize=512, mode='speech')
+    x = np.stack([_speechlike(5000, 1), _speechlike(5000, 2)])
+    S = p.stft(x)
+    assert S.shape == (2, o.num_frames(5000), 257) and S.dtype == np.complex64
+    ref = np.stack([o.stft(x[0]), o.stft(x[1])])
+    assert np.abs(S - ref).max() < 2e-6 * np.abs(ref).max()
+    y = p.istft(ref.astype(np.complex64))
+    assert y.shape == (2, (S.shape[1] - 1) * 192 + 512 - 640)
+    assert np.abs(y[:, :5000] - x).max() < 2e-6 * np.abs(x).max() * 10
+    single = p.stft(x[0])                       # the package's per-utterance call shape
+    assert single.shape == S.shape[1:] and np.array_equal(single, S[0])
+
+
+@pytest.mark.parametrize("U", [1, 2, 4])
+def test_run_lws_matches_oracle(L, U):
+    """Same sweeps (one 'no future', one online, 12 batch iterations with a fast-decaying threshold so that every
+    bin is visited) on three utterances with different gaps; U = utterances per wave of the sweeps kernel."""
+    kw = dict(nofuture_iterations=1, online_iterations=1, batch_iterations=12, batch_alpha=100, batch_beta=0.9)
+    p = L.lws(384, 192, fftsize=512, utterances_per_wave=U, **kw)
+    o = OL.LWS(384, 192, fftsize=512, **kw)
+    specs = []
+    for i, gap in enumerate([(8, 14), (3, 9), (12, 20)]):
+        S = o.stft(_speechlike(3840, 10 + i))
+        S[gap[0]:gap[1]] = np.abs(S[gap[0]:gap[1]])
+        specs.append(S)
+    S0 = np.stack(specs)
+    got = p.run_lws(S0.astype(np.complex64))
+    ref = np.stack([o.run_lws(s.astype(np.complex64)) for s in S0])
+    np.testing.assert_allclose(np.abs(got), np.abs(S0), rtol=2e-5, atol=1e-3)      # magnitudes are kept
+    # phases: compare the complex values, weighted by what a listener gets (large bins matter, tiny ones are noise)
+    err = np.abs(got - ref)
+    assert np.sqrt((err ** 2).sum() / (np.abs(ref) ** 2).sum()) < 2e-3
+    assert err.max() < 2e-2 * np.abs(ref).max()
+    # and the point of it all: as consistent as the oracle's result
+    for b in range(3):
+        assert o.inconsistency(got[b].astype(np.complex128)) < 1.05 * o.inconsistency(ref[b]) + 1e-6
+
+
+def test_utterances_per_wave_do_not_change_the_result(L):
+    kw = dict(fftsize=512, mode='speech')
+    o = OL.LWS(384, 192, **kw)
+    S0 = np.stack([np.abs(o.stft(_speechlike(4800, 30 + i))) for i in range(5)]).astype(np.complex64)
+    outs = [L.lws(384, 192, utterances_per_wave=U, **kw).run_lws(S0) for U in (1, 2, 4)]
+    assert np.array_equal(outs[0], outs[1]) and np.array_equal(outs[0], outs[2])
+
+
+def test_refine_enhanced_matches_oracle(L):
+    """inference.py:141-154 end to end (stft, mask stitching, run_lws, stitching, istft) on a batch."""
+    kw = dict(nofuture_iterations=1, online_iterations=1, batch_iterations=10, batch_alpha=100, batch_beta=1.0)
+    p = L.lws(384, 192, fftsize=512, **kw)
+    o = OL.LWS(384, 192, fftsize=512, **kw)
+    x = np.stack([_speechlike(3840, 40), _speechlike(3840, 41)])
+    masks = np.ones((2, 20, 257), dtype=np.float32)
+    masks[0, 6:11] = 0
+    masks[1, 12:17] = 0
+    got = p.refine_enhanced(torch.from_numpy(x).cuda(), torch.from_numpy(masks).cuda(), num_samples=3840).cpu().numpy()
+    ref = np.stack([OL.refine_enhanced(o, x[b].astype(np.float64), masks[b])[:3840] for b in range(2)])
+    assert got.shape == (2, 3840)
+    assert np.sqrt(np.mean((got - ref) ** 2)) < 2e-3 * np.abs(ref).max()
+
+
+def test_full_length_gap_becomes_consistent(L):
+    """A 3 s clip (252 frames) with a 400 ms gap of zero phases, reference settings (102 sweeps): the result keeps
+    the magnitudes and is far more consistent than the input; more sweeps never make it worse (sampled)."""
+    o = OL.LWS(384, 192, fftsize=512, mode='speech')
+    S = o.stft(_speechlike(48000, 50))
+    S0 = S.copy()
+    S0[100:133] = np.abs(S0[100:133])
+    before = o.inconsistency(S0)
+    S0 = S0.astype(np.complex64)
+    vals = []
+    for iters in (0, 20, 50, 100):
+        p = L.lws(384, 192, fftsize=512, mode='speech')
+        p.batch_iterations = iters
+        out = p.run_lws(S0)
+        np.testing.assert_allclose(np.abs(out), np.abs(S0), rtol=1e-4, atol=1e-2)
+        vals.append(o.inconsistency(out.astype(np.complex128)))
+    assert vals[-1] < 0.05 * before
+    assert vals[1] >= vals[2] * 0.999 and vals[2] >= vals[3] * 0.999
