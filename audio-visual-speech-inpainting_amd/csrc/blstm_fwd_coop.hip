@@ -387,20 +387,31 @@ extern "C" size_t avsi_blstm_rec_fwd_coop_workspace_bytes(int Bp) {
     return (size_t)(1 + 4 * (Bp > 0 ? Bp / 32 : 0)) * sizeof(unsigned);
 }
 
-// Tiles per launch: the whole launch must be resident (one workgroup per CU)
-static int coop_tiles_per_launch(int split) { return (AVSI_NUM_CU / split / AVSI_NUM_XCD) * AVSI_NUM_XCD / 2; }
+// Tiles per launch: the whole launch must be resident (one workgroup per CU) on the `max_cus` compute units the
+// caller grants it (<= 0: the chip).  A process that keeps other kernels in flight beside the recurrence -- RCCL
+// collectives under data parallelism, independent batches on other streams -- leaves those CUs out: peers of a
+// group that cannot become resident would otherwise wait for each other until the bounded spin gives up.
+// Whole (tile, direction) groups, in multiples of the XCD count when there are that many (members of a group sit
+// 8 block ids apart).  0 = not even one tile fits.
+static int coop_tiles_per_launch(int split, int max_cus) {
+    const int cus = (max_cus <= 0 || max_cus > AVSI_NUM_CU) ? AVSI_NUM_CU : max_cus;
+    int groups = cus / split;
+    if (groups >= AVSI_NUM_XCD) groups = groups / AVSI_NUM_XCD * AVSI_NUM_XCD;
+    return groups / 2;
+}
 
 extern "C" int avsi_blstm_rec_fwd_coop_f32(const float* xproj, const float* whp, float* hout, float* reserve, int T, int Bp,
-                                           int split, void* workspace, size_t workspace_bytes, void* stream) {
+                                           int split, int max_cus, void* workspace, size_t workspace_bytes, void* stream) {
     if (!xproj || !whp || !hout || T <= 0 || Bp <= 0 || (Bp & 31)) return AVSI_ERR_INVALID_ARG;
     if (split != 4 && split != 8 && split != 16 && split != 32) return AVSI_ERR_INVALID_ARG;
     if (!workspace || workspace_bytes < avsi_blstm_rec_fwd_coop_workspace_bytes(Bp)) return AVSI_ERR_WORKSPACE;
+    if (coop_tiles_per_launch(split, max_cus) < 1) return AVSI_ERR_UNSUPPORTED;   // 2 * split workgroups do not fit max_cus
     const hipStream_t st = (hipStream_t)stream;
     avsi_clear_error();
     if (hipMemsetAsync(workspace, 0, avsi_blstm_rec_fwd_coop_workspace_bytes(Bp), st) != hipSuccess) return AVSI_ERR_LAUNCH;
     // every member of a group must be resident while its peers wait for it: batches beyond one chip-full of
     // groups run as consecutive launches over tile ranges
-    const int tiles = Bp / 32, per = coop_tiles_per_launch(split);
+    const int tiles = Bp / 32, per = coop_tiles_per_launch(split, max_cus);
     for (int tile0 = 0; tile0 < tiles; tile0 += per) {
         const int nt = tiles - tile0 < per ? tiles - tile0 : per;
         CoopArgs a{xproj, whp, hout, reserve, (unsigned*)workspace, T, Bp, 2 * nt, tile0};
@@ -706,10 +717,12 @@ __global__ __launch_bounds__(512, 2) void blstm_rec_bwd_coop_fine_kernel(const C
 }  // namespace
 
 extern "C" int avsi_blstm_rec_bwd_coop_f32(const float* dhout, const float* reserve, const float* whbT, float* dz, int T,
-                                           int Bp, int split, void* workspace, size_t workspace_bytes, void* stream) {
+                                           int Bp, int split, int max_cus, void* workspace, size_t workspace_bytes,
+                                           void* stream) {
     if (!dhout || !reserve || !whbT || !dz || T <= 0 || Bp <= 0 || (Bp & 31)) return AVSI_ERR_INVALID_ARG;
     if (split != 4 && split != 8 && split != 16 && split != 32) return AVSI_ERR_INVALID_ARG;
     if (!workspace || workspace_bytes < avsi_blstm_rec_fwd_coop_workspace_bytes(Bp)) return AVSI_ERR_WORKSPACE;
+    if (coop_tiles_per_launch(split, max_cus) < 1) return AVSI_ERR_UNSUPPORTED;   // 2 * split workgroups do not fit max_cus
     const hipStream_t st = (hipStream_t)stream;
     avsi_clear_error();
     if (hipMemsetAsync(workspace, 0, avsi_blstm_rec_fwd_coop_workspace_bytes(Bp), st) != hipSuccess) return AVSI_ERR_LAUNCH;
@@ -719,7 +732,7 @@ extern "C" int avsi_blstm_rec_bwd_coop_f32(const float* dhout, const float* rese
     if (split == 32)
         (void)hipFuncSetAttribute((const void*)blstm_rec_bwd_coop_fine_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                   96 * 1024);
-    const int tiles = Bp / 32, per = coop_tiles_per_launch(split);
+    const int tiles = Bp / 32, per = coop_tiles_per_launch(split, max_cus);
     for (int tile0 = 0; tile0 < tiles; tile0 += per) {
         const int nt = tiles - tile0 < per ? tiles - tile0 : per;
         CoopBwdArgs a{dhout, reserve, whbT, dz, (unsigned*)workspace, T, Bp, 2 * nt, tile0};

@@ -58,7 +58,7 @@ def blstm_rec_fwd(xproj, whp, hout, reserve=None, rows_per_wg=0, split=None):
         L = _lib.lib()
         ws = _coop_ws(xproj.device, Bp)
         _lib.check(L.avsi_blstm_rec_fwd_coop_f32(_lib.ptr(xproj), _lib.ptr(whp), _lib.ptr(hout), _lib.ptr(reserve), T, Bp,
-                                                 split, _lib.ptr(ws), ws.numel() * 4, _lib.stream_ptr()),
+                                                 split, coop_cu_budget(), _lib.ptr(ws), ws.numel() * 4, _lib.stream_ptr()),
                    "avsi_blstm_rec_fwd_coop_f32")
         _coop_after_launch(xproj.device, ws)
         return hout
@@ -97,6 +97,39 @@ def _coop_after_launch(device, ws):
     event.record()
 
 
+_COOP_CU_BUDGET = None      # set_coop_cu_budget(); None = AVSI_COOP_CUS or the whole chip
+COOP_CU_RESERVE = 32        # CUs left to concurrent collectives under data parallelism (parallel.init)
+
+
+def set_coop_cu_budget(cus):
+    """Compute units ONE cooperative recurrent launch may occupy (None: AVSI_COOP_CUS, default 256).  Every
+    member of such a launch must be resident together, so whatever else this process keeps in flight beside it
+    has to be left out: ``parallel.init()`` reserves COOP_CU_RESERVE CUs for the RCCL kernels of the bucketed
+    gradient all-reduce, which run concurrently with the BPTT of the layers below; a process with several small
+    batches in flight on different streams divides the chip between them.  Both the split policy below and the
+    C-side cutting of a batch into resident-sized launches (``max_cus``) follow it."""
+    global _COOP_CU_BUDGET
+    _COOP_CU_BUDGET = None if cus is None else max(8, min(256, int(cus)))
+
+
+def coop_cu_budget():
+    if _COOP_CU_BUDGET is not None:
+        return _COOP_CU_BUDGET
+    budget = max(8, min(256, int(os.environ.get('AVSI_COOP_CUS', '256'))))
+    from . import parallel
+    if parallel.collectives_share_the_gpu():
+        budget = min(budget, 256 - COOP_CU_RESERVE)
+    return budget
+
+
+def occupy_cus(num_cus, release, max_ms=5000):
+    """Diagnostic (avsi_diag_occupy_cus): park `num_cus` whole-CU workgroups on the CURRENT stream until the device
+    int32 tensor `release` becomes non-zero (or max_ms passes)."""
+    _lib.require_cuda(release)
+    _lib.check(_lib.lib().avsi_diag_occupy_cus(int(num_cus), _lib.ptr(release), int(max_ms), _lib.stream_ptr()),
+               "avsi_diag_occupy_cus")
+
+
 def coop_split(Bp, backward=False):
     """Workgroups per (32-utterance tile, direction) of the small-batch recurrent kernels, 0 = use the
     batch-stationary kernels.  The cooperative grid must be resident on the 256 CUs at once, and the
@@ -114,14 +147,16 @@ def coop_split(Bp, backward=False):
         split = 16
     else:
         split = 8 if Bp <= 512 else (4 if Bp <= 2048 else 0)      # 1024 < Bp <= 2048: two resident-sized launches
-    # AVSI_COOP_CUS: CUs one cooperative launch may occupy (default: the chip).  Every member of a launch must be
-    # resident together, so a process that keeps several small batches in flight on different streams should
-    # divide the 256 CUs between them (8 streams: 32); the bounded spin catches an over-subscription anyway.
+    # coop_cu_budget(): CUs one cooperative launch may occupy (default: the chip; see set_coop_cu_budget).  A
+    # batch that fits the budget in one launch at a coarser split takes that; beyond it the C side cuts the batch
+    # into resident-sized launches.  The bounded spin catches an over-subscription anyway.
     forced = os.environ.get('AVSI_COOP_SPLIT_BWD' if backward else 'AVSI_COOP_SPLIT_FWD')     # diagnostics
     if forced and split:
         return int(forced)
-    budget = int(os.environ.get('AVSI_COOP_CUS', '256'))
+    budget = coop_cu_budget()
     while split > 4 and 2 * (Bp // 32) * split > budget:
+        split //= 2
+    while split > 4 and 2 * split > budget:       # not even one tile fits at this split
         split //= 2
     return split
 
@@ -321,7 +356,8 @@ def blstm_rec_bwd(dhout, reserve, whbt, dz, split=None):
     if split:
         ws = _coop_ws(dhout.device, Bp)
         _lib.check(_lib.lib().avsi_blstm_rec_bwd_coop_f32(_lib.ptr(dhout), _lib.ptr(reserve), _lib.ptr(whbt), _lib.ptr(dz),
-                                                          T, Bp, split, _lib.ptr(ws), ws.numel() * 4, _lib.stream_ptr()),
+                                                          T, Bp, split, coop_cu_budget(), _lib.ptr(ws), ws.numel() * 4,
+                                                          _lib.stream_ptr()),
                    "avsi_blstm_rec_bwd_coop_f32")
         _coop_after_launch(dhout.device, ws)
         return dz

@@ -35,6 +35,13 @@ def init(backend=None):
     return rank, world
 
 
+def collectives_share_the_gpu():
+    """True when this process runs RCCL collectives on its GPU (world > 1, backend nccl): their kernels hold compute
+    units while the cooperative recurrent kernels run (the bucketed gradient all-reduce overlaps the BPTT of the
+    layers below), so those kernels are sized to leave ops.COOP_CU_RESERVE CUs free (ops.coop_cu_budget)."""
+    return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1 and dist.get_backend() == 'nccl'
+
+
 def world_size():
     return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
 

@@ -146,12 +146,15 @@ int avsi_l1_loss_f32(const float* target, const float* pred, const float* mask, 
  * recurrent kernel in registers for all T steps and exchange h_t through hout with a per-step
  * counter in `workspace` (avsi_blstm_rec_fwd_coop_workspace_bytes(Bp) bytes, zeroed by the call).
  * A launch must be wholly resident (one workgroup per CU), so batches beyond 128 (split 32) / 256 (16) /
- * 512 (8) / 1024 (4) utterances run as consecutive launches over tile ranges.  After the stream has drained, word 0 of the
- * workspace is 0; a non-zero value means a workgroup stopped waiting for its peers (bounded spin)
- * and the outputs are invalid. */
+ * 512 (8) / 1024 (4) utterances run as consecutive launches over tile ranges.  `max_cus` (<= 0: all 256) is the
+ * number of compute units the caller grants one launch: a process that keeps other kernels in flight beside the
+ * recurrence (RCCL collectives of data-parallel training, batches on other streams) passes what is left, and the
+ * launches are cut to fit; AVSI_ERR_UNSUPPORTED when not even one tile (2 * split workgroups) fits.
+ * After the stream has drained, word 0 of the workspace is 0; a non-zero value means a workgroup stopped
+ * waiting for its peers (bounded spin) and the outputs are invalid. */
 size_t avsi_blstm_rec_fwd_coop_workspace_bytes(int Bp);
 int avsi_blstm_rec_fwd_coop_f32(const float* xproj, const float* whp, float* hout, float* reserve,
-                                int T, int Bp, int split, void* workspace, size_t workspace_bytes,
+                                int T, int Bp, int split, int max_cus, void* workspace, size_t workspace_bytes,
                                 void* stream);
 
 /* Small-batch form of avsi_blstm_rec_bwd_f32 (same operands and results), the gradient of the
@@ -159,8 +162,13 @@ int avsi_blstm_rec_fwd_coop_f32(const float* xproj, const float* whp, float* hou
  * the hidden state x 2 halves of the tile's 32 utterances), dz doubles as the exchange buffer between the
  * workgroups of a group. */
 int avsi_blstm_rec_bwd_coop_f32(const float* dhout, const float* reserve, const float* whbT, float* dz,
-                                int T, int Bp, int split, void* workspace, size_t workspace_bytes,
+                                int T, int Bp, int split, int max_cus, void* workspace, size_t workspace_bytes,
                                 void* stream);
+
+/* Diagnostic: park `num_cus` workgroups, each claiming a whole compute unit (160 KiB of LDS), on `stream` until
+ * *release (device int32) becomes non-zero or ~`max_ms` milliseconds have passed (every workgroup leaves by itself).
+ * Stands in for the CUs an RCCL collective holds while the cooperative kernels run (tests/test_coop_residency_gpu.py). */
+int avsi_diag_occupy_cus(int num_cus, const int* release, int max_ms, void* stream);
 
 /* Loss of the speaker-embedding model variants (reference models.py:1006-1029 StackedBLSTMSSNNModel,
  * :1367-1394 StackedBLSTMEmbeddingModel): the prediction keeps the known bins,

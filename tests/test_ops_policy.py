@@ -20,3 +20,26 @@ def test_cooperative_split_policy(monkeypatch):
     assert ops.coop_split(256) == 4                        # never below the coarsest cooperative kernel
     monkeypatch.setenv('AVSI_REC_COOP', '0')
     assert ops.coop_split(32) == 0
+
+
+def test_cu_budget_leaves_room_for_concurrent_collectives(monkeypatch):
+    """ops.set_coop_cu_budget / parallel.collectives_share_the_gpu: with 32 CUs reserved, every single-launch choice
+    of the policy fits 224 CUs, and no split is chosen whose one tile (2 * split workgroups) would not fit."""
+    monkeypatch.delenv('AVSI_COOP_CUS', raising=False)
+    monkeypatch.delenv('AVSI_REC_COOP', raising=False)
+    ops.set_coop_cu_budget(256 - ops.COOP_CU_RESERVE)
+    try:
+        assert ops.coop_cu_budget() == 224
+        for b in range(32, 2049, 32):
+            for back in (False, True):
+                s = ops.coop_split(b, back)
+                assert s in (4, 8, 16, 32) and 2 * s <= 224
+                if b <= 384:
+                    assert 2 * (b // 32) * s <= 224, (b, back, s)
+        ops.set_coop_cu_budget(40)
+        assert ops.coop_split(32) == 16 and 2 * ops.coop_split(32) <= 40
+    finally:
+        ops.set_coop_cu_budget(None)
+    assert ops.coop_cu_budget() == 256
+    from avsi_amd import parallel
+    assert parallel.collectives_share_the_gpu() is False
