@@ -159,8 +159,13 @@ class _Prefetcher(object):
     def __init__(self, gen, depth):
         self._q = queue.Queue(maxsize=max(1, int(depth)))
         self._stop = threading.Event()
-        self._thread = threading.Thread(target=self._run, args=(gen,), daemon=True, name='avsi-prefetch')
-        self._thread.start()
+        self._gen = gen
+        self._thread = None         # started by the first next(): a pass that is rewound before use costs nothing
+
+    def _start(self):
+        if self._thread is None:
+            self._thread = threading.Thread(target=self._run, args=(self._gen,), daemon=True, name='avsi-prefetch')
+            self._thread.start()
 
     def _put(self, item):
         while not self._stop.is_set():
@@ -184,6 +189,7 @@ class _Prefetcher(object):
         return self
 
     def __next__(self):
+        self._start()
         item = self._q.get()
         if item is self._END:
             self._q.put(item)               # stay exhausted
@@ -194,7 +200,12 @@ class _Prefetcher(object):
         return item
 
     def close(self):
+        """Stop the pass and WAIT for its thread: the next pass reuses the same host arenas and batch counter, which
+        a still-running thread would write into."""
         self._stop.set()
+        t = self._thread
+        if t is not None and t is not threading.current_thread():
+            t.join()
 
 
 class BatchIterator(object):

@@ -5,7 +5,12 @@ The hot path shards by utterance: inference needs no data-path collective; train
 gradients once per step (4.15 M / 4.42 M floats), in per-layer buckets of the packed gradient buffer that
 overlap with the backward pass (StackedBLSTMModel._backward).
 The loss is a mean over B*T*F, so summing per-rank gradients and dividing by the world size
-reproduces the single-GPU gradient of the global batch when ranks hold equal batches.
+reproduces the single-GPU gradient of the global batch when ranks hold equal batches of equal padded
+length -- the plain a / v / av models on fixed-length clips, which is what BASELINE config 4 trains.
+It is an APPROXIMATION (a mean of per-rank ratios instead of the ratio of global sums) for the variants whose
+objective is ``loss_hole = sum|err|(1-m) / sum(1-m)`` (-ssnn / -emb / -ctc: the denominator is per rank) and for
+ragged batches (T = the rank's own longest clip); ranks then weigh equally, not by their gap frames.
+``model.gradients`` is the LOCAL gradient before ``train_op`` and the world-SUM (not yet divided) after it.
 """
 import os
 
@@ -87,6 +92,16 @@ def all_reduce_sum_scalars(values):
     t = torch.tensor(list(values), dtype=torch.float64, device=dev)
     dist.all_reduce(t, op=dist.ReduceOp.SUM)
     return t.tolist()
+
+
+def all_reduce_max_scalar(value):
+    """Maximum over ranks of one python float (the 'some rank saw a non-finite loss' verdict of the trainer)."""
+    if world_size() == 1:
+        return float(value)
+    dev = 'cuda' if dist.get_backend() == 'nccl' else 'cpu'
+    t = torch.tensor([float(value)], dtype=torch.float64, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
 
 
 def all_reduce_sum_async(flat):

@@ -431,16 +431,33 @@ def import_variables(bundle, layout, scope=None):
 
 def export_variables(layout, flat, scope, adam_m=None, adam_v=None, global_step=0, beta1=0.9, beta2=0.999):
     """The inverse of import_variables: {tf name: array} as tf.train.Saver over
-    the model's global variables would store it (models.py:226-231 all_vars)."""
+    the model's global variables would store it (models.py:226-231 all_vars).
+
+    Names of the optimiser state follow how the reference creates it: ``train_op`` runs under
+    ``tf.variable_scope(<model>)`` and ``tf.name_scope('optimizer')`` (models.py:163-178,224), so the step counter is
+    ``<scope>/optimizer/Variable``, the Adam accumulators ``<scope>/optimizer/beta{1,2}_power``, and a slot created
+    inside a variable scope gets that scope prefixed to the variable's own name (``<scope>/<scope>/.../kernel/Adam``).
+    UNVERIFIED (no TensorFlow here, no checkpoint in the reference): each of these is ALSO written under the plain
+    name (``<scope>/Variable``, ``<scope>/beta1_power``, ``<var>/Adam``) -- extra entries are harmless to
+    ``Saver.restore``, a missing one is NotFound.  U-Net layouts also get the batch-norm moving statistics the
+    reference never updates (zeros / ones: UPDATE_OPS are not run) -- they are GLOBAL_VARIABLES."""
     names = tf_variable_names(layout, scope)
     out = {}
     for local, tf_name in names.items():
         out[tf_name] = np.array(layout.ref_view(flat, local), dtype=np.float32)
         if adam_m is not None and adam_v is not None:
-            out[tf_name + '/Adam'] = np.array(layout.ref_view(adam_m, local), dtype=np.float32)
-            out[tf_name + '/Adam_1'] = np.array(layout.ref_view(adam_v, local), dtype=np.float32)
-    out['%s/Variable' % scope] = np.array(global_step, dtype=np.int32)
-    if adam_m is not None and adam_v is not None:
-        out['%s/beta1_power' % scope] = np.array(beta1 ** (global_step + 1), dtype=np.float32)
-        out['%s/beta2_power' % scope] = np.array(beta2 ** (global_step + 1), dtype=np.float32)
+            for prefix in ('', scope + '/'):
+                out[prefix + tf_name + '/Adam'] = np.array(layout.ref_view(adam_m, local), dtype=np.float32)
+                out[prefix + tf_name + '/Adam_1'] = np.array(layout.ref_view(adam_v, local), dtype=np.float32)
+        m = _BN_RE.search(tf_name)
+        if m and m.group(2) == 'gamma':
+            base = tf_name[:-len('gamma')]
+            n = out[tf_name].shape
+            out[base + 'moving_mean'] = np.zeros(n, dtype=np.float32)
+            out[base + 'moving_variance'] = np.ones(n, dtype=np.float32)
+    for prefix in ('%s/optimizer/' % scope, '%s/' % scope):
+        out[prefix + 'Variable'] = np.array(global_step, dtype=np.int32)
+        if adam_m is not None and adam_v is not None:
+            out[prefix + 'beta1_power'] = np.array(beta1 ** (global_step + 1), dtype=np.float32)
+            out[prefix + 'beta2_power'] = np.array(beta2 ** (global_step + 1), dtype=np.float32)
     return out

@@ -164,7 +164,8 @@ def train(config_file, checkpoint_format=None):
 
     train_size = len(np.load(os.path.join(data_path_train, 'seq_lengths.npy')))
     val_size = len(np.load(os.path.join(data_path_val, 'seq_lengths.npy')))
-    n_steps_epoch = int(train_size / config['batch_size'])
+    # steps of ONE rank per epoch: global_step counts per-rank steps, so resuming recovers the epoch from it
+    n_steps_epoch = int(train_size / (config['batch_size'] * world))
     n_steps = n_steps_epoch * config['max_n_epochs']
 
     header = [
@@ -263,6 +264,13 @@ def train(config_file, checkpoint_format=None):
             """Bookkeeping of one finished training step (reference training_emb.py:244-262)."""
             nonlocal train_avg, nframe_sum
             vals = resolve(vals)
+            if world > 1:
+                # every rank must leave at the SAME step (a rank that exits alone leaves its peers waiting in the
+                # next gradient all-reduce): the verdict is the maximum over ranks of 'my loss is not finite'
+                bad = parallel.all_reduce_max_scalar(0.0 if np.isfinite(vals[0]) else (2.0 if np.isinf(vals[0]) else 1.0))
+                if bad and np.isfinite(vals[0]):
+                    print('GOT INSTABILITY on another rank: loss is %s there. Leaving...' % ('inf' if bad > 1 else 'NaN'))
+                    sys.exit(1)
             if np.isnan(vals[0]):
                 print('GOT INSTABILITY: loss is NaN. Leaving...')
                 sys.exit(1)

@@ -46,7 +46,7 @@ if __name__ == '__main__':
     out = sys.argv[1]
     from avsi_amd import parallel
     rank, world = parallel.init()
-    flat, losses = run(rank, world, steps=3)
+    flat, losses = run(rank, world, steps=3, B_global=int(sys.argv[2]) if len(sys.argv) > 2 else 4)
     np.save(os.path.join(out, 'flat_rank%d.npy' % rank), flat)
     np.save(os.path.join(out, 'loss_rank%d.npy' % rank), np.array(losses))
     import torch.distributed as dist

@@ -41,3 +41,34 @@ def test_two_ranks_equal_one_process_at_the_global_batch(tmp_path):
     # loss_func is a mean over B*T*F: the global loss is the mean of the two ranks' losses
     l0, l1 = np.load(str(tmp_path / 'loss_rank0.npy')), np.load(str(tmp_path / 'loss_rank1.npy'))
     np.testing.assert_allclose((l0 + l1) / 2, ref_losses, rtol=2e-4)
+
+
+def _gpu_count():
+    try:
+        import torch
+        return torch.cuda.device_count()
+    except Exception:
+        return 0
+
+
+@pytest.mark.skipif(_gpu_count() < 2, reason="needs two GPUs: the RCCL branch (backend nccl) refuses two ranks on one device")
+@pytest.mark.parametrize("B_global", [4, 192])
+def test_two_ranks_over_rccl_equal_one_process(tmp_path, B_global):
+    """The production branch: backend nccl (= RCCL), asynchronous all-reduce of the per-layer gradient buckets issued
+    behind each layer's weight-gradient kernels -- from the side stream at Bp <= 64 (B_global 4), from the main
+    stream above (B_global 192: 96 utterances per rank).  Bitwise-identical variables on both ranks, equal to one
+    process at the global batch up to summation order."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0')
+    env.pop('AVSI_DIST_BACKEND', None)
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+           '--master-port', str(_free_port()), os.path.join(HERE, 'dp_worker.py'), str(tmp_path), str(B_global)]
+    run = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert run.returncode == 0, run.stderr[-3000:]
+    f0, f1 = np.load(str(tmp_path / 'flat_rank0.npy')), np.load(str(tmp_path / 'flat_rank1.npy'))
+    assert np.array_equal(f0, f1)
+    sys.path.insert(0, HERE)
+    import dp_worker
+    ref, ref_losses = dp_worker.run(0, 1, steps=3, B_global=B_global)
+    np.testing.assert_allclose(f0, ref, rtol=0, atol=2e-5)
+    l0, l1 = np.load(str(tmp_path / 'loss_rank0.npy')), np.load(str(tmp_path / 'loss_rank1.npy'))
+    np.testing.assert_allclose((l0 + l1) / 2, ref_losses, rtol=2e-4)
