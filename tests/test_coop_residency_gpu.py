@@ -50,6 +50,7 @@ def test_training_beside_parked_compute_units(B, occupied):
     release = torch.zeros(1, dtype=torch.int32, device='cuda')
     side = torch.cuda.Stream()
     ops.set_coop_cu_budget(256 - ops.COOP_CU_RESERVE)
+    splits = {back: ops.coop_split(B, back) for back in (False, True)}      # what the budgeted run uses
     try:
         m2, feed2 = _model(B, 1)
         torch.cuda.synchronize()
@@ -62,8 +63,15 @@ def test_training_beside_parked_compute_units(B, occupied):
         torch.cuda.synchronize()
         ops.set_coop_cu_budget(None)
     assert parked_during
-    assert losses == ref_losses
-    assert torch.equal(vars_, ref_vars) and torch.equal(pred, ref_pred)
+    same_kernels = all(ops.coop_split(B, back) == split for back, split in splits.items())
+    if same_kernels:
+        # the budget only cut the batch into more launches of the same kernels: nothing may change
+        assert losses == ref_losses
+        assert torch.equal(vars_, ref_vars) and torch.equal(pred, ref_pred)
+    else:
+        # the budget also moved the policy to a coarser split (another reduction order): equal up to rounding
+        np.testing.assert_allclose(losses, ref_losses, rtol=1e-5)
+        assert (vars_ - ref_vars).abs().max().item() < 1e-5 and (pred - ref_pred).abs().max().item() < 1e-4
 
 
 def test_one_tile_that_does_not_fit_is_refused():
