@@ -6,7 +6,11 @@
 
 namespace avsi_fft {
 
-struct cf {
+// 8-byte aligned: an LDS array of cf is then accessed with ds_read_b64 / ds_write_b64 (one access per complex
+// value, 64 banks); with the natural 4-byte alignment the compiler must use ds_read2_b32 / ds_write2_b32, two
+// dword accesses that each see a stride of two banks -- SQ_LDS_BANK_CONFLICT was 2/3 of all LDS cycles of the
+// front-end kernel
+struct alignas(8) cf {
     float r, i;
 };
 

@@ -16,6 +16,8 @@
 //   - the epilogue maps thread -> frequency bin (so per-bin twiddle / mean / std stay in
 //     registers and every global store is a full coalesced row), recovers X[k] from Z[k] and
 //     Z[256-k], and writes every requested output exactly once.
+#include <stdlib.h>
+
 #include "avsi_common.h"
 #include "fft16.h"
 
@@ -51,13 +53,21 @@ __global__ void frontend_tables_kernel(float* tab, int frame_len) {
 }
 
 // NB = number of 32-sample column groups that can hold non-zero window taps = ceil(frame_len/32)
-template <int NB>
-__global__ __launch_bounds__(TPB, 2) void frontend_kernel(const avsi_frontend_args a, const int tiles_per_utt,
-                                                       const int n_tiles, const int seg_floats, const int step) {
+// WR = float4 staging registers per thread for the next tile's samples (256 threads x 4 floats each: WR = 4 covers
+// the 15 x 192 + 384 samples of the standard geometry, 8 covers hop <= 512); OCC = workgroups per CU the register
+// allocation is held to (3 -> 168 VGPRs).
+// STEP1: nfft = 512 (column = bin: the column / liveness arithmetic of the 256-point case folds away).
+// MODEL: the inpainter's own call (models.py:30-35) -- nfft 512, >= 256 bins, normalised log-magnitude spectrum AND
+// masked features out, mask given, no complex / log-mel output: every store and every mask load of the epilogue is
+// unconditional, so the compiler sees straight-line code and can count the stores it may leave in flight.
+template <int NB, int WR, int OCC, bool STEP1, bool MODEL>
+__global__ __launch_bounds__(TPB, OCC) void frontend_kernel(const avsi_frontend_args a, const int tiles_per_utt,
+                                                         const int n_tiles, const int seg_floats, const int step_arg) {
+    const int step = STEP1 ? 1 : step_arg;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* s_wav = reinterpret_cast<float*>(smem);
-    cf* s_z = reinterpret_cast<cf*>(smem + (size_t)seg_floats * 4);
-    float* s_pow = reinterpret_cast<float*>(smem + (size_t)seg_floats * 4 + (size_t)FR * ZSTRIDE * 8);
+    cf* s_z = reinterpret_cast<cf*>(smem + (size_t)(seg_floats + 4) * 4);
+    float* s_pow = reinterpret_cast<float*>(smem + (size_t)(seg_floats + 4) * 4 + (size_t)FR * ZSTRIDE * 8);
 
     const int tid = threadIdx.x;
     const int f = tid >> 4;   // frame of the tile handled in the FFT phase
@@ -74,57 +84,85 @@ __global__ __launch_bounds__(TPB, 2) void frontend_kernel(const avsi_frontend_ar
         s_tw[i][l] = *reinterpret_cast<const float2*>(tab + TAB_TW256 + 2 * ((l * i) & 255));
     }
     __syncthreads();
-    // ---- epilogue mapping: thread <-> 4 consecutive bins (kq) x 4 frames (its wave's quarter of the
-    //      tile): per-bin twiddle / mean / 1/std stay in registers, every global access is 16 B per lane
+    // ---- epilogue mapping: thread <-> bins kq, kq + 64, kq + 128, kq + 192 x 4 frames (its wave's quarter of the
+    //      tile): a wave reads 64 CONSECUTIVE complex values of the LDS row per access (and 64 consecutive ones of
+    //      the mirrored half, Z[256 - k]) -- no bank conflicts -- and every global access is 256 contiguous bytes
+    //      per wave.  (Four consecutive bins per thread gave 16-byte global accesses but a 32-byte lane stride in
+    //      LDS: 4-way conflicts on every read of the spectrum tile.)  The per-bin constants (twiddle, mean, 1/std)
+    //      sit in LDS as one float4 per thread each and are fetched at the top of the epilogue: as registers they
+    //      were 16 VGPRs alive across the whole FFT phase of a kernel whose occupancy is set by its registers.
     const int kq = tid & 63, fg = tid >> 6;
-    const int k0 = 4 * kq;
     const bool have_norm = a.mean != nullptr;
-    float wkr[4], wki[4], mean_k[4], istd_k[4];
+    __shared__ float4 s_c[4][64];          // [twiddle re | twiddle im | mean | 1 / std][kq]
     // `step` = 512 / nfft: a 256-point transform is read off the even bins of the 512-point one (the
     // frame is zero-padded to 512, which interpolates the spectrum), so output column = bin / step.
     bool live[4];
     int col[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-        const float2 w = *reinterpret_cast<const float2*>(tab + TAB_TW512 + 2 * (k0 + j));
-        wkr[j] = w.x, wki[j] = w.y;
-        col[j] = (k0 + j) / step;
-        live[j] = ((k0 + j) % step == 0) && col[j] < F;
-        mean_k[j] = (have_norm && live[j]) ? a.mean[col[j]] : 0.f;
-        istd_k[j] = (have_norm && live[j]) ? 1.f / a.stdev[col[j]] : 1.f;
+        col[j] = STEP1 ? kq + 64 * j : (kq + 64 * j) / step;
+        live[j] = STEP1 ? (kq + 64 * j < F) : (((kq + 64 * j) % step == 0) && col[j] < F);
     }
+    {
+        float wr4[4], wi4[4], mean4[4], istd4[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float2 w = *reinterpret_cast<const float2*>(tab + TAB_TW512 + 2 * (kq + 64 * j));
+            wr4[j] = w.x, wi4[j] = w.y;
+            mean4[j] = (have_norm && live[j]) ? a.mean[col[j]] : 0.f;
+            istd4[j] = (have_norm && live[j]) ? 1.f / a.stdev[col[j]] : 1.f;
+        }
+        if (tid < 64) {
+            s_c[0][kq] = make_float4(wr4[0], wr4[1], wr4[2], wr4[3]);
+            s_c[1][kq] = make_float4(wi4[0], wi4[1], wi4[2], wi4[3]);
+            s_c[2][kq] = make_float4(mean4[0], mean4[1], mean4[2], mean4[3]);
+            s_c[3][kq] = make_float4(istd4[0], istd4[1], istd4[2], istd4[3]);
+        }
+    }
+    __syncthreads();
     const int col_n = 256 / step;                                        // Nyquist bin
     const float mean_n = (have_norm && F > col_n) ? a.mean[col_n] : 0.f;
     const float istd_n = (have_norm && F > col_n) ? 1.f / a.stdev[col_n] : 1.f;
-    const bool want_pow = a.out_logmel != nullptr;
-    const bool full4 = step == 1 && k0 + 3 < F;  // all four bins of this thread are inside the requested slice
+    const bool want_pow = !MODEL && a.out_logmel != nullptr;
+    const bool has_stft = !MODEL && a.out_stft != nullptr;
+    const bool has_spec = MODEL || a.out_spec != nullptr;
+    const bool has_feat = MODEL || a.out_feat != nullptr;
+    const bool has_mask = MODEL || a.mask != nullptr;
+    const float spec_power = MODEL ? 1.f : a.spec_power;
+    const bool log_spec = MODEL || a.log_spec;
 
     // Software pipeline over tiles: the NEXT tile's samples are fetched into registers while the
     // current tile is transformed, and the current tile's mask values are fetched before the FFT and
     // consumed after it, so neither HBM latency sits on the critical path of a tile.
-    constexpr int WR = 8;  // float4 staging registers per thread (covers hop <= 512)
     float4 wreg[WR];
+    // BRANCH-FREE on purpose: with a per-lane `if (in range) load` the loads sat in divergent blocks and the
+    // compiler closed every one of them with s_waitcnt vmcnt(0) -- four serialised HBM round trips per tile
+    // (~8 of the 12 us a tile took), and nothing of the intended prefetch.  Out-of-range lanes load the tile's
+    // first sample(s) instead and select zero.
     auto fetch_wav = [&](int tl) {
         const int bb = tl / tiles_per_utt;
         const int64_t s0 = (int64_t)(tl - bb * tiles_per_utt) * FR * S;
         const float* src = a.wav + (int64_t)bb * a.wav_stride + s0;
-        const int valid = (int)max((int64_t)0, min((int64_t)seg_floats, (int64_t)N - s0));
-        const bool vec = ((reinterpret_cast<uintptr_t>(src) & 15) == 0);
+        const int valid = (int)max((int64_t)0, min((int64_t)seg_floats, (int64_t)N - s0));      // >= 1
+        // wave-uniform: whole float4s only (aligned rows, and the samples of this tile end on a multiple of four)
+        const bool vec = ((reinterpret_cast<uintptr_t>(src) & 15) == 0) && ((valid & 3) == 0);
+        if (vec) {
 #pragma unroll
-        for (int p = 0; p < WR; ++p) {
-            const int i = (p * TPB + tid) * 4;
-            float4 v = {0.f, 0.f, 0.f, 0.f};
-            if (i < seg_floats) {
-                if (vec && i + 3 < valid) {
-                    v = *reinterpret_cast<const float4*>(src + i);
-                } else {
-                    v.x = i < valid ? src[i] : 0.f;
-                    v.y = i + 1 < valid ? src[i + 1] : 0.f;
-                    v.z = i + 2 < valid ? src[i + 2] : 0.f;
-                    v.w = i + 3 < valid ? src[i + 3] : 0.f;
-                }
+            for (int p = 0; p < WR; ++p) {
+                const int i = (p * TPB + tid) * 4;
+                const bool ok = i + 3 < valid;
+                const float4 v = *reinterpret_cast<const float4*>(src + (ok ? i : 0));
+                wreg[p] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
             }
-            wreg[p] = v;
+        } else {
+#pragma unroll
+            for (int p = 0; p < WR; ++p) {
+                const int i = (p * TPB + tid) * 4;
+                const float x0 = src[i < valid ? i : 0], x1 = src[i + 1 < valid ? i + 1 : 0];
+                const float x2 = src[i + 2 < valid ? i + 2 : 0], x3 = src[i + 3 < valid ? i + 3 : 0];
+                wreg[p] = make_float4(i < valid ? x0 : 0.f, i + 1 < valid ? x1 : 0.f, i + 2 < valid ? x2 : 0.f,
+                                      i + 3 < valid ? x3 : 0.f);
+            }
         }
     };
     if (blockIdx.x < n_tiles) fetch_wav(blockIdx.x);
@@ -137,24 +175,13 @@ __global__ __launch_bounds__(TPB, 2) void frontend_kernel(const avsi_frontend_ar
 #pragma unroll
         for (int p = 0; p < WR; ++p) {
             const int i = (p * TPB + tid) * 4;
-            if (i < seg_floats) *reinterpret_cast<float4*>(s_wav + i) = wreg[p];
+            // lanes past the segment write a spare 16-byte slot behind it (no per-lane branch around the access)
+            *reinterpret_cast<float4*>(s_wav + (i < seg_floats ? i : seg_floats)) = wreg[p];
         }
-        __syncthreads();
+        // LDS-only barriers throughout the tile loop: __syncthreads() would also drain vmcnt, i.e. wait for this
+        // tile's output stores and for the NEXT tile's sample / mask loads -- exactly what the pipeline keeps in flight
+        AVSI_LDS_BARRIER();
         if (tile + (int)gridDim.x < n_tiles) fetch_wav(tile + gridDim.x);
-        float mk[4][4];
-#pragma unroll
-        for (int fi = 0; fi < 4; ++fi) {
-            const int t = t0 + fg * 4 + fi;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) mk[fi][j] = 1.f;
-            if (a.out_feat && a.mask && t < T) {
-                const float* mp = a.mask + (int64_t)b * a.mask_stride_b + (int64_t)t * a.mask_stride_t;
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    if (live[j]) mk[fi][j] = mp[col[j]];
-            }
-        }
-
         // ---- 2. window + first 16-point FFT (over n2, with n = ln + 16 n2) + twiddle
         cf v[16];
         {
@@ -185,16 +212,52 @@ __global__ __launch_bounds__(TPB, 2) void frontend_kernel(const avsi_frontend_ar
 #pragma unroll
         for (int n1 = 0; n1 < 16; ++n1) v[n1] = zf[ln * 17 + n1];
         asm volatile("" ::: "memory");
+        // this tile's mask values: requested here, in flight during the second FFT and the barrier, consumed by the
+        // epilogue (requested before the first FFT they were 16 more registers alive across both)
+        float mk[4][4], mkn[4];
+#pragma unroll
+        for (int fi = 0; fi < 4; ++fi) {
+            const int t = t0 + fg * 4 + fi;
+            mkn[fi] = 1.f;
+            if (MODEL && t < T)       // Nyquist column of the mask (one address per frame: a broadcast load)
+                mkn[fi] = a.mask[(int64_t)b * a.mask_stride_b + (int64_t)t * a.mask_stride_t + 256];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) mk[fi][j] = 1.f;
+            if (has_feat && has_mask && t < T) {       // wave-uniform; the loads themselves branch-free
+                const float* mp = a.mask + (int64_t)b * a.mask_stride_b + (int64_t)t * a.mask_stride_t;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) mk[fi][j] = mp[MODEL ? kq + 64 * j : (live[j] ? col[j] : 0)];      // RAW: any arithmetic on the value here
+                                                                               // (even a select) makes the wave wait for it now
+            }
+        }
+
 
         // ---- 4. second 16-point FFT (over n1): Z[16 k1 + ln], natural order; Z[256] := Z[0]
         fft16(v);
 #pragma unroll
         for (int k1 = 0; k1 < 16; ++k1) zf[16 * k1 + ln] = v[pos16(k1)];
         if (ln == 0) zf[256] = v[pos16(0)];
-        __syncthreads();
+        AVSI_LDS_BARRIER();
 
         // ---- 5. epilogue: X[k] = E[k] + W512^k O[k],  E = (Z[k] + conj Z[256-k]) / 2,
         //         O = -j (Z[k] - conj Z[256-k]) / 2
+        // The mask values are needed from here on.  Pin the wait for them HERE, before any store of this tile is
+        // issued: vmcnt counts loads and stores in order, and once stores sit between the mask loads and their
+        // first use the only wait the compiler can prove is vmcnt(0) -- a full drain of those stores, per frame.
+        if (has_feat) {
+#pragma unroll
+            for (int fi = 0; fi < 4; ++fi)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) asm volatile("v_mov_b32 %0, %0" : "+v"(mk[fi][j])::"memory");
+            if (MODEL) {
+#pragma unroll
+                for (int fi = 0; fi < 4; ++fi) asm volatile("v_mov_b32 %0, %0" : "+v"(mkn[fi])::"memory");
+            }
+        }
+        const bool all_live = MODEL || (STEP1 && F >= 256);        // wave-uniform: every bin of every lane is stored
+        const float4 wkr4 = s_c[0][kq], wki4 = s_c[1][kq], mean4v = s_c[2][kq], istd4v = s_c[3][kq];
+        const float wkr[4] = {wkr4.x, wkr4.y, wkr4.z, wkr4.w}, wki[4] = {wki4.x, wki4.y, wki4.z, wki4.w};
+        const float mean_k[4] = {mean4v.x, mean4v.y, mean4v.z, mean4v.w}, istd_k[4] = {istd4v.x, istd4v.y, istd4v.z, istd4v.w};
 #pragma unroll
         for (int fi = 0; fi < 4; ++fi) {
             const int ff = fg * 4 + fi;
@@ -204,52 +267,66 @@ __global__ __launch_bounds__(TPB, 2) void frontend_kernel(const avsi_frontend_ar
             float xr[4], xi[4], p2[4], sp[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const cf zk = zrow[k0 + j], zm = zrow[256 - k0 - j];
+                const int k = kq + 64 * j;
+                const cf zk = zrow[k], zm = zrow[256 - k];
                 const cf e{0.5f * (zk.r + zm.r), 0.5f * (zk.i - zm.i)};
                 const cf o{0.5f * (zk.i + zm.i), -0.5f * (zk.r - zm.r)};
                 xr[j] = e.r + (o.r * wkr[j] - o.i * wki[j]);
                 xi[j] = e.i + (o.r * wki[j] + o.i * wkr[j]);
                 p2[j] = xr[j] * xr[j] + xi[j] * xi[j];
                 float sv = __builtin_amdgcn_sqrtf(p2[j]);
-                if (a.spec_power != 1.f) sv = (a.spec_power == 2.f) ? sv * sv : __powf(sv, a.spec_power);
-                if (a.log_spec) sv = __logf(sv + a.eps);
+                if (spec_power != 1.f) sv = (spec_power == 2.f) ? sv * sv : __powf(sv, spec_power);
+                if (log_spec) sv = __logf(sv + a.eps);
                 sp[j] = (sv - mean_k[j]) * istd_k[j];
             }
-            if (want_pow) *reinterpret_cast<float4*>(s_pow + ff * PSTRIDE + k0) = make_float4(p2[0], p2[1], p2[2], p2[3]);
-            if (a.out_stft) {
-                float* o2 = a.out_stft + (int64_t)b * a.stft_stride_b + (int64_t)t * a.stft_stride_t;
-                if (full4) {
-                    reinterpret_cast<float4*>(o2 + 2 * k0)[0] = make_float4(xr[0], xi[0], xr[1], xi[1]);
-                    reinterpret_cast<float4*>(o2 + 2 * k0)[1] = make_float4(xr[2], xi[2], xr[3], xi[3]);
-                } else {
+            if (want_pow) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) s_pow[ff * PSTRIDE + kq + 64 * j] = p2[j];
+            }
+            float* o2 = a.out_stft + (int64_t)b * a.stft_stride_b + (int64_t)t * a.stft_stride_t;
+            float* o1 = a.out_spec + (int64_t)b * a.spec_stride_b + (int64_t)t * a.spec_stride_t;
+            float* o3 = a.out_feat + (int64_t)b * a.feat_stride_b + (int64_t)t * a.feat_stride_t;
+            if (all_live) {     // straight-line stores (no per-lane branch: the compiler can count them)
+                if (has_stft) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) *reinterpret_cast<float2*>(o2 + 2 * (kq + 64 * j)) = make_float2(xr[j], xi[j]);
+                }
+                if (has_spec) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) o1[kq + 64 * j] = sp[j];
+                }
+                if (has_feat) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) o3[kq + 64 * j] = sp[j] * mk[fi][j];
+                }
+                if (MODEL) {
+                    // Nyquist bin (X[256] = Re Z[0] - Im Z[0], real) and the zero fill of the padded feature columns,
+                    // by the frame's own wave: lane 0 owns column 256, lanes 1 .. feat_cols - 257 the padding
+                    const cf z0 = zrow[0];
+                    const float svn = (__logf(fabsf(z0.r - z0.i) + a.eps) - mean_n) * istd_n;
+                    if (kq == 0) o1[256] = svn;
+                    if (kq < a.feat_cols - 256) o3[256 + kq] = kq == 0 ? svn * mkn[fi] : 0.f;
+                }
+            } else {
+                if (a.out_stft) {
 #pragma unroll
                     for (int j = 0; j < 4; ++j)
-                        if (live[j]) o2[2 * col[j]] = xr[j], o2[2 * col[j] + 1] = xi[j];
+                        if (live[j]) *reinterpret_cast<float2*>(o2 + 2 * col[j]) = make_float2(xr[j], xi[j]);
                 }
-            }
-            if (a.out_spec) {
-                float* o1 = a.out_spec + (int64_t)b * a.spec_stride_b + (int64_t)t * a.spec_stride_t;
-                if (full4) {
-                    *reinterpret_cast<float4*>(o1 + k0) = make_float4(sp[0], sp[1], sp[2], sp[3]);
-                } else {
+                if (a.out_spec) {
 #pragma unroll
                     for (int j = 0; j < 4; ++j)
                         if (live[j]) o1[col[j]] = sp[j];
                 }
-            }
-            if (a.out_feat) {
-                float* o1 = a.out_feat + (int64_t)b * a.feat_stride_b + (int64_t)t * a.feat_stride_t;
-                if (full4) {
-                    *reinterpret_cast<float4*>(o1 + k0) = make_float4(sp[0] * mk[fi][0], sp[1] * mk[fi][1], sp[2] * mk[fi][2], sp[3] * mk[fi][3]);
-                } else {
+                if (a.out_feat) {
 #pragma unroll
                     for (int j = 0; j < 4; ++j)
-                        if (live[j]) o1[col[j]] = sp[j] * mk[fi][j];
+                        if (live[j]) o3[col[j]] = sp[j] * mk[fi][j];
                 }
             }
         }
         // Nyquist bin (k = 256) and zero fill of the padded feature columns: thread <-> frame
-        if (tid < FR && t0 + tid < T) {
+        if (!MODEL && tid < FR && t0 + tid < T) {
             const int t = t0 + tid;
             const cf z0 = s_z[tid * ZSTRIDE];
             const float xn = z0.r - z0.i;  // X[256] = Re Z[0] - Im Z[0], purely real
@@ -280,7 +357,7 @@ __global__ __launch_bounds__(TPB, 2) void frontend_kernel(const avsi_frontend_ar
 
         // ---- 6. log-mel: sparse triangular bands over the power spectrum tile
         if (want_pow) {
-            __syncthreads();
+            AVSI_LDS_BARRIER();
             const int items = FR * a.num_mel;
             for (int it = tid; it < items; it += TPB) {
                 const int ff = it / a.num_mel, m = it - ff * a.num_mel;
@@ -294,7 +371,7 @@ __global__ __launch_bounds__(TPB, 2) void frontend_kernel(const avsi_frontend_ar
                 a.out_logmel[(int64_t)b * a.logmel_stride_b + (int64_t)t * a.logmel_stride_t + m] = __logf(acc + a.eps);
             }
         }
-        __syncthreads();  // LDS is re-staged by the next tile
+        AVSI_LDS_BARRIER();  // LDS is re-staged by the next tile
     }
 }
 
@@ -328,6 +405,9 @@ extern "C" int avsi_frontend_f32(const avsi_frontend_args* args, void* stream) {
     if (a.num_bins <= 0 || a.num_bins > a.nfft / 2 + 1) return AVSI_ERR_INVALID_ARG;
     if ((a.mean == nullptr) != (a.stdev == nullptr)) return AVSI_ERR_INVALID_ARG;
     if (a.out_feat && a.feat_cols < a.num_bins) return AVSI_ERR_INVALID_ARG;
+    // complex bins are stored as 8-byte pairs
+    if (a.out_stft && (((a.stft_stride_b | a.stft_stride_t) & 1) || (reinterpret_cast<uintptr_t>(a.out_stft) & 7)))
+        return AVSI_ERR_INVALID_ARG;
     if (a.out_logmel) {
         if (a.num_mel <= 0 || !a.mel_start || !a.mel_len || !a.mel_w || a.mel_w_stride <= 0) return AVSI_ERR_INVALID_ARG;
     }
@@ -336,28 +416,48 @@ extern "C" int avsi_frontend_f32(const avsi_frontend_args* args, void* stream) {
     const int nb_need = (a.frame_len + 31) / 32;
     const int nb = nb_need <= 8 ? 8 : (nb_need <= 12 ? 12 : 16);  // template instance actually launched
     const int seg = (int)avsi_round_up((int64_t)(FR - 1) * a.hop + 32 * nb, 4);
-    const size_t lds = (size_t)seg * 4 + (size_t)FR * ZSTRIDE * 8 + (a.out_logmel ? (size_t)FR * PSTRIDE * 4 : 0);
+    const size_t lds = (size_t)(seg + 4) * 4 + (size_t)FR * ZSTRIDE * 8 + (a.out_logmel ? (size_t)FR * PSTRIDE * 4 : 0);
     if (lds > 160 * 1024 || seg > 8 * TPB * 4) return AVSI_ERR_UNSUPPORTED;  // staging registers cover 8192 samples
     const int tiles_per_utt = (int)avsi_ceil_div(a.num_frames, FR);
     const int64_t n_tiles64 = (int64_t)a.batch * tiles_per_utt;
     if (n_tiles64 > INT32_MAX) return AVSI_ERR_UNSUPPORTED;
     const int n_tiles = (int)n_tiles64;
-    // resident workgroups per CU: two by registers (256 VGPRs at 256 threads), fewer if the LDS tile is large
-    const int wg_per_cu = (int)(156 * 1024 / lds) > 2 ? 2 : ((int)(156 * 1024 / lds) < 1 ? 1 : (int)(156 * 1024 / lds));
+    // Resident workgroups per CU: TWO.  The model specialisation needs 165 VGPRs and would fit three, but three are
+    // slower (1.97 vs 1.87 ms at 8192 utterances): with the serialised waits gone the kernel moves 4.3 TB/s of real
+    // traffic (two outputs + mask + samples), and a third workgroup per CU only adds concurrent streams.
+    // AVSI_FE_OCC=3: diagnostics.
+    const bool small = seg <= 4 * TPB * 4;
+    // the inpainter's own call (see the MODEL template flag)
+    const bool model = small && step == 1 && a.num_bins == 257 && a.out_spec && a.out_feat && a.mask && a.mean && !a.out_stft &&
+                       !a.out_logmel && a.spec_power == 1.f && a.log_spec && a.feat_cols >= 257 && a.feat_cols <= 256 + 64;
+    const char* env_occ = getenv("AVSI_FE_OCC");
+    const int occ = (model && nb == 12 && env_occ && atoi(env_occ) == 3) ? 3 : 2;
+    const int by_lds = (int)(156 * 1024 / (lds + 4352));       // + the static constant tables
+    const int wg_per_cu = by_lds > occ ? occ : (by_lds < 1 ? 1 : by_lds);
     const int grid = n_tiles < AVSI_NUM_CU * wg_per_cu ? n_tiles : AVSI_NUM_CU * wg_per_cu;
     const hipStream_t st = (hipStream_t)stream;
     avsi_clear_error();
 
-#define AVSI_FE_LAUNCH(NBV)                                                                                   \
-    do {                                                                                                      \
-        if (lds > 64 * 1024)                                                                                  \
-            (void)hipFuncSetAttribute((const void*)frontend_kernel<NBV>, hipFuncAttributeMaxDynamicSharedMemorySize, \
-                                      (int)lds);                                                              \
-        hipLaunchKernelGGL(frontend_kernel<NBV>, dim3(grid), dim3(TPB), lds, st, a, tiles_per_utt, n_tiles, seg, step); \
+#define AVSI_FE_LAUNCH1(NBV, WRV, OCCV, S1V, MDV)                                                                               \
+    do {                                                                                                               \
+        if (lds > 64 * 1024)                                                                                           \
+            (void)hipFuncSetAttribute((const void*)frontend_kernel<NBV, WRV, OCCV, S1V, MDV>,                                \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                           \
+        hipLaunchKernelGGL((frontend_kernel<NBV, WRV, OCCV, S1V, MDV>), dim3(grid), dim3(TPB), lds, st, a, tiles_per_utt,    \
+                           n_tiles, seg, step);                                                                        \
+    } while (0)
+#define AVSI_FE_LAUNCH(NBV)                   \
+    do {                                      \
+        if (model && occ == 3) AVSI_FE_LAUNCH1(NBV, 4, 3, true, true); \
+        else if (model) AVSI_FE_LAUNCH1(NBV, 4, 2, true, true); \
+        else if (small && step == 1) AVSI_FE_LAUNCH1(NBV, 4, 2, true, false); \
+        else if (small) AVSI_FE_LAUNCH1(NBV, 4, 2, false, false); \
+        else AVSI_FE_LAUNCH1(NBV, 8, 2, false, false);      \
     } while (0)
     if (nb == 8) AVSI_FE_LAUNCH(8);
     else if (nb == 12) AVSI_FE_LAUNCH(12);
     else AVSI_FE_LAUNCH(16);
 #undef AVSI_FE_LAUNCH
+#undef AVSI_FE_LAUNCH1
     return avsi_launch_status();
 }

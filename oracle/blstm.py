@@ -198,8 +198,10 @@ def model_forward(wav, masks, mean, std, seq_len, params, video=None, input_type
     return out
 
 
-def enhanced_sources(pred, mean, std, target_stft, masks=None, num_samples=48000, dtype=np.float64):
-    """models.py:181-197: exp(pred*std+mean) with the masked (masks given) or oracle phase."""
+def enhanced_sources(pred, mean, std, target_stft, masks=None, num_samples=48000, dtype=np.float64, window_size=24,
+                     step_size=12):
+    """models.py:181-197: exp(pred*std+mean) with the masked (masks given) or oracle phase.  ``window_size`` /
+    ``step_size``: the U-Net's 16 / 8 ms geometry (models.py:664-680 with the App. B9 handling)."""
     mag = np.exp(pred * np.asarray(std, dtype=dtype) + np.asarray(mean, dtype=dtype))
     if masks is None:
         phase = np.angle(target_stft)
@@ -213,7 +215,8 @@ def enhanced_sources(pred, mean, std, target_stft, masks=None, num_samples=48000
         m = np.asarray(masks, dtype=dtype)
         zero = np.zeros((), dtype=dtype)
         phase = np.arctan2(a * zero + b * m, a * m - b * zero)
-    return frontend.get_sources(mag, phase, num_samples=num_samples, dtype=dtype)
+    return frontend.get_sources(mag, phase, num_samples=num_samples, window_size=window_size, step_size=step_size,
+                                dtype=dtype)
 
 
 # --------------------------------------------------------------------------------------

@@ -114,9 +114,12 @@ def test_bn_act_and_pool_kernels(mods):
     np.testing.assert_array_equal(dxp[:, :C].cpu().view(B, H, W, C).permute(0, 3, 1, 2).numpy(), xt.grad.numpy())
 
 
-def test_unet_forward_backward_matches_oracle(mods):
+@pytest.mark.parametrize("N", [16384, 8192])
+def test_unet_forward_backward_matches_oracle(mods, N):
+    """N = 16384 is the reference's own size (scripts/config/unet.config:6): 128 frames x 128 bins (config 5);
+    8192 adds a non-square map."""
     models, ops = mods
-    B, N = 2, 8192                       # 64 frames x 128 bins (the reference uses 16384 -> 128 x 128)
+    B = 2
     wav, masks, mean, std, T, _ = _inputs(B, N, 2)
     seq = np.array([T, T - 3])
     params = OU.init_params(3)
@@ -148,7 +151,8 @@ def test_unet_forward_backward_matches_oracle(mods):
         if name.endswith('/b') and (name[:-2] + '/bn/gamma') in params:
             assert np.abs(g).max() < 1e-6          # a bias in front of batch norm has zero gradient
             continue
-        assert np.abs(g - r).max() <= 5e-3 * scale, (name, np.abs(g - r).max(), scale)
+        # 128 x 128 maps: the batch-norm gradients are sums of 32768 signed L1 terms per channel in float32
+        assert np.abs(g - r).max() <= (1e-2 if N == 16384 else 5e-3) * scale, (name, np.abs(g - r).max(), scale)
     # three Adam steps reduce the loss and track the oracle's trajectory
     losses = []
     for _ in range(3):
@@ -156,8 +160,18 @@ def test_unet_forward_backward_matches_oracle(mods):
         losses.append(float(m.loss))
         m.train_op
     assert losses[2] < losses[0]
-    wavs = m.enhanced_sources_oracle_phase
-    assert wavs.shape == (B, N) and torch.isfinite(wavs).all()
+    # waveforms (models.py:664-680; 16 / 8 ms inverse STFT, fft length 256, the 129th bin zero) from the GPU's own
+    # prediction, masked and oracle phase, against the oracle's restatement of the same ops
+    from oracle import blstm as OB
+    m.feed(sequence_lengths=seq, target_sources=wav, masks=masks)
+    pred = m.prediction.cpu().numpy().astype(np.float64)
+    for oracle_phase in (True, False):
+        got = (m.enhanced_sources_oracle_phase if oracle_phase else m.enhanced_sources).cpu().numpy()
+        ref_w = OB.enhanced_sources(pred, mean, std, st, None if oracle_phase else masks, num_samples=N, window_size=16,
+                                    step_size=8)
+        assert got.shape == ref_w.shape == (B, N)
+        assert np.sqrt(np.mean((got - ref_w) ** 2)) < 1e-4 * np.abs(ref_w).max()
+        assert np.abs(got - ref_w).max() < 1e-3 * np.abs(ref_w).max()
 
 
 @pytest.mark.parametrize("c0,c1,k,cout,B,H,W", [(16, 0, 5, 32, 2, 12, 10), (32, 64, 3, 32, 3, 8, 16), (128, 128, 3, 128, 1, 4, 6),
