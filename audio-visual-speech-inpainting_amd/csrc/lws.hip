@@ -231,15 +231,56 @@ __device__ __forceinline__ float wave_max(float v) {
     return v;
 }
 
+// LDS of one wave (= one pipeline stage): its own ring of rows, partial sums and magnitudes
 template <int U>
-__global__ __launch_bounds__(64) void lws_sweeps_kernel(float2* __restrict__ spec, int B, int M, const LwsWeights W,
-                                                        const LwsSchedule sched) {
-    __shared__ float2 s_row[U][3][RS];   // ring of spectrogram rows m-1, m, m+1 with mirror images: entry j <-> bin j - LMAX
-    __shared__ float2 s_p[U][PS];        // phase-1 partial sums
-    __shared__ float s_amp[U][PS];       // magnitudes of row m
-    const int lane = threadIdx.x;
+struct LwsWaveLds {
+    float2 row[U][3][RS];   // ring of spectrogram rows m-1, m, m+1 with mirror images: entry j <-> bin j - LMAX
+    float2 p[U][PS];        // phase-1 partial sums
+    float amp[U][PS];       // magnitudes of row m
+};
+
+// wave-local ordering point: LDS accesses of one wave execute in order, so lanes exchanging data through LDS only
+// need the compiler not to reorder (and the counters drained before data another lane wrote is read)
+__device__ __forceinline__ void wave_sync() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+}
+// rows are handed from one wave (sweep s - 1) to the next (sweep s) through global memory: device-scope accesses,
+// i.e. never served from / parked in this CU's L1
+__device__ __forceinline__ float2 row_load(const float2* p) {
+    const unsigned* q = reinterpret_cast<const unsigned*>(p);
+    const unsigned a = __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned b = __hip_atomic_load(q + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return make_float2(__builtin_bit_cast(float, a), __builtin_bit_cast(float, b));
+}
+__device__ __forceinline__ void row_store(float2* p, float2 v) {
+    unsigned* q = reinterpret_cast<unsigned*>(p);
+    __hip_atomic_store(q, __builtin_bit_cast(unsigned, v.x), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(q + 1, __builtin_bit_cast(unsigned, v.y), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// NW waves per workgroup = NW sweeps of the same U utterances in flight, as a pipeline: wave w runs sweeps w, w + NW,
+// ...; sweep s may work on row m once sweep s - 1 has finished rows m + 1 and m + 2 (the rows it reads ahead), which
+// is exactly the raster-order dependence -- the result is bit-identical to running the sweeps one after the other.
+// Progress is a per-sweep row counter in LDS; rows travel through global memory (they stay in L2).  At small batches
+// the sweeps of ONE utterance thus run on up to 16 waves instead of one (0.84 s -> ~60 ms per utterance); large
+// batches use NW = 1 with several utterances per wave.
+template <int U, int NW>
+__global__ __launch_bounds__(64 * NW) void lws_sweeps_kernel(float2* __restrict__ spec, int B, int M, const LwsWeights W,
+                                                             const LwsSchedule sched, int* __restrict__ status) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    volatile int* done = reinterpret_cast<volatile int*>(smem);                 // [MAX_SWEEPS] rows finished by sweep s
+    const int wv = threadIdx.x >> 6;
+    LwsWaveLds<U>& L = *reinterpret_cast<LwsWaveLds<U>*>(smem + MAX_SWEEPS * 4 + (size_t)wv * sizeof(LwsWaveLds<U>));
+    auto& s_row = L.row;
+    auto& s_p = L.p;
+    auto& s_amp = L.amp;
+    const int lane = threadIdx.x & 63;
     const int b0 = blockIdx.x * U;
     const int nu = min(U, B - b0);
+    for (int i = threadIdx.x; i < MAX_SWEEPS; i += 64 * NW) done[i] = 0;
+    __syncthreads();
+    bool dead = false;       // a bounded wait gave up: stop waiting (results invalid, status word set), but finish
 
     // per-lane taps: bin k = lane + 64 i has (k + p) mod 64 = (lane + p) mod 64 for every i, and the phase factor
     // exp(-2 pi j (k + p) q R / N) has period 64 in k + p (host checks 64 R / N integer)
@@ -257,6 +298,7 @@ __global__ __launch_bounds__(64) void lws_sweeps_kernel(float2* __restrict__ spe
 
     // mean and max magnitude per utterance (thresholds are relative to the mean; a sweep whose threshold is above
     // the max touches nothing)
+    // (every wave of the workgroup computes them from the untouched input, before any sweep starts: barrier below)
     float mean_u[U], max_u[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
@@ -272,6 +314,26 @@ __global__ __launch_bounds__(64) void lws_sweeps_kernel(float2* __restrict__ spe
         mean_u[u] = wave_sum(sum) / (float)(M * KB);
         max_u[u] = wave_max(mx);
     }
+    __syncthreads();
+
+    // wait until sweep s - 1 has finished `need` rows (bounded: see `dead`)
+    auto wait_rows = [&](int s, int need) {
+        if (s == 0 || dead) return;
+        need = need < M ? need : M;
+        int spins = 0;
+        while (done[s - 1] < need) {
+            __builtin_amdgcn_s_sleep(8);
+            if (++spins > (1 << 22)) {
+                dead = true;
+                if (lane == 0 && status) atomicOr(status, 1);
+                break;
+            }
+        }
+    };
+    auto publish = [&](int s, int rows) {      // after every global store of those rows has completed
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (lane == 0) done[s] = rows;
+    };
 
     auto load_row = [&](int u, int m, float2 (&r)[5]) {      // global -> registers (zeros outside the spectrogram)
         const bool ok = u < nu && m >= 0 && m < M;
@@ -279,7 +341,7 @@ __global__ __launch_bounds__(64) void lws_sweeps_kernel(float2* __restrict__ spe
 #pragma unroll
         for (int i = 0; i < 5; ++i) {
             const int k = lane + 64 * i;
-            r[i] = (ok && k < KB) ? src[k] : make_float2(0.f, 0.f);
+            r[i] = (ok && k < KB) ? row_load(src + k) : make_float2(0.f, 0.f);
         }
     };
     auto store_row = [&](int u, int slot, const float2 (&r)[5]) {      // registers -> LDS row (bins only)
@@ -297,7 +359,7 @@ __global__ __launch_bounds__(64) void lws_sweeps_kernel(float2* __restrict__ spe
         }
     };
 
-    for (int sw = 0; sw < sched.n; ++sw) {
+    for (int sw = wv; sw < sched.n; sw += NW) {
         float thr[U];
         bool any_u = false;
 #pragma unroll
@@ -305,11 +367,16 @@ __global__ __launch_bounds__(64) void lws_sweeps_kernel(float2* __restrict__ spe
             thr[u] = sched.rel[sw] * mean_u[u];
             any_u |= (u < nu) && (max_u[u] > thr[u]);
         }
-        if (!any_u) continue;       // wave-uniform
+        if (!any_u) {               // wave-uniform: this sweep touches nothing -- it is done when its predecessor is
+            wait_rows(sw, M);
+            publish(sw, M);
+            continue;
+        }
         const bool past_only = sched.past_only[sw] != 0;
 
         // ring: slot (m + 3) % 3 holds row m
-        __syncthreads();
+        wait_rows(sw, 2);
+        wave_sync();
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             float2 r[5];
@@ -320,18 +387,19 @@ __global__ __launch_bounds__(64) void lws_sweeps_kernel(float2* __restrict__ spe
             load_row(u, 1, r);
             store_row(u, 1, r);
         }
-        __syncthreads();
+        wave_sync();
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             mirror_row(u, 0);
             mirror_row(u, 1);
             mirror_row(u, 2);
         }
-        __syncthreads();
+        wave_sync();
 
         for (int m = 0; m < M; ++m) {
             const int sc = m % 3, sp_ = (m + 2) % 3, sn_ = (m + 1) % 3;   // cur, prev, next
-            // prefetch row m + 2 (lands in the slot of row m - 1 after this frame)
+            // prefetch row m + 2 (lands in the slot of row m - 1 after this frame): final once sweep sw - 1 is past it
+            wait_rows(sw, m + 3);
             float2 pre[U][5];
 #pragma unroll
             for (int u = 0; u < U; ++u) load_row(u, m + 2, pre[u]);
@@ -380,7 +448,7 @@ __global__ __launch_bounds__(64) void lws_sweeps_kernel(float2* __restrict__ spe
                         }
                     }
                 }
-                __syncthreads();
+                wave_sync();
                 if (past_only) {
                     // "no future" pass: rows q < 0 only, no dependence inside the frame
 #pragma unroll
@@ -435,12 +503,18 @@ __global__ __launch_bounds__(64) void lws_sweeps_kernel(float2* __restrict__ spe
                     for (int k = 0; k < LMAX; ++k) edge_bin(k);
                     float2 s1 = row[LMAX - 1 + LMAX], s2 = row[LMAX - 2 + LMAX], s3 = row[LMAX - 3 + LMAX],
                            s4 = row[LMAX - 4 + LMAX], s5 = row[LMAX - 5 + LMAX];
-                    float2 pn = s_p[u][LMAX], on = row[LMAX + LMAX];
-                    float an = s_amp[u][LMAX];
+                    // Straight-line body (the store is unconditional: an inactive bin writes its old value back), operands
+                    // of the next TWO bins already requested: the loop-carried chain is five complex MACs, a reciprocal
+                    // square root and two multiplies, with no LDS round trip on it.
+                    float2 p0 = s_p[u][LMAX], o0 = row[LMAX + LMAX], p1 = s_p[u][LMAX + 1], o1 = row[LMAX + 1 + LMAX];
+                    float a0 = s_amp[u][LMAX], a1 = s_amp[u][LMAX + 1];
+#pragma unroll 2
                     for (int k = LMAX; k <= 256 - LMAX - 1; ++k) {
-                        const float2 pk = pn, old = on;
-                        const float a = an;
-                        pn = s_p[u][k + 1], on = row[k + 1 + LMAX], an = s_amp[u][k + 1];    // next bin's operands, off the chain
+                        const float2 pk = p0, old = o0;
+                        const float a = a0;
+                        p0 = p1, o0 = o1, a0 = a1;
+                        p1 = s_p[u][k + 2], o1 = row[k + 2 + LMAX], a1 = s_amp[u][k + 2];    // <= 258: inside the padded rows
+                        // the four older taps first: only the last MAC waits for the bin just finished
                         float2 t = cmadd(pk, c5, s5);
                         t = cmadd(t, c4, s4);
                         t = cmadd(t, c3, s3);
@@ -450,12 +524,12 @@ __global__ __launch_bounds__(64) void lws_sweeps_kernel(float2* __restrict__ spe
                         const bool upd = (a > thu) && (n2 > 0.f);
                         const float sc_ = a * rsqrtf(n2);
                         const float2 v = upd ? make_float2(t.x * sc_, t.y * sc_) : old;
-                        if (upd) row[k + LMAX] = v;
+                        row[k + LMAX] = v;
                         s5 = s4, s4 = s3, s3 = s2, s2 = s1, s1 = v;
                     }
                     for (int k = 256 - LMAX; k <= 256; ++k) edge_bin(k);
                 }
-                __syncthreads();
+                wave_sync();
                 // refresh the mirror images of row m (it becomes row m - 1 of the next frame) and write it back
 #pragma unroll
                 for (int u = 0; u < U; ++u) mirror_row(u, sc);
@@ -466,19 +540,20 @@ __global__ __launch_bounds__(64) void lws_sweeps_kernel(float2* __restrict__ spe
 #pragma unroll
                         for (int i = 0; i < 5; ++i) {
                             const int k = lane + 64 * i;
-                            if (k < KB) dst[k] = s_row[u][sc][k + LMAX];
+                            if (k < KB) row_store(dst + k, s_row[u][sc][k + LMAX]);
                         }
                     }
                 }
             }
-            __syncthreads();
+            wave_sync();
             // row m + 2 replaces row m - 1
 #pragma unroll
             for (int u = 0; u < U; ++u) store_row(u, sp_, pre[u]);
-            __syncthreads();
+            wave_sync();
 #pragma unroll
             for (int u = 0; u < U; ++u) mirror_row(u, sp_);
-            __syncthreads();
+            wave_sync();
+            publish(sw, m + 1);
         }
     }
 }
@@ -537,7 +612,7 @@ extern "C" int avsi_lws_stitch_f32(float* spec, const float* ref, const float* m
 extern "C" int avsi_lws_run_f32(float* spec, int batch, int num_frames, int frame_len, int hop, int nfft, int L,
                                 int nofuture_iterations, float nofuture_alpha, int online_iterations, float online_alpha,
                                 int batch_iterations, float batch_alpha, float batch_beta, float batch_gamma,
-                                int utterances_per_wave, void* stream) {
+                                int utterances_per_wave, int waves_per_group, int* status, void* stream) {
     if (!spec || batch <= 0 || num_frames <= 0 || L < 1 || nofuture_iterations < 0 || online_iterations < 0 ||
         batch_iterations < 0)
         return AVSI_ERR_INVALID_ARG;
@@ -554,21 +629,32 @@ extern "C" int avsi_lws_run_f32(float* spec, int batch, int num_frames, int fram
         S.rel[S.n] = (float)(batch_alpha * exp(-(double)batch_beta * pow((double)i, (double)batch_gamma))), S.past_only[S.n++] = 0;
     for (int i = S.n; i < MAX_SWEEPS; ++i) S.rel[i] = 0.f, S.past_only[i] = 0;
     if (S.n == 0) return AVSI_OK;
-    // utterances per wave: 4 fills the recurrence lanes four-fold at 38 KB of LDS per wave (4 waves per CU); small
-    // batches take fewer so that the waves spread over the chip
-    int U = utterances_per_wave;
+    // Shape of the launch: U utterances per wave (lane u < U runs the recurrence of utterance u), NW waves per
+    // workgroup (NW sweeps of those utterances in flight as a pipeline).  Small batches want their sweeps spread over
+    // waves (latency: 0.84 s per utterance on one wave); large batches fill the chip with utterances instead.
+    int U = utterances_per_wave, NW = waves_per_group;
     if (U == 0) U = batch >= 4 * 4 * AVSI_NUM_CU ? 4 : (batch >= 2 * 4 * AVSI_NUM_CU ? 2 : 1);
+    if (NW == 0) NW = (U > 1 || batch > 8 * AVSI_NUM_CU) ? 1 : (batch > 2 * AVSI_NUM_CU ? 4 : (batch > AVSI_NUM_CU ? 8 : 16));
+    if (status && hipMemsetAsync(status, 0, sizeof(int), (hipStream_t)stream) != hipSuccess) return AVSI_ERR_LAUNCH;
     avsi_clear_error();
     float2* sp = reinterpret_cast<float2*>(spec);
     const hipStream_t st = (hipStream_t)stream;
-    if (U == 4)
-        hipLaunchKernelGGL((lws_sweeps_kernel<4>), dim3((batch + 3) / 4), dim3(64), 0, st, sp, batch, num_frames, W, S);
-    else if (U == 2)
-        hipLaunchKernelGGL((lws_sweeps_kernel<2>), dim3((batch + 1) / 2), dim3(64), 0, st, sp, batch, num_frames, W, S);
-    else if (U == 1)
-        hipLaunchKernelGGL((lws_sweeps_kernel<1>), dim3(batch), dim3(64), 0, st, sp, batch, num_frames, W, S);
-    else
-        return AVSI_ERR_INVALID_ARG;
+#define AVSI_LWS_LAUNCH(UV, NWV)                                                                                          \
+    do {                                                                                                                   \
+        const size_t lds = MAX_SWEEPS * 4 + (size_t)(NWV) * sizeof(LwsWaveLds<UV>);                                        \
+        (void)hipFuncSetAttribute((const void*)lws_sweeps_kernel<UV, NWV>, hipFuncAttributeMaxDynamicSharedMemorySize,      \
+                                  (int)lds);                                                                               \
+        hipLaunchKernelGGL((lws_sweeps_kernel<UV, NWV>), dim3((batch + (UV) - 1) / (UV)), dim3(64 * (NWV)), lds, st, sp, batch, \
+                           num_frames, W, S, status);                                                                      \
+    } while (0)
+    if (U == 4 && NW == 1) AVSI_LWS_LAUNCH(4, 1);
+    else if (U == 2 && NW == 1) AVSI_LWS_LAUNCH(2, 1);
+    else if (U == 1 && NW == 1) AVSI_LWS_LAUNCH(1, 1);
+    else if (U == 1 && NW == 4) AVSI_LWS_LAUNCH(1, 4);
+    else if (U == 1 && NW == 8) AVSI_LWS_LAUNCH(1, 8);
+    else if (U == 1 && NW == 16) AVSI_LWS_LAUNCH(1, 16);
+    else return AVSI_ERR_INVALID_ARG;
+#undef AVSI_LWS_LAUNCH
     return avsi_launch_status();
 }
 

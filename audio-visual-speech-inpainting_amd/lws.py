@@ -42,7 +42,7 @@ class lws(object):
 
     def __init__(self, awin_or_fsize, fshift, L=5, swin=None, look_ahead=3, nofuture_iterations=0, nofuture_alpha=1,
                  online_iterations=0, online_alpha=1, batch_iterations=100, batch_alpha=100, batch_beta=0.1, batch_gamma=1,
-                 symmetric_win=True, mode=None, fftsize=None, utterances_per_wave=0):
+                 symmetric_win=True, mode=None, fftsize=None, utterances_per_wave=0, waves_per_group=0):
         if not isinstance(awin_or_fsize, (int, np.integer)) or swin is not None or not symmetric_win:
             raise _lib.AvsiError("lws: only the window-length form with the default sqrt-Hann windows is implemented")
         if mode == 'speech':
@@ -60,7 +60,8 @@ class lws(object):
         self.online_iterations, self.online_alpha = int(online_iterations), float(online_alpha)
         self.batch_iterations = int(batch_iterations)
         self.batch_alpha, self.batch_beta, self.batch_gamma = float(batch_alpha), float(batch_beta), float(batch_gamma)
-        self.utterances_per_wave = int(utterances_per_wave)
+        self.utterances_per_wave, self.waves_per_group = int(utterances_per_wave), int(waves_per_group)
+        self._status = None
         if _lib.lib().avsi_lws_table_floats(self.fsize, self.fshift, self.fftsize) == 0:
             raise _lib.AvsiError("unsupported LWS geometry: window %d, shift %d, fft %d" % (self.fsize, self.fshift, self.fftsize))
 
@@ -103,16 +104,25 @@ class lws(object):
         """complex spectrogram (magnitudes kept, phases = starting point) -> complex spectrogram."""
         s, host, single = self._as_spec(S)
         self._run(s)
+        self.check()
         out = torch.view_as_complex(s)
         out = out[0] if single else out
         return out.cpu().numpy() if host else out
 
     def _run(self, s):
         B, M = s.shape[0], s.shape[1]
+        if self._status is None or self._status.device != s.device:
+            self._status = torch.zeros(1, dtype=torch.int32, device=s.device)
         _lib.check(_lib.lib().avsi_lws_run_f32(_lib.ptr(s), B, M, self.fsize, self.fshift, self.fftsize, self.L,
                                                self.nofuture_iterations, self.nofuture_alpha, self.online_iterations,
                                                self.online_alpha, self.batch_iterations, self.batch_alpha, self.batch_beta,
-                                               self.batch_gamma, self.utterances_per_wave, _lib.stream_ptr()), "avsi_lws_run_f32")
+                                               self.batch_gamma, self.utterances_per_wave, self.waves_per_group,
+                                               _lib.ptr(self._status), _lib.stream_ptr()), "avsi_lws_run_f32")
+
+    def check(self):
+        """Raise if a pipeline stage of the last run gave up waiting for its predecessor (synchronises)."""
+        if self._status is not None and int(self._status.item()) != 0:
+            raise _lib.AvsiError("LWS sweep pipeline timed out waiting for a predecessor stage; results are invalid")
 
     def istft(self, S, num_samples=None):
         """complex [M, F] or [B, M, F] -> waveform (front / back padding removed; ``num_samples`` truncates)."""
@@ -159,4 +169,6 @@ class lws(object):
         # rec_mag * exp(1j * (ang_spec + rec_ang * (1 - mask_adj)))
         _lib.check(L.avsi_lws_stitch_f32(_lib.ptr(rec), _lib.ptr(init), _lib.ptr(m), msb, m.stride(1), m.shape[1], m.shape[2],
                                          B, M, self.fftsize, _lib.stream_ptr()), "avsi_lws_stitch_f32")
-        return self._istft(rec, num_samples)
+        out = self._istft(rec, num_samples)
+        self.check()
+        return out

@@ -308,7 +308,10 @@ int avsi_istft_f32(const avsi_istft_args* args, void* stream);
  *                        mask_adj = mask [B][mask_frames][mask_bins] (element strides), zero outside it
  *   avsi_lws_run_f32     lws.run_lws (inference.py:148): nofuture / online / batch sweeps in place; thresholds
  *                        alpha exp(-beta j^gamma) relative to the mean magnitude of each utterance;
- *                        utterances_per_wave 0 = chosen from the batch (1, 2 or 4)
+ *                        utterances_per_wave (1, 2, 4) x waves_per_group (1, 4, 8, 16; > 1 only with one utterance per
+ *                        wave): the sweeps of an utterance run as a pipeline over that many waves -- same results --
+ *                        0 = chosen from the batch; status (device int32, may be null): non-zero after the stream
+ *                        has drained = a pipeline stage stopped waiting for its predecessor, outputs invalid
  *   avsi_lws_istft_f32   lws.istft  (inference.py:153): out [B][out_samples], out_samples <=
  *                        (num_frames - 1) hop + nfft - 2 (nfft - hop); workspace from avsi_lws_istft_workspace_bytes
  * ------------------------------------------------------------------------------------ */
@@ -322,7 +325,7 @@ int avsi_lws_stitch_f32(float* spec, const float* ref, const float* mask, int64_
 int avsi_lws_run_f32(float* spec, int batch, int num_frames, int frame_len, int hop, int nfft, int L,
                      int nofuture_iterations, float nofuture_alpha, int online_iterations, float online_alpha,
                      int batch_iterations, float batch_alpha, float batch_beta, float batch_gamma,
-                     int utterances_per_wave, void* stream);
+                     int utterances_per_wave, int waves_per_group, int* status, void* stream);
 size_t avsi_lws_istft_workspace_bytes(int batch, int num_frames, int nfft);
 int avsi_lws_istft_f32(const float* spec, int batch, int num_frames, const float* table, int hop, int nfft, float* out,
                        int64_t out_stride, int out_samples, void* workspace, size_t workspace_bytes, void* stream);

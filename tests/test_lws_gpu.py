@@ -65,12 +65,17 @@ def test_run_lws_matches_oracle(L, U):
         assert o.inconsistency(got[b].astype(np.complex128)) < 1.05 * o.inconsistency(ref[b]) + 1e-6
 
 
-def test_utterances_per_wave_do_not_change_the_result(L):
+def test_launch_shape_does_not_change_the_result(L):
+    """Utterances per wave (1, 2, 4) and waves per group (the sweeps of an utterance pipelined over 4, 8 or 16 waves,
+    each sweep trailing its predecessor by two rows): the raster-order dependences are kept exactly, so the results
+    are bit-identical to one wave running the sweeps one after the other."""
     kw = dict(fftsize=512, mode='speech')
     o = OL.LWS(384, 192, **kw)
     S0 = np.stack([np.abs(o.stft(_speechlike(4800, 30 + i))) for i in range(5)]).astype(np.complex64)
-    outs = [L.lws(384, 192, utterances_per_wave=U, **kw).run_lws(S0) for U in (1, 2, 4)]
-    assert np.array_equal(outs[0], outs[1]) and np.array_equal(outs[0], outs[2])
+    ref = L.lws(384, 192, utterances_per_wave=1, waves_per_group=1, **kw).run_lws(S0)
+    for U, NW in ((2, 1), (4, 1), (1, 4), (1, 8), (1, 16)):
+        out = L.lws(384, 192, utterances_per_wave=U, waves_per_group=NW, **kw).run_lws(S0)
+        assert np.array_equal(ref, out), (U, NW)
 
 
 def test_refine_enhanced_matches_oracle(L):
