@@ -56,6 +56,10 @@ __global__ void istft_tables_kernel(float* tab, int frame_len, int hop) {
     }
 }
 
+// MODE / HAS_MASK are compile-time so that the 16 frames' loads of a tile are straight-line code: with the mode
+// tested at run time each frame's loads sat in their own blocks, closed by s_waitcnt vmcnt(0) -- sixteen memory
+// latencies in a row per tile.
+template <int MODE, bool HAS_MASK>
 __global__ __launch_bounds__(TPB) void istft_kernel(const avsi_istft_args a, const int tiles_per_utt, const int n_tiles,
                                                     const int n_hops, const int step) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -77,9 +81,9 @@ __global__ __launch_bounds__(TPB) void istft_kernel(const avsi_istft_args a, con
     // one spectrum element from the raw loaded values (r0 .. r3 as loaded by `fetch` below)
     auto make_x = [&](int kk, float r0, float r1, float r2, float r3, float mean_k, float std_k) -> cf {
         cf x{0.f, 0.f};
-        if (a.mode == 0) {          // complex spectrogram, interleaved
+        if (MODE == 0) {          // complex spectrogram, interleaved
             x = {r0, r1};
-        } else if (a.mode == 1) {   // magnitude + phase planes
+        } else if (MODE == 1) {   // magnitude + phase planes
             float sn, cs;
             __sincosf(r1, &sn, &cs);
             x = {r0 * cs, r0 * sn};
@@ -87,7 +91,7 @@ __global__ __launch_bounds__(TPB) void istft_kernel(const avsi_istft_args a, con
             float m = r0;
             if (have_norm) m = m * std_k + mean_k;
             m = __expf(m);
-            if (a.in2) {
+            if (HAS_MASK) {
                 // models.py:186 casts the mask to complex64 and takes a FULL complex product
                 // (a + bj)(m + 0j) = (a m - b 0) + (a 0 + b m) j; in a gap the signed zeros
                 // decide tf.angle = atan2: (-0, +0) -> pi, everything else -> 0.  Kept as is.
@@ -111,15 +115,15 @@ __global__ __launch_bounds__(TPB) void istft_kernel(const avsi_istft_args a, con
     };
     auto fetch = [&](int b, int t, int k, float& r0, float& r1, float& r2, float& r3) {
         const int64_t o = (int64_t)b * a.in_stride_b + (int64_t)t * a.in_stride_t;
-        if (a.mode == 0) {
+        if (MODE == 0) {
             r0 = a.in0[o + 2 * k], r1 = a.in0[o + 2 * k + 1];
-        } else if (a.mode == 1) {
+        } else if (MODE == 1) {
             r0 = a.in0[o + k], r1 = a.in1[o + k];
         } else {
             r0 = a.in0[o + k];
             const int64_t os = (int64_t)b * a.in1_stride_b + (int64_t)t * a.in1_stride_t;
             r1 = a.in1[os + 2 * k], r2 = a.in1[os + 2 * k + 1];
-            if (a.in2) r3 = a.in2[(int64_t)b * a.in2_stride_b + (int64_t)t * a.in2_stride_t + k];
+            if (HAS_MASK) r3 = a.in2[(int64_t)b * a.in2_stride_b + (int64_t)t * a.in2_stride_t + k];
         }
     };
     __syncthreads();
@@ -140,9 +144,13 @@ __global__ __launch_bounds__(TPB) void istft_kernel(const avsi_istft_args a, con
             float r0[FR], r1[FR], r2[FR], r3[FR];
 #pragma unroll
             for (int ff = 0; ff < FR; ++ff) {
+                // BRANCH-FREE: a load inside a per-lane `if` is closed by the compiler with s_waitcnt vmcnt(0) -- the 16
+                // frames were fetched one memory latency after the other.  Out-of-range lanes read element (0, 0)
+                // of the utterance instead; their value is never used (the select below).
                 const int t = t0 + ff;
+                const bool ok = kok && t >= 0 && t < T;
                 r0[ff] = r1[ff] = r2[ff] = 0.f, r3[ff] = 1.f;
-                if (kok && t >= 0 && t < T) fetch(b, t, k, r0[ff], r1[ff], r2[ff], r3[ff]);
+                fetch(b, ok ? t : 0, ok ? k : 0, r0[ff], r1[ff], r2[ff], r3[ff]);
             }
 #pragma unroll
             for (int ff = 0; ff < FR; ++ff) {
@@ -153,7 +161,7 @@ __global__ __launch_bounds__(TPB) void istft_kernel(const avsi_istft_args a, con
                 const int t = t0 + tid, kn = 256 / step;
                 const bool ok = (256 % step == 0) && kn < F && t >= 0 && t < T;
                 float q0 = 0.f, q1 = 0.f, q2 = 0.f, q3 = 1.f;
-                if (ok) fetch(b, t, kn, q0, q1, q2, q3);
+                fetch(b, ok ? t : 0, ok ? kn : 0, q0, q1, q2, q3);
                 s_x[tid * XS + 256] = ok ? make_x(256, q0, q1, q2, q3, have_norm ? a.mean[kn] : 0.f, have_norm ? a.stdev[kn] : 1.f)
                                          : cf{0.f, 0.f};
             }
@@ -263,7 +271,16 @@ extern "C" int avsi_istft_f32(const avsi_istft_args* args, void* stream) {
     const int n_tiles = (int)n_tiles64;
     const int grid = n_tiles < AVSI_NUM_CU * 2 ? n_tiles : AVSI_NUM_CU * 2;
     avsi_clear_error();
-    (void)hipFuncSetAttribute((const void*)istft_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(istft_kernel, dim3(grid), dim3(TPB), lds, (hipStream_t)stream, a, tiles_per_utt, n_tiles, n_hops, step);
+#define AVSI_ISTFT_LAUNCH(MV, HM)                                                                                       \
+    do {                                                                                                                \
+        (void)hipFuncSetAttribute((const void*)istft_kernel<MV, HM>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        hipLaunchKernelGGL((istft_kernel<MV, HM>), dim3(grid), dim3(TPB), lds, (hipStream_t)stream, a, tiles_per_utt, n_tiles, \
+                           n_hops, step);                                                                               \
+    } while (0)
+    if (a.mode == 0) AVSI_ISTFT_LAUNCH(0, false);
+    else if (a.mode == 1) AVSI_ISTFT_LAUNCH(1, false);
+    else if (a.in2) AVSI_ISTFT_LAUNCH(2, true);
+    else AVSI_ISTFT_LAUNCH(2, false);
+#undef AVSI_ISTFT_LAUNCH
     return avsi_launch_status();
 }
