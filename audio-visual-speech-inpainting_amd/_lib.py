@@ -88,6 +88,10 @@ PROTOTYPES = {
     "avsi_unet_workspace_bytes": (c_size_t, [c_int]),
     "avsi_colstats_f32": (c_int, [c_void_p, c_int64, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p, c_size_t,
                                   c_void_p]),
+    "avsi_bn_act_pool_f32": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
+                                     c_void_p, c_void_p, c_void_p]),
+    "avsi_conv2d_thin_relu_pool_f32": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_int,
+                                               c_void_p, c_int, c_void_p]),
     "avsi_bn_act_f32": (c_int, [c_void_p, c_int64, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p,
                                 c_void_p]),
     "avsi_bn_act_bwd_f32": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int,

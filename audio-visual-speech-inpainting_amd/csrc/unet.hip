@@ -88,6 +88,63 @@ __global__ __launch_bounds__(TPB) void im2col4_kernel(const float* __restrict__ 
 // matrix of the 17-channel layer alone is 5 GB at batch 512).  One thread per output pixel, lanes
 // along W; the loops are fully unrolled, so the filter taps are wave-uniform scalar loads and every
 // multiply-add has an SGPR operand.
+// Direct convolution + ReLU + 2x2 max pooling in one pass (the first encoder layer at inference: 1 -> 16 channels
+// 7 x 7, no batch norm, unet_layers.py:6-20 followed by the pooling): one thread per POOLED pixel computes the four
+// outputs of its window and keeps their maximum, so the full-resolution activation (537 MB at batch 512, written
+// and read back twice by the separate activation and pooling passes) never exists.
+template <int K, int COUT>
+__global__ __launch_bounds__(TPB) void direct_conv_relu_pool_kernel(const float* __restrict__ s0, int ld0,
+                                                                    const float* __restrict__ filt, int ldf,
+                                                                    const float* __restrict__ bias, float* __restrict__ out,
+                                                                    int ldo, int B, int H, int W) {
+    constexpr int P = K / 2;
+    const int H2 = H >> 1, W2 = W >> 1;
+    const int64_t n = (int64_t)B * H2 * W2;
+    for (int64_t e = (int64_t)blockIdx.x * TPB + threadIdx.x; e < n; e += (int64_t)gridDim.x * TPB) {
+        const int w2 = (int)(e % W2);
+        const int64_t bh = e / W2;
+        const int h2 = (int)(bh % H2), b = (int)(bh / H2);
+        // the (K + 1) x (K + 1) input patch of the 2 x 2 window, one channel
+        float patch[K + 1][K + 1];
+#pragma unroll
+        for (int dh = 0; dh <= K; ++dh) {
+            const int hh = 2 * h2 + dh - P;
+#pragma unroll
+            for (int dw = 0; dw <= K; ++dw) {
+                const int ww = 2 * w2 + dw - P;
+                const bool ok = hh >= 0 && hh < H && ww >= 0 && ww < W;
+                patch[dh][dw] = s0[ok ? (((int64_t)b * H + hh) * W + ww) * ld0 : 0];
+                patch[dh][dw] = ok ? patch[dh][dw] : 0.f;
+            }
+        }
+        float best[COUT];
+#pragma unroll
+        for (int o = 0; o < COUT; ++o) best[o] = 0.f;          // ReLU: max(0, .)
+#pragma unroll
+        for (int py = 0; py < 2; ++py)
+#pragma unroll
+            for (int px = 0; px < 2; ++px) {
+                float acc[COUT];
+#pragma unroll
+                for (int o = 0; o < COUT; ++o) acc[o] = bias ? bias[o] : 0.f;
+#pragma unroll
+                for (int dh = 0; dh < K; ++dh)
+#pragma unroll
+                    for (int dw = 0; dw < K; ++dw) {
+                        const float xv = patch[py + dh][px + dw];
+                        const float* wt = filt + (int64_t)(dh * K + dw) * ldf;
+#pragma unroll
+                        for (int o = 0; o < COUT; ++o) acc[o] += xv * wt[o];
+                    }
+#pragma unroll
+                for (int o = 0; o < COUT; ++o) best[o] = fmaxf(best[o], acc[o]);
+            }
+        float* op = out + e * ldo;
+#pragma unroll
+        for (int o = 0; o < COUT; o += 4) *reinterpret_cast<float4*>(op + o) = make_float4(best[o], best[o + 1], best[o + 2], best[o + 3]);
+    }
+}
+
 template <int K, int C0, int C1, int COUT>
 __global__ __launch_bounds__(TPB) void direct_conv_kernel(const float* __restrict__ s0, int ld0, const float* __restrict__ s1,
                                                           int ld1, const float* __restrict__ filt, int ldf,
@@ -361,6 +418,8 @@ __device__ __forceinline__ float act_grad(float z, int act) {
 
 // Rows are read whole with 16-byte loads: thread t owns the float4 column group t % (ld / 4) of rows
 // t / (ld / 4), + TPB / (ld / 4), ...; the row-threads of a column group are then summed through LDS.
+// (Tried and dropped: letting the last block to arrive run the final stage -- one launch per layer instead of two.
+// The device-scope fences every block then needs cost more than the second launch: 72 us against 36 + 39.)
 template <int MODE>
 __global__ __launch_bounds__(TPB) void colpair_partial_kernel(const BnArgs a, float* __restrict__ part) {
     __shared__ float red[2][TPB * 4];
@@ -377,8 +436,23 @@ __global__ __launch_bounds__(TPB) void colpair_partial_kernel(const BnArgs a, fl
             const int c = 4 * cq + k;
             if (c < a.C) mu[k] = a.mean[c], rs[k] = a.rstd[c], ga[k] = a.gamma[c], be[k] = a.beta[c];
         }
-    if (rl < rp)
-        for (int64_t r = r0 + rl; r < r1; r += rp) {
+    if (rl < rp) {
+        int64_t r = r0 + rl;
+        if (MODE == 0) {
+            // statistics: four rows per trip, their loads issued together (the sums stay in row order)
+            for (; r + 3 * (int64_t)rp < r1; r += 4 * (int64_t)rp) {
+                float4 v[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const float4*>(a.x + (r + u * (int64_t)rp) * a.ld + 4 * cq);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const float xv[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) s1[k] += xv[k], s2[k] += xv[k] * xv[k];
+                }
+            }
+        }
+        for (; r < r1; r += rp) {
             const float4 xv4 = *reinterpret_cast<const float4*>(a.x + r * a.ld + 4 * cq);
             const float xv[4] = {xv4.x, xv4.y, xv4.z, xv4.w};
             if (MODE == 0) {
@@ -395,6 +469,7 @@ __global__ __launch_bounds__(TPB) void colpair_partial_kernel(const BnArgs a, fl
                 }
             }
         }
+    }
 #pragma unroll
     for (int k = 0; k < 4; ++k) red[0][threadIdx.x * 4 + k] = s1[k], red[1][threadIdx.x * 4 + k] = s2[k];
     __syncthreads();
@@ -455,6 +530,67 @@ __global__ __launch_bounds__(TPB) void bn_act_kernel(const BnArgs a, float* __re
             if (a.act == 3) v = v > 0.f ? v : 0.3f * v;
         }
         y[e] = v;
+    }
+}
+
+__device__ __forceinline__ float bn_act_one(float v, float sc, float sh, int act) {
+    v = fmaf(v, sc, sh);
+    if (act == 1) v = fmaxf(v, 0.f);
+    if (act == 2) v = v > 0.f ? v : 0.2f * v;
+    if (act == 3) v = v > 0.f ? v : 0.3f * v;
+    return v;
+}
+
+// 16-byte form of bn_act_kernel (ld % 4 == 0): thread <-> four channels of one pixel; batch norm folded into one
+// multiply-add per element (scale = gamma rstd, shift = beta - mean scale; padding channels: scale = shift = 0).
+// POOL: thread <-> four channels of one POOLED pixel: the four pixels of its 2 x 2 window are normalised and
+// activated, written to y (when y is given: training keeps the activation for the backward pass) and their
+// maximum to `pooled` -- the separate pooling pass (one more read of the activation) is gone.
+template <bool POOL>
+__global__ __launch_bounds__(TPB) void bn_act4_kernel(const BnArgs a, float* __restrict__ y, float* __restrict__ pooled, int B,
+                                                      int H, int W) {
+    const int q4 = a.ld >> 2;
+    const int64_t pixels = POOL ? (int64_t)B * (H >> 1) * (W >> 1) : a.R;
+    const int64_t n = pixels * q4;
+    for (int64_t e = (int64_t)blockIdx.x * TPB + threadIdx.x; e < n; e += (int64_t)gridDim.x * TPB) {
+        const int cq = (int)(e % q4);
+        const int64_t pix = e / q4;
+        float sc[4], sh[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int c = 4 * cq + k;
+            sc[k] = c < a.C ? 1.f : 0.f, sh[k] = 0.f;
+            if (a.has_bn && c < a.C) {
+                sc[k] = a.gamma[c] * a.rstd[c];
+                sh[k] = a.beta[c] - a.mean[c] * sc[k];
+            }
+        }
+        if (!POOL) {
+            const float4 v = *reinterpret_cast<const float4*>(a.x + pix * a.ld + 4 * cq);
+            *reinterpret_cast<float4*>(y + pix * a.ld + 4 * cq) = make_float4(
+                bn_act_one(v.x, sc[0], sh[0], a.act), bn_act_one(v.y, sc[1], sh[1], a.act), bn_act_one(v.z, sc[2], sh[2], a.act),
+                bn_act_one(v.w, sc[3], sh[3], a.act));
+        } else {
+            const int W2 = W >> 1, H2 = H >> 1;
+            const int w2 = (int)(pix % W2);
+            const int64_t bh = pix / W2;
+            const int h2 = (int)(bh % H2);
+            const int64_t b = bh / H2;
+            const int64_t o00 = ((b * H + 2 * h2) * W + 2 * w2) * a.ld + 4 * cq;
+            const int64_t offs[4] = {0, a.ld, (int64_t)W * a.ld, (int64_t)W * a.ld + a.ld};
+            float4 in[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) in[q] = *reinterpret_cast<const float4*>(a.x + o00 + offs[q]);
+            float4 best;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float4 r = make_float4(bn_act_one(in[q].x, sc[0], sh[0], a.act), bn_act_one(in[q].y, sc[1], sh[1], a.act),
+                                             bn_act_one(in[q].z, sc[2], sh[2], a.act), bn_act_one(in[q].w, sc[3], sh[3], a.act));
+                if (y) *reinterpret_cast<float4*>(y + o00 + offs[q]) = r;
+                best = q == 0 ? r : make_float4(fmaxf(best.x, r.x), fmaxf(best.y, r.y), fmaxf(best.z, r.z), fmaxf(best.w, r.w));
+            }
+            *reinterpret_cast<float4*>(pooled + pix * a.ld + 4 * cq) = best;
+        }
     }
 }
 
@@ -527,7 +663,10 @@ __global__ __launch_bounds__(TPB) void maxpool2_bwd_kernel(const float* __restri
     }
 }
 
-constexpr int MAXPARTS = 256;
+// Row slabs of the column reductions: one workgroup each.  Four per CU for the large activations, four rows in
+// flight per thread (with 256 slabs and one row per pass a block streamed 512 KB through 256 threads' 16-byte loads,
+// one memory latency per pass: 1.3 TB/s on the 134 MB activation of the widest decoder layer).
+constexpr int MAXPARTS = 1024;
 inline int parts_for(int64_t R) {
     int64_t p = avsi_ceil_div(R, 512);
     return (int)(p < 1 ? 1 : (p > MAXPARTS ? MAXPARTS : p));
@@ -687,7 +826,7 @@ extern "C" int avsi_colstats_f32(const float* x, int64_t R, int C, int ld, float
     const int parts = parts_for(R);
     const hipStream_t st = (hipStream_t)stream;
     avsi_clear_error();
-    hipLaunchKernelGGL(colpair_partial_kernel<0>, dim3(1, parts), dim3(TPB), 0, st, a,
+    hipLaunchKernelGGL((colpair_partial_kernel<0>), dim3(1, parts), dim3(TPB), 0, st, a,
                        (float*)workspace);
     hipLaunchKernelGGL(colpair_final_kernel<0>, dim3(C), dim3(64), 0, st,
                        (const float*)workspace, parts, C, R, eps, mean, rstd);
@@ -701,7 +840,37 @@ extern "C" int avsi_bn_act_f32(const float* x, int64_t R, int C, int ld, const f
     if (has_bn && (!rstd || !gamma || !beta)) return AVSI_ERR_INVALID_ARG;
     BnArgs a{x, nullptr, mean, rstd, gamma, beta, R, C, ld, act, has_bn};
     avsi_clear_error();
-    hipLaunchKernelGGL(bn_act_kernel, dim3(grid_for(R * ld)), dim3(TPB), 0, (hipStream_t)stream, a, y);
+    if ((ld & 3) == 0 && ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y)) & 15) == 0)
+        hipLaunchKernelGGL((bn_act4_kernel<false>), dim3(grid_for(R * (ld / 4))), dim3(TPB), 0, (hipStream_t)stream, a, y, nullptr, 0,
+                           0, 0);
+    else
+        hipLaunchKernelGGL(bn_act_kernel, dim3(grid_for(R * ld)), dim3(TPB), 0, (hipStream_t)stream, a, y);
+    return avsi_launch_status();
+}
+
+extern "C" int avsi_bn_act_pool_f32(const float* x, int B, int H, int W, int C, int ld, const float* mean, const float* rstd,
+                                    const float* gamma, const float* beta, int act, float* y, float* pooled, void* stream) {
+    if (!x || !pooled || B <= 0 || H <= 0 || W <= 0 || ((H | W) & 1) || C <= 0 || ld < C || act < 0 || act > 3)
+        return AVSI_ERR_INVALID_ARG;
+    const int has_bn = mean != nullptr;
+    if (has_bn && (!rstd || !gamma || !beta)) return AVSI_ERR_INVALID_ARG;
+    if ((ld & 3) || ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(pooled)) & 15))
+        return AVSI_ERR_UNSUPPORTED;
+    BnArgs a{x, nullptr, mean, rstd, gamma, beta, (int64_t)B * H * W, C, ld, act, has_bn};
+    avsi_clear_error();
+    hipLaunchKernelGGL((bn_act4_kernel<true>), dim3(grid_for((int64_t)B * (H / 2) * (W / 2) * (ld / 4))), dim3(TPB), 0,
+                       (hipStream_t)stream, a, y, pooled, B, H, W);
+    return avsi_launch_status();
+}
+
+extern "C" int avsi_conv2d_thin_relu_pool_f32(const float* src0, int ld0, int B, int H, int W, int k, const float* filter, int ldf,
+                                              const float* bias, int Cout, float* out, int ldo, void* stream) {
+    if (!src0 || !filter || !out || B <= 0 || H <= 0 || W <= 0 || ((H | W) & 1) || ld0 < 1 || ldf < Cout || ldo < Cout)
+        return AVSI_ERR_INVALID_ARG;
+    if (k != 7 || Cout != 16 || (ldo & 3) || (reinterpret_cast<uintptr_t>(out) & 15)) return AVSI_ERR_UNSUPPORTED;
+    avsi_clear_error();
+    hipLaunchKernelGGL((direct_conv_relu_pool_kernel<7, 16>), dim3(grid_for((int64_t)B * (H / 2) * (W / 2))), dim3(TPB), 0,
+                       (hipStream_t)stream, src0, ld0, filter, ldf, bias, out, ldo, B, H, W);
     return avsi_launch_status();
 }
 

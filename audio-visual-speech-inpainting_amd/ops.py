@@ -510,6 +510,23 @@ def colstats(x, C, mean, rstd, eps=1e-3):
                                    _lib.ptr(ws), ws.numel() * 4, _lib.stream_ptr()), "avsi_colstats_f32")
 
 
+def bn_act_pool(x, B, H, W, C, pooled, y=None, mean=None, rstd=None, gamma=None, beta=None, act=0):
+    """act(bn(x)) and its 2 x 2 max pooling in one pass (avsi_bn_act_pool_f32); y = None: inference, the
+    full-resolution activation is not kept."""
+    _lib.check(_lib.lib().avsi_bn_act_pool_f32(_lib.ptr(x), B, H, W, C, x.stride(0), _lib.ptr(mean), _lib.ptr(rstd),
+                                               _lib.ptr(gamma), _lib.ptr(beta), int(act), _lib.ptr(y), _lib.ptr(pooled),
+                                               _lib.stream_ptr()), "avsi_bn_act_pool_f32")
+    return pooled
+
+
+def conv2d_thin_relu_pool(src0, B, H, W, k, filt, bias, out, cout):
+    """7 x 7 one-channel convolution + bias + ReLU + 2 x 2 max pooling (avsi_conv2d_thin_relu_pool_f32)."""
+    _lib.check(_lib.lib().avsi_conv2d_thin_relu_pool_f32(_lib.ptr(src0), src0.stride(0), B, H, W, k, _lib.ptr(filt),
+                                                         filt.stride(0), _lib.ptr(bias), cout, _lib.ptr(out), out.stride(0),
+                                                         _lib.stream_ptr()), "avsi_conv2d_thin_relu_pool_f32")
+    return out
+
+
 def bn_act(x, C, y, mean=None, rstd=None, gamma=None, beta=None, act=0):
     _lib.check(_lib.lib().avsi_bn_act_f32(_lib.ptr(x), x.shape[0], C, x.stride(0), _lib.ptr(mean), _lib.ptr(rstd),
                                           _lib.ptr(gamma), _lib.ptr(beta), int(act), _lib.ptr(y), _lib.stream_ptr()),

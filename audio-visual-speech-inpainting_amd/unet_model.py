@@ -261,9 +261,19 @@ class UNetFConvModel(object):
         return self._cache['net_inputs']
 
     # ------------------------------------------------------------------ network (models.py:582-607)
-    def _conv_fwd(self, name, k, cout, bn, act, src0, c0, src1, c1, B, H, W):
+    def _conv_fwd(self, name, k, cout, bn, act, src0, c0, src1, c1, B, H, W, pool=False):
+        """One layer: convolution, batch statistics, normalisation + activation -- and, for the encoder layers
+        (``pool``), the 2 x 2 max pooling in the same pass as the activation.  A model built for inference
+        (``is_training=False``) keeps nothing it does not need: the pooled layers never write their full-resolution
+        activation, and the first layer (7 x 7, one input channel, no batch norm) is ONE kernel from input to pooled
+        output.  Returns the layer's output (pooled if ``pool``)."""
         v = self.variables
         R, kc, ld = B * H * W, round_up(k * k * (c0 + c1), 4), round_up(cout, 4)
+        keep = bool(self.is_training) or bool(getattr(self, '_keep_for_backward', False))
+        pooled = self._buf(name + '/pool', (B * (H // 2) * (W // 2), ld)) if pool else None
+        if pool and not keep and not bn and act == 1 and (k, c0, c1, cout) == (7, 1, 0, 16):
+            ops.conv2d_thin_relu_pool(src0, B, H, W, k, v.p(name + '/w'), v.p(name + '/b'), pooled, cout)
+            return pooled
         conv = self._buf(name + '/conv', (R, ld))
         if ops.conv2d_supported(c0, c1):
             # implicit GEMM: the operand rows are gathered from the activations by the GEMM's DMA loads
@@ -278,12 +288,15 @@ class UNetFConvModel(object):
         if bn:
             st = (self._buf(name + '/mean', (ld,)), self._buf(name + '/rstd', (ld,)))
             ops.colstats(conv, cout, st[0], st[1])
-        y = self._buf(name + '/act', (R, ld))
-        ops.bn_act(conv, cout, y, *(st or (None, None)), v.p(name + '/bn/gamma') if bn else None,
-                   v.p(name + '/bn/beta') if bn else None, act)
+        bn_args = (*(st or (None, None)), v.p(name + '/bn/gamma') if bn else None, v.p(name + '/bn/beta') if bn else None)
+        y = self._buf(name + '/act', (R, ld)) if (keep or not pool) else None
+        if pool:
+            ops.bn_act_pool(conv, B, H, W, cout, pooled, y, *bn_args, act)
+        else:
+            ops.bn_act(conv, cout, y, *bn_args, act)
         self._cache['saved'][name] = dict(k=k, cout=cout, bn=bn, act=act, src0=src0, c0=c0, src1=src1, c1=c1, B=B, H=H,
                                           W=W, conv=conv, stats=st, y=y, kc=kc, ld=ld)
-        return y
+        return pooled if pool else y
 
     def _forward(self):
         c = self._cache
@@ -298,9 +311,7 @@ class UNetFConvModel(object):
         skips = [(c['x0'], 1, T, F)]
         for i, (k, ci, co, bn) in enumerate(ENCODER):
             name = 'e%d' % (i + 1)
-            y = self._conv_fwd(name, k, co, bn, 1, h, ch, None, 0, B, H, W)
-            pooled = self._buf(name + '/pool', (B * (H // 2) * (W // 2), round_up(co, 4)))
-            ops.maxpool2(y, pooled, B, H, W, co)
+            pooled = self._conv_fwd(name, k, co, bn, 1, h, ch, None, 0, B, H, W, pool=True)
             c['pool'][name] = pooled
             h, H, W, ch = pooled, H // 2, W // 2, co
             skips.append((pooled, co, H, W))
@@ -422,6 +433,12 @@ class UNetFConvModel(object):
         c = self._cache
         if 'grads' in c:
             return c['grads']
+        if not self.is_training and not getattr(self, '_keep_for_backward', False):
+            # gradients asked of a model built for inference: its forward pass kept nothing (fused pooling layers);
+            # run it again in the keeping form
+            self._keep_for_backward = True
+            for key in ('pred', 'inference', 'saved', 'pool', 'loss3', 'dpred', 'rowmask'):
+                c.pop(key, None)
         self._loss(want_grad=True)
         B, T, F = self._dims()
         lay, saved = self.layout, c['saved']

@@ -391,6 +391,15 @@ int avsi_col2im_f32(const float* dcol, int Kc, float* dsrc0, int C0, int ld0, fl
 size_t avsi_unet_workspace_bytes(int C);
 int avsi_colstats_f32(const float* x, int64_t R, int C, int ld, float eps, float* mean, float* rstd,
                       void* workspace, size_t workspace_bytes, void* stream);
+/* Batch norm + activation + 2 x 2 max pooling of an encoder layer in one pass (unet_layers.py:6-20 followed by the
+ * pooling): pooled [B*H/2*W/2][ld] = max over the window of act(bn(x)); y, when given, also receives
+ * the full-resolution activation (training keeps it for the backward pass).  ld % 4 == 0, 16-byte aligned. */
+int avsi_bn_act_pool_f32(const float* x, int B, int H, int W, int C, int ld, const float* mean, const float* rstd,
+                         const float* gamma, const float* beta, int act, float* y, float* pooled, void* stream);
+/* The first encoder layer at inference: 7 x 7 convolution of the one-channel input, bias, ReLU and 2 x 2 max pooling
+ * fused (the full-resolution 16-channel activation is never written). */
+int avsi_conv2d_thin_relu_pool_f32(const float* src0, int ld0, int B, int H, int W, int k, const float* filter, int ldf,
+                                   const float* bias, int Cout, float* out, int ldo, void* stream);
 int avsi_bn_act_f32(const float* x, int64_t R, int C, int ld, const float* mean, const float* rstd,
                     const float* gamma, const float* beta, int act, float* y, void* stream);
 int avsi_bn_act_bwd_f32(const float* x, const float* dy, int64_t R, int C, int ld, const float* mean,

@@ -282,3 +282,34 @@ def test_captured_hip_graph_replays_the_inference_step(mods):
     m.release_graph()
     m.feed(np.full(B - 1, 128), wavs[0][:B - 1], masks[:B - 1])
     assert m.prediction.shape == (B - 1, 128, 128)
+
+
+def test_inference_model_fused_layers_match_training_form(mods):
+    """A model built with is_training=False takes the fused kernels (first layer: 7 x 7 convolution + ReLU + pooling in
+    one pass; encoder layers: batch norm + activation + pooling in one pass without the full-resolution activation;
+    single-launch statistics): same prediction and loss as the keeping form and as the oracle; asking it for gradients
+    re-runs the forward pass in the keeping form."""
+    models, ops = mods
+    B, N = 3, 16384
+    wav, masks, mean, std, T, _ = _inputs(B, N, 5)
+    seq = np.array([T, T, T - 5])
+    params = OU.init_params(6)
+    rng = np.random.default_rng(7)
+    for k in params:
+        if k.endswith('gamma'):
+            params[k] = rng.uniform(0.7, 1.3, params[k].shape).astype(np.float32)
+        elif k.endswith('beta') or k.endswith('/b'):
+            params[k] = rng.normal(0, 0.1, params[k].shape).astype(np.float32)
+    mt = models.UNetFConvModel(seq, wav, masks, mean, std, 0.0, _cfg(N), is_training=True)
+    mt.variables.load_flat(mt.layout.flatten_params(params))
+    mi = models.UNetFConvModel(seq, wav, masks, mean, std, 0.0, _cfg(N), is_training=False, variables=mt.variables)
+    pt, pi = mt.prediction.cpu().numpy(), mi.prediction.cpu().numpy()
+    assert 'e1' not in mi._cache['saved'] and mi._cache['saved']['e2']['y'] is None      # nothing kept
+    assert np.abs(pt - pi).max() < 1e-5
+    assert float(mi.loss_func) == pytest.approx(float(mt.loss_func), rel=1e-6)
+    st = OF.get_stft(wav, window_size=16, step_size=8, n_fft=256)[:, :, :128]
+    ref_norm = (OF.get_spectrogram(st, log=True) - mean) / std
+    ref = OU.forward_backward(ref_norm * masks, ref_norm, seq, params, want_grads=False)
+    assert np.sqrt(np.mean((pi - ref['prediction']) ** 2)) < 2e-4
+    gi, gt = mi.gradients.cpu().numpy(), mt.gradients.cpu().numpy()
+    assert np.abs(gi - gt).max() <= 1e-6 * np.abs(gt).max() + 1e-9
