@@ -145,6 +145,76 @@ __global__ __launch_bounds__(TPB) void direct_conv_relu_pool_kernel(const float*
     }
 }
 
+// The first encoder layer on the matrix cores: 7 x 7, one input channel -> 16, bias (+ ReLU + 2 x 2 max pooling).
+// As a direct convolution it is VALU-bound (3136 multiply-adds per pooled pixel: 0.54 ms at batch 512, 24 TFLOP/s).
+// Here a workgroup owns 16 x 64 output pixels of one image; their (16 + 6) x (64 + 6) input patch sits in LDS, and
+// every group of 16 consecutive pixels of a row is a 16 x 49 by 49 x 16 product on v_mfma_f32_16x16x4_f32:
+// 13 k-steps of four taps (49 padded to 52 with zero weights); lane l supplies A[pixel l % 16][tap 4 kk + l / 16] --
+// one ds_read_b32 from the patch -- and B[tap][channel l % 16], thirteen registers loaded once per kernel.
+// D[pixel 4 (l / 16) + i][channel l % 16], i = 0..3: horizontally adjacent pixels meet in one lane, vertically
+// adjacent ones in the same lane of the next row's group, so ReLU + pooling are lane-local.
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+template <bool POOL>
+__global__ __launch_bounds__(256) void conv7_c1_mfma_kernel(const float* __restrict__ s0, int ld0, const float* __restrict__ filt,
+                                                            int ldf, const float* __restrict__ bias, float* __restrict__ out,
+                                                            int ldo, int H, int W) {
+    constexpr int K = 7, P = 3, TH = 16, TW = 64, PW = TW + 2 * P + 2;      // patch row pitch 72
+    __shared__ float patch[(TH + 2 * P) * PW];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int tiles_w = W / TW, tiles_h = H / TH;
+    const int tile = blockIdx.x % (tiles_w * tiles_h), b = blockIdx.x / (tiles_w * tiles_h);
+    const int h0 = (tile / tiles_w) * TH, w0 = (tile % tiles_w) * TW;
+    for (int i = tid; i < (TH + 2 * P) * (TW + 2 * P); i += 256) {
+        const int r = i / (TW + 2 * P), c = i - r * (TW + 2 * P);
+        const int hh = h0 + r - P, ww = w0 + c - P;
+        const bool ok = hh >= 0 && hh < H && ww >= 0 && ww < W;
+        const float v = s0[ok ? (((int64_t)b * H + hh) * W + ww) * ld0 : 0];
+        patch[r * PW + c] = ok ? v : 0.f;
+    }
+    const int ch = lane & 15, kq = lane >> 4;
+    float wreg[13];      // B operand: weight of tap 4 kk + kq for this lane's channel
+    int aoff[13];        // patch offset of that tap relative to the pixel
+#pragma unroll
+    for (int kk = 0; kk < 13; ++kk) {
+        const int t = 4 * kk + kq;
+        wreg[kk] = t < K * K ? filt[(int64_t)t * ldf + ch] : 0.f;
+        const int tt = t < K * K ? t : 0;
+        aoff[kk] = (tt / K) * PW + (tt % K);
+    }
+    const float bv = bias ? bias[ch] : 0.f;
+    __syncthreads();
+    // wave wv owns rows 4 wv .. 4 wv + 3 of the tile, as two row pairs; four groups of 16 columns
+    for (int rp = 0; rp < 2; ++rp) {
+        const int r = 4 * wv + 2 * rp;
+        for (int g = 0; g < TW / 16; ++g) {
+            f32x4 d0 = {bv, bv, bv, bv}, d1 = {bv, bv, bv, bv};
+            const float* p0 = patch + r * PW + 16 * g + (lane & 15);
+            const float* p1 = p0 + PW;
+#pragma unroll
+            for (int kk = 0; kk < 13; ++kk) {
+                d0 = __builtin_amdgcn_mfma_f32_16x16x4f32(p0[aoff[kk]], wreg[kk], d0, 0, 0, 0);
+                d1 = __builtin_amdgcn_mfma_f32_16x16x4f32(p1[aoff[kk]], wreg[kk], d1, 0, 0, 0);
+            }
+            if (POOL) {
+                // pixels 4 kq + i of the group: pooled columns (16 g + 4 kq) / 2 + {0, 1}
+                const float m0 = fmaxf(fmaxf(fmaxf(d0[0], d0[1]), fmaxf(d1[0], d1[1])), 0.f);
+                const float m1 = fmaxf(fmaxf(fmaxf(d0[2], d0[3]), fmaxf(d1[2], d1[3])), 0.f);
+                const int64_t prow = ((int64_t)b * (H / 2) + (h0 + r) / 2) * (W / 2) + (w0 + 16 * g + 4 * kq) / 2;
+                out[prow * ldo + ch] = m0;
+                out[(prow + 1) * ldo + ch] = m1;
+            } else {
+                const int64_t pix0 = ((int64_t)b * H + h0 + r) * W + w0 + 16 * g + 4 * kq;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    out[(pix0 + i) * ldo + ch] = d0[i];
+                    out[(pix0 + W + i) * ldo + ch] = d1[i];
+                }
+            }
+        }
+    }
+}
+
 template <int K, int C0, int C1, int COUT>
 __global__ __launch_bounds__(TPB) void direct_conv_kernel(const float* __restrict__ s0, int ld0, const float* __restrict__ s1,
                                                           int ld1, const float* __restrict__ filt, int ldf,
@@ -710,7 +780,10 @@ extern "C" int avsi_conv2d_thin_f32(const float* src0, int C0, int ld0, const fl
     const dim3 grid(grid_for((int64_t)B * H * W)), block(TPB);
     const hipStream_t st = (hipStream_t)stream;
     avsi_clear_error();
-    if (k == 7 && C0 == 1 && C1 == 0 && Cout == 16)
+    if (k == 7 && C0 == 1 && C1 == 0 && Cout == 16 && H % 16 == 0 && W % 64 == 0)
+        hipLaunchKernelGGL((conv7_c1_mfma_kernel<false>), dim3(B * (H / 16) * (W / 64)), dim3(256), 0, st, src0, ld0, filter, ldf,
+                           bias, out, ldo, H, W);
+    else if (k == 7 && C0 == 1 && C1 == 0 && Cout == 16)
         hipLaunchKernelGGL((direct_conv_kernel<7, 1, 0, 16>), grid, block, 0, st, src0, ld0, src1_coarse, ld1, filter, ldf, bias,
                            out, ldo, B, H, W);
     else if (k == 3 && C0 == 1 && C1 == 16 && Cout == 1)
@@ -869,8 +942,12 @@ extern "C" int avsi_conv2d_thin_relu_pool_f32(const float* src0, int ld0, int B,
         return AVSI_ERR_INVALID_ARG;
     if (k != 7 || Cout != 16 || (ldo & 3) || (reinterpret_cast<uintptr_t>(out) & 15)) return AVSI_ERR_UNSUPPORTED;
     avsi_clear_error();
-    hipLaunchKernelGGL((direct_conv_relu_pool_kernel<7, 16>), dim3(grid_for((int64_t)B * (H / 2) * (W / 2))), dim3(TPB), 0,
-                       (hipStream_t)stream, src0, ld0, filter, ldf, bias, out, ldo, B, H, W);
+    if (H % 16 == 0 && W % 64 == 0)
+        hipLaunchKernelGGL((conv7_c1_mfma_kernel<true>), dim3(B * (H / 16) * (W / 64)), dim3(256), 0, (hipStream_t)stream, src0, ld0,
+                           filter, ldf, bias, out, ldo, H, W);
+    else
+        hipLaunchKernelGGL((direct_conv_relu_pool_kernel<7, 16>), dim3(grid_for((int64_t)B * (H / 2) * (W / 2))), dim3(TPB), 0,
+                           (hipStream_t)stream, src0, ld0, filter, ldf, bias, out, ldo, B, H, W);
     return avsi_launch_status();
 }
 

@@ -192,7 +192,7 @@ def bench_unet(args, torch, dist, rank, world, device):
     model = models.UNetFConvModel(seq, wav, masks, mean, std, 0.0, cfg, is_training=False, seed=7)
     timer = KernelTimer(torch)
     if B >= 256:      # below that a step is launch-bound and the per-call events would dominate what they measure
-        for name in ("conv2d", "conv2d_thin", "colstats", "bn_act", "maxpool2"):
+        for name in ("conv2d", "conv2d_thin", "conv2d_thin_relu_pool", "colstats", "bn_act", "bn_act_pool", "maxpool2"):
             setattr(ops, name, timer.wrap(name, getattr(ops, name)))
 
     def step():
