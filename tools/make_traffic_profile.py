@@ -1,7 +1,7 @@
 """Build profiles/rNN_traffic_b<batch>.json from two rocprofv3 --pmc passes of the same bench command
 (one with FETCH_SIZE, one with WRITE_SIZE -- separate passes, MI355X_MICROARCH.md HBM section).
 
-python tools/make_traffic_profile.py <fetch counter_collection.csv> <write counter_collection.csv> <out.json> [skip_launches_per_kernel]
+python tools/make_traffic_profile.py <fetch counter_collection.csv> <write counter_collection.csv> <out.json> [commit] [date]
 
 FETCH_SIZE / WRITE_SIZE are in KiB-units of 1024 B per the counter definition; FETCH_SIZE is doubled
 (gfx950 tallies 128-byte requests as 64 B for 16-byte-per-lane streams -- the guide's correction).
@@ -31,9 +31,11 @@ def main():
     fetch = per_kernel(sys.argv[1], 'FETCH_SIZE')
     write = per_kernel(sys.argv[2], 'WRITE_SIZE')
     out = {"command": "rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE --kernel-trace -- python3 bench.py --batch 8192 --steps 1 "
-                      "--warmup 1 --no-cpu-baseline (two separate passes)",
+                      "--warmup 1 --no-cpu-baseline --no-also (two separate passes)",
            "units": "bytes per launch; FETCH_SIZE (KB) doubled per MI355X_MICROARCH.md (gfx950 tallies 128-B requests at "
                     "64 B for 16-B-per-lane streams; dword-per-lane streams uncalibrated), WRITE_SIZE (KB) as read",
+           "commit": sys.argv[4] if len(sys.argv) > 4 else None,        # the tree the counters were collected on
+           "collected": sys.argv[5] if len(sys.argv) > 5 else None,
            "kernels": {}}
     for k, n in KERNELS.items():
         f = [2.0 * 1024.0 * x for x in fetch.get(k, [])][-n:]
