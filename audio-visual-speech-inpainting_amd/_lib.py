@@ -67,6 +67,10 @@ PROTOTYPES = {
     "avsi_frontend_f32": (c_int, [POINTER(FrontendArgs), c_void_p]),
     "avsi_gemm_f32": (c_int, [c_int, c_int, c_int, c_int, c_int, c_float, c_void_p, c_int64, c_void_p, c_int64,
                               c_float, c_void_p, c_int64, POINTER(GemmEpilogue), c_void_p]),
+    "avsi_pack_bf16x3_b_bytes": (c_size_t, [c_int, c_int]),
+    "avsi_pack_bf16x3_b": (c_int, [c_void_p, c_int64, c_int, c_int, c_void_p, c_size_t, c_void_p]),
+    "avsi_gemm_bf16x3_f32": (c_int, [c_int, c_int, c_int, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int64,
+                                     c_void_p]),
     "avsi_blstm_rec_fwd_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     "avsi_gemm_splitk_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
     "avsi_gemm_splitk_f32": (c_int, [c_int, c_int, c_int, c_int, c_int, c_float, c_void_p, c_int64, c_void_p, c_int64,

@@ -78,6 +78,7 @@ class BLSTMVariables:
 
     def repack(self):
         """packed <- gather(flat): one index_select (padding positions read the appended 0)."""
+        self.version = getattr(self, 'version', 0) + 1
         ext = torch.cat([self.flat, self.flat.new_zeros(1)])
         torch.index_select(ext, 0, self._pack_index, out=self.packed)
 
@@ -190,6 +191,11 @@ class StackedBLSTMModel(object):
         self.regularization = config['l2']
         self.var_scope = None
         self.rows_per_wg = int(config.get('rows_per_wg', 0))   # 0 = kernel picks 32/64 from the batch
+        # 'f32' (default: exact fp32 fma chains on the fp32 matrix cores) or 'bf16x3' (EXPLORATORY: the layer input
+        # projections with split-bf16 operands, ops.gemm_bf16x3; inference only)
+        self.precision = config.get('precision', 'f32')
+        if self.precision not in ('f32', 'bf16x3'):
+            raise _lib.AvsiError("precision must be 'f32' or 'bf16x3'")
         in_dim = {'a': self.audio_feat_dim, 'v': self.video_feat_dim,
                   'av': self.audio_feat_dim + self.video_feat_dim}[input]
         self.layout = variables.layout if variables is not None else ParamLayout(in_dim, self.net_dim,
@@ -317,6 +323,13 @@ class StackedBLSTMModel(object):
                 xproj.copy_(eb.unsqueeze(0).expand(T, Bp, 2 * GP))
                 ops.gemm(x.view(T * Bp, kp), v.p('wx%d' % li), out=xproj.view(T * Bp, 2 * GP), beta=1.0)
                 c['side_p'] = sp
+            elif self.precision == 'bf16x3' and not keep:
+                # the split weights are packed once per set of variables (repack() bumps the version)
+                key = ('wx_bf16x3', li)
+                hit = self._ws.get(key)
+                if hit is None or hit[0] != v.version:
+                    hit = self._ws[key] = (v.version, ops.pack_bf16x3_b(v.p('wx%d' % li)))
+                ops.gemm_bf16x3(x.view(T * Bp, kp), hit[1], xproj.view(T * Bp, 2 * GP), kp, bias=v.p('b%d' % li))
             else:
                 ops.gemm(x.view(T * Bp, kp), v.p('wx%d' % li), out=xproj.view(T * Bp, 2 * GP), bias=v.p('b%d' % li))
             hout = self._buf('h%d' % li, (T, Bp, 2 * HP))

@@ -41,6 +41,34 @@ def gemm(a, b, out=None, trans_a=False, trans_b=False, m=None, n=None, k=None, a
     return out
 
 
+def pack_bf16x3_b(b):
+    """Split the weight matrix b [K, N] (float32, unit inner stride) into bf16 hi / lo planes in MFMA fragment order
+    (avsi_pack_bf16x3_b); returns the packed buffer for gemm_bf16x3."""
+    _lib.require_cuda(b)
+    L = _lib.lib()
+    K, N = b.shape
+    nbytes = L.avsi_pack_bf16x3_b_bytes(K, N)
+    if not nbytes:
+        raise _lib.AvsiError("pack_bf16x3_b: N must be a multiple of 32")
+    packed = torch.empty(nbytes // 2, dtype=torch.bfloat16, device=b.device)
+    _lib.check(L.avsi_pack_bf16x3_b(_lib.ptr(b), b.stride(0), K, N, _lib.ptr(packed), nbytes, _lib.stream_ptr()),
+               "avsi_pack_bf16x3_b")
+    return packed
+
+
+def gemm_bf16x3(a, b_packed, out, k, bias=None):
+    """EXPLORATORY: out [M, N] = a [M, k] . B + bias with split-bf16 operands (hi.hi + hi.lo + lo.hi, fp32
+    accumulation) through avsi_gemm_bf16x3_f32; B comes packed from pack_bf16x3_b."""
+    _lib.require_cuda(a, b_packed, out, bias)
+    for x in (a, out):
+        if x.dtype != torch.float32 or x.dim() != 2 or x.stride(1) != 1:
+            raise _lib.AvsiError("gemm_bf16x3 operands must be 2-D float32 with unit inner stride")
+    M, N = a.shape[0], out.shape[1]
+    _lib.check(_lib.lib().avsi_gemm_bf16x3_f32(M, N, int(k), _lib.ptr(a), a.stride(0), _lib.ptr(b_packed), _lib.ptr(bias),
+                                               _lib.ptr(out), out.stride(0), _lib.stream_ptr()), "avsi_gemm_bf16x3_f32")
+    return out
+
+
 def blstm_rec_fwd(xproj, whp, hout, reserve=None, rows_per_wg=0, split=None):
     """All T steps of both directions of one layer (avsi_blstm_rec_fwd_f32, or its small-batch
     cooperative form avsi_blstm_rec_fwd_coop_f32: `split` 4 / 8 forces it, 0 forbids it, None = by Bp).

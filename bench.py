@@ -320,6 +320,9 @@ def main():
     ap.add_argument("--rows-per-wg", type=int, default=0)
     ap.add_argument("--cpu-sample", type=int, default=384, help="utterances timed on the CPU oracle (~15 s)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--precision", choices=["f32", "bf16x3"], default="f32",
+                    help="EXPLORATORY, inference only: bf16x3 = layer input projections with split-bf16 operands (hi.hi + hi.lo "
+                         "+ lo.hi on the bf16 matrix cores, fp32 accumulation); never the default, never the headline")
     ap.add_argument("--no-also", action="store_true", help="skip the named-workload entries (`also` block)")
     ap.add_argument("--also-timeout", type=int, default=240)
     ap.add_argument("--mode", choices=["infer", "train", "unet"], default="infer",
@@ -357,7 +360,7 @@ def main():
     B = args.batch
     cfg = dict(audio_feat_dim=F_BINS, video_feat_dim=136, audio_len=N_SAMPLES, net_dim=[H, H, H],
                optimizer_type='adam', starter_learning_rate=1e-3, lr_updating_steps=10000, lr_decay=1.0,
-               batch_size=B, l2=0.0, rows_per_wg=args.rows_per_wg)
+               batch_size=B, l2=0.0, rows_per_wg=args.rows_per_wg, precision=args.precision)
     wav, masks = synth_batch(torch, B, 1234 + rank, device)
     # per-bin statistics of the synthetic set (restated compute_mean_std_features, type='spec')
     from avsi_amd import audio_processing as ap_mod
@@ -378,6 +381,8 @@ def main():
     timer = KernelTimer(torch)
     untimed = (ops.gemm, ops.blstm_rec_fwd, ap_mod.frontend)
     ops.gemm = timer.wrap("gemm_dma_kernel", ops.gemm)
+    if args.precision == "bf16x3":
+        ops.gemm_bf16x3 = timer.wrap("gemm_bf16x3_kernel", ops.gemm_bf16x3)
     ops.blstm_rec_fwd = timer.wrap("blstm_rec_fwd_kernel", ops.blstm_rec_fwd)
     ap_mod.frontend = timer.wrap("frontend_kernel", ap_mod.frontend)
     if train:
@@ -433,8 +438,12 @@ def main():
         # gemm_dma_kernel<false, false, 16, 3, false, 256>, the dominant kernel) and the 257-bin output
         # projection (same kernel with the 64-wide N tile); the roofline block is for the former alone
         ev = timer.events["gemm_dma_kernel"]
-        layer_ms = [s_.elapsed_time(e_) for i, (s_, e_) in enumerate(ev) if i % 4 != 3]
-        proj_ms = [s_.elapsed_time(e_) for i, (s_, e_) in enumerate(ev) if i % 4 == 3]
+        if args.precision == "bf16x3":      # exploratory: the layer projections are the split-bf16 launches
+            layer_ms = [s_.elapsed_time(e_) for s_, e_ in timer.events["gemm_bf16x3_kernel"]]
+            proj_ms = [s_.elapsed_time(e_) for s_, e_ in ev]
+        else:
+            layer_ms = [s_.elapsed_time(e_) for i, (s_, e_) in enumerate(ev) if i % 4 != 3]
+            proj_ms = [s_.elapsed_time(e_) for i, (s_, e_) in enumerate(ev) if i % 4 == 3]
         t_gemm, n_gemm = sum(layer_ms), len(layer_ms)
         t_proj = sum(proj_ms)
         t_fe, n_fe = totals["frontend_kernel"]
@@ -452,6 +461,11 @@ def main():
             roof = {"kernel": "gemm_dma_kernel<false, false, 16, 3, false, 256>", "bound": "mfma", "achieved": gemm_tf,
                     "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": gemm_tf / FP32_MFMA_PEAK_TFLOPS,
                     "traffic": traffic, "traffic_source": traffic_src, "avg_launch_ms": t_gemm / n_gemm}
+        if args.precision == "bf16x3":
+            roof["kernel"] = "gemm_bf16x3_kernel (EXPLORATORY: three bf16 MFMAs per fp32-equivalent product)"
+            roof["peak"] = 2500.0 / 3.0      # dense bf16 MFMA peak (MI355X_MICROARCH.md) over the three products
+            roof["frac"] = roof["achieved"] / roof["peak"]
+            roof["traffic"], roof["traffic_source"] = None, None
         roof["others"] = {
             "blstm_rec_fwd_kernel": {"TFLOP/s": rec_tf, "ms_per_step": t_rec / args.steps},
             "gemm_dma_kernel": {"TFLOP/s": gemm_tf, "ms_per_step": t_gemm / args.steps},
@@ -472,7 +486,9 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
+            "dtype": "f32" if args.precision == "f32" else "bf16x3 (layer input projections: split-bf16 operands, fp32 "
+                                                             "accumulation; recurrence, projection, front end f32) -- EXPLORATORY",
+            "data": "synthetic",
             "config": {"workload": "configs[1]: audio-only 3xBLSTM-250 inpainter, 3 s 16 kHz clips, one 400 ms gap, "
                                    "HIP STFT front end + fp32-MFMA BLSTM forward",
                        "per_gpu_batch": B, "global_batch": B * world, "frames": T_FRAMES, "parallelism": "dp%d" % world},
@@ -481,7 +497,7 @@ def main():
             "roofline": roof,
             "cpu_baseline": cpu,
         }
-    if not train and not args.no_also:
+    if not train and not args.no_also and args.precision == "f32":
         # The named workloads run AFTER the headline measurement is complete.  Their training entry is the first
         # code of this repository to issue RCCL collectives from inside the backward pass on real multi-GPU
         # hardware; a watchdog makes sure a stall there cannot cost the headline line: when it fires, rank 0 prints

@@ -130,6 +130,16 @@ int avsi_gemm_f32(int transA, int transB, int M, int N, int K, float alpha,
 int avsi_blstm_rec_fwd_f32(const float* xproj, const float* whp, float* hout, float* reserve,
                            int T, int Bp, int rows_per_wg, void* stream);
 
+/* EXPLORATORY, not on the default path: C[M,N] = A[M,K] . B[K,N] + bias with every fp32 operand split into two bf16
+ * values and the product taken as hi.hi + hi.lo + lo.hi on the bf16 matrix cores (fp32 accumulation).  Same role as
+ * avsi_gemm_f32 for the layer input projections of models.py:95-115, selected by config['precision'] = 'bf16x3'.
+ * B (the weights) is split and put into MFMA fragment order once, by avsi_pack_bf16x3_b, into a caller-owned buffer of
+ * avsi_pack_bf16x3_b_bytes(K, N) bytes; A is split on the fly.  N % 128 == 0, K % 4 == 0, lda % 4 == 0, 16-byte aligned. */
+size_t avsi_pack_bf16x3_b_bytes(int K, int N);
+int avsi_pack_bf16x3_b(const float* B, int64_t ldb, int K, int N, void* packed, size_t packed_bytes, void* stream);
+int avsi_gemm_bf16x3_f32(int M, int N, int K, const float* A, int64_t lda, const void* packed_b, const float* bias,
+                         float* C, int64_t ldc, void* stream);
+
 /* ------------------------------------------------------------------------------------
  * L1 loss and its diagnostics over [n] elements (models.py:144-151):
  *   out[0] = mean|t-p|, out[1] = sum|t-p|(1-m)/sum(1-m), out[2] = sum|t-p|m/sum(m)
