@@ -148,8 +148,9 @@ PROTOTYPES = {
     "avsi_lws_stft_f32": (c_int, [c_void_p, c_int64, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_int, c_void_p]),
     "avsi_lws_stitch_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int, c_int, c_int, c_int, c_int,
                                     c_void_p]),
+    "avsi_lws_run_workspace_bytes": (c_size_t, [c_int]),
     "avsi_lws_run_f32": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_int, c_float, c_int,
-                                 c_float, c_float, c_float, c_int, c_int, c_void_p, c_void_p]),
+                                 c_float, c_float, c_float, c_int, c_int, c_int, c_void_p, c_size_t, c_void_p]),
     "avsi_lws_istft_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
     "avsi_lws_istft_f32": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_int64, c_int, c_void_p,
                                    c_size_t, c_void_p]),

@@ -265,18 +265,47 @@ __device__ __forceinline__ void row_store(float2* p, float2 v) {
 // Progress is a per-sweep row counter in LDS; rows travel through global memory (they stay in L2).  At small batches
 // the sweeps of ONE utterance thus run on up to 16 waves instead of one (0.84 s -> ~60 ms per utterance); large
 // batches use NW = 1 with several utterances per wave.
+// mean and max magnitude of every utterance, from the untouched input (thresholds are relative to the mean; a sweep
+// whose threshold is above the max touches nothing).  A kernel of its own so that every pipeline stage, whichever
+// workgroup it sits in and whenever it starts, sees the same two numbers: stats[b] = (mean, max)
+__global__ __launch_bounds__(256) void lws_stats_kernel(const float2* __restrict__ spec, int M, float2* __restrict__ stats) {
+    __shared__ float s_sum[4], s_max[4];
+    const float2* sp = spec + (int64_t)blockIdx.x * M * KB;
+    float sum = 0.f, mx = 0.f;
+    for (int i = threadIdx.x; i < M * KB; i += 256) {
+        const float2 v = sp[i];
+        const float a = sqrtf(v.x * v.x + v.y * v.y);
+        sum += a, mx = fmaxf(mx, a);
+    }
+    sum = wave_sum(sum), mx = wave_max(mx);
+    if ((threadIdx.x & 63) == 0) s_sum[threadIdx.x >> 6] = sum, s_max[threadIdx.x >> 6] = mx;
+    __syncthreads();
+    if (threadIdx.x == 0)
+        stats[blockIdx.x] = make_float2((s_sum[0] + s_sum[1] + s_sum[2] + s_sum[3]) / (float)(M * KB),
+                                        fmaxf(fmaxf(s_max[0], s_max[1]), fmaxf(s_max[2], s_max[3])));
+}
+
+// G workgroups of NW waves per group of U utterances: G * NW pipeline stages.  Stages of one workgroup hand over
+// through LDS counters, the last stage of a workgroup to the first stage of the next through a counter in global memory
+// (`gdone`, one row of MAX_SWEEPS per utterance group, zero on entry).  All G workgroups of a group must be resident
+// together (bounded waits, status word): the host keeps G * groups within the CU count.
 template <int U, int NW>
 __global__ __launch_bounds__(64 * NW) void lws_sweeps_kernel(float2* __restrict__ spec, int B, int M, const LwsWeights W,
-                                                             const LwsSchedule sched, int* __restrict__ status) {
+                                                             const LwsSchedule sched, int* __restrict__ status,
+                                                             const float2* __restrict__ stats, int* __restrict__ gdone_all,
+                                                             int G) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     volatile int* done = reinterpret_cast<volatile int*>(smem);                 // [MAX_SWEEPS] rows finished by sweep s
     const int wv = threadIdx.x >> 6;
+    const int cluster = blockIdx.x / G, wg = blockIdx.x - cluster * G;
+    int* gdone = gdone_all + (int64_t)cluster * MAX_SWEEPS;
+    const int stage = wg * NW + wv, stages = G * NW;
     LwsWaveLds<U>& L = *reinterpret_cast<LwsWaveLds<U>*>(smem + MAX_SWEEPS * 4 + (size_t)wv * sizeof(LwsWaveLds<U>));
     auto& s_row = L.row;
     auto& s_p = L.p;
     auto& s_amp = L.amp;
     const int lane = threadIdx.x & 63;
-    const int b0 = blockIdx.x * U;
+    const int b0 = cluster * U;
     const int nu = min(U, B - b0);
     for (int i = threadIdx.x; i < MAX_SWEEPS; i += 64 * NW) done[i] = 0;
     __syncthreads();
@@ -296,23 +325,11 @@ __global__ __launch_bounds__(64 * NW) void lws_sweeps_kernel(float2* __restrict_
         w0[p] = make_float2(W.w[1][p][0], W.w[1][p][1]);
     }
 
-    // mean and max magnitude per utterance (thresholds are relative to the mean; a sweep whose threshold is above
-    // the max touches nothing)
-    // (every wave of the workgroup computes them from the untouched input, before any sweep starts: barrier below)
     float mean_u[U], max_u[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-        float sum = 0.f, mx = 0.f;
-        if (u < nu) {
-            const float2* sp = spec + (int64_t)(b0 + u) * M * KB;
-            for (int i = lane; i < M * KB; i += 64) {
-                const float2 v = sp[i];
-                const float a = sqrtf(v.x * v.x + v.y * v.y);
-                sum += a, mx = fmaxf(mx, a);
-            }
-        }
-        mean_u[u] = wave_sum(sum) / (float)(M * KB);
-        max_u[u] = wave_max(mx);
+        const float2 st = stats[min(b0 + u, B - 1)];
+        mean_u[u] = st.x, max_u[u] = st.y;
     }
     __syncthreads();
 
@@ -321,7 +338,8 @@ __global__ __launch_bounds__(64 * NW) void lws_sweeps_kernel(float2* __restrict_
         if (s == 0 || dead) return;
         need = need < M ? need : M;
         int spins = 0;
-        while (done[s - 1] < need) {
+        const bool remote = wv == 0 && G > 1;          // the predecessor stage lives in the previous workgroup
+        while ((remote ? __hip_atomic_load(gdone + s - 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : done[s - 1]) < need) {
             __builtin_amdgcn_s_sleep(8);
             if (++spins > (1 << 22)) {
                 dead = true;
@@ -332,9 +350,11 @@ __global__ __launch_bounds__(64 * NW) void lws_sweeps_kernel(float2* __restrict_
     };
     auto publish = [&](int s, int rows) {      // after every global store of those rows has completed
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (lane == 0) done[s] = rows;
+        if (lane == 0) {
+            done[s] = rows;
+            if (wv == NW - 1 && G > 1) __hip_atomic_store(gdone + s, rows, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
     };
-
     auto load_row = [&](int u, int m, float2 (&r)[5]) {      // global -> registers (zeros outside the spectrogram)
         const bool ok = u < nu && m >= 0 && m < M;
         const float2* src = spec + ((int64_t)(b0 + u) * M + (ok ? m : 0)) * KB;
@@ -359,7 +379,7 @@ __global__ __launch_bounds__(64 * NW) void lws_sweeps_kernel(float2* __restrict_
         }
     };
 
-    for (int sw = wv; sw < sched.n; sw += NW) {
+    for (int sw = stage; sw < sched.n; sw += stages) {
         float thr[U];
         bool any_u = false;
 #pragma unroll
@@ -609,10 +629,16 @@ extern "C" int avsi_lws_stitch_f32(float* spec, const float* ref, const float* m
     return avsi_launch_status();
 }
 
+// word 0: status; then (mean, max) per utterance; then one row of progress counters per utterance group
+extern "C" size_t avsi_lws_run_workspace_bytes(int batch) {
+    return batch > 0 ? 16 + (size_t)batch * sizeof(float2) + (size_t)batch * MAX_SWEEPS * sizeof(int) : 0;
+}
+
 extern "C" int avsi_lws_run_f32(float* spec, int batch, int num_frames, int frame_len, int hop, int nfft, int L,
                                 int nofuture_iterations, float nofuture_alpha, int online_iterations, float online_alpha,
                                 int batch_iterations, float batch_alpha, float batch_beta, float batch_gamma,
-                                int utterances_per_wave, int waves_per_group, int* status, void* stream) {
+                                int utterances_per_wave, int waves_per_group, int groups_per_utterance, void* workspace,
+                                size_t workspace_bytes, void* stream) {
     if (!spec || batch <= 0 || num_frames <= 0 || L < 1 || nofuture_iterations < 0 || online_iterations < 0 ||
         batch_iterations < 0)
         return AVSI_ERR_INVALID_ARG;
@@ -630,22 +656,36 @@ extern "C" int avsi_lws_run_f32(float* spec, int batch, int num_frames, int fram
     for (int i = S.n; i < MAX_SWEEPS; ++i) S.rel[i] = 0.f, S.past_only[i] = 0;
     if (S.n == 0) return AVSI_OK;
     // Shape of the launch: U utterances per wave (lane u < U runs the recurrence of utterance u), NW waves per
-    // workgroup (NW sweeps of those utterances in flight as a pipeline).  Small batches want their sweeps spread over
-    // waves (latency: 0.84 s per utterance on one wave); large batches fill the chip with utterances instead.
+    // workgroup and G workgroups per utterance group (G * NW sweeps of those utterances in flight as a pipeline).
+    // Small batches want their sweeps spread over waves and CUs (latency: 0.84 s per utterance on one wave); large
+    // batches fill the chip with utterances instead.
     int U = utterances_per_wave, NW = waves_per_group;
     if (U == 0) U = batch >= 4 * 4 * AVSI_NUM_CU ? 4 : (batch >= 2 * 4 * AVSI_NUM_CU ? 2 : 1);
     if (NW == 0) NW = (U > 1 || batch > 8 * AVSI_NUM_CU) ? 1 : (batch > 2 * AVSI_NUM_CU ? 4 : (batch > AVSI_NUM_CU ? 8 : 16));
-    if (status && hipMemsetAsync(status, 0, sizeof(int), (hipStream_t)stream) != hipSuccess) return AVSI_ERR_LAUNCH;
+    const int clusters = (batch + U - 1) / U;
+    int G = groups_per_utterance;
+    if (G == 0) {      // 16-wave workgroups take a CU each: as many per utterance as the chip holds, at most one per 16 sweeps
+        G = NW == 16 ? AVSI_NUM_CU / clusters : 1;
+        const int useful = (S.n + NW - 1) / NW;
+        G = G < 1 ? 1 : (G > useful ? useful : G);
+    }
+    if (G < 1 || (G > 1 && (int64_t)G * clusters > AVSI_NUM_CU)) return AVSI_ERR_INVALID_ARG;     // all must be resident
+    if (!workspace || workspace_bytes < avsi_lws_run_workspace_bytes(batch)) return AVSI_ERR_WORKSPACE;
+    const hipStream_t st = (hipStream_t)stream;
+    if (hipMemsetAsync(workspace, 0, avsi_lws_run_workspace_bytes(batch), st) != hipSuccess) return AVSI_ERR_LAUNCH;
+    int* status = static_cast<int*>(workspace);
+    float2* stats = reinterpret_cast<float2*>(static_cast<char*>(workspace) + 16);
+    int* gdone = reinterpret_cast<int*>(static_cast<char*>(workspace) + 16 + (size_t)batch * sizeof(float2));
     avsi_clear_error();
     float2* sp = reinterpret_cast<float2*>(spec);
-    const hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(lws_stats_kernel, dim3(batch), dim3(256), 0, st, sp, num_frames, stats);
 #define AVSI_LWS_LAUNCH(UV, NWV)                                                                                          \
     do {                                                                                                                   \
         const size_t lds = MAX_SWEEPS * 4 + (size_t)(NWV) * sizeof(LwsWaveLds<UV>);                                        \
         (void)hipFuncSetAttribute((const void*)lws_sweeps_kernel<UV, NWV>, hipFuncAttributeMaxDynamicSharedMemorySize,      \
                                   (int)lds);                                                                               \
-        hipLaunchKernelGGL((lws_sweeps_kernel<UV, NWV>), dim3((batch + (UV) - 1) / (UV)), dim3(64 * (NWV)), lds, st, sp, batch, \
-                           num_frames, W, S, status);                                                                      \
+        hipLaunchKernelGGL((lws_sweeps_kernel<UV, NWV>), dim3(clusters * G), dim3(64 * (NWV)), lds, st, sp, batch, num_frames, W, \
+                           S, status, stats, gdone, G);                                                                    \
     } while (0)
     if (U == 4 && NW == 1) AVSI_LWS_LAUNCH(4, 1);
     else if (U == 2 && NW == 1) AVSI_LWS_LAUNCH(2, 1);

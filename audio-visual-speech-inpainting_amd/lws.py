@@ -42,7 +42,8 @@ class lws(object):
 
     def __init__(self, awin_or_fsize, fshift, L=5, swin=None, look_ahead=3, nofuture_iterations=0, nofuture_alpha=1,
                  online_iterations=0, online_alpha=1, batch_iterations=100, batch_alpha=100, batch_beta=0.1, batch_gamma=1,
-                 symmetric_win=True, mode=None, fftsize=None, utterances_per_wave=0, waves_per_group=0):
+                 symmetric_win=True, mode=None, fftsize=None, utterances_per_wave=0, waves_per_group=0,
+                 groups_per_utterance=0):
         if not isinstance(awin_or_fsize, (int, np.integer)) or swin is not None or not symmetric_win:
             raise _lib.AvsiError("lws: only the window-length form with the default sqrt-Hann windows is implemented")
         if mode == 'speech':
@@ -61,6 +62,7 @@ class lws(object):
         self.batch_iterations = int(batch_iterations)
         self.batch_alpha, self.batch_beta, self.batch_gamma = float(batch_alpha), float(batch_beta), float(batch_gamma)
         self.utterances_per_wave, self.waves_per_group = int(utterances_per_wave), int(waves_per_group)
+        self.groups_per_utterance = int(groups_per_utterance)
         self._status = None
         if _lib.lib().avsi_lws_table_floats(self.fsize, self.fshift, self.fftsize) == 0:
             raise _lib.AvsiError("unsupported LWS geometry: window %d, shift %d, fft %d" % (self.fsize, self.fshift, self.fftsize))
@@ -111,17 +113,19 @@ class lws(object):
 
     def _run(self, s):
         B, M = s.shape[0], s.shape[1]
-        if self._status is None or self._status.device != s.device:
-            self._status = torch.zeros(1, dtype=torch.int32, device=s.device)
+        need = _lib.lib().avsi_lws_run_workspace_bytes(B)
+        if self._status is None or self._status.device != s.device or self._status.numel() * 4 < need:
+            self._status = torch.zeros((need + 3) // 4, dtype=torch.int32, device=s.device)     # word 0: status
         _lib.check(_lib.lib().avsi_lws_run_f32(_lib.ptr(s), B, M, self.fsize, self.fshift, self.fftsize, self.L,
                                                self.nofuture_iterations, self.nofuture_alpha, self.online_iterations,
                                                self.online_alpha, self.batch_iterations, self.batch_alpha, self.batch_beta,
                                                self.batch_gamma, self.utterances_per_wave, self.waves_per_group,
-                                               _lib.ptr(self._status), _lib.stream_ptr()), "avsi_lws_run_f32")
+                                               self.groups_per_utterance, _lib.ptr(self._status), self._status.numel() * 4,
+                                               _lib.stream_ptr()), "avsi_lws_run_f32")
 
     def check(self):
         """Raise if a pipeline stage of the last run gave up waiting for its predecessor (synchronises)."""
-        if self._status is not None and int(self._status.item()) != 0:
+        if self._status is not None and int(self._status[0].item()) != 0:
             raise _lib.AvsiError("LWS sweep pipeline timed out waiting for a predecessor stage; results are invalid")
 
     def istft(self, S, num_samples=None):

@@ -319,9 +319,11 @@ int avsi_istft_f32(const avsi_istft_args* args, void* stream);
  *   avsi_lws_run_f32     lws.run_lws (inference.py:148): nofuture / online / batch sweeps in place; thresholds
  *                        alpha exp(-beta j^gamma) relative to the mean magnitude of each utterance;
  *                        utterances_per_wave (1, 2, 4) x waves_per_group (1, 4, 8, 16; > 1 only with one utterance per
- *                        wave): the sweeps of an utterance run as a pipeline over that many waves -- same results --
- *                        0 = chosen from the batch; status (device int32, may be null): non-zero after the stream
- *                        has drained = a pipeline stage stopped waiting for its predecessor, outputs invalid
+ *                        wave) x groups_per_utterance (workgroups, each a CU at 16 waves): the sweeps of an utterance
+ *                        run as a pipeline over that many waves -- same results; 0 = chosen from the batch.
+ *                        workspace (avsi_lws_run_workspace_bytes(batch), zeroed by the call): word 0 is the status --
+ *                        non-zero after the stream has drained = a pipeline stage stopped waiting for its
+ *                        predecessor (all workgroups of an utterance must be resident together), outputs invalid
  *   avsi_lws_istft_f32   lws.istft  (inference.py:153): out [B][out_samples], out_samples <=
  *                        (num_frames - 1) hop + nfft - 2 (nfft - hop); workspace from avsi_lws_istft_workspace_bytes
  * ------------------------------------------------------------------------------------ */
@@ -335,7 +337,9 @@ int avsi_lws_stitch_f32(float* spec, const float* ref, const float* mask, int64_
 int avsi_lws_run_f32(float* spec, int batch, int num_frames, int frame_len, int hop, int nfft, int L,
                      int nofuture_iterations, float nofuture_alpha, int online_iterations, float online_alpha,
                      int batch_iterations, float batch_alpha, float batch_beta, float batch_gamma,
-                     int utterances_per_wave, int waves_per_group, int* status, void* stream);
+                     int utterances_per_wave, int waves_per_group, int groups_per_utterance, void* workspace,
+                     size_t workspace_bytes, void* stream);
+size_t avsi_lws_run_workspace_bytes(int batch);
 size_t avsi_lws_istft_workspace_bytes(int batch, int num_frames, int nfft);
 int avsi_lws_istft_f32(const float* spec, int batch, int num_frames, const float* table, int hop, int nfft, float* out,
                        int64_t out_stride, int out_samples, void* workspace, size_t workspace_bytes, void* stream);

@@ -67,15 +67,15 @@ def test_run_lws_matches_oracle(L, U):
 
 def test_launch_shape_does_not_change_the_result(L):
     """Utterances per wave (1, 2, 4) and waves per group (the sweeps of an utterance pipelined over 4, 8 or 16 waves,
-    each sweep trailing its predecessor by two rows): the raster-order dependences are kept exactly, so the results
+    each sweep trailing its predecessor by two rows, over one or several workgroups): the raster-order dependences are kept exactly, so the results
     are bit-identical to one wave running the sweeps one after the other."""
     kw = dict(fftsize=512, mode='speech')
     o = OL.LWS(384, 192, **kw)
     S0 = np.stack([np.abs(o.stft(_speechlike(4800, 30 + i))) for i in range(5)]).astype(np.complex64)
     ref = L.lws(384, 192, utterances_per_wave=1, waves_per_group=1, **kw).run_lws(S0)
-    for U, NW in ((2, 1), (4, 1), (1, 4), (1, 8), (1, 16)):
-        out = L.lws(384, 192, utterances_per_wave=U, waves_per_group=NW, **kw).run_lws(S0)
-        assert np.array_equal(ref, out), (U, NW)
+    for U, NW, G in ((2, 1, 1), (4, 1, 1), (1, 4, 1), (1, 8, 1), (1, 16, 1), (1, 16, 3), (1, 16, 7), (1, 8, 5), (1, 16, 0)):
+        out = L.lws(384, 192, utterances_per_wave=U, waves_per_group=NW, groups_per_utterance=G, **kw).run_lws(S0)
+        assert np.array_equal(ref, out), (U, NW, G)
 
 
 def test_refine_enhanced_matches_oracle(L):
