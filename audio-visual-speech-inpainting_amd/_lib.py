@@ -94,6 +94,9 @@ PROTOTYPES = {
                                   c_void_p]),
     "avsi_bn_act_pool_f32": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
                                      c_void_p, c_void_p, c_void_p]),
+    "avsi_conv2d_thin_mfma_supported": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int]),
+    "avsi_conv2d_thin_mfma_f32": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p,
+                                          c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p]),
     "avsi_conv2d_thin_relu_pool_f32": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_int,
                                                c_void_p, c_int, c_void_p]),
     "avsi_bn_act_f32": (c_int, [c_void_p, c_int64, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p,

@@ -215,6 +215,90 @@ __global__ __launch_bounds__(256) void conv7_c1_mfma_kernel(const float* __restr
     }
 }
 
+// Convolutions with few channels at high resolution on v_mfma_f32_16x16x4_f32 (the decoder layer 16 + 32 -> 16 at
+// 64 x 64 and the encoder layer 16 -> 32, 5 x 5, at 64 x 64): as implicit GEMMs on the 128 x 32 tile of gemm.hip they
+// run at 41 / 83 TFLOP/s -- a 16-channel output fills half of every 32-column MFMA, and a wave's one 32 x 32 tile
+// re-reads both operands from LDS for every MFMA.  Here a workgroup owns 4 x 32 output pixels; their input patch
+// ((4 + KS - 1) x (32 + KS - 1) pixels, all CT channels of [skip, up2x(coarse)], channel pitch CT + 1: pixel-strided
+// reads are conflict-free) and the whole filter sit in LDS; a wave owns one row = two groups of 16 pixels, and a
+// group is a 16 x (KS^2 CT) by (KS^2 CT) x COUT product in k-steps of four channels of one tap: lane l supplies
+// A[pixel l % 16][channel 4 kk' + l / 16] (one ds_read_b32 from the patch) and B[.][output channel l % 16] (one from
+// the filter); D[pixel 4 (l / 16) + i][channel l % 16].
+template <int KS, int C0, int C1, int COUT>
+__global__ __launch_bounds__(256) void thin_mfma_conv_kernel(const float* __restrict__ s0, int ld0, const float* __restrict__ s1,
+                                                             int ld1, const float* __restrict__ filt, int ldf,
+                                                             const float* __restrict__ bias, float* __restrict__ out, int ldo,
+                                                             int H, int W, const float* __restrict__ zeros) {
+    constexpr int P = KS / 2, CT = C0 + C1, CP = CT + 1, TH = 4, TW = 32, PH = TH + KS - 1, PWD = TW + KS - 1;
+    constexpr int NCG = COUT / 16, KSTEPS = KS * KS * CT / 4, CQ = CT / 4;
+    extern __shared__ __attribute__((aligned(16))) float smem_f[];
+    float* patch = smem_f;                           // [PH][PWD][CP]
+    float* wts = smem_f + PH * PWD * CP;             // [KS * KS * CT][COUT]
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int tiles_w = W / TW, tiles_h = H / TH;
+    const int tile = blockIdx.x % (tiles_w * tiles_h), b = blockIdx.x / (tiles_w * tiles_h);
+    const int h0 = (tile / tiles_w) * TH, w0 = (tile % tiles_w) * TW;
+    const int H2 = H >> 1, W2 = W >> 1;
+    // filter -> LDS (rows of COUT floats, 16-byte pieces)
+    for (int i = tid; i < KS * KS * CT * (COUT / 4); i += 256) {
+        const int row = i / (COUT / 4), q = i - row * (COUT / 4);
+        *reinterpret_cast<float4*>(wts + row * COUT + 4 * q) = *reinterpret_cast<const float4*>(filt + (int64_t)row * ldf + 4 * q);
+    }
+    // patch -> LDS: one float4 (four channels of one pixel) per item; pixels outside the image read a page of zeros
+    for (int i = tid; i < PH * PWD * CQ; i += 256) {
+        const int pix = i / CQ, c4 = (i - pix * CQ) * 4;
+        const int pr = pix / PWD, pc = pix - pr * PWD;
+        const int hh = h0 + pr - P, ww = w0 + pc - P;
+        const bool ok = hh >= 0 && hh < H && ww >= 0 && ww < W;
+        const float* src = zeros;
+        if (ok) {
+            if (c4 < C0) src = s0 + (((int64_t)b * H + hh) * W + ww) * ld0 + c4;
+            else src = s1 + (((int64_t)b * H2 + (hh >> 1)) * W2 + (ww >> 1)) * ld1 + (c4 - C0);
+        }
+        const float4 v = *reinterpret_cast<const float4*>(src);
+        float* d = patch + pix * CP + c4;
+        d[0] = v.x, d[1] = v.y, d[2] = v.z, d[3] = v.w;
+    }
+    __syncthreads();
+    const int px = lane & 15, kq = lane >> 4;
+    typedef float f32x4v __attribute__((ext_vector_type(4)));
+    f32x4v acc[2][NCG];
+#pragma unroll
+    for (int g = 0; g < 2; ++g)
+#pragma unroll
+        for (int n = 0; n < NCG; ++n) {
+            const float bv = bias ? bias[16 * n + px] : 0.f;
+            acc[g][n] = (f32x4v){bv, bv, bv, bv};
+        }
+    const float* prow = patch + (wv * PWD + px) * CP + kq;       // row wv of the tile, tap (0, 0), this lane's channel
+    const float* wlan = wts + kq * COUT + px;
+#pragma unroll 1
+    for (int tap = 0; tap < KS * KS; ++tap) {
+        const int dh = tap / KS, dw = tap - dh * KS;
+        const float* pa = prow + (dh * PWD + dw) * CP;
+        const float* pw = wlan + tap * CT * COUT;
+#pragma unroll
+        for (int cq = 0; cq < CQ; ++cq) {
+            const float a0 = pa[4 * cq], a1 = pa[16 * CP + 4 * cq];          // the wave's two pixel groups
+#pragma unroll
+            for (int n = 0; n < NCG; ++n) {
+                const float wv_ = pw[4 * cq * COUT + 16 * n];
+                acc[0][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, wv_, acc[0][n], 0, 0, 0);
+                acc[1][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, wv_, acc[1][n], 0, 0, 0);
+            }
+        }
+    }
+    (void)KSTEPS;
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+        const int64_t pix0 = ((int64_t)b * H + h0 + wv) * W + w0 + 16 * g + 4 * kq;
+#pragma unroll
+        for (int n = 0; n < NCG; ++n)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) out[(pix0 + i) * ldo + 16 * n + px] = acc[g][n][i];
+    }
+}
+
 template <int K, int C0, int C1, int COUT>
 __global__ __launch_bounds__(TPB) void direct_conv_kernel(const float* __restrict__ s0, int ld0, const float* __restrict__ s1,
                                                           int ld1, const float* __restrict__ filt, int ldf,
@@ -933,6 +1017,40 @@ extern "C" int avsi_bn_act_pool_f32(const float* x, int B, int H, int W, int C, 
     avsi_clear_error();
     hipLaunchKernelGGL((bn_act4_kernel<true>), dim3(grid_for((int64_t)B * (H / 2) * (W / 2) * (ld / 4))), dim3(TPB), 0,
                        (hipStream_t)stream, a, y, pooled, B, H, W);
+    return avsi_launch_status();
+}
+
+// Few-channel convolutions on the 16-wide MFMA (thin_mfma_conv_kernel): (k, C0, C1, Cout) = (3, 16, 32, 16) and (5, 16, 0, 32).
+extern "C" int avsi_conv2d_thin_mfma_supported(int k, int C0, int C1, int Cout, int H, int W) {
+    return (H % 4 == 0 && W % 32 == 0) && ((k == 3 && C0 == 16 && C1 == 32 && Cout == 16) || (k == 5 && C0 == 16 && C1 == 0 && Cout == 32));
+}
+
+extern "C" int avsi_conv2d_thin_mfma_f32(const float* src0, int C0, int ld0, const float* src1_coarse, int C1, int ld1, int B, int H,
+                                         int W, int k, const float* filter, int ldf, const float* bias, int Cout, float* out,
+                                         int ldo, const float* zeros64, void* stream) {
+    if (!src0 || !filter || !out || !zeros64 || B <= 0 || (C1 && !src1_coarse) || ldf < Cout || ldo < Cout || ld0 < C0 ||
+        (C1 && ld1 < C1))
+        return AVSI_ERR_INVALID_ARG;
+    if (!avsi_conv2d_thin_mfma_supported(k, C0, C1, Cout, H, W) || (ld0 & 3) || (ld1 & 3) || (ldf & 3) ||
+        ((reinterpret_cast<uintptr_t>(src0) | reinterpret_cast<uintptr_t>(src1_coarse) | reinterpret_cast<uintptr_t>(filter) |
+          reinterpret_cast<uintptr_t>(zeros64)) & 15))
+        return AVSI_ERR_UNSUPPORTED;
+    const dim3 grid(B * (H / 4) * (W / 32)), block(256);
+    const hipStream_t st = (hipStream_t)stream;
+    avsi_clear_error();
+    if (k == 3) {
+        constexpr size_t lds = ((size_t)6 * 34 * 49 + 9 * 48 * 16) * 4;
+        (void)hipFuncSetAttribute((const void*)thin_mfma_conv_kernel<3, 16, 32, 16>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)lds);
+        hipLaunchKernelGGL((thin_mfma_conv_kernel<3, 16, 32, 16>), grid, block, lds, st, src0, ld0, src1_coarse, ld1, filter, ldf, bias,
+                           out, ldo, H, W, zeros64);
+    } else {
+        constexpr size_t lds = ((size_t)8 * 36 * 17 + 25 * 16 * 32) * 4;
+        (void)hipFuncSetAttribute((const void*)thin_mfma_conv_kernel<5, 16, 0, 32>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)lds);
+        hipLaunchKernelGGL((thin_mfma_conv_kernel<5, 16, 0, 32>), grid, block, lds, st, src0, ld0, src1_coarse, ld1, filter, ldf, bias,
+                           out, ldo, H, W, zeros64);
+    }
     return avsi_launch_status();
 }
 

@@ -448,6 +448,24 @@ def conv2d(src0, c0, src1, c1, B, H, W, k, filt, bias, out, cout):
     return out
 
 
+def conv2d_thin_mfma_supported(k, c0, c1, cout, H, W):
+    """Few-channel layers the 16-wide-MFMA convolution takes (avsi_conv2d_thin_mfma_f32)."""
+    return os.environ.get('AVSI_CONV_THIN_MFMA', '1') != '0' and \
+        bool(_lib.lib().avsi_conv2d_thin_mfma_supported(int(k), int(c0), int(c1), int(cout), int(H), int(W)))
+
+
+def conv2d_thin_mfma(src0, c0, src1, c1, B, H, W, k, filt, bias, out, cout):
+    _lib.require_cuda(src0, src1, filt, out)
+    z = _ZEROS.get(out.device.index)
+    if z is None:
+        z = _ZEROS[out.device.index] = torch.zeros(64, dtype=torch.float32, device=out.device)
+    _lib.check(_lib.lib().avsi_conv2d_thin_mfma_f32(_lib.ptr(src0), c0, src0.stride(0), _lib.ptr(src1), c1,
+                                                    src1.stride(0) if src1 is not None else 0, B, H, W, k, _lib.ptr(filt),
+                                                    filt.stride(0), _lib.ptr(bias), cout, _lib.ptr(out), out.stride(0), _lib.ptr(z),
+                                                    _lib.stream_ptr()), "avsi_conv2d_thin_mfma_f32")
+    return out
+
+
 _THIN = {(7, 1, 0, 16), (3, 1, 16, 1), (1, 1, 0, 1)}
 
 

@@ -275,7 +275,10 @@ class UNetFConvModel(object):
             ops.conv2d_thin_relu_pool(src0, B, H, W, k, v.p(name + '/w'), v.p(name + '/b'), pooled, cout)
             return pooled
         conv = self._buf(name + '/conv', (R, ld))
-        if ops.conv2d_supported(c0, c1):
+        if ops.conv2d_thin_mfma_supported(k, c0, c1, cout, H, W):
+            # few channels at high resolution: 16-wide MFMA from an LDS patch (the 128 x 32 GEMM tile wastes half of it)
+            ops.conv2d_thin_mfma(src0, c0, src1, c1, B, H, W, k, v.p(name + '/w'), v.p(name + '/b'), conv, cout)
+        elif ops.conv2d_supported(c0, c1):
             # implicit GEMM: the operand rows are gathered from the activations by the GEMM's DMA loads
             ops.conv2d(src0, c0, src1, c1, B, H, W, k, v.p(name + '/w'), v.p(name + '/b'), conv, cout)
         elif ops.conv2d_thin_supported(k, c0, c1, cout):

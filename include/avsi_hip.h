@@ -410,6 +410,13 @@ int avsi_colstats_f32(const float* x, int64_t R, int C, int ld, float eps, float
  * the full-resolution activation (training keeps it for the backward pass).  ld % 4 == 0, 16-byte aligned. */
 int avsi_bn_act_pool_f32(const float* x, int B, int H, int W, int C, int ld, const float* mean, const float* rstd,
                          const float* gamma, const float* beta, int act, float* y, float* pooled, void* stream);
+/* Few-channel convolutions at high resolution on the 16-wide fp32 MFMA, input patch and filter in LDS (same operands as
+ * avsi_conv2d_f32): the U-Net's decoder layer 16 + 32 -> 16 (3 x 3) and encoder layer 16 -> 32 (5 x 5); H % 4 == 0,
+ * W % 32 == 0.  avsi_conv2d_thin_mfma_supported returns 1 for the shapes it takes. */
+int avsi_conv2d_thin_mfma_supported(int k, int C0, int C1, int Cout, int H, int W);
+int avsi_conv2d_thin_mfma_f32(const float* src0, int C0, int ld0, const float* src1_coarse, int C1, int ld1, int B, int H, int W,
+                              int k, const float* filter, int ldf, const float* bias, int Cout, float* out, int ldo,
+                              const float* zeros64, void* stream);
 /* The first encoder layer at inference: 7 x 7 convolution of the one-channel input, bias, ReLU and 2 x 2 max pooling
  * fused (the full-resolution 16-channel activation is never written). */
 int avsi_conv2d_thin_relu_pool_f32(const float* src0, int ld0, int B, int H, int W, int k, const float* filter, int ldf,

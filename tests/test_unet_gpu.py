@@ -313,3 +313,25 @@ def test_inference_model_fused_layers_match_training_form(mods):
     assert np.sqrt(np.mean((pi - ref['prediction']) ** 2)) < 2e-4
     gi, gt = mi.gradients.cpu().numpy(), mt.gradients.cpu().numpy()
     assert np.abs(gi - gt).max() <= 1e-6 * np.abs(gt).max() + 1e-9
+
+
+@pytest.mark.parametrize("k,c0,c1,cout,B,H,W", [(3, 16, 32, 16, 3, 64, 64), (5, 16, 0, 32, 2, 64, 64), (3, 16, 32, 16, 1, 8, 32),
+                                                (5, 16, 0, 32, 2, 4, 96)])
+def test_thin_mfma_conv_matches_implicit_gemm(k, c0, c1, cout, B, H, W):
+    """avsi_conv2d_thin_mfma_f32 (LDS patch + v_mfma_f32_16x16x4_f32) against the implicit-GEMM convolution, incl. the
+    image border, the fused 2x up-sampling + concat and tiles at the image corner."""
+    import avsi_amd  # noqa: F401
+    from avsi_amd import ops
+    assert ops.conv2d_thin_mfma_supported(k, c0, c1, cout, H, W)
+    g = torch.Generator(device='cuda')
+    g.manual_seed(k + c1)
+    R = B * H * W
+    src0 = torch.randn(R, c0, generator=g, device='cuda')
+    src1 = torch.randn(B * (H // 2) * (W // 2), c1, generator=g, device='cuda') if c1 else None
+    filt = torch.randn(k * k * (c0 + c1), cout, generator=g, device='cuda') * 0.1
+    bias = torch.randn(cout, generator=g, device='cuda')
+    ref = torch.empty(R, cout, device='cuda')
+    ops.conv2d(src0, c0, src1, c1, B, H, W, k, filt, bias, ref, cout)
+    got = torch.full((R, cout), 7.0, device='cuda')
+    ops.conv2d_thin_mfma(src0, c0, src1, c1, B, H, W, k, filt, bias, got, cout)
+    assert (got - ref).abs().max().item() < 2e-4 * ref.abs().max().item()
