@@ -163,6 +163,59 @@ extern "C" int avsi_colsum_f32(const float* x, int64_t ld, int64_t M, int N, flo
     return avsi_launch_status();
 }
 
+// tf.nn.dropout(x, rate) (reference models.py:117, on the last BLSTM layer's output in front of the projection):
+// y = x * scale, scale = 0 with probability rate, 1 / (1 - rate) otherwise.  The draw is a counter-based generator
+// (splitmix64 of seed + element index): reproducible for a given (seed, shape), independent of the launch geometry.
+// TensorFlow's own random stream cannot be reproduced, so `scale` is written out: the backward pass multiplies by it
+// and tests feed the same factors to the oracle.  Rows are [rows][ld] with `cols` live columns.
+namespace {
+__global__ __launch_bounds__(TPB) void dropout_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                      float* __restrict__ scale, int64_t rows, int cols, int ld, float rate,
+                                                      unsigned long long seed) {
+    const int64_t n = rows * cols;
+    const float keep_scale = 1.f / (1.f - rate);
+    for (int64_t e = (int64_t)blockIdx.x * TPB + threadIdx.x; e < n; e += (int64_t)gridDim.x * TPB) {
+        const int64_t r = e / cols;
+        const int c = (int)(e - r * cols);
+        unsigned long long z = seed + 0x9E3779B97F4A7C15ull * (unsigned long long)(e + 1);
+        z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+        z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+        z ^= z >> 31;
+        const float u = (float)(z >> 40) * (1.f / 16777216.f);          // 24 uniform bits in [0, 1)
+        const float sc = u >= rate ? keep_scale : 0.f;
+        const int64_t o = r * ld + c;
+        scale[o] = sc;
+        y[o] = x[o] * sc;
+    }
+}
+__global__ __launch_bounds__(TPB) void scale_rows_kernel(float* __restrict__ x, const float* __restrict__ scale, int64_t rows,
+                                                         int cols, int ld) {
+    const int64_t n = rows * cols;
+    for (int64_t e = (int64_t)blockIdx.x * TPB + threadIdx.x; e < n; e += (int64_t)gridDim.x * TPB) {
+        const int64_t r = e / cols;
+        const int64_t o = r * ld + (e - r * cols);
+        x[o] *= scale[o];
+    }
+}
+}  // namespace
+
+extern "C" int avsi_dropout_f32(const float* x, float* y, float* scale, int64_t rows, int cols, int ld, float rate,
+                                unsigned long long seed, void* stream) {
+    if (!x || !y || !scale || rows <= 0 || cols <= 0 || ld < cols || !(rate >= 0.f) || !(rate < 1.f)) return AVSI_ERR_INVALID_ARG;
+    avsi_clear_error();
+    hipLaunchKernelGGL(dropout_kernel, dim3(grid_for(rows * cols, TPB)), dim3(TPB), 0, (hipStream_t)stream, x, y, scale, rows, cols,
+                       ld, rate, seed);
+    return avsi_launch_status();
+}
+
+// x[r][c] *= scale[r][c] on the live columns (the gradient of the dropout above)
+extern "C" int avsi_scale_elements_f32(float* x, const float* scale, int64_t rows, int cols, int ld, void* stream) {
+    if (!x || !scale || rows <= 0 || cols <= 0 || ld < cols) return AVSI_ERR_INVALID_ARG;
+    avsi_clear_error();
+    hipLaunchKernelGGL(scale_rows_kernel, dim3(grid_for(rows * cols, TPB)), dim3(TPB), 0, (hipStream_t)stream, x, scale, rows, cols, ld);
+    return avsi_launch_status();
+}
+
 // internal (gemm.hip): out[i] = alpha * sum_k slabs[k * stride + i]
 int avsi_sum_slabs_launch(const float* slabs, int64_t n, int count, int64_t stride, float* out, float alpha,
                           hipStream_t st) {

@@ -142,6 +142,10 @@ class StackedBLSTM2StepsModel(object):
     def build_graph(self, var_scope=''):
         self.var_scope = var_scope
 
+    def set_dropout_rate(self, rate):
+        self.video_model.set_dropout_rate(rate)
+        self.av_model.set_dropout_rate(rate)
+
     def feed(self, sequence_lengths=None, target_sources=None, masks=None, video_features=None, **kw):
         self.video_model.feed(sequence_lengths, target_sources, masks, video_features, **kw)
         self.av_model.feed(sequence_lengths, target_sources, masks, video_features, **kw)

@@ -177,9 +177,13 @@ class StackedBLSTMModel(object):
         if input not in ('a', 'v', 'av'):
             print('Model input must be "a", "v" or "av". Closing...')
             sys.exit(1)
-        self.dropout_rate = dropout_rate
-        if dropout_rate not in (0, 0.0, None):
-            raise _lib.AvsiError("dropout_rate != 0 is not supported by the gfx950 path (reference configs use 0.0)")
+        # tf.nn.dropout on the last layer's output (models.py:117): the fed value, replaceable per feed() like the
+        # reference's dropout_rate placeholder (training feeds config['dropout_rate'], validation 0.0)
+        self.dropout_rate = float(dropout_rate or 0.0)
+        if not 0.0 <= self.dropout_rate < 1.0:
+            raise _lib.AvsiError("dropout_rate must be in [0, 1)")
+        self._dropout_seed = (int(seed) + 1) * 0x9E3779B1
+        self._dropout_calls = 0
         self.net_dim = config['net_dim']
         self.num_layers = len(self.net_dim)
         self.optimizer_choice = config['optimizer_type']
@@ -216,9 +220,13 @@ class StackedBLSTMModel(object):
 
     # ---------------------------------------------------------------- feed boundary
     def feed(self, sequence_lengths=None, target_sources=None, masks=None, video_features=None,
-             audio_features=None, audio_feat_mean=None, audio_feat_std=None):
+             audio_features=None, audio_feat_mean=None, audio_feat_std=None, dropout_rate=None):
         """Replace the fed values (the reference's feed_dict, training.py:67-74) and drop cached results."""
         self._cache = {}
+        if dropout_rate is not None:
+            if not 0.0 <= float(dropout_rate) < 1.0:
+                raise _lib.AvsiError("dropout_rate must be in [0, 1)")
+            self.dropout_rate = float(dropout_rate)
         if sequence_lengths is not None:
             new_len = np.asarray(sequence_lengths.cpu() if isinstance(sequence_lengths, torch.Tensor) else sequence_lengths,
                                  dtype=np.int64)
@@ -238,6 +246,13 @@ class StackedBLSTMModel(object):
             self.audio_feat_mean = _as_device(audio_feat_mean, device=self.device)
         if audio_feat_std is not None:
             self.audio_feat_std = _as_device(audio_feat_std, device=self.device)
+
+    def set_dropout_rate(self, rate):
+        """The fed value of the reference's dropout_rate placeholder for the following steps (training_emb.py:251
+        feeds config['dropout_rate'] when training, :314,326 feed 0.0 when validating)."""
+        if not 0.0 <= float(rate) < 1.0:
+            raise _lib.AvsiError("dropout_rate must be in [0, 1)")
+        self.dropout_rate = float(rate)
 
     def build_graph(self, var_scope=''):
         """Kept for API parity (reference models.py:74-87): variables already exist."""
@@ -343,6 +358,16 @@ class StackedBLSTMModel(object):
                 # fill comes after it (nothing reads the column before the backward pass)
                 x[:, :B, self.layout.ones_col[li]] = 1.0
             x = hout
+        if self.dropout_rate > 0.0:
+            # rnn_outputs_res = tf.nn.dropout(rnn_outputs, rate) (models.py:117): the projection (and its weight
+            # gradient) sees the dropped activations, the BPTT below receives dh * scale; a fresh draw per forward pass
+            xd = self._buf('rnn_drop', (T, Bp, 2 * HP), zero=True)
+            sc = self._buf('drop_scale', (T, Bp, 2 * HP), zero=True)
+            self._dropout_calls += 1
+            ops.dropout(x.view(T * Bp, 2 * HP), xd.view(T * Bp, 2 * HP), sc.view(T * Bp, 2 * HP), 2 * HP, self.dropout_rate,
+                        self._dropout_seed + self._dropout_calls * 0x632BE5AB)
+            c['drop_scale'] = sc
+            x = xd
         if keep and self.layout.ones_col_top >= 0:
             x[:, :B, self.layout.ones_col_top] = 1.0
         c['rnn_out'] = x
@@ -544,6 +569,8 @@ class StackedBLSTMModel(object):
         on_side(head_grads)
         dh = self._buf('dh', (T, Bp, 2 * HP))
         ops.gemm(dlog2, v.p('pw'), out=dh.view(M, 2 * HP), trans_b=True, m=M, n=2 * HP, k=ldp)
+        if c.get('drop_scale') is not None:
+            ops.scale_elements(dh.view(M, 2 * HP), c['drop_scale'].view(M, 2 * HP), 2 * HP)      # gradient of the dropout
         for li in range(self.num_layers - 1, -1, -1):
             kp = lay.kp[li]
             dz = self._buf('dz%d' % li if overlap else 'dz', (T, Bp, 2 * GP))

@@ -41,6 +41,23 @@ def gemm(a, b, out=None, trans_a=False, trans_b=False, m=None, n=None, k=None, a
     return out
 
 
+def dropout(x, y, scale, cols, rate, seed):
+    """y = x * scale on the first `cols` columns of the 2-D views x / y / scale (same pitch), scale drawn per element:
+    0 with probability rate, else 1 / (1 - rate) (avsi_dropout_f32, tf.nn.dropout of models.py:117)."""
+    _lib.require_cuda(x, y, scale)
+    _lib.check(_lib.lib().avsi_dropout_f32(_lib.ptr(x), _lib.ptr(y), _lib.ptr(scale), x.shape[0], int(cols), x.stride(0),
+                                           float(rate), int(seed) & 0xFFFFFFFFFFFFFFFF, _lib.stream_ptr()), "avsi_dropout_f32")
+    return y
+
+
+def scale_elements(x, scale, cols):
+    """x *= scale on the first `cols` columns (avsi_scale_elements_f32)."""
+    _lib.require_cuda(x, scale)
+    _lib.check(_lib.lib().avsi_scale_elements_f32(_lib.ptr(x), _lib.ptr(scale), x.shape[0], int(cols), x.stride(0),
+                                                  _lib.stream_ptr()), "avsi_scale_elements_f32")
+    return x
+
+
 def pack_bf16x3_b(b):
     """Split the weight matrix b [K, N] (float32, unit inner stride) into bf16 hi / lo planes in MFMA fragment order
     (avsi_pack_bf16x3_b); returns the packed buffer for gemm_bf16x3."""

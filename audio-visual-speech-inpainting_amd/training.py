@@ -309,6 +309,7 @@ def train(config_file, checkpoint_format=None):
                 break
             n_step += 1
             tot_step += 1
+            model.set_dropout_rate(config['dropout_rate'])          # training_emb.py:251
             model.feed(**feed)
             vals, lr = fetch(True), model.learning_rate
             model.train_op
@@ -328,6 +329,7 @@ def train(config_file, checkpoint_format=None):
             except OutOfRangeError:
                 break
             n_step += 1
+            model.set_dropout_rate(0.0)                             # training_emb.py:314,326
             model.feed(**feed)
             val_avg, nframe_sum = accumulate(val_avg, resolve(fetch(False)), nframe_sum, np.count_nonzero(batch[-1] == 0),
                                              n_step == 1)

@@ -155,6 +155,9 @@ class UNetFConvModel(object):
         self.feed(sequence_lengths=sequence_lengths, target_sources=target_sources, masks=masks)
 
     # ------------------------------------------------------------------ feed boundary
+    def set_dropout_rate(self, rate):
+        """The reference's U-Net takes the dropout_rate placeholder and never uses it (models.py:519-715)."""
+
     def feed(self, sequence_lengths=None, target_sources=None, masks=None, audio_feat_mean=None, audio_feat_std=None,
              **_unused):
         self._cache = {}

@@ -140,6 +140,13 @@ int avsi_pack_bf16x3_b(const float* B, int64_t ldb, int K, int N, void* packed, 
 int avsi_gemm_bf16x3_f32(int M, int N, int K, const float* A, int64_t lda, const void* packed_b, const float* bias,
                          float* C, int64_t ldc, void* stream);
 
+/* tf.nn.dropout(x, rate) on the last BLSTM layer's output in front of the projection (models.py:117): y = x * scale over
+ * [rows][ld] with `cols` live columns, scale = 0 with probability rate, else 1 / (1 - rate), from a counter-based
+ * generator (seed + element index).  `scale` is written out for the backward pass (avsi_scale_elements_f32: x *= scale). */
+int avsi_dropout_f32(const float* x, float* y, float* scale, int64_t rows, int cols, int ld, float rate,
+                     unsigned long long seed, void* stream);
+int avsi_scale_elements_f32(float* x, const float* scale, int64_t rows, int cols, int ld, void* stream);
+
 /* ------------------------------------------------------------------------------------
  * L1 loss and its diagnostics over [n] elements (models.py:144-151):
  *   out[0] = mean|t-p|, out[1] = sum|t-p|(1-m)/sum(1-m), out[2] = sum|t-p|m/sum(m)

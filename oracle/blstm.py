@@ -129,12 +129,16 @@ def sequence_mask(seq_len, T, dtype):
     return (np.arange(T)[None, :] < np.asarray(seq_len)[:, None]).astype(dtype)
 
 
-def inference(net_inputs, params, keep=False):
-    """models.py:89-125 with dropout rate 0 (identity, App. A.8)."""
+def inference(net_inputs, params, keep=False, drop_scale=None):
+    """models.py:89-125.  ``drop_scale`` [B, T, 2H]: the factor tf.nn.dropout(rnn_outputs, rate) multiplies each
+    element with (0 for a dropped element, 1 / (1 - rate) for a kept one; models.py:117); None = rate 0, the identity
+    (App. A.8).  The random draw itself cannot be restated (TensorFlow's generator), so the factor is an input."""
     if keep:
         rnn, caches = blstm_stack(net_inputs, params, True)
     else:
         rnn = blstm_stack(net_inputs, params)
+    if drop_scale is not None:
+        rnn = rnn * np.asarray(drop_scale, dtype=rnn.dtype)
     B, T, C = rnn.shape
     logits = rnn.reshape(B * T, C) @ params['proj']['weights'] + params['proj']['biases']
     logits = logits.reshape(B, T, -1)
@@ -173,7 +177,7 @@ def net_inputs(audio_features, video_features, input_type):
 
 
 def model_forward(wav, masks, mean, std, seq_len, params, video=None, input_type='a',
-                  dtype=np.float64, l2=0.0, keep=False):
+                  dtype=np.float64, l2=0.0, keep=False, drop_scale=None):
     """Whole StackedBLSTMModel forward from the feed boundary (training.py:67-74):
     wav [B, N], masks [B, T, F], mean/std [F], seq_len [B] -> dict of every tensor the
     reference drivers fetch."""
@@ -184,9 +188,9 @@ def model_forward(wav, masks, mean, std, seq_len, params, video=None, input_type
                                                       audio_feat_dim=masks.shape[2], max_len=T)
     x = net_inputs(feats, video, input_type)
     if keep:
-        logits, rnn, caches = inference(x, p, True)
+        logits, rnn, caches = inference(x, p, True, drop_scale)     # rnn: AFTER dropout (what the projection saw)
     else:
-        logits = inference(x, p)
+        logits = inference(x, p, drop_scale=drop_scale)
     pred = prediction(logits, seq_len)
     out = {'target_stft': stft_c, 'target_spec_norm': norm, 'audio_features': feats,
            'net_inputs': x, 'inference': logits, 'prediction': pred}
@@ -195,6 +199,7 @@ def model_forward(wav, masks, mean, std, seq_len, params, video=None, input_type
         out['rnn_outputs'] = rnn
         out['caches'] = caches
         out['params'] = p
+        out['drop_scale'] = None if drop_scale is None else np.asarray(drop_scale, dtype=dtype)
     return out
 
 
@@ -266,6 +271,8 @@ def model_backward(fwd, masks, seq_len, l2=0.0):
     grads['proj']['weights'] = rnn.reshape(B * T, -1).T @ dl2
     grads['proj']['biases'] = dl2.sum(axis=0)
     dout = (dl2 @ p['proj']['weights'].T).reshape(B, T, -1)
+    if fwd.get('drop_scale') is not None:
+        dout = dout * fwd['drop_scale']              # gradient of tf.nn.dropout: the same factor
     for li in range(len(p['layers']) - 1, -1, -1):
         layer, cache = p['layers'][li], fwd['caches'][li]
         H = layer['fw']['kernel'].shape[1] // 4

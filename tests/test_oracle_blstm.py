@@ -5,6 +5,7 @@ import pytest
 import torch
 
 from oracle import blstm as O
+from oracle import frontend as F
 
 
 def _perm_ijfo_to_ifgo(w, H):
@@ -162,3 +163,31 @@ def test_model_forward_shapes_and_padded_frames_run_through_recurrence():
     np.testing.assert_array_equal(short['prediction'][1, 9:], 0)
     # frames before the cut are identical: the backward direction still started at t = T-1
     np.testing.assert_allclose(short['prediction'][1, :9], full['prediction'][1, :9], atol=0)
+
+
+def test_dropout_factor_gradient_matches_autograd():
+    """model_forward(drop_scale=...) / model_backward: the gradient through tf.nn.dropout (models.py:117) is the same
+    factor; checked against torch.autograd on a tiny model."""
+    import torch
+    rng = np.random.default_rng(21)
+    B, N, T = 2, 960, 5
+    wav = np.round(rng.normal(0, 3000, size=(B, N))).astype(np.float32)
+    masks = np.ones((B, T, 257), dtype=np.float32)
+    masks[:, 2:4] = 0
+    spec = F.get_spectrogram(F.get_stft(wav, window_size=24, step_size=12), log=True)
+    mean, std = F.feature_stats(list(spec))
+    p = O.init_params(2, 257, (6, 6), 257)
+    seq = np.full(B, T)
+    drop = (rng.uniform(size=(B, T, 12)) > 0.3) / 0.7
+    fwd = O.model_forward(wav, masks, mean, std, seq, p, keep=True, drop_scale=drop)
+    grads = O.model_backward(fwd, masks.astype(np.float64), seq)
+    # torch: the projection part with autograd on the dropped activations
+    w = torch.tensor(O.cast_params(p, np.float64)['proj']['weights'], requires_grad=True)
+    b = torch.tensor(O.cast_params(p, np.float64)['proj']['biases'], requires_grad=True)
+    h = torch.tensor(fwd['rnn_outputs'])
+    pred = (h.reshape(B * T, -1) @ w + b).reshape(B, T, -1)
+    loss = (torch.tensor(fwd['target_spec_norm']) - pred).abs().mean()
+    loss.backward()
+    np.testing.assert_allclose(grads['proj']['weights'], w.grad.numpy(), atol=1e-12)
+    np.testing.assert_allclose(grads['proj']['biases'], b.grad.numpy(), atol=1e-12)
+    assert np.all(fwd['rnn_outputs'][drop == 0] == 0)
