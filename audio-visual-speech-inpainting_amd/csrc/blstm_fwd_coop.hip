@@ -36,13 +36,17 @@ constexpr int HP = 256, GP = 4 * HP;
 constexpr int PSTRIDE = 36;                          // LDS pitch of one unit's 32 rows (+4: conflict-free b128)
 constexpr int PART_FLOATS = 8 * 4 * 32 * PSTRIDE;    // [wave][gate][unit][row]
 constexpr unsigned SPIN_LIMIT = 1u << 22;
+// One 256-byte line per step counter.  Packed counters (16 to a line) made every poller and every increment of
+// 16 groups queue on one memory channel: at 512 workgroups that, not the exchange itself, set the step time
+// (column-split kernel, 1024 utterances: 5.9 -> 3.0 ms per layer from this alone).
+constexpr int CTR_STRIDE = 64;
 
 struct CoopArgs {
     const float* xproj;
     const float* whp;
     float* hout;
     float* resv;
-    unsigned* sync;    // [0] status, [1 + group] step counters
+    unsigned* sync;    // [0] status, [CTR_STRIDE * (1 + group)] step counters
     int T, Bp, ngroups;
     int tile0;         // first 32-utterance tile of this launch (large batches run in resident-sized chunks)
 };
@@ -111,7 +115,7 @@ __global__ __launch_bounds__(512, 2) void blstm_rec_fwd_coop_kernel(const CoopAr
 #pragma unroll
     for (int c = 0; c < CPL; ++c) cstate[c] = 0.f;
 
-    unsigned* ctr = a.sync + 1 + 2 * a.tile0 + group;
+    unsigned* ctr = a.sync + CTR_STRIDE * (1 + 2 * a.tile0 + group);
     __syncthreads();
 
     for (int step = 0; step < T; ++step) {
@@ -269,7 +273,7 @@ __global__ __launch_bounds__(512, 2) void blstm_rec_fwd_coop_fine_kernel(const C
     const bool fin = frow < 32;
     float cstate = 0.f;
 
-    unsigned* ctr = a.sync + 1 + 2 * a.tile0 + group;
+    unsigned* ctr = a.sync + CTR_STRIDE * (1 + 2 * a.tile0 + group);
     __syncthreads();
 
     for (int step = 0; step < T; ++step) {
@@ -384,7 +388,7 @@ int launch_coop(const CoopArgs& a, hipStream_t st) {
 
 // word 0: status, then step counters: one per (tile, direction), two for the half-tile BPTT kernel
 extern "C" size_t avsi_blstm_rec_fwd_coop_workspace_bytes(int Bp) {
-    return (size_t)(1 + 4 * (Bp > 0 ? Bp / 32 : 0)) * sizeof(unsigned);
+    return (size_t)CTR_STRIDE * (1 + 4 * (Bp > 0 ? Bp / 32 : 0)) * sizeof(unsigned);
 }
 
 // Tiles per launch: the whole launch must be resident (one workgroup per CU) on the `max_cus` compute units the
@@ -489,7 +493,7 @@ __global__ __launch_bounds__(512, 2) void blstm_rec_bwd_coop_kernel(const CoopBw
     float dcn[CPL];
 #pragma unroll
     for (int c = 0; c < CPL; ++c) dcn[c] = 0.f;
-    unsigned* ctr = a.sync + 1 + 2 * a.tile0 + group;
+    unsigned* ctr = a.sync + CTR_STRIDE * (1 + 2 * a.tile0 + group);
     __syncthreads();
 
     for (int s = 0; s < T; ++s) {
@@ -622,7 +626,7 @@ __global__ __launch_bounds__(512, 2) void blstm_rec_bwd_coop_fine_kernel(const C
     const bool fin = frow < 16 * NR;
     const int unit = w * 32 + u0 + fu;
     float dcn = 0.f;
-    unsigned* ctr = a.sync + 1 + RH * (2 * a.tile0 + group) + half;
+    unsigned* ctr = a.sync + CTR_STRIDE * (1 + RH * (2 * a.tile0 + group) + half);
     __syncthreads();
 
     for (int s = 0; s < T; ++s) {

@@ -88,7 +88,8 @@ def gemm_bf16x3(a, b_packed, out, k, bias=None):
 
 def blstm_rec_fwd(xproj, whp, hout, reserve=None, rows_per_wg=0, split=None):
     """All T steps of both directions of one layer (avsi_blstm_rec_fwd_f32, or its small-batch
-    cooperative form avsi_blstm_rec_fwd_coop_f32: `split` 4 / 8 forces it, 0 forbids it, None = by Bp).
+    cooperative form avsi_blstm_rec_fwd_coop_f32: `split` 4 / 8 / 16 / 32 forces it, 0 forbids it, None = by Bp;
+    `split` -16 / -32 = the column-split kernel avsi_blstm_rec_fwd_cs_f32 with that many utterances per group).
     xproj [T, Bp, 2048], whp [2 * 262144], hout [T, Bp, 512], reserve [T, Bp, 2, 5, 256] or None."""
     _lib.require_cuda(xproj, whp, hout, reserve)
     T, Bp = xproj.shape[0], xproj.shape[1]
@@ -99,6 +100,13 @@ def blstm_rec_fwd(xproj, whp, hout, reserve=None, rows_per_wg=0, split=None):
     if reserve is not None and (tuple(reserve.shape) != (T, Bp, 2, 5, 256) or not reserve.is_contiguous()):
         raise _lib.AvsiError("blstm_rec_fwd: bad reserve shape")
     split = coop_split(Bp) if (rows_per_wg == 0 and split is None) else int(split or 0)
+    if split < 0:
+        ws = _coop_ws(xproj.device, Bp, _lib.lib().avsi_blstm_rec_fwd_cs_workspace_bytes(Bp))
+        _lib.check(_lib.lib().avsi_blstm_rec_fwd_cs_f32(_lib.ptr(xproj), _lib.ptr(whp), _lib.ptr(hout), _lib.ptr(reserve), T, Bp,
+                                                        -split, coop_cu_budget(), _lib.ptr(ws), ws.numel() * 4,
+                                                        _lib.stream_ptr()), "avsi_blstm_rec_fwd_cs_f32")
+        _coop_after_launch(xproj.device, ws)
+        return hout
     if split:
         L = _lib.lib()
         ws = _coop_ws(xproj.device, Bp)
@@ -117,10 +125,10 @@ _COOP_WS, _COOP_STICKY, _COOP_HOST = {}, {}, {}      # all keyed by (device inde
 _COOP_MSG = "cooperative recurrent kernel timed out waiting for a peer workgroup; results are invalid"
 
 
-def _coop_ws(device, Bp):
+def _coop_ws(device, Bp, need=None):
     """Step counters of the cooperative kernels: one buffer per (device, stream) -- launches on one
     stream run in order and may share it, launches on different streams may overlap and must not."""
-    need = _lib.lib().avsi_blstm_rec_fwd_coop_workspace_bytes(Bp)
+    need = max(need or 0, _lib.lib().avsi_blstm_rec_fwd_coop_workspace_bytes(Bp))
     key = (device.index, _lib.stream_ptr().value)
     ws = _COOP_WS.get(key)
     if ws is None or ws.numel() * 4 < need:
@@ -176,22 +184,26 @@ def occupy_cus(num_cus, release, max_ms=5000):
 
 
 def coop_split(Bp, backward=False):
-    """Workgroups per (32-utterance tile, direction) of the small-batch recurrent kernels, 0 = use the
-    batch-stationary kernels.  The cooperative grid must be resident on the 256 CUs at once, and the
-    fewer utterances there are, the finer the hidden state is cut (measured per layer, T = 250:
-    Bp = 32: 1.81 ms at 8, 1.04 at 16, 0.83 at 32; Bp = 256: 1.89 / 1.37 / 2.78)."""
+    """Which small-batch recurrent kernel runs a layer: > 0 = workgroups per (32-utterance tile, direction) of the
+    reduction-split cooperative kernels, < 0 = the column-split kernel with that many utterances per group of 8
+    workgroups (forward only), 0 = the batch-stationary kernels.  A cooperative grid must be resident at once, and
+    the fewer utterances there are, the finer the hidden state is cut.  Measured per layer, T = 250, ms (forward):
+    Bp = 32: 1.81 at 8, 1.02 at 16, 0.82 at 32; 256: 1.87 / 1.09 / 2.11; 512: 1.91 at 8, 1.55 column-split by 16;
+    1024: 2.97 at 4, 2.78 column-split by 32."""
     if os.environ.get('AVSI_REC_COOP', '1') == '0':
         return 0
     if backward:
-        # BPTT: 16 unit slices x 2 halves of 16 utterances up to four tiles (1.08 ms per layer at Bp = 32
-        # against 1.76 at 8), then the 8-way kernel
+        # BPTT: 16 unit slices x 2 halves of 16 utterances up to four tiles (0.94 ms per layer at Bp = 32
+        # against 1.75 at 8), then the 8-way kernel
         split = 32 if Bp <= 128 else (8 if Bp <= 512 else (4 if Bp <= 2048 else 0))
-    elif Bp <= 64:
+    elif Bp <= 128:
         split = 32
     elif Bp <= 256:
         split = 16
+    elif os.environ.get('AVSI_REC_CS', '1') != '0':
+        split = -16 if Bp <= 512 else (-32 if Bp <= 2048 else 0)  # 1024 < Bp <= 2048: two resident-sized launches
     else:
-        split = 8 if Bp <= 512 else (4 if Bp <= 2048 else 0)      # 1024 < Bp <= 2048: two resident-sized launches
+        split = 8 if Bp <= 512 else (4 if Bp <= 2048 else 0)
     # coop_cu_budget(): CUs one cooperative launch may occupy (default: the chip; see set_coop_cu_budget).  A
     # batch that fits the budget in one launch at a coarser split takes that; beyond it the C side cuts the batch
     # into resident-sized launches.  The bounded spin catches an over-subscription anyway.
@@ -199,6 +211,12 @@ def coop_split(Bp, backward=False):
     if forced and split:
         return int(forced)
     budget = coop_cu_budget()
+    if split < 0:
+        if budget < 4:                                # 8 workgroups, two to a CU
+            return 0
+        if split == -16 and 2 * (Bp // 16) * 8 > 2 * budget:      # by 16 does not fit one launch, by 32 does
+            split = -32
+        return split
     while split > 4 and 2 * (Bp // 32) * split > budget:
         split //= 2
     while split > 4 and 2 * split > budget:       # not even one tile fits at this split

@@ -182,6 +182,23 @@ int avsi_blstm_rec_bwd_coop_f32(const float* dhout, const float* reserve, const 
                                 int T, int Bp, int split, int max_cus, void* workspace, size_t workspace_bytes,
                                 void* stream);
 
+/* Mid-batch form of avsi_blstm_rec_fwd_f32 (same operands and results; reference models.py:95-115): groups of 8
+ * workgroups own (`rows_per_group` = 16 or 32 utterances, direction); the waves of a workgroup split the gate COLUMNS
+ * (4 hidden units each, their piece of the recurrent kernel in registers for all T steps), so there are no partial
+ * sums to park and two workgroups share a compute unit -- one's wait for its peers hides under the other's MFMAs.
+ * Same exchange protocol, workspace word 0 and `max_cus` meaning as avsi_blstm_rec_fwd_coop_f32; a launch holds
+ * 2 * max_cus workgroups (the occupancy the runtime reports), larger batches run as consecutive launches. */
+size_t avsi_blstm_rec_fwd_cs_workspace_bytes(int Bp);
+/* (utterance tile, direction) groups one launch of the kernel holds on `max_cus` compute units (needs a GPU). */
+int avsi_blstm_rec_fwd_cs_groups_per_launch(int rows_per_group, int with_reserve, int max_cus);
+int avsi_blstm_rec_fwd_cs_f32(const float* xproj, const float* whp, float* hout, float* reserve,
+                              int T, int Bp, int rows_per_group, int max_cus, void* workspace,
+                              size_t workspace_bytes, void* stream);
+
+/* Diagnostic: while `buffer` (device memory, 32 * 8 * 2 * 8 uint64) is set, avsi_blstm_rec_fwd_cs_f32 records the
+ * 100 MHz wall clock at eight phases of steps 64 .. 71 for waves 0 and 1 of its first 32 workgroups; NULL ends it. */
+int avsi_diag_cs_stamps(void* buffer);
+
 /* Diagnostic: park `num_cus` workgroups, each claiming a whole compute unit (160 KiB of LDS), on `stream` until
  * *release (device int32) becomes non-zero or ~`max_ms` milliseconds have passed (every workgroup leaves by itself).
  * Stands in for the CUs an RCCL collective holds while the cooperative kernels run (tests/test_coop_residency_gpu.py). */

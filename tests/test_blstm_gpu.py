@@ -205,7 +205,10 @@ def test_feed_reuses_model_and_variables(mods):
 @pytest.mark.parametrize("Bp,split,save", [(32, 8, False), (64, 8, True), (512, 8, False), (1024, 4, True), (96, 4, False),
                                            (1056, 4, False), (544, 8, True),    # these two: more than one resident-sized launch
                                            (32, 16, False), (256, 16, True), (288, 16, False),   # finer splits: 16 / 8 units per
-                                           (64, 32, True), (160, 32, False)])                     # workgroup (288, 160: two launches)
+                                           (64, 32, True), (160, 32, False),                      # workgroup (288, 160: two launches)
+                                           # column-split kernel (avsi_blstm_rec_fwd_cs_f32): 16 / 32 utterances per group
+                                           (32, -32, False), (64, -16, True), (512, -16, False), (1024, -32, True),
+                                           (1088, -32, False), (544, -16, True)])                 # these two: two launches
 def test_cooperative_small_batch_kernel_matches_batch_stationary(Bp, split, save):
     """avsi_blstm_rec_fwd_coop_f32 (weights resident in registers, h exchanged through hout with a
     per-step counter) against avsi_blstm_rec_fwd_f32 on the same operands: same maths, different
@@ -215,7 +218,7 @@ def test_cooperative_small_batch_kernel_matches_batch_stationary(Bp, split, save
     from avsi_amd import ops
     T = 37
     g = torch.Generator(device='cuda')
-    g.manual_seed(Bp + split)
+    g.manual_seed(Bp + abs(split))
     xproj = torch.randn(T, Bp, 2048, generator=g, device='cuda')
     whp = torch.randn(2 * 262144, generator=g, device='cuda') * 0.05
     outs = []
@@ -230,7 +233,7 @@ def test_cooperative_small_batch_kernel_matches_batch_stationary(Bp, split, save
         np.testing.assert_allclose(outs[1][1].cpu().numpy(), outs[0][1].cpu().numpy(), rtol=0, atol=5e-5)
     assert ops.coop_split(32) == 32 and ops.coop_split(32, backward=True) == 32 and ops.coop_split(256) == 16
     assert ops.coop_split(256, backward=True) == 8
-    assert ops.coop_split(512) == 8 and ops.coop_split(1024) == 4 and ops.coop_split(2048) == 4 and ops.coop_split(4096) == 0
+    assert ops.coop_split(512) == -16 and ops.coop_split(1024) == -32 and ops.coop_split(2048) == -32 and ops.coop_split(4096) == 0
 
 
 @pytest.mark.parametrize("Bp,split", [(32, 8), (256, 8), (1024, 4), (64, 4), (1088, 4), (32, 16), (256, 16), (288, 16), (32, 32), (128, 32), (160, 32)])

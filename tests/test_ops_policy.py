@@ -6,14 +6,20 @@ from avsi_amd import ops
 def test_cooperative_split_policy(monkeypatch):
     monkeypatch.delenv('AVSI_COOP_CUS', raising=False)
     monkeypatch.delenv('AVSI_REC_COOP', raising=False)
-    fwd = {b: ops.coop_split(b) for b in (32, 64, 96, 256, 288, 512, 544, 2048, 2080)}
-    assert fwd == {32: 32, 64: 32, 96: 16, 256: 16, 288: 8, 512: 8, 544: 4, 2048: 4, 2080: 0}
+    monkeypatch.delenv('AVSI_REC_CS', raising=False)
+    fwd = {b: ops.coop_split(b) for b in (32, 64, 96, 128, 160, 256, 288, 512, 544, 2048, 2080)}
+    # < 0: the column-split kernel, that many utterances per group of 8 workgroups, two workgroups to a CU
+    assert fwd == {32: 32, 64: 32, 96: 32, 128: 32, 160: 16, 256: 16, 288: -16, 512: -16, 544: -32, 2048: -32, 2080: 0}
     bwd = {b: ops.coop_split(b, backward=True) for b in (32, 128, 160, 512, 544, 2048, 4096)}
     assert bwd == {32: 32, 128: 32, 160: 8, 512: 8, 544: 4, 2048: 4, 4096: 0}
     # every single-launch choice fits the chip: members = 2 directions x tiles x split <= 256 CUs
     for b in range(32, 513, 32):
         for back in (False, True):
-            assert 2 * (b // 32) * ops.coop_split(b, back) <= 256, (b, back)
+            sp = ops.coop_split(b, back)
+            assert (2 * (b // 32) * sp <= 256) if sp > 0 else (2 * (b // -sp) * 8 <= 512), (b, back)
+    monkeypatch.setenv('AVSI_REC_CS', '0')
+    assert ops.coop_split(512) == 8 and ops.coop_split(1024) == 4
+    monkeypatch.delenv('AVSI_REC_CS')
     # a process that shares the chip between 8 streams gives each launch 32 CUs
     monkeypatch.setenv('AVSI_COOP_CUS', '32')
     assert ops.coop_split(32) == 16 and ops.coop_split(32, backward=True) == 16 and ops.coop_split(64) == 8
@@ -33,9 +39,9 @@ def test_cu_budget_leaves_room_for_concurrent_collectives(monkeypatch):
         for b in range(32, 2049, 32):
             for back in (False, True):
                 s = ops.coop_split(b, back)
-                assert s in (4, 8, 16, 32) and 2 * s <= 224
+                assert s in (4, 8, 16, 32, -16, -32) and 2 * abs(s) <= 224
                 if b <= 384:
-                    assert 2 * (b // 32) * s <= 224, (b, back, s)
+                    assert (2 * (b // 32) * s <= 224) if s > 0 else (2 * (b // -s) * 8 <= 2 * 224), (b, back, s)
         ops.set_coop_cu_budget(40)
         assert ops.coop_split(32) == 16 and 2 * ops.coop_split(32) <= 40
     finally:

@@ -7,7 +7,7 @@ import avsi_amd  # noqa: F401
 from avsi_amd import ops
 
 T = int(sys.argv[1]) if len(sys.argv) > 1 else 250
-for Bp in (32, 64, 128, 256, 512):
+for Bp in [int(x) for x in sys.argv[2:]] or (32, 64, 128, 256, 512):
     dh = torch.randn(T, Bp, 512, device='cuda')
     resv = torch.rand(T, Bp, 2, 5, 256, device='cuda') * 0.9 + 0.05
     whbt = torch.randn(2 * 262144, device='cuda') * 0.05
