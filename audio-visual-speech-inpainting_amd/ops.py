@@ -193,9 +193,9 @@ def coop_split(Bp, backward=False):
     if os.environ.get('AVSI_REC_COOP', '1') == '0':
         return 0
     if backward:
-        # BPTT: 16 unit slices x 2 halves of 16 utterances up to four tiles (0.94 ms per layer at Bp = 32
-        # against 1.75 at 8), then the 8-way kernel
-        split = 32 if Bp <= 128 else (8 if Bp <= 512 else (4 if Bp <= 2048 else 0))
+        # BPTT: 16 unit slices x 2 halves of 16 utterances up to four tiles (0.97 ms per layer at Bp = 32
+        # against 1.66 at 8), 16 unit slices up to eight (256: 1.61 against 1.80 at 8), then the 8- and 4-way kernels
+        split = 32 if Bp <= 128 else (16 if Bp <= 256 else (8 if Bp <= 512 else (4 if Bp <= 2048 else 0)))
     elif Bp <= 128:
         split = 32
     elif Bp <= 256:

@@ -11,7 +11,7 @@ def test_cooperative_split_policy(monkeypatch):
     # < 0: the column-split kernel, that many utterances per group of 8 workgroups, two workgroups to a CU
     assert fwd == {32: 32, 64: 32, 96: 32, 128: 32, 160: 16, 256: 16, 288: -16, 512: -16, 544: -32, 2048: -32, 2080: 0}
     bwd = {b: ops.coop_split(b, backward=True) for b in (32, 128, 160, 512, 544, 2048, 4096)}
-    assert bwd == {32: 32, 128: 32, 160: 8, 512: 8, 544: 4, 2048: 4, 4096: 0}
+    assert bwd == {32: 32, 128: 32, 160: 16, 512: 8, 544: 4, 2048: 4, 4096: 0}
     # every single-launch choice fits the chip: members = 2 directions x tiles x split <= 256 CUs
     for b in range(32, 513, 32):
         for back in (False, True):
