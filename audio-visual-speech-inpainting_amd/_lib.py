@@ -126,6 +126,7 @@ PROTOTYPES = {
     "avsi_blstm_rec_fwd_cs_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p,
                                           c_size_t, c_void_p]),
     "avsi_diag_cs_stamps": (c_int, [c_void_p]),
+    "avsi_stream_delay_us": (c_int, [c_int, c_void_p]),
     "avsi_diag_occupy_cus": (c_int, [c_int, c_void_p, c_int, c_void_p]),
     "avsi_conv2d_f32": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_int,
                                 c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p]),

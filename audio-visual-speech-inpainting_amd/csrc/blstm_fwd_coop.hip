@@ -367,7 +367,12 @@ __global__ __launch_bounds__(512, 2) void blstm_rec_fwd_coop_fine_kernel(const C
                 rv[0 * HP] = ig, rv[1 * HP] = jg, rv[2 * HP] = fg, rv[3 * HP] = og, rv[4 * HP] = cn;
             }
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // Only the h store has to be complete before the counter moves.  Stores complete in issue order, so with the
+        // five reserve stores issued BEHIND it the wait leaves those in flight: in a training step they go to lines no
+        // cache holds (read-for-ownership from HBM), and waiting for them made the kernel 20 % slower there than on
+        // the warm buffers of tools/rec_coop_time.py.
+        if (SAVE) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (tid == 0) __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
@@ -424,7 +429,10 @@ extern "C" int avsi_blstm_rec_fwd_coop_f32(const float* xproj, const float* whp,
     if (coop_tiles_per_launch(split, max_cus) < 1) return AVSI_ERR_UNSUPPORTED;   // 2 * split workgroups do not fit max_cus
     const hipStream_t st = (hipStream_t)stream;
     avsi_clear_error();
-    if (hipMemsetAsync(workspace, 0, avsi_blstm_rec_fwd_coop_workspace_bytes(Bp), st) != hipSuccess) return AVSI_ERR_LAUNCH;
+    // the step counters only: the first line (status word) is sticky -- the caller zeroes it when it allocates
+    if (hipMemsetAsync((char*)workspace + CTR_STRIDE * sizeof(unsigned), 0,
+                       avsi_blstm_rec_fwd_coop_workspace_bytes(Bp) - CTR_STRIDE * sizeof(unsigned), st) != hipSuccess)
+        return AVSI_ERR_LAUNCH;
     // every member of a group must be resident while its peers wait for it: batches beyond one chip-full of
     // groups run as consecutive launches over tile ranges
     const int tiles = Bp / 32, per = coop_tiles_per_launch(split, max_cus);
@@ -741,7 +749,10 @@ extern "C" int avsi_blstm_rec_bwd_coop_f32(const float* dhout, const float* rese
     if (coop_tiles_per_launch(split, max_cus) < 1) return AVSI_ERR_UNSUPPORTED;   // 2 * split workgroups do not fit max_cus
     const hipStream_t st = (hipStream_t)stream;
     avsi_clear_error();
-    if (hipMemsetAsync(workspace, 0, avsi_blstm_rec_fwd_coop_workspace_bytes(Bp), st) != hipSuccess) return AVSI_ERR_LAUNCH;
+    // the step counters only: the first line (status word) is sticky -- the caller zeroes it when it allocates
+    if (hipMemsetAsync((char*)workspace + CTR_STRIDE * sizeof(unsigned), 0,
+                       avsi_blstm_rec_fwd_coop_workspace_bytes(Bp) - CTR_STRIDE * sizeof(unsigned), st) != hipSuccess)
+        return AVSI_ERR_LAUNCH;
     if (split == 16)
         (void)hipFuncSetAttribute((const void*)blstm_rec_bwd_coop_fine_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                   96 * 1024);

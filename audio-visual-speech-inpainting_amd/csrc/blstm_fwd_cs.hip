@@ -312,7 +312,10 @@ extern "C" int avsi_blstm_rec_fwd_cs_f32(const float* xproj, const float* whp, f
     if (!workspace || workspace_bytes < avsi_blstm_rec_fwd_cs_workspace_bytes(Bp)) return AVSI_ERR_WORKSPACE;
     const hipStream_t st = (hipStream_t)stream;
     avsi_clear_error();
-    if (hipMemsetAsync(workspace, 0, avsi_blstm_rec_fwd_cs_workspace_bytes(Bp), st) != hipSuccess) return AVSI_ERR_LAUNCH;
+    // the step counters only: the first line (status word) is sticky -- the caller zeroes it when it allocates
+    if (hipMemsetAsync((char*)workspace + CTR_STRIDE * sizeof(unsigned), 0,
+                       avsi_blstm_rec_fwd_cs_workspace_bytes(Bp) - CTR_STRIDE * sizeof(unsigned), st) != hipSuccess)
+        return AVSI_ERR_LAUNCH;
     unsigned* sync = (unsigned*)workspace;
     if (rows_per_group == 16)
         return reserve ? launch_cs<1, true>(xproj, whp, hout, reserve, T, Bp, max_cus, sync, st)

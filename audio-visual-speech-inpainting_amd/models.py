@@ -24,6 +24,9 @@ from . import _lib, ops, parallel
 from . import audio_processing as ap
 from .blstm_layout import GP, HP, ParamLayout, round_up
 
+SIDE_DELAY_US = int(os.environ.get('AVSI_SIDE_DELAY_US', '60'))   # head start of a BPTT grid over the side-stream GEMMs
+DX_SPLITS = int(os.environ.get('AVSI_DX_SPLITS', '2'))      # reduction slabs of the dX product at small batches (1: unsplit)
+
 
 def _as_device(x, dtype=torch.float32, device=None):
     if x is None:
@@ -376,7 +379,9 @@ class StackedBLSTMModel(object):
         # prediction = sequence_mask * (rnn_out . W + b), stored batch-major [B, T, F]
         seq = self._seq_dev
         row_scale = self._buf('row_scale', (T, Bp), zero=True)
-        row_scale[:, :B] = (torch.arange(T, device=self.device)[:, None] < seq[None, :]).to(torch.float32)
+        if self._ws.get(('row_scale_of', T, Bp, B)) is not seq:      # same lengths as last time (feed keeps the tensor): five small
+            row_scale[:, :B] = (torch.arange(T, device=self.device)[:, None] < seq[None, :]).to(torch.float32)   # kernels saved
+            self._ws[('row_scale_of', T, Bp, B)] = seq
         pred = torch.empty((B, T, self.audio_feat_dim), dtype=torch.float32, device=self.device)
         ops.gemm(x.view(T * Bp, 2 * HP), v.p('pw'), out=pred.view(B * T, self.audio_feat_dim),
                  n=self.audio_feat_dim, bias=v.p('pb'), row_scale=row_scale.view(-1), row_map=(Bp, T, B))
@@ -552,14 +557,28 @@ class StackedBLSTMModel(object):
                 hi = lay.gpacked_size if upto is None else lay.gpacked[upto][0]
                 works.append(parallel.all_reduce_sum_async(gp[lo:hi]))
 
-        def on_side(fn):
-            """Run fn on the side stream once everything enqueued on the main stream so far has finished."""
+        # Three side streams when nothing orders the products of a layer among themselves (no all-reduce behind
+        # them): dWx and the two dWh of a layer are independent few-tile GEMMs, and those of layer 0 are the tail of
+        # the step -- one after the other they were 0.40 ms with the chip otherwise idle
+        sides = [side]
+        if overlap and not reduce:
+            if getattr(self, '_side_streams', None) is None:
+                self._side_streams = [torch.cuda.Stream(device=self.device) for _ in range(2)]
+            sides = [side] + self._side_streams
+
+        def on_side(fn, which=0, delay=0):
+            """Run fn on a side stream once everything enqueued on the main stream so far has finished (`delay` us
+            later: the next cooperative BPTT grid on the main stream becomes ready at the same instant and must
+            get its CUs first -- behind three GEMM grids it waited 250 us for residency)."""
             if not overlap:
                 return fn()
+            st = sides[which % len(sides)]
             ev = torch.cuda.Event()
             ev.record(main)
-            side.wait_event(ev)
-            with torch.cuda.stream(side):
+            st.wait_event(ev)
+            with torch.cuda.stream(st):
+                if delay:
+                    ops.stream_delay(delay)
                 fn()
 
         def head_grads():
@@ -577,7 +596,18 @@ class StackedBLSTMModel(object):
             ops.blstm_rec_bwd(dh, c['reserve'][li], v.p('whb%d' % li), dz)
             dz2 = dz.view(M, 2 * GP)
 
-            def weight_grads(li=li, kp=kp, dz=dz, dz2=dz2):
+            # dX first: it is on the chain to the BPTT of the layer below, the weight gradients are not -- started
+            # together with it (they need the same dz) four GEMMs shared the chip and the dX product took 427 us
+            # instead of 230; behind it they run beside the next BPTT kernel, which occupies 64 CUs
+            if li > 0:
+                if DX_SPLITS > 1 and M * 2 * HP < 2 * 256 * 128 * 128:
+                    # too few 128 x 128 output tiles to fill the chip once (8000 rows: 252): cut the 2048-deep reduction
+                    ops.gemm_splitk(dz2, v.p('wx%d' % li), dh.view(M, 2 * HP), trans_b=True, m=M, n=2 * HP, k=2 * GP,
+                                    splits=DX_SPLITS)
+                else:
+                    ops.gemm(dz2, v.p('wx%d' % li), out=dh.view(M, 2 * HP), trans_b=True, m=M, n=2 * HP, k=2 * GP)
+
+            def input_grads(li=li, kp=kp, dz=dz, dz2=dz2):
                 x = c['layer_in'][li].view(M, kp)
                 ops.gemm_splitk(x, dz2, lay.gpacked_view(gp, 'dwx%d' % li), trans_a=True, m=kp, n=2 * GP, k=M, splits=splits)
                 if lay.ones_col[li] < 0:
@@ -591,21 +621,35 @@ class StackedBLSTMModel(object):
                     dside = self._buf('dside', (Bp, lay.side_p))
                     ops.gemm(dsb, v.p('we'), out=dside, trans_b=True, m=Bp, n=lay.side_p, k=2 * GP)
                     self._side_backward(dside[:B, :E], gp)
+
+            def recurrent_grads(d, li=li, dz2=dz2):
                 # dWh[d] = H_prev^T . dZ_d : fw pairs h[t-1] with dz[t], bw pairs h[t+1] with dz[t]
                 hout = self._ws[('h%d' % li, (T, Bp, 2 * HP))].view(M, 2 * HP)
                 dwh = lay.gpacked_view(gp, 'dwh%d' % li)
                 if T > 1:
                     Mr = (T - 1) * Bp
-                    ops.gemm_splitk(hout[:Mr, :HP], dz2[Bp:, :GP], dwh[0], trans_a=True, m=HP, n=GP, k=Mr, splits=splits)
-                    ops.gemm_splitk(hout[Bp:, HP:], dz2[:Mr, GP:], dwh[1], trans_a=True, m=HP, n=GP, k=Mr, splits=splits)
+                    if d == 0:
+                        ops.gemm_splitk(hout[:Mr, :HP], dz2[Bp:, :GP], dwh[0], trans_a=True, m=HP, n=GP, k=Mr, splits=splits)
+                    else:
+                        ops.gemm_splitk(hout[Bp:, HP:], dz2[:Mr, GP:], dwh[1], trans_a=True, m=HP, n=GP, k=Mr, splits=splits)
                 else:
-                    dwh.zero_()
-                reduce_from('dwx%d' % li, 'dwx%d' % (li + 1) if li + 1 < self.num_layers else 'dpw')
-            on_side(weight_grads)
-            if li > 0:
-                ops.gemm(dz2, v.p('wx%d' % li), out=dh.view(M, 2 * HP), trans_b=True, m=M, n=2 * HP, k=2 * GP)
+                    dwh[d].zero_()
+
+            if len(sides) > 1:
+                hold = SIDE_DELAY_US if li > 0 else 0
+                on_side(input_grads, 0, hold)
+                on_side(lambda: recurrent_grads(0), 1, hold)
+                on_side(lambda: recurrent_grads(1), 2, hold)
+            else:
+                def weight_grads(li=li):
+                    input_grads()
+                    recurrent_grads(0)
+                    recurrent_grads(1)
+                    reduce_from('dwx%d' % li, 'dwx%d' % (li + 1) if li + 1 < self.num_layers else 'dpw')
+                on_side(weight_grads)
         if overlap:
-            main.wait_stream(side)
+            for st in sides:
+                main.wait_stream(st)
         reduce_from('dpw')                       # projection head (+ the speaker-embedding MLP of the SSNN variant)
         for w in works:
             if w is not None:

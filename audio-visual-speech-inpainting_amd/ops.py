@@ -105,7 +105,6 @@ def blstm_rec_fwd(xproj, whp, hout, reserve=None, rows_per_wg=0, split=None):
         _lib.check(_lib.lib().avsi_blstm_rec_fwd_cs_f32(_lib.ptr(xproj), _lib.ptr(whp), _lib.ptr(hout), _lib.ptr(reserve), T, Bp,
                                                         -split, coop_cu_budget(), _lib.ptr(ws), ws.numel() * 4,
                                                         _lib.stream_ptr()), "avsi_blstm_rec_fwd_cs_f32")
-        _coop_after_launch(xproj.device, ws)
         return hout
     if split:
         L = _lib.lib()
@@ -113,7 +112,6 @@ def blstm_rec_fwd(xproj, whp, hout, reserve=None, rows_per_wg=0, split=None):
         _lib.check(L.avsi_blstm_rec_fwd_coop_f32(_lib.ptr(xproj), _lib.ptr(whp), _lib.ptr(hout), _lib.ptr(reserve), T, Bp,
                                                  split, coop_cu_budget(), _lib.ptr(ws), ws.numel() * 4, _lib.stream_ptr()),
                    "avsi_blstm_rec_fwd_coop_f32")
-        _coop_after_launch(xproj.device, ws)
         return hout
     _lib.check(_lib.lib().avsi_blstm_rec_fwd_f32(_lib.ptr(xproj), _lib.ptr(whp), _lib.ptr(hout), _lib.ptr(reserve),
                                                  T, Bp, int(rows_per_wg), _lib.stream_ptr()),
@@ -121,33 +119,28 @@ def blstm_rec_fwd(xproj, whp, hout, reserve=None, rows_per_wg=0, split=None):
     return hout
 
 
-_COOP_WS, _COOP_STICKY, _COOP_HOST = {}, {}, {}      # all keyed by (device index, stream)
+_COOP_WS, _COOP_HOST = {}, {}      # keyed by (device index, stream)
 _COOP_MSG = "cooperative recurrent kernel timed out waiting for a peer workgroup; results are invalid"
 
 
 def _coop_ws(device, Bp, need=None):
     """Step counters of the cooperative kernels: one buffer per (device, stream) -- launches on one
-    stream run in order and may share it, launches on different streams may overlap and must not."""
+    stream run in order and may share it, launches on different streams may overlap and must not.
+    Word 0 is the sticky status word of the C ABI: zero here, never cleared by a launch, so a failure stays
+    visible without any host-side bookkeeping behind the launches (that bookkeeping -- an OR into a sticky flag
+    and its copy to pinned memory -- was two more kernels per recurrent launch: 0.16 ms of an 8 ms training step
+    at 32 utterances)."""
     need = max(need or 0, _lib.lib().avsi_blstm_rec_fwd_coop_workspace_bytes(Bp))
     key = (device.index, _lib.stream_ptr().value)
     ws = _COOP_WS.get(key)
     if ws is None or ws.numel() * 4 < need:
-        ws = torch.zeros((need + 3) // 4, dtype=torch.int32, device=device)
-        _COOP_WS[key] = ws
-    if key not in _COOP_STICKY:
-        _COOP_STICKY[key] = torch.zeros(1, dtype=torch.int32, device=device)
+        new = torch.zeros((need + 3) // 4, dtype=torch.int32, device=device)
+        if ws is not None:
+            new[:1].copy_(ws[:1])                    # a failure already recorded stays recorded
+        ws = _COOP_WS[key] = new
+    if key not in _COOP_HOST:
         _COOP_HOST[key] = (torch.zeros(1, dtype=torch.int32).pin_memory(), torch.cuda.Event())
     return ws
-
-
-def _coop_after_launch(device, ws):
-    """Fold the launch's status word into the stream's sticky flag (so a failure stays visible across
-    later launches, which zero the workspace) and queue its asynchronous copy to pinned host memory."""
-    key = (device.index, _lib.stream_ptr().value)
-    _COOP_STICKY[key].bitwise_or_(ws[:1])
-    host, event = _COOP_HOST[key]
-    host.copy_(_COOP_STICKY[key], non_blocking=True)
-    event.record()
 
 
 _COOP_CU_BUDGET = None      # set_coop_cu_budget(); None = AVSI_COOP_CUS or the whole chip
@@ -173,6 +166,11 @@ def coop_cu_budget():
     if parallel.collectives_share_the_gpu():
         budget = min(budget, 256 - COOP_CU_RESERVE)
     return budget
+
+
+def stream_delay(microseconds):
+    """Hold the CURRENT stream back for that long (avsi_stream_delay_us: one idle wave)."""
+    _lib.check(_lib.lib().avsi_stream_delay_us(int(microseconds), _lib.stream_ptr()), "avsi_stream_delay_us")
 
 
 def occupy_cus(num_cus, release, max_ms=5000):
@@ -225,21 +223,27 @@ def coop_split(Bp, backward=False):
 
 
 def coop_poll(device=None):
-    """Non-blocking form of coop_check: raises if a failure has ALREADY been observed on the host
-    (the flag travels asynchronously behind every cooperative launch).  Never synchronises, so
-    independent small batches can be in flight on several streams."""
+    """Non-blocking form of coop_check: raises if a failure has ALREADY been observed on the host, then queues
+    the next asynchronous copy of the status words to pinned memory (the flag travels behind the launches).
+    Never synchronises, so independent small batches can be in flight on several streams."""
     idx = torch.cuda.current_device() if device is None else torch.device(device).index
-    for (dev, _), (host, event) in _COOP_HOST.items():
-        if dev == idx and event.query() and int(host[0]) != 0:
+    cur = _lib.stream_ptr().value
+    for (dev, st), (host, event) in _COOP_HOST.items():
+        if dev != idx:
+            continue
+        if event.query() and int(host[0]) != 0:
             raise _lib.AvsiError(_COOP_MSG)
+        if st == cur and event.query():
+            host.copy_(_COOP_WS[(dev, st)][:1], non_blocking=True)
+            event.record()
 
 
 def coop_check(device=None):
     """Raise if a cooperative recurrent launch on `device` ever gave up waiting for its peer
     workgroups (its outputs are then invalid).  Synchronises with the device."""
     idx = torch.cuda.current_device() if device is None else torch.device(device).index
-    flags = [st for (dev, _), st in _COOP_STICKY.items() if dev == idx]
-    if flags and int(torch.stack(flags).max().item()) != 0:
+    flags = [ws[:1] for (dev, _), ws in _COOP_WS.items() if dev == idx]
+    if flags and int(torch.cat(flags).max().item()) != 0:
         raise _lib.AvsiError(_COOP_MSG)
 
 
@@ -422,7 +426,6 @@ def blstm_rec_bwd(dhout, reserve, whbt, dz, split=None):
                                                           T, Bp, split, coop_cu_budget(), _lib.ptr(ws), ws.numel() * 4,
                                                           _lib.stream_ptr()),
                    "avsi_blstm_rec_bwd_coop_f32")
-        _coop_after_launch(dhout.device, ws)
         return dz
     _lib.check(_lib.lib().avsi_blstm_rec_bwd_f32(_lib.ptr(dhout), _lib.ptr(reserve), _lib.ptr(whbt), _lib.ptr(dz),
                                                  T, Bp, _lib.stream_ptr()), "avsi_blstm_rec_bwd_f32")

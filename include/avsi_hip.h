@@ -167,8 +167,10 @@ int avsi_l1_loss_f32(const float* target, const float* pred, const float* mask, 
  * number of compute units the caller grants one launch: a process that keeps other kernels in flight beside the
  * recurrence (RCCL collectives of data-parallel training, batches on other streams) passes what is left, and the
  * launches are cut to fit; AVSI_ERR_UNSUPPORTED when not even one tile (2 * split workgroups) fits.
- * After the stream has drained, word 0 of the workspace is 0; a non-zero value means a workgroup stopped
- * waiting for its peers (bounded spin) and the outputs are invalid. */
+ * Word 0 of the workspace is a STICKY status: the calls zero the counters (one 256-byte line each, behind the
+ * first line) but never word 0 -- zero it when the workspace is allocated.  Once the stream has drained, a non-zero
+ * value means some launch since then had a workgroup stop waiting for its peers (bounded spin); its outputs are
+ * invalid. */
 size_t avsi_blstm_rec_fwd_coop_workspace_bytes(int Bp);
 int avsi_blstm_rec_fwd_coop_f32(const float* xproj, const float* whp, float* hout, float* reserve,
                                 int T, int Bp, int split, int max_cus, void* workspace, size_t workspace_bytes,
@@ -198,6 +200,10 @@ int avsi_blstm_rec_fwd_cs_f32(const float* xproj, const float* whp, float* hout,
 /* Diagnostic: while `buffer` (device memory, 32 * 8 * 2 * 8 uint64) is set, avsi_blstm_rec_fwd_cs_f32 records the
  * 100 MHz wall clock at eight phases of steps 64 .. 71 for waves 0 and 1 of its first 32 workgroups; NULL ends it. */
 int avsi_diag_cs_stamps(void* buffer);
+
+/* Holds `stream` back for `microseconds` (0 .. 1000) with one idle wave: lets a kernel on another stream that becomes
+ * ready at the same instant (a cooperative recurrent grid, which must be wholly resident) be dispatched first. */
+int avsi_stream_delay_us(int microseconds, void* stream);
 
 /* Diagnostic: park `num_cus` workgroups, each claiming a whole compute unit (160 KiB of LDS), on `stream` until
  * *release (device int32) becomes non-zero or ~`max_ms` milliseconds have passed (every workgroup leaves by itself).
