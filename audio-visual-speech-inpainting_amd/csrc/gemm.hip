@@ -722,7 +722,8 @@ int avsi_gemm_launch(int transA, int transB, int M, int N, int K, float alpha, c
     // wide layer GEMMs (N = 2048): 128 x 256 output tiles, each wave 64 x 128 -- half the barriers and a quarter less
     // LDS traffic per MFMA (K = 4096: 135 -> 142 TFLOP/s; the 512-deep layer GEMMs gain 2 %, the split-K weight
     // gradients 6 %), when that still leaves two workgroups per CU.  AVSI_GEMM_BNT=128: diagnostics
-    if (dma_ok && !transB && g.bnt == BN && N % 256 == 0 && N >= 1024 && (int64_t)g.m_blocks * (N / 256) * splits >= 2 * AVSI_NUM_CU &&
+    static const int wide_min = getenv("AVSI_GEMM_WIDE_MIN") ? atoi(getenv("AVSI_GEMM_WIDE_MIN")) : 2 * AVSI_NUM_CU - 32;   // 8000 rows (32 utterances): 504 wide tiles, 111 -> 99 us
+    if (dma_ok && !transB && g.bnt == BN && N % 256 == 0 && N >= 1024 && (int64_t)g.m_blocks * (N / 256) * splits >= wide_min &&
         !(getenv("AVSI_GEMM_BNT") && atoi(getenv("AVSI_GEMM_BNT")) == 128))
         g.bnt = 256;
     g.n_blocks = (int)avsi_ceil_div(N, g.bnt);
