@@ -159,9 +159,12 @@ def cpu_baseline(torch, model, wav, masks, mean, std, sample, pred_gpu):
                     best = (rate, fb)
             fused = {"value": best[0], "unit": "utterances/s", "threads": torch.get_num_threads(),
                      "what": "torch.nn.LSTM + Linear forward, float32, batches of %d (best of 32 / 128)" % best[1]}
-        torch.set_num_threads(threads_before)
     except Exception as e:   # a reported extra, never a reason to lose the bench line
         fused = {"error": str(e)[:200]}
+    # The rest of this process only launches GPU work.  Back at the default thread count, every small host-side
+    # tensor op of a training step woke the whole OpenMP pool on a box that grants this process 16 cores, and the
+    # pool's spin-waiting starved the launching thread (training at 32 utterances: 8.1 instead of 7.4 ms per step).
+    torch.set_num_threads(1)
     return {"value": sample / dt32, "unit": "utterances/s", "cores": cores, "kind": "port",
             "sample": "%d utterances in batches of 32, float32 numpy oracle (per-step loop), %.1f s" % (sample, dt32),
             "batch_8": {"value": n8 / dt8, "unit": "utterances/s",
