@@ -294,10 +294,21 @@ __global__ __launch_bounds__(512, 2) void blstm_rec_fwd_coop_fine_kernel(const C
         const size_t row0 = (size_t)t * Bp + b0;
 
         float xz[4];
-        if (fin)
+        float touched = 0.f;
+        if (fin) {
 #pragma unroll
             for (int g = 0; g < 4; ++g)
                 xz[g] = a.xproj[(row0 + frow) * (2 * GP) + dir * GP + w * 128 + g * 32 + u0 + fu];
+            {   // Touch the line this lane will store to two steps from now.  A workgroup writes 32- or 64-byte pieces
+                // of a line; to a line no cache holds, the write-through store was acknowledged later (the L2 fetches
+                // the rest of the line first): 0.86 -> 0.76 ms per layer at 32 utterances on cold buffers, which is
+                // what a real step has (and 0.78 -> 0.76 on warm ones).  The register stays reserved until the
+                // end-of-step wait: the compiler does not know the load is still in flight.
+                const int st2 = step + 2 < T ? step + 2 : T - 1;
+                const int t2 = dir ? (T - 1 - st2) : st2;
+                asm volatile("global_load_dword %0, %1, off" : "=v"(touched) : "v"(a.hout + ((size_t)t2 * Bp + b0 + frow) * (2 * HP) + dir * HP + w * 32 + u0 + fu) : "memory");
+            }
+        }
 
         f32x16 acc[NT];
 #pragma unroll
@@ -368,11 +379,11 @@ __global__ __launch_bounds__(512, 2) void blstm_rec_fwd_coop_fine_kernel(const C
             }
         }
         // Only the h store has to be complete before the counter moves.  Stores complete in issue order, so with the
-        // five reserve stores issued BEHIND it the wait leaves those in flight: in a training step they go to lines no
-        // cache holds (read-for-ownership from HBM), and waiting for them made the kernel 20 % slower there than on
-        // the warm buffers of tools/rec_coop_time.py.
+        // five reserve stores issued BEHIND it the wait leaves those in flight.  (Measured: no difference, neither on
+        // warm buffers nor inside a training step -- kept because it is the weaker, sufficient condition.)
         if (SAVE) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("" ::"v"(touched));
         __syncthreads();
         if (tid == 0) __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
@@ -659,10 +670,18 @@ __global__ __launch_bounds__(512, 2) void blstm_rec_bwd_coop_fine_kernel(const C
         const size_t row = row0 + (fin ? frow : 0);
         const float* rv = a.resv + row * (2 * 5 * HP) + dir * 5 * HP + unit;
         float dh = 0.f, ig = 0.f, jg = 0.f, fg = 0.f, og = 0.f, cc = 0.f, cp = 0.f;
+        float touched[4] = {0.f, 0.f, 0.f, 0.f};
         if (fin) {
             dh = a.dhout[row * (2 * HP) + dir * HP + unit];
             ig = rv[0 * HP], jg = rv[1 * HP], fg = rv[2 * HP], og = rv[3 * HP], cc = rv[4 * HP];
             cp = has_prev ? a.resv[((size_t)tp * Bp + b0 + frow) * (2 * 5 * HP) + dir * 5 * HP + 4 * HP + unit] : 0.f;
+            // touch the four dz lines this lane will store to two steps from now (see the forward kernel)
+            const int s2 = s + 2 < T ? s + 2 : T - 1;
+            const int t2 = dir ? s2 : (T - 1 - s2);
+            const float* z2 = a.dz + ((size_t)t2 * Bp + b0 + frow) * (2 * GP) + dir * GP + w * 128 + u0 + fu;
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+                asm volatile("global_load_dword %0, %1, off offset:%2" : "=v"(touched[g]) : "v"(z2), "i"(128 * g) : "memory");
         }
 
         f32x4 acc[NR];
@@ -733,6 +752,8 @@ __global__ __launch_bounds__(512, 2) void blstm_rec_bwd_coop_fine_kernel(const C
             __hip_atomic_store(zo + 96, d * tc * og * (1.f - og), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int g = 0; g < 4; ++g) asm volatile("" ::"v"(touched[g]));
         __syncthreads();
         if (tid == 0) __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
