@@ -1,0 +1,65 @@
+"""Host-visible contract of the cooperative recurrent kernels' exchange machinery (C ABI level): the sticky status word,
+the residency query of the column-split kernel, the stream head-start helper."""
+import time
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def test_status_word_is_sticky_and_counters_are_cleared():
+    """Word 0 of the counter workspace is never cleared by a launch (include/avsi_hip.h: STICKY status); everything
+    behind the first 256-byte line is zeroed by every call, so a dirty workspace does not disturb the exchange."""
+    import torch
+    import avsi_amd  # noqa: F401
+    from avsi_amd import _lib, ops
+    L = _lib.lib()
+    T, Bp = 12, 64
+    g = torch.Generator(device='cuda')
+    g.manual_seed(5)
+    xproj = torch.randn(T, Bp, 2048, generator=g, device='cuda')
+    whp = torch.randn(2 * 262144, generator=g, device='cuda') * 0.05
+    ref = torch.empty(T, Bp, 512, device='cuda')
+    ops.blstm_rec_fwd(xproj, whp, ref, None, split=0)
+    for entry, split, need in ((L.avsi_blstm_rec_fwd_coop_f32, 32, L.avsi_blstm_rec_fwd_coop_workspace_bytes(Bp)),
+                               (L.avsi_blstm_rec_fwd_cs_f32, 16, L.avsi_blstm_rec_fwd_cs_workspace_bytes(Bp))):
+        ws = torch.full((need // 4,), 12345, dtype=torch.int32, device='cuda')     # dirty counters ...
+        ws[0] = 7                                                                   # ... and a recorded failure
+        hout = torch.zeros(T, Bp, 512, device='cuda')
+        rc = entry(_lib.ptr(xproj), _lib.ptr(whp), _lib.ptr(hout), None, T, Bp, split, 0, _lib.ptr(ws), need, _lib.stream_ptr())
+        assert rc == 0
+        torch.cuda.synchronize()
+        assert int(ws[0]) == 7                                  # sticky: the call did not touch it
+        np.testing.assert_allclose(hout.cpu().numpy(), ref.cpu().numpy(), rtol=0, atol=2e-5)
+        assert int(ws[64]) == 8 * T if split == 16 else int(ws[64]) == 32 * T      # first counter: members x steps
+
+
+def test_column_split_residency_query_and_workspace():
+    import avsi_amd  # noqa: F401
+    from avsi_amd import _lib
+    L = _lib.lib()
+    for rows in (16, 32):
+        for reserve in (0, 1):
+            per = L.avsi_blstm_rec_fwd_cs_groups_per_launch(rows, reserve, 0)
+            assert per in (32, 64)                              # 8 workgroups per group, one or two of them per CU
+            assert L.avsi_blstm_rec_fwd_cs_groups_per_launch(rows, reserve, 128) == per // 2
+    assert L.avsi_blstm_rec_fwd_cs_groups_per_launch(24, 0, 0) == 0
+    # one 256-byte line for the status word and one per (16-utterance tile, direction) counter
+    assert L.avsi_blstm_rec_fwd_cs_workspace_bytes(1024) == 256 * (1 + 2 * 64)
+
+
+def test_stream_delay_holds_a_stream_back():
+    import torch
+    import avsi_amd  # noqa: F401
+    from avsi_amd import _lib, ops
+    L = _lib.lib()
+    assert L.avsi_stream_delay_us(-1, None) != 0 and L.avsi_stream_delay_us(1001, None) != 0
+    assert L.avsi_stream_delay_us(0, _lib.stream_ptr()) == 0
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    ops.stream_delay(500)
+    e1.record()
+    torch.cuda.synchronize()
+    assert 0.45 <= e0.elapsed_time(e1) <= 5.0                  # ms: at least the half millisecond asked for
