@@ -239,6 +239,15 @@ __global__ __launch_bounds__(512, 4) void blstm_rec_fwd_cs_kernel(const CsArgs a
             }
         }
     }
+    // leave the counter at zero for the next launch on this workspace (see blstm_fwd_coop.hip)
+    if (member == 0 && tid == 0 && !wg_dead) {
+        unsigned polls = 0;
+        while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)MEMBERS * (unsigned)T) {
+            __builtin_amdgcn_s_sleep(2);
+            if (++polls > SPIN_LIMIT) return;
+        }
+        __hip_atomic_store(ctr, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
 }
 
 unsigned long long* g_cs_stamps = nullptr;     // avsi_diag_cs_stamps()
@@ -312,10 +321,8 @@ extern "C" int avsi_blstm_rec_fwd_cs_f32(const float* xproj, const float* whp, f
     if (!workspace || workspace_bytes < avsi_blstm_rec_fwd_cs_workspace_bytes(Bp)) return AVSI_ERR_WORKSPACE;
     const hipStream_t st = (hipStream_t)stream;
     avsi_clear_error();
-    // the step counters only: the first line (status word) is sticky -- the caller zeroes it when it allocates
-    if (hipMemsetAsync((char*)workspace + CTR_STRIDE * sizeof(unsigned), 0,
-                       avsi_blstm_rec_fwd_cs_workspace_bytes(Bp) - CTR_STRIDE * sizeof(unsigned), st) != hipSuccess)
-        return AVSI_ERR_LAUNCH;
+    // no memset: the caller zeroes the workspace once, every launch leaves its counters at zero again and never
+    // touches the sticky status word
     unsigned* sync = (unsigned*)workspace;
     if (rows_per_group == 16)
         return reserve ? launch_cs<1, true>(xproj, whp, hout, reserve, T, Bp, max_cus, sync, st)

@@ -232,6 +232,7 @@ def coop_poll(device=None):
         if dev != idx:
             continue
         if event.query() and int(host[0]) != 0:
+            _coop_recover(idx)
             raise _lib.AvsiError(_COOP_MSG)
         if st == cur and event.query():
             host.copy_(_COOP_WS[(dev, st)][:1], non_blocking=True)
@@ -244,7 +245,20 @@ def coop_check(device=None):
     idx = torch.cuda.current_device() if device is None else torch.device(device).index
     flags = [ws[:1] for (dev, _), ws in _COOP_WS.items() if dev == idx]
     if flags and int(torch.cat(flags).max().item()) != 0:
+        _coop_recover(idx)
         raise _lib.AvsiError(_COOP_MSG)
+
+
+def _coop_recover(idx):
+    """A launch that gave up waiting may have left step counters behind (the kernels zero them only on a clean
+    end): start over with clean workspaces once the failure has been reported."""
+    torch.cuda.synchronize(idx)
+    for (dev, _), ws in _COOP_WS.items():
+        if dev == idx:
+            ws.zero_()
+    for (dev, _), (host, _) in _COOP_HOST.items():
+        if dev == idx:
+            host.zero_()
 
 
 _LOSS_WS = {}

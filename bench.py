@@ -195,7 +195,12 @@ def bench_unet(args, torch, dist, rank, world, device):
     model = models.UNetFConvModel(seq, wav, masks, mean, std, 0.0, cfg, is_training=False, seed=7)
     timer = KernelTimer(torch)
     if B >= 256:      # below that a step is launch-bound and the per-call events would dominate what they measure
-        for name in ("conv2d", "conv2d_thin", "conv2d_thin_relu_pool", "colstats", "bn_act", "bn_act_pool", "maxpool2"):
+        # the matrix-core convolutions only (11 of ~70 launches, 70 % of the kernel time): events around every launch of
+        # the step cost 0.4 of its 4.4 ms (AVSI_BENCH_UNET_ALL=1 times them all, for the per-kernel table of DESIGN 4.5)
+        names = ("conv2d", "conv2d_thin_mfma")
+        if os.environ.get("AVSI_BENCH_UNET_ALL", "0") == "1":
+            names += ("conv2d_thin", "conv2d_thin_relu_pool", "colstats", "bn_act", "bn_act_pool", "maxpool2")
+        for name in names:
             setattr(ops, name, timer.wrap(name, getattr(ops, name)))
 
     def step():

@@ -161,16 +161,17 @@ int avsi_l1_loss_f32(const float* target, const float* pred, const float* mask, 
 /* Small-batch form of avsi_blstm_rec_fwd_f32 (same operands and results): every (32-utterance
  * tile, direction) pair is spread over `split` = 4, 8, 16 or 32 workgroups that keep their piece of the
  * recurrent kernel in registers for all T steps and exchange h_t through hout with a per-step
- * counter in `workspace` (avsi_blstm_rec_fwd_coop_workspace_bytes(Bp) bytes, zeroed by the call).
+ * counter in `workspace` (avsi_blstm_rec_fwd_coop_workspace_bytes(Bp) bytes, see below).
  * A launch must be wholly resident (one workgroup per CU), so batches beyond 128 (split 32) / 256 (16) /
  * 512 (8) / 1024 (4) utterances run as consecutive launches over tile ranges.  `max_cus` (<= 0: all 256) is the
  * number of compute units the caller grants one launch: a process that keeps other kernels in flight beside the
  * recurrence (RCCL collectives of data-parallel training, batches on other streams) passes what is left, and the
  * launches are cut to fit; AVSI_ERR_UNSUPPORTED when not even one tile (2 * split workgroups) fits.
- * Word 0 of the workspace is a STICKY status: the calls zero the counters (one 256-byte line each, behind the
- * first line) but never word 0 -- zero it when the workspace is allocated.  Once the stream has drained, a non-zero
- * value means some launch since then had a workgroup stop waiting for its peers (bounded spin); its outputs are
- * invalid. */
+ * The workspace is zeroed ONCE by the caller, when it is allocated: word 0 is a STICKY status that no call clears,
+ * the counters behind it (one 256-byte line each) are put back to zero by the kernels themselves when a launch ends,
+ * so consecutive calls on one stream need nothing in between.  Once the stream has drained, a non-zero word 0 means
+ * some launch since the allocation had a workgroup stop waiting for its peers (bounded spin): its outputs are
+ * invalid and it may have left counters behind -- zero the whole workspace before using it again. */
 size_t avsi_blstm_rec_fwd_coop_workspace_bytes(int Bp);
 int avsi_blstm_rec_fwd_coop_f32(const float* xproj, const float* whp, float* hout, float* reserve,
                                 int T, int Bp, int split, int max_cus, void* workspace, size_t workspace_bytes,
