@@ -313,7 +313,10 @@ __global__ __launch_bounds__(512, 4) void blstm_rec_bwd_kh_kernel(const BwdArgs 
     };
 
     // (Delaying one of a CU's two workgroups by a fraction of a step at the start changes nothing: 19.5 ms for any
-    // delay from 0 to 80 us.  PMC: the matrix pipe is busy 76 % of the kernel's cycles at the 2.19 GHz the chip holds
+    // delay from 0 to 80 us.  Neither does keeping the two out of the elementwise phase at the same time -- a token per
+    // physical CU (HW_REG_XCC_ID / HW_REG_HW_ID), taken with a scalar atomic at the top of the phase: 20.6 ms with and
+    // without the token in a build whose extra control flow cost 15 spills, so the idle quarter of the matrix pipe is
+    // not two coinciding elementwise phases.  PMC: the matrix pipe is busy 76 % of the kernel's cycles at the 2.19 GHz the chip holds
     // under this load; waves are parked on s_waitcnt / barriers 25 % of their time.)
     RowsC ca, cb;
     loadc(ca, 0, 0);
