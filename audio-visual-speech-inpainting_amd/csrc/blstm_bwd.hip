@@ -364,8 +364,8 @@ extern "C" int avsi_blstm_rec_bwd_f32(const float* dhout, const float* reserve, 
     BwdArgs a{dhout, reserve, whbT, dz, T, Bp};
     avsi_clear_error();
     // K-halved kernel (two workgroups per CU) by default; AVSI_BWD_KH=0 selects the whole-tile kernel (A/B runs)
-    const char* env = getenv("AVSI_BWD_KH");
-    if (!(env && atoi(env) == 0)) {
+    static const bool whole_tile = getenv("AVSI_BWD_KH") && atoi(getenv("AVSI_BWD_KH")) == 0;
+    if (!whole_tile) {
         const size_t lds = (size_t)32 * ZH * 4;
         (void)hipFuncSetAttribute((const void*)blstm_rec_bwd_kh_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipLaunchKernelGGL(blstm_rec_bwd_kh_kernel, dim3(Bp / 32, 2), dim3(512), lds, (hipStream_t)stream, a);

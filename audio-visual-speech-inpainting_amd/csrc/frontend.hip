@@ -430,8 +430,8 @@ extern "C" int avsi_frontend_f32(const avsi_frontend_args* args, void* stream) {
     // the inpainter's own call (see the MODEL template flag)
     const bool model = small && step == 1 && a.num_bins == 257 && a.out_spec && a.out_feat && a.mask && a.mean && !a.out_stft &&
                        !a.out_logmel && a.spec_power == 1.f && a.log_spec && a.feat_cols >= 257 && a.feat_cols <= 256 + 64;
-    const char* env_occ = getenv("AVSI_FE_OCC");
-    const int occ = (model && nb == 12 && env_occ && atoi(env_occ) == 3) ? 3 : 2;
+    static const bool env_occ3 = getenv("AVSI_FE_OCC") && atoi(getenv("AVSI_FE_OCC")) == 3;      // diagnostics, read once
+    const int occ = (model && nb == 12 && env_occ3) ? 3 : 2;
     const int by_lds = (int)(156 * 1024 / (lds + 4352));       // + the static constant tables
     const int wg_per_cu = by_lds > occ ? occ : (by_lds < 1 ? 1 : by_lds);
     const int grid = n_tiles < AVSI_NUM_CU * wg_per_cu ? n_tiles : AVSI_NUM_CU * wg_per_cu;

@@ -627,15 +627,31 @@ __global__ __launch_bounds__(256, BNT == 256 ? 2 : (BK == 16 ? (NST == 3 ? 3 : 4
     }
 }
 
+// Diagnostic switches, read once per process (a getenv per launch is a linear scan of the environment, and a small-batch
+// step issues ten GEMMs): AVSI_GEMM_BK / _MI / _DMA / _BNT / _NGROUP, -1 = not set.
+struct GemmEnv {
+    int bk, mi, dma, bnt, ngroup;
+    static int read(const char* name) {
+        const char* e = getenv(name);
+        return e ? atoi(e) : -1;
+    }
+    GemmEnv() : bk(read("AVSI_GEMM_BK")), mi(read("AVSI_GEMM_MI")), dma(read("AVSI_GEMM_DMA")), bnt(read("AVSI_GEMM_BNT")),
+                ngroup(read("AVSI_GEMM_NGROUP")) {}
+};
+static const GemmEnv& gemm_env() {
+    static const GemmEnv e;
+    return e;
+}
+
 template <bool TA, bool TB>
 int launch_dma(const GemmArgs& g, int splits, hipStream_t st) {
     constexpr size_t lds = (size_t)2 * 3 * 128 * 16 * 4;   // 48 KiB: three stages of A and B
-    if (getenv("AVSI_GEMM_DMA") && atoi(getenv("AVSI_GEMM_DMA")) == 2 && g.k_split_len % 32 == 0 && g.K % 32 == 0) {
+    if (gemm_env().dma == 2 && g.k_split_len % 32 == 0 && g.K % 32 == 0) {
         hipLaunchKernelGGL((gemm_dma_kernel<TA, TB, 32, 2>), dim3(g.m_blocks * g.n_blocks, 1, splits), dim3(256),
                            2 * 2 * 128 * 32 * 4, st, g);
         return avsi_launch_status();
     }
-    if (getenv("AVSI_GEMM_DMA") && atoi(getenv("AVSI_GEMM_DMA")) == 3) {
+    if (gemm_env().dma == 3) {
         hipLaunchKernelGGL((gemm_dma_kernel<TA, TB, 16, 2>), dim3(g.m_blocks * g.n_blocks, 1, splits), dim3(256),
                            2 * 2 * 128 * 16 * 4, st, g);
         return avsi_launch_status();
@@ -705,36 +721,34 @@ int avsi_gemm_launch(int transA, int transB, int M, int N, int K, float alpha, c
     g.lda = lda, g.ldb = ldb, g.ldc = ldc;
     g.alpha = alpha, g.beta = beta;
     // tuning overrides (diagnostic): AVSI_GEMM_BK = 16 | 32, AVSI_GEMM_MI = 2 | 4
-    const char* env_bk = getenv("AVSI_GEMM_BK");
-    const char* env_mi = getenv("AVSI_GEMM_MI");
-    const int bk = env_bk ? atoi(env_bk) : (transB ? 32 : 16);
+    const GemmEnv& env = gemm_env();
+    const bool env_bk = env.bk >= 0, env_mi = env.mi >= 0;
+    const int bk = env_bk ? env.bk : (transB ? 32 : 16);
     // A . B^T over many rows (the dX products of training): 256-row tiles, +2.7 % (129.7 -> 133.2 TFLOP/s)
-    const int mi = env_mi ? atoi(env_mi) : ((transB && !transA && M >= 65536) ? 4 : 2);
+    const int mi = env_mi ? env.mi : ((transB && !transA && M >= 65536) ? 4 : 2);
     const int BM = 64 * mi;
     g.m_blocks = (int)avsi_ceil_div(M, BM);
     // A . B whose last 128-wide tile would be at most half full and that is narrow enough for the tail to matter
     // (the 257-bin projection: 5 x 64 instead of 3 x 128 columns of MFMA work)
     g.k_split_len = (int)avsi_round_up(avsi_ceil_div(K, splits), 32);
-    const char* env_dma = getenv("AVSI_GEMM_DMA");
-    const bool dma_ok = !(transB && !transA) && (K % 16 == 0) && (g.k_split_len % 16 == 0) && !env_bk && !env_mi &&
-                        !(env_dma && atoi(env_dma) == 0);
-    g.bnt = (dma_ok && !transA && !transB && N < 1024 && ((N - 1) % BN) < 64 && !(env_dma && atoi(env_dma) > 1)) ? 64 : BN;
+    const bool dma_ok = !(transB && !transA) && (K % 16 == 0) && (g.k_split_len % 16 == 0) && !env_bk && !env_mi && env.dma != 0;
+    g.bnt = (dma_ok && !transA && !transB && N < 1024 && ((N - 1) % BN) < 64 && !(env.dma > 1)) ? 64 : BN;
     // wide layer GEMMs (N = 2048): 128 x 256 output tiles, each wave 64 x 128 -- half the barriers and a quarter less
     // LDS traffic per MFMA (K = 4096: 135 -> 142 TFLOP/s; the 512-deep layer GEMMs gain 2 %, the split-K weight
     // gradients 6 %), when that still leaves two workgroups per CU.  AVSI_GEMM_BNT=128: diagnostics
     static const int wide_min = getenv("AVSI_GEMM_WIDE_MIN") ? atoi(getenv("AVSI_GEMM_WIDE_MIN")) : 2 * AVSI_NUM_CU - 32;   // 8000 rows (32 utterances): 504 wide tiles, 111 -> 99 us
     if (dma_ok && !transB && g.bnt == BN && N % 256 == 0 && N >= 1024 && (int64_t)g.m_blocks * (N / 256) * splits >= wide_min &&
-        !(getenv("AVSI_GEMM_BNT") && atoi(getenv("AVSI_GEMM_BNT")) == 128))
+        env.bnt != 128)
         g.bnt = 256;
     g.n_blocks = (int)avsi_ceil_div(N, g.bnt);
     g.c_split_stride = splits > 1 ? c_split_stride : 0;
     {   // column-group width: the group's slice of op(B), k_split_len x (n_group * 128) floats, should fill about half of
         // one XCD's 4 MiB L2
-        const char* env_ng = getenv("AVSI_GEMM_NGROUP");
+
         const int64_t slice_bytes_per_block = (int64_t)g.k_split_len * g.bnt * 4;
         int ng = (int)((2 << 20) / (slice_bytes_per_block > 0 ? slice_bytes_per_block : 1));
         if (ng < 4) ng = 4;      // narrower groups re-read A more often than they save on B
-        if (env_ng) ng = atoi(env_ng);
+        if (env.ngroup >= 0) ng = env.ngroup;
         g.n_group = ng < 1 ? 1 : (ng > g.n_blocks ? g.n_blocks : ng);
     }
     if ((int64_t)g.m_blocks * g.n_blocks > INT32_MAX) return AVSI_ERR_UNSUPPORTED;

@@ -65,3 +65,29 @@ def test_stream_delay_holds_a_stream_back():
     e1.record()
     torch.cuda.synchronize()
     assert 0.45 <= e0.elapsed_time(e1) <= 5.0                  # ms: at least the half millisecond asked for
+
+
+def test_reported_failure_resets_the_workspaces():
+    """ops.coop_check raises once for a recorded failure and leaves clean workspaces behind (the kernels only put
+    their counters back to zero on a clean end), so the next launch works again."""
+    import torch
+    import avsi_amd  # noqa: F401
+    from avsi_amd import _lib, ops
+    T, Bp = 6, 32
+    xproj = torch.randn(T, Bp, 2048, device='cuda')
+    whp = torch.randn(2 * 262144, device='cuda') * 0.05
+    hout = torch.zeros(T, Bp, 512, device='cuda')
+    ops.blstm_rec_fwd(xproj, whp, hout, None, split=32)
+    ops.coop_check()
+    key = (torch.cuda.current_device(), _lib.stream_ptr().value)
+    ws = ops._COOP_WS[key]
+    ws[0] = 1                      # what a workgroup that gave up waiting would have written
+    ws[64] = 999                   # ... and a counter it left behind
+    with pytest.raises(_lib.AvsiError):
+        ops.coop_check()
+    assert int(ws.abs().max()) == 0
+    ref = torch.zeros(T, Bp, 512, device='cuda')
+    ops.blstm_rec_fwd(xproj, whp, ref, None, split=0)
+    ops.blstm_rec_fwd(xproj, whp, hout, None, split=32)
+    ops.coop_check()
+    np.testing.assert_allclose(hout.cpu().numpy(), ref.cpu().numpy(), rtol=0, atol=2e-5)
