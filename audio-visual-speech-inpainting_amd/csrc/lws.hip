@@ -660,12 +660,34 @@ extern "C" int avsi_lws_run_f32(float* spec, int batch, int num_frames, int fram
     // Small batches want their sweeps spread over waves and CUs (latency: 0.84 s per utterance on one wave); large
     // batches fill the chip with utterances instead.
     int U = utterances_per_wave, NW = waves_per_group;
-    if (U == 0) U = batch >= 4 * 4 * AVSI_NUM_CU ? 4 : (batch >= 2 * 4 * AVSI_NUM_CU ? 2 : 1);
-    if (NW == 0) NW = (U > 1 || batch > 8 * AVSI_NUM_CU) ? 1 : (batch > 2 * AVSI_NUM_CU ? 4 : (batch > AVSI_NUM_CU ? 8 : 16));
+    // more than one utterance per CU: as many per wave as LDS allows next to a useful number of waves (one lane per
+    // utterance runs the in-frame recurrence), 16 utterance-waves per CU in all.  Measured, utterances/s: 512 as
+    // 2 x 8 waves 3.8 k (1 x 8: 2.2 k), 1024 .. 4096 as 4 x 4 waves 4.4 k (1 x 4: 2.3 k at 1024, 4 x 1: 3.8 k at 4096)
+    if (U == 0) U = batch > 2 * AVSI_NUM_CU ? 4 : (batch > AVSI_NUM_CU ? 2 : 1);
     const int clusters = (batch + U - 1) / U;
+    const bool whole_cus = U == 1 && batch <= AVSI_NUM_CU;      // every utterance gets one or more CUs to itself
+    if (NW == 0) {
+        if (U > 1) NW = 16 / U;
+        else if (batch > AVSI_NUM_CU) NW = 8;
+        else {
+            // The in-frame recurrence is issue-bound per wave, so waves that share a SIMD only slow each other down:
+            // the fewest waves per workgroup with which the utterance still gets ~64 pipeline stages (measured, ms per
+            // batch: 8 utterances 4 x 26: 34.9, 8 x 13: 40.9, 16 x 7: 48.3; 32 utterances 8 x 8: 30.6, 4 x 8: 38.6,
+            // 16 x 7: 47.5; 100 utterances 16 x 2: 63.0, 8 x 2: 66.3)
+            const int gmax = AVSI_NUM_CU / clusters;
+            NW = 16;
+            for (int nw = 4; nw <= 8; nw *= 2) {
+                const int useful = (S.n + nw - 1) / nw;
+                if ((gmax < useful ? gmax : useful) * nw >= 64) {
+                    NW = nw;
+                    break;
+                }
+            }
+        }
+    }
     int G = groups_per_utterance;
-    if (G == 0) {      // 16-wave workgroups take a CU each: as many per utterance as the chip holds, at most one per 16 sweeps
-        G = NW == 16 ? AVSI_NUM_CU / clusters : 1;
+    if (G == 0) {      // as many workgroups per utterance as the chip holds, at most one per NW sweeps
+        G = whole_cus ? AVSI_NUM_CU / clusters : 1;
         const int useful = (S.n + NW - 1) / NW;
         G = G < 1 ? 1 : (G > useful ? useful : G);
     }
@@ -693,6 +715,8 @@ extern "C" int avsi_lws_run_f32(float* spec, int batch, int num_frames, int fram
     else if (U == 1 && NW == 4) AVSI_LWS_LAUNCH(1, 4);
     else if (U == 1 && NW == 8) AVSI_LWS_LAUNCH(1, 8);
     else if (U == 1 && NW == 16) AVSI_LWS_LAUNCH(1, 16);
+    else if (U == 2 && NW == 8) AVSI_LWS_LAUNCH(2, 8);
+    else if (U == 4 && NW == 4) AVSI_LWS_LAUNCH(4, 4);
     else return AVSI_ERR_INVALID_ARG;
 #undef AVSI_LWS_LAUNCH
     return avsi_launch_status();

@@ -73,7 +73,8 @@ def test_launch_shape_does_not_change_the_result(L):
     o = OL.LWS(384, 192, **kw)
     S0 = np.stack([np.abs(o.stft(_speechlike(4800, 30 + i))) for i in range(5)]).astype(np.complex64)
     ref = L.lws(384, 192, utterances_per_wave=1, waves_per_group=1, **kw).run_lws(S0)
-    for U, NW, G in ((2, 1, 1), (4, 1, 1), (1, 4, 1), (1, 8, 1), (1, 16, 1), (1, 16, 3), (1, 16, 7), (1, 8, 5), (1, 16, 0)):
+    for U, NW, G in ((2, 1, 1), (4, 1, 1), (1, 4, 1), (1, 8, 1), (1, 16, 1), (1, 16, 3), (1, 16, 7), (1, 8, 5), (1, 16, 0),
+                     (2, 8, 1), (4, 4, 1), (1, 4, 26), (0, 0, 0)):       # 5 utterances with 0, 0, 0: the policy's own choice
         out = L.lws(384, 192, utterances_per_wave=U, waves_per_group=NW, groups_per_utterance=G, **kw).run_lws(S0)
         assert np.array_equal(ref, out), (U, NW, G)
 

@@ -41,9 +41,12 @@ config = check_trainconfiguration(load_configfile(os.path.join(net, "config.txt"
 m = training.build_model(config, np.zeros(257), np.ones(257), is_training=False)
 m.variables.save(os.path.join(net, "sinet"))
 import contextlib, io
-for rep in range(2):
-    t0 = time.time()
-    with contextlib.redirect_stdout(io.StringIO()):
-        inference.infer(net, root, os.path.join(base, "audio%d" % rep), "enh", norm=True, oracle_phase=False, batch_size=batch)
-    dt = time.time() - t0
-    print("infer(): %d utterances in %.2f s: %.0f utterances/s end to end (batch %d)" % (n, dt, n / dt, batch), flush=True)
+for oracle_phase in (False, True):
+    for rep in range(2):
+        t0 = time.time()
+        with contextlib.redirect_stdout(io.StringIO()):
+            inference.infer(net, root, os.path.join(base, "audio%d%d" % (oracle_phase, rep)), "enh", norm=True,
+                            oracle_phase=oracle_phase, batch_size=batch)
+        dt = time.time() - t0
+        print("infer(%s): %d utterances in %.2f s: %.0f utterances/s end to end (batch %d)"
+              % ("oracle phase" if oracle_phase else "LWS phase, the default", n, dt, n / dt, batch), flush=True)
