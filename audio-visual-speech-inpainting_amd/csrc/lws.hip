@@ -660,20 +660,21 @@ extern "C" int avsi_lws_run_f32(float* spec, int batch, int num_frames, int fram
     // Small batches want their sweeps spread over waves and CUs (latency: 0.84 s per utterance on one wave); large
     // batches fill the chip with utterances instead.
     int U = utterances_per_wave, NW = waves_per_group;
-    // more than one utterance per CU: as many per wave as LDS allows next to a useful number of waves (one lane per
-    // utterance runs the in-frame recurrence), 16 utterance-waves per CU in all.  Measured, utterances/s: 512 as
-    // 2 x 8 waves 3.8 k (1 x 8: 2.2 k), 1024 .. 4096 as 4 x 4 waves 4.4 k (1 x 4: 2.3 k at 1024, 4 x 1: 3.8 k at 4096)
-    if (U == 0) U = batch > 2 * AVSI_NUM_CU ? 4 : (batch > AVSI_NUM_CU ? 2 : 1);
+    // Launch shape.  One lane per utterance runs the in-frame recurrence, so a wave should carry several utterances
+    // (U, at most 4 next to a useful number of waves: a CU's LDS holds 16 utterance-waves); the sweeps of an utterance
+    // group are pipelined over the NW waves of a workgroup and over G workgroups, which must all be resident.  The
+    // recurrence is issue-bound per wave, so waves that share a SIMD slow each other down: spread over CUs first.
+    // Measured (tools/lws_time.py, ms per batch, U x NW x G): 8 utterances 1x4x26: 33.7, 4x4x26: 43.4, 1x16x7: 48.3;
+    // 32: 1x8x8: 30.6, 4x4x16: 35.8, 1x16x7: 47.5; 64: 4x4x16: 32.9, 2x8x8: 34.8, 1x16x4: 45.9; 100: 4x4x10: 40.5,
+    // 1x16x2: 63.0; 256: 4x4x4: 69.1, 2x8x2: 74.5, 1x16x1: 106; 512: 4x4x2: 124, 2x8x1: 134, 1x8x1: 237;
+    // 1024 .. 4096: 4x4x1: 4.4 k utterances/s (1x4x1: 2.3 k at 1024, 4x1x1: 3.8 k at 4096).
+    if (U == 0) U = batch > 32 ? 4 : 1;
     const int clusters = (batch + U - 1) / U;
-    const bool whole_cus = U == 1 && batch <= AVSI_NUM_CU;      // every utterance gets one or more CUs to itself
     if (NW == 0) {
         if (U > 1) NW = 16 / U;
         else if (batch > AVSI_NUM_CU) NW = 8;
         else {
-            // The in-frame recurrence is issue-bound per wave, so waves that share a SIMD only slow each other down:
-            // the fewest waves per workgroup with which the utterance still gets ~64 pipeline stages (measured, ms per
-            // batch: 8 utterances 4 x 26: 34.9, 8 x 13: 40.9, 16 x 7: 48.3; 32 utterances 8 x 8: 30.6, 4 x 8: 38.6,
-            // 16 x 7: 47.5; 100 utterances 16 x 2: 63.0, 8 x 2: 66.3)
+            // the fewest waves per workgroup with which the utterance still gets ~64 pipeline stages
             const int gmax = AVSI_NUM_CU / clusters;
             NW = 16;
             for (int nw = 4; nw <= 8; nw *= 2) {
@@ -686,8 +687,8 @@ extern "C" int avsi_lws_run_f32(float* spec, int batch, int num_frames, int fram
         }
     }
     int G = groups_per_utterance;
-    if (G == 0) {      // as many workgroups per utterance as the chip holds, at most one per NW sweeps
-        G = whole_cus ? AVSI_NUM_CU / clusters : 1;
+    if (G == 0) {      // as many workgroups per utterance group as the chip holds, at most one per NW sweeps
+        G = clusters <= AVSI_NUM_CU ? AVSI_NUM_CU / clusters : 1;
         const int useful = (S.n + NW - 1) / NW;
         G = G < 1 ? 1 : (G > useful ? useful : G);
     }
