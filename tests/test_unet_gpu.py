@@ -228,6 +228,32 @@ def test_thin_direct_conv_matches_im2col_gemm(k, c0, c1, cout):
     np.testing.assert_allclose(got[:, :cout].cpu().numpy(), want[:, :cout].cpu().numpy(), rtol=1e-5, atol=1e-5)
 
 
+def test_tiled_output_layer_matches_im2col_gemm():
+    """The 3 x 3 (1 ++ 16 up-sampled) -> 1 layer at sizes whose tiles fit (H % 8 == 0, W % 32 == 0) takes
+    conv3_c17_out1_kernel (LDS patch of fine and coarse pixels): several tiles per image in both directions,
+    so every image border and every tile seam is exercised."""
+    import torch
+    import avsi_amd  # noqa: F401
+    from avsi_amd import ops
+    g = torch.Generator(device='cuda')
+    g.manual_seed(77)
+    B, H, W, k, c0, c1, cout = 3, 24, 64, 3, 1, 16, 1
+    R = B * H * W
+    src0 = torch.randn(R, 4, generator=g, device='cuda')
+    src1 = torch.randn(B * (H // 2) * (W // 2), c1, generator=g, device='cuda')
+    kc = -(-(k * k * (c0 + c1)) // 4) * 4
+    filt = torch.zeros(kc, 4, device='cuda')
+    filt[:k * k * (c0 + c1), :cout] = torch.randn(k * k * (c0 + c1), cout, generator=g, device='cuda') * 0.2
+    bias = torch.randn(4, generator=g, device='cuda')
+    col = torch.empty(R, kc, device='cuda')
+    ops.im2col(src0, c0, src1, c1, B, H, W, k, col, kc)
+    want = torch.zeros(R, 4, device='cuda')
+    ops.gemm(col, filt, out=want, n=cout, bias=bias)
+    got = torch.zeros(R, 4, device='cuda')
+    ops.conv2d_thin(src0, c0, src1, c1, B, H, W, k, filt, bias, got, cout)
+    np.testing.assert_allclose(got[:, :cout].cpu().numpy(), want[:, :cout].cpu().numpy(), rtol=1e-5, atol=1e-5)
+
+
 @pytest.mark.parametrize("c0,c1,k,cout,B,H,W,splits", [(16, 0, 5, 32, 2, 12, 8, 3), (32, 64, 3, 32, 3, 8, 16, 1), (128, 128, 3, 128, 1, 4, 4, 2),
                                                        (16, 32, 3, 16, 2, 64, 8, 5), (4, 0, 3, 7, 1, 8, 8, 1)])
 def test_implicit_filter_gradient_matches_im2col_gemm(c0, c1, k, cout, B, H, W, splits):
