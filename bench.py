@@ -13,7 +13,8 @@ inpainter on 3 s / 16 kHz clips with one 400 ms gap each.
 For N > 1 launch with torch.distributed.run (one rank per GPU); utterances are sharded across
 ranks with no data-path collective (weak scaling: per-GPU batch fixed).  Rank 0 prints ONE JSON
 line.  Its `also` block reports the sizes the reference and BASELINE.json name (inference at 100 and
-32 utterances, AV training at 32 utterances per GPU -- with the gradient all-reduce when N > 1), each
+32 utterances, AV training at 32 utterances per GPU -- with the gradient all-reduce when N > 1) and two
+mid sizes (inference at 128 and 1024 utterances), each
 with its own ms_per_step, measured after the headline.  `roofline` is measured live with HIP events on the launch stream around the dominant
 kernel; `cpu_baseline` times the CPU oracle (a numpy port of the reference graph) on a bounded
 sample of the same workload on this node's host cores.
@@ -278,11 +279,12 @@ def time_steps(torch, step, steps, warmup):
 
 def named_workloads(torch, models, ops, model, cfg, mean, std, device, rank, world):
     """The sizes the reference and BASELINE.json name, next to the headline batch: inference on the 100 clips of
-    configs[0/1] as ONE batch and at the reference's inference batch of 32 (scripts/inference.sh:7), and the AV
+    configs[0/1] as ONE batch and at the reference's inference batch of 32 (scripts/inference.sh:7) -- plus 128 and 1024
+    utterances, the mid sizes the round-1 review set targets for -- and the AV
     training step at 32 utterances per GPU (configs[3]: global batch 256 over 8 GPUs; under torch.distributed this
     entry includes the bucketed RCCL all-reduce of the gradients).  Each entry has its own ms_per_step."""
     out = {}
-    for name, b in (("infer_b100", 100), ("infer_b32", 32)):
+    for name, b in (("infer_b100", 100), ("infer_b32", 32), ("infer_b128", 128), ("infer_b1024", 1024)):
         wav, masks = synth_batch(torch, b, 4321 + rank, device)
         seq = np.full(b, T_FRAMES)
         m = models.StackedBLSTMModel(seq, wav, masks, mean, std, 0.0, dict(cfg, batch_size=b, rows_per_wg=0), input='a',
@@ -292,8 +294,9 @@ def named_workloads(torch, models, ops, model, cfg, mean, std, device, rank, wor
             m.feed(sequence_lengths=seq, target_sources=wav, masks=masks)
             _ = m.prediction
             return m.loss_func
-        ms = time_steps(torch, step, 30, 5)
+        ms = time_steps(torch, step, 30 if b <= 128 else 10, 5 if b <= 128 else 3)
         ops.coop_check(device)
+        del m
         out[name] = {"workload": "configs[1] inference, %d utterances per step per GPU" % b, "per_gpu_batch": b,
                      "ms_per_step": ms, "value": b * world / ms * 1e3, "unit": "utterances/s"}
     b = 32
@@ -331,7 +334,7 @@ def main():
     ap.add_argument("--precision", choices=["f32", "bf16x3"], default="f32",
                     help="EXPLORATORY, inference only: bf16x3 = layer input projections with split-bf16 operands (hi.hi + hi.lo "
                          "+ lo.hi on the bf16 matrix cores, fp32 accumulation); never the default, never the headline")
-    ap.add_argument("--no-also", action="store_true", help="skip the named-workload entries (`also` block)")
+    ap.add_argument("--no-also", action="store_true", help="skip the named-workload entries (`also` block: inference at 100, 32, 128 and 1024 utterances, training at 32)")
     ap.add_argument("--also-timeout", type=int, default=240)
     ap.add_argument("--mode", choices=["infer", "train", "unet"], default="infer",
                     help="infer = headline workload (configs[1]); train = configs[2]: AV model, fwd + BPTT + Adam; "
