@@ -524,6 +524,7 @@ def main():
         dog.daemon = True
         dog.start()
         ops.gemm, ops.blstm_rec_fwd, ap_mod.frontend = untimed      # no per-call events in the small-batch entries
+        torch.set_num_threads(1)       # launch-bound entries: no intra-op pool beside the launching thread (see cpu_baseline)
         try:
             also = named_workloads(torch, models, ops, model, cfg, mean, std, device, rank, world)
         except Exception as e:        # never a reason to lose the headline
