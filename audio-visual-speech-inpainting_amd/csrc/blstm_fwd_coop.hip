@@ -49,6 +49,7 @@ struct CoopArgs {
     unsigned* sync;    // [0] status, [CTR_STRIDE * (1 + group)] step counters
     int T, Bp, ngroups;
     int tile0;         // first 32-utterance tile of this launch (large batches run in resident-sized chunks)
+    float* xch;        // fine kernels: h in exchange layout [T][group][member][32 utterances][units of the member], or null
 };
 
 __device__ __forceinline__ float sigmoidf_fast(float x) { return __builtin_amdgcn_rcpf(1.f + __expf(-x)); }
@@ -62,20 +63,26 @@ __device__ __forceinline__ float tanhf_fast(float x) { return 2.f * __builtin_am
 // every loaded value is passed through an empty asm so that no consumer can be scheduled before it.
 typedef float v4f __attribute__((ext_vector_type(4)));
 // byte_off: a constant after unrolling -- one address register pair serves a whole batch.
-// PLAIN drops the scope bits: the load may then be served by this XCD's L2 (or the CU's L1).  That is still correct
-// HERE because of how the exchange buffers are used: within a launch every 128-byte line of hout / dz is written
-// once, in full, before the step counter that releases its readers moves, nobody reads it earlier, and the caches
-// hold nothing of it from before the launch (kernel boundaries invalidate them) -- so a cached copy can only be the
-// final one.  The eight-plus members of a group sit on one XCD (block ids 8 apart), so all but the first reader of
-// a line then hit in L2 instead of going to the memory side: forward, 32 workgroups per tile at 128 utterances
-// 0.91 -> 0.80 ms per layer, BPTT 8 per tile at 512: 2.13 -> 1.85; no gain (or a small loss) where a workgroup reads
-// little (forward 4 / 8 per tile, BPTT half tiles), which keep the device-scope form.
+// PLAIN drops the scope bits: the load may then be served by this XCD's L2 (or the CU's L1).  That is correct only
+// under an invariant of the kernel that uses it: within a launch every 128-byte line of the exchange buffer is written
+// once, in full, before the step counter that releases its readers moves, NO load of any kind touches it earlier on
+// any CU (so no cache can hold a copy from before it was complete), and the caches hold nothing of it from before the
+// launch (kernel boundaries invalidate them).  The 4- and 8-way BPTT kernels satisfy it and read 64 - 128 KB of dz per
+// workgroup and step this way (the members of a group sit on one XCD, so all but the first reader of a line hit in its
+// L2: 2.13 -> 1.85 ms per layer at 512 utterances, 3.43 -> 3.16 at 1024).  The fine kernels do NOT: they touch lines
+// ahead of time (see below), which leaves early copies in the toucher's L1 and L2, so every load of exchanged bytes
+// there is a device-scope load (agent_load4_issue) -- the rule of cdna_hip_programming.md, Guideline 16.
 template <bool PLAIN = false>
 __device__ __forceinline__ void coherent_load4_issue(v4f& dst, const float* p, int byte_off) {
     if (PLAIN)
         asm volatile("global_load_dwordx4 %0, %1, off offset:%2" : "=v"(dst) : "v"(p), "i"(byte_off) : "memory");
     else
         asm volatile("global_load_dwordx4 %0, %1, off offset:%2 sc0 sc1" : "=v"(dst) : "v"(p), "i"(byte_off) : "memory");
+}
+// (`sc1` alone, the agent-scope form, measured the same as `sc0 sc1`: 0.825 / 0.853 against 0.824 / 0.866 ms per layer at 32 /
+// 128 utterances.)
+__device__ __forceinline__ void agent_load4_issue(v4f& dst, const float* p, int byte_off) {
+    asm volatile("global_load_dwordx4 %0, %1, off offset:%2 sc0 sc1" : "=v"(dst) : "v"(p), "i"(byte_off) : "memory");
 }
 // After its last step, member 0 of a group waits until every member has published that step (nobody polls the
 // counter any more) and puts the counter back to zero: the workspace is left as it was found, so the next launch on
@@ -257,7 +264,14 @@ __global__ __launch_bounds__(512, 2) void blstm_rec_fwd_coop_kernel(const CoopAr
 // columns form NT = 2 or 1 MFMA column tiles (gates (i, j) and (f, o) of 16 units, or all four gates of 8
 // units -- the B fragments are gathered accordingly from the same packed Wh, once); the eight waves split
 // the reduction as before (4 k-groups each), so a wave issues 16 NT MFMAs per step instead of 64.
-template <int NT, bool SAVE>
+// XCH: the members exchange h through a buffer of their own, laid out [step][group][member][32 utterances][UW units]:
+// a member's contribution to a step is ONE contiguous block (1 or 2 KB), so its write-through stores fill whole
+// 128-byte lines (in hout a member owns 32- or 64-byte pieces of lines: to a line no cache holds, such a store is
+// acknowledged only after the L2 has fetched the rest, 0.78 -> 0.86 ms per layer at 32 utterances on the cold buffers a
+// real step has), a reading wave's fragment load is one contiguous block, and the invariant of cacheable loads holds
+// (coherent_load4_issue): nothing touches a line before it is complete.  hout is written beside it with plain stores
+// nobody waits for.  Without XCH the exchange runs through hout itself: device-scope loads, lines touched ahead.
+template <int NT, bool SAVE, bool XCH>
 __global__ __launch_bounds__(512, 2) void blstm_rec_fwd_coop_fine_kernel(const CoopArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* part = reinterpret_cast<float*>(smem);      // [wave][tile][column][row]
@@ -300,6 +314,9 @@ __global__ __launch_bounds__(512, 2) void blstm_rec_fwd_coop_fine_kernel(const C
     float cstate = 0.f;
 
     unsigned* ctr = a.sync + CTR_STRIDE * (1 + 2 * a.tile0 + group);
+    // exchange layout: [step][global group][256 units as S member blocks][32 rows][UW]
+    const size_t xgroups = (size_t)2 * (Bp / 32);
+    float* xbase = XCH ? a.xch + (size_t)(2 * a.tile0 + group) * (32 * HP) : nullptr;
     __syncthreads();
 
     for (int step = 0; step < T; ++step) {
@@ -313,10 +330,12 @@ __global__ __launch_bounds__(512, 2) void blstm_rec_fwd_coop_fine_kernel(const C
 #pragma unroll
             for (int g = 0; g < 4; ++g)
                 xz[g] = a.xproj[(row0 + frow) * (2 * GP) + dir * GP + w * 128 + g * 32 + u0 + fu];
-            {   // Touch the line this lane will store to two steps from now.  A workgroup writes 32- or 64-byte pieces
+            if (!XCH) {   // Touch the line this lane will store to two steps from now.  A workgroup writes 32- or 64-byte pieces
                 // of a line; to a line no cache holds, the write-through store was acknowledged later (the L2 fetches
-                // the rest of the line first): 0.86 -> 0.76 ms per layer at 32 utterances on cold buffers, which is
-                // what a real step has (and 0.78 -> 0.76 on warm ones).  The register stays reserved until the
+                // the rest of the line first).  The loaded value is never used and the readers of this kernel use
+                // device-scope loads only, so the early (incomplete) copy this leaves in the L1 and L2 is never read;
+                // an `sc1` touch (no L1 copy) did not help at all (0.92 ms against 0.78), a scalar-cache touch less,
+                // and `buffer_inv sc1` before cacheable reads cost 4 ms.  The register stays reserved until the
                 // end-of-step wait: the compiler does not know the load is still in flight.
                 const int st2 = step + 2 < T ? step + 2 : T - 1;
                 const int t2 = dir ? (T - 1 - st2) : st2;
@@ -344,10 +363,20 @@ __global__ __launch_bounds__(512, 2) void blstm_rec_fwd_coop_fine_kernel(const C
                 }
             }
             __syncthreads();
-            const float* hp = a.hout + ((size_t)tprev * Bp + b0 + li) * (2 * HP) + dir * HP + 4 * hi;
             v4f af[4];
+            if (XCH) {
+                // k group q of this wave = units 32 ks + 8 q ..: block of member (32 ks + 8 q) / UW, offset (8 q) % UW
+                const float* xp = xbase + (size_t)(step - 1) * xgroups * (32 * HP);
 #pragma unroll
-            for (int q = 0; q < 4; ++q) coherent_load4_issue<true>(af[q], hp + 8 * ks * QPW, 32 * q);
+                for (int q = 0; q < 4; ++q) {
+                    const int unit0 = 32 * ks + 8 * q;
+                    coherent_load4_issue<true>(af[q], xp + ((unit0 / UW) * 32 + li) * UW + unit0 % UW + 4 * hi, 0);
+                }
+            } else {
+                const float* hp = a.hout + ((size_t)tprev * Bp + b0 + li) * (2 * HP) + dir * HP + 4 * hi;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) agent_load4_issue(af[q], hp + 8 * ks * QPW, 32 * q);
+            }
             coherent_wait(af);
 #pragma unroll
             for (int q = 0; q < 4; ++q)
@@ -385,8 +414,14 @@ __global__ __launch_bounds__(512, 2) void blstm_rec_fwd_coop_fine_kernel(const C
             cstate = cn;
             const float hn = og * tanhf_fast(cn);
             const int unit = w * 32 + u0 + fu;
-            __hip_atomic_store(a.hout + (row0 + frow) * (2 * HP) + dir * HP + unit, hn, __ATOMIC_RELAXED,
-                               __HIP_MEMORY_SCOPE_AGENT);
+            if (XCH) {      // the exchange copy first (the only store the publication waits for), hout beside it
+                __hip_atomic_store(xbase + (size_t)step * xgroups * (32 * HP) + (member * 32 + frow) * UW + fu, hn,
+                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                a.hout[(row0 + frow) * (2 * HP) + dir * HP + unit] = hn;
+            } else {
+                __hip_atomic_store(a.hout + (row0 + frow) * (2 * HP) + dir * HP + unit, hn, __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_AGENT);
+            }
             if (SAVE) {
                 float* rv = a.resv + (row0 + frow) * (2 * 5 * HP) + dir * 5 * HP + unit;
                 rv[0 * HP] = ig, rv[1 * HP] = jg, rv[2 * HP] = fg, rv[3 * HP] = og, rv[4 * HP] = cn;
@@ -395,7 +430,9 @@ __global__ __launch_bounds__(512, 2) void blstm_rec_fwd_coop_fine_kernel(const C
         // Only the h store has to be complete before the counter moves.  Stores complete in issue order, so with the
         // five reserve stores issued BEHIND it the wait leaves those in flight.  (Measured: no difference, neither on
         // warm buffers nor inside a training step -- kept because it is the weaker, sufficient condition.)
-        if (SAVE) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+        if (SAVE && XCH) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        else if (SAVE) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+        else if (XCH) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         asm volatile("" ::"v"(touched));
         __syncthreads();
@@ -404,17 +441,21 @@ __global__ __launch_bounds__(512, 2) void blstm_rec_fwd_coop_fine_kernel(const C
     if (member == 0 && tid == 0 && !dead) reset_counter_when_done(ctr, (unsigned)S * (unsigned)T);
 }
 
-template <int NT, bool SAVE>
-int launch_coop_fine(const CoopArgs& a, hipStream_t st) {
+template <int NT, bool SAVE, bool XCH>
+int launch_coop_fine_x(const CoopArgs& a, hipStream_t st) {
     constexpr int S = 32 / NT;
     // > half of the CU's LDS on purpose: one workgroup per CU, so the members of a group spread over S CUs
     const size_t lds = 96 * 1024;
     static_assert((size_t)8 * NT * 32 * PSTRIDE * sizeof(float) <= 96 * 1024, "partial tiles must fit");
-    (void)hipFuncSetAttribute((const void*)blstm_rec_fwd_coop_fine_kernel<NT, SAVE>,
+    (void)hipFuncSetAttribute((const void*)blstm_rec_fwd_coop_fine_kernel<NT, SAVE, XCH>,
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     const int blocks = (int)avsi_ceil_div(a.ngroups, AVSI_NUM_XCD) * AVSI_NUM_XCD * S;
-    hipLaunchKernelGGL((blstm_rec_fwd_coop_fine_kernel<NT, SAVE>), dim3(blocks), dim3(512), lds, st, a);
+    hipLaunchKernelGGL((blstm_rec_fwd_coop_fine_kernel<NT, SAVE, XCH>), dim3(blocks), dim3(512), lds, st, a);
     return avsi_launch_status();
+}
+template <int NT, bool SAVE>
+int launch_coop_fine(const CoopArgs& a, hipStream_t st) {
+    return a.xch ? launch_coop_fine_x<NT, SAVE, true>(a, st) : launch_coop_fine_x<NT, SAVE, false>(a, st);
 }
 
 template <int S, bool SAVE>
@@ -432,6 +473,11 @@ int launch_coop(const CoopArgs& a, hipStream_t st) {
 // word 0: status, then step counters: one per (tile, direction), two for the half-tile BPTT kernel
 extern "C" size_t avsi_blstm_rec_fwd_coop_workspace_bytes(int Bp) {
     return (size_t)CTR_STRIDE * (1 + 4 * (Bp > 0 ? Bp / 32 : 0)) * sizeof(unsigned);
+}
+
+// h of a whole launch in the exchange layout of the fine forward kernels: as many bytes as hout
+extern "C" size_t avsi_blstm_rec_fwd_coop_exchange_bytes(int T, int Bp) {
+    return (T > 0 && Bp > 0) ? (size_t)T * (size_t)Bp * (2 * HP) * sizeof(float) : 0;
 }
 
 // Tiles per launch: the whole launch must be resident (one workgroup per CU) on the `max_cus` compute units the
@@ -460,9 +506,14 @@ extern "C" int avsi_blstm_rec_fwd_coop_f32(const float* xproj, const float* whp,
     // every member of a group must be resident while its peers wait for it: batches beyond one chip-full of
     // groups run as consecutive launches over tile ranges
     const int tiles = Bp / 32, per = coop_tiles_per_launch(split, max_cus);
+    // a workspace that also holds avsi_blstm_rec_fwd_coop_exchange_bytes(T, Bp) at AVSI_COOP_EXCHANGE_OFFSET switches the fine
+    // splits (16, 32) to the exchange layout (see blstm_rec_fwd_coop_fine_kernel)
+    // (at a FIXED offset: the counters of a later, larger batch must not land on old exchange data)
+    float* xch = (split >= 16 && workspace_bytes >= AVSI_COOP_EXCHANGE_OFFSET + avsi_blstm_rec_fwd_coop_exchange_bytes(T, Bp))
+                     ? reinterpret_cast<float*>(static_cast<char*>(workspace) + AVSI_COOP_EXCHANGE_OFFSET) : nullptr;
     for (int tile0 = 0; tile0 < tiles; tile0 += per) {
         const int nt = tiles - tile0 < per ? tiles - tile0 : per;
-        CoopArgs a{xproj, whp, hout, reserve, (unsigned*)workspace, T, Bp, 2 * nt, tile0};
+        CoopArgs a{xproj, whp, hout, reserve, (unsigned*)workspace, T, Bp, 2 * nt, tile0, xch};
         int rc;
         if (split == 32)
             rc = reserve ? launch_coop_fine<1, true>(a, st) : launch_coop_fine<1, false>(a, st);
@@ -723,10 +774,10 @@ __global__ __launch_bounds__(512, 2) void blstm_rec_bwd_coop_fine_kernel(const C
             // (starting the MFMAs on the first loads while the rest is still landing -- staged vmcnt waits -- was slower)
             v4f a0[8], a1[8];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) coherent_load4_issue<RH == 1>(a0[j], zp, 64 * j);
+            for (int j = 0; j < 8; ++j) agent_load4_issue(a0[j], zp, 64 * j);
             if (NR == 2)
 #pragma unroll
-                for (int j = 0; j < 8; ++j) coherent_load4_issue<RH == 1>(a1[j], zq, 64 * j);
+                for (int j = 0; j < 8; ++j) agent_load4_issue(a1[j], zq, 64 * j);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
             for (int j = 0; j < 8; ++j) {

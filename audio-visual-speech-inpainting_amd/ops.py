@@ -108,9 +108,13 @@ def blstm_rec_fwd(xproj, whp, hout, reserve=None, rows_per_wg=0, split=None):
         return hout
     if split:
         L = _lib.lib()
-        ws = _coop_ws(xproj.device, Bp)
+        # fine splits: room for the exchange copy of h at its fixed offset (AVSI_COOP_EXCHANGE=0: exchange through hout)
+        need = L.avsi_blstm_rec_fwd_coop_workspace_bytes(Bp)
+        if split >= 16 and _COOP_EXCHANGE:
+            need = COOP_EXCHANGE_OFFSET + L.avsi_blstm_rec_fwd_coop_exchange_bytes(T, Bp)
+        ws = _coop_ws(xproj.device, Bp, need)
         _lib.check(L.avsi_blstm_rec_fwd_coop_f32(_lib.ptr(xproj), _lib.ptr(whp), _lib.ptr(hout), _lib.ptr(reserve), T, Bp,
-                                                 split, coop_cu_budget(), _lib.ptr(ws), ws.numel() * 4, _lib.stream_ptr()),
+                                                 split, coop_cu_budget(), _lib.ptr(ws), need, _lib.stream_ptr()),
                    "avsi_blstm_rec_fwd_coop_f32")
         return hout
     _lib.check(_lib.lib().avsi_blstm_rec_fwd_f32(_lib.ptr(xproj), _lib.ptr(whp), _lib.ptr(hout), _lib.ptr(reserve),
@@ -120,6 +124,8 @@ def blstm_rec_fwd(xproj, whp, hout, reserve=None, rows_per_wg=0, split=None):
 
 
 _COOP_WS, _COOP_HOST = {}, {}      # keyed by (device index, stream)
+_COOP_EXCHANGE = os.environ.get('AVSI_COOP_EXCHANGE', '1') != '0'
+COOP_EXCHANGE_OFFSET = 1 << 20       # AVSI_COOP_EXCHANGE_OFFSET of include/avsi_hip.h
 _COOP_MSG = "cooperative recurrent kernel timed out waiting for a peer workgroup; results are invalid"
 
 

@@ -91,3 +91,33 @@ def test_reported_failure_resets_the_workspaces():
     ops.blstm_rec_fwd(xproj, whp, hout, None, split=32)
     ops.coop_check()
     np.testing.assert_allclose(hout.cpu().numpy(), ref.cpu().numpy(), rtol=0, atol=2e-5)
+
+
+@pytest.mark.parametrize("Bp,split,save", [(32, 32, False), (96, 32, True), (64, 16, False), (288, 16, True)])
+def test_exchange_layout_gives_the_same_result(Bp, split, save, monkeypatch):
+    """The fine forward kernels with the exchange copy of h behind the counters (whole-line stores, contiguous fragment
+    loads) against the same kernels exchanging through hout: identical summation order, so identical bits -- in hout
+    and in the reserve."""
+    import torch
+    import avsi_amd  # noqa: F401
+    from avsi_amd import ops
+    T = 19
+    g = torch.Generator(device='cuda')
+    g.manual_seed(Bp + split)
+    xproj = torch.randn(T, Bp, 2048, generator=g, device='cuda')
+    whp = torch.randn(2 * 262144, generator=g, device='cuda') * 0.05
+    outs = []
+    for exchange in (True, False):
+        monkeypatch.setattr(ops, '_COOP_EXCHANGE', exchange)
+        hout = torch.full((T, Bp, 512), 7.0, device='cuda')
+        resv = torch.full((T, Bp, 2, 5, 256), 7.0, device='cuda') if save else None
+        for _ in range(2):          # twice into the same buffers: a stale cached line of the first run would show
+            ops.blstm_rec_fwd(xproj if _ else xproj * 0.5, whp, hout, resv, split=split)
+        outs.append((hout, resv))
+    ops.coop_check()
+    assert torch.equal(outs[0][0], outs[1][0])
+    if save:
+        assert torch.equal(outs[0][1], outs[1][1])
+    ref = torch.zeros(T, Bp, 512, device='cuda')
+    ops.blstm_rec_fwd(xproj, whp, ref, None, split=0)
+    np.testing.assert_allclose(outs[0][0].cpu().numpy(), ref.cpu().numpy(), rtol=0, atol=2e-5)
