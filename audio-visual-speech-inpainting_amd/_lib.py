@@ -118,6 +118,7 @@ PROTOTYPES = {
                                  c_size_t, c_void_p]),
     "avsi_blstm_rec_fwd_coop_workspace_bytes": (c_size_t, [c_int]),
     "avsi_blstm_rec_fwd_coop_exchange_bytes": (c_size_t, [c_int, c_int]),
+    "avsi_blstm_rec_bwd_coop_exchange_bytes": (c_size_t, [c_int, c_int]),
     "avsi_blstm_rec_fwd_coop_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p,
                                             c_size_t, c_void_p]),
     "avsi_blstm_rec_bwd_coop_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p,

@@ -479,6 +479,10 @@ extern "C" size_t avsi_blstm_rec_fwd_coop_workspace_bytes(int Bp) {
 extern "C" size_t avsi_blstm_rec_fwd_coop_exchange_bytes(int T, int Bp) {
     return (T > 0 && Bp > 0) ? (size_t)T * (size_t)Bp * (2 * HP) * sizeof(float) : 0;
 }
+// ... and dz of a whole launch for the fine BPTT kernels
+extern "C" size_t avsi_blstm_rec_bwd_coop_exchange_bytes(int T, int Bp) {
+    return (T > 0 && Bp > 0) ? (size_t)T * (size_t)Bp * (2 * 4 * HP) * sizeof(float) : 0;
+}
 
 // Tiles per launch: the whole launch must be resident (one workgroup per CU) on the `max_cus` compute units the
 // caller grants it (<= 0: the chip).  A process that keeps other kernels in flight beside the recurrence -- RCCL
@@ -548,6 +552,7 @@ struct CoopBwdArgs {
     unsigned* sync;
     int T, Bp, ngroups;
     int tile0;
+    float* xch;        // fine kernel: dz in exchange layout [step][group x half][member][gate][rows][16 units], or null
 };
 
 constexpr int BPART_FLOATS = 8 * 32 * PSTRIDE;      // [wave][unit][row]
@@ -684,7 +689,11 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 // RH = 2: the 32 utterances of a tile are two independent halves of 16 with 16 workgroups each (32 per
 // (tile, direction)): one MFMA row tile and half the dz rows per workgroup.
-template <int RH>
+// XCH: as in the forward kernel, the members exchange dz through a copy of their own, [step][group x half][member]
+// [gate][rows][16 units]: a member's four gate blocks of a step are written as whole lines (in dz it owns 64-byte pieces),
+// a reading wave's fragment load is one contiguous KB, cacheable loads are valid by construction; dz itself is written
+// beside it with plain stores nobody waits for.  Without XCH: exchange through dz, lines touched ahead, device-scope loads.
+template <int RH, bool XCH>
 __global__ __launch_bounds__(512, 2) void blstm_rec_bwd_coop_fine_kernel(const CoopBwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem_b[];
     float* part = reinterpret_cast<float*>(smem_b);    // [wave][unit 16][row 32 (+4 pad)]
@@ -723,6 +732,9 @@ __global__ __launch_bounds__(512, 2) void blstm_rec_bwd_coop_fine_kernel(const C
     const int unit = w * 32 + u0 + fu;
     float dcn = 0.f;
     unsigned* ctr = a.sync + CTR_STRIDE * (1 + RH * (2 * a.tile0 + group) + half);
+    constexpr int R = 16 * NR;                          // rows of this workgroup's (half) tile
+    const size_t xstep = (size_t)Bp * (2 * GP);        // floats of one step in the exchange layout (= one step of dz)
+    float* xbase = XCH ? a.xch + (size_t)(RH * (2 * a.tile0 + group) + half) * (S * 4 * R * 16) : nullptr;
     __syncthreads();
 
     for (int s = 0; s < T; ++s) {
@@ -741,12 +753,13 @@ __global__ __launch_bounds__(512, 2) void blstm_rec_bwd_coop_fine_kernel(const C
             ig = rv[0 * HP], jg = rv[1 * HP], fg = rv[2 * HP], og = rv[3 * HP], cc = rv[4 * HP];
             cp = has_prev ? a.resv[((size_t)tp * Bp + b0 + frow) * (2 * 5 * HP) + dir * 5 * HP + 4 * HP + unit] : 0.f;
             // touch the four dz lines this lane will store to two steps from now (see the forward kernel)
-            const int s2 = s + 2 < T ? s + 2 : T - 1;
+            const int s2 = XCH ? s : (s + 2 < T ? s + 2 : T - 1);
             const int t2 = dir ? s2 : (T - 1 - s2);
             const float* z2 = a.dz + ((size_t)t2 * Bp + b0 + frow) * (2 * GP) + dir * GP + w * 128 + u0 + fu;
+            if (!XCH)
 #pragma unroll
-            for (int g = 0; g < 4; ++g)
-                asm volatile("global_load_dword %0, %1, off offset:%2" : "=v"(touched[g]) : "v"(z2), "i"(128 * g) : "memory");
+                for (int g = 0; g < 4; ++g)
+                    asm volatile("global_load_dword %0, %1, off offset:%2" : "=v"(touched[g]) : "v"(z2), "i"(128 * g) : "memory");
         }
 
         f32x4 acc[NR];
@@ -773,11 +786,22 @@ __global__ __launch_bounds__(512, 2) void blstm_rec_bwd_coop_fine_kernel(const C
             const float* zq = zp + (size_t)16 * (2 * GP);
             // (starting the MFMAs on the first loads while the rest is still landing -- staged vmcnt waits -- was slower)
             v4f a0[8], a1[8];
+            if (XCH) {
+                // columns ks * 128 + 16 j + 4 kq ..: block (member 2 ks + (j & 1), gate j >> 1), row l16 (and 16 + l16)
+                const float* xp = xbase + (size_t)(s - 1) * xstep + (size_t)l16 * 16 + 4 * kq;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) agent_load4_issue(a0[j], zp, 64 * j);
-            if (NR == 2)
+                for (int j = 0; j < 8; ++j) {
+                    const float* bp = xp + (((2 * ks + (j & 1)) * 4 + (j >> 1)) * R) * 16;
+                    coherent_load4_issue<true>(a0[j], bp, 0);
+                    if (NR == 2) coherent_load4_issue<true>(a1[j], bp, 16 * 16 * 4);
+                }
+            } else {
 #pragma unroll
-                for (int j = 0; j < 8; ++j) agent_load4_issue(a1[j], zq, 64 * j);
+                for (int j = 0; j < 8; ++j) agent_load4_issue(a0[j], zp, 64 * j);
+                if (NR == 2)
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) agent_load4_issue(a1[j], zq, 64 * j);
+            }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
@@ -811,12 +835,24 @@ __global__ __launch_bounds__(512, 2) void blstm_rec_bwd_coop_fine_kernel(const C
             const float dc = d * og * (1.f - tc * tc) + dcn;
             dcn = dc * fg;
             float* zo = a.dz + row * (2 * GP) + dir * GP + w * 128 + u0 + fu;
-            __hip_atomic_store(zo + 0, dc * jg * ig * (1.f - ig), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(zo + 32, dc * ig * (1.f - jg * jg), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(zo + 64, dc * cp * fg * (1.f - fg), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(zo + 96, d * tc * og * (1.f - og), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const float dzi = dc * jg * ig * (1.f - ig), dzj = dc * ig * (1.f - jg * jg);
+            const float dzf = dc * cp * fg * (1.f - fg), dzo = d * tc * og * (1.f - og);
+            if (XCH) {      // the exchange copy first (the only stores the publication waits for), dz beside it
+                float* xo = xbase + (size_t)s * xstep + ((size_t)(member * 4) * R + frow) * 16 + fu;
+                __hip_atomic_store(xo + 0 * R * 16, dzi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(xo + 1 * R * 16, dzj, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(xo + 2 * R * 16, dzf, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(xo + 3 * R * 16, dzo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                zo[0] = dzi, zo[32] = dzj, zo[64] = dzf, zo[96] = dzo;
+            } else {
+                __hip_atomic_store(zo + 0, dzi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(zo + 32, dzj, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(zo + 64, dzf, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(zo + 96, dzo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (XCH) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");      // stores complete in issue order: the four exchange stores are done
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
         for (int g = 0; g < 4; ++g) asm volatile("" ::"v"(touched[g]));
         __syncthreads();
@@ -838,21 +874,29 @@ extern "C" int avsi_blstm_rec_bwd_coop_f32(const float* dhout, const float* rese
     avsi_clear_error();
     // no memset: the caller zeroes the workspace once, every launch leaves its counters at zero again
     // (reset_counter_when_done) and never touches the sticky status word
-    if (split == 16)
-        (void)hipFuncSetAttribute((const void*)blstm_rec_bwd_coop_fine_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  96 * 1024);
-    if (split == 32)
-        (void)hipFuncSetAttribute((const void*)blstm_rec_bwd_coop_fine_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  96 * 1024);
+    // a workspace that also holds avsi_blstm_rec_bwd_coop_exchange_bytes(T, Bp) at AVSI_COOP_EXCHANGE_OFFSET switches the
+    // fine splits (16, 32) to the exchange layout
+    float* xch = (split >= 16 && workspace_bytes >= AVSI_COOP_EXCHANGE_OFFSET + avsi_blstm_rec_bwd_coop_exchange_bytes(T, Bp))
+                     ? reinterpret_cast<float*>(static_cast<char*>(workspace) + AVSI_COOP_EXCHANGE_OFFSET) : nullptr;
+    if (split >= 16) {
+        (void)hipFuncSetAttribute((const void*)blstm_rec_bwd_coop_fine_kernel<1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+        (void)hipFuncSetAttribute((const void*)blstm_rec_bwd_coop_fine_kernel<1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+        (void)hipFuncSetAttribute((const void*)blstm_rec_bwd_coop_fine_kernel<2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+        (void)hipFuncSetAttribute((const void*)blstm_rec_bwd_coop_fine_kernel<2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+    }
     const int tiles = Bp / 32, per = coop_tiles_per_launch(split, max_cus);
     for (int tile0 = 0; tile0 < tiles; tile0 += per) {
         const int nt = tiles - tile0 < per ? tiles - tile0 : per;
-        CoopBwdArgs a{dhout, reserve, whbT, dz, (unsigned*)workspace, T, Bp, 2 * nt, tile0};
+        CoopBwdArgs a{dhout, reserve, whbT, dz, (unsigned*)workspace, T, Bp, 2 * nt, tile0, xch};
         const int blocks = (int)avsi_ceil_div(2 * nt, AVSI_NUM_XCD) * AVSI_NUM_XCD * split;
-        if (split == 32)     // 16 unit slices x 2 row halves
-            hipLaunchKernelGGL(blstm_rec_bwd_coop_fine_kernel<2>, dim3(blocks), dim3(512), 96 * 1024, st, a);
-        else if (split == 16)     // 96 KiB of LDS requested on purpose: one workgroup per CU (it uses 18 KiB)
-            hipLaunchKernelGGL(blstm_rec_bwd_coop_fine_kernel<1>, dim3(blocks), dim3(512), 96 * 1024, st, a);
+        if (split == 32 && xch)     // 16 unit slices x 2 row halves
+            hipLaunchKernelGGL((blstm_rec_bwd_coop_fine_kernel<2, true>), dim3(blocks), dim3(512), 96 * 1024, st, a);
+        else if (split == 32)
+            hipLaunchKernelGGL((blstm_rec_bwd_coop_fine_kernel<2, false>), dim3(blocks), dim3(512), 96 * 1024, st, a);
+        else if (split == 16 && xch)     // 96 KiB of LDS requested on purpose: one workgroup per CU (it uses 18 KiB)
+            hipLaunchKernelGGL((blstm_rec_bwd_coop_fine_kernel<1, true>), dim3(blocks), dim3(512), 96 * 1024, st, a);
+        else if (split == 16)
+            hipLaunchKernelGGL((blstm_rec_bwd_coop_fine_kernel<1, false>), dim3(blocks), dim3(512), 96 * 1024, st, a);
         else if (split == 8)
             hipLaunchKernelGGL(blstm_rec_bwd_coop_kernel<8>, dim3(blocks), dim3(512), 0, st, a);
         else

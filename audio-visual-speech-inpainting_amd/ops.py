@@ -441,10 +441,13 @@ def blstm_rec_bwd(dhout, reserve, whbt, dz, split=None):
         raise _lib.AvsiError("blstm_rec_bwd: bad operand shapes / strides")
     split = coop_split(Bp, backward=True) if split is None else int(split)
     if split:
-        ws = _coop_ws(dhout.device, Bp)
-        _lib.check(_lib.lib().avsi_blstm_rec_bwd_coop_f32(_lib.ptr(dhout), _lib.ptr(reserve), _lib.ptr(whbt), _lib.ptr(dz),
-                                                          T, Bp, split, coop_cu_budget(), _lib.ptr(ws), ws.numel() * 4,
-                                                          _lib.stream_ptr()),
+        L = _lib.lib()
+        need = L.avsi_blstm_rec_fwd_coop_workspace_bytes(Bp)
+        if split >= 16 and _COOP_EXCHANGE:      # fine splits: room for the exchange copy of dz at its fixed offset
+            need = COOP_EXCHANGE_OFFSET + L.avsi_blstm_rec_bwd_coop_exchange_bytes(T, Bp)
+        ws = _coop_ws(dhout.device, Bp, need)
+        _lib.check(L.avsi_blstm_rec_bwd_coop_f32(_lib.ptr(dhout), _lib.ptr(reserve), _lib.ptr(whbt), _lib.ptr(dz),
+                                                 T, Bp, split, coop_cu_budget(), _lib.ptr(ws), need, _lib.stream_ptr()),
                    "avsi_blstm_rec_bwd_coop_f32")
         return dz
     _lib.check(_lib.lib().avsi_blstm_rec_bwd_f32(_lib.ptr(dhout), _lib.ptr(reserve), _lib.ptr(whbt), _lib.ptr(dz),

@@ -179,6 +179,9 @@ size_t avsi_blstm_rec_fwd_coop_workspace_bytes(int Bp);
  * offset, clear of the counters of any batch size, and needs no initialisation.  Results are identical. */
 #define AVSI_COOP_EXCHANGE_OFFSET ((size_t)1 << 20)
 size_t avsi_blstm_rec_fwd_coop_exchange_bytes(int T, int Bp);
+/* The same for avsi_blstm_rec_bwd_coop_f32 with split 16 / 32 (dz in exchange layout; same offset, the two calls may
+ * share one workspace: a launch is done with its copy when it ends). */
+size_t avsi_blstm_rec_bwd_coop_exchange_bytes(int T, int Bp);
 int avsi_blstm_rec_fwd_coop_f32(const float* xproj, const float* whp, float* hout, float* reserve,
                                 int T, int Bp, int split, int max_cus, void* workspace, size_t workspace_bytes,
                                 void* stream);

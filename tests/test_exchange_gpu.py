@@ -121,3 +121,31 @@ def test_exchange_layout_gives_the_same_result(Bp, split, save, monkeypatch):
     ref = torch.zeros(T, Bp, 512, device='cuda')
     ops.blstm_rec_fwd(xproj, whp, ref, None, split=0)
     np.testing.assert_allclose(outs[0][0].cpu().numpy(), ref.cpu().numpy(), rtol=0, atol=2e-5)
+
+
+@pytest.mark.parametrize("Bp,split", [(32, 32), (160, 32), (64, 16), (288, 16)])
+def test_exchange_layout_gives_the_same_bptt_result(Bp, split, monkeypatch):
+    """The fine BPTT kernels with dz exchanged through the copy in exchange layout against the same kernels exchanging
+    through dz itself: identical bits, and both equal to the batch-stationary kernel within rounding."""
+    import torch
+    import avsi_amd  # noqa: F401
+    from avsi_amd import ops
+    T = 17
+    g = torch.Generator(device='cuda')
+    g.manual_seed(Bp * 3 + split)
+    dh = torch.randn(T, Bp, 512, generator=g, device='cuda')
+    resv = torch.rand(T, Bp, 2, 5, 256, generator=g, device='cuda') * 0.9 + 0.05
+    whbt = torch.randn(2 * 262144, generator=g, device='cuda') * 0.05
+    outs = []
+    for exchange in (True, False):
+        monkeypatch.setattr(ops, '_COOP_EXCHANGE', exchange)
+        dz = torch.full((T, Bp, 2048), 7.0, device='cuda')
+        for k in range(2):          # twice into the same buffers: a stale cached line of the first run would show
+            ops.blstm_rec_bwd(dh if k else dh * 0.5, resv, whbt, dz, split=split)
+        outs.append(dz)
+    ops.coop_check()
+    assert torch.equal(outs[0], outs[1])
+    ref = torch.zeros(T, Bp, 2048, device='cuda')
+    ops.blstm_rec_bwd(dh, resv, whbt, ref, split=0)
+    scale = float(ref.abs().max())
+    np.testing.assert_allclose(outs[0].cpu().numpy(), ref.cpu().numpy(), rtol=0, atol=2e-6 * scale + 1e-7)
