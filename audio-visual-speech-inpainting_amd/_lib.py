@@ -153,6 +153,10 @@ PROTOTYPES = {
     "avsi_sequence_example_decode_fixed_host": (c_int, [c_void_p, c_size_t, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
                                                         c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p,
                                                         c_void_p]),
+    "avsi_tfrecord_file_shape_host": (c_int, [c_char_p, c_int, c_void_p]),
+    "avsi_tfrecord_file_decode_fixed_host": (c_int, [c_char_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
+                                                     c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p,
+                                                     c_void_p]),
     "avsi_ctc_beam_search_host_f32": (c_int, [c_void_p, c_int64, c_int64, c_int, c_int, c_int, c_void_p, c_int, c_int,
                                               c_void_p, c_int, c_void_p, c_void_p]),
     "avsi_lws_num_frames": (c_int, [c_int, c_int, c_int]),

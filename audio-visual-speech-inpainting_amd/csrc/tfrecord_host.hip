@@ -6,7 +6,10 @@
 // allocation, re-entrant: the Python side calls it from a thread pool (ctypes drops the GIL).
 #include <stddef.h>
 #include <stdint.h>
+#include <stdio.h>
 #include <string.h>
+
+#include <vector>
 
 #include "../../include/avsi_hip.h"
 
@@ -343,4 +346,77 @@ extern "C" int avsi_sequence_example_decode_fixed_host(const void* buf, size_t n
     if (!(have_len && have_lab && have_wav && have_path && have_emb && have_mask && have_video && have_labels))
         return AVSI_ERR_INVALID_ARG;
     return AVSI_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Whole-file form for the reference's datasets (ONE record per .tfrecord file): open, read, verify the TFRecord
+// framing (length + masked CRC-32C of the length, payload + masked CRC-32C of the payload), parse.  Everything
+// between the path and the batch rows happens here, outside the interpreter lock, so a Python reader can run
+// several files in parallel threads (the pure-Python framing loop got SLOWER with threads: 0.17 ms per file
+// serial, 0.47 ms with eight).
+extern "C" uint32_t avsi_crc32c(const void* data, size_t n, uint32_t seed);
+
+namespace {
+
+uint32_t masked_crc(const void* p, size_t n) {
+    const uint32_t c = avsi_crc32c(p, n, 0);
+    return ((c >> 15) | (c << 17)) + 0xa282ead8u;
+}
+
+// 0 = ok (payload in `buf`), AVSI_ERR_INVALID_ARG = unreadable / truncated / checksum mismatch,
+// AVSI_ERR_UNSUPPORTED = more than one record in the file
+int read_single_record(const char* path, int verify, std::vector<unsigned char>& buf) {
+    FILE* fh = fopen(path, "rb");
+    if (!fh) return AVSI_ERR_INVALID_ARG;
+    unsigned char head[12];
+    int rc = AVSI_OK;
+    uint64_t n = 0;
+    if (fread(head, 1, 12, fh) != 12) rc = AVSI_ERR_INVALID_ARG;
+    if (rc == AVSI_OK) {
+        memcpy(&n, head, 8);
+        uint32_t hcrc;
+        memcpy(&hcrc, head + 8, 4);
+        if (n > ((uint64_t)1 << 32) || (verify && hcrc != masked_crc(head, 8))) rc = AVSI_ERR_INVALID_ARG;
+    }
+    if (rc == AVSI_OK) {
+        buf.resize((size_t)n + 4);
+        if (fread(buf.data(), 1, (size_t)n + 4, fh) != (size_t)n + 4) rc = AVSI_ERR_INVALID_ARG;
+    }
+    if (rc == AVSI_OK && verify) {
+        uint32_t dcrc;
+        memcpy(&dcrc, buf.data() + n, 4);
+        if (dcrc != masked_crc(buf.data(), (size_t)n)) rc = AVSI_ERR_INVALID_ARG;
+    }
+    if (rc == AVSI_OK) {
+        unsigned char extra;
+        if (fread(&extra, 1, 1, fh) == 1) rc = AVSI_ERR_UNSUPPORTED;      // a second record follows
+        buf.resize((size_t)n);
+    }
+    fclose(fh);
+    return rc;
+}
+
+}  // namespace
+
+extern "C" int avsi_tfrecord_file_shape_host(const char* path, int verify, int64_t* shape5) {
+    if (!path || !shape5) return AVSI_ERR_INVALID_ARG;
+    std::vector<unsigned char> buf;
+    const int rc = read_single_record(path, verify, buf);
+    if (rc != AVSI_OK) return rc;
+    return avsi_sequence_example_shape_host(buf.data(), buf.size(), shape5);
+}
+
+extern "C" int avsi_tfrecord_file_decode_fixed_host(const char* path, int verify, int num_audio_samples, int audio_feat_size,
+                                                    int video_feat_size, int embedding_size, int num_frames,
+                                                    int num_video_frames, int num_labels, int32_t* lengths2, int32_t* wav_i32,
+                                                    float* embedding, char* sample_path, int sample_path_cap, float* labels,
+                                                    float* video, float* mask) {
+    if (!path) return AVSI_ERR_INVALID_ARG;
+    // one buffer per thread, kept: a record is 590 KB, and mapping fresh pages for every file was a third of the cost
+    static thread_local std::vector<unsigned char> buf;
+    const int rc = read_single_record(path, verify, buf);
+    if (rc != AVSI_OK) return rc;
+    return avsi_sequence_example_decode_fixed_host(buf.data(), buf.size(), num_audio_samples, audio_feat_size, video_feat_size,
+                                                   embedding_size, num_frames, num_video_frames, num_labels, lengths2, wav_i32,
+                                                   embedding, sample_path, sample_path_cap, labels, video, mask);
 }

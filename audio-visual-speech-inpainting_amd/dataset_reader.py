@@ -45,21 +45,51 @@ class OutOfRangeError(Exception):
     """End of the dataset (the role of tf.errors.OutOfRangeError)."""
 
 
+class RecordFile(str):
+    """Path of a .tfrecord file that holds exactly one record (the reference's datasets).  It stands in for the
+    record's payload in the stream: the native batch decoder reads, checks and parses such files itself, off the
+    interpreter lock and several at a time (avsi_tfrecord_file_decode_fixed_host); everything else gets the bytes
+    through ``payload_bytes``."""
+    __slots__ = ()
+
+
+def payload_bytes(item):
+    """The serialized record behind an element of ``Dataset.payloads()``."""
+    if isinstance(item, RecordFile):
+        return next(iter(tfrecord_io.read_records(item)))
+    return item
+
+
 class Dataset(object):
     def __init__(self, files, shuffle, seed, buffer_size, parse):
         self.files = list(files)
         self.shuffle = shuffle
         self.seed = seed
         self.buffer_size = buffer_size
-        self.parse = parse
+        self._parse = parse
         self._epoch = 0
+        # one record per file (checked on the first file; a later file with more records fails loudly in the decoder):
+        # the stream then carries paths, and the files are read where they are decoded
+        self.record_files = False
+        if self.files and os.environ.get('AVSI_READER_FILES', '1') != '0':
+            shape = (ctypes.c_int64 * 5)()
+            rc = _lib.lib().avsi_tfrecord_file_shape_host(os.fsencode(self.files[0]), 0, shape)
+            self.record_files = rc == _lib.AVSI_OK
+
+    def parse(self, item):
+        return self._parse(payload_bytes(item))
 
     def payloads(self):
-        """One pass: serialized records in file order, passed through a tf.data-style shuffle buffer."""
+        """One pass: serialized records (or ``RecordFile`` paths, see there) in file order, passed through a tf.data-style
+        shuffle buffer."""
         def read_file(path):
             return list(tfrecord_io.read_records(path))
 
         def raw():
+            if self.record_files:
+                for path in self.files:
+                    yield RecordFile(path)
+                return
             # the reference's datasets are one file per sample: files are read (and their checksums verified)
             # on the pool a bounded distance ahead, and handed on strictly in file order
             pending, ahead = [], 16
@@ -336,7 +366,12 @@ class DataManager:
         L = _lib.lib()
         B = len(payloads)
         shape = (ctypes.c_int64 * 5)()
-        if L.avsi_sequence_example_shape_host(payloads[0], len(payloads[0]), shape) != _lib.AVSI_OK:
+        from_files = isinstance(payloads[0], RecordFile)
+        if from_files:
+            paths_fs = [os.fsencode(p) for p in payloads]
+            if L.avsi_tfrecord_file_shape_host(paths_fs[0], 1, shape) != _lib.AVSI_OK:
+                raise IOError("%s: unreadable, truncated, corrupted (crc mismatch) or malformed record" % payloads[0])
+        elif L.avsi_sequence_example_shape_host(payloads[0], len(payloads[0]), shape) != _lib.AVSI_OK:
             raise ValueError("malformed SequenceExample record")
         n_wav, n_emb, T, Tv, n_lab = (int(v) for v in shape)
         if n_wav != self.num_audio_samples:
@@ -364,15 +399,26 @@ class DataManager:
             return a.ctypes.data + i * a.strides[0] if a is not None and a.size else 0
 
         def one(i):
+            if from_files:       # open + read + checksums + parse in one native call: no interpreter lock held
+                return L.avsi_tfrecord_file_decode_fixed_host(
+                    paths_fs[i], 1, n_wav, self.audio_feat_size, self.video_feat_size, E, T, Tv, n_lab,
+                    row(lengths, i), row(wav, i), row(emb, i), paths_addr + i * 1024, 1024, row(labels, i), row(video, i),
+                    row(mask, i))
             return L.avsi_sequence_example_decode_fixed_host(
                 payloads[i], len(payloads[i]), n_wav, self.audio_feat_size, self.video_feat_size, E, T, Tv, n_lab,
                 row(lengths, i), row(wav, i), row(emb, i), paths_addr + i * 1024, 1024, row(labels, i), row(video, i),
                 row(mask, i))
-        # serial on purpose: a record is ~0.2 ms of memcpy into freshly mapped pages, which threads only contend on
-        for i, rc in enumerate(one(i) for i in range(B)):
+        # records already in memory: serial on purpose (a record is ~0.2 ms of memcpy, which threads only contend on);
+        # files: on the pool -- the calls release the interpreter lock, and reading + checking a file is most of the work
+        codes = list(_pool().map(one, range(B))) if from_files and B > 1 else [one(i) for i in range(B)]
+        for i, rc in enumerate(codes):
+            if from_files and rc == _lib.AVSI_ERR_INVALID_ARG:
+                raise IOError("%s: unreadable, truncated, corrupted (crc mismatch) or malformed record" % payloads[i])
             if rc == _lib.AVSI_ERR_UNSUPPORTED:
                 raise ValueError("record %d of the batch does not have the sizes of the first one / of the DataManager "
-                                 "configuration (feature sizes, frame or label counts)" % i)
+                                 "configuration (feature sizes, frame or label counts)%s" % (
+                                     i, " -- or its file holds more than one record (AVSI_READER_FILES=0 reads such datasets)"
+                                     if from_files else ""))
             if rc != _lib.AVSI_OK:
                 raise ValueError("malformed SequenceExample record (or a feature of the 'fixed' schema is missing)")
         sample_paths = np.array([ctypes.string_at(paths_addr + i * 1024) for i in range(B)], dtype=object)

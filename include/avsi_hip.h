@@ -505,6 +505,18 @@ int avsi_sequence_example_decode_fixed_host(const void* buf, size_t n, int num_a
                                             char* sample_path, int sample_path_cap, float* labels,
                                             float* video, float* mask);
 
+/* The same for a whole .tfrecord file that holds ONE record (the reference's datasets: one sample per file): open,
+ * read, check the TFRecord framing (masked CRC-32C of length and payload; verify = 0 skips the checks), parse.  All of
+ * it outside any interpreter lock, so readers may run files on parallel threads.  AVSI_ERR_INVALID_ARG: unreadable,
+ * truncated, checksum mismatch or malformed record; AVSI_ERR_UNSUPPORTED: more than one record in the file, or sizes
+ * that differ from the ones passed. */
+int avsi_tfrecord_file_shape_host(const char* path, int verify, int64_t* shape5);
+int avsi_tfrecord_file_decode_fixed_host(const char* path, int verify, int num_audio_samples, int audio_feat_size,
+                                         int video_feat_size, int embedding_size, int num_frames,
+                                         int num_video_frames, int num_labels, int32_t* lengths2, int32_t* wav_i32,
+                                         float* embedding, char* sample_path, int sample_path_cap, float* labels,
+                                         float* video, float* mask);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,5 +1,8 @@
 // Sanitizer harness for the host-side SequenceExample decoder (CPU only): reads length-prefixed cases from a
-// file and runs avsi_sequence_example_shape_host + avsi_sequence_example_decode_fixed_host on each.
+// file and runs avsi_sequence_example_shape_host + avsi_sequence_example_decode_fixed_host on each; with a second
+// argument (a scratch file path) every case is also written out as the content of a .tfrecord file and read back
+// through avsi_tfrecord_file_shape_host / avsi_tfrecord_file_decode_fixed_host (the cases of that run are whole FILES:
+// valid framing, truncations, flipped bits, a second record).
 // Built by tests/test_native_sanitizers.py with g++ -fsanitize=address,undefined.
 #include <stdint.h>
 #include <stdio.h>
@@ -32,6 +35,23 @@ int main(int argc, char** argv) {
         const int rc = avsi_sequence_example_decode_fixed_host(buf.data(), n, N, F, V, E, T, Tv, L, lengths.data(), wav.data(),
                                                                emb.data(), path.data(), (int)path.size(), labels.data(),
                                                                video.data(), mask.data());
+        if (argc > 2) {      // the same bytes as a file
+            FILE* o = fopen(argv[2], "wb");
+            if (!o) return 4;
+            if (n) fwrite(buf.data(), 1, n, o);
+            fclose(o);
+            int64_t fshape[5];
+            const int frc0 = avsi_tfrecord_file_shape_host(argv[2], 1, fshape);
+            const int fT = frc0 == 0 && fshape[2] >= 0 && fshape[2] < 64 ? (int)fshape[2] : 12;
+            const int fTv = frc0 == 0 && fshape[3] >= 0 && fshape[3] < 64 ? (int)fshape[3] : 12;
+            const int fL = frc0 == 0 && fshape[4] >= 0 && fshape[4] < 128 ? (int)fshape[4] : 50;
+            std::vector<float> flabels(fL ? fL : 1), fvideo((size_t)(fTv ? fTv : 1) * V), fmask((size_t)(fT ? fT : 1) * F);
+            const int frc = avsi_tfrecord_file_decode_fixed_host(argv[2], 1, N, F, V, E, fT, fTv, fL, lengths.data(), wav.data(),
+                                                                 emb.data(), path.data(), (int)path.size(), flabels.data(),
+                                                                 fvideo.data(), fmask.data());
+            (frc == 0 ? ok : rejected)++;
+            continue;
+        }
         (rc == 0 ? ok : rejected)++;
     }
     fclose(f);

@@ -13,6 +13,7 @@ from avsi_amd import tfrecord_io as tio
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, "audio-visual-speech-inpainting_amd", "csrc", "tfrecord_host.hip")
+CRC = os.path.join(ROOT, "audio-visual-speech-inpainting_amd", "csrc", "host_io.hip")
 MAIN = os.path.join(ROOT, "tests", "native", "asan_tfrecord_main.cpp")
 
 
@@ -20,7 +21,7 @@ MAIN = os.path.join(ROOT, "tests", "native", "asan_tfrecord_main.cpp")
 def test_decoder_under_address_and_ub_sanitizers(tmp_path):
     exe = str(tmp_path / "asan_tfrecord")
     cmd = ["g++", "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=all",
-           "-x", "c++", SRC, MAIN, "-o", exe]
+           "-x", "c++", SRC, CRC, MAIN, "-o", exe]
     build = subprocess.run(cmd, capture_output=True, text=True)
     if build.returncode != 0 and "sanitize" in build.stderr and "cannot find" in build.stderr:
         pytest.skip("sanitizer runtime not installed: " + build.stderr.splitlines()[-1])
@@ -57,3 +58,29 @@ def test_decoder_under_address_and_ub_sanitizers(tmp_path):
     assert run.returncode == 0, run.stderr[-2000:]
     ok, rejected = (int(v) for v in run.stdout.split()[1::2])
     assert ok >= 1 and rejected >= 200 and ok + rejected == len(cases)
+
+    # the whole-file readers (avsi_tfrecord_file_*): valid single-record file, truncations, flipped bits (every one a
+    # checksum mismatch or a broken length), a file with a second record, an empty file
+    good = str(tmp_path / "good.tfrecord")
+    tio.write_records(good, [rec])
+    blob = open(good, "rb").read()
+    fcases = [blob, b"", blob[:5], blob[:12], blob[:-1], blob + blob, blob + b"x"]
+    for trial in range(120):
+        buf = bytearray(blob)
+        if trial % 3 == 0:
+            buf = buf[:rng.integers(0, len(buf))]
+        elif trial % 3 == 1:
+            buf[rng.integers(0, len(buf))] ^= 1 << rng.integers(0, 8)
+        else:
+            buf[rng.integers(0, 12)] = rng.integers(0, 256)       # the length word / its checksum
+        fcases.append(bytes(buf))
+    fpath = str(tmp_path / "fcases.bin")
+    with open(fpath, "wb") as fh:
+        for c in fcases:
+            fh.write(struct.pack("<I", len(c)))
+            fh.write(c)
+    run = subprocess.run([exe, fpath, str(tmp_path / "scratch.tfrecord")], capture_output=True, text=True, timeout=120,
+                         env=dict(os.environ, ASAN_OPTIONS="detect_leaks=0"))
+    assert run.returncode == 0, run.stderr[-2000:]
+    ok, rejected = (int(v) for v in run.stdout.split()[1::2])
+    assert ok >= 1 and rejected >= 100 and ok + rejected == len(fcases)

@@ -304,3 +304,40 @@ def test_even_rounds_give_every_rank_the_same_number_of_batches(tmp_path):
     assert [len(b[0]) for b in plain] == [2, 2]            # batches 0 and 2 (the short one, index 3, is rank 1's)
     _, single = dm.get_iterator(ds, batch_size=2, n_epochs=1, even_rounds=True)
     assert [len(b[0]) for b in single] == [2, 2, 2, 1]     # one process: nothing to even out
+
+
+def test_whole_file_reader_matches_the_framed_path(tmp_path, monkeypatch):
+    """One-record files are read, checked and parsed natively on parallel threads (avsi_tfrecord_file_decode_fixed_host):
+    same batches, same shuffle order as the Python framing loop + in-memory decoder (AVSI_READER_FILES=0), with and
+    without the embedding feature; a dataset whose FIRST file holds several records takes the framed path by itself,
+    and one that turns out to hold several records later fails with a message that says so."""
+    files, _ = _write_dataset(tmp_path, 11, with_emb=True)
+    dm = dr.DataManager(2304, 257, 136, buffer_size=5, embedding_size=512)
+
+    def batches(flag):
+        monkeypatch.setenv('AVSI_READER_FILES', flag)
+        ds = dm.get_dataset(files, shuffle=True, seed=3)
+        assert ds.record_files == (flag == '1')
+        _, it = dm.get_iterator(ds, batch_size=4, n_epochs=2, prefetch=0)
+        return [tuple(np.array(f) for f in b) for b in it]
+
+    native, framed = batches('1'), batches('0')
+    assert [len(b[0]) for b in native] == [len(b[0]) for b in framed] and len(native) == 6
+    for a, b in zip(native, framed):
+        for x, y in zip(a, b):
+            assert x.dtype == y.dtype and x.shape == y.shape
+            assert (x == y).all()
+    monkeypatch.setenv('AVSI_READER_FILES', '1')
+    # several records in the first file: the framed path, by itself
+    multi = str(tmp_path / "multi_00000.tfrecord")
+    tio.write_records(multi, [_sample(50, with_emb=True)[0], _sample(51, with_emb=True)[0]])
+    ds = dm.get_dataset([multi] + files[:2], shuffle=False)
+    assert not ds.record_files
+    _, it = dm.get_iterator(ds, batch_size=4, n_epochs=1, prefetch=0)
+    assert len(next(it)[0]) == 4
+    # several records in a LATER file: a clear error
+    ds = dm.get_dataset(files[:2] + [multi], shuffle=False)
+    assert ds.record_files
+    _, it = dm.get_iterator(ds, batch_size=3, n_epochs=1, prefetch=0)
+    with pytest.raises(ValueError, match="more than one record"):
+        next(it)
