@@ -424,24 +424,26 @@ __global__ __launch_bounds__(64 * NW) void lws_sweeps_kernel(float2* __restrict_
 #pragma unroll
             for (int u = 0; u < U; ++u) load_row(u, m + 2, pre[u]);
 
-            // magnitudes of row m, and is any bin above the threshold?
-            bool frame_active = false;
+            // magnitudes of row m, and which bins are above the threshold for at least one utterance of the wave?  (one
+            // bit per bin: the magnitudes never change -- an update only turns a bin -- so a bin that is below now is
+            // copied, not computed, by the recurrence below)
+            unsigned long long amask[5];
 #pragma unroll
-            for (int u = 0; u < U; ++u) {
+            for (int i = 0; i < 5; ++i) {
+                const int k = lane + 64 * i;
                 bool act = false;
+                if (k < KB) {
 #pragma unroll
-                for (int i = 0; i < 5; ++i) {
-                    const int k = lane + 64 * i;
-                    if (k < KB) {
+                    for (int u = 0; u < U; ++u) {
                         const float2 v = s_row[u][sc][k + LMAX];
                         const float a = sqrtf(v.x * v.x + v.y * v.y);
                         s_amp[u][k] = a;
                         act |= (u < nu) && (a > thr[u]);
                     }
                 }
-                frame_active |= act;
+                amask[i] = __ballot(act);
             }
-            frame_active = __any(frame_active);
+            const bool frame_active = (amask[0] | amask[1] | amask[2] | amask[3] | amask[4]) != 0ull;
 
             if (frame_active) {
                 // ---- phase 1: the taps that are known before the frame starts
@@ -450,6 +452,7 @@ __global__ __launch_bounds__(64 * NW) void lws_sweeps_kernel(float2* __restrict_
 #pragma unroll
                     for (int i = 0; i < 5; ++i) {
                         const int k = lane + 64 * i;
+                        if (amask[i] == 0ull) continue;                 // 64 bins none of which is updated in this sweep
                         if (k < KB) {
                             float2 acc = make_float2(0.f, 0.f);
                             const float2* rp = &s_row[u][sp_][k];        // entry k + p + LMAX, p = -LMAX ..
@@ -528,12 +531,20 @@ __global__ __launch_bounds__(64 * NW) void lws_sweeps_kernel(float2* __restrict_
                     // square root and two multiplies, with no LDS round trip on it.
                     float2 p0 = s_p[u][LMAX], o0 = row[LMAX + LMAX], p1 = s_p[u][LMAX + 1], o1 = row[LMAX + 1 + LMAX];
                     float a0 = s_amp[u][LMAX], a1 = s_amp[u][LMAX + 1];
+                    unsigned long long bits = amask[0] >> LMAX;       // bit 0 = bin k of the loop below
 #pragma unroll 2
                     for (int k = LMAX; k <= 256 - LMAX - 1; ++k) {
+                        if ((k & 63) == 0) bits = amask[k >> 6];
+                        const bool on = bits & 1ull;                 // wave-uniform: some utterance of the wave has this bin active
+                        bits >>= 1;
                         const float2 pk = p0, old = o0;
                         const float a = a0;
                         p0 = p1, o0 = o1, a0 = a1;
                         p1 = s_p[u][k + 2], o1 = row[k + 2 + LMAX], a1 = s_amp[u][k + 2];    // <= 258: inside the padded rows
+                        if (!on) {      // below every threshold: the bin keeps its value (a sixth of the instructions)
+                            s5 = s4, s4 = s3, s3 = s2, s2 = s1, s1 = old;
+                            continue;
+                        }
                         // the four older taps first: only the last MAC waits for the bin just finished
                         float2 t = cmadd(pk, c5, s5);
                         t = cmadd(t, c4, s4);
