@@ -239,6 +239,10 @@ struct LwsWaveLds {
     float amp[U][PS];       // magnitudes of row m
 };
 
+// v_rsq_f32 alone: rsqrtf() wraps it in a denormal-input rescue (scale, compare, two selects) that sits on the loop-carried
+// chain of the in-frame recurrence; |t|^2 of a bin that is updated is nowhere near 1e-38
+__device__ __forceinline__ float fast_rsqrt(float x) { return __builtin_amdgcn_rsqf(x); }
+
 // wave-local ordering point: LDS accesses of one wave execute in order, so lanes exchanging data through LDS only
 // need the compiler not to reorder (and the counters drained before data another lane wrote is read)
 __device__ __forceinline__ void wave_sync() {
@@ -483,7 +487,7 @@ __global__ __launch_bounds__(64 * NW) void lws_sweeps_kernel(float2* __restrict_
                                 const float2 t = s_p[u][k];
                                 const float a = s_amp[u][k], n2 = t.x * t.x + t.y * t.y;
                                 if (u < nu && a > thr[u] && n2 > 0.f) {
-                                    const float sc_ = a * rsqrtf(n2);
+                                    const float sc_ = a * fast_rsqrt(n2);
                                     s_row[u][sc][k + LMAX] = make_float2(t.x * sc_, t.y * sc_);
                                 }
                             }
@@ -516,7 +520,7 @@ __global__ __launch_bounds__(64 * NW) void lws_sweeps_kernel(float2* __restrict_
                             if (k + p > 256) t = cmadd(t, make_float2(W.w[1][LMAX + p][0], W.w[1][LMAX + p][1]), row[k + p + LMAX]);
                         const float n2 = t.x * t.x + t.y * t.y;
                         if (n2 > 0.f) {
-                            const float sc_ = a * rsqrtf(n2);
+                            const float sc_ = a * fast_rsqrt(n2);
                             const float2 v = make_float2(t.x * sc_, t.y * sc_);
                             row[k + LMAX] = v;
                             if (k >= 1 && k <= LMAX) row[LMAX - k] = make_float2(v.x, -v.y);
@@ -553,7 +557,7 @@ __global__ __launch_bounds__(64 * NW) void lws_sweeps_kernel(float2* __restrict_
                         t = cmadd(t, c1, s1);
                         const float n2 = t.x * t.x + t.y * t.y;
                         const bool upd = (a > thu) && (n2 > 0.f);
-                        const float sc_ = a * rsqrtf(n2);
+                        const float sc_ = a * fast_rsqrt(n2);
                         const float2 v = upd ? make_float2(t.x * sc_, t.y * sc_) : old;
                         row[k + LMAX] = v;
                         s5 = s4, s4 = s3, s3 = s2, s2 = s1, s1 = v;
