@@ -506,63 +506,90 @@ __global__ __launch_bounds__(64 * NW) void lws_sweeps_kernel(float2* __restrict_
                     const float2 c3 = make_float2(W.w[1][LMAX - 3][0], W.w[1][LMAX - 3][1]);
                     const float2 c4 = make_float2(W.w[1][LMAX - 4][0], W.w[1][LMAX - 4][1]);
                     const float2 c5 = make_float2(W.w[1][LMAX - 5][0], W.w[1][LMAX - 5][1]);
-                    // edge bins: every row-0 tap that may have changed in this sweep is read back from the row
-                    auto edge_bin = [&](int k) {
+                    const float2 cpast[LMAX] = {c1, c2, c3, c4, c5};
+                    // Lower edge (bins 0 .. LMAX-1): their taps below bin 0 are mirror images of bins 1 .. LMAX, which this
+                    // same sweep updates -- the 2*LMAX values involved are held in registers (the loop is fully unrolled) and
+                    // every change goes to the row AND to its image, so no bin waits for an LDS round trip.
+                    float2 e[2 * LMAX];
+#pragma unroll
+                    for (int i = 0; i < 2 * LMAX; ++i) e[i] = row[i];           // bins -LMAX .. LMAX-1
+#pragma unroll
+                    for (int k = 0; k < LMAX; ++k) {
                         const float a = s_amp[u][k];
-                        if (!(a > thu)) return;
                         float2 t = s_p[u][k];
-                        t = cmadd(t, c1, row[k - 1 + LMAX]);
-                        t = cmadd(t, c2, row[k - 2 + LMAX]);
-                        t = cmadd(t, c3, row[k - 3 + LMAX]);
-                        t = cmadd(t, c4, row[k - 4 + LMAX]);
-                        t = cmadd(t, c5, row[k - 5 + LMAX]);
-                        for (int p = 1; p <= LMAX; ++p)
-                            if (k + p > 256) t = cmadd(t, make_float2(W.w[1][LMAX + p][0], W.w[1][LMAX + p][1]), row[k + p + LMAX]);
+#pragma unroll
+                        for (int p = LMAX; p >= 1; --p) t = cmadd(t, cpast[p - 1], e[k - p + LMAX]);   // newest tap last
                         const float n2 = t.x * t.x + t.y * t.y;
-                        if (n2 > 0.f) {
-                            const float sc_ = a * fast_rsqrt(n2);
-                            const float2 v = make_float2(t.x * sc_, t.y * sc_);
-                            row[k + LMAX] = v;
-                            if (k >= 1 && k <= LMAX) row[LMAX - k] = make_float2(v.x, -v.y);
-                            if (k >= 256 - LMAX && k <= 255) row[LMAX + 512 - k] = make_float2(v.x, -v.y);
+                        const bool upd = (a > thu) && (n2 > 0.f);
+                        const float sc_ = a * fast_rsqrt(n2);
+                        const float2 v = upd ? make_float2(t.x * sc_, t.y * sc_) : e[k + LMAX];
+                        e[k + LMAX] = v;
+                        row[k + LMAX] = v;
+                        if (k >= 1) {
+                            const float2 im = upd ? make_float2(v.x, -v.y) : e[LMAX - k];
+                            e[LMAX - k] = im;
+                            row[LMAX - k] = im;
                         }
-                    };
-                    for (int k = 0; k < LMAX; ++k) edge_bin(k);
-                    float2 s1 = row[LMAX - 1 + LMAX], s2 = row[LMAX - 2 + LMAX], s3 = row[LMAX - 3 + LMAX],
-                           s4 = row[LMAX - 4 + LMAX], s5 = row[LMAX - 5 + LMAX];
-                    // Straight-line body (the store is unconditional: an inactive bin writes its old value back), operands
-                    // of the next TWO bins already requested: the loop-carried chain is five complex MACs, a reciprocal
-                    // square root and two multiplies, with no LDS round trip on it.
-                    float2 p0 = s_p[u][LMAX], o0 = row[LMAX + LMAX], p1 = s_p[u][LMAX + 1], o1 = row[LMAX + 1 + LMAX];
+                    }
+                    float2 s1 = e[2 * LMAX - 1], s2 = e[2 * LMAX - 2], s3 = e[2 * LMAX - 3], s4 = e[2 * LMAX - 4],
+                           s5 = e[2 * LMAX - 5];
+                    // Software-pipelined straight-line body. Only nu <= 4 lanes run here, so the latency of the loop-carried
+                    // chain is fully exposed: it is kept to the NEWEST tap (one complex MAC), the norm, a reciprocal
+                    // square root and two multiplies, and the four older taps of the NEXT bin (which need nothing of the
+                    // bin in flight) sit beside it in the same basic block to fill its issue slots. The store is
+                    // unconditional (an inactive bin writes its old value back); LDS operands are requested two bins ahead.
+                    float2 p1 = s_p[u][LMAX + 1], o0 = row[LMAX + LMAX], o1 = row[LMAX + 1 + LMAX];
                     float a0 = s_amp[u][LMAX], a1 = s_amp[u][LMAX + 1];
-                    unsigned long long bits = amask[0] >> LMAX;       // bit 0 = bin k of the loop below
-#pragma unroll 2
+                    float2 part = cmadd(cmadd(cmadd(cmadd(s_p[u][LMAX], c5, s5), c4, s4), c3, s3), c2, s2);
+#pragma unroll 4
                     for (int k = LMAX; k <= 256 - LMAX - 1; ++k) {
-                        if ((k & 63) == 0) bits = amask[k >> 6];
-                        const bool on = bits & 1ull;                 // wave-uniform: some utterance of the wave has this bin active
-                        bits >>= 1;
-                        const float2 pk = p0, old = o0;
+                        const float2 old = o0;
                         const float a = a0;
-                        p0 = p1, o0 = o1, a0 = a1;
-                        p1 = s_p[u][k + 2], o1 = row[k + 2 + LMAX], a1 = s_amp[u][k + 2];    // <= 258: inside the padded rows
-                        if (!on) {      // below every threshold: the bin keeps its value (a sixth of the instructions)
-                            s5 = s4, s4 = s3, s3 = s2, s2 = s1, s1 = old;
-                            continue;
-                        }
-                        // the four older taps first: only the last MAC waits for the bin just finished
-                        float2 t = cmadd(pk, c5, s5);
-                        t = cmadd(t, c4, s4);
-                        t = cmadd(t, c3, s3);
-                        t = cmadd(t, c2, s2);
-                        t = cmadd(t, c1, s1);
+                        const float2 p2 = s_p[u][k + 2], o2 = row[k + 2 + LMAX];    // <= 258: inside the padded rows
+                        const float a2 = s_amp[u][k + 2];
+                        const float2 t = cmadd(part, c1, s1);
+                        float2 nxt = cmadd(p1, c5, s4);          // bin k + 1 without its newest tap
+                        nxt = cmadd(nxt, c4, s3);
+                        nxt = cmadd(nxt, c3, s2);
+                        nxt = cmadd(nxt, c2, s1);
                         const float n2 = t.x * t.x + t.y * t.y;
                         const bool upd = (a > thu) && (n2 > 0.f);
                         const float sc_ = a * fast_rsqrt(n2);
                         const float2 v = upd ? make_float2(t.x * sc_, t.y * sc_) : old;
                         row[k + LMAX] = v;
-                        s5 = s4, s4 = s3, s3 = s2, s2 = s1, s1 = v;
+                        s4 = s3, s3 = s2, s2 = s1, s1 = v;
+                        part = nxt, p1 = p2, o0 = o1, o1 = o2, a0 = a1, a1 = a2;
                     }
-                    for (int k = 256 - LMAX; k <= 256; ++k) edge_bin(k);
+                    // Upper edge (bins 256-LMAX .. 256): besides the LMAX past bins, their taps above bin 256 are mirror images
+                    // of bins 256-LMAX .. 255, updated by this same block -- registers again, newest tap last.
+                    float2 q[2 * LMAX + 1], img[LMAX + 1];
+                    q[0] = row[256 - 2 * LMAX + LMAX], q[1] = s4, q[2] = s3, q[3] = s2, q[4] = s1;   // bins 256-2*LMAX .. 256-LMAX-1
+                    static_assert(LMAX == 5, "the past-tap registers s1..s4 above are written out for LMAX = 5");
+#pragma unroll
+                    for (int p = 1; p <= LMAX; ++p) img[p] = row[256 + p + LMAX];
+#pragma unroll
+                    for (int j = 0; j <= LMAX; ++j) {
+                        const int k = 256 - LMAX + j;
+                        const float a = s_amp[u][k];
+                        const float2 old = row[k + LMAX];
+                        float2 t = s_p[u][k];
+#pragma unroll
+                        for (int p = LMAX; p >= 1; --p)
+                            if (k + p > 256) t = cmadd(t, make_float2(W.w[1][LMAX + p][0], W.w[1][LMAX + p][1]), img[k + p - 256]);
+#pragma unroll
+                        for (int p = LMAX; p >= 1; --p) t = cmadd(t, cpast[p - 1], q[j + LMAX - p]);
+                        const float n2 = t.x * t.x + t.y * t.y;
+                        const bool upd = (a > thu) && (n2 > 0.f);
+                        const float sc_ = a * fast_rsqrt(n2);
+                        const float2 v = upd ? make_float2(t.x * sc_, t.y * sc_) : old;
+                        q[j + LMAX] = v;
+                        row[k + LMAX] = v;
+                        if (k <= 255) {
+                            const float2 im = upd ? make_float2(v.x, -v.y) : img[256 - k];
+                            img[256 - k] = im;
+                            row[LMAX + 512 - k] = im;
+                        }
+                    }
                 }
                 wave_sync();
                 // refresh the mirror images of row m (it becomes row m - 1 of the next frame) and write it back
