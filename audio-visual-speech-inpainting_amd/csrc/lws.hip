@@ -706,10 +706,9 @@ extern "C" int avsi_lws_run_f32(float* spec, int batch, int num_frames, int fram
     // (U, at most 4 next to a useful number of waves: a CU's LDS holds 16 utterance-waves); the sweeps of an utterance
     // group are pipelined over the NW waves of a workgroup and over G workgroups, which must all be resident.  The
     // recurrence is issue-bound per wave, so waves that share a SIMD slow each other down: spread over CUs first.
-    // Measured (tools/lws_time.py, ms per batch, U x NW x G): 8 utterances 1x4x26: 33.7, 4x4x26: 43.4, 1x16x7: 48.3;
-    // 32: 1x8x8: 30.6, 4x4x16: 35.8, 1x16x7: 47.5; 64: 4x4x16: 32.9, 2x8x8: 34.8, 1x16x4: 45.9; 100: 4x4x10: 40.5,
-    // 1x16x2: 63.0; 256: 4x4x4: 69.1, 2x8x2: 74.5, 1x16x1: 106; 512: 4x4x2: 124, 2x8x1: 134, 1x8x1: 237;
-    // 1024 .. 4096: 4x4x1: 4.4 k utterances/s (1x4x1: 2.3 k at 1024, 4x1x1: 3.8 k at 4096).
+    // Measured (tools/lws_shapes.sh, ms per batch, U x NW x G): 8 utterances 1x4x26: 23.6, 1x8x13: 28.7; 32: 1x8x8: 23.4,
+    // 4x4x16: 23.7, 2x8x8: 25.0, 1x4x8: 26.9; 64: 4x4x16: 22.0, 2x8x8: 24.9, 1x8x4: 31.1; 100: 4x4x10: 27.3, 2x8x5: 30.5,
+    // 1x8x2: 50.0; 256: 4x4x4: 47.0, 2x8x2: 54.1, 1x8x1: 90.0; 512: 4x4x2: 83.9, 2x8x1: 98.3; 1024: 4x4x1: 6.5 k utterances/s.
     if (U == 0) U = batch > 32 ? 4 : 1;
     const int clusters = (batch + U - 1) / U;
     if (NW == 0) {
