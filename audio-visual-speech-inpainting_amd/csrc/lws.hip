@@ -338,12 +338,11 @@ __global__ __launch_bounds__(64 * NW) void lws_sweeps_kernel(float2* __restrict_
     __syncthreads();
 
     // wait until sweep s - 1 has finished `need` rows (bounded: see `dead`)
-    auto wait_rows = [&](int s, int need) {
-        if (s == 0 || dead) return;
+    auto wait_rows = [&](int pred, bool remote, int need) {
+        if (pred < 0 || dead) return;
         need = need < M ? need : M;
         int spins = 0;
-        const bool remote = wv == 0 && G > 1;          // the predecessor stage lives in the previous workgroup
-        while ((remote ? __hip_atomic_load(gdone + s - 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : done[s - 1]) < need) {
+        while ((remote ? __hip_atomic_load(gdone + pred, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : done[pred]) < need) {
             __builtin_amdgcn_s_sleep(8);
             if (++spins > (1 << 22)) {
                 dead = true;
@@ -356,7 +355,7 @@ __global__ __launch_bounds__(64 * NW) void lws_sweeps_kernel(float2* __restrict_
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (lane == 0) {
             done[s] = rows;
-            if (wv == NW - 1 && G > 1) __hip_atomic_store(gdone + s, rows, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (G > 1) __hip_atomic_store(gdone + s, rows, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     };
     auto load_row = [&](int u, int m, float2 (&r)[5]) {      // global -> registers (zeros outside the spectrogram)
@@ -391,15 +390,23 @@ __global__ __launch_bounds__(64 * NW) void lws_sweeps_kernel(float2* __restrict_
             thr[u] = sched.rel[sw] * mean_u[u];
             any_u |= (u < nu) && (max_u[u] > thr[u]);
         }
-        if (!any_u) {               // wave-uniform: this sweep touches nothing -- it is done when its predecessor is
-            wait_rows(sw, M);
-            publish(sw, M);
-            continue;
+        if (!any_u) continue;       // wave-uniform: this sweep touches nothing, and nobody waits for it (see `pred`)
+        // The sweep this one follows: the nearest earlier sweep that touches anything (a sweep whose threshold is above
+        // every magnitude leaves the rows as they were, so waiting for IT would only serialise the pipeline -- it could
+        // report a row finished no earlier than its own predecessor's LAST row).  Every stage of the utterance group sees
+        // the same thresholds and statistics, hence the same answer.
+        int pred = sw - 1;
+        for (; pred >= 0; --pred) {
+            bool on = false;
+#pragma unroll
+            for (int u = 0; u < U; ++u) on |= (u < nu) && (max_u[u] > sched.rel[pred] * mean_u[u]);
+            if (on) break;
         }
+        const bool pred_remote = pred >= 0 && G > 1 && (pred % stages) / NW != wg;     // its stage sits in another workgroup
         const bool past_only = sched.past_only[sw] != 0;
 
         // ring: slot (m + 3) % 3 holds row m
-        wait_rows(sw, 2);
+        wait_rows(pred, pred_remote, 2);
         wave_sync();
 #pragma unroll
         for (int u = 0; u < U; ++u) {
@@ -423,7 +430,7 @@ __global__ __launch_bounds__(64 * NW) void lws_sweeps_kernel(float2* __restrict_
         for (int m = 0; m < M; ++m) {
             const int sc = m % 3, sp_ = (m + 2) % 3, sn_ = (m + 1) % 3;   // cur, prev, next
             // prefetch row m + 2 (lands in the slot of row m - 1 after this frame): final once sweep sw - 1 is past it
-            wait_rows(sw, m + 3);
+            wait_rows(pred, pred_remote, m + 3);
             float2 pre[U][5];
 #pragma unroll
             for (int u = 0; u < U; ++u) load_row(u, m + 2, pre[u]);
