@@ -351,6 +351,11 @@ __global__ __launch_bounds__(64 * NW) void lws_sweeps_kernel(float2* __restrict_
             }
         }
     };
+    auto rows_done = [&](int pred, bool remote) -> int {      // wave-uniform; a sweep without predecessor sees all rows
+        if (pred < 0 || dead) return 1 << 30;
+        const int n = remote ? __hip_atomic_load(gdone + pred, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : done[pred];
+        return __builtin_amdgcn_readfirstlane(n);
+    };
     auto publish = [&](int s, int rows) {      // after every global store of those rows has completed
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (lane == 0) {
@@ -429,11 +434,17 @@ __global__ __launch_bounds__(64 * NW) void lws_sweeps_kernel(float2* __restrict_
 
         for (int m = 0; m < M; ++m) {
             const int sc = m % 3, sp_ = (m + 2) % 3, sn_ = (m + 1) % 3;   // cur, prev, next
-            // prefetch row m + 2 (lands in the slot of row m - 1 after this frame): final once sweep sw - 1 is past it
-            wait_rows(pred, pred_remote, m + 3);
+            // Row m + 2 (it lands in the slot of row m - 1 after this frame) is final once sweep `pred` is past it.  If it
+            // already is, the row is requested now and its latency hides behind this frame; if not, the frame does NOT
+            // wait for it -- everything it reads (rows m and m + 1) is here -- and fetches the row after its own row has
+            // been published: a sweep then starts two rows behind its predecessor instead of three, which with ~100
+            // sweeps in a chain is most of what one utterance waits for.
+            const bool early = rows_done(pred, pred_remote) >= (m + 3 < M ? m + 3 : M);
             float2 pre[U][5];
+            if (early) {
 #pragma unroll
-            for (int u = 0; u < U; ++u) load_row(u, m + 2, pre[u]);
+                for (int u = 0; u < U; ++u) load_row(u, m + 2, pre[u]);
+            }
 
             // magnitudes of row m, and which bins are above the threshold for at least one utterance of the wave?  (one
             // bit per bin: the magnitudes never change -- an update only turns a bin -- so a bin that is below now is
@@ -614,6 +625,12 @@ __global__ __launch_bounds__(64 * NW) void lws_sweeps_kernel(float2* __restrict_
                     }
                 }
             }
+            publish(sw, m + 1);
+            if (!early) {
+                wait_rows(pred, pred_remote, m + 3);
+#pragma unroll
+                for (int u = 0; u < U; ++u) load_row(u, m + 2, pre[u]);
+            }
             wave_sync();
             // row m + 2 replaces row m - 1
 #pragma unroll
@@ -622,7 +639,6 @@ __global__ __launch_bounds__(64 * NW) void lws_sweeps_kernel(float2* __restrict_
 #pragma unroll
             for (int u = 0; u < U; ++u) mirror_row(u, sp_);
             wave_sync();
-            publish(sw, m + 1);
         }
     }
 }
