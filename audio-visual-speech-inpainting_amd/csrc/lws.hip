@@ -732,7 +732,10 @@ extern "C" int avsi_lws_run_f32(float* spec, int batch, int num_frames, int fram
     // Measured (tools/lws_shapes.sh, ms per batch, U x NW x G): 8 utterances 1x4x26: 23.6, 1x8x13: 28.7; 32: 1x8x8: 23.4,
     // 4x4x16: 23.7, 2x8x8: 25.0, 1x4x8: 26.9; 64: 4x4x16: 22.0, 2x8x8: 24.9, 1x8x4: 31.1; 100: 4x4x10: 27.3, 2x8x5: 30.5,
     // 1x8x2: 50.0; 256: 4x4x4: 47.0, 2x8x2: 54.1, 1x8x1: 90.0; 512: 4x4x2: 83.9, 2x8x1: 98.3; 1024: 4x4x1: 6.5 k utterances/s.
-    if (U == 0) U = batch > 32 ? 4 : 1;
+    // 17 .. 32 utterances: two per wave, 8 waves, so that 16 utterance groups x 13 workgroups give every sweep a stage of
+    // its own (32 utterances: 2x8x16 14.8 ms, 1x8x8 17.5, 4x4x16 17.1 -- since the chain of sweeps got shorter, section 4.3d
+    // of DESIGN.md, more stages pay even with two waves to a SIMD)
+    if (U == 0) U = batch > 32 ? 4 : batch > 16 ? 2 : 1;
     const int clusters = (batch + U - 1) / U;
     if (NW == 0) {
         if (U > 1) NW = 16 / U;
