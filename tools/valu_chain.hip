@@ -71,5 +71,25 @@ int main() {
                "dependent fma %.2f, rsq+add pair %.2f\n", lanes, ms * 1e3, h[0] + h[1] + h[2] + h[3],
                (h[0] + h[1] + h[2] + h[3]) / (ms * 1e3), h[0] / n, h[1] / n, h[2] / n, h[3] / n);
     }
+    // the same with the rest of the chip busy on another stream (does a lone wave run faster on a loaded chip?)
+    hipStream_t side;
+    (void)hipStreamCreateWithFlags(&side, hipStreamNonBlocking);
+    for (int heaters : {64, 224}) {
+        hipLaunchKernelGGL(warm, dim3(heaters * 4), dim3(256), 0, side, out + 1);      // ~4 resident workgroups per CU
+        hipEvent_t e0, e1;
+        (void)hipEventCreate(&e0), (void)hipEventCreate(&e1);
+        hipLaunchKernelGGL(k, dim3(1), dim3(64), 0, 0, out, cyc, 64);
+        (void)hipEventRecord(e0, 0);
+        hipLaunchKernelGGL(k, dim3(1), dim3(64), 0, 0, out, cyc, 64);
+        (void)hipEventRecord(e1, 0);
+        long long h[4];
+        if (hipMemcpy(h, cyc, 32, hipMemcpyDeviceToHost) != hipSuccess) return 1;
+        float ms = 0;
+        (void)hipEventElapsedTime(&ms, e0, e1);
+        const double n = 16.0 * REPS;
+        printf("beside %d x 4 spinning workgroups: kernel %.0f us; per instruction: dependent pk_fma %.2f, 4 independent pk_fma chains %.2f, "
+               "dependent fma %.2f, rsq+add pair %.2f\n", heaters, ms * 1e3, h[0] / n, h[1] / n, h[2] / n, h[3] / n);
+        (void)hipStreamSynchronize(side);
+    }
     return 0;
 }
