@@ -111,12 +111,41 @@ def infer(model_path, data_path_test, audio_path, out_file_prefix, norm=True, or
     total_samples = 0
     loss_list = []
     writer = _WavWriter(audio_path, out_file_prefix, int(os.environ.get('AVSI_WAV_THREADS', '0')))
+    # The LWS kernel is a pipeline of ~100 sweeps: a batch of 32 takes it 16 ms, four such batches together 27 ms
+    # (DESIGN 4.3d).  Batches are therefore collected until LWS_GROUP utterances wait for their phase, refined in one
+    # launch and written in the order they came; the per-batch lines below are printed when their files are queued.
+    lws_group = int(os.environ.get('AVSI_LWS_GROUP', '128'))
+    pending = []                    # (enhanced, masks, paths, lengths) of batches whose phase is still to be refined
+
+    def written(paths, lengths):
+        nonlocal total_samples
+        total_samples += len(lengths)
+        print('Written {:d} enhanced wavs. Total samples written so far {:d}.'.format(len(lengths), total_samples))
+
+    def flush():
+        if not pending:
+            return
+        if len(pending) == 1:
+            wavs, masks = pending[0][0], pending[0][1]
+        else:
+            wavs = torch.cat([p[0] for p in pending])
+            masks = torch.cat([p[1] for p in pending])
+        # Reconstruct phase with LWS algorithm (reference inference.py:141-154), all collected batches on the device
+        out = lws_processor.refine_enhanced(wavs, masks, num_samples=wavs.shape[1]).cpu().numpy()
+        at = 0
+        for _, _, paths, lengths in pending:
+            writer.submit(out[at:at + len(lengths)], paths, lengths)
+            at += len(lengths)
+            written(paths, lengths)
+        pending.clear()
+
     print('Starting inference on dataset: {:s}'.format(data_path_test))
     while True:
         try:
             feed, test_sample_path = unpack_batch(test_it.get_next(), uses_embeddings(config))
             test_length = feed['sequence_lengths']
         except OutOfRangeError:
+            flush()
             print('done.')
             break
         model.feed(**feed)
@@ -124,13 +153,20 @@ def infer(model_path, data_path_test, audio_path, out_file_prefix, norm=True, or
         loss = model.loss                       # read back once, after the loop: no host round trip per batch
         loss = loss.detach().clone() if hasattr(loss, 'detach') else float(loss)
         ops.coop_poll()
-        if not oracle_phase:
-            # Reconstruct phase with LWS algorithm (reference inference.py:141-154), whole batch on the device
-            enhanced = lws_processor.refine_enhanced(enhanced, model.masks, num_samples=enhanced.shape[1])
-        writer.submit(enhanced.cpu().numpy(), test_sample_path, test_length)
         loss_list.append(loss)
-        total_samples += len(test_length)
-        print('Written {:d} enhanced wavs. Total samples written so far {:d}.'.format(len(test_length), total_samples))
+        if oracle_phase:
+            writer.submit(enhanced.cpu().numpy(), test_sample_path, test_length)
+            written(test_sample_path, test_length)
+            continue
+        masks = model.masks
+        if pending and (pending[0][0].shape[1:] != enhanced.shape[1:] or pending[0][1].shape[1:] != masks.shape[1:]):
+            flush()                             # a batch of another length: it cannot share the launch
+        if len(test_length) >= lws_group and not pending:
+            pending.append((enhanced, masks, test_sample_path, test_length))        # alone: no copy needed
+        else:
+            pending.append((enhanced.clone(), masks.clone(), test_sample_path, test_length))   # the model reuses its buffers
+        if sum(len(p[3]) for p in pending) >= lws_group:
+            flush()
     writer.close()          # every file is on disk (or its error raised) before the summary line
     ops.coop_check()
     loss_list = [float(x) for x in loss_list]

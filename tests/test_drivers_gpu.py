@@ -140,6 +140,33 @@ def test_infer_default_phase_is_lws_refined(experiment, monkeypatch):
     assert np.array_equal(wav, after[0][: T * 192].astype(np.int16))
 
 
+def test_infer_collects_batches_for_one_lws_launch(experiment, monkeypatch):
+    """infer() refines the phase of several small batches in ONE LWS launch (AVSI_LWS_GROUP utterances): the files are
+    the same, sample for sample, as with one launch per batch, and the per-batch lines are still printed in order."""
+    from avsi_amd import inference
+    from avsi_amd import lws as lws_mod
+    base, data, cfg = experiment
+    net = base / "logs" / "av_exp0" / "netmodel"
+    calls = []
+    orig = lws_mod.lws.refine_enhanced
+
+    def spy(self, enhanced, masks, num_samples=None):
+        calls.append(int(enhanced.shape[0]))
+        return orig(self, enhanced, masks, num_samples)
+    monkeypatch.setattr(lws_mod.lws, "refine_enhanced", spy)
+    outs = {}
+    for group in (1, 4, 128):
+        monkeypatch.setenv('AVSI_LWS_GROUP', str(group))
+        calls.clear()
+        audio_out = base / ("audio_group%d" % group)
+        inference.infer(str(net), os.path.join(data, "test-set"), str(audio_out), "g", norm=True, oracle_phase=False, batch_size=2)
+        assert calls == {1: [2, 2, 1], 4: [4, 1], 128: [5]}[group]
+        outs[group] = [wavfile.read(str(audio_out / ("clip_%03d" % i) / "enhanced" / "g.wav"))[1] for i in range(5)]
+    for group in (4, 128):
+        for a, b in zip(outs[1], outs[group]):
+            assert np.array_equal(a, b)
+
+
 @pytest.mark.parametrize("model_name,fmt", [("a-blstm-emb", "npz"), ("av-blstm-ssnn", "tf"), ("av-blstm-twosteps", "tf"),
                                             ("av-blstm-twosteps", "npz")])
 def test_variant_models_train_and_infer(experiment, tmp_path, model_name, fmt, capsys):
