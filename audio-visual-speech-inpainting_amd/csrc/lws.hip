@@ -264,8 +264,9 @@ __device__ __forceinline__ void row_store(float2* p, float2 v) {
 }
 
 // NW waves per workgroup = NW sweeps of the same U utterances in flight, as a pipeline: wave w runs sweeps w, w + NW,
-// ...; sweep s may work on row m once sweep s - 1 has finished rows m + 1 and m + 2 (the rows it reads ahead), which
-// is exactly the raster-order dependence -- the result is bit-identical to running the sweeps one after the other.
+// ...; sweep s may work on row m once the sweep before it (the nearest one that touches anything) has finished row
+// m + 1, the row it reads ahead -- exactly the raster-order dependence, so the result is bit-identical to running the
+// sweeps one after the other.  (Row m + 2 is fetched one frame early when it is already final, otherwise after the frame.)
 // Progress is a per-sweep row counter in LDS; rows travel through global memory (they stay in L2).  At small batches
 // the sweeps of ONE utterance thus run on up to 16 waves instead of one (0.84 s -> ~60 ms per utterance); large
 // batches use NW = 1 with several utterances per wave.
