@@ -209,7 +209,7 @@ def test_feed_reuses_model_and_variables(mods):
                                            # column-split kernel (avsi_blstm_rec_fwd_cs_f32): 16 / 32 utterances per group
                                            (32, -32, False), (64, -16, True), (512, -16, False), (1024, -32, True),
                                            (1088, -32, False), (544, -16, True)])                 # these two: two launches
-def test_cooperative_small_batch_kernel_matches_batch_stationary(Bp, split, save):
+def test_cooperative_small_batch_kernel_matches_batch_stationary(Bp, split, save, monkeypatch):
     """avsi_blstm_rec_fwd_coop_f32 (weights resident in registers, h exchanged through hout with a
     per-step counter) against avsi_blstm_rec_fwd_f32 on the same operands: same maths, different
     summation order of the 256-long reduction."""
@@ -231,6 +231,8 @@ def test_cooperative_small_batch_kernel_matches_batch_stationary(Bp, split, save
     np.testing.assert_allclose(outs[1][0].cpu().numpy(), outs[0][0].cpu().numpy(), rtol=0, atol=2e-5)
     if save:
         np.testing.assert_allclose(outs[1][1].cpu().numpy(), outs[0][1].cpu().numpy(), rtol=0, atol=5e-5)
+    for name in ('AVSI_REC_CS', 'AVSI_COOP_CUS', 'AVSI_REC_COOP'):      # the default policy, whatever the caller's switches
+        monkeypatch.delenv(name, raising=False)
     assert ops.coop_split(32) == 32 and ops.coop_split(32, backward=True) == 32 and ops.coop_split(256) == 16
     assert ops.coop_split(256, backward=True) == 16 and ops.coop_split(512, backward=True) == 8
     assert ops.coop_split(512) == -16 and ops.coop_split(1024) == -32 and ops.coop_split(2048) == -32 and ops.coop_split(4096) == 0
