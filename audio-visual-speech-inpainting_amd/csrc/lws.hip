@@ -388,7 +388,14 @@ __global__ __launch_bounds__(64 * NW) void lws_sweeps_kernel(float2* __restrict_
         }
     };
 
-    for (int sw = stage; sw < sched.n; sw += stages) {
+    // The sweeps that touch anything ("active": some utterance of the group has a magnitude above the threshold) are
+    // dealt to the stages in turn -- the a-th active sweep runs on stage a % stages -- and each follows the active sweep
+    // before it.  An idle sweep leaves the rows as they were: it needs no stage (dealing by sweep NUMBER gave the stages
+    // of the 7 idle sweeps of the 'speech' schedule one sweep less and the others 7 instead of 6 at 16 stages), and
+    // waiting for it would only serialise the pipeline (it could report a row finished no earlier than its own
+    // predecessor's LAST row).  Every stage of the group sees the same thresholds and statistics, hence the same deal.
+    int rank_a = -1, last_active = -1;
+    for (int sw = 0; sw < sched.n; ++sw) {
         float thr[U];
         bool any_u = false;
 #pragma unroll
@@ -396,19 +403,11 @@ __global__ __launch_bounds__(64 * NW) void lws_sweeps_kernel(float2* __restrict_
             thr[u] = sched.rel[sw] * mean_u[u];
             any_u |= (u < nu) && (max_u[u] > thr[u]);
         }
-        if (!any_u) continue;       // wave-uniform: this sweep touches nothing, and nobody waits for it (see `pred`)
-        // The sweep this one follows: the nearest earlier sweep that touches anything (a sweep whose threshold is above
-        // every magnitude leaves the rows as they were, so waiting for IT would only serialise the pipeline -- it could
-        // report a row finished no earlier than its own predecessor's LAST row).  Every stage of the utterance group sees
-        // the same thresholds and statistics, hence the same answer.
-        int pred = sw - 1;
-        for (; pred >= 0; --pred) {
-            bool on = false;
-#pragma unroll
-            for (int u = 0; u < U; ++u) on |= (u < nu) && (max_u[u] > sched.rel[pred] * mean_u[u]);
-            if (on) break;
-        }
-        const bool pred_remote = pred >= 0 && G > 1 && (pred % stages) / NW != wg;     // its stage sits in another workgroup
+        if (!any_u) continue;       // wave-uniform
+        const int pred = last_active;
+        last_active = sw, ++rank_a;
+        if (rank_a % stages != stage) continue;
+        const bool pred_remote = pred >= 0 && G > 1 && ((rank_a - 1) % stages) / NW != wg;     // its stage sits in another workgroup
         const bool past_only = sched.past_only[sw] != 0;
 
         // ring: slot (m + 3) % 3 holds row m
