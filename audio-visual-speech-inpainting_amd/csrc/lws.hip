@@ -252,15 +252,14 @@ __device__ __forceinline__ void wave_sync() {
 // rows are handed from one wave (sweep s - 1) to the next (sweep s) through global memory: device-scope accesses,
 // i.e. never served from / parked in this CU's L1
 __device__ __forceinline__ float2 row_load(const float2* p) {
-    const unsigned* q = reinterpret_cast<const unsigned*>(p);
-    const unsigned a = __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const unsigned b = __hip_atomic_load(q + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    return make_float2(__builtin_bit_cast(float, a), __builtin_bit_cast(float, b));
+    const unsigned long long v = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(p), __ATOMIC_RELAXED,
+                                                   __HIP_MEMORY_SCOPE_AGENT);      // one 8-byte access: a wave covers whole lines
+    return make_float2(__builtin_bit_cast(float, (unsigned)v), __builtin_bit_cast(float, (unsigned)(v >> 32)));
 }
 __device__ __forceinline__ void row_store(float2* p, float2 v) {
-    unsigned* q = reinterpret_cast<unsigned*>(p);
-    __hip_atomic_store(q, __builtin_bit_cast(unsigned, v.x), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __hip_atomic_store(q + 1, __builtin_bit_cast(unsigned, v.y), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned long long w = (unsigned long long)__builtin_bit_cast(unsigned, v.x) |
+                                 ((unsigned long long)__builtin_bit_cast(unsigned, v.y) << 32);
+    __hip_atomic_store(reinterpret_cast<unsigned long long*>(p), w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // NW waves per workgroup = NW sweeps of the same U utterances in flight, as a pipeline: wave w runs sweeps w, w + NW,
