@@ -33,6 +33,9 @@ def packed_gate_col(direction, gate, unit):
     return direction * GP + (unit // 32) * 128 + gate * 32 + unit % 32
 
 
+_INDEX_CACHE = {}      # constructor arguments -> (pack_index, grad_index); shared between layouts, never written
+
+
 class ParamLayout:
     """``side = (layer, dim)`` declares a per-utterance side input (a speaker embedding) that the
     reference concatenates, tiled over time, to the input of BLSTM layer ``layer``
@@ -141,7 +144,11 @@ class ParamLayout:
                 alloc(name, shape)
         self.packed_size = poff
 
-        self.pack_index = self._build_pack_index()     # packed pos -> ref pos (ref_size = zero slot)
+        # the two index maps depend on the constructor arguments alone and cost ~0.1 s of numpy to build: every model
+        # of the same shape in a process (bench entries, the inference model next to the training one) shares them
+        key = (self.input_dim, net_dim, F, self.side, mlp, mlp_in_pitch, self.asr)
+        cached = _INDEX_CACHE.get(key)
+        self.pack_index = cached[0] if cached else self._build_pack_index()     # packed pos -> ref pos (ref_size = zero slot)
 
         # ---- gradient layout produced by the backward kernels (GEMM outputs, natural k-major form)
         self.gpacked = {}
@@ -162,7 +169,9 @@ class ParamLayout:
         for name, shape in self._mlp_shapes:
             galloc('d' + name, shape)
         self.gpacked_size = goff
-        self.grad_index = self._build_grad_index()     # ref pos -> gpacked pos
+        self.grad_index = cached[1] if cached else self._build_grad_index()     # ref pos -> gpacked pos
+        if not cached:
+            _INDEX_CACHE[key] = (self.pack_index, self.grad_index)
 
     def signature(self):
         """Shape signature stored in checkpoints."""
