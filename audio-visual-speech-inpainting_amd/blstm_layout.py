@@ -203,6 +203,25 @@ class ParamLayout:
         H, F, Z = self.H, self.F, self.ref_size
         idx = np.full(self.packed_size, Z, dtype=np.int64)
         u = np.arange(H)
+        # the two fragment orders of the recurrent kernel do not depend on layer, direction or gate: positions and
+        # (k, unit) of the cells that hold a weight, once
+        #   forward  [d][w][q][g][lane][s]:  Wh[k = 8q + 4(lane >> 5) + s][unit = 32w + (lane & 31)] of gate g
+        w_, q_, lane_, s_ = np.meshgrid(np.arange(8), np.arange(32), np.arange(64), np.arange(4), indexing='ij')
+        kk, uu = 8 * q_ + 4 * (lane_ >> 5) + s_, 32 * w_ + (lane_ & 31)
+        ok = (kk < H) & (uu < H)
+        f_pos, f_k, f_u = (((w_ * 32 + q_) * 4) * 256 + lane_ * 4 + s_)[ok], kk[ok], uu[ok]
+        #   transposed product [d][w][q 128][lane][s]:  Wh[unit' = 32w + (lane & 31)][packed col = 8q + 4(lane >> 5) + s]
+        w_, q_, lane_, s_ = np.meshgrid(np.arange(8), np.arange(128), np.arange(64), np.arange(4), indexing='ij')
+        col = 8 * q_ + 4 * (lane_ >> 5) + s_              # packed col inside this direction
+        up = 32 * w_ + (lane_ & 31)                       # unit' (row of Wh)
+        cg = (col % 128) // 32                            # gate of that column
+        cu = (col // 128) * 32 + col % 32                 # hidden unit of that column
+        okb = (up < H) & (cu < H)
+        posb = ((w_ * 128 + q_) * 64 + lane_) * 4 + s_
+        t_pos, t_up, t_cu = [], [], []
+        for g in range(4):
+            sel = okb & (cg == g)
+            t_pos.append(posb[sel]), t_up.append(up[sel]), t_cu.append(cu[sel])
         for li in range(self.num_layers):
             E = self.side_dim(li)
             D = self.in_dims[li] + E                                    # first recurrent row of the TF kernel
@@ -226,25 +245,10 @@ class ParamLayout:
                         idx[we_off + er[:, None] * (2 * GP) + cols[None, :]] = (
                             k_off + (self.in_dims[li] + er)[:, None] * (4 * H) + (g * H + u)[None, :])
                     # recurrent kernel in fragment order [d][w][q][g][lane][s]
-                    w_, q_, lane_, s_ = np.meshgrid(np.arange(8), np.arange(32), np.arange(64), np.arange(4),
-                                                    indexing='ij')
-                    kk = 8 * q_ + 4 * (lane_ >> 5) + s_
-                    uu = 32 * w_ + (lane_ & 31)
-                    ok = (kk < H) & (uu < H)
-                    pos = wh_off + ((((d * 8 + w_) * 32 + q_) * 4 + g) * 64 + lane_) * 4 + s_
-                    idx[pos[ok]] = k_off + (D + kk[ok]) * (4 * H) + g * H + uu[ok]
-                    # transposed-product fragment order [d][w][q 128][lane][s]:
-                    #   Wh[unit' = 32w + (lane & 31)][packed col = 8q + 4(lane >> 5) + s]
+                    idx[wh_off + d * (8 * 32 * 4 * 256) + g * 256 + f_pos] = k_off + (D + f_k) * (4 * H) + g * H + f_u
+                    # transposed-product fragment order [d][w][q 128][lane][s]
                     whb_off, _ = self.packed['whb%d' % li]
-                    w_, q_, lane_, s_ = np.meshgrid(np.arange(8), np.arange(128), np.arange(64), np.arange(4),
-                                                    indexing='ij')
-                    col = 8 * q_ + 4 * (lane_ >> 5) + s_              # packed col inside this direction
-                    up = 32 * w_ + (lane_ & 31)                       # unit' (row of Wh)
-                    cg = (col % 128) // 32                            # gate of that column
-                    cu = (col // 128) * 32 + col % 32                 # hidden unit of that column
-                    ok = (cg == g) & (up < H) & (cu < H)
-                    pos = whb_off + (((d * 8 + w_) * 128 + q_) * 64 + lane_) * 4 + s_
-                    idx[pos[ok]] = k_off + (D + up[ok]) * (4 * H) + g * H + cu[ok]
+                    idx[whb_off + d * (8 * 128 * 256) + t_pos[g]] = k_off + (D + t_up[g]) * (4 * H) + g * H + t_cu[g]
         pw_off, _ = self.packed['pw']
         pb_off, _ = self.packed['pb']
         rmap = np.full(2 * HP, -1, dtype=np.int64)
