@@ -14,7 +14,8 @@ For N > 1 launch with torch.distributed.run (one rank per GPU); utterances are s
 ranks with no data-path collective (weak scaling: per-GPU batch fixed).  Rank 0 prints ONE JSON
 line.  Its `also` block reports the sizes the reference and BASELINE.json name (inference at 100 and
 32 utterances, AV training at 32 utterances per GPU -- with the gradient all-reduce when N > 1) and two
-mid sizes (inference at 128 and 1024 utterances), each
+mid sizes (inference at 128 and 1024 utterances), plus the LWS phase reconstruction of 32 enhanced utterances (the step
+after the path in the reference's default `infer`), each
 with its own ms_per_step, measured after the headline.  `roofline` is measured live with HIP events on the launch stream around the dominant
 kernel; `cpu_baseline` times the CPU oracle (a numpy port of the reference graph) on a bounded
 sample of the same workload on this node's host cores.
@@ -315,6 +316,24 @@ def named_workloads(torch, models, ops, model, cfg, mean, std, device, rank, wor
         return loss
     ms = time_steps(torch, tstep, 30, 5)
     ops.coop_check(device)
+    del mt
+    # the step after the path in the reference's default `infer` (inference.py:141-154): LWS phase reconstruction of the
+    # enhanced batch (STFT, 102 sweeps, stitching, inverse STFT) at the reference's inference batch of 32
+    from avsi_amd import lws as lws_mod
+    lb = 32
+    gl = torch.Generator(device=device)
+    gl.manual_seed(77 + rank)
+    tt = torch.arange(N_SAMPLES, device=device)[None, :].float()
+    f0 = 150 + 100 * torch.rand(lb, 1, generator=gl, device=device)
+    lwav = sum(2000 / h * torch.sin(2 * np.pi * h * f0 * tt / 16000) for h in range(1, 9))
+    lwav = lwav * (0.6 + 0.4 * torch.sin(2 * np.pi * 4 * tt / 16000)) + 100 * torch.randn(lb, N_SAMPLES, generator=gl, device=device)
+    lmask = torch.ones(lb, T_FRAMES, 257, device=device)
+    lmask[:, 100:133] = 0
+    proc = lws_mod.lws(384, 192, fftsize=512, mode='speech')
+    lms = time_steps(torch, lambda: proc.refine_enhanced(lwav, lmask, num_samples=N_SAMPLES), 5, 2)
+    out["lws_b32"] = {"workload": "LWS phase reconstruction of 32 enhanced utterances (inference.py:141-154; harmonic "
+                                  "test signal + noise, 33 gap frames)", "per_gpu_batch": lb, "ms_per_step": lms,
+                      "value": lb * world / lms * 1e3, "unit": "utterances/s"}
     out["train_b32"] = {"workload": "configs[2]/[3] AV training step (forward + BPTT + %sTF-Adam), 32 utterances per GPU"
                                     % ("RCCL gradient all-reduce + " if world > 1 else ""),
                         "per_gpu_batch": b, "global_batch": b * world, "ms_per_step": ms,
@@ -334,7 +353,7 @@ def main():
     ap.add_argument("--precision", choices=["f32", "bf16x3"], default="f32",
                     help="EXPLORATORY, inference only: bf16x3 = layer input projections with split-bf16 operands (hi.hi + hi.lo "
                          "+ lo.hi on the bf16 matrix cores, fp32 accumulation); never the default, never the headline")
-    ap.add_argument("--no-also", action="store_true", help="skip the named-workload entries (`also` block: inference at 100, 32, 128 and 1024 utterances, training at 32)")
+    ap.add_argument("--no-also", action="store_true", help="skip the named-workload entries (`also` block: inference at 100, 32, 128 and 1024 utterances, training and LWS phase reconstruction at 32)")
     ap.add_argument("--also-timeout", type=int, default=240)
     ap.add_argument("--mode", choices=["infer", "train", "unet"], default="infer",
                     help="infer = headline workload (configs[1]); train = configs[2]: AV model, fwd + BPTT + Adam; "

@@ -38,7 +38,8 @@ def test_default_mode_line():
     # the sizes the reference and BASELINE.json name, each with its own ms_per_step
     also = d["also"]
     assert "error" not in also, also
-    for k, b in (("infer_b100", 100), ("infer_b32", 32), ("infer_b128", 128), ("infer_b1024", 1024), ("train_b32", 32)):
+    for k, b in (("infer_b100", 100), ("infer_b32", 32), ("infer_b128", 128), ("infer_b1024", 1024), ("train_b32", 32),
+                 ("lws_b32", 32)):
         assert also[k]["per_gpu_batch"] == b and also[k]["ms_per_step"] > 0
         assert abs(also[k]["value"] - b / also[k]["ms_per_step"] * 1e3) < 1e-6 * also[k]["value"]
     assert abs(d["value"] - 256 * 2 / (d["ms_per_step"] * 2e-3)) < 1e-6 * d["value"]
