@@ -18,6 +18,14 @@ for w in $what; do
         train_b32) flags="--mode train --batch 32 --steps 20 --warmup 3 --no-cpu-baseline --no-also" ;;
         b1024) flags="--batch 1024 --steps 10 --warmup 3 --no-cpu-baseline --no-also" ;;
         unet_b512) flags="--mode unet --batch 512 --steps 5 --warmup 2 --no-cpu-baseline --no-also" ;;
+        lws_b*)      # LWS phase reconstruction alone (tools/lws_time.py <utterances>): kernel statistics + the tool's line
+            n=${w#lws_b}
+            rm -rf /tmp/prof_$w
+            rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$w -- python3 $R/tools/lws_time.py $n > /tmp/prof_$w.txt 2> /tmp/prof_$w.err
+            cp $(ls /tmp/prof_$w/*/*kernel_stats.csv | head -1) $out/${tag}_${w}_kernel_stats.csv
+            grep "B=" /tmp/prof_$w.txt > $out/${tag}_${w}_under_rocprof.txt
+            echo "$w: $(cat $out/${tag}_${w}_under_rocprof.txt)"
+            continue ;;
         *) echo "unknown $w"; exit 1 ;;
     esac
     rm -rf /tmp/prof_$w
