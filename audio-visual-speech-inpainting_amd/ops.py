@@ -187,6 +187,9 @@ def occupy_cus(num_cus, release, max_ms=5000):
                "avsi_diag_occupy_cus")
 
 
+CS_MAX_BATCH = int(os.environ.get('AVSI_REC_CS_MAX', '3584'))     # largest batch of the column-split forward kernel
+
+
 def coop_split(Bp, backward=False):
     """Which small-batch recurrent kernel runs a layer: > 0 = workgroups per (32-utterance tile, direction) of the
     reduction-split cooperative kernels, < 0 = the column-split kernel with that many utterances per group of 8
@@ -205,7 +208,10 @@ def coop_split(Bp, backward=False):
     elif Bp <= 256:
         split = 16
     elif os.environ.get('AVSI_REC_CS', '1') != '0':
-        split = -16 if Bp <= 512 else (-32 if Bp <= 2048 else 0)  # 1024 < Bp <= 2048: two resident-sized launches
+        # 1024 < Bp: resident-sized launches one after the other.  Up to 3584 utterances that still beats the
+        # batch-stationary 32-row kernel, whose Bp / 16 workgroups take one full round of the chip whether 132 or 256 of
+        # them exist (whole inference step, ms: 2112: 55.7 -> 41.9, 2560: 60.2 -> 50.6, 3072: 65.3 -> 60.5; 3584: a tie)
+        split = -16 if Bp <= 512 else (-32 if Bp <= CS_MAX_BATCH else 0)
     else:
         split = 8 if Bp <= 512 else (4 if Bp <= 2048 else 0)
     # coop_cu_budget(): CUs one cooperative launch may occupy (default: the chip; see set_coop_cu_budget).  A

@@ -208,7 +208,8 @@ def test_feed_reuses_model_and_variables(mods):
                                            (64, 32, True), (160, 32, False),                      # workgroup (288, 160: two launches)
                                            # column-split kernel (avsi_blstm_rec_fwd_cs_f32): 16 / 32 utterances per group
                                            (32, -32, False), (64, -16, True), (512, -16, False), (1024, -32, True),
-                                           (1088, -32, False), (544, -16, True)])                 # these two: two launches
+                                           (1088, -32, False), (544, -16, True),                  # these two: two launches
+                                           (3104, -32, False)])                                    # four (the policy's range ends at 3584)
 def test_cooperative_small_batch_kernel_matches_batch_stationary(Bp, split, save, monkeypatch):
     """avsi_blstm_rec_fwd_coop_f32 (weights resident in registers, h exchanged through hout with a
     per-step counter) against avsi_blstm_rec_fwd_f32 on the same operands: same maths, different
@@ -236,6 +237,33 @@ def test_cooperative_small_batch_kernel_matches_batch_stationary(Bp, split, save
     assert ops.coop_split(32) == 32 and ops.coop_split(32, backward=True) == 32 and ops.coop_split(256) == 16
     assert ops.coop_split(256, backward=True) == 16 and ops.coop_split(512, backward=True) == 8
     assert ops.coop_split(512) == -16 and ops.coop_split(1024) == -32 and ops.coop_split(2048) == -32 and ops.coop_split(4096) == 0
+
+
+def test_batch_stationary_kernel_choice_above_4096():
+    """avsi_blstm_rec_fwd_f32 with rows_per_wg = 0: beyond 4096 utterances (where 32-row workgroups would need a second
+    round of the chip) the 64-row ping-pong kernel runs -- same result as forcing either form; at 4096 the 32-row one."""
+    import torch
+    import avsi_amd  # noqa: F401
+    from avsi_amd import ops
+    T, Bp = 5, 4160
+    g = torch.Generator(device='cuda')
+    g.manual_seed(11)
+    xproj = torch.randn(T, Bp, 2048, generator=g, device='cuda')
+    whp = torch.randn(2 * 262144, generator=g, device='cuda') * 0.05
+    outs = {}
+    for rows in (0, 32, 64):
+        hout = torch.full((T, Bp, 512), 7.0, device='cuda')
+        ops.blstm_rec_fwd(xproj, whp, hout, None, rows_per_wg=rows, split=0)
+        outs[rows] = hout
+    assert torch.equal(outs[0], outs[64])                    # the automatic choice IS the 64-row kernel here
+    np.testing.assert_allclose(outs[0].cpu().numpy(), outs[32].cpu().numpy(), rtol=0, atol=2e-5)
+    Bp = 4096
+    xproj = xproj[:, :Bp].contiguous()
+    for rows in (0, 32):
+        hout = torch.full((T, Bp, 512), 7.0, device='cuda')
+        ops.blstm_rec_fwd(xproj, whp, hout, None, rows_per_wg=rows, split=0)
+        outs[rows] = hout
+    assert torch.equal(outs[0], outs[32])
 
 
 @pytest.mark.parametrize("Bp,split", [(32, 8), (256, 8), (1024, 4), (64, 4), (1088, 4), (32, 16), (256, 16), (288, 16), (32, 32), (128, 32), (160, 32)])

@@ -7,9 +7,11 @@ def test_cooperative_split_policy(monkeypatch):
     monkeypatch.delenv('AVSI_COOP_CUS', raising=False)
     monkeypatch.delenv('AVSI_REC_COOP', raising=False)
     monkeypatch.delenv('AVSI_REC_CS', raising=False)
-    fwd = {b: ops.coop_split(b) for b in (32, 64, 96, 128, 160, 256, 288, 512, 544, 2048, 2080)}
+    fwd = {b: ops.coop_split(b) for b in (32, 64, 96, 128, 160, 256, 288, 512, 544, 2048, 2080, 3584, 3616)}
     # < 0: the column-split kernel, that many utterances per group of 8 workgroups, two workgroups to a CU
-    assert fwd == {32: 32, 64: 32, 96: 32, 128: 32, 160: 16, 256: 16, 288: -16, 512: -16, 544: -32, 2048: -32, 2080: 0}
+    # ... up to 3584 utterances, in resident-sized launches: beyond, the batch-stationary kernels fill the chip
+    assert fwd == {32: 32, 64: 32, 96: 32, 128: 32, 160: 16, 256: 16, 288: -16, 512: -16, 544: -32, 2048: -32, 2080: -32,
+                   3584: -32, 3616: 0}
     bwd = {b: ops.coop_split(b, backward=True) for b in (32, 128, 160, 512, 544, 2048, 4096)}
     assert bwd == {32: 32, 128: 32, 160: 16, 512: 8, 544: 4, 2048: 4, 4096: 0}
     # every single-launch choice fits the chip: members = 2 directions x tiles x split <= 256 CUs
