@@ -202,6 +202,8 @@ def coop_split(Bp, backward=False):
     if backward:
         # BPTT: 16 unit slices x 2 halves of 16 utterances up to four tiles (0.97 ms per layer at Bp = 32
         # against 1.66 at 8), 16 unit slices up to eight (256: 1.61 against 1.80 at 8), then the 8- and 4-way kernels
+        # (beyond 2048 the 4-way kernel's launches of 1024 utterances, ~6.5 ms each per layer, add up to what the
+        # batch-stationary BPTT kernel takes for any batch up to 8192: 3072 utterances 179.6 against 178.5 ms per step)
         split = 32 if Bp <= 128 else (16 if Bp <= 256 else (8 if Bp <= 512 else (4 if Bp <= 2048 else 0)))
     elif Bp <= 128:
         split = 32
@@ -213,7 +215,7 @@ def coop_split(Bp, backward=False):
         # them exist (whole inference step, ms: 2112: 55.7 -> 41.9, 2560: 60.2 -> 50.6, 3072: 65.3 -> 60.5; 3584: a tie)
         split = -16 if Bp <= 512 else (-32 if Bp <= CS_MAX_BATCH else 0)
     else:
-        split = 8 if Bp <= 512 else (4 if Bp <= 2048 else 0)
+        split = 8 if Bp <= 512 else (4 if Bp <= CS_MAX_BATCH else 0)
     # coop_cu_budget(): CUs one cooperative launch may occupy (default: the chip; see set_coop_cu_budget).  A
     # batch that fits the budget in one launch at a coarser split takes that; beyond it the C side cuts the batch
     # into resident-sized launches.  The bounded spin catches an over-subscription anyway.

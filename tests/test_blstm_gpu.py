@@ -266,7 +266,7 @@ def test_batch_stationary_kernel_choice_above_4096():
     assert torch.equal(outs[0], outs[32])
 
 
-@pytest.mark.parametrize("Bp,split", [(32, 8), (256, 8), (1024, 4), (64, 4), (1088, 4), (32, 16), (256, 16), (288, 16), (32, 32), (128, 32), (160, 32)])
+@pytest.mark.parametrize("Bp,split", [(32, 8), (256, 8), (1024, 4), (64, 4), (1088, 4), (3104, 4), (32, 16), (256, 16), (288, 16), (32, 32), (128, 32), (160, 32)])
 def test_cooperative_bptt_matches_batch_stationary(Bp, split):
     import torch
     import avsi_amd  # noqa: F401

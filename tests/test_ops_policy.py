@@ -12,15 +12,15 @@ def test_cooperative_split_policy(monkeypatch):
     # ... up to 3584 utterances, in resident-sized launches: beyond, the batch-stationary kernels fill the chip
     assert fwd == {32: 32, 64: 32, 96: 32, 128: 32, 160: 16, 256: 16, 288: -16, 512: -16, 544: -32, 2048: -32, 2080: -32,
                    3584: -32, 3616: 0}
-    bwd = {b: ops.coop_split(b, backward=True) for b in (32, 128, 160, 512, 544, 2048, 4096)}
-    assert bwd == {32: 32, 128: 32, 160: 16, 512: 8, 544: 4, 2048: 4, 4096: 0}
+    bwd = {b: ops.coop_split(b, backward=True) for b in (32, 128, 160, 512, 544, 2048, 2080, 4096)}
+    assert bwd == {32: 32, 128: 32, 160: 16, 512: 8, 544: 4, 2048: 4, 2080: 0, 4096: 0}
     # every single-launch choice fits the chip: members = 2 directions x tiles x split <= 256 CUs
     for b in range(32, 513, 32):
         for back in (False, True):
             sp = ops.coop_split(b, back)
             assert (2 * (b // 32) * sp <= 256) if sp > 0 else (2 * (b // -sp) * 8 <= 512), (b, back)
     monkeypatch.setenv('AVSI_REC_CS', '0')
-    assert ops.coop_split(512) == 8 and ops.coop_split(1024) == 4
+    assert ops.coop_split(512) == 8 and ops.coop_split(1024) == 4 and ops.coop_split(3584) == 4
     monkeypatch.delenv('AVSI_REC_CS')
     # a process that shares the chip between 8 streams gives each launch 32 CUs
     monkeypatch.setenv('AVSI_COOP_CUS', '32')
