@@ -273,7 +273,9 @@ class StackedBLSTMModel(object):
     def _dims(self):
         B = int(self.target_sources.shape[0]) if self.target_sources is not None else int(self.video_features.shape[0])
         T = int(self.sequence_lengths.max())
-        return B, T, round_up(B, 32)
+        # whole 32-row MFMA tiles; beyond 4096 utterances whole 64-row ones, so that the 64-row recurrent kernel is
+        # taken (an odd number of 32-row tiles there would send the layer through two rounds of the 32-row kernel)
+        return B, T, round_up(B, 64 if B > 4096 else 32)
 
     # ---------------------------------------------------------------- front end (models.py:30-45)
     def _frontend(self):
