@@ -9,7 +9,7 @@ from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int32, c_int6
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libavsi_hip.so")
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 AVSI_OK = 0
 AVSI_ERR_INVALID_ARG, AVSI_ERR_UNSUPPORTED, AVSI_ERR_LAUNCH, AVSI_ERR_WORKSPACE = -1, -2, -3, -4
@@ -121,12 +121,16 @@ PROTOTYPES = {
     "avsi_blstm_rec_bwd_coop_exchange_bytes": (c_size_t, [c_int, c_int]),
     "avsi_blstm_rec_fwd_coop_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p,
                                             c_size_t, c_void_p]),
+    "avsi_blstm_rec_fwd_coop_rows_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int,
+                                                 c_void_p, c_size_t, c_void_p]),
     "avsi_blstm_rec_bwd_coop_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p,
                                             c_size_t, c_void_p]),
     "avsi_blstm_rec_fwd_cs_workspace_bytes": (c_size_t, [c_int]),
     "avsi_blstm_rec_fwd_cs_groups_per_launch": (c_int, [c_int, c_int, c_int]),
     "avsi_blstm_rec_fwd_cs_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p,
                                           c_size_t, c_void_p]),
+    "avsi_blstm_rec_fwd_cs_rows_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int,
+                                               c_void_p, c_size_t, c_void_p]),
     "avsi_diag_cs_stamps": (c_int, [c_void_p]),
     "avsi_stream_delay_us": (c_int, [c_int, c_void_p]),
     "avsi_diag_occupy_cus": (c_int, [c_int, c_void_p, c_int, c_void_p]),

@@ -50,6 +50,7 @@ struct CoopArgs {
     int T, Bp, ngroups;
     int tile0;         // first 32-utterance tile of this launch (large batches run in resident-sized chunks)
     float* xch;        // fine kernels: h in exchange layout [T][group][member][32 utterances][units of the member], or null
+    int xtile0, xtiles;   // ... of the tiles [xtile0, xtile0 + xtiles) of the CALL (a row-range call covers part of the batch)
 };
 
 __device__ __forceinline__ float sigmoidf_fast(float x) { return __builtin_amdgcn_rcpf(1.f + __expf(-x)); }
@@ -315,8 +316,8 @@ __global__ __launch_bounds__(512, 2) void blstm_rec_fwd_coop_fine_kernel(const C
 
     unsigned* ctr = a.sync + CTR_STRIDE * (1 + 2 * a.tile0 + group);
     // exchange layout: [step][global group][256 units as S member blocks][32 rows][UW]
-    const size_t xgroups = (size_t)2 * (Bp / 32);
-    float* xbase = XCH ? a.xch + (size_t)(2 * a.tile0 + group) * (32 * HP) : nullptr;
+    const size_t xgroups = (size_t)2 * a.xtiles;
+    float* xbase = XCH ? a.xch + (size_t)(2 * (a.tile0 - a.xtile0) + group) * (32 * HP) : nullptr;
     __syncthreads();
 
     for (int step = 0; step < T; ++step) {
@@ -497,10 +498,12 @@ static int coop_tiles_per_launch(int split, int max_cus) {
     return groups / 2;
 }
 
-extern "C" int avsi_blstm_rec_fwd_coop_f32(const float* xproj, const float* whp, float* hout, float* reserve, int T, int Bp,
-                                           int split, int max_cus, void* workspace, size_t workspace_bytes, void* stream) {
+extern "C" int avsi_blstm_rec_fwd_coop_rows_f32(const float* xproj, const float* whp, float* hout, float* reserve, int T, int Bp,
+                                                int split, int first_row, int rows, int max_cus, void* workspace,
+                                                size_t workspace_bytes, void* stream) {
     if (!xproj || !whp || !hout || T <= 0 || Bp <= 0 || (Bp & 31)) return AVSI_ERR_INVALID_ARG;
     if (split != 4 && split != 8 && split != 16 && split != 32) return AVSI_ERR_INVALID_ARG;
+    if (first_row < 0 || rows <= 0 || (first_row & 31) || (rows & 31) || first_row + rows > Bp) return AVSI_ERR_INVALID_ARG;
     if (!workspace || workspace_bytes < avsi_blstm_rec_fwd_coop_workspace_bytes(Bp)) return AVSI_ERR_WORKSPACE;
     if (coop_tiles_per_launch(split, max_cus) < 1) return AVSI_ERR_UNSUPPORTED;   // 2 * split workgroups do not fit max_cus
     const hipStream_t st = (hipStream_t)stream;
@@ -509,15 +512,15 @@ extern "C" int avsi_blstm_rec_fwd_coop_f32(const float* xproj, const float* whp,
     // (reset_counter_when_done) and never touches the sticky status word
     // every member of a group must be resident while its peers wait for it: batches beyond one chip-full of
     // groups run as consecutive launches over tile ranges
-    const int tiles = Bp / 32, per = coop_tiles_per_launch(split, max_cus);
+    const int tbeg = first_row / 32, tiles = tbeg + rows / 32, per = coop_tiles_per_launch(split, max_cus);
     // a workspace that also holds avsi_blstm_rec_fwd_coop_exchange_bytes(T, Bp) at AVSI_COOP_EXCHANGE_OFFSET switches the fine
     // splits (16, 32) to the exchange layout (see blstm_rec_fwd_coop_fine_kernel)
     // (at a FIXED offset: the counters of a later, larger batch must not land on old exchange data)
-    float* xch = (split >= 16 && workspace_bytes >= AVSI_COOP_EXCHANGE_OFFSET + avsi_blstm_rec_fwd_coop_exchange_bytes(T, Bp))
+    float* xch = (split >= 16 && workspace_bytes >= AVSI_COOP_EXCHANGE_OFFSET + avsi_blstm_rec_fwd_coop_exchange_bytes(T, rows))
                      ? reinterpret_cast<float*>(static_cast<char*>(workspace) + AVSI_COOP_EXCHANGE_OFFSET) : nullptr;
-    for (int tile0 = 0; tile0 < tiles; tile0 += per) {
+    for (int tile0 = tbeg; tile0 < tiles; tile0 += per) {
         const int nt = tiles - tile0 < per ? tiles - tile0 : per;
-        CoopArgs a{xproj, whp, hout, reserve, (unsigned*)workspace, T, Bp, 2 * nt, tile0, xch};
+        CoopArgs a{xproj, whp, hout, reserve, (unsigned*)workspace, T, Bp, 2 * nt, tile0, xch, tbeg, rows / 32};
         int rc;
         if (split == 32)
             rc = reserve ? launch_coop_fine<1, true>(a, st) : launch_coop_fine<1, false>(a, st);
@@ -530,6 +533,12 @@ extern "C" int avsi_blstm_rec_fwd_coop_f32(const float* xproj, const float* whp,
         if (rc != AVSI_OK) return rc;
     }
     return AVSI_OK;
+}
+
+extern "C" int avsi_blstm_rec_fwd_coop_f32(const float* xproj, const float* whp, float* hout, float* reserve, int T, int Bp,
+                                           int split, int max_cus, void* workspace, size_t workspace_bytes, void* stream) {
+    return avsi_blstm_rec_fwd_coop_rows_f32(xproj, whp, hout, reserve, T, Bp, split, 0, Bp, max_cus, workspace, workspace_bytes,
+                                            stream);
 }
 
 // ==========================================================================================

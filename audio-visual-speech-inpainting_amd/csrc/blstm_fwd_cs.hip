@@ -265,15 +265,16 @@ int cs_blocks_per_cu() {
 }
 
 template <int RT, bool SAVE>
-int launch_cs(const float* xproj, const float* whp, float* hout, float* reserve, int T, int Bp, int max_cus, unsigned* sync,
-              hipStream_t st) {
+int launch_cs(const float* xproj, const float* whp, float* hout, float* reserve, int T, int Bp, int first_row, int rows,
+              int max_cus, unsigned* sync, hipStream_t st) {
     const int cus = (max_cus <= 0 || max_cus > AVSI_NUM_CU) ? AVSI_NUM_CU : max_cus;
     // whole groups, in multiples of the XCD count when there are that many (members sit 8 block ids apart)
     int per = cus * cs_blocks_per_cu<RT, SAVE>() / MEMBERS;
     if (per >= AVSI_NUM_XCD) per = per / AVSI_NUM_XCD * AVSI_NUM_XCD;
     if (per < 1) return AVSI_ERR_UNSUPPORTED;
-    const int groups = 2 * (Bp / (16 * RT));
-    for (int g0 = 0; g0 < groups; g0 += per) {
+    // groups 2 * tile + direction of the utterance tiles [first_row, first_row + rows) / (16 RT)
+    const int gbeg = 2 * (first_row / (16 * RT)), groups = gbeg + 2 * (rows / (16 * RT));
+    for (int g0 = gbeg; g0 < groups; g0 += per) {
         const int ng = groups - g0 < per ? groups - g0 : per;
         CsArgs a{xproj, whp, hout, reserve, sync, T, Bp, ng, g0, g_cs_stamps};
         const int blocks = (int)avsi_ceil_div(ng, AVSI_NUM_XCD) * AVSI_NUM_XCD * MEMBERS;
@@ -313,11 +314,13 @@ extern "C" size_t avsi_blstm_rec_fwd_cs_workspace_bytes(int Bp) {
     return (size_t)CTR_STRIDE * (1 + 2 * (Bp > 0 ? (Bp + 15) / 16 : 0)) * sizeof(unsigned);
 }
 
-extern "C" int avsi_blstm_rec_fwd_cs_f32(const float* xproj, const float* whp, float* hout, float* reserve, int T, int Bp,
-                                         int rows_per_group, int max_cus, void* workspace, size_t workspace_bytes,
-                                         void* stream) {
+extern "C" int avsi_blstm_rec_fwd_cs_rows_f32(const float* xproj, const float* whp, float* hout, float* reserve, int T, int Bp,
+                                              int rows_per_group, int first_row, int rows, int max_cus, void* workspace,
+                                              size_t workspace_bytes, void* stream) {
     if (!xproj || !whp || !hout || T <= 0 || Bp <= 0 || (Bp & 31)) return AVSI_ERR_INVALID_ARG;
     if (rows_per_group != 16 && rows_per_group != 32) return AVSI_ERR_INVALID_ARG;
+    if (first_row < 0 || rows <= 0 || first_row % rows_per_group || rows % rows_per_group || first_row + rows > Bp)
+        return AVSI_ERR_INVALID_ARG;
     if (!workspace || workspace_bytes < avsi_blstm_rec_fwd_cs_workspace_bytes(Bp)) return AVSI_ERR_WORKSPACE;
     const hipStream_t st = (hipStream_t)stream;
     avsi_clear_error();
@@ -325,8 +328,15 @@ extern "C" int avsi_blstm_rec_fwd_cs_f32(const float* xproj, const float* whp, f
     // touches the sticky status word
     unsigned* sync = (unsigned*)workspace;
     if (rows_per_group == 16)
-        return reserve ? launch_cs<1, true>(xproj, whp, hout, reserve, T, Bp, max_cus, sync, st)
-                       : launch_cs<1, false>(xproj, whp, hout, reserve, T, Bp, max_cus, sync, st);
-    return reserve ? launch_cs<2, true>(xproj, whp, hout, reserve, T, Bp, max_cus, sync, st)
-                   : launch_cs<2, false>(xproj, whp, hout, reserve, T, Bp, max_cus, sync, st);
+        return reserve ? launch_cs<1, true>(xproj, whp, hout, reserve, T, Bp, first_row, rows, max_cus, sync, st)
+                       : launch_cs<1, false>(xproj, whp, hout, reserve, T, Bp, first_row, rows, max_cus, sync, st);
+    return reserve ? launch_cs<2, true>(xproj, whp, hout, reserve, T, Bp, first_row, rows, max_cus, sync, st)
+                   : launch_cs<2, false>(xproj, whp, hout, reserve, T, Bp, first_row, rows, max_cus, sync, st);
+}
+
+extern "C" int avsi_blstm_rec_fwd_cs_f32(const float* xproj, const float* whp, float* hout, float* reserve, int T, int Bp,
+                                         int rows_per_group, int max_cus, void* workspace, size_t workspace_bytes,
+                                         void* stream) {
+    return avsi_blstm_rec_fwd_cs_rows_f32(xproj, whp, hout, reserve, T, Bp, rows_per_group, 0, Bp, max_cus, workspace,
+                                          workspace_bytes, stream);
 }

@@ -185,6 +185,12 @@ size_t avsi_blstm_rec_bwd_coop_exchange_bytes(int T, int Bp);
 int avsi_blstm_rec_fwd_coop_f32(const float* xproj, const float* whp, float* hout, float* reserve,
                                 int T, int Bp, int split, int max_cus, void* workspace, size_t workspace_bytes,
                                 void* stream);
+/* The same for the utterances [first_row, first_row + rows) of the batch only (both multiples of 32; the operands are
+ * still the whole [T, Bp, ...] arrays): lets a caller give the remainder of a batch to the kernel of ITS size instead of a
+ * second launch of the large one (cooperative launches are latency-bound: 250 steps whatever the number of groups). */
+int avsi_blstm_rec_fwd_coop_rows_f32(const float* xproj, const float* whp, float* hout, float* reserve,
+                                     int T, int Bp, int split, int first_row, int rows, int max_cus, void* workspace,
+                                     size_t workspace_bytes, void* stream);
 
 /* Small-batch form of avsi_blstm_rec_bwd_f32 (same operands and results), the gradient of the
  * cooperative forward above: same group / split / workspace / residency rules (split 32 here = 16 slices of
@@ -206,6 +212,11 @@ int avsi_blstm_rec_fwd_cs_groups_per_launch(int rows_per_group, int with_reserve
 int avsi_blstm_rec_fwd_cs_f32(const float* xproj, const float* whp, float* hout, float* reserve,
                               int T, int Bp, int rows_per_group, int max_cus, void* workspace,
                               size_t workspace_bytes, void* stream);
+/* The same for the utterances [first_row, first_row + rows) only (multiples of rows_per_group); see
+ * avsi_blstm_rec_fwd_coop_rows_f32. */
+int avsi_blstm_rec_fwd_cs_rows_f32(const float* xproj, const float* whp, float* hout, float* reserve,
+                                   int T, int Bp, int rows_per_group, int first_row, int rows, int max_cus,
+                                   void* workspace, size_t workspace_bytes, void* stream);
 
 /* Diagnostic: while `buffer` (device memory, 32 * 8 * 2 * 8 uint64) is set, avsi_blstm_rec_fwd_cs_f32 records the
  * 100 MHz wall clock at eight phases of steps 64 .. 71 for waves 0 and 1 of its first 32 workgroups; NULL ends it. */

@@ -239,6 +239,40 @@ def test_cooperative_small_batch_kernel_matches_batch_stationary(Bp, split, save
     assert ops.coop_split(512) == -16 and ops.coop_split(1024) == -32 and ops.coop_split(2048) == -32 and ops.coop_split(4096) == 0
 
 
+@pytest.mark.parametrize("Bp,save", [(544, False), (640, True), (768, False), (1088, True), (1536, False), (2112, False)])
+def test_forward_recurrence_in_pieces_matches_batch_stationary(Bp, save, monkeypatch):
+    """The automatic choice cuts these batches into a large part and a remainder on the kernel of its size
+    (ops.rec_fwd_parts, avsi_blstm_rec_fwd_{cs,coop}_rows_f32): same result as the batch-stationary kernel, every
+    utterance written exactly once, counters and status word left at zero."""
+    import torch
+    import avsi_amd  # noqa: F401
+    from avsi_amd import ops
+    for name in ('AVSI_REC_CS', 'AVSI_COOP_CUS', 'AVSI_REC_COOP', 'AVSI_COOP_SPLIT_FWD'):
+        monkeypatch.delenv(name, raising=False)
+    assert len(ops.rec_fwd_parts(Bp)) > 1
+    T = 19
+    g = torch.Generator(device='cuda')
+    g.manual_seed(Bp)
+    xproj = torch.randn(T, Bp, 2048, generator=g, device='cuda')
+    whp = torch.randn(2 * 262144, generator=g, device='cuda') * 0.05
+    outs = []
+    for auto in (False, True):
+        hout = torch.full((T, Bp, 512), 7.0, device='cuda')
+        resv = torch.full((T, Bp, 2, 5, 256), 7.0, device='cuda') if save else None
+        if auto:
+            ops.blstm_rec_fwd(xproj, whp, hout, resv)
+        else:
+            ops.blstm_rec_fwd(xproj, whp, hout, resv, split=0)
+        outs.append((hout, resv))
+    ops.coop_check()
+    np.testing.assert_allclose(outs[1][0].cpu().numpy(), outs[0][0].cpu().numpy(), rtol=0, atol=2e-5)
+    if save:
+        np.testing.assert_allclose(outs[1][1].cpu().numpy(), outs[0][1].cpu().numpy(), rtol=0, atol=5e-5)
+    from avsi_amd import _lib
+    ws = ops._COOP_WS[(torch.cuda.current_device(), _lib.stream_ptr().value)]
+    assert int(ws[: 64 * (1 + 4 * Bp // 32)].abs().sum()) == 0           # status word and every counter back at zero
+
+
 def test_batch_stationary_kernel_choice_above_4096():
     """avsi_blstm_rec_fwd_f32 with rows_per_wg = 0: beyond 4096 utterances (where 32-row workgroups would need a second
     round of the chip) the 64-row ping-pong kernel runs -- same result as forcing either form; at 4096 the 32-row one."""

@@ -51,3 +51,32 @@ def test_cu_budget_leaves_room_for_concurrent_collectives(monkeypatch):
     assert ops.coop_cu_budget() == 256
     from avsi_amd import parallel
     assert parallel.collectives_share_the_gpu() is False
+
+
+def test_forward_recurrence_is_cut_into_pieces_of_their_own_size(monkeypatch):
+    """ops.rec_fwd_parts: whole multiples of 1024 utterances go to the column-split kernel by 32, the remainder to the
+    kernel of its size; every piece starts and ends on its kernel's tile, the pieces tile the batch without overlap."""
+    for name in ('AVSI_REC_CS', 'AVSI_COOP_CUS', 'AVSI_REC_COOP', 'AVSI_COOP_SPLIT_FWD'):
+        monkeypatch.delenv(name, raising=False)
+    assert ops.rec_fwd_parts(1024) == [(0, 1024, -32)] and ops.rec_fwd_parts(2048) == [(0, 2048, -32)]
+    assert ops.rec_fwd_parts(1088) == [(0, 1024, -32), (1024, 64, 32)]
+    assert ops.rec_fwd_parts(1536) == [(0, 1024, -32), (1024, 512, -16)]
+    assert ops.rec_fwd_parts(2112) == [(0, 2048, -32), (2048, 64, 32)]
+    assert ops.rec_fwd_parts(640) == [(0, 512, -16), (512, 128, 32)]
+    assert ops.rec_fwd_parts(768) == [(0, 512, -16), (512, 256, 16)]
+    assert ops.rec_fwd_parts(800) == [(0, 800, -32)] and ops.rec_fwd_parts(3584)[-1] == (3072, 512, -16)
+    assert ops.rec_fwd_parts(512) == [(0, 512, -16)] and ops.rec_fwd_parts(128) == [(0, 128, 32)]      # single-kernel sizes
+    for b in range(544, 3585, 32):
+        parts = ops.rec_fwd_parts(b)
+        at = 0
+        for first, rows, sp in parts:
+            tile = {-32: 32, -16: 16, 32: 32, 16: 32}[sp]
+            assert first == at and rows > 0 and first % tile == 0 and rows % tile == 0, (b, parts)
+            assert rows <= {32: 128, 16: 256, -16: 512}.get(sp, 1 << 30), (b, parts)
+            at += rows
+        assert at == b
+    ops.set_coop_cu_budget(224)          # CUs reserved for collectives: the single-kernel form
+    try:
+        assert ops.rec_fwd_parts(1088) == [(0, 1088, ops.coop_split(1088))]
+    finally:
+        ops.set_coop_cu_budget(None)
