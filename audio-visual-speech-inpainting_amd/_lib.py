@@ -74,6 +74,7 @@ PROTOTYPES = {
     "avsi_dropout_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_float, ctypes.c_uint64, c_void_p]),
     "avsi_scale_elements_f32": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p]),
     "avsi_blstm_rec_fwd_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
+    "avsi_blstm_rec_fwd_rows_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "avsi_gemm_splitk_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
     "avsi_gemm_splitk_f32": (c_int, [c_int, c_int, c_int, c_int, c_int, c_float, c_void_p, c_int64, c_void_p, c_int64,
                                      c_void_p, c_int, c_void_p, c_size_t, c_void_p]),

@@ -40,6 +40,7 @@ struct RecArgs {
     float* resv;
     int T, Bp;
     unsigned long long* stamps;  // diagnostic builds only (-DAVSI_REC_STAMPS): [wg][wave][4] phase cycles
+    int row0, rend;              // the utterances [row0, rend) of the batch are this launch's (the whole batch: 0, Bp)
 };
 
 // In-kernel phase stamps (diagnostic build only; the shipped library never executes one).
@@ -107,9 +108,9 @@ __global__ __launch_bounds__(512, MT == 1 ? 4 : 2) void blstm_rec_fwd_kernel(con
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);  // provably wave-uniform
     const int li = lane & 31, hi = lane >> 5;
     const int dir = blockIdx.y;
-    const int b0 = blockIdx.x * (MT * 32);
+    const int b0 = a.row0 + blockIdx.x * (MT * 32);
     const int T = a.T, Bp = a.Bp;
-    const int live_rows = min(MT * 32, Bp - b0);
+    const int live_rows = min(MT * 32, a.rend - b0);
 
     for (int i = tid; i < 2 * HTILE; i += 512) hbuf[i] = 0.f;
 
@@ -332,9 +333,9 @@ __global__ __launch_bounds__(512, 2) void blstm_rec_fwd_pp_kernel(const RecArgs 
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int li = lane & 31, hi = lane >> 5;
     const int dir = blockIdx.y;
-    const int b0 = blockIdx.x * 64;
+    const int b0 = a.row0 + blockIdx.x * 64;
     const int T = a.T, Bp = a.Bp;
-    const int live_rows = min(64, Bp - b0);
+    const int live_rows = min(64, a.rend - b0);
 
     for (int i = tid; i < 2 * 32 * HS; i += 512) hbuf[i] = 0.f;
 
@@ -399,7 +400,7 @@ int launch_rec_pp(const RecArgs& a, hipStream_t st) {
     const size_t lds = (size_t)2 * 32 * HS * 4;
     (void)hipFuncSetAttribute((const void*)blstm_rec_fwd_pp_kernel<SAVE>, hipFuncAttributeMaxDynamicSharedMemorySize,
                               (int)lds);
-    const int tiles = (int)avsi_ceil_div(a.Bp, 64);
+    const int tiles = (int)avsi_ceil_div(a.rend - a.row0, 64);
     hipLaunchKernelGGL((blstm_rec_fwd_pp_kernel<SAVE>), dim3(tiles, 2), dim3(512), lds, st, a);
     return avsi_launch_status();
 }
@@ -409,24 +410,25 @@ int launch_rec(const RecArgs& a, hipStream_t st) {
     const size_t lds = (size_t)2 * MT * 32 * HS * 4;
     (void)hipFuncSetAttribute((const void*)blstm_rec_fwd_kernel<MT, SAVE>, hipFuncAttributeMaxDynamicSharedMemorySize,
                               (int)lds);
-    const int tiles = (int)avsi_ceil_div(a.Bp, MT * 32);
+    const int tiles = (int)avsi_ceil_div(a.rend - a.row0, MT * 32);
     hipLaunchKernelGGL((blstm_rec_fwd_kernel<MT, SAVE>), dim3(tiles, 2), dim3(512), lds, st, a);
     return avsi_launch_status();
 }
 
 }  // namespace
 
-extern "C" int avsi_blstm_rec_fwd_f32(const float* xproj, const float* whp, float* hout, float* reserve, int T, int Bp,
-                                      int rows_per_wg, void* stream) {
+extern "C" int avsi_blstm_rec_fwd_rows_f32(const float* xproj, const float* whp, float* hout, float* reserve, int T, int Bp,
+                                           int rows_per_wg, int first_row, int rows, void* stream) {
     if (!xproj || !whp || !hout || T <= 0 || Bp <= 0) return AVSI_ERR_INVALID_ARG;
     if (Bp % 32) return AVSI_ERR_INVALID_ARG;  // batch is padded to whole 32-row MFMA tiles
+    if (first_row < 0 || rows <= 0 || (first_row & 31) || (rows & 31) || first_row + rows > Bp) return AVSI_ERR_INVALID_ARG;
     if ((reinterpret_cast<uintptr_t>(whp) & 15)) return AVSI_ERR_UNSUPPORTED;
-    RecArgs a{xproj, whp, hout, reserve, T, Bp, nullptr};
+    RecArgs a{xproj, whp, hout, reserve, T, Bp, nullptr, first_row, first_row + rows};
     // 64 rows per workgroup halves the Wh stream per flop; 32 rows spreads a small batch wider: up to 4096 utterances
-    // the 32-row workgroups (two directions x Bp / 32) fit the chip in one round, beyond that they would need a second
+    // the 32-row workgroups (two directions x rows / 32) fit the chip in one round, beyond that they would need a second
     // round where the 64-row kernel still needs one (6144 utterances, whole inference step: 131 -> 119 ms)
     int mt = rows_per_wg;
-    if (mt == 0) mt = (Bp > 32 * AVSI_NUM_CU / 2 && Bp % 64 == 0) ? 64 : 32;
+    if (mt == 0) mt = (rows > 32 * AVSI_NUM_CU / 2 && rows % 64 == 0) ? 64 : 32;
     if (mt != 32 && mt != 64 && mt != 65) return AVSI_ERR_INVALID_ARG;
     avsi_clear_error();
     const hipStream_t st = (hipStream_t)stream;
@@ -435,11 +437,16 @@ extern "C" int avsi_blstm_rec_fwd_f32(const float* xproj, const float* whp, floa
     return reserve ? launch_rec<1, true>(a, st) : launch_rec<1, false>(a, st);
 }
 
+extern "C" int avsi_blstm_rec_fwd_f32(const float* xproj, const float* whp, float* hout, float* reserve, int T, int Bp,
+                                      int rows_per_wg, void* stream) {
+    return avsi_blstm_rec_fwd_rows_f32(xproj, whp, hout, reserve, T, Bp, rows_per_wg, 0, Bp, stream);
+}
+
 #ifdef AVSI_REC_STAMPS
 // Diagnostic entry (tools/rec_stamps.cpp): same kernel with phase stamps written to `stamps`.
 extern "C" int avsi_blstm_rec_fwd_stamps(const float* xproj, const float* whp, float* hout, int T, int Bp, int mt,
                                          unsigned long long* stamps, void* stream) {
-    RecArgs a{xproj, whp, hout, nullptr, T, Bp, stamps};
+    RecArgs a{xproj, whp, hout, nullptr, T, Bp, stamps, 0, Bp};
     avsi_clear_error();
     return mt == 64 ? launch_rec<2, false>(a, (hipStream_t)stream) : launch_rec<1, false>(a, (hipStream_t)stream);
 }

@@ -376,7 +376,7 @@ class StackedBLSTMModel(object):
         if keep and self.layout.ones_col_top >= 0:
             x[:, :B, self.layout.ones_col_top] = 1.0
         c['rnn_out'] = x
-        if not self.rows_per_wg and ops.coop_split(Bp):
+        if not self.rows_per_wg and any(sp for _, _, sp in ops.rec_fwd_parts(Bp)):
             ops.coop_poll(self.device)       # small batches: a bounded wait that gave up surfaces here, without a sync
         # prediction = sequence_mask * (rnn_out . W + b), stored batch-major [B, T, F]
         seq = self._seq_dev

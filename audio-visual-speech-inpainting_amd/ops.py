@@ -101,15 +101,14 @@ def blstm_rec_fwd(xproj, whp, hout, reserve=None, rows_per_wg=0, split=None):
         raise _lib.AvsiError("blstm_rec_fwd: bad reserve shape")
     auto = rows_per_wg == 0 and split is None
     split = coop_split(Bp) if auto else int(split or 0)
-    if split == 0:
-        _lib.check(_lib.lib().avsi_blstm_rec_fwd_f32(_lib.ptr(xproj), _lib.ptr(whp), _lib.ptr(hout), _lib.ptr(reserve),
-                                                     T, Bp, int(rows_per_wg), _lib.stream_ptr()),
-                   "avsi_blstm_rec_fwd_f32")
-        return hout
     # (first_row, rows, split) pieces: by default the whole batch with one kernel; the automatic choice gives the
     # remainder beyond the large kernel's launches to the kernel of its own size (rec_fwd_parts)
     parts = rec_fwd_parts(Bp) if (auto and _REC_PARTS) else [(0, Bp, split)]
     L = _lib.lib()
+    if len(parts) == 1 and parts[0][2] == 0:
+        _lib.check(L.avsi_blstm_rec_fwd_f32(_lib.ptr(xproj), _lib.ptr(whp), _lib.ptr(hout), _lib.ptr(reserve),
+                                            T, Bp, int(rows_per_wg), _lib.stream_ptr()), "avsi_blstm_rec_fwd_f32")
+        return hout
     need = max(L.avsi_blstm_rec_fwd_cs_workspace_bytes(Bp), L.avsi_blstm_rec_fwd_coop_workspace_bytes(Bp))
     fine = [rows for _, rows, sp in parts if sp >= 16]
     if _COOP_EXCHANGE and fine:
@@ -118,7 +117,10 @@ def blstm_rec_fwd(xproj, whp, hout, reserve=None, rows_per_wg=0, split=None):
         need = max(need, COOP_EXCHANGE_OFFSET + L.avsi_blstm_rec_fwd_coop_exchange_bytes(T, max(fine)))
     ws = _coop_ws(xproj.device, Bp, need)
     for first, rows, sp in parts:
-        if sp < 0:
+        if sp == 0:
+            _lib.check(L.avsi_blstm_rec_fwd_rows_f32(_lib.ptr(xproj), _lib.ptr(whp), _lib.ptr(hout), _lib.ptr(reserve), T, Bp,
+                                                     0, first, rows, _lib.stream_ptr()), "avsi_blstm_rec_fwd_rows_f32")
+        elif sp < 0:
             _lib.check(L.avsi_blstm_rec_fwd_cs_rows_f32(_lib.ptr(xproj), _lib.ptr(whp), _lib.ptr(hout), _lib.ptr(reserve), T, Bp,
                                                         -sp, first, rows, coop_cu_budget(), _lib.ptr(ws), ws.numel() * 4,
                                                         _lib.stream_ptr()), "avsi_blstm_rec_fwd_cs_rows_f32")
@@ -131,37 +133,48 @@ def blstm_rec_fwd(xproj, whp, hout, reserve=None, rows_per_wg=0, split=None):
 
 
 _REC_PARTS = os.environ.get('AVSI_REC_PARTS', '1') != '0'
+REC_TAIL_MAX = 1536        # largest remainder (utterances) cut off a batch of more than 4096 for the small-batch kernels
 
 
-def rec_fwd_parts(Bp):
-    """[(first_row, rows, split)]: how the forward recurrence of a batch of Bp utterances (coop_split(Bp) != 0) is cut.
-    The cooperative launches are latency-bound -- 250 steps of 3 .. 11 us whatever the number of groups -- so a
-    remainder beyond the large kernel's resident launches is cheaper on the kernel of ITS size than as one more launch
-    of the large one.  Per layer, ms: 32-way (<= 128 utterances) 0.8, 16-way (<= 256) 1.1, column-split by 16 (<= 512)
-    1.6, by 32 (<= 1024 per launch) 2.8.  1088 = 1024 by 32 + 64 32-way: 3.6 instead of 5.6; 640 = 512 by 16 + 128 32-way:
-    2.4 instead of 2.8.  Only taken at the full CU budget (a reserved-CU run keeps the single-kernel form)."""
-    split = coop_split(Bp)
-    if split >= 0 or split == -16 or coop_cu_budget() < 256 or os.environ.get('AVSI_COOP_SPLIT_FWD'):
-        return [(0, Bp, split)]
-    parts, at = [], 0
-    whole = Bp // 1024 * 1024
+def _small_parts(at, r):
+    """Pieces for the r utterances from row `at` on (r <= CS_MAX_BATCH), each on the cooperative kernel of its size."""
+    parts = []
+    whole = r // 1024 * 1024
     if whole:
-        parts.append((0, whole, -32))
-        at = whole
-    r = Bp - at
+        parts.append((at, whole, -32))
+        at, r = at + whole, r - whole
     if r > 768:
         parts.append((at, r, -32))
-        return parts
-    if r > 512:
+    elif r > 512:
         parts.append((at, 512, -16))
-        at, r = at + 512, r - 512
-        if r:
-            parts.append((at, r, 32 if r <= 128 else 16))
+        parts.append((at + 512, r - 512, 32 if r - 512 <= 128 else 16))
     elif r > 256:
         parts.append((at, r, -16))
     elif r:
         parts.append((at, r, 32 if r <= 128 else 16))
     return parts
+
+
+def rec_fwd_parts(Bp):
+    """[(first_row, rows, split)]: how the forward recurrence of a batch of Bp utterances is cut (split as coop_split: 0 =
+    the batch-stationary kernel).  The cooperative launches are latency-bound -- 250 steps of 3 .. 11 us whatever the
+    number of groups -- so a remainder beyond the large kernel's resident launches is cheaper on the kernel of ITS size
+    than as one more launch of the large one.  Per layer, ms: 32-way (<= 128 utterances) 0.8, 16-way (<= 256) 1.1,
+    column-split by 16 (<= 512) 1.6, by 32 (<= 1024 per launch) 2.8; batch-stationary 32-row kernel 10.3 for anything up
+    to 4096, 64-row kernel 16.5 up to 8192.  1088 = 1024 by 32 + 64 32-way: 3.6 instead of 5.6; 640 = 512 by 16 + 128
+    32-way: 2.4 instead of 2.8; 5120 = 4096 batch-stationary + 1024 by 32: 13.1 instead of 16.5.  Only taken at the full
+    CU budget (a reserved-CU run keeps the single-kernel form)."""
+    split = coop_split(Bp)
+    single = [(0, Bp, split)]
+    if coop_cu_budget() < 256 or os.environ.get('AVSI_COOP_SPLIT_FWD') or os.environ.get('AVSI_REC_COOP', '1') == '0':
+        return single
+    if split == 0:
+        if 4096 < Bp <= 4096 + REC_TAIL_MAX and os.environ.get('AVSI_REC_CS', '1') != '0':
+            return [(0, 4096, 0)] + _small_parts(4096, Bp - 4096)
+        return single
+    if split != -32:
+        return single
+    return _small_parts(0, Bp)
 
 
 _COOP_WS, _COOP_HOST = {}, {}      # keyed by (device index, stream)

@@ -129,6 +129,11 @@ int avsi_gemm_f32(int transA, int transB, int M, int N, int K, float alpha,
  * ------------------------------------------------------------------------------------ */
 int avsi_blstm_rec_fwd_f32(const float* xproj, const float* whp, float* hout, float* reserve,
                            int T, int Bp, int rows_per_wg, void* stream);
+/* The same for the utterances [first_row, first_row + rows) of the batch only (multiples of 32; operands are still the
+ * whole [T, Bp, ...] arrays; rows_per_wg 0 chooses from `rows`): the batch-stationary piece of a batch whose remainder
+ * goes to a small-batch kernel (avsi_blstm_rec_fwd_coop_rows_f32 / avsi_blstm_rec_fwd_cs_rows_f32). */
+int avsi_blstm_rec_fwd_rows_f32(const float* xproj, const float* whp, float* hout, float* reserve,
+                                int T, int Bp, int rows_per_wg, int first_row, int rows, void* stream);
 
 /* EXPLORATORY, not on the default path: C[M,N] = A[M,K] . B[K,N] + bias with every fp32 operand split into two bf16
  * values and the product taken as hi.hi + hi.lo + lo.hi on the bf16 matrix cores (fp32 accumulation).  Same role as

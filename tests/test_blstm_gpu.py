@@ -239,7 +239,8 @@ def test_cooperative_small_batch_kernel_matches_batch_stationary(Bp, split, save
     assert ops.coop_split(512) == -16 and ops.coop_split(1024) == -32 and ops.coop_split(2048) == -32 and ops.coop_split(4096) == 0
 
 
-@pytest.mark.parametrize("Bp,save", [(544, False), (640, True), (768, False), (1088, True), (1536, False), (2112, False)])
+@pytest.mark.parametrize("Bp,save", [(544, False), (640, True), (768, False), (1088, True), (1536, False), (2112, False),
+                                     (4160, False), (4672, True)])          # these two: 4096 batch-stationary + remainder
 def test_forward_recurrence_in_pieces_matches_batch_stationary(Bp, save, monkeypatch):
     """The automatic choice cuts these batches into a large part and a remainder on the kernel of its size
     (ops.rec_fwd_parts, avsi_blstm_rec_fwd_{cs,coop}_rows_f32): same result as the batch-stationary kernel, every

@@ -75,6 +75,12 @@ def test_forward_recurrence_is_cut_into_pieces_of_their_own_size(monkeypatch):
             assert rows <= {32: 128, 16: 256, -16: 512}.get(sp, 1 << 30), (b, parts)
             at += rows
         assert at == b
+    # just above 4096 utterances: one round of the 32-row batch-stationary kernel + the remainder on its own kernel
+    assert ops.rec_fwd_parts(4096) == [(0, 4096, 0)] and ops.rec_fwd_parts(8192) == [(0, 8192, 0)]
+    assert ops.rec_fwd_parts(4160) == [(0, 4096, 0), (4096, 64, 32)]
+    assert ops.rec_fwd_parts(5120) == [(0, 4096, 0), (4096, 1024, -32)]
+    assert ops.rec_fwd_parts(5632) == [(0, 4096, 0), (4096, 1024, -32), (5120, 512, -16)]
+    assert ops.rec_fwd_parts(5696) == [(0, 5696, 0)]
     ops.set_coop_cu_budget(224)          # CUs reserved for collectives: the single-kernel form
     try:
         assert ops.rec_fwd_parts(1088) == [(0, 1088, ops.coop_split(1088))]
