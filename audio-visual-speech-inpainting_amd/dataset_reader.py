@@ -135,6 +135,7 @@ class Batch(tuple):
     to device tensors, ``ready`` is the event a consuming stream has to wait for (see ``to_device``)."""
     device_arrays = None
     ready = None
+    gap_count = None        # zero elements of the mask field, counted on the prefetch thread (training.gap_elements)
 
     def to_device(self, index):
         """Device tensor of field ``index`` (or None if it was not uploaded), ordered after the upload on the
@@ -172,6 +173,8 @@ class _Uploader(object):
             self.stream = torch.cuda.Stream(device=self.device)
         out = Batch(batch)
         out.device_arrays = {}
+        if isinstance(batch[-1], np.ndarray) and batch[-1].dtype != object:
+            out.gap_count = int(batch[-1].size - np.count_nonzero(batch[-1]))
         with torch.cuda.stream(self.stream):
             for i in sorted(f % len(batch) for f in self.fields):
                 a = batch[i]

@@ -167,7 +167,7 @@ class StackedBLSTM2StepsModel(object):
         # everything else the drivers fetch is the second step's (models.py:280-294)
         if name in ('target_spec_norm', 'inference', 'prediction', 'loss', 'loss_func', 'loss_hole', 'loss_valid',
                     'train_op', 'learning_rate', 'global_step', 'enhanced_sources', 'enhanced_sources_oracle_phase',
-                    'all_vars', 'train_vars', 'gradients', 'net_inputs', 'target_stft', 'sequence_lengths', 'masks',
+                    'all_vars', 'train_vars', 'gradients', 'nonfinite_flag', 'net_inputs', 'target_stft', 'sequence_lengths', 'masks',
                     'target_sources'):
             return getattr(self._chain(), name)
         raise AttributeError(name)

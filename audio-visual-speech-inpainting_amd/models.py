@@ -523,7 +523,11 @@ class StackedBLSTMModel(object):
         v, lay = self.variables, self.layout
         F, ldp = self.audio_feat_dim, self.layout.ldp
         M = T * Bp
-        gp = self._buf('gpacked', (lay.gpacked_size,), zero=True)
+        # one slot behind the gradients carries this rank's "my loss is not finite" word through the LAST all-reduce
+        # bucket (loss * 0: NaN for a NaN or infinite loss, and NaN survives the sum over ranks) -- the trainer reads
+        # it one step late together with the loss, so the rank-synchronous abort costs neither a collective of its
+        # own nor a host synchronisation (`nonfinite_flag`)
+        gp = self._buf('gpacked', (lay.gpacked_size + 1,), zero=True)
         # d logits, time-major + padded, sequence mask folded in (rows of padded utterances stay 0)
         dlog = self._buf('dlog', (T, Bp, ldp), zero=True)
         ops.relayout_rows(c['dpred'], dlog, B, T, F, ldp, (T * F, F), (ldp, Bp * ldp),
@@ -556,7 +560,7 @@ class StackedBLSTMModel(object):
         def reduce_from(name, upto=None):
             if reduce:
                 lo = lay.gpacked[name][0]
-                hi = lay.gpacked_size if upto is None else lay.gpacked[upto][0]
+                hi = lay.gpacked_size + 1 if upto is None else lay.gpacked[upto][0]
                 works.append(parallel.all_reduce_sum_async(gp[lo:hi]))
 
         # Three side streams when nothing orders the products of a layer among themselves (no all-reduce behind
@@ -652,11 +656,15 @@ class StackedBLSTMModel(object):
         if overlap:
             for st in sides:
                 main.wait_stream(st)
-        reduce_from('dpw')                       # projection head (+ the speaker-embedding MLP of the SSNN variant)
+        if reduce:
+            torch.mul(c['loss3'][0:1], 0.0, out=gp[lay.gpacked_size:])
+        reduce_from('dpw')                       # projection head (+ the speaker-embedding MLP of the SSNN variant) + the flag
         for w in works:
             if w is not None:
                 w.wait()
         c['grads_reduced'] = reduce
+        if reduce:
+            c['nonfinite'] = gp[lay.gpacked_size:].clone()        # gp is this model's buffer for the next step too
         if ops.coop_split(Bp):
             ops.coop_poll(self.device)
         grads = v.unpack_grads(gp, out=self._buf('grads', (lay.ref_size,)))
@@ -690,6 +698,8 @@ class StackedBLSTMModel(object):
         if not c.get('grads_reduced'):
             parallel.all_reduce_sum_(g)          # gradients were fetched (unreduced) before train_op: one flat all-reduce
             c['grads_reduced'] = world > 1
+            if world > 1:
+                c['nonfinite'] = parallel.all_reduce_sum_(c['loss3'][0:1] * 0.0)
         step = v.global_step + 1
         l2 = float(self.regularization or 0.0)
         if self.optimizer_choice == 'adam':
@@ -714,6 +724,18 @@ class StackedBLSTMModel(object):
         v.repack()
         c['trained'] = True
         return None
+
+    @property
+    def nonfinite_flag(self):
+        """One-element device tensor: 0 while the loss of this step is finite on EVERY data-parallel rank, NaN otherwise
+        (after ``train_op`` under torch.distributed it has been summed over the ranks inside the last gradient bucket;
+        before, or on a single process, it is this rank's own ``loss_func * 0``).  The trainer's NaN / Inf abort
+        (training_emb.py:244-249) reads it one step late with the loss -- no collective or host wait of its own."""
+        c = self._cache
+        if c.get('nonfinite') is not None:
+            return c['nonfinite']
+        self._loss()
+        return c['loss3'][0:1] * 0.0
 
     @property
     def global_step(self):

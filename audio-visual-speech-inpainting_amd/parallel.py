@@ -44,15 +44,36 @@ def collectives_share_the_gpu():
     """True when this process runs RCCL collectives on its GPU (world > 1, backend nccl): their kernels hold compute
     units while the cooperative recurrent kernels run (the bucketed gradient all-reduce overlaps the BPTT of the
     layers below), so those kernels are sized to leave ops.COOP_CU_RESERVE CUs free (ops.coop_cu_budget)."""
-    return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1 and dist.get_backend() == 'nccl'
+    return dist.is_available() and dist.is_initialized() and not _SOLO and dist.get_world_size() > 1 \
+        and dist.get_backend() == 'nccl'
+
+
+_SOLO = 0
+
+
+class solo(object):
+    """Context manager: inside it this process behaves as a single-process job (world_size() == 1, rank() == 0: no
+    gradient all-reduce, no CU reserve for collectives) although a process group exists.  For the self-check of a
+    data-parallel run -- one rank repeats the global batch alone while its peers wait at a barrier (bench.py,
+    `dp_train.check`) -- never for training proper: the ranks' variables diverge under it."""
+
+    def __enter__(self):
+        global _SOLO
+        _SOLO += 1
+        return self
+
+    def __exit__(self, *exc):
+        global _SOLO
+        _SOLO -= 1
+        return False
 
 
 def world_size():
-    return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+    return dist.get_world_size() if dist.is_available() and dist.is_initialized() and not _SOLO else 1
 
 
 def rank():
-    return dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
+    return dist.get_rank() if dist.is_available() and dist.is_initialized() and not _SOLO else 0
 
 
 def shard_range(n, rank_, world):

@@ -102,6 +102,14 @@ def unpack_batch(batch, with_embeddings, with_labels=False):
     return feed, paths
 
 
+def gap_elements(batch):
+    """Number of zero elements of the batch's mask (the weight of the running loss means, training_emb.py:252).
+    Counted by the reader's prefetch thread when the batch came through it (dataset_reader.Batch.gap_count): on the
+    training thread the scan of 2 M mask elements cost more host time per step than launching the step."""
+    n = getattr(batch, 'gap_count', None)
+    return int(n) if n is not None else int(np.count_nonzero(batch[-1] == 0))
+
+
 def train(config_file, checkpoint_format=None):
     """
     Train the speech inpainting model.
@@ -271,10 +279,12 @@ def train(config_file, checkpoint_format=None):
             vals = resolve(vals)
             if world > 1:
                 # every rank must leave at the SAME step (a rank that exits alone leaves its peers waiting in the
-                # next gradient all-reduce): the verdict is the maximum over ranks of 'my loss is not finite'
-                bad = parallel.all_reduce_max_scalar(0.0 if np.isfinite(vals[0]) else (2.0 if np.isinf(vals[0]) else 1.0))
+                # next gradient all-reduce).  The verdict came with the gradients: the last all-reduce bucket of the
+                # step carries 'my loss is not finite' of every rank (model.nonfinite_flag), and it is read here, one
+                # step late like the loss -- no collective and no host wait of its own
+                bad = not np.isfinite(vals.pop())
                 if bad and np.isfinite(vals[0]):
-                    print('GOT INSTABILITY on another rank: loss is %s there. Leaving...' % ('inf' if bad > 1 else 'NaN'))
+                    print('GOT INSTABILITY on another rank: loss is not finite there. Leaving...')
                     sys.exit(1)
             if np.isnan(vals[0]):
                 print('GOT INSTABILITY: loss is NaN. Leaving...')
@@ -318,7 +328,9 @@ def train(config_file, checkpoint_format=None):
             model.feed(**feed)
             vals, lr = fetch(True), model.learning_rate
             model.train_op
-            step_done, pending = pending, (vals, np.count_nonzero(batch[-1] == 0), n_step, tot_step, lr)
+            if world > 1:
+                vals = list(vals) + [model.nonfinite_flag]
+            step_done, pending = pending, (vals, gap_elements(batch), n_step, tot_step, lr)
             if step_done is not None:
                 book(*step_done)
         if chief:
@@ -336,8 +348,7 @@ def train(config_file, checkpoint_format=None):
             n_step += 1
             model.set_dropout_rate(0.0)                             # training_emb.py:314,326
             model.feed(**feed)
-            val_avg, nframe_sum = accumulate(val_avg, resolve(fetch(False)), nframe_sum, np.count_nonzero(batch[-1] == 0),
-                                             n_step == 1)
+            val_avg, nframe_sum = accumulate(val_avg, resolve(fetch(False)), nframe_sum, gap_elements(batch), n_step == 1)
             if chief and (n_step % 200 == 0 or n_step == 1):
                 print('Step[{:7d}] Loss[{:3.5f}]'.format(n_step, val_avg[1]))
         model.is_training = True

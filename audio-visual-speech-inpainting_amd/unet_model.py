@@ -477,6 +477,15 @@ class UNetFConvModel(object):
         return g + self.regularization * self.variables.flat if self.regularization else g
 
     @property
+    def nonfinite_flag(self):
+        """See StackedBLSTMModel.nonfinite_flag."""
+        c = self._cache
+        if c.get('nonfinite') is not None:
+            return c['nonfinite']
+        self._loss()
+        return c['loss3'][0:1] * 0.0
+
+    @property
     def global_step(self):
         return self.variables.global_step
 
@@ -493,7 +502,15 @@ class UNetFConvModel(object):
         g = self._backward()
         v = self.variables
         world = parallel.world_size()
-        parallel.all_reduce_sum_(g)
+        if world > 1:
+            # one flat all-reduce; the word behind the gradients is this rank's "my loss is not finite" flag
+            # (loss * 0, NaN survives the sum): see StackedBLSTMModel.nonfinite_flag
+            gf = self._buf('grads+flag', (self.layout.ref_size + 1,))
+            gf[:-1].copy_(g)
+            torch.mul(c['loss3'][0:1], 0.0, out=gf[-1:])
+            parallel.all_reduce_sum_(gf)
+            g = gf[:-1]
+            c['nonfinite'] = gf[-1:].clone()
         step = v.global_step + 1
         if self.optimizer_choice != 'adam':
             print('Optimizer must be adam on the MI355X U-Net path. Closing...')

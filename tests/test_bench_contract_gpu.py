@@ -43,6 +43,22 @@ def test_default_mode_line():
         assert also[k]["per_gpu_batch"] == b and also[k]["ms_per_step"] > 0
         assert abs(also[k]["value"] - b / also[k]["ms_per_step"] * 1e3) < 1e-6 * also[k]["value"]
     assert abs(d["value"] - 256 * 2 / (d["ms_per_step"] * 2e-3)) < 1e-6 * d["value"]
+    # the other configurations and the steps either side of the path (N = 1 only), each with an algorithmic roofline figure
+    for k, b in (("train_b8192", 8192), ("unet_b512", 512), ("unet_b32", 32), ("istft_b4096", 4096), ("lws_b1024", 1024),
+                 ("infer_b8192_hostfed", 8192)):
+        assert "error" not in also[k], also[k]
+        assert also[k]["per_gpu_batch"] == b and also[k]["ms_per_step"] > 0 and also[k]["value"] > 0
+    assert 0 < also["train_b8192"]["kernels"]["blstm_rec_bwd_kh_kernel"]["frac"] < 1
+    assert 0 < also["unet_b512"]["frac_of_fp32_mfma_peak"] < 1 and 0 < also["istft_b4096"]["frac_of_hbm_peak"] < 1
+    assert also["infer_b8192_hostfed"]["serial_upload_then_compute"]["ms_per_step"] >= also["infer_b8192_hostfed"]["ms_per_step"] * 0.9
+    # configs[3], the same keys at every N: weak (32 per GPU) and fixed global 256 (256 / N per GPU)
+    dp = d["dp_train"]
+    assert "error" not in dp, dp
+    assert dp["rccl_ranks"] == 1 and dp["weak_32_per_gpu"]["per_gpu_batch"] == 32 and dp["fixed_global_256"]["per_gpu_batch"] == 256
+    assert dp["check"]["max_abs_update"] > 1e-3
+    fe = d["roofline"]["others"]["frontend_kernel"]
+    lo, med, hi = fe["launch_ms_min_median_max"]
+    assert 0 < lo <= med <= hi
 
 
 def test_train_and_unet_modes():
@@ -78,3 +94,15 @@ def test_multi_rank_launch_as_the_driver_does(mode):
     if mode == "infer":
         assert "error" not in d["also"], d["also"]
         assert d["also"]["train_b32"]["global_batch"] == 64 and d["also"]["train_b32"]["ms_per_step"] > 0
+        # the data-parallel self-check of the bench line: every rank ends with the same bits, equal to one process at
+        # the global batch up to summation order (gloo here; the driver's multi-GPU run is the same code over RCCL)
+        dp = d["dp_train"]
+        assert "error" not in dp, dp
+        assert dp["rccl_ranks"] == 2 and dp["backend"] == "gloo"
+        c = dp["check"]
+        assert c["ranks_bit_identical"] is True and c["global_batch"] == 64 and c["frames"] == 250
+        assert c["max_abs_diff_vs_single_process"] < 2e-5 < 1e-3 < c["max_abs_update"] and c["ok"] is True
+        assert c["loss_max_rel_diff_vs_single_process"] < 2e-4
+        assert dp["weak_32_per_gpu"]["global_batch"] == 64 and dp["fixed_global_256"]["per_gpu_batch"] == 128
+        for k in ("weak_32_per_gpu", "fixed_global_256"):
+            assert dp[k]["ms_per_step"] > 0 and dp[k]["ms_per_step_no_collective"] > 0
