@@ -418,10 +418,14 @@ __global__ __launch_bounds__(512, 2) void blstm_rec_fwd_coop_fine_kernel(const C
             if (XCH) {      // the exchange copy first (the only store the publication waits for), hout beside it
                 __hip_atomic_store(xbase + (size_t)step * xgroups * (32 * HP) + (member * 32 + frow) * UW + fu, hn,
                                    __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                // compiler barrier: the counted wait below assumes the exchange store is ISSUED before the plain stores
+                // that follow; nothing else stops the compiler from moving a non-atomic store across a relaxed atomic one
+                asm volatile("" ::: "memory");
                 a.hout[(row0 + frow) * (2 * HP) + dir * HP + unit] = hn;
             } else {
                 __hip_atomic_store(a.hout + (row0 + frow) * (2 * HP) + dir * HP + unit, hn, __ATOMIC_RELAXED,
                                    __HIP_MEMORY_SCOPE_AGENT);
+                asm volatile("" ::: "memory");
             }
             if (SAVE) {
                 float* rv = a.resv + (row0 + frow) * (2 * 5 * HP) + dir * 5 * HP + unit;
@@ -518,6 +522,8 @@ extern "C" int avsi_blstm_rec_fwd_coop_rows_f32(const float* xproj, const float*
     // (at a FIXED offset: the counters of a later, larger batch must not land on old exchange data)
     float* xch = (split >= 16 && workspace_bytes >= AVSI_COOP_EXCHANGE_OFFSET + avsi_blstm_rec_fwd_coop_exchange_bytes(T, rows))
                      ? reinterpret_cast<float*>(static_cast<char*>(workspace) + AVSI_COOP_EXCHANGE_OFFSET) : nullptr;
+    // the exchange copy sits at a fixed offset: the counters of this batch must end in front of it
+    if (xch && avsi_blstm_rec_fwd_coop_workspace_bytes(Bp) > AVSI_COOP_EXCHANGE_OFFSET) return AVSI_ERR_WORKSPACE;
     for (int tile0 = tbeg; tile0 < tiles; tile0 += per) {
         const int nt = tiles - tile0 < per ? tiles - tile0 : per;
         CoopArgs a{xproj, whp, hout, reserve, (unsigned*)workspace, T, Bp, 2 * nt, tile0, xch, tbeg, rows / 32};
@@ -852,6 +858,7 @@ __global__ __launch_bounds__(512, 2) void blstm_rec_bwd_coop_fine_kernel(const C
                 __hip_atomic_store(xo + 1 * R * 16, dzj, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 __hip_atomic_store(xo + 2 * R * 16, dzf, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 __hip_atomic_store(xo + 3 * R * 16, dzo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                asm volatile("" ::: "memory");      // issue order = program order: the counted wait below relies on it
                 zo[0] = dzi, zo[32] = dzj, zo[64] = dzf, zo[96] = dzo;
             } else {
                 __hip_atomic_store(zo + 0, dzi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -887,6 +894,7 @@ extern "C" int avsi_blstm_rec_bwd_coop_f32(const float* dhout, const float* rese
     // fine splits (16, 32) to the exchange layout
     float* xch = (split >= 16 && workspace_bytes >= AVSI_COOP_EXCHANGE_OFFSET + avsi_blstm_rec_bwd_coop_exchange_bytes(T, Bp))
                      ? reinterpret_cast<float*>(static_cast<char*>(workspace) + AVSI_COOP_EXCHANGE_OFFSET) : nullptr;
+    if (xch && avsi_blstm_rec_fwd_coop_workspace_bytes(Bp) > AVSI_COOP_EXCHANGE_OFFSET) return AVSI_ERR_WORKSPACE;
     if (split >= 16) {
         (void)hipFuncSetAttribute((const void*)blstm_rec_bwd_coop_fine_kernel<1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
         (void)hipFuncSetAttribute((const void*)blstm_rec_bwd_coop_fine_kernel<1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);

@@ -371,15 +371,25 @@ int read_single_record(const char* path, int verify, std::vector<unsigned char>&
     unsigned char head[12];
     int rc = AVSI_OK;
     uint64_t n = 0;
-    if (fread(head, 1, 12, fh) != 12) rc = AVSI_ERR_INVALID_ARG;
+    // the size of the file bounds the record: a corrupt (or non-TFRecord) header must not size a buffer
+    long fsize = -1;
+    if (fseek(fh, 0, SEEK_END) == 0) fsize = ftell(fh);
+    if (fsize < 16 || fseek(fh, 0, SEEK_SET) != 0) rc = AVSI_ERR_INVALID_ARG;
+    if (rc == AVSI_OK && fread(head, 1, 12, fh) != 12) rc = AVSI_ERR_INVALID_ARG;
     if (rc == AVSI_OK) {
         memcpy(&n, head, 8);
         uint32_t hcrc;
         memcpy(&hcrc, head + 8, 4);
-        if (n > ((uint64_t)1 << 32) || (verify && hcrc != masked_crc(head, 8))) rc = AVSI_ERR_INVALID_ARG;
+        // the 12-byte header checksum is always verified (it costs nothing and guards the length); `verify` adds the payload's
+        if (n > (uint64_t)fsize - 16 || hcrc != masked_crc(head, 8)) rc = AVSI_ERR_INVALID_ARG;
     }
     if (rc == AVSI_OK) {
-        buf.resize((size_t)n + 4);
+        try {
+            buf.resize((size_t)n + 4);
+        } catch (const std::bad_alloc&) {       // never across the extern "C" boundary
+            fclose(fh);
+            return AVSI_ERR_INVALID_ARG;
+        }
         if (fread(buf.data(), 1, (size_t)n + 4, fh) != (size_t)n + 4) rc = AVSI_ERR_INVALID_ARG;
     }
     if (rc == AVSI_OK && verify) {
@@ -416,6 +426,7 @@ extern "C" int avsi_tfrecord_file_decode_fixed_host(const char* path, int verify
     static thread_local std::vector<unsigned char> buf;
     const int rc = read_single_record(path, verify, buf);
     if (rc != AVSI_OK) return rc;
+    if (buf.capacity() > ((size_t)64 << 20) && buf.size() < buf.capacity() / 4) buf.shrink_to_fit();   // one huge record must not pin its pages for ever
     return avsi_sequence_example_decode_fixed_host(buf.data(), buf.size(), num_audio_samples, audio_feat_size, video_feat_size,
                                                    embedding_size, num_frames, num_video_frames, num_labels, lengths2, wav_i32,
                                                    embedding, sample_path, sample_path_cap, labels, video, mask);

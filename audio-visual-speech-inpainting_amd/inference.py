@@ -132,7 +132,8 @@ def infer(model_path, data_path_test, audio_path, out_file_prefix, norm=True, or
             masks = torch.cat([p[1] for p in pending])
         # Reconstruct phase with LWS algorithm (reference inference.py:141-154), all collected batches on the device
         out = lws_processor.refine_enhanced(wavs, masks, num_samples=wavs.shape[1]).cpu().numpy()
-        at = 0
+        ops.coop_check()            # the read-back synchronised: a cooperative kernel that gave up its bounded wait (its
+        at = 0                      # outputs are invalid) raises HERE, before any file of these batches is written
         for _, _, paths, lengths in pending:
             writer.submit(out[at:at + len(lengths)], paths, lengths)
             at += len(lengths)
@@ -155,7 +156,9 @@ def infer(model_path, data_path_test, audio_path, out_file_prefix, norm=True, or
         ops.coop_poll()
         loss_list.append(loss)
         if oracle_phase:
-            writer.submit(enhanced.cpu().numpy(), test_sample_path, test_length)
+            enhanced_host = enhanced.cpu().numpy()
+            ops.coop_check()                    # as in flush(): checked after the synchronising read-back, before the files
+            writer.submit(enhanced_host, test_sample_path, test_length)
             written(test_sample_path, test_length)
             continue
         masks = model.masks

@@ -26,10 +26,10 @@ def config(N, B):
                 starter_learning_rate=1e-3, lr_updating_steps=10000, lr_decay=1.0, batch_size=B, l2=0.0)
 
 
-def run(rank, world, steps, B_global=4):
+def run(rank, world, steps, B_global=4, N=2880):
     import avsi_amd  # noqa: F401
     from avsi_amd import models
-    wav, masks, video, mean, std, T = make_inputs(B_global)
+    wav, masks, video, mean, std, T = make_inputs(B_global, N)
     per = B_global // world
     sl = slice(rank * per, (rank + 1) * per)
     m = models.StackedBLSTMModel(np.full(per, T), wav[sl], masks[sl], mean, std, 0.0, config(wav.shape[1], per),
@@ -46,7 +46,8 @@ if __name__ == '__main__':
     out = sys.argv[1]
     from avsi_amd import parallel
     rank, world = parallel.init()
-    flat, losses = run(rank, world, steps=3, B_global=int(sys.argv[2]) if len(sys.argv) > 2 else 4)
+    flat, losses = run(rank, world, steps=int(sys.argv[4]) if len(sys.argv) > 4 else 3,
+                       B_global=int(sys.argv[2]) if len(sys.argv) > 2 else 4, N=int(sys.argv[3]) if len(sys.argv) > 3 else 2880)
     np.save(os.path.join(out, 'flat_rank%d.npy' % rank), flat)
     np.save(os.path.join(out, 'loss_rank%d.npy' % rank), np.array(losses))
     import torch.distributed as dist

@@ -43,6 +43,26 @@ def test_two_ranks_equal_one_process_at_the_global_batch(tmp_path):
     np.testing.assert_allclose((l0 + l1) / 2, ref_losses, rtol=2e-4)
 
 
+def test_two_ranks_at_config_4_shape_equal_one_process(tmp_path):
+    """BASELINE configs[3]'s per-GPU share: 32 utterances per rank, 3 s clips (T = 250), AV model, two Adam steps; the result
+    equals one process at 64 utterances."""
+    env = dict(os.environ, AVSI_DIST_BACKEND='gloo', HSA_ENABLE_IPC_MODE_LEGACY='0', AVSI_COOP_CUS='128')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+           '--master-port', str(_free_port()), os.path.join(HERE, 'dp_worker.py'), str(tmp_path), '64', '48000', '2']
+    run = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert run.returncode == 0, run.stderr[-3000:]
+    f0, f1 = np.load(str(tmp_path / 'flat_rank0.npy')), np.load(str(tmp_path / 'flat_rank1.npy'))
+    assert np.array_equal(f0, f1)
+    sys.path.insert(0, HERE)
+    import dp_worker
+    ref, ref_losses = dp_worker.run(0, 1, steps=2, B_global=64, N=48000)
+    init, _ = dp_worker.run(0, 1, steps=0, B_global=64, N=48000)
+    assert np.abs(ref - init).max() > 1e-3
+    np.testing.assert_allclose(f0, ref, rtol=0, atol=2e-5)
+    l0, l1 = np.load(str(tmp_path / 'loss_rank0.npy')), np.load(str(tmp_path / 'loss_rank1.npy'))
+    np.testing.assert_allclose((l0 + l1) / 2, ref_losses, rtol=2e-4)
+
+
 def _gpu_count():
     try:
         import torch

@@ -317,3 +317,30 @@ def test_data_parallel_training_through_the_driver(experiment, tmp_path):
     assert len([l for l in log if l[:1].isdigit()]) == 2 and log[0] == "+-- EXPERIMENT NAME - dp_exp --+"
     assert (exp / "netmodel" / "sinet.npz").is_file()
     assert run.stdout.count('+---- Done training: epoch limit reached ----+') == 1      # rank 0 only
+
+
+def test_non_finite_loss_on_one_rank_stops_every_rank(experiment, tmp_path):
+    """The NaN / Inf abort of the trainer (training_emb.py:244-249, exit code 1) under data parallelism: the verdict
+    travels in the last gradient all-reduce bucket (model.nonfinite_flag), so the rank whose loss is fine leaves at the
+    same step as the rank whose loss is NaN -- nobody is left waiting in the next collective."""
+    import socket
+    import subprocess
+    import sys
+    base, data, cfg0 = experiment
+    exp = tmp_path / "logs" / "dp_nan"
+    text = open(cfg0).read().replace("exp_folder = %s" % (base / "logs" / "av_exp0"), "exp_folder = %s" % exp)
+    cfg = tmp_path / "dp_nan.config"
+    cfg.write_text(text)
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, AVSI_DIST_BACKEND='gloo', HSA_ENABLE_IPC_MODE_LEGACY='0', AVSI_COOP_CUS='128', AVSI_TEST_NAN_RANK='1')
+    here = os.path.dirname(os.path.abspath(__file__))
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+           '--master-port', str(port), os.path.join(here, 'dp_train_worker.py'), str(cfg)]
+    run = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert run.returncode != 0
+    assert 'GOT INSTABILITY: loss is NaN. Leaving...' in run.stdout
+    assert 'GOT INSTABILITY on another rank: loss is not finite there. Leaving...' in run.stdout
+    assert (tmp_path / "exit_rank0").read_text() == "1" and (tmp_path / "exit_rank1").read_text() == "1"
