@@ -170,7 +170,11 @@ class _Uploader(object):
         torch = self.torch
         if self.stream is None:
             torch.cuda.set_device(self.device)
-            self.stream = torch.cuda.Stream(device=self.device)
+            # high priority: HIP maps its streams onto four hardware queues per priority level, and a normal stream created
+            # after the model's side streams can land on the queue of the launch stream, where the upload and its event
+            # would sit in order between the step's kernels (tools/hostfed_probe.py: a 3.7 GB upload then adds its full
+            # 67 ms to a 140 ms step instead of hiding under it); queues of another priority level are not shared
+            self.stream = torch.cuda.Stream(device=self.device, priority=-1)
         out = Batch(batch)
         out.device_arrays = {}
         if isinstance(batch[-1], np.ndarray) and batch[-1].dtype != object:

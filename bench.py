@@ -298,7 +298,7 @@ def av_batch(torch, n, seed, device):
     return wav, masks, torch.randn(n, T_FRAMES, 136, generator=g, device=device)
 
 
-def dp_train_block(torch, dist, models, ops, cfg, mean, std, device, rank, world):
+def dp_train_block(torch, dist, models, ops, ap_mod, cfg, device, rank, world):
     """configs[3]: AV data-parallel training, gradients all-reduced over RCCL inside the backward pass.
 
     `check` -- three TF-Adam steps on a fixed seeded GLOBAL batch of 32 x world utterances (T = 250, config 4's per-GPU
@@ -317,6 +317,11 @@ def dp_train_block(torch, dist, models, ops, cfg, mean, std, device, rank, world
     from avsi_amd import parallel
     out = {"n_gpus": world, "backend": dist.get_backend() if world > 1 else None,
            "rccl_ranks": dist.get_world_size() if world > 1 else 1}
+
+    # normalisation statistics from a seeded batch that is the same on every rank (the headline's are per-rank data)
+    spec = ap_mod.frontend(synth_batch(torch, 64, 4242, device)[0], want_spec=True)['spec']
+    mean, std = spec.mean(dim=(0, 1)), spec.std(dim=(0, 1), unbiased=False)
+    del spec
 
     def build(n, w, m_, v, seed=11):
         seq = np.full(n, T_FRAMES)
@@ -569,7 +574,11 @@ def extra_workloads(torch, models, ops, ap_mod, cfg, mean, std, device):
         seq = np.full(B, T_FRAMES)
         m = models.StackedBLSTMModel(seq, wav_d, masks_d, mean, std, 0.0, dict(cfg, batch_size=B, rows_per_wg=0, precision='f32'),
                                      input='a', seed=7, is_training=False)
-        copy = torch.cuda.Stream(device=device)
+        # a HIGH-PRIORITY stream: HIP multiplexes its streams onto four hardware queues per priority level, and by now
+        # this process has created enough streams that the next normal one shares the queue of the launch stream -- its
+        # copies and their event waits then sit IN ORDER between the step's kernels and nothing overlaps (measured:
+        # 207 ms instead of 140, tools/hostfed_probe.py); queues of another priority are never shared with it
+        copy = torch.cuda.Stream(device=device, priority=-1)
         main = torch.cuda.current_stream(device)
         state = {"i": 0, "ready": None}
 
@@ -647,6 +656,8 @@ def main():
         # the multi-rank path on a single-GPU box (tests/test_bench_contract_gpu.py)
         backend = os.environ.get("AVSI_DIST_BACKEND", "nccl")
         if backend == "nccl":
+            from avsi_amd import parallel
+            parallel.prefer_high_priority_collectives()
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
@@ -832,7 +843,7 @@ def main():
         torch.cuda.empty_cache()
         try:
             progress["at"] = "dp_train"
-            dp = dp_train_block(torch, dist, models, ops, cfg, mean, std, device, rank, world)
+            dp = dp_train_block(torch, dist, models, ops, ap_mod, cfg, device, rank, world)
         except Exception as e:        # never a reason to lose the headline
             dp = {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
         line["dp_train"] = dp
