@@ -26,6 +26,8 @@
 // The launch needs all S members of a group resident together; groups are contiguous windows of
 // 8 S block ids and the kernel uses one workgroup per CU, so in-order dispatch guarantees that for
 // any grid (and the host only selects this kernel when the whole grid fits the chip anyway).
+#include <stdlib.h>
+
 #include "avsi_common.h"
 
 namespace {
@@ -51,6 +53,7 @@ struct CoopArgs {
     int tile0;         // first 32-utterance tile of this launch (large batches run in resident-sized chunks)
     float* xch;        // fine kernels: h in exchange layout [T][group][member][32 utterances][units of the member], or null
     int xtile0, xtiles;   // ... of the tiles [xtile0, xtile0 + xtiles) of the CALL (a row-range call covers part of the batch)
+    int coherent;      // AVSI_COOP_COHERENT=1: every load of exchanged bytes at device scope, whatever the invariants allow
 };
 
 __device__ __forceinline__ float sigmoidf_fast(float x) { return __builtin_amdgcn_rcpf(1.f + __expf(-x)); }
@@ -368,10 +371,18 @@ __global__ __launch_bounds__(512, 2) void blstm_rec_fwd_coop_fine_kernel(const C
             if (XCH) {
                 // k group q of this wave = units 32 ks + 8 q ..: block of member (32 ks + 8 q) / UW, offset (8 q) % UW
                 const float* xp = xbase + (size_t)(step - 1) * xgroups * (32 * HP);
+                if (a.coherent) {       // triage switch: the same loads served at the memory side
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int unit0 = 32 * ks + 8 * q;
-                    coherent_load4_issue<true>(af[q], xp + ((unit0 / UW) * 32 + li) * UW + unit0 % UW + 4 * hi, 0);
+                    for (int q = 0; q < 4; ++q) {
+                        const int unit0 = 32 * ks + 8 * q;
+                        coherent_load4_issue<false>(af[q], xp + ((unit0 / UW) * 32 + li) * UW + unit0 % UW + 4 * hi, 0);
+                    }
+                } else {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int unit0 = 32 * ks + 8 * q;
+                        coherent_load4_issue<true>(af[q], xp + ((unit0 / UW) * 32 + li) * UW + unit0 % UW + 4 * hi, 0);
+                    }
                 }
             } else {
                 const float* hp = a.hout + ((size_t)tprev * Bp + b0 + li) * (2 * HP) + dir * HP + 4 * hi;
@@ -489,6 +500,15 @@ extern "C" size_t avsi_blstm_rec_bwd_coop_exchange_bytes(int T, int Bp) {
     return (T > 0 && Bp > 0) ? (size_t)T * (size_t)Bp * (2 * 4 * HP) * sizeof(float) : 0;
 }
 
+// AVSI_COOP_COHERENT=1 (read at every call): the one switch that takes EVERY cooperative exchange back to device-scope
+// loads -- the kernels that read exchanged bytes with cacheable loads under an invariant (4- / 8-way BPTT: dz lines
+// written once before their counter moves and touched by nobody earlier; fine kernels: the exchange layout) then use
+// `sc0 sc1` loads like the rest.  For triage: a result that changes with this switch is a stale-line bug.
+static int coop_coherent() {
+    const char* e = getenv("AVSI_COOP_COHERENT");
+    return e && e[0] == '1';
+}
+
 // Tiles per launch: the whole launch must be resident (one workgroup per CU) on the `max_cus` compute units the
 // caller grants it (<= 0: the chip).  A process that keeps other kernels in flight beside the recurrence -- RCCL
 // collectives under data parallelism, independent batches on other streams -- leaves those CUs out: peers of a
@@ -526,7 +546,7 @@ extern "C" int avsi_blstm_rec_fwd_coop_rows_f32(const float* xproj, const float*
     if (xch && avsi_blstm_rec_fwd_coop_workspace_bytes(Bp) > AVSI_COOP_EXCHANGE_OFFSET) return AVSI_ERR_WORKSPACE;
     for (int tile0 = tbeg; tile0 < tiles; tile0 += per) {
         const int nt = tiles - tile0 < per ? tiles - tile0 : per;
-        CoopArgs a{xproj, whp, hout, reserve, (unsigned*)workspace, T, Bp, 2 * nt, tile0, xch, tbeg, rows / 32};
+        CoopArgs a{xproj, whp, hout, reserve, (unsigned*)workspace, T, Bp, 2 * nt, tile0, xch, tbeg, rows / 32, coop_coherent()};
         int rc;
         if (split == 32)
             rc = reserve ? launch_coop_fine<1, true>(a, st) : launch_coop_fine<1, false>(a, st);
@@ -568,6 +588,7 @@ struct CoopBwdArgs {
     int T, Bp, ngroups;
     int tile0;
     float* xch;        // fine kernel: dz in exchange layout [step][group x half][member][gate][rows][16 units], or null
+    int coherent;      // AVSI_COOP_COHERENT=1 (see CoopArgs)
 };
 
 constexpr int BPART_FLOATS = 8 * 32 * PSTRIDE;      // [wave][unit][row]
@@ -652,8 +673,13 @@ __global__ __launch_bounds__(512, 2) void blstm_rec_bwd_coop_kernel(const CoopBw
 #pragma unroll
             for (int c0 = 0; c0 < QPW; c0 += 8) {
                 v4f af[8];
+                if (a.coherent) {
 #pragma unroll
-                for (int q = 0; q < 8; ++q) coherent_load4_issue<true>(af[q], zp + 8 * ks * QPW, 32 * (c0 + q));
+                    for (int q = 0; q < 8; ++q) coherent_load4_issue<false>(af[q], zp + 8 * ks * QPW, 32 * (c0 + q));
+                } else {
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) coherent_load4_issue<true>(af[q], zp + 8 * ks * QPW, 32 * (c0 + q));
+                }
                 coherent_wait(af);
 #pragma unroll
                 for (int q = 0; q < 8; ++q) {
@@ -804,11 +830,20 @@ __global__ __launch_bounds__(512, 2) void blstm_rec_bwd_coop_fine_kernel(const C
             if (XCH) {
                 // columns ks * 128 + 16 j + 4 kq ..: block (member 2 ks + (j & 1), gate j >> 1), row l16 (and 16 + l16)
                 const float* xp = xbase + (size_t)(s - 1) * xstep + (size_t)l16 * 16 + 4 * kq;
+                if (a.coherent) {
 #pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const float* bp = xp + (((2 * ks + (j & 1)) * 4 + (j >> 1)) * R) * 16;
-                    coherent_load4_issue<true>(a0[j], bp, 0);
-                    if (NR == 2) coherent_load4_issue<true>(a1[j], bp, 16 * 16 * 4);
+                    for (int j = 0; j < 8; ++j) {
+                        const float* bp = xp + (((2 * ks + (j & 1)) * 4 + (j >> 1)) * R) * 16;
+                        coherent_load4_issue<false>(a0[j], bp, 0);
+                        if (NR == 2) coherent_load4_issue<false>(a1[j], bp, 16 * 16 * 4);
+                    }
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const float* bp = xp + (((2 * ks + (j & 1)) * 4 + (j >> 1)) * R) * 16;
+                        coherent_load4_issue<true>(a0[j], bp, 0);
+                        if (NR == 2) coherent_load4_issue<true>(a1[j], bp, 16 * 16 * 4);
+                    }
                 }
             } else {
 #pragma unroll
@@ -904,7 +939,7 @@ extern "C" int avsi_blstm_rec_bwd_coop_f32(const float* dhout, const float* rese
     const int tiles = Bp / 32, per = coop_tiles_per_launch(split, max_cus);
     for (int tile0 = 0; tile0 < tiles; tile0 += per) {
         const int nt = tiles - tile0 < per ? tiles - tile0 : per;
-        CoopBwdArgs a{dhout, reserve, whbT, dz, (unsigned*)workspace, T, Bp, 2 * nt, tile0, xch};
+        CoopBwdArgs a{dhout, reserve, whbT, dz, (unsigned*)workspace, T, Bp, 2 * nt, tile0, xch, coop_coherent()};
         const int blocks = (int)avsi_ceil_div(2 * nt, AVSI_NUM_XCD) * AVSI_NUM_XCD * split;
         if (split == 32 && xch)     // 16 unit slices x 2 row halves
             hipLaunchKernelGGL((blstm_rec_bwd_coop_fine_kernel<2, true>), dim3(blocks), dim3(512), 96 * 1024, st, a);

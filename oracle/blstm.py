@@ -227,8 +227,9 @@ def enhanced_sources(pred, mean, std, target_stft, masks=None, num_samples=48000
 # --------------------------------------------------------------------------------------
 # backward (manual BPTT; checked against torch.autograd in tests/test_oracle_blstm.py)
 # --------------------------------------------------------------------------------------
-def _lstm_direction_bwd(x, kernel, cache, dh_out):
-    """Gradient of lstm_direction.  dh_out [B, T, H] -> (dx [B,T,D], dkernel, dbias)."""
+def _lstm_direction_bwd(x, kernel, cache, dh_out, return_dz=False):
+    """Gradient of lstm_direction.  dh_out [B, T, H] -> (dx [B,T,D], dkernel, dbias); with return_dz also the gradient
+    of the gate pre-activations, dz [B, T, 4H] (column blocks i, j, f, o) -- what the BPTT kernels write."""
     B, T, D = x.shape
     H = kernel.shape[1] // 4
     dt = x.dtype
@@ -237,6 +238,7 @@ def _lstm_direction_bwd(x, kernel, cache, dh_out):
     db = np.zeros(4 * H, dtype=dt)
     dh_next = np.zeros((B, H), dtype=dt)
     dc_next = np.zeros((B, H), dtype=dt)
+    dz_all = np.zeros((B, T, 4 * H), dtype=dt) if return_dz else None
     for (t, i, j, f, o, c_new, c_prev, h_prev) in reversed(cache):
         dh = dh_out[:, t, :] + dh_next
         tc = np.tanh(c_new)
@@ -248,13 +250,15 @@ def _lstm_direction_bwd(x, kernel, cache, dh_out):
         dc_next = dc * f
         dz = np.concatenate([di * i * (1 - i), dj * (1 - j * j), df * f * (1 - f),
                              do * o * (1 - o)], axis=1)
+        if return_dz:
+            dz_all[:, t, :] = dz
         xin = np.concatenate([x[:, t, :], h_prev], axis=1)
         dk += xin.T @ dz
         db += dz.sum(axis=0)
         dxin = dz @ kernel.T
         dx[:, t, :] = dxin[:, :D]
         dh_next = dxin[:, D:]
-    return dx, dk, db
+    return (dx, dk, db, dz_all) if return_dz else (dx, dk, db)
 
 
 def model_backward(fwd, masks, seq_len, l2=0.0):

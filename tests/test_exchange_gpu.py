@@ -149,3 +149,45 @@ def test_exchange_layout_gives_the_same_bptt_result(Bp, split, monkeypatch):
     ops.blstm_rec_bwd(dh, resv, whbt, ref, split=0)
     scale = float(ref.abs().max())
     np.testing.assert_allclose(outs[0].cpu().numpy(), ref.cpu().numpy(), rtol=0, atol=2e-6 * scale + 1e-7)
+
+
+@pytest.mark.parametrize("Bp,fwd_split,bwd_split", [(32, 32, 32), (128, 32, 32), (256, 16, 16), (288, 8, 8), (544, 4, 4),
+                                                   (64, -16, 8), (1056, -32, 4)])
+def test_coherent_switch_is_bit_identical_on_every_split_kind(Bp, fwd_split, bwd_split, monkeypatch):
+    """AVSI_COOP_COHERENT=1 takes every cooperative exchange back to device-scope (`sc0 sc1`) loads -- the triage switch
+    for the cacheable-load invariants of DESIGN 4.3a.  Same arithmetic in the same order: results must be BIT-identical to
+    the default on every kind of split (exchange-layout fine kernels, 4- / 8-way BPTT with plain loads of dz, column-split)."""
+    import torch
+    import avsi_amd  # noqa: F401
+    from avsi_amd import ops
+    T = 23
+    g = torch.Generator(device='cuda')
+    g.manual_seed(Bp + 5 * abs(fwd_split))
+    xproj = torch.randn(T, Bp, 2048, generator=g, device='cuda')
+    whp = torch.randn(2 * 262144, generator=g, device='cuda') * 0.05
+    dh = torch.randn(T, Bp, 512, generator=g, device='cuda')
+    junk = torch.randn(T, Bp, 2048, generator=g, device='cuda')
+    results = {}
+    for coherent in ('0', '1'):
+        monkeypatch.setenv('AVSI_COOP_COHERENT', coherent)
+        hout = torch.full((T, Bp, 512), 7.0, device='cuda')
+        resv = torch.full((T, Bp, 2, 5, 256), 7.0, device='cuda')
+        dz = torch.full((T, Bp, 2048), 7.0, device='cuda')
+        # other data through the same buffers first: a stale line would show in the second result
+        ops.blstm_rec_fwd(junk, whp, hout, resv, split=fwd_split)
+        ops.blstm_rec_bwd(dh * 3.0, resv, whp, dz, split=bwd_split)
+        ops.blstm_rec_fwd(xproj, whp, hout, resv, split=fwd_split)
+        ops.blstm_rec_bwd(dh, resv, whp, dz, split=bwd_split)
+        ops.coop_check()
+        results[coherent] = (hout.clone(), resv.clone(), dz.clone())
+    for a, b in zip(results['0'], results['1']):
+        assert torch.equal(a, b)
+    # and both agree with the batch-stationary kernels to rounding
+    hout0 = torch.empty(T, Bp, 512, device='cuda')
+    resv0 = torch.empty(T, Bp, 2, 5, 256, device='cuda')
+    dz0 = torch.empty(T, Bp, 2048, device='cuda')
+    ops.blstm_rec_fwd(xproj, whp, hout0, resv0, split=0)
+    ops.blstm_rec_bwd(dh, resv0, whp, dz0, split=0)
+    np.testing.assert_allclose(results['1'][0].cpu().numpy(), hout0.cpu().numpy(), rtol=0, atol=2e-5)
+    scale = float(dz0.abs().max())
+    np.testing.assert_allclose(results['1'][2].cpu().numpy(), dz0.cpu().numpy(), rtol=0, atol=5e-6 * scale)
