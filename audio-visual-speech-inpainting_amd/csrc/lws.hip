@@ -24,6 +24,7 @@
 #include <math.h>
 
 #include "avsi_common.h"
+#include "lws_shared.h"
 
 namespace {
 
@@ -648,6 +649,40 @@ bool geometry_ok(int frame_len, int hop, int nfft) {
 }
 
 }  // namespace
+
+// ---- shared with lws_skew.hip (lws_shared.h)
+void avsi_lws_host_alpha(int frame_len, int hop, int nfft, int L, double alpha[3][AVSI_LWS_NP][2]) {
+    double awin[NF], swin[NF];
+    host_windows(frame_len, hop, nfft, awin, swin);
+    for (int q = -1; q <= 1; ++q)
+        for (int p = -LMAX; p <= LMAX; ++p) {
+            double re = 0.0, im = 0.0;
+            if (p >= -L && p <= L)
+                for (int n = 0; n < nfft; ++n) {
+                    const int s = n - q * hop;
+                    if (s < 0 || s >= nfft) continue;
+                    const double pr = awin[n] * swin[s], ph = 2.0 * M_PI * p * n / nfft;
+                    re += pr * cos(ph), im += pr * sin(ph);
+                }
+            alpha[q + 1][p + LMAX][0] = re / nfft, alpha[q + 1][p + LMAX][1] = im / nfft;
+        }
+}
+bool avsi_lws_geometry_ok(int frame_len, int hop, int nfft) { return geometry_ok(frame_len, hop, nfft); }
+bool avsi_lws_make_schedule(int nofuture_iterations, float nofuture_alpha, int online_iterations, float online_alpha,
+                            int batch_iterations, float batch_alpha, float batch_beta, float batch_gamma, AvsiLwsSchedule& S) {
+    if (nofuture_iterations + online_iterations + batch_iterations > AVSI_LWS_MAX_SWEEPS) return false;
+    S.n = 0;
+    for (int i = 0; i < nofuture_iterations; ++i) S.rel[S.n] = nofuture_alpha, S.past_only[S.n++] = 1;
+    for (int i = 0; i < online_iterations; ++i) S.rel[S.n] = online_alpha, S.past_only[S.n++] = 0;
+    for (int i = 0; i < batch_iterations; ++i)
+        S.rel[S.n] = (float)(batch_alpha * exp(-(double)batch_beta * pow((double)i, (double)batch_gamma))), S.past_only[S.n++] = 0;
+    for (int i = S.n; i < AVSI_LWS_MAX_SWEEPS; ++i) S.rel[i] = 0.f, S.past_only[i] = 0;
+    return true;
+}
+void avsi_lws_launch_stats(const float* spec, int batch, int M, float* stats, hipStream_t st) {
+    hipLaunchKernelGGL(lws_stats_kernel, dim3(batch), dim3(256), 0, st, reinterpret_cast<const float2*>(spec), M,
+                       reinterpret_cast<float2*>(stats));
+}
 
 extern "C" int avsi_lws_num_frames(int num_samples, int hop, int nfft) {
     if (num_samples <= 0 || hop <= 0 || nfft < hop) return 0;

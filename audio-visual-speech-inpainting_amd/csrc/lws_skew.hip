@@ -1,0 +1,451 @@
+// LWS sweeps with the FRAMES of a sweep in the lanes of a wave (skewed-frame pipeline) -- the default kernel behind
+// avsi_lws_run_skew_f32, the phase refinement of the reference's `infer` (inference.py:119,141-154; see lws.hip for the
+// algorithm, the conventions and the transforms around it).
+//
+// A sweep updates S[m, k] <- A[m, k] t / |t| in raster order IN PLACE, t = sum over rows m-1, m, m+1 and |p| <= 5 bins.
+// Bin (m, k) needs (m-1, k+5) and (m, k-1) of THIS sweep and (m, k+5), (m+1, k+5) of the sweep before, nothing else:
+//   * frame m may run LMAX + 1 = 6 bins behind frame m-1            -> the 64 lanes of a wave work on 64 consecutive frames,
+//     lane j at bin k = t - 6 m at step t (lane = m mod 64; a lane is busy 257 + margins of every 384 steps);
+//   * sweep s may run a few dozen steps behind sweep s-1            -> the sweeps of an utterance are a pipeline of waves.
+// lws_sweeps_kernel (lws.hip) ran the in-frame recurrence on ONE lane (four with four utterances per wave): 60 of 64
+// lanes idle, 16 us per frame whatever else happened.  Here every lane runs a recurrence.
+//
+// What a lane keeps (all in registers, rings of 12 indexed by step mod 12, so every index is a compile-time constant
+// in the 12-fold unrolled step loop):
+//   R  its own row's values from the sweep before ("old"), positions k .. k+11, streamed from memory 12 steps ahead;
+//   P  its own row's values of this sweep ("new"), positions k-1 .. k-12.
+// Per step it forms three sums over ITS OWN rings and hands two of them to its neighbours with one DPP rotate each:
+//   own  = sum_{p=1..5} a_0(p) R[k+p] + a_0(-p) P[k-p]                  (10 taps, its own bin)
+//   up   = sum_p b_{+1}(p) R[k+6+p]   for lane j-1, whose bin is k+6     (row m+1 of that lane: still the old values)
+//   down = sum_p b_{-1}(p) P[k-6+p]   for lane j+1, whose bin is k-6     (row m-1 of that lane: already the new values)
+//   t = own + c(k) . up(from j+1) + conj c(k) . down(from j-1),          c(k) = e^{-2 pi j k R / N},
+//   b_q(p) = alpha_q(p) c_q(p): the consistency phase factor e^{-2 pi j (k+p) q R / N} splits into a constant weight and
+//   one per-bin rotation.  The loop-carried chain per step is one complex MAC (the newest tap), the rotate, the norm,
+//   a reciprocal square root and two multiplies; the other ~30 MACs are independent of it.
+// Conjugate-mirror bins (k < 0, k > 256) are positions of the same rings: the five below DC are written when their
+// source arrives / changes (predicated register moves), the five above Nyquist are stored in the layout like bins.
+//
+// Memory layout ("diagonal-major"): element (m, x), x in [-5, 261], lives in row x + 6 m + 5, column m mod 64 of a
+// [rows][64] complex array per utterance -- at step t EVERY lane loads row t + 16 + 12 (its own position k + 11, twelve
+// steps ahead) and stores row t + 5 (its own bin): two 512-byte rows per step, nothing strided.  Magnitudes (constant
+// through all sweeps, as in oracle/lws.py) sit in a float array of the same shape.
+//
+// Pipeline of sweeps: a workgroup is NW waves = NW consecutive (active) sweeps of ONE utterance, G workgroups chain up
+// per utterance (G * NW stages; the a-th active sweep runs on stage a mod stages).  A stage publishes "bodies (12 steps)
+// finished and visible" -- in LDS for the next wave of its workgroup, which reads the rows back through the CU's own L1
+// (coherent within a workgroup), in global memory (device-scope stores / loads) where the next stage sits in another
+// workgroup or is wave 0 of the next round.  A stage starts a body when its predecessor has published four bodies more.
+// All stages of an utterance must be resident together (bounded waits, status word).
+#include <math.h>
+
+#include <utility>
+
+#include "avsi_common.h"
+#include "lws_shared.h"
+
+namespace {
+
+constexpr int KB = AVSI_LWS_KB, LMAX = AVSI_LWS_LMAX, NP = AVSI_LWS_NP, MAX_SWEEPS = AVSI_LWS_MAX_SWEEPS;
+constexpr int SKEW = LMAX + 1;             // bins a frame runs behind the frame before it
+constexpr int LANES = 64;
+constexpr int PERIOD = SKEW * LANES;       // 384 steps between two frames of a lane
+constexpr int UNR = 12;                    // steps per unrolled body = ring length = prefetch distance
+constexpr int T0 = -24;                    // time of step 0 (a multiple of 12 and of 6)
+constexpr int ROW_OFF = 5;                 // row of (frame m, position x) = x + 6 m + ROW_OFF
+constexpr int TAU_LAST = 2 * (KB - 1) - (KB - 1 - LMAX) + 0;   // 261: last mirror position above Nyquist
+constexpr int NONE = -100000;
+static_assert(TAU_LAST == 261 && KB == 257 && SKEW == 6, "the edge rules below are written out for 257 bins, L = 5");
+static_assert(LANES * SKEW >= TAU_LAST + 1 + 24, "a lane must be done with a frame (and its prefetch) before the next one starts");
+
+struct SkewConst {          // kernel argument: the compiler keeps what it needs in SGPRs
+    float bu[NP][2];        // b_{+1}(p), p = -5 .. 5
+    float bd[NP][2];        // b_{-1}(p)
+    float b0[NP][2];        // alpha_0(p) (the centre tap is not used)
+    int phase_step;         // 64 R / N: c(k) = e^{-2 pi j k phase_step / 64}
+};
+
+// rows of the diagonal layout for M frames (a multiple of UNR; the tail covers the look-ahead of the last steps)
+__host__ __device__ constexpr int skew_rows(int M) { return ((SKEW * (M - 1) + TAU_LAST + ROW_OFF + 1 + 2 * UNR + 16 + UNR - 1) / UNR) * UNR; }
+__host__ __device__ constexpr int skew_steps(int M) { return SKEW * (M - 1) + TAU_LAST - T0 + 1; }
+
+__device__ __forceinline__ float2 cmadd(float2 acc, float wr, float wi, float2 x) {
+    return make_float2(fmaf(wr, x.x, fmaf(-wi, x.y, acc.x)), fmaf(wr, x.y, fmaf(wi, x.x, acc.y)));
+}
+__device__ __forceinline__ float2 conjf2(float2 v) { return make_float2(v.x, -v.y); }
+__device__ __forceinline__ float2 sel(bool c, float2 a, float2 b) { return make_float2(c ? a.x : b.x, c ? a.y : b.y); }
+__device__ __forceinline__ float dpp_from_prev(float v) {      // lane j gets lane j - 1 (lane 0 gets lane 63)
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x13C, 0xf, 0xf, false));   // wave_ror:1
+}
+__device__ __forceinline__ float dpp_from_next(float v) {      // lane j gets lane j + 1 (lane 63 gets lane 0)
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x134, 0xf, 0xf, false));   // wave_rol:1
+}
+
+// The memory operations of the step loop are inline asm: exactly three per step and lane (two loads, one store), in a
+// fixed order, so that "the loads issued twelve steps ago have landed" is ONE counted wait (s_waitcnt vmcnt(34): 34
+// younger operations may still be in flight) -- the compiler's own bookkeeping gives up at vmcnt(0) once stores sit
+// between a load and its use, which would expose a memory round trip per step.
+// a pointer that is wave-uniform by construction, as SGPRs whatever the register allocator made of it ("s" operands below).
+// The v_readfirstlane it may cost writes SGPRs that the very next instruction -- inside the asm, invisible to the
+// compiler's hazard recogniser -- reads as an address: "VALU writes SGPR -> VMEM reads it" needs five wait states, hence
+// the `s_nop 4` in front of every memory instruction below (without it the instruction used the PREVIOUS pointer).
+template <class T>
+__device__ __forceinline__ T* uniform_ptr(T* p) {
+    const unsigned long long v = (unsigned long long)p;
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+    return (T*)(((unsigned long long)hi << 32) | lo);
+}
+__device__ __forceinline__ void row_load8(bool DEV, float2& dst, const float2* row, unsigned lane_off) {      // DEV: wave-uniform
+    row = uniform_ptr(row);
+    if (DEV) asm volatile("s_nop 4\n\tglobal_load_dwordx2 %0, %1, %2 sc0 sc1" : "=v"(dst) : "v"(lane_off), "s"(row) : "memory");
+    else asm volatile("s_nop 4\n\tglobal_load_dwordx2 %0, %1, %2" : "=v"(dst) : "v"(lane_off), "s"(row) : "memory");
+}
+__device__ __forceinline__ void row_load4(float& dst, const float* row, unsigned lane_off) {
+    row = uniform_ptr(row);
+    asm volatile("s_nop 4\n\tglobal_load_dword %0, %1, %2" : "=v"(dst) : "v"(lane_off), "s"(row) : "memory");
+}
+__device__ __forceinline__ void row_store8(bool DEV, float2* row, unsigned lane_off, float2 v) {
+    row = uniform_ptr(row);
+    if (DEV) asm volatile("s_nop 4\n\tglobal_store_dwordx2 %0, %1, %2 sc0 sc1\n\ts_nop 1" ::"v"(lane_off), "v"(v), "s"(row) : "memory");
+    else asm volatile("s_nop 4\n\tglobal_store_dwordx2 %0, %1, %2\n\ts_nop 1" ::"v"(lane_off), "v"(v), "s"(row) : "memory");
+}
+
+// the value c in [lo, hi] (hi - lo < 6) that a lane's local time tau can take in copy I of the unrolled body, or NONE:
+// tau = t - 6 m and t = T0 + 12 body + I, so tau = I (mod 6) in copy I -- one candidate per edge rule and copy, which makes
+// every edge rule "compare tau with a constant, then move between two registers known at compile time"
+constexpr int cand(int I, int lo, int hi) {
+    for (int c = lo; c <= hi; ++c)
+        if (((c - I) % 6 + 6) % 6 == 0) return c;
+    return NONE;
+}
+constexpr int ring(int i) { return ((i % UNR) + UNR) % UNR; }
+
+struct LaneState {
+    float2 R[UNR], P[UNR], Lb[UNR];
+    float Ab[UNR];
+    int tau, m;
+};
+
+struct StepCtx {
+    const float2* Dg;       // this utterance's [rows][64] complex array
+    const float* Ag;        // ... and its magnitudes
+    float2* Dw;
+    const float2* ctab;     // LDS: c(k), k mod 64
+    int M, trash_row;
+    float thr;
+    bool past_only;
+    bool dev_in, dev_out;   // wave-uniform: device-scope loads (the stage before sits in another workgroup) / stores (the stage after)
+    unsigned lane8, lane4;
+};
+
+template <int I>
+__device__ __forceinline__ void skew_step(LaneState& L, const StepCtx& C, const SkewConst& W, int n) {
+    const int t = T0 + n;                                  // wave-uniform
+    // ---- the operands requested twelve steps ago
+    // (the wait takes the landing registers as operands: nothing may read them, or give them to another value, before it)
+    asm volatile("s_waitcnt vmcnt(34)" : "+v"(L.Lb[I].x), "+v"(L.Lb[I].y), "+v"(L.Ab[I])::"memory");
+    const float2 arr = L.Lb[I];
+    const float amp = L.Ab[I];
+    row_load8(C.dev_in, L.Lb[I], C.Dg + (size_t)(t + UNR + 16) * LANES, C.lane8);     // position tau + 11 of step n + 12
+    row_load4(L.Ab[I], C.Ag + (size_t)(t + UNR + ROW_OFF > 0 ? t + UNR + ROW_OFF : 0) * LANES, C.lane4);   // magnitude of the bin of step n + 12
+    const int tau = L.tau, m = L.m;
+    L.R[I] = arr;                                                                      // position tau + 11
+    {   // positions 1 .. 5 of a row also define its mirror images -1 .. -5, which "arrived" 2 x steps earlier
+        constexpr int x = cand(I + 11, 1, 5);
+        if (x != NONE) L.R[ring(I - 2 * x)] = sel(tau + 11 == x, conjf2(arr), L.R[ring(I - 2 * x)]);
+    }
+    // ---- three sums over this lane's own rings (newest elements last: they end the dependence chain)
+    float2 up = make_float2(0.f, 0.f), dn = up, own = up;
+#pragma unroll
+    for (int p = -LMAX; p <= LMAX; ++p) up = cmadd(up, W.bu[p + LMAX][0], W.bu[p + LMAX][1], L.R[ring(I - LMAX + p)]);
+#pragma unroll
+    for (int p = 1; p <= LMAX; ++p) own = cmadd(own, W.b0[LMAX + p][0], W.b0[LMAX + p][1], L.R[ring(I - 11 + p)]);
+#pragma unroll
+    for (int p = -LMAX; p <= LMAX; ++p) dn = cmadd(dn, W.bd[p + LMAX][0], W.bd[p + LMAX][1], L.P[ring(I - (SKEW - p))]);
+#pragma unroll
+    for (int p = LMAX; p >= 1; --p) own = cmadd(own, W.b0[LMAX - p][0], W.b0[LMAX - p][1], L.P[ring(I - p)]);
+    // ---- exchange: the row below (old values) from lane j + 1, the row above (new values) from lane j - 1
+    float2 upr = make_float2(dpp_from_next(up.x), dpp_from_next(up.y));
+    float2 dnr = make_float2(dpp_from_prev(dn.x), dpp_from_prev(dn.y));
+    const float2 c = C.ctab[tau & 63];
+    const bool has_next = m + 1 < C.M && !C.past_only, has_prev = m >= 1;
+    upr = sel(has_next, upr, make_float2(0.f, 0.f));
+    dnr = sel(has_prev, dnr, make_float2(0.f, 0.f));
+    if (C.past_only) own = make_float2(0.f, 0.f);
+    float2 T = own;
+    T.x = fmaf(c.x, upr.x, fmaf(-c.y, upr.y, T.x)), T.y = fmaf(c.x, upr.y, fmaf(c.y, upr.x, T.y));          // c . up
+    T.x = fmaf(c.x, dnr.x, fmaf(c.y, dnr.y, T.x)), T.y = fmaf(c.x, dnr.y, fmaf(-c.y, dnr.x, T.y));          // conj(c) . down
+    const float n2 = T.x * T.x + T.y * T.y;
+    const bool valid = tau >= 0 && tau <= KB - 1 && m < C.M;
+    const bool upd = valid && amp > C.thr && n2 > 0.f;
+    const float sc = amp * __builtin_amdgcn_rsqf(n2);
+    const float2 old = L.R[ring(I - 11)];                                              // position tau
+    const float2 v = sel(upd, make_float2(T.x * sc, T.y * sc), old);
+    // ---- what this lane hands on for position tau: the bin, or a mirror image
+    float2 out = v;
+    {   // below DC (tau in [-5, -1]): conj of the old bins 5 .. 1, the start values of the "new" ring
+        constexpr int tc = cand(I, -LMAX, -1);
+        if (tc != NONE) out = sel(tau == tc, conjf2(L.R[ring(I - (11 + 2 * tc))]), out);
+    }
+    {   // above Nyquist (tau in [257, 261]): conj of the NEW bins 255 .. 251
+        constexpr int tc = cand(I, KB, TAU_LAST);
+        if (tc != NONE) out = sel(tau == tc, conjf2(L.P[ring(I - (2 * tc - 2 * (KB - 1)))]), out);
+    }
+    L.P[I] = out;
+    {   // bins 1 .. 5 refresh their mirror images below DC (2 x steps back in the "new" ring) ...
+        constexpr int x = cand(I, 1, LMAX);
+        if (x != NONE) L.P[ring(I - 2 * x)] = sel(tau == x, conjf2(v), L.P[ring(I - 2 * x)]);
+    }
+    {   // ... and bins 251 .. 255 theirs above Nyquist (positions 512 - tau of the "old" ring, still ahead of this lane)
+        constexpr int tc = cand(I, KB - 1 - LMAX, KB - 2);
+        if (tc != NONE) {
+            constexpr int d = 11 - (2 * (KB - 1) - 2 * tc);            // slots back from the newest arrival
+            L.R[ring(I - d)] = sel(tau == tc, conjf2(v), L.R[ring(I - d)]);
+        }
+    }
+    // ---- store (row t + 5, every lane, always: lanes with nothing to store write a scratch row)
+    const bool st = tau >= 0 && tau <= TAU_LAST && m < C.M;
+    float2* rp = C.Dw + (int64_t)(t + ROW_OFF) * LANES;          // (before the array while t + 5 < 0: no lane stores there)
+    const unsigned off = st ? C.lane8 : C.lane8 + (unsigned)((C.trash_row - (t + ROW_OFF)) * (int)(LANES * sizeof(float2)));
+    row_store8(C.dev_out, rp, off, out);
+    // ---- next step of this lane
+    const int nt = tau + 1;
+    const bool wrap = nt > TAU_LAST;
+    L.tau = wrap ? nt - PERIOD : nt;
+    L.m = wrap ? m + LANES : m;
+    __builtin_amdgcn_sched_barrier(0);          // steps are not interleaved: their live ranges would add up
+}
+
+template <int... Is>
+__device__ __forceinline__ void skew_body(LaneState& L, const StepCtx& C, const SkewConst& W, int n0, std::integer_sequence<int, Is...>) {
+    (skew_step<Is>(L, C, W, n0 + Is), ...);
+}
+
+// NW waves per workgroup = NW pipeline stages of one utterance; G workgroups per utterance
+template <int NW>
+__global__ __launch_bounds__(64 * NW) void lws_skew_kernel(float2* __restrict__ Dall, const float* __restrict__ Aall, int B, int M,
+                                                          const SkewConst W, const AvsiLwsSchedule sched, int* __restrict__ status,
+                                                          const float2* __restrict__ stats, int* __restrict__ gprog_all, int G) {
+    __shared__ float2 ctab[64];
+    __shared__ int prog[NW];                    // bodies finished and visible, per stage of this workgroup (monotone)
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;      // wv: wave-uniform, and known to be
+    const int b = blockIdx.x / G, wg = blockIdx.x - b * G;
+    const int stage = wg * NW + wv, stages = G * NW;
+    const int rows = skew_rows(M);
+    const int nb = (skew_steps(M) + UNR - 1) / UNR;           // bodies per sweep
+    const int nbp = nb + 8;                                   // counter values per sweep of a stage
+    int* gprog = gprog_all + (size_t)b * MAX_SWEEPS;          // one counter per stage (stages <= MAX_SWEEPS)
+    volatile int* vprog = prog;
+    if (threadIdx.x < 64) {
+        float sn, cs;
+        sincospif(-2.f * (float)((threadIdx.x * W.phase_step) & 63) / 64.f, &sn, &cs);
+        ctab[threadIdx.x] = make_float2(cs, sn);
+    }
+    if (threadIdx.x < NW) prog[threadIdx.x] = 0;
+    __syncthreads();
+    const float2 st = stats[b];
+    const float mean = st.x, amax = st.y;
+    StepCtx C;
+    C.Dg = Dall + (size_t)b * rows * LANES;
+    C.Dw = Dall + (size_t)b * rows * LANES;
+    C.Ag = Aall + (size_t)b * rows * LANES;
+    C.ctab = ctab;
+    C.M = M;
+    C.trash_row = rows - 1;
+    C.lane8 = lane * 8u, C.lane4 = lane * 4u;
+    const bool dev_in = wv == 0, dev_out = wv == NW - 1;       // the stage before / after sits in another workgroup (or round)
+    C.dev_in = dev_in, C.dev_out = dev_out;
+    bool dead = false;
+    int known = 0;            // last value read from the predecessor's counter
+    int mine = 0;             // sweeps this stage has finished
+
+    int rank_a = -1, last_active = -1;
+    for (int sw = 0; sw < sched.n; ++sw) {
+        const float thr = sched.rel[sw] * mean;
+        if (!(amax > thr)) continue;              // an idle sweep changes nothing and needs no stage
+        const int pred = last_active;
+        last_active = sw, ++rank_a;
+        if (rank_a % stages != stage) continue;
+        C.thr = thr;
+        C.past_only = sched.past_only[sw] != 0;
+        const int pstage = pred < 0 ? -1 : (rank_a - 1) % stages;
+        const int pbase = pred < 0 ? 0 : ((rank_a - 1) / stages) * nbp;       // counter value at the start of the predecessor's sweep
+        const int base = mine * nbp;
+        LaneState L;
+#pragma unroll
+        for (int i = 0; i < UNR; ++i) L.R[i] = L.P[i] = L.Lb[i] = make_float2(0.f, 0.f), L.Ab[i] = 0.f;
+        L.m = lane;
+        L.tau = T0 - SKEW * lane;
+        // a stage whose predecessor sits in another workgroup polls device memory, which drains the loads in flight: it
+        // asks for eight bodies more than it needs and then runs eight bodies on what it knows
+        auto wait_pred = [&](int body) {
+            if (pstage < 0 || dead) return;
+            const int need = pbase + (body + 4 < nb + 3 ? body + 4 : nb + 3);
+            if (known >= need) return;
+            const int want = dev_in ? (need + 8 < pbase + nb + 3 ? need + 8 : pbase + nb + 3) : need;
+            int spins = 0;
+            for (;;) {
+                known = dev_in ? __hip_atomic_load(gprog + pstage, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : vprog[wv - 1];
+                known = __builtin_amdgcn_readfirstlane(known);
+                if (known >= want) break;
+                __builtin_amdgcn_s_sleep(4);
+                if (++spins > (1 << 22)) {
+                    dead = true;
+                    if (lane == 0 && status) atomicOr(status, 1);
+                    break;
+                }
+            }
+        };
+        auto publish = [&](int value) {
+            if (lane == 0) {
+                vprog[wv] = value;
+                if (dev_out) __hip_atomic_store(gprog + stage, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        };
+        // prefetch of the first body: rows of steps 0 .. 11 (nothing of them is used before position 1 arrives)
+        wait_pred(0);
+#pragma unroll
+        for (int i = 0; i < UNR; ++i) {
+            row_load8(dev_in, L.Lb[i], C.Dg + (size_t)(T0 + i + 16 > 0 ? T0 + i + 16 : 0) * LANES, C.lane8);     // (rows < 0: positions nobody reads)
+            row_load4(L.Ab[i], C.Ag + (size_t)(T0 + i + ROW_OFF > 0 ? T0 + i + ROW_OFF : 0) * LANES, C.lane4);
+            // keep the count of the step loop: a store per step (scratch row)
+            row_store8(false, C.Dw + (size_t)C.trash_row * LANES, C.lane8, make_float2(0.f, 0.f));
+        }
+        for (int body = 0; body < nb; ++body) {
+            wait_pred(body);
+            const int n0 = body * UNR;
+            skew_body(L, C, W, n0, std::make_integer_sequence<int, UNR>{});
+            // the stores of the body BEFORE this one are complete once at most this body's 36 operations are in flight
+            asm volatile("s_waitcnt vmcnt(36)" ::: "memory");
+            publish(base + body);
+        }
+        // the loads of the last body land in registers nobody reads any more: they stay reserved until they have landed
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int i = 0; i < UNR; ++i) asm volatile("" : "+v"(L.Lb[i].x), "+v"(L.Lb[i].y), "+v"(L.Ab[i]));
+        publish(base + nb + 3);
+        ++mine;
+    }
+}
+
+// spec [B][M][257] -> diagonal layout (bins, the five mirror positions above Nyquist, magnitudes); everything else zero
+__global__ __launch_bounds__(256) void lws_to_diag_kernel(const float2* __restrict__ spec, int M, int rows, float2* __restrict__ D,
+                                                         float* __restrict__ A) {
+    const int b = blockIdx.y, l = threadIdx.x & 63;
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= rows) return;
+    const int x0 = r - ROW_OFF - SKEW * l;                    // position if the frame were l
+    float2 v = make_float2(0.f, 0.f);
+    float a = 0.f;
+    if (x0 >= 0) {
+        const int rnd = x0 / PERIOD, x = x0 - rnd * PERIOD, m = rnd * LANES + l;
+        if (x <= TAU_LAST && m < M) {
+            const float2* sp = spec + ((int64_t)b * M + m) * KB;
+            if (x < KB) {
+                v = sp[x];
+                a = sqrtf(v.x * v.x + v.y * v.y);
+            } else {
+                v = conjf2(sp[2 * (KB - 1) - x]);
+            }
+        }
+    }
+    D[((int64_t)b * rows + r) * LANES + l] = v;
+    A[((int64_t)b * rows + r) * LANES + l] = a;
+}
+
+__global__ __launch_bounds__(256) void lws_from_diag_kernel(const float2* __restrict__ D, int M, int rows, float2* __restrict__ spec) {
+    const int b = blockIdx.y, l = threadIdx.x & 63;
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= rows) return;
+    const int x0 = r - ROW_OFF - SKEW * l;
+    if (x0 < 0) return;
+    const int rnd = x0 / PERIOD, x = x0 - rnd * PERIOD, m = rnd * LANES + l;
+    if (x < KB && m < M) spec[((int64_t)b * M + m) * KB + x] = D[((int64_t)b * rows + r) * LANES + l];
+}
+
+size_t align256(size_t n) { return (n + 255) & ~(size_t)255; }
+
+}  // namespace
+
+// word 0: status; (mean, max) per utterance; one row of stage counters per utterance; the diagonal arrays
+extern "C" size_t avsi_lws_run_skew_workspace_bytes(int batch, int num_frames) {
+    if (batch <= 0 || num_frames <= 0) return 0;
+    const size_t cells = (size_t)batch * skew_rows(num_frames) * LANES;
+    return align256(16 + (size_t)batch * sizeof(float2)) + align256((size_t)batch * MAX_SWEEPS * sizeof(int)) +
+           align256(cells * sizeof(float2)) + align256(cells * sizeof(float));
+}
+
+extern "C" int avsi_lws_run_skew_f32(float* spec, int batch, int num_frames, int frame_len, int hop, int nfft, int L,
+                                     int nofuture_iterations, float nofuture_alpha, int online_iterations, float online_alpha,
+                                     int batch_iterations, float batch_alpha, float batch_beta, float batch_gamma,
+                                     int waves_per_group, int groups_per_utterance, void* workspace, size_t workspace_bytes,
+                                     void* stream) {
+    if (!spec || batch <= 0 || num_frames <= 0 || L < 1 || nofuture_iterations < 0 || online_iterations < 0 ||
+        batch_iterations < 0)
+        return AVSI_ERR_INVALID_ARG;
+    AvsiLwsSchedule S;
+    if (!avsi_lws_geometry_ok(frame_len, hop, nfft) || L > LMAX ||
+        !avsi_lws_make_schedule(nofuture_iterations, nofuture_alpha, online_iterations, online_alpha, batch_iterations,
+                                batch_alpha, batch_beta, batch_gamma, S))
+        return AVSI_ERR_UNSUPPORTED;
+    if (S.n == 0) return AVSI_OK;
+    if (!workspace || workspace_bytes < avsi_lws_run_skew_workspace_bytes(batch, num_frames)) return AVSI_ERR_WORKSPACE;
+    // b_q(p) = alpha_q(p) e^{-2 pi j p q R / N}
+    double alpha[3][NP][2];
+    avsi_lws_host_alpha(frame_len, hop, nfft, L, alpha);
+    SkewConst W;
+    for (int p = -LMAX; p <= LMAX; ++p) {
+        const double ph = -2.0 * M_PI * p * hop / nfft, cs = cos(ph), sn = sin(ph);
+        const double *au = alpha[2][p + LMAX], *ad = alpha[0][p + LMAX], *a0 = alpha[1][p + LMAX];
+        W.bu[p + LMAX][0] = (float)(au[0] * cs - au[1] * sn), W.bu[p + LMAX][1] = (float)(au[0] * sn + au[1] * cs);
+        W.bd[p + LMAX][0] = (float)(ad[0] * cs + ad[1] * sn), W.bd[p + LMAX][1] = (float)(-ad[0] * sn + ad[1] * cs);
+        W.b0[p + LMAX][0] = (float)a0[0], W.b0[p + LMAX][1] = (float)a0[1];
+    }
+    W.phase_step = 64 * hop / nfft;
+    // Launch shape: NW stages per workgroup, G workgroups per utterance, all resident together.  A workgroup of 16 waves
+    // fills a CU (four waves per SIMD); small batches spread the ~100 sweeps of an utterance over as many workgroups as
+    // the chip has room for, large batches run one workgroup per utterance and several rounds of sweeps on it.
+    int NW = waves_per_group ? waves_per_group : 16;
+    if (NW != 4 && NW != 8 && NW != 16) return AVSI_ERR_INVALID_ARG;
+    int G = groups_per_utterance;
+    if (G == 0) {
+        const int useful = (S.n + NW - 1) / NW;
+        G = batch <= AVSI_NUM_CU ? AVSI_NUM_CU / batch : 1;
+        G = G < 1 ? 1 : (G > useful ? useful : G);
+    }
+    if (G < 1 || G * NW > MAX_SWEEPS) return AVSI_ERR_INVALID_ARG;
+    const hipStream_t st = (hipStream_t)stream;
+    const int rows = skew_rows(num_frames);
+    char* ws = static_cast<char*>(workspace);
+    int* status = reinterpret_cast<int*>(ws);
+    float2* stats = reinterpret_cast<float2*>(ws + 16);
+    size_t off = align256(16 + (size_t)batch * sizeof(float2));
+    int* gprog = reinterpret_cast<int*>(ws + off);
+    off += align256((size_t)batch * MAX_SWEEPS * sizeof(int));
+    float2* D = reinterpret_cast<float2*>(ws + off);
+    off += align256((size_t)batch * rows * LANES * sizeof(float2));
+    float* A = reinterpret_cast<float*>(ws + off);
+    if (hipMemsetAsync(workspace, 0, align256(16 + (size_t)batch * sizeof(float2)) + align256((size_t)batch * MAX_SWEEPS * sizeof(int)),
+                       st) != hipSuccess)
+        return AVSI_ERR_LAUNCH;
+    avsi_clear_error();
+    avsi_lws_launch_stats(spec, batch, num_frames, reinterpret_cast<float*>(stats), st);
+    // every workgroup of a launch must be resident (its stages wait for each other): batches beyond the chip's capacity
+    // run as consecutive launches
+    const int per_launch = AVSI_NUM_CU / G > 0 ? AVSI_NUM_CU / G : 1;
+    for (int b0 = 0; b0 < batch; b0 += per_launch) {
+        const int nbatch = batch - b0 < per_launch ? batch - b0 : per_launch;
+        float2* sp = reinterpret_cast<float2*>(spec) + (size_t)b0 * num_frames * KB;
+        float2* Db = D + (size_t)b0 * rows * LANES;
+        float* Ab = A + (size_t)b0 * rows * LANES;
+        hipLaunchKernelGGL(lws_to_diag_kernel, dim3((rows + 3) / 4, nbatch), dim3(256), 0, st, sp, num_frames, rows, Db, Ab);
+#define AVSI_SKEW_LAUNCH(NWV)                                                                                              \
+    hipLaunchKernelGGL((lws_skew_kernel<NWV>), dim3(nbatch* G), dim3(64 * (NWV)), 0, st, Db, Ab, nbatch, num_frames, W, S, status, \
+                       stats + b0, gprog + (size_t)b0 * MAX_SWEEPS, G)
+        if (NW == 16) AVSI_SKEW_LAUNCH(16);
+        else if (NW == 8) AVSI_SKEW_LAUNCH(8);
+        else AVSI_SKEW_LAUNCH(4);
+#undef AVSI_SKEW_LAUNCH
+        hipLaunchKernelGGL(lws_from_diag_kernel, dim3((rows + 3) / 4, nbatch), dim3(256), 0, st, Db, num_frames, rows, sp);
+    }
+    return avsi_launch_status();
+}

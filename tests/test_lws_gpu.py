@@ -40,12 +40,16 @@ def test_stft_and_istft_match_oracle(L):
     assert single.shape == S.shape[1:] and np.array_equal(single, S[0])
 
 
-@pytest.mark.parametrize("U", [1, 2, 4])
-def test_run_lws_matches_oracle(L, U):
+@pytest.mark.parametrize("shape", [dict(utterances_per_wave=1), dict(utterances_per_wave=2), dict(utterances_per_wave=4),
+                                   dict(kernel='skew'), dict(kernel='skew', waves_per_group=4, groups_per_utterance=1),
+                                   dict(kernel='skew', waves_per_group=8, groups_per_utterance=2),
+                                   dict(kernel='skew', waves_per_group=16, groups_per_utterance=1)])
+def test_run_lws_matches_oracle(L, shape):
     """Same sweeps (one 'no future', one online, 12 batch iterations with a fast-decaying threshold so that every
-    bin is visited) on three utterances with different gaps; U = utterances per wave of the sweeps kernel."""
+    bin is visited) on three utterances with different gaps, through both kernels: the frame-by-frame one (U utterances
+    per wave) and the skewed-frame one (frames in the lanes, csrc/lws_skew.hip; the default)."""
     kw = dict(nofuture_iterations=1, online_iterations=1, batch_iterations=12, batch_alpha=100, batch_beta=0.9)
-    p = L.lws(384, 192, fftsize=512, utterances_per_wave=U, **kw)
+    p = L.lws(384, 192, fftsize=512, **shape, **kw)
     o = OL.LWS(384, 192, fftsize=512, **kw)
     specs = []
     for i, gap in enumerate([(8, 14), (3, 9), (12, 20)]):
@@ -77,6 +81,25 @@ def test_launch_shape_does_not_change_the_result(L):
                      (2, 8, 1), (4, 4, 1), (1, 4, 26), (0, 0, 0)):       # 5 utterances with 0, 0, 0: the policy's own choice
         out = L.lws(384, 192, utterances_per_wave=U, waves_per_group=NW, groups_per_utterance=G, **kw).run_lws(S0)
         assert np.array_equal(ref, out), (U, NW, G)
+
+
+def test_skewed_kernel_launch_shape_does_not_change_the_result(L):
+    """The skewed-frame kernel: stages per workgroup (4, 8, 16) and workgroups per utterance (1 .. 7, 0 = the policy) only
+    decide which wave runs which sweep and whether a hand-over goes through the CU's L1 or through device memory -- every
+    bin sees exactly the values the raster order gives it, so the results are bit-identical.  252 frames (four rounds of
+    the 64 lanes, the last one partial) and 26 frames (less than one round)."""
+    kw = dict(fftsize=512, mode='speech', kernel='skew')
+    o = OL.LWS(384, 192, fftsize=512, mode='speech')
+    for n, B in ((48000, 3), (4800, 5)):
+        S0 = np.stack([np.abs(o.stft(_speechlike(n, 60 + i))) for i in range(B)]).astype(np.complex64)
+        ref = L.lws(384, 192, waves_per_group=4, groups_per_utterance=1, **kw).run_lws(S0)
+        for NW, G in ((8, 1), (16, 1), (4, 3), (8, 5), (16, 7), (16, 0), (0, 0)):
+            out = L.lws(384, 192, waves_per_group=NW, groups_per_utterance=G, **kw).run_lws(S0)
+            assert np.array_equal(ref, out), (n, NW, G)
+        # and the two kernels agree to rounding (different order of the 33 taps' sum, magnitudes taken once vs per sweep)
+        other = L.lws(384, 192, fftsize=512, mode='speech', kernel='raster').run_lws(S0)
+        err = np.abs(ref - other)
+        assert np.sqrt((err ** 2).sum() / (np.abs(other) ** 2).sum()) < 2e-3, n
 
 
 def test_refine_enhanced_matches_oracle(L):

@@ -14,7 +14,8 @@ f0 = 150 + 100 * torch.rand(B, 1, generator=g, device='cuda')
 wav = sum(2000 / h * torch.sin(2 * 3.14159265 * h * f0 * t / 16000) for h in range(1, 9))
 wav = wav * (0.6 + 0.4 * torch.sin(2 * 3.14159265 * 4 * t / 16000)) + 100 * torch.randn(B, 48000, generator=g, device='cuda')
 masks = torch.ones(B, 250, 257, device='cuda'); masks[:, 100:133] = 0
-p = L.lws(384, 192, fftsize=512, mode='speech', utterances_per_wave=U, waves_per_group=NW, groups_per_utterance=G)
+p = L.lws(384, 192, fftsize=512, mode='speech', utterances_per_wave=U, waves_per_group=NW, groups_per_utterance=G)      # AVSI_LWS_KERNEL=raster|skew
+print("kernel:", p.kernel, flush=True)
 out = p.refine_enhanced(wav, masks, num_samples=48000)
 torch.cuda.synchronize()
 s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
