@@ -42,6 +42,7 @@
 
 #include "avsi_common.h"
 #include "lws_shared.h"
+#include "lws_skew_weights.h"
 
 namespace {
 
@@ -54,6 +55,9 @@ constexpr int T0 = -24;                    // time of step 0 (a multiple of 12 a
 constexpr int ROW_OFF = 5;                 // row of (frame m, position x) = x + 6 m + ROW_OFF
 constexpr int TAU_LAST = 2 * (KB - 1) - (KB - 1 - LMAX) + 0;   // 261: last mirror position above Nyquist
 constexpr int NONE = -100000;
+constexpr int QSLACK = 3;             // bodies a stage asks for beyond its need when it has to poll device memory
+constexpr int CTR_STRIDE = 64;                                        // ints between two device-scope counters (256 bytes)
+constexpr int GPROG_INTS = (MAX_SWEEPS / 4) * CTR_STRIDE;            // per utterance: up to MAX_SWEEPS / 4 workgroups
 static_assert(TAU_LAST == 261 && KB == 257 && SKEW == 6, "the edge rules below are written out for 257 bins, L = 5");
 static_assert(LANES * SKEW >= TAU_LAST + 1 + 24, "a lane must be done with a frame (and its prefetch) before the next one starts");
 
@@ -95,16 +99,13 @@ __device__ __forceinline__ T* uniform_ptr(T* p) {
     return (T*)(((unsigned long long)hi << 32) | lo);
 }
 __device__ __forceinline__ void row_load8(bool DEV, float2& dst, const float2* row, unsigned lane_off) {      // DEV: wave-uniform
-    row = uniform_ptr(row);
     if (DEV) asm volatile("s_nop 4\n\tglobal_load_dwordx2 %0, %1, %2 sc0 sc1" : "=v"(dst) : "v"(lane_off), "s"(row) : "memory");
     else asm volatile("s_nop 4\n\tglobal_load_dwordx2 %0, %1, %2" : "=v"(dst) : "v"(lane_off), "s"(row) : "memory");
 }
 __device__ __forceinline__ void row_load4(float& dst, const float* row, unsigned lane_off) {
-    row = uniform_ptr(row);
     asm volatile("s_nop 4\n\tglobal_load_dword %0, %1, %2" : "=v"(dst) : "v"(lane_off), "s"(row) : "memory");
 }
 __device__ __forceinline__ void row_store8(bool DEV, float2* row, unsigned lane_off, float2 v) {
-    row = uniform_ptr(row);
     if (DEV) asm volatile("s_nop 4\n\tglobal_store_dwordx2 %0, %1, %2 sc0 sc1\n\ts_nop 1" ::"v"(lane_off), "v"(v), "s"(row) : "memory");
     else asm volatile("s_nop 4\n\tglobal_store_dwordx2 %0, %1, %2\n\ts_nop 1" ::"v"(lane_off), "v"(v), "s"(row) : "memory");
 }
@@ -137,16 +138,24 @@ struct StepCtx {
     unsigned lane8, lane4;
 };
 
-template <int I>
+// STD: the weights of the reference's geometry as compile-time constants (lws_skew_weights.h) -- literal operands of the
+// multiply-adds.  As kernel arguments the 66 values do not fit the scalar registers beside everything else: the compiler
+// parked them in VGPR lanes and fetched every one with a v_readlane per tap (30 of ~340 instructions per step).
+template <int I, bool STD>
 __device__ __forceinline__ void skew_step(LaneState& L, const StepCtx& C, const SkewConst& W, int n) {
+#define WBU(p, c) (STD ? AVSI_LWS_STD_BU[p][c] : W.bu[p][c])
+#define WBD(p, c) (STD ? AVSI_LWS_STD_BD[p][c] : W.bd[p][c])
+#define WB0(p, c) (STD ? AVSI_LWS_STD_B0[p][c] : W.b0[p][c])
     const int t = T0 + n;                                  // wave-uniform
     // ---- the operands requested twelve steps ago
     // (the wait takes the landing registers as operands: nothing may read them, or give them to another value, before it)
     asm volatile("s_waitcnt vmcnt(34)" : "+v"(L.Lb[I].x), "+v"(L.Lb[I].y), "+v"(L.Ab[I])::"memory");
     const float2 arr = L.Lb[I];
     const float amp = L.Ab[I];
-    row_load8(C.dev_in, L.Lb[I], C.Dg + (size_t)(t + UNR + 16) * LANES, C.lane8);     // position tau + 11 of step n + 12
-    row_load4(L.Ab[I], C.Ag + (size_t)(t + UNR + ROW_OFF > 0 ? t + UNR + ROW_OFF : 0) * LANES, C.lane4);   // magnitude of the bin of step n + 12
+    // (addresses: the utterance's base pointer in SGPRs for the whole kernel + a 32-bit byte offset per lane that includes the
+    // row -- one v_add per access instead of 64-bit pointer arithmetic and a v_readfirstlane pair per row)
+    row_load8(C.dev_in, L.Lb[I], C.Dg, C.lane8 + (unsigned)(t + UNR + 16) * (unsigned)(LANES * sizeof(float2)));     // position tau + 11 of step n + 12
+    row_load4(L.Ab[I], C.Ag, C.lane4 + (unsigned)(t + UNR + ROW_OFF > 0 ? t + UNR + ROW_OFF : 0) * (unsigned)(LANES * sizeof(float)));   // magnitude of the bin of step n + 12
     const int tau = L.tau, m = L.m;
     L.R[I] = arr;                                                                      // position tau + 11
     {   // positions 1 .. 5 of a row also define its mirror images -1 .. -5, which "arrived" 2 x steps earlier
@@ -156,13 +165,13 @@ __device__ __forceinline__ void skew_step(LaneState& L, const StepCtx& C, const 
     // ---- three sums over this lane's own rings (newest elements last: they end the dependence chain)
     float2 up = make_float2(0.f, 0.f), dn = up, own = up;
 #pragma unroll
-    for (int p = -LMAX; p <= LMAX; ++p) up = cmadd(up, W.bu[p + LMAX][0], W.bu[p + LMAX][1], L.R[ring(I - LMAX + p)]);
+    for (int p = -LMAX; p <= LMAX; ++p) up = cmadd(up, WBU(p + LMAX, 0), WBU(p + LMAX, 1), L.R[ring(I - LMAX + p)]);
 #pragma unroll
-    for (int p = 1; p <= LMAX; ++p) own = cmadd(own, W.b0[LMAX + p][0], W.b0[LMAX + p][1], L.R[ring(I - 11 + p)]);
+    for (int p = 1; p <= LMAX; ++p) own = cmadd(own, WB0(LMAX + p, 0), WB0(LMAX + p, 1), L.R[ring(I - 11 + p)]);
 #pragma unroll
-    for (int p = -LMAX; p <= LMAX; ++p) dn = cmadd(dn, W.bd[p + LMAX][0], W.bd[p + LMAX][1], L.P[ring(I - (SKEW - p))]);
+    for (int p = -LMAX; p <= LMAX; ++p) dn = cmadd(dn, WBD(p + LMAX, 0), WBD(p + LMAX, 1), L.P[ring(I - (SKEW - p))]);
 #pragma unroll
-    for (int p = LMAX; p >= 1; --p) own = cmadd(own, W.b0[LMAX - p][0], W.b0[LMAX - p][1], L.P[ring(I - p)]);
+    for (int p = LMAX; p >= 1; --p) own = cmadd(own, WB0(LMAX - p, 0), WB0(LMAX - p, 1), L.P[ring(I - p)]);
     // ---- exchange: the row below (old values) from lane j + 1, the row above (new values) from lane j - 1
     float2 upr = make_float2(dpp_from_next(up.x), dpp_from_next(up.y));
     float2 dnr = make_float2(dpp_from_prev(dn.x), dpp_from_prev(dn.y));
@@ -204,24 +213,26 @@ __device__ __forceinline__ void skew_step(LaneState& L, const StepCtx& C, const 
     }
     // ---- store (row t + 5, every lane, always: lanes with nothing to store write a scratch row)
     const bool st = tau >= 0 && tau <= TAU_LAST && m < C.M;
-    float2* rp = C.Dw + (int64_t)(t + ROW_OFF) * LANES;          // (before the array while t + 5 < 0: no lane stores there)
-    const unsigned off = st ? C.lane8 : C.lane8 + (unsigned)((C.trash_row - (t + ROW_OFF)) * (int)(LANES * sizeof(float2)));
-    row_store8(C.dev_out, rp, off, out);
+    const unsigned off = C.lane8 + (unsigned)(st ? t + ROW_OFF : C.trash_row) * (unsigned)(LANES * sizeof(float2));
+    row_store8(C.dev_out, C.Dw, off, out);
     // ---- next step of this lane
     const int nt = tau + 1;
     const bool wrap = nt > TAU_LAST;
     L.tau = wrap ? nt - PERIOD : nt;
     L.m = wrap ? m + LANES : m;
     __builtin_amdgcn_sched_barrier(0);          // steps are not interleaved: their live ranges would add up
+#undef WBU
+#undef WBD
+#undef WB0
 }
 
-template <int... Is>
+template <bool STD, int... Is>
 __device__ __forceinline__ void skew_body(LaneState& L, const StepCtx& C, const SkewConst& W, int n0, std::integer_sequence<int, Is...>) {
-    (skew_step<Is>(L, C, W, n0 + Is), ...);
+    (skew_step<Is, STD>(L, C, W, n0 + Is), ...);
 }
 
 // NW waves per workgroup = NW pipeline stages of one utterance; G workgroups per utterance
-template <int NW>
+template <int NW, bool STD>
 __global__ __launch_bounds__(64 * NW) void lws_skew_kernel(float2* __restrict__ Dall, const float* __restrict__ Aall, int B, int M,
                                                           const SkewConst W, const AvsiLwsSchedule sched, int* __restrict__ status,
                                                           const float2* __restrict__ stats, int* __restrict__ gprog_all, int G) {
@@ -233,7 +244,9 @@ __global__ __launch_bounds__(64 * NW) void lws_skew_kernel(float2* __restrict__ 
     const int rows = skew_rows(M);
     const int nb = (skew_steps(M) + UNR - 1) / UNR;           // bodies per sweep
     const int nbp = nb + 8;                                   // counter values per sweep of a stage
-    int* gprog = gprog_all + (size_t)b * MAX_SWEEPS;          // one counter per stage (stages <= MAX_SWEEPS)
+    // one counter per workgroup of the chain (its last stage publishes there), each on a 256-byte line of its own: polls
+    // and publications are device-scope accesses served at the memory side, and neighbours in one line queue on one channel
+    int* gprog = gprog_all + (size_t)b * GPROG_INTS;
     volatile int* vprog = prog;
     if (threadIdx.x < 64) {
         float sn, cs;
@@ -245,9 +258,9 @@ __global__ __launch_bounds__(64 * NW) void lws_skew_kernel(float2* __restrict__ 
     const float2 st = stats[b];
     const float mean = st.x, amax = st.y;
     StepCtx C;
-    C.Dg = Dall + (size_t)b * rows * LANES;
-    C.Dw = Dall + (size_t)b * rows * LANES;
-    C.Ag = Aall + (size_t)b * rows * LANES;
+    C.Dg = uniform_ptr(Dall + (size_t)b * rows * LANES);        // SGPRs from here on: the "s" operands of the memory instructions
+    C.Dw = uniform_ptr(Dall + (size_t)b * rows * LANES);
+    C.Ag = uniform_ptr(Aall + (size_t)b * rows * LANES);
     C.ctab = ctab;
     C.M = M;
     C.trash_row = rows - 1;
@@ -276,18 +289,22 @@ __global__ __launch_bounds__(64 * NW) void lws_skew_kernel(float2* __restrict__ 
         L.m = lane;
         L.tau = T0 - SKEW * lane;
         // a stage whose predecessor sits in another workgroup polls device memory, which drains the loads in flight: it
-        // asks for eight bodies more than it needs and then runs eight bodies on what it knows
+        // asks for QSLACK bodies more than it needs and then runs that many bodies on what it knows
         auto wait_pred = [&](int body) {
             if (pstage < 0 || dead) return;
             const int need = pbase + (body + 4 < nb + 3 ? body + 4 : nb + 3);
             if (known >= need) return;
-            const int want = dev_in ? (need + 8 < pbase + nb + 3 ? need + 8 : pbase + nb + 3) : need;
+            const int want = dev_in ? (need + QSLACK < pbase + nb + 3 ? need + QSLACK : pbase + nb + 3) : need;
             int spins = 0;
             for (;;) {
-                known = dev_in ? __hip_atomic_load(gprog + pstage, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : vprog[wv - 1];
+                known = dev_in ? __hip_atomic_load(gprog + (pstage / NW) * CTR_STRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                               : vprog[wv - 1];
                 known = __builtin_amdgcn_readfirstlane(known);
                 if (known >= want) break;
-                __builtin_amdgcn_s_sleep(4);
+                // a predecessor that is still bodies away is not worth asking often: with hundreds of stages waiting for their
+                // turn, their polls alone kept the memory side busy (32 utterances x 26 workgroups: 20 ms instead of 5)
+                if (known + 2 < want) __builtin_amdgcn_s_sleep(127);
+                else __builtin_amdgcn_s_sleep(8);
                 if (++spins > (1 << 22)) {
                     dead = true;
                     if (lane == 0 && status) atomicOr(status, 1);
@@ -298,22 +315,22 @@ __global__ __launch_bounds__(64 * NW) void lws_skew_kernel(float2* __restrict__ 
         auto publish = [&](int value) {
             if (lane == 0) {
                 vprog[wv] = value;
-                if (dev_out) __hip_atomic_store(gprog + stage, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (dev_out) __hip_atomic_store(gprog + wg * CTR_STRIDE, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
         };
         // prefetch of the first body: rows of steps 0 .. 11 (nothing of them is used before position 1 arrives)
         wait_pred(0);
 #pragma unroll
         for (int i = 0; i < UNR; ++i) {
-            row_load8(dev_in, L.Lb[i], C.Dg + (size_t)(T0 + i + 16 > 0 ? T0 + i + 16 : 0) * LANES, C.lane8);     // (rows < 0: positions nobody reads)
-            row_load4(L.Ab[i], C.Ag + (size_t)(T0 + i + ROW_OFF > 0 ? T0 + i + ROW_OFF : 0) * LANES, C.lane4);
+            row_load8(dev_in, L.Lb[i], C.Dg, C.lane8 + (unsigned)(T0 + i + 16 > 0 ? T0 + i + 16 : 0) * (unsigned)(LANES * sizeof(float2)));     // (rows < 0: positions nobody reads)
+            row_load4(L.Ab[i], C.Ag, C.lane4 + (unsigned)(T0 + i + ROW_OFF > 0 ? T0 + i + ROW_OFF : 0) * (unsigned)(LANES * sizeof(float)));
             // keep the count of the step loop: a store per step (scratch row)
-            row_store8(false, C.Dw + (size_t)C.trash_row * LANES, C.lane8, make_float2(0.f, 0.f));
+            row_store8(false, C.Dw, C.lane8 + (unsigned)C.trash_row * (unsigned)(LANES * sizeof(float2)), make_float2(0.f, 0.f));
         }
         for (int body = 0; body < nb; ++body) {
             wait_pred(body);
             const int n0 = body * UNR;
-            skew_body(L, C, W, n0, std::make_integer_sequence<int, UNR>{});
+            skew_body<STD>(L, C, W, n0, std::make_integer_sequence<int, UNR>{});
             // the stores of the body BEFORE this one are complete once at most this body's 36 operations are in flight
             asm volatile("s_waitcnt vmcnt(36)" ::: "memory");
             publish(base + body);
@@ -370,7 +387,7 @@ size_t align256(size_t n) { return (n + 255) & ~(size_t)255; }
 extern "C" size_t avsi_lws_run_skew_workspace_bytes(int batch, int num_frames) {
     if (batch <= 0 || num_frames <= 0) return 0;
     const size_t cells = (size_t)batch * skew_rows(num_frames) * LANES;
-    return align256(16 + (size_t)batch * sizeof(float2)) + align256((size_t)batch * MAX_SWEEPS * sizeof(int)) +
+    return align256(16 + (size_t)batch * sizeof(float2)) + align256((size_t)batch * GPROG_INTS * sizeof(int)) +
            align256(cells * sizeof(float2)) + align256(cells * sizeof(float));
 }
 
@@ -401,18 +418,35 @@ extern "C" int avsi_lws_run_skew_f32(float* spec, int batch, int num_frames, int
         W.b0[p + LMAX][0] = (float)a0[0], W.b0[p + LMAX][1] = (float)a0[1];
     }
     W.phase_step = 64 * hop / nfft;
-    // Launch shape: NW stages per workgroup, G workgroups per utterance, all resident together.  A workgroup of 16 waves
-    // fills a CU (four waves per SIMD); small batches spread the ~100 sweeps of an utterance over as many workgroups as
-    // the chip has room for, large batches run one workgroup per utterance and several rounds of sweeps on it.
-    int NW = waves_per_group ? waves_per_group : 16;
+    // the reference's geometry: the same weights as compile-time constants (checked here against the ones just computed)
+    bool standard = frame_len == AVSI_LWS_STD_FRAME && hop == AVSI_LWS_STD_HOP && nfft == AVSI_LWS_STD_NFFT && L == AVSI_LWS_STD_L;
+    for (int p = 0; p < NP && standard; ++p)
+        for (int c = 0; c < 2; ++c)
+            standard = fabs((double)W.bu[p][c] - AVSI_LWS_STD_BU[p][c]) <= 1e-7 && fabs((double)W.bd[p][c] - AVSI_LWS_STD_BD[p][c]) <= 1e-7 &&
+                       fabs((double)W.b0[p][c] - AVSI_LWS_STD_B0[p][c]) <= 1e-7;
+    if (frame_len == AVSI_LWS_STD_FRAME && hop == AVSI_LWS_STD_HOP && nfft == AVSI_LWS_STD_NFFT && L == AVSI_LWS_STD_L && !standard)
+        return AVSI_ERR_UNSUPPORTED;          // lws_skew_weights.h is stale: regenerate it (tools/gen_lws_skew_weights.py)
+    // Launch shape: NW stages (waves) per workgroup, G workgroups chained per utterance, all of them resident together (a CU
+    // holds 16 waves of this kernel: 128 VGPRs).  The sweeps of an utterance are a pipeline, so what counts is how many of its
+    // ~100 stages are in flight and how evenly the ACTIVE ones (about forty at any time: a stage trails its predecessor by
+    // four bodies) spread over the SIMDs: small batches take 4-wave workgroups, as many per utterance as the chip has room
+    // for; large batches fill the chip with utterances, 16 stages each.  Measured (ms per batch, NW x G): 32 utterances
+    // 16 x 8: 9.6, 8 x 8: 6.6, 4 x 8: 5.7; 1024 utterances 16 x 1: 60.8, 8 x 1: 72.1, 4 x 1: 94.7.
+    int NW = waves_per_group;
+    if (NW == 0) NW = batch <= 32 ? 4 : (batch <= 128 ? 8 : 16);
     if (NW != 4 && NW != 8 && NW != 16) return AVSI_ERR_INVALID_ARG;
+    if (!standard) NW = 8;
+    const int capacity = AVSI_NUM_CU * (16 / NW);             // workgroups the chip holds at once
     int G = groups_per_utterance;
     if (G == 0) {
         const int useful = (S.n + NW - 1) / NW;
-        G = batch <= AVSI_NUM_CU ? AVSI_NUM_CU / batch : 1;
+        // (every workgroup boundary is a hand-over through device memory: beyond eight of them per utterance the extra lag
+        // costs more than the stages bring -- 32 utterances, 4-wave workgroups: 8 per utterance 5.5 ms, 16: 6.3, 26: 7.4)
+        G = batch <= capacity ? capacity / batch : 1;
         G = G < 1 ? 1 : (G > useful ? useful : G);
+        if (batch > 8 && G > 8) G = 8;
     }
-    if (G < 1 || G * NW > MAX_SWEEPS) return AVSI_ERR_INVALID_ARG;
+    if (G < 1 || G * NW > MAX_SWEEPS || G > MAX_SWEEPS / 4 || G > capacity) return AVSI_ERR_INVALID_ARG;
     const hipStream_t st = (hipStream_t)stream;
     const int rows = skew_rows(num_frames);
     char* ws = static_cast<char*>(workspace);
@@ -420,30 +454,31 @@ extern "C" int avsi_lws_run_skew_f32(float* spec, int batch, int num_frames, int
     float2* stats = reinterpret_cast<float2*>(ws + 16);
     size_t off = align256(16 + (size_t)batch * sizeof(float2));
     int* gprog = reinterpret_cast<int*>(ws + off);
-    off += align256((size_t)batch * MAX_SWEEPS * sizeof(int));
+    off += align256((size_t)batch * GPROG_INTS * sizeof(int));
     float2* D = reinterpret_cast<float2*>(ws + off);
     off += align256((size_t)batch * rows * LANES * sizeof(float2));
     float* A = reinterpret_cast<float*>(ws + off);
-    if (hipMemsetAsync(workspace, 0, align256(16 + (size_t)batch * sizeof(float2)) + align256((size_t)batch * MAX_SWEEPS * sizeof(int)),
+    if (hipMemsetAsync(workspace, 0, align256(16 + (size_t)batch * sizeof(float2)) + align256((size_t)batch * GPROG_INTS * sizeof(int)),
                        st) != hipSuccess)
         return AVSI_ERR_LAUNCH;
     avsi_clear_error();
     avsi_lws_launch_stats(spec, batch, num_frames, reinterpret_cast<float*>(stats), st);
     // every workgroup of a launch must be resident (its stages wait for each other): batches beyond the chip's capacity
     // run as consecutive launches
-    const int per_launch = AVSI_NUM_CU / G > 0 ? AVSI_NUM_CU / G : 1;
+    const int per_launch = capacity / G > 0 ? capacity / G : 1;
     for (int b0 = 0; b0 < batch; b0 += per_launch) {
         const int nbatch = batch - b0 < per_launch ? batch - b0 : per_launch;
         float2* sp = reinterpret_cast<float2*>(spec) + (size_t)b0 * num_frames * KB;
         float2* Db = D + (size_t)b0 * rows * LANES;
         float* Ab = A + (size_t)b0 * rows * LANES;
         hipLaunchKernelGGL(lws_to_diag_kernel, dim3((rows + 3) / 4, nbatch), dim3(256), 0, st, sp, num_frames, rows, Db, Ab);
-#define AVSI_SKEW_LAUNCH(NWV)                                                                                              \
-    hipLaunchKernelGGL((lws_skew_kernel<NWV>), dim3(nbatch* G), dim3(64 * (NWV)), 0, st, Db, Ab, nbatch, num_frames, W, S, status, \
-                       stats + b0, gprog + (size_t)b0 * MAX_SWEEPS, G)
-        if (NW == 16) AVSI_SKEW_LAUNCH(16);
-        else if (NW == 8) AVSI_SKEW_LAUNCH(8);
-        else AVSI_SKEW_LAUNCH(4);
+#define AVSI_SKEW_LAUNCH(NWV, STDV)                                                                                          \
+    hipLaunchKernelGGL((lws_skew_kernel<NWV, STDV>), dim3(nbatch* G), dim3(64 * (NWV)), 0, st, Db, Ab, nbatch, num_frames, W, S,   \
+                       status, stats + b0, gprog + (size_t)b0 * GPROG_INTS, G)
+        if (!standard) AVSI_SKEW_LAUNCH(8, false);            // other geometries: one shape, weights as kernel arguments
+        else if (NW == 16) AVSI_SKEW_LAUNCH(16, true);
+        else if (NW == 8) AVSI_SKEW_LAUNCH(8, true);
+        else AVSI_SKEW_LAUNCH(4, true);
 #undef AVSI_SKEW_LAUNCH
         hipLaunchKernelGGL(lws_from_diag_kernel, dim3((rows + 3) / 4, nbatch), dim3(256), 0, st, Db, num_frames, rows, sp);
     }
