@@ -164,6 +164,7 @@ PROTOTYPES = {
                                                      c_void_p]),
     "avsi_ctc_beam_search_host_f32": (c_int, [c_void_p, c_int64, c_int64, c_int, c_int, c_int, c_void_p, c_int, c_int,
                                               c_void_p, c_int, c_void_p, c_void_p]),
+    "avsi_wav_write_batch_int16_host": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_int, c_int, c_int]),
     "avsi_lws_num_frames": (c_int, [c_int, c_int, c_int]),
     "avsi_lws_table_floats": (c_size_t, [c_int, c_int, c_int]),
     "avsi_lws_init_tables": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p]),

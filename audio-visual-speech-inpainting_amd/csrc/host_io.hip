@@ -61,3 +61,68 @@ extern "C" uint32_t avsi_crc32c(const void* data, size_t n, uint32_t seed) {
     while (n--) c = (c >> 8) ^ T.t[0][(c ^ *p++) & 0xFF];
     return ~c;
 }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// WAV files of the inference driver: `wavfile.write(path, 16000, enhanced[:seq_len * 192].astype(np.int16))`
+// (reference inference.py:159-162) for a batch of utterances, natively -- called from a few host threads outside the
+// interpreter lock.  16-bit PCM mono with the 44-byte header scipy.io.wavfile.write produces (RIFF / WAVE / 'fmt ' of 16
+// bytes / 'data'); float -> int16 as numpy's astype does it on x86 (truncation toward zero of the 32-bit conversion, low
+// 16 bits kept; NaN and values beyond the int32 range give 0).
+#include <errno.h>
+#include <stdio.h>
+#include <string.h>
+#include <sys/stat.h>
+
+#include <string>
+#include <vector>
+
+namespace {
+bool make_parent_dirs(const char* path) {
+    std::string p(path);
+    const size_t last = p.rfind('/');
+    if (last == std::string::npos || last == 0) return true;
+    p.resize(last);
+    struct stat sb;
+    if (stat(p.c_str(), &sb) == 0) return S_ISDIR(sb.st_mode);
+    for (size_t i = 1; i <= p.size(); ++i) {
+        if (i < p.size() && p[i] != '/') continue;
+        const std::string part = p.substr(0, i);
+        if (mkdir(part.c_str(), 0777) != 0 && errno != EEXIST) return false;
+    }
+    return true;
+}
+inline void put_u32(unsigned char* d, uint32_t v) { d[0] = v & 0xFF, d[1] = (v >> 8) & 0xFF, d[2] = (v >> 16) & 0xFF, d[3] = (v >> 24) & 0xFF; }
+inline void put_u16(unsigned char* d, uint16_t v) { d[0] = v & 0xFF, d[1] = (v >> 8) & 0xFF; }
+}  // namespace
+
+extern "C" int avsi_wav_write_batch_int16_host(const char* const* paths, const float* samples, int64_t stride,
+                                               const int32_t* num_samples, int count, int sample_rate, int make_dirs) {
+    if (!paths || !samples || !num_samples || count < 0 || sample_rate <= 0) return AVSI_ERR_INVALID_ARG;
+    try {
+        std::vector<unsigned char> buf;
+        for (int i = 0; i < count; ++i) {
+            const int n = num_samples[i];
+            if (!paths[i] || n < 0) return AVSI_ERR_INVALID_ARG;
+            buf.resize(44 + (size_t)n * 2);
+            unsigned char* h = buf.data();
+            memcpy(h, "RIFF", 4), put_u32(h + 4, 36 + (uint32_t)n * 2), memcpy(h + 8, "WAVEfmt ", 8), put_u32(h + 16, 16);
+            put_u16(h + 20, 1), put_u16(h + 22, 1), put_u32(h + 24, (uint32_t)sample_rate), put_u32(h + 28, (uint32_t)sample_rate * 2);
+            put_u16(h + 32, 2), put_u16(h + 34, 16), memcpy(h + 36, "data", 4), put_u32(h + 40, (uint32_t)n * 2);
+            const float* x = samples + (int64_t)i * stride;
+            unsigned char* d = h + 44;
+            for (int k = 0; k < n; ++k) {
+                const float v = x[k];
+                const int32_t q = (v >= -2147483648.f && v < 2147483648.f) ? (int32_t)v : INT32_MIN;
+                put_u16(d + 2 * k, (uint16_t)((uint32_t)q & 0xFFFFu));
+            }
+            if (make_dirs && !make_parent_dirs(paths[i])) return AVSI_ERR_INVALID_ARG;
+            FILE* fh = fopen(paths[i], "wb");
+            if (!fh) return AVSI_ERR_INVALID_ARG;
+            const bool ok = fwrite(buf.data(), 1, buf.size(), fh) == buf.size();
+            if (fclose(fh) != 0 || !ok) return AVSI_ERR_INVALID_ARG;
+        }
+    } catch (const std::bad_alloc&) {
+        return AVSI_ERR_INVALID_ARG;
+    }
+    return AVSI_OK;
+}

@@ -37,7 +37,10 @@ _POOL = None
 def _pool():
     global _POOL
     if _POOL is None:
-        _POOL = ThreadPoolExecutor(max_workers=max(1, min(8, os.cpu_count() or 1)), thread_name_prefix='avsi-parse')
+        # a record is ~0.2 ms of open + read + checksum + parse on one core: sixteen threads keep a GPU fed at batches of a
+        # thousand (AVSI_READER_THREADS overrides; a GPU box grants a process about that many cores per GPU)
+        n = int(os.environ.get('AVSI_READER_THREADS', '0')) or min(16, os.cpu_count() or 1)
+        _POOL = ThreadPoolExecutor(max_workers=max(1, n), thread_name_prefix='avsi-parse')
     return _POOL
 
 
@@ -153,9 +156,9 @@ class Batch(tuple):
 class _Uploader(object):
     """Copies the bulky fields of a batch (audio, video, mask, embedding) to the GPU from the prefetch thread, on a
     stream of its own, one event per batch.  The reference's feed_dict crossing is a synchronous pageable copy
-    on the training thread; here the same copy blocks only the reader thread, and the training stream waits for
-    the event.  (A ring of pinned staging buffers with non-blocking copies was no faster on this host -- 1 ms per
-    19 MB batch either way -- and stalled for ~80 ms every few batches.)"""
+    on the training thread; here the records are parsed straight into PINNED arenas (DataManager.decode_batch) and the
+    copies are asynchronous at the link's rate -- 600 MB per batch of 1024 utterances: 11 ms, where the pageable copy took
+    60 ms, i.e. capped the driver at 17 k utterances/s whatever the GPU did -- and the training stream waits for the event."""
 
     def __init__(self, device, fields):
         import torch
@@ -166,7 +169,7 @@ class _Uploader(object):
             self.device = torch.device('cuda', torch.cuda.current_device())
         self.stream = None
 
-    def __call__(self, batch):
+    def __call__(self, batch, arena=None):
         torch = self.torch
         if self.stream is None:
             torch.cuda.set_device(self.device)
@@ -179,13 +182,20 @@ class _Uploader(object):
         out.device_arrays = {}
         if isinstance(batch[-1], np.ndarray) and batch[-1].dtype != object:
             out.gap_count = int(batch[-1].size - np.count_nonzero(batch[-1]))
+        pinned = (arena or {}).get('_pinned', {})
         with torch.cuda.stream(self.stream):
             for i in sorted(f % len(batch) for f in self.fields):
                 a = batch[i]
                 if isinstance(a, np.ndarray) and a.dtype != object and a.size:
-                    out.device_arrays[i] = torch.from_numpy(np.ascontiguousarray(a)).to(self.device)
+                    t = pinned.get(a.ctypes.data)           # the pinned tensor this array is a view of, if any
+                    if t is not None:
+                        out.device_arrays[i] = t[:a.shape[0]].to(self.device, non_blocking=True)
+                    else:
+                        out.device_arrays[i] = torch.from_numpy(np.ascontiguousarray(a)).to(self.device)
             out.ready = torch.cuda.Event()
             out.ready.record(self.stream)
+        if arena is not None:
+            arena['_event'] = out.ready             # the arena's next user waits for these copies (BatchIterator._make)
         return out
 
 
@@ -261,7 +271,7 @@ class BatchIterator(object):
         self.upload = _Uploader(device, upload_fields) if device is not None else None
         # with a device the consumer works on the uploaded copies, so the host arrays are recycled: a batch's numpy
         # fields stay valid until prefetch + 2 further batches have been fetched
-        self._arenas = [dict() for _ in range(self.prefetch + 3)] if device is not None else None
+        self._arenas = [{'_pin': True} for _ in range(self.prefetch + 3)] if device is not None else None
         self._made = 0
         self._gen = None
         self.initializer()
@@ -285,8 +295,12 @@ class BatchIterator(object):
         if self.decode_batch is None:
             batch = _collate([self.dataset.parse(p) for p in payloads])
         elif self._arenas is not None:
-            batch = self.decode_batch(payloads, self._arenas[self._made % len(self._arenas)])
+            arena = self._arenas[self._made % len(self._arenas)]
             self._made += 1
+            if arena.get('_event') is not None:
+                arena['_event'].synchronize()       # its previous contents are on the device
+            batch = self.decode_batch(payloads, arena)
+            return self.upload(batch, arena) if self.upload is not None else batch
         else:
             batch = self.decode_batch(payloads)
         return self.upload(batch) if self.upload is not None else batch
@@ -391,7 +405,16 @@ class DataManager:
                 return np.empty(shape, dtype=dtype)
             a = arena.get(name)
             if a is None or a.dtype != dtype or a.shape[1:] != tuple(shape[1:]) or a.shape[0] < shape[0]:
-                a = arena[name] = np.empty(shape, dtype=dtype)
+                if arena.get('_pin') and int(np.prod(shape)) > 0:
+                    # page-locked: the uploader's copies then run at the link's rate and asynchronously (_Uploader)
+                    import torch
+                    t = torch.empty(tuple(int(v) for v in shape), dtype={np.dtype(np.int32): torch.int32,
+                                                                         np.dtype(np.float32): torch.float32}[np.dtype(dtype)],
+                                    pin_memory=True)
+                    a = arena[name] = t.numpy()
+                    arena.setdefault('_pinned', {})[a.ctypes.data] = t
+                else:
+                    a = arena[name] = np.empty(shape, dtype=dtype)
             return a[:shape[0]]
         lengths = np.empty((B, 2), dtype=np.int32)
         wav = alloc('wav', (B, n_wav), np.int32)

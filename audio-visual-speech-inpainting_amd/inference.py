@@ -11,16 +11,15 @@ target STFT (zero inside gaps), whose gap frames are then refined by LWS phase r
 as the reference does with the ``lws`` package (inference.py:119,141-154) -- here ``avsi_amd.lws``,
 the gfx950 implementation of the published algorithm (see that module: unpinned against the package).
 """
+import ctypes
 import os
-import queue
 import sys
 import threading
 from glob import glob
 
 import numpy as np
-from scipy.io import wavfile
 
-from . import ops, parallel
+from . import _lib, ops, parallel
 from . import lws as lws_mod
 from .config_utils import check_trainconfiguration, load_configfile
 from .dataset_reader import DataManager, OutOfRangeError
@@ -28,47 +27,85 @@ from .training import EMBEDDING_SIZE, build_model, unpack_batch, uses_embeddings
 
 
 class _WavWriter(object):
-    """Writes the enhanced utterances of a finished batch: ``<audio_path>/<sample>/enhanced/<prefix>.wav``, 16 kHz int16,
-    ``seq_len * 192`` samples, as the reference's loop does.  In line by default (80 us per file; the reader thread, not
-    this, bounds the driver); ``AVSI_WAV_THREADS=n`` hands the files to n worker threads instead -- worth it on slow
-    storage only: on a local disk four threads were slower (2.4 k against 2.7 k utterances/s, they compete with the
-    reader thread for the interpreter)."""
+    """Turns finished batches into ``<audio_path>/<sample>/enhanced/<prefix>.wav`` files (16 kHz int16, ``seq_len * 192``
+    samples: the reference's loop, inference.py:159-162) WITHOUT holding up the launch thread: a batch is submitted as
+    a device tensor; its waveforms are copied into a pinned host buffer on a stream of their own (high priority: see
+    dataset_reader._Uploader), and a few host threads wait for that copy and write the files natively, outside the
+    interpreter lock (avsi_wav_write_batch_int16_host: directory creation, float -> int16, header, write).
+    The reference writes per utterance on the thread that also feeds the GPU; at batch 1024 that thread spent more time in
+    ``wavfile.write`` (50 us a file) and in the pageable device-to-host copy (33 ms per 196 MB) than the GPU on the batch.
+    A batch whose cooperative-kernel / LWS status word is non-zero when its copy arrives is NOT written and fails the run
+    (``close`` raises): outputs of a kernel that gave up a bounded wait are invalid."""
 
-    def __init__(self, audio_path, prefix, threads):
+    def __init__(self, audio_path, prefix, threads, device):
+        import torch
+        from concurrent.futures import ThreadPoolExecutor
+        self.torch = torch
         self.audio_path, self.prefix = audio_path, prefix
-        self.jobs = queue.Queue(maxsize=4 * max(1, threads))
+        self.device = device
+        self.threads = max(1, threads)
+        self.pool = ThreadPoolExecutor(max_workers=self.threads, thread_name_prefix='avsi-wav')
+        self.stream = torch.cuda.Stream(device=device, priority=-1)
+        self.slots = []                 # [host buffer, status words, event, pending futures]
+        self.next = 0
         self.errors = []
-        self.workers = [threading.Thread(target=self._run, daemon=True) for _ in range(max(0, threads))]
-        for w in self.workers:
-            w.start()
+        self.lock = threading.Lock()
 
-    def _write(self, wav, sample_dir, seq_len):
-        out_dir = os.path.join(self.audio_path, sample_dir.decode(), 'enhanced')
-        os.makedirs(out_dir, exist_ok=True)
-        wavfile.write(os.path.join(out_dir, self.prefix + '.wav'), 16000, wav[: int(seq_len) * 192].astype(np.int16))
+    def _slot(self, shape):
+        torch = self.torch
+        if len(self.slots) < 3:
+            self.slots.append([None, torch.zeros(2, dtype=torch.int32).pin_memory(), torch.cuda.Event(), []])
+        slot = self.slots[self.next % 3]
+        self.next += 1
+        for f in slot[3]:               # the files of the batch that used this buffer three batches ago are on disk
+            f.result()
+        slot[3] = []
+        if slot[0] is None or tuple(slot[0].shape[1:]) != tuple(shape[1:]) or slot[0].shape[0] < shape[0]:
+            slot[0] = torch.empty(tuple(shape), dtype=torch.float32).pin_memory()
+        return slot
 
-    def _run(self):
-        while True:
-            job = self.jobs.get()
-            if job is None:
-                return
-            try:
-                self._write(*job)
-            except Exception as e:      # surfaces in close(): a failed write must not pass silently
+    def _write(self, slot, lo, hi, paths, counts):
+        try:
+            slot[2].synchronize()                              # the waveforms (and the status words) have arrived
+            if int(slot[1][0]) != 0 or int(slot[1][1]) != 0:
+                raise _lib.AvsiError("a cooperative recurrent kernel or an LWS pipeline stage gave up a bounded wait: the outputs of "
+                                     "this batch are invalid and were not written")
+            host = slot[0]
+            arr = (ctypes.c_char_p * (hi - lo))(*paths[lo:hi])
+            n = np.ascontiguousarray(counts[lo:hi], dtype=np.int32)
+            rc = _lib.lib().avsi_wav_write_batch_int16_host(arr, host.data_ptr() + lo * host.stride(0) * 4, host.stride(0),
+                                                           n.ctypes.data, hi - lo, 16000, 1)
+            if rc != _lib.AVSI_OK:
+                raise IOError("could not write the enhanced wavs of %s ..." % paths[lo].decode())
+        except Exception as e:          # surfaces in close(): a failed write must not pass silently
+            with self.lock:
                 self.errors.append(e)
 
-    def submit(self, wavs, sample_dirs, seq_lens):
-        for job in zip(wavs, sample_dirs, seq_lens):
-            if self.workers:
-                self.jobs.put(job)
-            else:
-                self._write(*job)
+    def submit(self, wavs, sample_dirs, seq_lens, status=()):
+        """wavs: device tensor [B, n] (results of work already enqueued on the current stream); ``status``: device int
+        tensors whose first word must be zero for the batch to be valid (cooperative kernels, LWS)."""
+        torch = self.torch
+        B = int(wavs.shape[0])
+        slot = self._slot(wavs.shape)
+        cur = torch.cuda.current_stream(wavs.device)
+        self.stream.wait_stream(cur)
+        with torch.cuda.stream(self.stream):
+            slot[0][:B].copy_(wavs, non_blocking=True)
+            slot[1].zero_()
+            for i, st in enumerate(status[:2]):
+                slot[1][i:i + 1].copy_(st.reshape(-1)[:1], non_blocking=True)
+            slot[2].record(self.stream)
+        wavs.record_stream(self.stream)
+        paths = [os.path.join(self.audio_path, d.decode(), 'enhanced', self.prefix + '.wav').encode() for d in sample_dirs]
+        counts = np.minimum(np.asarray(seq_lens, dtype=np.int64) * 192, int(wavs.shape[1]))
+        step = -(-B // self.threads)
+        slot[3] = [self.pool.submit(self._write, slot, lo, min(lo + step, B), paths, counts) for lo in range(0, B, step)]
 
     def close(self):
-        for _ in self.workers:
-            self.jobs.put(None)
-        for w in self.workers:
-            w.join()
+        for slot in self.slots:
+            for f in slot[3]:
+                f.result()
+        self.pool.shutdown()
         if self.errors:
             raise self.errors[0]
 
@@ -110,11 +147,12 @@ def infer(model_path, data_path_test, audio_path, out_file_prefix, norm=True, or
 
     total_samples = 0
     loss_list = []
-    writer = _WavWriter(audio_path, out_file_prefix, int(os.environ.get('AVSI_WAV_THREADS', '0')))
-    # The LWS kernel is a pipeline of ~100 sweeps: a batch of 32 takes it 16 ms, four such batches together 27 ms
-    # (DESIGN 4.3d).  Batches are therefore collected until LWS_GROUP utterances wait for their phase, refined in one
-    # launch and written in the order they came; the per-batch lines below are printed when their files are queued.
-    lws_group = int(os.environ.get('AVSI_LWS_GROUP', '128'))
+    device = torch.device('cuda', torch.cuda.current_device())
+    writer = _WavWriter(audio_path, out_file_prefix, int(os.environ.get('AVSI_WAV_THREADS', '6')), device)
+    # The LWS sweeps are a pipeline of ~100 stages per utterance: small batches are collected until LWS_GROUP utterances
+    # wait for their phase, refined in one launch and written in the order they came (32 utterances 4.8 ms, 256: 15 ms,
+    # DESIGN 4.3d); the per-batch lines below are printed when their files are queued.
+    lws_group = int(os.environ.get('AVSI_LWS_GROUP', '256'))
     pending = []                    # (enhanced, masks, paths, lengths) of batches whose phase is still to be refined
 
     def written(paths, lengths):
@@ -130,12 +168,13 @@ def infer(model_path, data_path_test, audio_path, out_file_prefix, norm=True, or
         else:
             wavs = torch.cat([p[0] for p in pending])
             masks = torch.cat([p[1] for p in pending])
-        # Reconstruct phase with LWS algorithm (reference inference.py:141-154), all collected batches on the device
-        out = lws_processor.refine_enhanced(wavs, masks, num_samples=wavs.shape[1]).cpu().numpy()
-        ops.coop_check()            # the read-back synchronised: a cooperative kernel that gave up its bounded wait (its
-        at = 0                      # outputs are invalid) raises HERE, before any file of these batches is written
+        # Reconstruct phase with LWS algorithm (reference inference.py:141-154), all collected batches on the device;
+        # nothing here waits for the GPU: the status words travel with the waveforms and are checked before a file is written
+        out = lws_processor.refine_enhanced(wavs, masks, num_samples=wavs.shape[1], check=False)
+        status = (ops.coop_status(device), lws_processor.status_word())
+        at = 0
         for _, _, paths, lengths in pending:
-            writer.submit(out[at:at + len(lengths)], paths, lengths)
+            writer.submit(out[at:at + len(lengths)], paths, lengths, status)
             at += len(lengths)
             written(paths, lengths)
         pending.clear()
@@ -153,12 +192,9 @@ def infer(model_path, data_path_test, audio_path, out_file_prefix, norm=True, or
         enhanced = model.enhanced_sources_oracle_phase if oracle_phase else model.enhanced_sources
         loss = model.loss                       # read back once, after the loop: no host round trip per batch
         loss = loss.detach().clone() if hasattr(loss, 'detach') else float(loss)
-        ops.coop_poll()
         loss_list.append(loss)
         if oracle_phase:
-            enhanced_host = enhanced.cpu().numpy()
-            ops.coop_check()                    # as in flush(): checked after the synchronising read-back, before the files
-            writer.submit(enhanced_host, test_sample_path, test_length)
+            writer.submit(enhanced, test_sample_path, test_length, (ops.coop_status(device),))
             written(test_sample_path, test_length)
             continue
         masks = model.masks
@@ -172,6 +208,7 @@ def infer(model_path, data_path_test, audio_path, out_file_prefix, norm=True, or
             flush()
     writer.close()          # every file is on disk (or its error raised) before the summary line
     ops.coop_check()
+    lws_processor.check()
     loss_list = [float(x) for x in loss_list]
 
     # np.mean over the batches of ALL ranks (reference inference.py:170), whatever share of them each rank had

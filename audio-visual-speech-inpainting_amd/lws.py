@@ -169,7 +169,13 @@ class lws(object):
         return out
 
     # ------------------------------------------------------------------------------------------------ inference.py:141-154
-    def refine_enhanced(self, enhanced, masks, num_samples=None):
+    def status_word(self):
+        """Device int32[1]: non-zero once a pipeline stage of a run on this object has given up waiting (see check())."""
+        if self._status is None:
+            return torch.zeros(1, dtype=torch.int32, device='cuda')
+        return self._status[:1]
+
+    def refine_enhanced(self, enhanced, masks, num_samples=None, check=True):
         """The reference's per-utterance block, batched on the device: ``enhanced`` [B, n] (output of
         ``enhanced_sources``: masked target phase, zero phase inside the gaps), ``masks`` [B, T, F] ->
         [B, num_samples or all] with the gap phases replaced by LWS estimates."""
@@ -195,5 +201,6 @@ class lws(object):
         _lib.check(L.avsi_lws_stitch_f32(_lib.ptr(rec), _lib.ptr(init), _lib.ptr(m), msb, m.stride(1), m.shape[1], m.shape[2],
                                          B, M, self.fftsize, _lib.stream_ptr()), "avsi_lws_stitch_f32")
         out = self._istft(rec, num_samples)
-        self.check()
+        if check:               # (synchronises; callers that check status_word() where the result arrives pass False)
+            self.check()
         return out

@@ -307,6 +307,17 @@ def coop_poll(device=None):
             event.record()
 
 
+def coop_status(device=None):
+    """One-element device int32 tensor, enqueued on the current stream: non-zero once any cooperative recurrent launch
+    issued so far on `device` has given up a bounded wait (the maximum of the sticky status words).  For consumers that
+    ship results off the device asynchronously and check the word where the results arrive (inference._WavWriter)."""
+    idx = torch.cuda.current_device() if device is None else torch.device(device).index
+    flags = [ws[:1] for (dev, _), ws in _COOP_WS.items() if dev == idx]
+    if not flags:
+        return torch.zeros(1, dtype=torch.int32, device=torch.device('cuda', idx))
+    return flags[0].clone() if len(flags) == 1 else torch.cat(flags).max().reshape(1)
+
+
 def coop_check(device=None):
     """Raise if a cooperative recurrent launch on `device` ever gave up waiting for its peer
     workgroups (its outputs are then invalid).  Synchronises with the device."""

@@ -514,6 +514,15 @@ int avsi_delta_f32(const float* x, float* y, int64_t B, int T, int F, int N, voi
  * stores masked CRC-32C values of the length and payload of every record. */
 uint32_t avsi_crc32c(const void* data, size_t n, uint32_t seed);
 
+/* Host helper (no GPU work): the WAV files of the inference driver, `wavfile.write(path, 16000,
+ * enhanced[:seq_len * 192].astype(np.int16))` (inference.py:159-162), for `count` utterances: samples [count][stride]
+ * float32 (host memory), num_samples[i] of row i go to paths[i] as 16-bit PCM mono with the 44-byte header
+ * scipy.io.wavfile.write produces; float -> int16 as numpy.astype on x86 (truncation toward zero, low 16 bits).
+ * make_dirs: create missing parent directories (os.makedirs(..., exist_ok=True)).  Thread-safe; the driver calls it
+ * from a few host threads outside the interpreter lock.  AVSI_ERR_INVALID_ARG if a file cannot be written. */
+int avsi_wav_write_batch_int16_host(const char* const* paths, const float* samples, int64_t stride,
+                                    const int32_t* num_samples, int count, int sample_rate, int make_dirs);
+
 /* Host helpers (no GPU work; HOST pointers; re-entrant): the native half of the TFRecord reader.  The
  * reference parses its samples inside TensorFlow's C++ input pipeline
  * (tf.parse_single_sequence_example over the 'fixed' schema, dataset_reader.py:62-79, with the
