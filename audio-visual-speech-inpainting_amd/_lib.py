@@ -162,6 +162,9 @@ PROTOTYPES = {
     "avsi_tfrecord_file_decode_fixed_host": (c_int, [c_char_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
                                                      c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p,
                                                      c_void_p]),
+    "avsi_tfrecord_files_decode_fixed_host": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
+                                                      c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p,
+                                                      c_void_p, c_void_p]),
     "avsi_ctc_beam_search_host_f32": (c_int, [c_void_p, c_int64, c_int64, c_int, c_int, c_int, c_void_p, c_int, c_int,
                                               c_void_p, c_int, c_void_p, c_void_p]),
     "avsi_wav_write_batch_int16_host": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_int, c_int, c_int]),

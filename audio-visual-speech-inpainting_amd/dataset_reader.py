@@ -269,9 +269,11 @@ class BatchIterator(object):
         self.decode_batch = decode_batch    # list of payloads -> batch tuple (native); None = parse + stack in Python
         self.prefetch = int(prefetch)
         self.upload = _Uploader(device, upload_fields) if device is not None else None
-        # with a device the consumer works on the uploaded copies, so the host arrays are recycled: a batch's numpy
-        # fields stay valid until prefetch + 2 further batches have been fetched
-        self._arenas = [{'_pin': True} for _ in range(self.prefetch + 3)] if device is not None else None
+        # with a device the consumer works on the uploaded copies, so the host arrays of the bulky fields (audio, video,
+        # mask, embedding) are recycled: they are valid only until the reader moves on -- use Batch.to_device()
+        # ... two arenas when they are page-locked: one is parsed into while the other's copies run (its next user waits for
+        # their event); pinning is the expensive part of a short run (~0.3 s per GB), so no more of them than needed
+        self._arenas = [{'_pin': True} for _ in range(2)] if device is not None else None
         self._made = 0
         self._gen = None
         self.initializer()
@@ -420,7 +422,7 @@ class DataManager:
         wav = alloc('wav', (B, n_wav), np.int32)
         emb = alloc('emb', (B, E), np.float32) if E else None
         paths = ctypes.create_string_buffer(B * 1024)
-        labels = alloc('labels', (B, n_lab), np.float32)
+        labels = np.empty((B, n_lab), dtype=np.float32)         # small, and read on the host (CTC): never from a recycled arena
         video = alloc('video', (B, Tv, self.video_feat_size), np.float32)
         mask = alloc('mask', (B, T, self.audio_feat_size), np.float32)
         paths_addr = ctypes.addressof(paths)
@@ -439,8 +441,25 @@ class DataManager:
                 row(lengths, i), row(wav, i), row(emb, i), paths_addr + i * 1024, 1024, row(labels, i), row(video, i),
                 row(mask, i))
         # records already in memory: serial on purpose (a record is ~0.2 ms of memcpy, which threads only contend on);
-        # files: on the pool -- the calls release the interpreter lock, and reading + checking a file is most of the work
-        codes = list(_pool().map(one, range(B))) if from_files and B > 1 else [one(i) for i in range(B)]
+        # files: on the pool, one contiguous SLICE of the batch per thread and native call (the calls release the interpreter
+        # lock; a task per record cost ~30 us of hand-over under the lock, which capped 1024-record batches at 14 k records/s)
+        if from_files and B > 1:
+            threads = min(_pool()._max_workers, max(1, B // 4))
+            step = -(-B // threads)
+            arr = (ctypes.c_char_p * B)(*paths_fs)
+            arr_addr = ctypes.addressof(arr)
+            codes_a = np.zeros(B, dtype=np.int32)
+
+            def some(lo):
+                n = min(step, B - lo)
+                L.avsi_tfrecord_files_decode_fixed_host(
+                    arr_addr + lo * ctypes.sizeof(ctypes.c_char_p), n, 1, n_wav, self.audio_feat_size, self.video_feat_size, E, T,
+                    Tv, n_lab, row(lengths, lo), row(wav, lo), row(emb, lo), paths_addr + lo * 1024, 1024, row(labels, lo),
+                    row(video, lo), row(mask, lo), codes_a.ctypes.data + 4 * lo)
+            list(_pool().map(some, range(0, B, step)))
+            codes = codes_a.tolist()
+        else:
+            codes = [one(i) for i in range(B)]
         for i, rc in enumerate(codes):
             if from_files and rc == _lib.AVSI_ERR_INVALID_ARG:
                 raise IOError("%s: unreadable, truncated, corrupted (crc mismatch) or malformed record" % payloads[i])

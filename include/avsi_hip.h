@@ -554,6 +554,13 @@ int avsi_tfrecord_file_decode_fixed_host(const char* path, int verify, int num_a
                                          int num_video_frames, int num_labels, int32_t* lengths2, int32_t* wav_i32,
                                          float* embedding, char* sample_path, int sample_path_cap, float* labels,
                                          float* video, float* mask);
+/* `count` such files in one call: row i of every output array ([count][...], contiguous) belongs to paths[i], codes[i] is
+ * that file's status, the return value the first non-zero one.  The reader hands each of its threads one slice of a batch. */
+int avsi_tfrecord_files_decode_fixed_host(const char* const* paths, int count, int verify, int num_audio_samples,
+                                          int audio_feat_size, int video_feat_size, int embedding_size, int num_frames,
+                                          int num_video_frames, int num_labels, int32_t* lengths2, int32_t* wav_i32,
+                                          float* embedding, char* sample_paths, int sample_path_cap, float* labels,
+                                          float* video, float* mask, int32_t* codes);
 
 #ifdef __cplusplus
 }
