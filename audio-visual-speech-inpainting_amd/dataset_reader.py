@@ -138,7 +138,8 @@ class Batch(tuple):
     to device tensors, ``ready`` is the event a consuming stream has to wait for (see ``to_device``)."""
     device_arrays = None
     ready = None
-    gap_count = None        # zero elements of the mask field, counted on the prefetch thread (training.gap_elements)
+    gap_count = None        # zero elements of the mask field: a device scalar counted behind the upload when the iterator was
+                            # asked to (get_iterator(count_gaps=True): the trainer's loss weights, training.gap_elements)
 
     def to_device(self, index):
         """Device tensor of field ``index`` (or None if it was not uploaded), ordered after the upload on the
@@ -160,9 +161,10 @@ class _Uploader(object):
     copies are asynchronous at the link's rate -- 600 MB per batch of 1024 utterances: 11 ms, where the pageable copy took
     60 ms, i.e. capped the driver at 17 k utterances/s whatever the GPU did -- and the training stream waits for the event."""
 
-    def __init__(self, device, fields):
+    def __init__(self, device, fields, count_gaps=False):
         import torch
         self.torch = torch
+        self.count_gaps = bool(count_gaps)
         self.fields = tuple(fields)         # positions of the batch tuple to upload (negative = from the end)
         self.device = torch.device(device)
         if self.device.type == 'cuda' and self.device.index is None:
@@ -180,8 +182,6 @@ class _Uploader(object):
             self.stream = torch.cuda.Stream(device=self.device, priority=-1)
         out = Batch(batch)
         out.device_arrays = {}
-        if isinstance(batch[-1], np.ndarray) and batch[-1].dtype != object:
-            out.gap_count = int(batch[-1].size - np.count_nonzero(batch[-1]))
         pinned = (arena or {}).get('_pinned', {})
         with torch.cuda.stream(self.stream):
             for i in sorted(f % len(batch) for f in self.fields):
@@ -192,6 +192,10 @@ class _Uploader(object):
                         out.device_arrays[i] = t[:a.shape[0]].to(self.device, non_blocking=True)
                     else:
                         out.device_arrays[i] = torch.from_numpy(np.ascontiguousarray(a)).to(self.device)
+            last = len(batch) - 1
+            if self.count_gaps and last in out.device_arrays:
+                # on the device, behind the copy (a scan of the host array cost the reader thread 60 ms per 1024 records)
+                out.gap_count = (out.device_arrays[last] == 0).sum()
             out.ready = torch.cuda.Event()
             out.ready.record(self.stream)
         if arena is not None:
@@ -257,7 +261,7 @@ class _Prefetcher(object):
 
 class BatchIterator(object):
     def __init__(self, dataset, batch_size, n_epochs, drop_remainder, shard=(0, 1), decode_batch=None, prefetch=2,
-                 device=None, upload_fields=(2, -2, -1), even_rounds=False):
+                 device=None, upload_fields=(2, -2, -1), even_rounds=False, count_gaps=False):
         self.dataset = dataset
         # data-parallel training does one collective per step: every rank must see the same number of batches, so
         # batches are dealt in whole rounds of `world` and a last incomplete round (and a short last batch) is dropped
@@ -268,7 +272,7 @@ class BatchIterator(object):
         self.shard = shard
         self.decode_batch = decode_batch    # list of payloads -> batch tuple (native); None = parse + stack in Python
         self.prefetch = int(prefetch)
-        self.upload = _Uploader(device, upload_fields) if device is not None else None
+        self.upload = _Uploader(device, upload_fields, count_gaps) if device is not None else None
         # with a device the consumer works on the uploaded copies, so the host arrays of the bulky fields (audio, video,
         # mask, embedding) are recycled: they are valid only until the reader moves on -- use Batch.to_device()
         # ... two arenas when they are page-locked: one is parsed into while the other's copies run (its next user waits for
@@ -372,14 +376,15 @@ class DataManager:
         return Dataset(file_list, shuffle, seed, self.buffer_size, self.read_data_format_fixed)
 
     def get_iterator(self, dataset, batch_size=16, n_epochs=None, drop_remainder=False, shard=(0, 1), native=True,
-                     prefetch=2, device=None, even_rounds=False):
+                     prefetch=2, device=None, even_rounds=False, count_gaps=False):
         """`shard=(rank, world)` deals whole batches round-robin to data-parallel ranks.  `native=False`
         parses with the pure-Python decoder, `prefetch=0` parses on the caller's thread, `device` (e.g. 'cuda')
         also uploads audio / video / mask from the prefetch thread (see `Batch`), `even_rounds` gives every rank the same
         number of (full) batches -- what a training loop with one collective per step needs."""
         it = BatchIterator(dataset, batch_size, n_epochs, drop_remainder, shard,
                            decode_batch=self.decode_batch if native else None, prefetch=prefetch, device=device,
-                           upload_fields=(2, 3, -2, -1) if self.embedding_size else (2, -2, -1), even_rounds=even_rounds)
+                           upload_fields=(2, 3, -2, -1) if self.embedding_size else (2, -2, -1), even_rounds=even_rounds,
+                           count_gaps=count_gaps)
         return it, it
 
     def decode_batch(self, payloads, arena=None):

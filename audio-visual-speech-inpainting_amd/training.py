@@ -104,10 +104,11 @@ def unpack_batch(batch, with_embeddings, with_labels=False):
 
 def gap_elements(batch):
     """Number of zero elements of the batch's mask (the weight of the running loss means, training_emb.py:252).
-    Counted by the reader's prefetch thread when the batch came through it (dataset_reader.Batch.gap_count): on the
-    training thread the scan of 2 M mask elements cost more host time per step than launching the step."""
+    Counted on the device behind the reader's upload when the batch came through it (dataset_reader.Batch.gap_count, a
+    device scalar that `book` resolves one step late with the losses): on the training thread the scan of 2 M mask
+    elements cost more host time per step than launching the step."""
     n = getattr(batch, 'gap_count', None)
-    return int(n) if n is not None else int(np.count_nonzero(batch[-1] == 0))
+    return n if n is not None else int(np.count_nonzero(batch[-1] == 0))
 
 
 def train(config_file, checkpoint_format=None):
@@ -150,10 +151,10 @@ def train(config_file, checkpoint_format=None):
     train_dm, val_dm = manager(), manager()
     _, train_it = train_dm.get_iterator(train_dm.get_dataset(train_files, shuffle=True, seed=1234 if world > 1 else None),
                                         batch_size=config['batch_size'], n_epochs=1, shard=(rank, world), device=device,
-                                        even_rounds=True)
+                                        even_rounds=True, count_gaps=True)
     val_files = sorted(glob(os.path.join(data_path_val, '*.tfrecord')))
     _, val_it = val_dm.get_iterator(val_dm.get_dataset(val_files, shuffle=False), batch_size=config['batch_size'],
-                                    n_epochs=1, shard=(rank, world), device=device)
+                                    n_epochs=1, shard=(rank, world), device=device, count_gaps=True)
 
     ctc = is_ctc(config)
     audio_feat_mean = np.load(config['audio_feat_mean'])
@@ -277,6 +278,7 @@ def train(config_file, checkpoint_format=None):
             """Bookkeeping of one finished training step (reference training_emb.py:244-262)."""
             nonlocal train_avg, nframe_sum
             vals = resolve(vals)
+            frames = int(frames)        # (a device scalar when the reader counted the gap elements: resolved with the losses)
             if world > 1:
                 # every rank must leave at the SAME step (a rank that exits alone leaves its peers waiting in the
                 # next gradient all-reduce).  The verdict came with the gradients: the last all-reduce bucket of the
@@ -348,7 +350,7 @@ def train(config_file, checkpoint_format=None):
             n_step += 1
             model.set_dropout_rate(0.0)                             # training_emb.py:314,326
             model.feed(**feed)
-            val_avg, nframe_sum = accumulate(val_avg, resolve(fetch(False)), nframe_sum, gap_elements(batch), n_step == 1)
+            val_avg, nframe_sum = accumulate(val_avg, resolve(fetch(False)), nframe_sum, int(gap_elements(batch)), n_step == 1)
             if chief and (n_step % 200 == 0 or n_step == 1):
                 print('Step[{:7d}] Loss[{:3.5f}]'.format(n_step, val_avg[1]))
         model.is_training = True

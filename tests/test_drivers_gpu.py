@@ -126,8 +126,8 @@ def test_infer_default_phase_is_lws_refined(experiment, monkeypatch):
     seen = []
     orig = lws_mod.lws.refine_enhanced
 
-    def spy(self, enhanced, masks, num_samples=None):
-        out = orig(self, enhanced, masks, num_samples)
+    def spy(self, enhanced, masks, num_samples=None, **kw):
+        out = orig(self, enhanced, masks, num_samples, **kw)
         seen.append((enhanced.cpu().numpy(), out.cpu().numpy()))
         return out
     monkeypatch.setattr(lws_mod.lws, "refine_enhanced", spy)
@@ -150,9 +150,9 @@ def test_infer_collects_batches_for_one_lws_launch(experiment, monkeypatch):
     calls = []
     orig = lws_mod.lws.refine_enhanced
 
-    def spy(self, enhanced, masks, num_samples=None):
+    def spy(self, enhanced, masks, num_samples=None, **kw):
         calls.append(int(enhanced.shape[0]))
-        return orig(self, enhanced, masks, num_samples)
+        return orig(self, enhanced, masks, num_samples, **kw)
     monkeypatch.setattr(lws_mod.lws, "refine_enhanced", spy)
     outs = {}
     for group in (1, 4, 128):
@@ -283,7 +283,9 @@ def test_reader_uploads_batches_from_its_prefetch_thread(experiment):
         np.testing.assert_array_equal(feed['target_sources'].cpu().numpy(), r[2])
         np.testing.assert_array_equal(feed['video_features'].cpu().numpy(), r[5])
         np.testing.assert_array_equal(feed['masks'].cpu().numpy(), r[6])
-        np.testing.assert_array_equal(b[6], r[6])             # the host copy is still there
+        # (the HOST arrays of the bulky fields are views of two page-locked arenas the reader recycles: only valid until it
+        # moves on, which it already may have -- consumers use the device copies; the small fields are copies)
+        np.testing.assert_array_equal(b[0], r[0])
         assert list(paths) == list(r[3])
     assert n == 3
 

@@ -13,7 +13,7 @@ n_train = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 batch = int(sys.argv[2]) if len(sys.argv) > 2 else 32
 model = sys.argv[3] if len(sys.argv) > 3 else 'av-blstm'
 N, T = 48000, 250
-base = tempfile.mkdtemp(prefix='avsi_e2e_')
+base = tempfile.mkdtemp(prefix='avsi_e2e_', dir='/dev/shm' if os.path.isdir('/dev/shm') else None)
 rng = np.random.default_rng(0)
 
 
@@ -50,9 +50,16 @@ open(cfg, "w").write("\n".join([
     "num_asr_labels = 33", "ctc_loss = 0.001",
     "root_folder = %s" % os.path.join(base, "data"), "exp_folder = %s" % os.path.join(base, "logs", "exp"), "device = /gpu:0",
     "audio_feat_mean = %s" % os.path.join(base, "mean.npy"), "audio_feat_std = %s" % os.path.join(base, "std.npy"), ""]))
+import contextlib, io, re
 t0 = time.time()
-m = training.train(cfg)
+out = io.StringIO()
+with contextlib.redirect_stdout(out):
+    m = training.train(cfg)
 dt = time.time() - t0
 steps = m.global_step
+epochs = [float(x) for x in re.findall(r"Epoch training time \(seconds\) = ([0-9.]+)", out.getvalue())]
+per_epoch = steps // max(1, len(epochs))
+print("inside an epoch (reading, parsing, upload, step, loss bookkeeping): " + ", ".join(
+    "%.2f ms / step" % (e / per_epoch * 1e3) for e in epochs) + "  (%d steps per epoch)" % per_epoch, flush=True)
 print("model %s: %d steps of %d in %.2f s (3 epochs incl. validation and checkpoints): %.1f ms / step, %.0f utterances/s end to end"
       % (model, steps, batch, dt, dt / steps * 1e3, steps * batch / dt))
