@@ -138,8 +138,12 @@ class Batch(tuple):
     to device tensors, ``ready`` is the event a consuming stream has to wait for (see ``to_device``)."""
     device_arrays = None
     ready = None
-    gap_count = None        # zero elements of the mask field: a device scalar counted behind the upload when the iterator was
-                            # asked to (get_iterator(count_gaps=True): the trainer's loss weights, training.gap_elements)
+    def gap_count(self):
+        """Zero elements of the mask field as a DEVICE scalar (None without an uploaded mask), counted on the current
+        stream behind the upload -- the trainer's loss weights (training.gap_elements): a scan of the host array cost 2 ms
+        per 32 records, and kernels on the upload stream itself slow the step down (see _Uploader)."""
+        t = self.to_device(len(self) - 1)
+        return None if t is None else (t == 0).sum()
 
     def to_device(self, index):
         """Device tensor of field ``index`` (or None if it was not uploaded), ordered after the upload on the
@@ -159,7 +163,7 @@ class _Uploader(object):
     stream of its own, one event per batch.  The reference's feed_dict crossing is a synchronous pageable copy
     on the training thread; here the records are parsed straight into PINNED arenas (DataManager.decode_batch) and the
     copies are asynchronous at the link's rate -- 600 MB per batch of 1024 utterances: 11 ms, where the pageable copy took
-    60 ms, i.e. capped the driver at 17 k utterances/s whatever the GPU did -- and the training stream waits for the event."""
+    32 ms -- and the training stream waits for the event."""
 
     def __init__(self, device, fields, count_gaps=False):
         import torch
@@ -175,11 +179,17 @@ class _Uploader(object):
         torch = self.torch
         if self.stream is None:
             torch.cuda.set_device(self.device)
-            # high priority: HIP maps its streams onto four hardware queues per priority level, and a normal stream created
-            # after the model's side streams can land on the queue of the launch stream, where the upload and its event
-            # would sit in order between the step's kernels (tools/hostfed_probe.py: a 3.7 GB upload then adds its full
-            # 67 ms to a 140 ms step instead of hiding under it); queues of another priority level are not shared
-            self.stream = torch.cuda.Stream(device=self.device, priority=-1)
+            nbytes = sum(a.nbytes for a in batch if isinstance(a, np.ndarray) and a.dtype != object)
+            # HIP maps its streams onto four hardware queues per priority level, and a normal stream created after the
+            # model's side streams can land on the queue of the launch stream, where the upload and its event sit in order
+            # between the step's kernels (tools/hostfed_probe.py: a 3.7 GB upload then adds its full 67 ms to a 140 ms step
+            # instead of hiding under it); queues of another priority level are not shared.  But work on a high-priority
+            # queue holds the cooperative recurrent kernels of a small-batch training step back, copies included (8.2
+            # instead of 6.9 ms per step of 32 utterances).  So: high priority for batches whose upload is worth hiding
+            # (tens of MB: the steps behind them are long), normal priority for small ones.  AVSI_UPLOAD_PRIORITY overrides.
+            prio = os.environ.get('AVSI_UPLOAD_PRIORITY')
+            prio = int(prio) if prio is not None else (-1 if nbytes >= (64 << 20) else 0)
+            self.stream = torch.cuda.Stream(device=self.device, priority=prio)
         out = Batch(batch)
         out.device_arrays = {}
         pinned = (arena or {}).get('_pinned', {})
@@ -192,10 +202,6 @@ class _Uploader(object):
                         out.device_arrays[i] = t[:a.shape[0]].to(self.device, non_blocking=True)
                     else:
                         out.device_arrays[i] = torch.from_numpy(np.ascontiguousarray(a)).to(self.device)
-            last = len(batch) - 1
-            if self.count_gaps and last in out.device_arrays:
-                # on the device, behind the copy (a scan of the host array cost the reader thread 60 ms per 1024 records)
-                out.gap_count = (out.device_arrays[last] == 0).sum()
             out.ready = torch.cuda.Event()
             out.ready.record(self.stream)
         if arena is not None:

@@ -36,18 +36,8 @@ def init(backend=None):
             backend = os.environ.get("AVSI_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         if torch.cuda.is_available():
             torch.cuda.set_device(local_rank % torch.cuda.device_count())
-        prefer_high_priority_collectives()
         dist.init_process_group(backend, rank=rank, world_size=world)
     return rank, world
-
-
-def prefer_high_priority_collectives():
-    """The communicator's stream on a high-priority hardware queue (TORCH_NCCL_HIGH_PRIORITY, unless the user set it): HIP
-    multiplexes streams onto four hardware queues per priority level, and a collective stream that shares its queue with
-    the launch stream or a side stream runs IN ORDER with that stream's kernels -- the bucketed all-reduce would then wait
-    behind the BPTT it is meant to overlap (tools/hostfed_probe.py shows the effect for an upload stream).  Must run
-    before the process group is created."""
-    os.environ.setdefault('TORCH_NCCL_HIGH_PRIORITY', '1')
 
 
 def collectives_share_the_gpu():

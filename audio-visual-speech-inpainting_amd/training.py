@@ -102,12 +102,52 @@ def unpack_batch(batch, with_embeddings, with_labels=False):
     return feed, paths
 
 
+class _LateScalars(object):
+    """Device scalars of one step, read ONE STEP LATE without waiting for the step in between.
+
+    ``float(tensor)`` is a device-to-host copy on the current stream: issued after the next step has been enqueued it
+    waits for THAT step too, the host then starts launching the step after it on an idle GPU, and every step pays its
+    launch time in the open (7.9 ms per step of 32 utterances against 6.2 ms of kernels).  Here the values of step k are
+    gathered into one small tensor and copied to a page-locked buffer behind step k's own kernels, with an event; step
+    k + 1 is enqueued, and only then the host waits for that EVENT -- which the GPU passed before it started step k + 1."""
+
+    def __init__(self, n=3):
+        self.slots = []
+        self.n = n
+        self.at = 0
+
+    def push(self, values):
+        import torch
+        dev = [i for i, v in enumerate(values) if isinstance(v, torch.Tensor) and v.is_cuda]
+        out = {'values': list(values), 'dev': dev, 'event': None, 'host': None}
+        if dev:
+            if len(self.slots) < self.n:
+                self.slots.append(torch.empty(16, dtype=torch.float64).pin_memory())
+            host = self.slots[self.at % self.n]
+            self.at += 1
+            packed = torch.stack([values[i].reshape(-1)[0].to(torch.float64) for i in dev])
+            host[:len(dev)].copy_(packed, non_blocking=True)
+            out['event'] = torch.cuda.Event()
+            out['event'].record()
+            out['host'] = host
+        return out
+
+    @staticmethod
+    def get(handle):
+        vals = list(handle['values'])
+        if handle['event'] is not None:
+            handle['event'].synchronize()
+            for j, i in enumerate(handle['dev']):
+                vals[i] = float(handle['host'][j])
+        return [float(v) for v in vals]
+
+
 def gap_elements(batch):
     """Number of zero elements of the batch's mask (the weight of the running loss means, training_emb.py:252).
     Counted on the device behind the reader's upload when the batch came through it (dataset_reader.Batch.gap_count, a
     device scalar that `book` resolves one step late with the losses): on the training thread the scan of 2 M mask
     elements cost more host time per step than launching the step."""
-    n = getattr(batch, 'gap_count', None)
+    n = batch.gap_count() if hasattr(batch, 'gap_count') else None
     return n if n is not None else int(np.count_nonzero(batch[-1] == 0))
 
 
@@ -225,6 +265,18 @@ def train(config_file, checkpoint_format=None):
         print('\n'.join(header))
         print('')
 
+    # The steps are launched on a HIGH-PRIORITY stream.  HIP multiplexes streams onto a few hardware queues per priority
+    # level, and which of the model's side streams (weight-gradient GEMMs beside the BPTT of the layers below) happens to
+    # share a queue with the launch stream decides what overlaps: with the legacy default stream the same step took 6.3 to
+    # 7.4 ms depending on how many streams the process had created before (tools/train_step_time.py).  A queue of another
+    # priority level is shared with none of them, and the cooperative recurrent grids get their CUs before the side grids.
+    prev_stream = None
+    if os.environ.get('AVSI_TRAIN_STREAM', 'high') == 'high':
+        prev_stream = torch.cuda.current_stream(device)
+        launch_stream = torch.cuda.Stream(device=device, priority=-1)
+        launch_stream.wait_stream(prev_stream)
+        torch.cuda.set_stream(launch_stream)
+
     tot_step = model.global_step
     epoch_counter = int(tot_step / n_steps_epoch) if n_steps_epoch else 0
     best_val_checkpoint = (0, 0)
@@ -247,11 +299,14 @@ def train(config_file, checkpoint_format=None):
             return [model.loss, model.loss_func]
         return [model.loss_func] * 2
 
+    late = _LateScalars()
+    # AVSI_TRAIN_TIMING=1: host time of the phases of a training iteration, printed at the end (diagnostics)
+    timing = [0.0] * 6 if os.environ.get('AVSI_TRAIN_TIMING') else None
+
     def resolve(vals):
-        """Device scalars -> floats.  Called one step late in the training loop: reading a loss is a host
-        synchronisation, and doing it right after enqueuing the step would leave the GPU idle while the host
-        prepares the next one (12.3 -> ~9 ms per step of 32 utterances).  The NaN / Inf abort therefore fires one
-        step after the offending batch."""
+        """Device scalars -> floats, synchronously (validation loop).  The training loop reads its scalars one step
+        late through `late` instead (see _LateScalars); the NaN / Inf abort therefore fires one step after the
+        offending batch."""
         vals = [float(x) for x in vals]
         ops.coop_check()                # the float() above synchronised; a cooperative-kernel timeout aborts here
         return vals
@@ -277,8 +332,11 @@ def train(config_file, checkpoint_format=None):
         def book(vals, frames, n_step, tot_step, lr):
             """Bookkeeping of one finished training step (reference training_emb.py:244-262)."""
             nonlocal train_avg, nframe_sum
-            vals = resolve(vals)
-            frames = int(frames)        # (a device scalar when the reader counted the gap elements: resolved with the losses)
+            # [losses ..., (non-finite word of all ranks,) gap elements, cooperative-kernel status word] of that step
+            vals = _LateScalars.get(vals)
+            if vals.pop() != 0.0:
+                raise ops._lib.AvsiError(ops._COOP_MSG)
+            frames = int(vals.pop())
             if world > 1:
                 # every rank must leave at the SAME step (a rank that exits alone leaves its peers waiting in the
                 # next gradient all-reduce).  The verdict came with the gradients: the last all-reduce bucket of the
@@ -306,6 +364,8 @@ def train(config_file, checkpoint_format=None):
                 print('Model checkpoint saved in file %s' % save_checkpoint(os.path.join(checkpoints_dir, 'ckpt')))
 
         while True:
+            if timing is not None:
+                t_a = time()
             try:
                 batch = train_it.get_next()
                 feed, _ = unpack_batch(batch, uses_embeddings(config), ctc)
@@ -326,15 +386,29 @@ def train(config_file, checkpoint_format=None):
                 break
             n_step += 1
             tot_step += 1
+            if timing is not None:
+                t_b = time()
             model.set_dropout_rate(config['dropout_rate'])          # training_emb.py:251
             model.feed(**feed)
             vals, lr = fetch(True), model.learning_rate
+            if timing is not None:
+                t_c = time()
             model.train_op
+            if timing is not None:
+                t_d = time()
             if world > 1:
                 vals = list(vals) + [model.nonfinite_flag]
-            step_done, pending = pending, (vals, gap_elements(batch), n_step, tot_step, lr)
+            vals = late.push(list(vals) + [gap_elements(batch), ops.coop_status(device)])
+            step_done, pending = pending, (vals, None, n_step, tot_step, lr)
+            if timing is not None:
+                t_e = time()
             if step_done is not None:
                 book(*step_done)
+            if timing is not None:
+                t_f = time()
+                for i, dt_ in enumerate((t_b - t_a, t_c - t_b, t_d - t_c, t_e - t_d, t_f - t_e)):
+                    timing[i] += dt_
+                timing[5] += 1
         if chief:
             print('Start validation set evaluation...')
         model.is_training = False          # validation: no BPTT reserve, no gradient stream
@@ -390,6 +464,12 @@ def train(config_file, checkpoint_format=None):
             break
 
     log.close()
+    if timing is not None and timing[5]:
+        print('host ms per training iteration: next batch %.2f, feed + forward launches %.2f, backward + update launches %.2f, '
+              'scalars %.2f, wait for the step before %.2f' % tuple(1e3 * t / timing[5] for t in timing[:5]), file=sys.stderr)
+    if prev_stream is not None:
+        torch.cuda.current_stream(device).synchronize()
+        torch.cuda.set_stream(prev_stream)
     if chief:
         if cneg_epochs >= config['n_earlystop_epochs']:
             print('+---- Done training: early stopped ----+')

@@ -53,8 +53,15 @@ open(cfg, "w").write("\n".join([
 import contextlib, io, re
 t0 = time.time()
 out = io.StringIO()
+prof = None
+if os.environ.get('AVSI_PROFILE'):
+    import cProfile
+    prof = cProfile.Profile()
 with contextlib.redirect_stdout(out):
-    m = training.train(cfg)
+    m = prof.runcall(training.train, cfg) if prof else training.train(cfg)
+if prof:
+    import pstats
+    st = io.StringIO(); pstats.Stats(prof, stream=st).sort_stats('tottime').print_stats(28); print(st.getvalue()[:6000])
 dt = time.time() - t0
 steps = m.global_step
 epochs = [float(x) for x in re.findall(r"Epoch training time \(seconds\) = ([0-9.]+)", out.getvalue())]
