@@ -471,6 +471,107 @@ AV_WGRAD_FLOPS = 2.0 * ((393 + 500 + 500) * 2000 * 250 + 6 * 250 * 1000 * 249 + 
 ISTFT_BYTES = 250 * 257 * 4 * 2 + 250 * 257 * 8 + 48000 * 4     # prediction + mask + complex target STFT in, waveform out
 
 
+def e2e_workloads(torch, device):
+    """The reference's drivers end to end on GRID-sized records (one TFRecord file per utterance, as its datasets have them)
+    under /dev/shm: `infer()` -- records in, int16 WAV files out: reading, parsing, upload, network, waveform reconstruction,
+    (LWS phase refinement,) read-back and file writing (inference.py:121-170) -- and `train()` (training_emb.py:214-363:
+    reading, parsing, upload, step, loss bookkeeping; the per-step figure is the time inside an epoch).  What a drop-in user
+    of `speech_inpainting_main.py inference / training` gets from one GPU, next to the resident-input kernel rates above."""
+    import contextlib
+    import io
+    import re
+    import shutil
+    import struct
+    import tempfile
+    from avsi_amd import inference, training, tfrecord_io as tio
+    from avsi_amd.config_utils import check_trainconfiguration, load_configfile
+    out = {}
+    base = tempfile.mkdtemp(prefix='avsi_bench_e2e_', dir='/dev/shm' if os.path.isdir('/dev/shm') else None)
+    try:
+        n_infer, n_train = 16384, 2048
+        rng = np.random.default_rng(0)
+        wav = np.round(rng.normal(0, 3000, N_SAMPLES)).astype(np.float32)
+        mask = np.ones((T_FRAMES, F_BINS), np.float32)
+        mask[100:100 + GAP_FRAMES] = 0
+        video = rng.normal(size=(T_FRAMES, 136)).astype(np.float32)
+        # one record, serialised once; every file gets its own sample path (same length) and checksum
+        tag = b"clip_0000000"
+        payload = bytearray(tio.serialize_sample_fixed(T_FRAMES, 20, wav, video, mask, np.zeros(50, np.float32), tag.decode()))
+        at = bytes(payload).index(tag)
+        head = struct.pack('<Q', len(payload))
+        head += struct.pack('<I', tio.masked_crc32c(head))
+        root = os.path.join(base, "data", "test-set")
+        os.makedirs(root)
+        t0 = time.perf_counter()
+        for i in range(n_infer):
+            payload[at:at + len(tag)] = b"clip_%07d" % i
+            body = bytes(payload)
+            with open(os.path.join(root, "data_%05d.tfrecord" % (i + 1)), 'wb') as fh:
+                fh.write(head + body + struct.pack('<I', tio.masked_crc32c(body)))
+        for name, n in (("training-set", n_train), ("validation-set", 64)):
+            d = os.path.join(base, "data", name)
+            os.makedirs(d)
+            for i in range(n):
+                os.link(os.path.join(root, "data_%05d.tfrecord" % (i + 1)), os.path.join(d, "data_%05d.tfrecord" % (i + 1)))
+            np.save(os.path.join(d, "seq_lengths.npy"), np.full(n, T_FRAMES))
+        t_write = time.perf_counter() - t0
+        net = os.path.join(base, "logs", "exp", "netmodel")
+        os.makedirs(net)
+        np.save(os.path.join(base, "mean.npy"), np.zeros(F_BINS))
+        np.save(os.path.join(base, "std.npy"), np.full(F_BINS, 3.0))
+        cfg_lines = ["model = av-blstm", "audio_feat_dim = 257", "video_feat_dim = 136", "audio_len = %d" % N_SAMPLES,
+                     "batch_size = 32", "net_dim = [250, 250, 250]", "dropout_rate = 0.0", "max_n_epochs = 2",
+                     "n_earlystop_epochs = 5", "optimizer_type = adam", "starter_learning_rate = 0.001", "lr_decay = 1.0",
+                     "lr_updating_steps = 10000", "l2 = 0.0", "num_asr_labels = 33", "ctc_loss = 0.001", "learning_rate = 0.001",
+                     "integration_layer = 0", "root_folder = %s" % os.path.join(base, "data"),
+                     "exp_folder = %s" % os.path.join(base, "logs", "exp"), "device = /gpu:0",
+                     "audio_feat_mean = %s" % os.path.join(base, "mean.npy"), "audio_feat_std = %s" % os.path.join(base, "std.npy"), ""]
+        cfg_file = os.path.join(base, "train.config")
+        open(cfg_file, "w").write("\n".join(cfg_lines))
+
+        # ---- train(): two epochs of 64 steps of 32 utterances (configs[3]'s per-GPU share), then its checkpoint serves infer()
+        buf = io.StringIO()
+        t0 = time.perf_counter()
+        with contextlib.redirect_stdout(buf):
+            training.train(cfg_file)
+        t_train = time.perf_counter() - t0
+        epochs = [float(x) for x in re.findall(r"Epoch training time \(seconds\) = ([0-9.]+)", buf.getvalue())]
+        steps = n_train // 32
+        out["e2e_train_b32"] = {
+            "workload": "training.train() end to end on %d GRID-sized TFRecord files under /dev/shm, batch 32: ms per step INSIDE an "
+                        "epoch (reading, parsing, upload, step, loss bookkeeping), best epoch of %d" % (n_train, len(epochs)),
+            "per_gpu_batch": 32, "ms_per_step": min(epochs) / steps * 1e3, "value": 32 * steps / min(epochs), "unit": "utterances/s",
+            "whole_call_s": t_train, "epochs_s": epochs}
+
+        def run_infer(n, batch, oracle_phase, tag_):
+            sub = os.path.join(base, "sub_%s" % tag_)
+            os.makedirs(sub)
+            for i in range(n):
+                os.link(os.path.join(root, "data_%05d.tfrecord" % (i + 1)), os.path.join(sub, "data_%05d.tfrecord" % (i + 1)))
+            best = None
+            for rep in range(2):
+                t0_ = time.perf_counter()
+                with contextlib.redirect_stdout(io.StringIO()):
+                    inference.infer(net, sub, os.path.join(base, "audio_%s_%d" % (tag_, rep)), "enh", norm=True,
+                                    oracle_phase=oracle_phase, batch_size=batch)
+                dt = time.perf_counter() - t0_
+                best = dt if best is None else min(best, dt)
+                shutil.rmtree(os.path.join(base, "audio_%s_%d" % (tag_, rep)), ignore_errors=True)
+            return {"workload": "inference.infer() end to end: %d TFRecord files -> int16 WAV files under /dev/shm, batch %d, %s; whole "
+                                "call including model construction and checkpoint restore, best of 2" % (
+                                    n, batch, "oracle phase" if oracle_phase else "LWS phase refinement (the reference's default)"),
+                    "per_gpu_batch": batch, "utterances": n, "seconds": best, "ms_per_step": best / (n / batch) * 1e3,
+                    "value": n / best, "unit": "utterances/s"}
+        out["e2e_infer_b1024_oracle_phase"] = run_infer(n_infer, 1024, True, "o1024")
+        out["e2e_infer_b1024"] = run_infer(n_infer, 1024, False, "l1024")
+        out["e2e_infer_b32_oracle_phase"] = run_infer(4096, 32, True, "o32")
+        out["e2e_infer_b32"] = run_infer(4096, 32, False, "l32")
+        out["e2e_dataset"] = {"files": n_infer, "bytes_per_file": len(payload) + 16, "written_in_s": t_write, "where": base.rsplit('/', 1)[0]}
+    finally:
+        shutil.rmtree(base, ignore_errors=True)
+    return out
+
+
 def extra_workloads(torch, models, ops, ap_mod, cfg, mean, std, device):
     """N = 1 only: the other configurations of BASELINE.json and the steps either side of the path, each with its own
     ms_per_step and an ALGORITHMIC (unpadded) roofline figure: AV training at 8192 utterances (configs[2]), the U-Net at
@@ -861,6 +962,12 @@ def main():
             if world == 1:
                 progress["at"] = "also (training at 8192, U-Net, inverse STFT, LWS at 1024, host-fed step)"
                 also.update(extra_workloads(torch, models, ops, ap_mod, cfg, mean, std, device))
+                progress["at"] = "also (drivers end to end: train(), infer())"
+                torch.cuda.empty_cache()
+                try:
+                    also.update(e2e_workloads(torch, device))
+                except Exception as e:
+                    also["e2e"] = {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
         except Exception as e:
             also = {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
         dog.cancel()
