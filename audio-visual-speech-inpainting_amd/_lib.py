@@ -137,6 +137,10 @@ PROTOTYPES = {
     "avsi_diag_occupy_cus": (c_int, [c_int, c_void_p, c_int, c_void_p]),
     "avsi_conv2d_f32": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_int,
                                 c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p]),
+    "avsi_conv2d_splitk_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int]),
+    "avsi_conv2d_splitk_suggest": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, c_int]),
+    "avsi_conv2d_splitk_f32": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p,
+                                       c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_size_t, c_void_p]),
     "avsi_conv2d_thin_f32": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_int,
                                      c_void_p, c_int, c_void_p, c_int, c_void_p]),
     "avsi_split_sumpool_f32": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_int, c_int, c_int,

@@ -576,7 +576,7 @@ __global__ __launch_bounds__(256, BNT == 256 ? 2 : (BK == 16 ? (NST == 3 ? 3 : 4
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         const int col = n0 + wn * (32 * TN) + j * 32 + li;
-        bv[j] = (g.bias && col < g.N) ? g.bias[col] : 0.f;
+        bv[j] = (g.bias && col < g.N && blockIdx.z == 0) ? g.bias[col] : 0.f;      // (split launches: the bias goes into slab 0)
     }
     // Fast path of the 128 x 256 tile (whole tile inside the matrix, plain C = alpha A.B + bias): one 64-bit add per
     // store instead of the general addressing / masking / row-map code below.  Measured on the three layer GEMMs
@@ -803,6 +803,79 @@ extern "C" int avsi_conv2d_f32(const float* src0, int C0, int ld0, const float* 
         hipLaunchKernelGGL((gemm_dma_kernel<false, false, 16, 3, true, 128>), grid, block, (size_t)3 * (128 + 128) * 16 * 4, st, g);
     return avsi_launch_status();
 }
+
+int avsi_sum_slabs_launch(const float* slabs, int64_t n, int count, int64_t stride, float* out, float alpha,
+                          hipStream_t st);
+
+// The same convolution with the reduction over (tap, channel) cut into `splits` chunks (grid.z), partial slabs summed in
+// chunk order by a second kernel (deterministic, like avsi_gemm_splitk_f32).  For the layers whose output is only a few
+// tiles: at the reference's batch of 32 the 128-channel layers of the U-Net are 4 .. 64 output tiles on a 256-CU chip,
+// each walking 36 .. 144 k-tiles on its own (134 us a launch whatever the size); cut to ~8 k-tiles per workgroup they
+// fill the chip.  splits <= 1 or a workspace too small for the slabs: the plain launch.
+extern "C" size_t avsi_conv2d_splitk_workspace_bytes(int B, int H, int W, int ldo, int splits) {
+    if (B <= 0 || H <= 0 || W <= 0 || ldo <= 0 || splits < 2) return 0;
+    return (size_t)splits * (size_t)B * H * W * (size_t)ldo * sizeof(float);
+}
+
+// splits that fill the chip about once with at least `min_ktiles` 16-deep k-tiles per workgroup (1 = do not split)
+extern "C" int avsi_conv2d_splitk_suggest(int B, int H, int W, int k, int C0, int C1, int Cout) {
+    if (B <= 0 || H <= 0 || W <= 0 || k < 1 || Cout <= 0 || C0 + C1 <= 0) return 1;
+    const int64_t M = (int64_t)B * H * W;
+    const int bnt = Cout <= 32 ? 32 : (Cout <= 64 ? 64 : 128);
+    const int64_t tiles = avsi_ceil_div(M, 128) * avsi_ceil_div(Cout, bnt);
+    const int ktiles = k * k * (C0 + C1) / 16;
+    if (tiles >= AVSI_NUM_CU / 2 || ktiles < 16) return 1;
+    int splits = (int)(AVSI_NUM_CU / tiles);
+    const int max_by_depth = ktiles / 8;                 // at least 8 k-tiles per workgroup
+    if (splits > max_by_depth) splits = max_by_depth;
+    return splits < 2 ? 1 : splits;
+}
+
+extern "C" int avsi_conv2d_splitk_f32(const float* src0, int C0, int ld0, const float* src1_coarse, int C1, int ld1, int B, int H,
+                                      int W, int k, const float* filter, int ldf, const float* bias, int Cout, float* out,
+                                      int ldo, const float* zeros64, int splits, void* workspace, size_t workspace_bytes,
+                                      void* stream) {
+    if (splits < 2 || ldo != Cout || !workspace || workspace_bytes < avsi_conv2d_splitk_workspace_bytes(B, H, W, ldo, splits))
+        return avsi_conv2d_f32(src0, C0, ld0, src1_coarse, C1, ld1, B, H, W, k, filter, ldf, bias, Cout, out, ldo, zeros64, stream);
+    if (!filter || !out || !zeros64 || B <= 0 || H <= 0 || W <= 0 || k < 1 || !(k & 1) || Cout <= 0 || C0 < 0 || C1 < 0)
+        return AVSI_ERR_INVALID_ARG;
+    if ((C0 && !src0) || (C1 && !src1_coarse) || ldf < Cout || ldo < Cout || (C0 && ld0 < C0) || (C1 && ld1 < C1))
+        return AVSI_ERR_INVALID_ARG;
+    if ((C0 & 15) || (C1 & 15) || C0 + C1 < 16 || (ld0 & 3) || (ld1 & 3) || (ldf & 3) || (C1 && ((H | W) & 1)))
+        return AVSI_ERR_UNSUPPORTED;
+    if ((reinterpret_cast<uintptr_t>(src0) | reinterpret_cast<uintptr_t>(src1_coarse) | reinterpret_cast<uintptr_t>(filter) |
+         reinterpret_cast<uintptr_t>(zeros64) | reinterpret_cast<uintptr_t>(workspace)) & 15)
+        return AVSI_ERR_UNSUPPORTED;
+    const int64_t M64 = (int64_t)B * H * W;
+    if (M64 > INT32_MAX) return AVSI_ERR_UNSUPPORTED;
+    GemmArgs g{};
+    g.A = zeros64, g.B = filter, g.C = static_cast<float*>(workspace), g.bias = bias, g.row_scale = nullptr;
+    g.M = (int)M64, g.N = Cout, g.K = k * k * (C0 + C1);
+    g.lda = 0, g.ldb = ldf, g.ldc = ldo;
+    g.alpha = 1.f, g.beta = 0.f;
+    const int bnt = Cout <= 32 ? 32 : (Cout <= 64 ? 64 : 128);
+    g.m_blocks = (int)avsi_ceil_div(g.M, 128), g.n_blocks = (int)avsi_ceil_div(Cout, bnt);
+    g.k_split_len = (int)avsi_round_up(avsi_ceil_div(g.K, splits), 16);
+    g.c_split_stride = M64 * ldo, g.n_group = g.n_blocks;
+    g.conv_s0 = src0, g.conv_s1 = src1_coarse, g.conv_zeros = zeros64;
+    g.cH = H, g.cW = W, g.cC0 = C0, g.cld0 = ld0, g.cC1 = C1, g.cld1 = ld1, g.ck = k;
+    if ((int64_t)g.m_blocks * g.n_blocks > INT32_MAX) return AVSI_ERR_UNSUPPORTED;
+    avsi_clear_error();
+    const dim3 grid(g.m_blocks * g.n_blocks, 1, splits), block(256);
+    const hipStream_t st = (hipStream_t)stream;
+    if (bnt == 32)
+        hipLaunchKernelGGL((gemm_dma_kernel<false, false, 16, 3, true, 32>), grid, block, (size_t)3 * (128 + 32) * 16 * 4, st, g);
+    else if (bnt == 64)
+        hipLaunchKernelGGL((gemm_dma_kernel<false, false, 16, 3, true, 64>), grid, block, (size_t)3 * (128 + 64) * 16 * 4, st, g);
+    else
+        hipLaunchKernelGGL((gemm_dma_kernel<false, false, 16, 3, true, 128>), grid, block, (size_t)3 * (128 + 128) * 16 * 4, st, g);
+    if (avsi_launch_status() != AVSI_OK) return AVSI_ERR_LAUNCH;
+    // every split writes its whole slab (columns < Cout of every row; an empty chunk writes zeros / the bias)
+    return avsi_sum_slabs_launch(static_cast<const float*>(workspace), M64 * ldo, splits, M64 * ldo, out, 1.f, st);
+}
+
+int avsi_sum_slabs_launch(const float* slabs, int64_t n, int count, int64_t stride, float* out, float alpha,
+                          hipStream_t st);
 
 // Filter gradient of the convolution as an implicit GEMM: dW[(tap, c)][n] = sum over pixels of
 // in(b, h+dh, w+dw, c) dY[(b,h,w)][n], i.e. im2col^T . dY without the im2col matrix; the reduction over

@@ -564,6 +564,10 @@ def adam_tf(param, grad, m, v, step, lr, beta1=0.9, beta2=0.999, eps=1e-8, grad_
 _ZEROS = {}
 
 
+_CONV_WS = {}           # split-K slabs of conv2d, per (device, stream)
+_CONV_SPLITK = os.environ.get('AVSI_CONV_SPLITK', '1') != '0'
+
+
 def conv2d_supported(c0, c1):
     """Layers the implicit-GEMM convolution takes (avsi_conv2d_f32): channel counts multiples of 16."""
     return c0 % 16 == 0 and c1 % 16 == 0 and c0 + c1 >= 16
@@ -575,10 +579,24 @@ def conv2d(src0, c0, src1, c1, B, H, W, k, filt, bias, out, cout):
     z = _ZEROS.get(out.device.index)
     if z is None:
         z = _ZEROS[out.device.index] = torch.zeros(64, dtype=torch.float32, device=out.device)
-    _lib.check(_lib.lib().avsi_conv2d_f32(_lib.ptr(src0), c0, src0.stride(0) if src0 is not None else 0, _lib.ptr(src1), c1,
-                                          src1.stride(0) if src1 is not None else 0, B, H, W, k, _lib.ptr(filt),
-                                          filt.stride(0), _lib.ptr(bias), cout, _lib.ptr(out), out.stride(0), _lib.ptr(z),
-                                          _lib.stream_ptr()), "avsi_conv2d_f32")
+    L = _lib.lib()
+    # few output tiles (small batch, deep layers): cut the reduction so that the launch fills the chip (avsi_conv2d_splitk_f32)
+    splits = L.avsi_conv2d_splitk_suggest(B, H, W, k, c0, c1, cout) if _CONV_SPLITK and out.stride(0) == cout else 1
+    if splits > 1:
+        need = L.avsi_conv2d_splitk_workspace_bytes(B, H, W, out.stride(0), splits)
+        key = (out.device.index, _lib.stream_ptr().value)
+        ws = _CONV_WS.get(key)
+        if ws is None or ws.numel() * 4 < need:
+            ws = _CONV_WS[key] = torch.empty((need + 3) // 4, dtype=torch.float32, device=out.device)
+        _lib.check(L.avsi_conv2d_splitk_f32(_lib.ptr(src0), c0, src0.stride(0) if src0 is not None else 0, _lib.ptr(src1), c1,
+                                            src1.stride(0) if src1 is not None else 0, B, H, W, k, _lib.ptr(filt), filt.stride(0),
+                                            _lib.ptr(bias), cout, _lib.ptr(out), out.stride(0), _lib.ptr(z), splits, _lib.ptr(ws),
+                                            ws.numel() * 4, _lib.stream_ptr()), "avsi_conv2d_splitk_f32")
+        return out
+    _lib.check(L.avsi_conv2d_f32(_lib.ptr(src0), c0, src0.stride(0) if src0 is not None else 0, _lib.ptr(src1), c1,
+                                 src1.stride(0) if src1 is not None else 0, B, H, W, k, _lib.ptr(filt),
+                                 filt.stride(0), _lib.ptr(bias), cout, _lib.ptr(out), out.stride(0), _lib.ptr(z),
+                                 _lib.stream_ptr()), "avsi_conv2d_f32")
     return out
 
 

@@ -18,6 +18,7 @@ im2col matrix (filter) and a GEMM + gather-form col2im (input).  Activations are
 ``[B*H*W][C]`` with the channel pitch padded to a multiple of 4.
 """
 import math
+import os
 import sys
 
 import numpy as np
@@ -160,6 +161,7 @@ class UNetFConvModel(object):
 
     def feed(self, sequence_lengths=None, target_sources=None, masks=None, audio_feat_mean=None, audio_feat_std=None,
              **_unused):
+        self._auto_graph(sequence_lengths, target_sources, masks)
         self._cache = {}
         graph = getattr(self, '_graph', None)
         if sequence_lengths is not None:
@@ -191,8 +193,41 @@ class UNetFConvModel(object):
     def build_graph(self, var_scope=''):
         self.var_scope = var_scope
 
+    # Inference at the reference's batch sizes is launch-bound once the convolutions fill the chip (32 clips: 0.81 ms per
+    # step issued launch by launch, 0.62 ms as one graph), so an inference model captures its step BY ITSELF after it has
+    # been fed the same shapes three times in a row (up to AUTO_GRAPH_MAX_CLIPS clips; AVSI_UNET_GRAPH=0: never), and goes
+    # back to plain launches when the shapes change.  Results of a step then live in buffers the next feed() overwrites.
+    AUTO_GRAPH_AFTER = 3
+    AUTO_GRAPH_MAX_CLIPS = 128
+
+    def _auto_graph(self, sequence_lengths, target_sources, masks):
+        if self.is_training or os.environ.get('AVSI_UNET_GRAPH', '1') == '0' or getattr(self, '_graph_manual', False):
+            return
+        shape = (None if sequence_lengths is None else (len(sequence_lengths), int(np.max(np.asarray(
+                     sequence_lengths.cpu() if isinstance(sequence_lengths, torch.Tensor) else sequence_lengths)))),
+                 None if target_sources is None else tuple(target_sources.shape),
+                 None if masks is None else tuple(masks.shape))
+        if None in shape:
+            return
+        captured = getattr(self, '_graph', None) is not None
+        if shape != getattr(self, '_auto_shape', None):
+            self._auto_shape, self._auto_count = shape, 0
+            if captured:
+                self.release_graph()
+            return
+        if captured:
+            return
+        # count only steps whose results were asked for: those workspaces and tables exist
+        self._auto_count += 1 if 'loss3' in self._cache else 0
+        if self._auto_count >= self.AUTO_GRAPH_AFTER and shape[0][0] <= self.AUTO_GRAPH_MAX_CLIPS:
+            try:
+                self.capture_graph(_auto=True)
+            except Exception:              # never a reason to fail a step: stay with plain launches
+                self.release_graph()
+                self._auto_count = -(1 << 30)
+
     # ------------------------------------------------------------------ HIP graph of the inference step
-    def capture_graph(self):
+    def capture_graph(self, _auto=False):
         """Capture front end -> 13 layers -> prediction -> loss (about 70 launches) into one HIP graph
         (torch.cuda.CUDAGraph).  At the reference's batch of 32 a step is launch-bound -- the kernels
         take about half of the 1.5 ms -- so replaying one graph per feed() instead of issuing every
@@ -205,6 +240,7 @@ class UNetFConvModel(object):
         if self.target_sources is None or self.masks is None or self.sequence_lengths is None:
             raise _lib.AvsiError("feed() the model once before capture_graph()")
         self.release_graph()
+        self._graph_manual = not _auto
         self.target_sources, self.masks = self.target_sources.clone(), self.masks.clone()
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
@@ -223,6 +259,7 @@ class UNetFConvModel(object):
 
     def release_graph(self):
         self._graph, self._graph_cache = None, None
+        self._graph_manual = False
 
     def _buf(self, name, shape, zero=True):
         key = (name, tuple(shape))

@@ -434,6 +434,16 @@ int avsi_lws_istft_f32(const float* spec, int batch, int num_frames, const float
 int avsi_conv2d_f32(const float* src0, int C0, int ld0, const float* src1_coarse, int C1, int ld1,
                     int B, int H, int W, int k, const float* filter, int ldf, const float* bias,
                     int Cout, float* out, int ldo, const float* zeros64, void* stream);
+/* The same with the reduction over (tap, channel) cut into `splits` chunks whose partial slabs (workspace) are summed in chunk
+ * order by a second kernel: for layers whose output is only a few 128-row tiles (the 128-channel U-Net layers at the
+ * reference's batch of 32: 4 .. 64 tiles on 256 CUs).  avsi_conv2d_splitk_suggest gives the number of chunks that fills the chip
+ * about once with at least eight 16-deep k-tiles per workgroup (1 = do not split); splits < 2, ldo != Cout or a workspace
+ * smaller than avsi_conv2d_splitk_workspace_bytes: the plain launch.  Same results up to the order of the sum. */
+size_t avsi_conv2d_splitk_workspace_bytes(int B, int H, int W, int ldo, int splits);
+int avsi_conv2d_splitk_suggest(int B, int H, int W, int k, int C0, int C1, int Cout);
+int avsi_conv2d_splitk_f32(const float* src0, int C0, int ld0, const float* src1_coarse, int C1, int ld1, int B, int H,
+                           int W, int k, const float* filter, int ldf, const float* bias, int Cout, float* out, int ldo,
+                           const float* zeros64, int splits, void* workspace, size_t workspace_bytes, void* stream);
 /* Direct form for the thin full-resolution layers no MFMA shape fits: (k, C0, C1, Cout) in
  * {(7, 1, 0, 16), (3, 1, 16, 1), (1, 1, 0, 1)} (unet_layers.py / models.py:592,605,607);
  * AVSI_ERR_UNSUPPORTED for anything else. */
