@@ -664,6 +664,11 @@ int launch_dma(const GemmArgs& g, int splits, hipStream_t st) {
                            lds256, st, g);
         return avsi_launch_status();
     }
+    if (!TA && !TB && g.bnt == 32) {     // at most 32 columns (the last bin of the 257-bin projection): bound by reading A
+        hipLaunchKernelGGL((gemm_dma_kernel<false, false, 16, 3, false, 32>), dim3(g.m_blocks * g.n_blocks, 1, splits), dim3(256),
+                           (size_t)3 * (128 + 32) * 16 * 4, st, g);
+        return avsi_launch_status();
+    }
     if (!TA && !TB && g.bnt == 64) {
         hipLaunchKernelGGL((gemm_dma_kernel<false, false, 16, 3, false, 64>), dim3(g.m_blocks * g.n_blocks, 1, splits), dim3(256),
                            (size_t)3 * (128 + 64) * 16 * 4, st, g);
@@ -732,13 +737,14 @@ int avsi_gemm_launch(int transA, int transB, int M, int N, int K, float alpha, c
     // (the 257-bin projection: 5 x 64 instead of 3 x 128 columns of MFMA work)
     g.k_split_len = (int)avsi_round_up(avsi_ceil_div(K, splits), 32);
     const bool dma_ok = !(transB && !transA) && (K % 16 == 0) && (g.k_split_len % 16 == 0) && !env_bk && !env_mi && env.dma != 0;
-    g.bnt = (dma_ok && !transA && !transB && N < 1024 && ((N - 1) % BN) < 64 && !(env.dma > 1)) ? 64 : BN;
+    g.bnt = (dma_ok && !transA && !transB && N < 1024 && ((N - 1) % BN) < 64 && !(env.dma > 1)) ? (N <= 32 ? 32 : 64) : BN;
     // wide layer GEMMs (N = 2048): 128 x 256 output tiles, each wave 64 x 128 -- half the barriers and a quarter less
     // LDS traffic per MFMA (K = 4096: 135 -> 142 TFLOP/s; the 512-deep layer GEMMs gain 2 %, the split-K weight
     // gradients 6 %), when that still leaves two workgroups per CU.  AVSI_GEMM_BNT=128: diagnostics
     static const int wide_min = getenv("AVSI_GEMM_WIDE_MIN") ? atoi(getenv("AVSI_GEMM_WIDE_MIN")) : 2 * AVSI_NUM_CU - 32;   // 8000 rows (32 utterances): 504 wide tiles, 111 -> 99 us
-    if (dma_ok && !transB && g.bnt == BN && N % 256 == 0 && N >= 1024 && (int64_t)g.m_blocks * (N / 256) * splits >= wide_min &&
-        env.bnt != 128)
+    // N = 256 exactly: the first 256 bins of the 257-bin projection, which the model issues on their own (round 3)
+    if (dma_ok && !transB && g.bnt == BN && N % 256 == 0 && (N >= 1024 || N == 256) &&
+        (int64_t)g.m_blocks * (N / 256) * splits >= wide_min && env.bnt != 128)
         g.bnt = 256;
     g.n_blocks = (int)avsi_ceil_div(N, g.bnt);
     g.c_split_stride = splits > 1 ? c_split_stride : 0;

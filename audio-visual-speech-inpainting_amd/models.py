@@ -26,6 +26,7 @@ from .blstm_layout import GP, HP, ParamLayout, round_up
 
 SIDE_DELAY_US = int(os.environ.get('AVSI_SIDE_DELAY_US', '60'))   # head start of a BPTT grid over the side-stream GEMMs
 DX_SPLITS = int(os.environ.get('AVSI_DX_SPLITS', '2'))      # reduction slabs of the dX product at small batches (1: unsplit)
+_PROJ_SPLIT = os.environ.get('AVSI_PROJ_SPLIT', '1') != '0'    # 257-bin projection as 256 bins + 1 bin (see _forward)
 
 
 def _as_device(x, dtype=torch.float32, device=None):
@@ -385,8 +386,15 @@ class StackedBLSTMModel(object):
             row_scale[:, :B] = (torch.arange(T, device=self.device)[:, None] < seq[None, :]).to(torch.float32)   # kernels saved
             self._ws[('row_scale_of', T, Bp, B)] = seq
         pred = torch.empty((B, T, self.audio_feat_dim), dtype=torch.float32, device=self.device)
-        ops.gemm(x.view(T * Bp, 2 * HP), v.p('pw'), out=pred.view(B * T, self.audio_feat_dim),
-                 n=self.audio_feat_dim, bias=v.p('pb'), row_scale=row_scale.view(-1), row_map=(Bp, T, B))
+        F = self.audio_feat_dim
+        x2, p2 = x.view(T * Bp, 2 * HP), pred.view(B * T, F)
+        # 257 bins = one 256-column product on the wide (128 x 256) tile + the last bin on a narrow one, instead of five
+        # 64-column tiles of which the fifth carries one useful column (AVSI_PROJ_SPLIT=0: the single product)
+        n_main = F - F % 256 if (_PROJ_SPLIT and F > 256 and 0 < F % 256 <= 32 and T * Bp >= 65536) else F
+        ops.gemm(x2, v.p('pw'), out=p2, n=n_main, bias=v.p('pb'), row_scale=row_scale.view(-1), row_map=(Bp, T, B))
+        if n_main < F:
+            ops.gemm(x2, v.p('pw')[:, n_main:F], out=p2[:, n_main:], n=F - n_main, bias=v.p('pb')[n_main:F],
+                     row_scale=row_scale.view(-1), row_map=(Bp, T, B))
         c['row_scale'] = row_scale
         c['pred'] = pred
         c['kept'] = keep

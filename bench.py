@@ -41,6 +41,21 @@ FP32_MFMA_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, d
 HBM_PEAK_GBS = 8000.0
 
 
+def device_copy_rate(torch, device, mib=2048, reps=5):
+    """Read + write bytes per second of a plain tensor copy of `mib` MiB (torch's copy kernel): what a pure streaming
+    kernel reaches on this GPU, the practical ceiling for the HBM-bound kernels next to the 8 TB/s of the data sheet."""
+    src = torch.empty(mib << 18, dtype=torch.float32, device=device).normal_()
+    dst = torch.empty_like(src)
+    dst.copy_(src)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        dst.copy_(src)
+    e1.record()
+    torch.cuda.synchronize(device)
+    return 2.0 * src.numel() * 4 * reps / (e0.elapsed_time(e1) * 1e-3) / 1e9
+
+
 def algorithmic_flops(batch, input_dim=257):
     """forward FLOPs of the gate GEMMs, split by kernel, per `batch` utterances."""
     d = [input_dim, 2 * H, 2 * H]
@@ -849,22 +864,28 @@ def main():
     if rank == 0 and not train:
         gemm_in, rec, proj = algorithmic_flops(B)
         t_rec, n_rec = totals["blstm_rec_fwd_kernel"]
-        # ops.gemm is called 4 times per step: the three layer input projections (kernel symbol
-        # gemm_dma_kernel<false, false, 16, 3, false, 256>, the dominant kernel) and the 257-bin output
-        # projection (same kernel with the 64-wide N tile); the roofline block is for the former alone
+        # ops.gemm is called 5 times per step: the three layer input projections and the first 256 bins of the output
+        # projection (all four on the kernel symbol gemm_dma_kernel<false, false, 16, 3, false, 256>, the dominant
+        # kernel: the roofline block covers every launch of that symbol, as rocprofv3 --stats averages them), then
+        # the 257th bin on the 32-wide tile.  AVSI_PROJ_SPLIT=0: 4 calls, the projection on five 64-wide tiles
         ev = timer.events["gemm_dma_kernel"]
+        per_step = len(ev) // args.steps
+        ms = [s_.elapsed_time(e_) for s_, e_ in ev]
         if args.precision == "bf16x3":      # exploratory: the layer projections are the split-bf16 launches
             layer_ms = [s_.elapsed_time(e_) for s_, e_ in timer.events["gemm_bf16x3_kernel"]]
-            proj_ms = [s_.elapsed_time(e_) for s_, e_ in ev]
+            proj_ms, wide_proj_ms = ms, []
         else:
-            layer_ms = [s_.elapsed_time(e_) for i, (s_, e_) in enumerate(ev) if i % 4 != 3]
-            proj_ms = [s_.elapsed_time(e_) for i, (s_, e_) in enumerate(ev) if i % 4 == 3]
-        t_gemm, n_gemm = sum(layer_ms), len(layer_ms)
+            layer_ms = [t for i, t in enumerate(ms) if i % per_step < 3]
+            proj_ms = [t for i, t in enumerate(ms) if i % per_step >= 3]
+            wide_proj_ms = [t for i, t in enumerate(ms) if i % per_step == 3] if per_step == 5 else []
+        t_layer = sum(layer_ms)
+        t_gemm, n_gemm = t_layer + sum(wide_proj_ms), len(layer_ms) + len(wide_proj_ms)
         t_proj = sum(proj_ms)
         t_fe, n_fe = totals["frontend_kernel"]
         fe_ms = sorted(s_.elapsed_time(e_) for s_, e_ in timer.events["frontend_kernel"])
         rec_tf = rec * n_rec / (t_rec * 1e-3) / 1e12
-        gemm_tf = sum(gemm_in) * args.steps / (t_gemm * 1e-3) / 1e12
+        layer_tf = sum(gemm_in) * args.steps / (t_layer * 1e-3) / 1e12
+        gemm_tf = (sum(gemm_in) + (proj * 256.0 / 257.0 if wide_proj_ms else 0.0)) * args.steps / (t_gemm * 1e-3) / 1e12
         proj_tf = proj * args.steps / (t_proj * 1e-3) / 1e12
         fe_gbs = 706000.0 * B * n_fe / (t_fe * 1e-3) / 1e9
         if t_rec >= t_gemm:
@@ -884,14 +905,20 @@ def main():
             roof["traffic"], roof["traffic_source"] = None, None
         roof["others"] = {
             "blstm_rec_fwd_kernel": {"TFLOP/s": rec_tf, "ms_per_step": t_rec / args.steps},
-            "gemm_dma_kernel": {"TFLOP/s": gemm_tf, "ms_per_step": t_gemm / args.steps},
-            "gemm_dma_kernel(projection, 64-wide tiles)": {"TFLOP/s": proj_tf, "ms_per_step": t_proj / args.steps},
+            "gemm_dma_kernel(layer input projections)": {"TFLOP/s": layer_tf, "ms_per_step": t_layer / args.steps},
+            "gemm_dma_kernel(257-bin projection: %s)" % ("256 bins on the wide tile + 1 bin on a 32-wide tile"
+                                                         if wide_proj_ms else "64-wide tiles"):
+                {"TFLOP/s": proj_tf, "ms_per_step": t_proj / args.steps},
             "frontend_kernel": {"GB/s": fe_gbs, "frac_of_hbm_peak": fe_gbs / HBM_PEAK_GBS,
                                 "ms_per_step": t_fe / args.steps,
                                 # one launch per step: spread over the timed steps, and the rate at the median launch
                                 "launch_ms_min_median_max": [fe_ms[0], fe_ms[len(fe_ms) // 2], fe_ms[-1]],
                                 "GB/s_at_median": 706000.0 * B / (fe_ms[len(fe_ms) // 2] * 1e-3) / 1e9,
-                                "algorithmic_bytes_per_utterance": 706000},
+                                "algorithmic_bytes_per_utterance": 706000,
+                                # the model's call also writes the un-masked target spectrogram (257,000 B more per
+                                # utterance), and a plain device copy on this GPU is the practical ceiling beside 8 TB/s
+                                "GB/s_with_target_output_at_median": 963000.0 * B / (fe_ms[len(fe_ms) // 2] * 1e-3) / 1e9,
+                                "device_copy_GB/s": device_copy_rate(torch, device)},
         }
         cpu, rms = (None, None)
         if not args.no_cpu_baseline and world == 1:     # the CPU leg is reported at N = 1 only

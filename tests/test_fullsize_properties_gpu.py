@@ -85,6 +85,29 @@ def test_utterances_are_independent_full_size():
     assert (small - pred[:50]).abs().max().item() < 2e-4
 
 
+def test_projection_in_two_products_is_the_single_product(monkeypatch):
+    """From 263 utterances on the 257-bin projection is issued as 256 bins (128 x 256 tiles) + 1 bin (32-wide tile)
+    instead of five 64-column tiles (models.py:117-123 is one matmul): the same sums in the same order, so the
+    prediction -- ragged lengths, sequence mask and the batch-major scatter included -- is bit-identical."""
+    import avsi_amd  # noqa: F401
+    from avsi_amd import models
+    B = 300
+    wav, masks = _batch(B, 5)
+    lens = np.full(B, T)
+    lens[::7] = 113
+    lens[3] = 1
+    m = _model(B, wav, masks)
+    m.feed(lens, wav, masks)
+    assert models._PROJ_SPLIT
+    split = m.prediction.clone()
+    loss = float(m.loss_func)
+    monkeypatch.setattr(models, '_PROJ_SPLIT', False)
+    m.feed(lens, wav, masks)
+    assert torch.equal(m.prediction, split)
+    assert float(m.loss_func) == loss
+    assert float(split[3, 1:].abs().max()) == 0.0 and float(split[0, :, 256].abs().max()) > 0.0
+
+
 def test_blstm_time_reversal_symmetry_full_size():
     """Swapping the forward and backward cells of every layer and reversing the input in time
     reverses the output in time with its two halves swapped -- a property of

@@ -63,6 +63,44 @@ def test_row_scale_and_time_major_row_map(ops):
     np.testing.assert_allclose(out.cpu().numpy(), ref[:, :B].transpose(1, 0, 2), atol=1e-4)
 
 
+@pytest.mark.parametrize("T,B,Bp", [(250, 270, 288), (9, 7500, 7520)])
+def test_projection_as_256_bins_plus_tail(ops, T, B, Bp):
+    """The 257-bin projection the way the model issues it from 65536 rows on (models.py:117-123): N = 256 takes the
+    128 x 256 tile with the general epilogue (sequence mask, time-major -> batch-major rows, row pitch 257), the last
+    bin a 32-wide tile on column views of W, bias and the output -- against numpy, and bit for bit against the single
+    257-column product."""
+    K, N = 512, 257
+    rng = np.random.default_rng(B)
+    X = rng.normal(size=(T, Bp, K)).astype(np.float32)
+    W = _pad_cols((rng.normal(size=(K, N)) * 0.05).astype(np.float32), 260)
+    bias = rng.normal(size=260).astype(np.float32)
+    scale = (rng.uniform(size=(T, Bp)) > 0.3).astype(np.float32)
+    x, w, b = torch.from_numpy(X).cuda().view(T * Bp, K), torch.from_numpy(W).cuda(), torch.from_numpy(bias).cuda()
+    rs = torch.from_numpy(scale).cuda().view(-1)
+    one = torch.full((B * T, N), 7.0, device='cuda')
+    two = torch.full((B * T, N), 9.0, device='cuda')
+    ops.gemm(x, w, out=one, n=N, bias=b, row_scale=rs, row_map=(Bp, T, B))
+    ops.gemm(x, w, out=two, n=256, bias=b, row_scale=rs, row_map=(Bp, T, B))
+    assert float(two[:, 256].min()) == 9.0          # the 256-bin product leaves the last column alone
+    ops.gemm(x, w[:, 256:N], out=two[:, 256:], n=1, bias=b[256:N], row_scale=rs, row_map=(Bp, T, B))
+    assert torch.equal(one, two)
+    ref = (X.astype(np.float64) @ W[:, :N].astype(np.float64) + bias[:N]) * scale[:, :, None]
+    np.testing.assert_allclose(two.view(B, T, N).cpu().numpy(), ref[:, :B].transpose(1, 0, 2), atol=2e-4)
+
+
+@pytest.mark.parametrize("N", [1, 5, 32])
+def test_at_most_32_columns_take_the_narrow_tile(ops, N):
+    M, K = 1000, 272
+    rng = np.random.default_rng(N)
+    A = rng.normal(size=(M, K)).astype(np.float32)
+    Bm = _pad_cols(rng.normal(size=(K, N)).astype(np.float32), 36)
+    bias = rng.normal(size=N).astype(np.float32)
+    got = ops.gemm(torch.from_numpy(A).cuda(), torch.from_numpy(Bm).cuda(), n=N, bias=torch.from_numpy(bias).cuda())
+    ref = A.astype(np.float64) @ Bm[:, :N].astype(np.float64) + bias
+    assert got.shape == (M, N)
+    assert np.abs(got.cpu().numpy() - ref).max() < 2e-6 * K * 4
+
+
 def test_rejects_unaligned(ops):
     import avsi_amd
     a = torch.zeros(8, 6, device='cuda')
