@@ -182,6 +182,7 @@ PROTOTYPES = {
     "avsi_lws_run_f32": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_int, c_float, c_int,
                                  c_float, c_float, c_float, c_int, c_int, c_int, c_void_p, c_size_t, c_void_p]),
     "avsi_lws_run_skew_workspace_bytes": (c_size_t, [c_int, c_int]),
+    "avsi_lws_skew_launch_shape": (c_int, [c_int, c_int, c_int, ctypes.POINTER(c_int), ctypes.POINTER(c_int)]),
     "avsi_lws_run_skew_f32": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_int, c_float, c_int,
                                       c_float, c_float, c_float, c_int, c_int, c_void_p, c_size_t, c_void_p]),
     "avsi_lws_istft_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),

@@ -12,7 +12,7 @@
 //
 // What a lane keeps (all in registers, rings of 12 indexed by step mod 12, so every index is a compile-time constant
 // in the 12-fold unrolled step loop):
-//   R  its own row's values from the sweep before ("old"), positions k .. k+11, streamed from memory 12 steps ahead;
+//   R  its own row's values from the sweep before ("old"), positions k .. k+11, streamed from memory PF = 6 steps ahead;
 //   P  its own row's values of this sweep ("new"), positions k-1 .. k-12.
 // Per step it forms three sums over ITS OWN rings and hands two of them to its neighbours with one DPP rotate each:
 //   own  = sum_{p=1..5} a_0(p) R[k+p] + a_0(-p) P[k-p]                  (10 taps, its own bin)
@@ -26,15 +26,16 @@
 // source arrives / changes (predicated register moves), the five above Nyquist are stored in the layout like bins.
 //
 // Memory layout ("diagonal-major"): element (m, x), x in [-5, 261], lives in row x + 6 m + 5, column m mod 64 of a
-// [rows][64] complex array per utterance -- at step t EVERY lane loads row t + 16 + 12 (its own position k + 11, twelve
+// [rows][64] complex array per utterance -- at step t EVERY lane loads row t + 16 + PF (its own position k + 11, PF = 6
 // steps ahead) and stores row t + 5 (its own bin): two 512-byte rows per step, nothing strided.  Magnitudes (constant
 // through all sweeps, as in oracle/lws.py) sit in a float array of the same shape.
 //
 // Pipeline of sweeps: a workgroup is NW waves = NW consecutive (active) sweeps of ONE utterance, G workgroups chain up
-// per utterance (G * NW stages; the a-th active sweep runs on stage a mod stages).  A stage publishes "bodies (12 steps)
+// per utterance (G * NW stages; the a-th active sweep runs on stage a mod stages).  A stage publishes "half bodies (6 steps)
 // finished and visible" -- in LDS for the next wave of its workgroup, which reads the rows back through the CU's own L1
 // (coherent within a workgroup), in global memory (device-scope stores / loads) where the next stage sits in another
-// workgroup or is wave 0 of the next round.  A stage starts a body when its predecessor has published four bodies more.
+// workgroup or is wave 0 of the next round.  A stage starts a half body (6 steps) when its predecessor has published
+// AHEAD half bodies more (the exact data dependence, see AHEAD).
 // All stages of an utterance must be resident together (bounded waits, status word).
 #include <math.h>
 
@@ -55,7 +56,15 @@ constexpr int T0 = -24;                    // time of step 0 (a multiple of 12 a
 constexpr int ROW_OFF = 5;                 // row of (frame m, position x) = x + 6 m + ROW_OFF
 constexpr int TAU_LAST = 2 * (KB - 1) - (KB - 1 - LMAX) + 0;   // 261: last mirror position above Nyquist
 constexpr int NONE = -100000;
-constexpr int QSLACK = 3;             // bodies a stage asks for beyond its need when it has to poll device memory
+// Progress is counted in HALF bodies (6 steps): a published value h says "the stores of the half bodies before h are
+// complete".  Half x of body b (steps 12 b + 6 x ..) loads rows up to t + PF + 16, which the predecessor stores up to its
+// step 12 b + 6 x + 5 + PF + 11, i.e. in its half body 2 b + x + (PF + 16) / 6: the stage starts that half once it has seen
+// one more.  PF = 12 (round 3's first version, bodies as the unit and one body of slack: 60 steps between consecutive
+// sweeps) -> half bodies, no slack: 36 -> PF = 6: 30 steps; 1 utterance 4.6 -> 4.0 -> 3.7 -> 3.4 ms.
+constexpr int HALF = UNR / 2;
+constexpr int PF = 6;                 // steps between the request of a row and its use (the landing ring has UNR slots)
+constexpr int AHEAD = (PF + 16) / HALF + 1;
+constexpr int QSLACK = 6;             // half bodies a stage asks for beyond its need when it has to poll device memory
 constexpr int CTR_STRIDE = 64;                                        // ints between two device-scope counters (256 bytes)
 constexpr int GPROG_INTS = (MAX_SWEEPS / 4) * CTR_STRIDE;            // per utterance: up to MAX_SWEEPS / 4 workgroups
 static_assert(TAU_LAST == 261 && KB == 257 && SKEW == 6, "the edge rules below are written out for 257 bins, L = 5");
@@ -85,7 +94,7 @@ __device__ __forceinline__ float dpp_from_next(float v) {      // lane j gets la
 }
 
 // The memory operations of the step loop are inline asm: exactly three per step and lane (two loads, one store), in a
-// fixed order, so that "the loads issued twelve steps ago have landed" is ONE counted wait (s_waitcnt vmcnt(34): 34
+// fixed order, so that "the loads issued PF steps ago have landed" is ONE counted wait (s_waitcnt vmcnt(3 PF - 2): that many
 // younger operations may still be in flight) -- the compiler's own bookkeeping gives up at vmcnt(0) once stores sit
 // between a load and its use, which would expose a memory round trip per step.
 // a pointer that is wave-uniform by construction, as SGPRs whatever the register allocator made of it ("s" operands below).
@@ -147,15 +156,15 @@ __device__ __forceinline__ void skew_step(LaneState& L, const StepCtx& C, const 
 #define WBD(p, c) (STD ? AVSI_LWS_STD_BD[p][c] : W.bd[p][c])
 #define WB0(p, c) (STD ? AVSI_LWS_STD_B0[p][c] : W.b0[p][c])
     const int t = T0 + n;                                  // wave-uniform
-    // ---- the operands requested twelve steps ago
+    // ---- the operands requested PF steps ago
     // (the wait takes the landing registers as operands: nothing may read them, or give them to another value, before it)
-    asm volatile("s_waitcnt vmcnt(34)" : "+v"(L.Lb[I].x), "+v"(L.Lb[I].y), "+v"(L.Ab[I])::"memory");
+    asm volatile("s_waitcnt vmcnt(%3)" : "+v"(L.Lb[I].x), "+v"(L.Lb[I].y), "+v"(L.Ab[I]) : "n"(3 * PF - 2) : "memory");
     const float2 arr = L.Lb[I];
     const float amp = L.Ab[I];
     // (addresses: the utterance's base pointer in SGPRs for the whole kernel + a 32-bit byte offset per lane that includes the
     // row -- one v_add per access instead of 64-bit pointer arithmetic and a v_readfirstlane pair per row)
-    row_load8(C.dev_in, L.Lb[I], C.Dg, C.lane8 + (unsigned)(t + UNR + 16) * (unsigned)(LANES * sizeof(float2)));     // position tau + 11 of step n + 12
-    row_load4(L.Ab[I], C.Ag, C.lane4 + (unsigned)(t + UNR + ROW_OFF > 0 ? t + UNR + ROW_OFF : 0) * (unsigned)(LANES * sizeof(float)));   // magnitude of the bin of step n + 12
+    row_load8(C.dev_in, L.Lb[ring(I + PF)], C.Dg, C.lane8 + (unsigned)(t + PF + 16 > 0 ? t + PF + 16 : 0) * (unsigned)(LANES * sizeof(float2)));     // position tau + 11 of step n + PF
+    row_load4(L.Ab[ring(I + PF)], C.Ag, C.lane4 + (unsigned)(t + PF + ROW_OFF > 0 ? t + PF + ROW_OFF : 0) * (unsigned)(LANES * sizeof(float)));   // magnitude of the bin of step n + PF
     const int tau = L.tau, m = L.m;
     L.R[I] = arr;                                                                      // position tau + 11
     {   // positions 1 .. 5 of a row also define its mirror images -1 .. -5, which "arrived" 2 x steps earlier
@@ -226,9 +235,9 @@ __device__ __forceinline__ void skew_step(LaneState& L, const StepCtx& C, const 
 #undef WB0
 }
 
-template <bool STD, int... Is>
-__device__ __forceinline__ void skew_body(LaneState& L, const StepCtx& C, const SkewConst& W, int n0, std::integer_sequence<int, Is...>) {
-    (skew_step<Is, STD>(L, C, W, n0 + Is), ...);
+template <bool STD, int H, int... Is>
+__device__ __forceinline__ void skew_half(LaneState& L, const StepCtx& C, const SkewConst& W, int n0, std::integer_sequence<int, Is...>) {
+    (skew_step<H * HALF + Is, STD>(L, C, W, n0 + H * HALF + Is), ...);
 }
 
 // NW waves per workgroup = NW pipeline stages of one utterance; G workgroups per utterance
@@ -243,7 +252,8 @@ __global__ __launch_bounds__(64 * NW) void lws_skew_kernel(float2* __restrict__ 
     const int stage = wg * NW + wv, stages = G * NW;
     const int rows = skew_rows(M);
     const int nb = (skew_steps(M) + UNR - 1) / UNR;           // bodies per sweep
-    const int nbp = nb + 8;                                   // counter values per sweep of a stage
+    const int hlast = 2 * nb + AHEAD + 1;                     // published when a sweep is finished: every need is capped there
+    const int nbp = 2 * nb + 16;                              // counter values per sweep of a stage
     // one counter per workgroup of the chain (its last stage publishes there), each on a 256-byte line of its own: polls
     // and publications are device-scope accesses served at the memory side, and neighbours in one line queue on one channel
     int* gprog = gprog_all + (size_t)b * GPROG_INTS;
@@ -290,11 +300,11 @@ __global__ __launch_bounds__(64 * NW) void lws_skew_kernel(float2* __restrict__ 
         L.tau = T0 - SKEW * lane;
         // a stage whose predecessor sits in another workgroup polls device memory, which drains the loads in flight: it
         // asks for QSLACK bodies more than it needs and then runs that many bodies on what it knows
-        auto wait_pred = [&](int body) {
+        auto wait_pred = [&](int half) {           // half: index of the half body about to start
             if (pstage < 0 || dead) return;
-            const int need = pbase + (body + 4 < nb + 3 ? body + 4 : nb + 3);
+            const int need = pbase + (half + AHEAD < hlast ? half + AHEAD : hlast);
             if (known >= need) return;
-            const int want = dev_in ? (need + QSLACK < pbase + nb + 3 ? need + QSLACK : pbase + nb + 3) : need;
+            const int want = dev_in ? (need + QSLACK < pbase + hlast ? need + QSLACK : pbase + hlast) : need;
             int spins = 0;
             for (;;) {
                 known = dev_in ? __hip_atomic_load(gprog + (pstage / NW) * CTR_STRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
@@ -303,7 +313,7 @@ __global__ __launch_bounds__(64 * NW) void lws_skew_kernel(float2* __restrict__ 
                 if (known >= want) break;
                 // a predecessor that is still bodies away is not worth asking often: with hundreds of stages waiting for their
                 // turn, their polls alone kept the memory side busy (32 utterances x 26 workgroups: 20 ms instead of 5)
-                if (known + 2 < want) __builtin_amdgcn_s_sleep(127);
+                if (known + 4 < want) __builtin_amdgcn_s_sleep(127);
                 else __builtin_amdgcn_s_sleep(8);
                 if (++spins > (1 << 22)) {
                     dead = true;
@@ -318,28 +328,32 @@ __global__ __launch_bounds__(64 * NW) void lws_skew_kernel(float2* __restrict__ 
                 if (dev_out) __hip_atomic_store(gprog + wg * CTR_STRIDE, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
         };
-        // prefetch of the first body: rows of steps 0 .. 11 (nothing of them is used before position 1 arrives)
+        // prefetch: the rows of steps 0 .. PF - 1 (nothing of them is used before position 1 arrives)
         wait_pred(0);
 #pragma unroll
-        for (int i = 0; i < UNR; ++i) {
+        for (int i = 0; i < PF; ++i) {
             row_load8(dev_in, L.Lb[i], C.Dg, C.lane8 + (unsigned)(T0 + i + 16 > 0 ? T0 + i + 16 : 0) * (unsigned)(LANES * sizeof(float2)));     // (rows < 0: positions nobody reads)
             row_load4(L.Ab[i], C.Ag, C.lane4 + (unsigned)(T0 + i + ROW_OFF > 0 ? T0 + i + ROW_OFF : 0) * (unsigned)(LANES * sizeof(float)));
             // keep the count of the step loop: a store per step (scratch row)
             row_store8(false, C.Dw, C.lane8 + (unsigned)C.trash_row * (unsigned)(LANES * sizeof(float2)), make_float2(0.f, 0.f));
         }
         for (int body = 0; body < nb; ++body) {
-            wait_pred(body);
             const int n0 = body * UNR;
-            skew_body<STD>(L, C, W, n0, std::make_integer_sequence<int, UNR>{});
-            // the stores of the body BEFORE this one are complete once at most this body's 36 operations are in flight
-            asm volatile("s_waitcnt vmcnt(36)" ::: "memory");
-            publish(base + body);
+            wait_pred(2 * body);
+            skew_half<STD, 0>(L, C, W, n0, std::make_integer_sequence<int, HALF>{});
+            // everything issued before this half body's 18 operations is complete: the stores of the half bodies before it
+            asm volatile("s_waitcnt vmcnt(18)" ::: "memory");
+            publish(base + 2 * body);
+            wait_pred(2 * body + 1);
+            skew_half<STD, 1>(L, C, W, n0, std::make_integer_sequence<int, HALF>{});
+            asm volatile("s_waitcnt vmcnt(18)" ::: "memory");
+            publish(base + 2 * body + 1);
         }
         // the loads of the last body land in registers nobody reads any more: they stay reserved until they have landed
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
         for (int i = 0; i < UNR; ++i) asm volatile("" : "+v"(L.Lb[i].x), "+v"(L.Lb[i].y), "+v"(L.Ab[i]));
-        publish(base + nb + 3);
+        publish(base + hlast);
         ++mine;
     }
 }
@@ -381,6 +395,59 @@ __global__ __launch_bounds__(256) void lws_from_diag_kernel(const float2* __rest
 
 size_t align256(size_t n) { return (n + 255) & ~(size_t)255; }
 
+// steps (of one wave) until the last of `sweeps` sweeps of `len` steps has finished on `stages` pipeline stages
+double skew_pipeline_steps(int sweeps, int stages, int len, int lag) {
+    double start[MAX_SWEEPS + 1];
+    for (int a = 0; a < sweeps; ++a) {
+        const double chain = a ? start[a - 1] + lag : 0.0, stage = a >= stages ? start[a - stages] + len : 0.0;
+        start[a] = chain > stage ? chain : stage;
+    }
+    return start[sweeps - 1] + len;
+}
+
+// The launch shape for a batch.  NW by rule (up to 32 utterances 4, up to 128: 8, up to 256: 8 or 16, beyond: 16): the more
+// stages share a workgroup, the fewer hand-overs go through device memory -- at 1024 utterances 16 x 1 takes 57.5 ms,
+// 8 x 1 72, 4 x 1 95 -- but a wave that shares its SIMD with three others is slow, so small batches take 4-wave
+// workgroups.  G (and NW where the rule leaves two) under a model of the pipeline: sweep a starts LAG steps after
+// sweep a - 1 and not before its stage has finished sweep a - stages; a step costs a wave 0.6 us with a SIMD to itself
+// (non-VALU instructions and dependent issue: 55 % of the VALU rate), 0.75 with two, 1.28 with four waves on the SIMD of
+// the most loaded CU (which the batch waits for).  Measured at a lag of 36 steps, ms per batch: 1 .. 8 utterances 4 x 13: 3.7; 32: 4 x 8 4.2
+// (4 x 12: 4.6, 4 x 16: 4.7); 64: 8 x 4 5.5 (8 x 6: 6.9, 8 x 8: 7.2); 100: 8 x 5 7.7 (8 x 3: 10.1); 128: 8 x 2 8.8 (8 x 4: 9.3);
+// 160: 8 x 3 10.7 (16 x 1: 12.7, 16 x 3 in two launches: 16.9); 200: 16 x 1 12.9 (8 x 2: 14.8).
+// A given nw / g (non-zero) is kept.
+void skew_shape(int batch, int sweeps, int len, int& nw, int& g) {
+    const int lag = (AHEAD + 1) * HALF;
+    if (sweeps > MAX_SWEEPS) sweeps = MAX_SWEEPS;
+    double best_t = 0.0;
+    int best_nw = 0, best_g = 0;
+    for (int cnw : {4, 8, 16}) {
+        if (nw ? cnw != nw : (batch <= 32 ? cnw != 4 : (batch <= 128 ? cnw != 8 : (batch <= 256 ? cnw == 4 : cnw != 16)))) continue;
+        const int capacity = AVSI_NUM_CU * (16 / cnw);
+        double cost[MAX_SWEEPS / 4 + 1], best = 0.0;
+        int n = 0;
+        for (int cg = 1; cg <= MAX_SWEEPS / 4; ++cg) {
+            if (cg > capacity || cg * cnw > MAX_SWEEPS || (cg > 1 && (cg - 1) * cnw >= sweeps)) break;
+            const int per_launch = capacity / cg, launches = (batch + per_launch - 1) / per_launch;
+            const int resident = batch < per_launch ? batch : per_launch;
+            const int wg_per_cu = (resident * cg + AVSI_NUM_CU - 1) / AVSI_NUM_CU;
+            const double w = wg_per_cu * cnw / 4.0;                  // waves per SIMD on the most loaded CU
+            // (the waves of a SIMD get on best when they are consecutive stages of one utterance: one 16-wave workgroup
+            // 1.05 us per step at w = 4, two 8-wave ones 1.2; two 4-wave ones 0.85 at w = 2, one 8-wave one 0.75)
+            const double step_us = w <= 1.0 ? 0.6 : 0.30 * w + 0.30 / w + (cnw == 4 ? 0.1 : (cnw == 16 ? -0.2 : 0.0));
+            // (chained 16-wave workgroups: 129 utterances 16 x 3 took 16.9 ms where this model without the factor says 12)
+            cost[cg] = launches * step_us * skew_pipeline_steps(sweeps, cg * cnw, len, lag) * (cnw == 16 && cg > 1 ? 1.4 : 1.0);
+            if (n == 0 || cost[cg] < best) best = cost[cg];
+            n = cg;
+        }
+        int pick = 0;
+        for (int cg = 1; cg <= n && pick == 0; ++cg)
+            if (g ? cg == g : cost[cg] <= 1.05 * best) pick = cg;    // within 5 % of the cheapest: the smallest shape
+        if (pick && (best_nw == 0 || cost[pick] < best_t)) best_t = cost[pick], best_nw = cnw, best_g = pick;
+    }
+    if (best_nw) nw = best_nw, g = best_g;
+    else nw = nw ? nw : 8, g = g ? g : 1;         // (a given shape outside the table: the caller's range checks decide)
+}
+
 }  // namespace
 
 // word 0: status; (mean, max) per utterance; one row of stage counters per utterance; the diagonal arrays
@@ -389,6 +456,14 @@ extern "C" size_t avsi_lws_run_skew_workspace_bytes(int batch, int num_frames) {
     const size_t cells = (size_t)batch * skew_rows(num_frames) * LANES;
     return align256(16 + (size_t)batch * sizeof(float2)) + align256((size_t)batch * GPROG_INTS * sizeof(int)) +
            align256(cells * sizeof(float2)) + align256(cells * sizeof(float));
+}
+
+// the launch shape avsi_lws_run_skew_f32 takes for a batch (a given, non-zero *waves_per_group / *groups_per_utterance is kept)
+extern "C" int avsi_lws_skew_launch_shape(int batch, int num_frames, int sweeps, int* waves_per_group, int* groups_per_utterance) {
+    if (batch <= 0 || num_frames <= 0 || sweeps <= 0 || !waves_per_group || !groups_per_utterance) return AVSI_ERR_INVALID_ARG;
+    if (*waves_per_group != 0 && *waves_per_group != 4 && *waves_per_group != 8 && *waves_per_group != 16) return AVSI_ERR_INVALID_ARG;
+    skew_shape(batch, sweeps, skew_steps(num_frames), *waves_per_group, *groups_per_utterance);
+    return AVSI_OK;
 }
 
 extern "C" int avsi_lws_run_skew_f32(float* spec, int batch, int num_frames, int frame_len, int hop, int nfft, int L,
@@ -427,26 +502,17 @@ extern "C" int avsi_lws_run_skew_f32(float* spec, int batch, int num_frames, int
     if (frame_len == AVSI_LWS_STD_FRAME && hop == AVSI_LWS_STD_HOP && nfft == AVSI_LWS_STD_NFFT && L == AVSI_LWS_STD_L && !standard)
         return AVSI_ERR_UNSUPPORTED;          // lws_skew_weights.h is stale: regenerate it (tools/gen_lws_skew_weights.py)
     // Launch shape: NW stages (waves) per workgroup, G workgroups chained per utterance, all of them resident together (a CU
-    // holds 16 waves of this kernel: 128 VGPRs).  The sweeps of an utterance are a pipeline, so what counts is how many of its
-    // ~100 stages are in flight and how evenly the ACTIVE ones (about forty at any time: a stage trails its predecessor by
-    // four bodies) spread over the SIMDs: small batches take 4-wave workgroups, as many per utterance as the chip has room
-    // for; large batches fill the chip with utterances, 16 stages each.  Measured (ms per batch, NW x G): 32 utterances
-    // 16 x 8: 9.6, 8 x 8: 6.6, 4 x 8: 5.7; 1024 utterances 16 x 1: 60.8, 8 x 1: 72.1, 4 x 1: 94.7.
-    int NW = waves_per_group;
-    if (NW == 0) NW = batch <= 32 ? 4 : (batch <= 128 ? 8 : 16);
-    if (NW != 4 && NW != 8 && NW != 16) return AVSI_ERR_INVALID_ARG;
-    if (!standard) NW = 8;
-    const int capacity = AVSI_NUM_CU * (16 / NW);             // workgroups the chip holds at once
-    int G = groups_per_utterance;
-    if (G == 0) {
-        const int useful = (S.n + NW - 1) / NW;
-        // (every workgroup boundary is a hand-over through device memory: beyond eight of them per utterance the extra lag
-        // costs more than the stages bring -- 32 utterances, 4-wave workgroups: 8 per utterance 5.5 ms, 16: 6.3, 26: 7.4)
-        G = batch <= capacity ? capacity / batch : 1;
-        G = G < 1 ? 1 : (G > useful ? useful : G);
-        if (batch > 8 && G > 8) G = 8;
-    }
-    if (G < 1 || G * NW > MAX_SWEEPS || G > MAX_SWEEPS / 4 || G > capacity) return AVSI_ERR_INVALID_ARG;
+    // holds 16 waves of this kernel: 128 VGPRs) -- see skew_shape().
+    if (waves_per_group != 0 && waves_per_group != 4 && waves_per_group != 8 && waves_per_group != 16) return AVSI_ERR_INVALID_ARG;
+    // (each launch of a batch that needs several takes the shape of what is left: 257 utterances = 256 on 16 x 1, one on 4 x 12)
+    auto shape_for = [&](int utterances, int& nw, int& g) {
+        nw = standard ? waves_per_group : 8, g = groups_per_utterance;
+        if (nw == 0 || g == 0) skew_shape(utterances, S.n, skew_steps(num_frames), nw, g);
+        const int cap = AVSI_NUM_CU * (16 / nw);              // workgroups the chip holds at once
+        return g >= 1 && g * nw <= MAX_SWEEPS && g <= MAX_SWEEPS / 4 && g <= cap;
+    };
+    int NW, G;
+    if (!shape_for(batch, NW, G)) return AVSI_ERR_INVALID_ARG;
     const hipStream_t st = (hipStream_t)stream;
     const int rows = skew_rows(num_frames);
     char* ws = static_cast<char*>(workspace);
@@ -465,9 +531,10 @@ extern "C" int avsi_lws_run_skew_f32(float* spec, int batch, int num_frames, int
     avsi_lws_launch_stats(spec, batch, num_frames, reinterpret_cast<float*>(stats), st);
     // every workgroup of a launch must be resident (its stages wait for each other): batches beyond the chip's capacity
     // run as consecutive launches
-    const int per_launch = capacity / G > 0 ? capacity / G : 1;
-    for (int b0 = 0; b0 < batch; b0 += per_launch) {
-        const int nbatch = batch - b0 < per_launch ? batch - b0 : per_launch;
+    for (int b0 = 0, nbatch = 0; b0 < batch; b0 += nbatch) {
+        if (!shape_for(batch - b0, NW, G)) return AVSI_ERR_INVALID_ARG;
+        const int per_launch = AVSI_NUM_CU * (16 / NW) / G;
+        nbatch = batch - b0 < per_launch ? batch - b0 : per_launch;
         float2* sp = reinterpret_cast<float2*>(spec) + (size_t)b0 * num_frames * KB;
         float2* Db = D + (size_t)b0 * rows * LANES;
         float* Ab = A + (size_t)b0 * rows * LANES;

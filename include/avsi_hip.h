@@ -382,9 +382,10 @@ int avsi_istft_f32(const avsi_istft_args* args, void* stream);
  *                        predecessor (all workgroups of an utterance must be resident together), outputs invalid
  *   avsi_lws_run_skew_f32  the same sweeps (same arguments, same results up to the order of the 33 taps' sum) with the
  *                        FRAMES of a sweep in the lanes of a wave, six bins apart (csrc/lws_skew.hip): the default of the
- *                        host layer.  waves_per_group (4, 8, 16; 0 = 16) consecutive sweeps of ONE utterance per
- *                        workgroup, groups_per_utterance workgroups chained per utterance (0 = as many as the chip has
- *                        room for); results do not depend on either.  The workspace
+ *                        host layer.  waves_per_group (4, 8, 16) consecutive sweeps of ONE utterance per
+ *                        workgroup, groups_per_utterance workgroups chained per utterance; 0 = the cheapest shape under
+ *                        the library's pipeline model (avsi_lws_skew_launch_shape tells which: a host-side query, no
+ *                        GPU work); results do not depend on either.  The workspace
  *                        (avsi_lws_run_skew_workspace_bytes(batch, num_frames), ~1.4 MB per utterance of 252 frames)
  *                        holds the spectrogram in the kernel's diagonal layout; word 0 is the status as above
  *   avsi_lws_istft_f32   lws.istft  (inference.py:153): out [B][out_samples], out_samples <=
@@ -409,6 +410,7 @@ int avsi_lws_run_skew_f32(float* spec, int batch, int num_frames, int frame_len,
                           int waves_per_group, int groups_per_utterance, void* workspace, size_t workspace_bytes,
                           void* stream);
 size_t avsi_lws_run_skew_workspace_bytes(int batch, int num_frames);
+int avsi_lws_skew_launch_shape(int batch, int num_frames, int sweeps, int* waves_per_group, int* groups_per_utterance);
 size_t avsi_lws_istft_workspace_bytes(int batch, int num_frames, int nfft);
 int avsi_lws_istft_f32(const float* spec, int batch, int num_frames, const float* table, int hop, int nfft, float* out,
                        int64_t out_stride, int out_samples, void* workspace, size_t workspace_bytes, void* stream);

@@ -86,3 +86,32 @@ def test_forward_recurrence_is_cut_into_pieces_of_their_own_size(monkeypatch):
         assert ops.rec_fwd_parts(1088) == [(0, 1088, ops.coop_split(1088))]
     finally:
         ops.set_coop_cu_budget(None)
+
+
+def test_lws_skew_launch_shape():
+    """avsi_lws_skew_launch_shape (host-side query): the shapes avsi_lws_run_skew_f32 takes by itself -- every one
+    resident at once (its stages wait for each other), a given shape kept, bad arguments refused."""
+    import ctypes
+    from avsi_amd import _lib
+    L = _lib.lib()
+
+    def shape(batch, nw=0, g=0, frames=252, sweeps=102):
+        a, b = ctypes.c_int(nw), ctypes.c_int(g)
+        rc = L.avsi_lws_skew_launch_shape(batch, frames, sweeps, ctypes.byref(a), ctypes.byref(b))
+        return rc, a.value, b.value
+
+    got = {b: shape(b)[1:] for b in (1, 32, 64, 100, 128, 160, 200, 256, 1024)}
+    assert got == {1: (4, 13), 32: (4, 13), 64: (8, 4), 100: (8, 5), 128: (8, 2), 160: (8, 3), 200: (16, 1), 256: (16, 1),
+                   1024: (16, 1)}
+    for batch in list(range(1, 300)) + [511, 512, 1000, 4096]:
+        rc, nw, g = shape(batch)
+        assert rc == 0 and nw in (4, 8, 16) and 1 <= g <= 25
+        capacity = 256 * (16 // nw)                      # workgroups the chip holds: 16 waves of this kernel per CU
+        assert g <= capacity and g * nw <= 128
+        assert (g - 1) * nw < 102                        # no workgroup without a sweep
+        if batch * g > capacity:                         # consecutive launches: only when one workgroup per utterance is too many
+            assert g == 1 or batch > capacity // g
+    assert shape(1024, nw=8)[1:] == (8, 1) and shape(10, g=5)[1:] == (4, 5) and shape(10, nw=16, g=2)[1:] == (16, 2)
+    assert shape(2, sweeps=3)[1:] == (4, 1)              # fewer sweeps than stages of one workgroup
+    for bad in ((0, 0, 0), (4, 5, 0), (4, 0, 0, 0), (4, 0, 0, 252, 0)):
+        assert shape(*bad)[0] != 0
