@@ -132,6 +132,7 @@ constexpr int ring(int i) { return ((i % UNR) + UNR) % UNR; }
 struct LaneState {
     float2 R[UNR], P[UNR], Lb[UNR];
     float Ab[UNR];
+    float2 cnext;           // c(tau) of the coming step, requested from LDS a step ahead
     int tau, m;
 };
 
@@ -143,14 +144,16 @@ struct StepCtx {
     int M, trash_row;
     float thr;
     bool past_only;
-    bool dev_in, dev_out;   // wave-uniform: device-scope loads (the stage before sits in another workgroup) / stores (the stage after)
     unsigned lane8, lane4;
 };
 
 // STD: the weights of the reference's geometry as compile-time constants (lws_skew_weights.h) -- literal operands of the
 // multiply-adds.  As kernel arguments the 66 values do not fit the scalar registers beside everything else: the compiler
 // parked them in VGPR lanes and fetched every one with a v_readlane per tap (30 of ~340 instructions per step).
-template <int I, bool STD>
+// DIN / DOUT: device-scope loads (the stage before sits in another workgroup) / stores (the stage after) -- properties of
+// the wave (first / last of its workgroup), compiled in: as run-time flags they were two scalar branches per memory
+// operation, and a wave that has its SIMD to itself pays an issue slot for every scalar instruction.
+template <int I, bool STD, bool DIN, bool DOUT>
 __device__ __forceinline__ void skew_step(LaneState& L, const StepCtx& C, const SkewConst& W, int n) {
 #define WBU(p, c) (STD ? AVSI_LWS_STD_BU[p][c] : W.bu[p][c])
 #define WBD(p, c) (STD ? AVSI_LWS_STD_BD[p][c] : W.bd[p][c])
@@ -163,7 +166,7 @@ __device__ __forceinline__ void skew_step(LaneState& L, const StepCtx& C, const 
     const float amp = L.Ab[I];
     // (addresses: the utterance's base pointer in SGPRs for the whole kernel + a 32-bit byte offset per lane that includes the
     // row -- one v_add per access instead of 64-bit pointer arithmetic and a v_readfirstlane pair per row)
-    row_load8(C.dev_in, L.Lb[ring(I + PF)], C.Dg, C.lane8 + (unsigned)(t + PF + 16 > 0 ? t + PF + 16 : 0) * (unsigned)(LANES * sizeof(float2)));     // position tau + 11 of step n + PF
+    row_load8(DIN, L.Lb[ring(I + PF)], C.Dg, C.lane8 + (unsigned)(t + PF + 16 > 0 ? t + PF + 16 : 0) * (unsigned)(LANES * sizeof(float2)));     // position tau + 11 of step n + PF
     row_load4(L.Ab[ring(I + PF)], C.Ag, C.lane4 + (unsigned)(t + PF + ROW_OFF > 0 ? t + PF + ROW_OFF : 0) * (unsigned)(LANES * sizeof(float)));   // magnitude of the bin of step n + PF
     const int tau = L.tau, m = L.m;
     L.R[I] = arr;                                                                      // position tau + 11
@@ -184,7 +187,8 @@ __device__ __forceinline__ void skew_step(LaneState& L, const StepCtx& C, const 
     // ---- exchange: the row below (old values) from lane j + 1, the row above (new values) from lane j - 1
     float2 upr = make_float2(dpp_from_next(up.x), dpp_from_next(up.y));
     float2 dnr = make_float2(dpp_from_prev(dn.x), dpp_from_prev(dn.y));
-    const float2 c = C.ctab[tau & 63];
+    const float2 c = L.cnext;
+    L.cnext = C.ctab[(tau + 1) & 63];          // (a wrap to the next frame moves tau by 384 = 6 x 64: the same entry)
     const bool has_next = m + 1 < C.M && !C.past_only, has_prev = m >= 1;
     upr = sel(has_next, upr, make_float2(0.f, 0.f));
     dnr = sel(has_prev, dnr, make_float2(0.f, 0.f));
@@ -223,7 +227,7 @@ __device__ __forceinline__ void skew_step(LaneState& L, const StepCtx& C, const 
     // ---- store (row t + 5, every lane, always: lanes with nothing to store write a scratch row)
     const bool st = tau >= 0 && tau <= TAU_LAST && m < C.M;
     const unsigned off = C.lane8 + (unsigned)(st ? t + ROW_OFF : C.trash_row) * (unsigned)(LANES * sizeof(float2));
-    row_store8(C.dev_out, C.Dw, off, out);
+    row_store8(DOUT, C.Dw, off, out);
     // ---- next step of this lane
     const int nt = tau + 1;
     const bool wrap = nt > TAU_LAST;
@@ -235,48 +239,29 @@ __device__ __forceinline__ void skew_step(LaneState& L, const StepCtx& C, const 
 #undef WB0
 }
 
-template <bool STD, int H, int... Is>
+template <bool STD, int H, bool DIN, bool DOUT, int... Is>
 __device__ __forceinline__ void skew_half(LaneState& L, const StepCtx& C, const SkewConst& W, int n0, std::integer_sequence<int, Is...>) {
-    (skew_step<H * HALF + Is, STD>(L, C, W, n0 + H * HALF + Is), ...);
+    (skew_step<H * HALF + Is, STD, DIN, DOUT>(L, C, W, n0 + H * HALF + Is), ...);
 }
 
-// NW waves per workgroup = NW pipeline stages of one utterance; G workgroups per utterance
-template <int NW, bool STD>
-__global__ __launch_bounds__(64 * NW) void lws_skew_kernel(float2* __restrict__ Dall, const float* __restrict__ Aall, int B, int M,
-                                                          const SkewConst W, const AvsiLwsSchedule sched, int* __restrict__ status,
-                                                          const float2* __restrict__ stats, int* __restrict__ gprog_all, int G) {
-    __shared__ float2 ctab[64];
-    __shared__ int prog[NW];                    // bodies finished and visible, per stage of this workgroup (monotone)
-    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;      // wv: wave-uniform, and known to be
-    const int b = blockIdx.x / G, wg = blockIdx.x - b * G;
-    const int stage = wg * NW + wv, stages = G * NW;
-    const int rows = skew_rows(M);
-    const int nb = (skew_steps(M) + UNR - 1) / UNR;           // bodies per sweep
-    const int hlast = 2 * nb + AHEAD + 1;                     // published when a sweep is finished: every need is capped there
-    const int nbp = 2 * nb + 16;                              // counter values per sweep of a stage
-    // one counter per workgroup of the chain (its last stage publishes there), each on a 256-byte line of its own: polls
-    // and publications are device-scope accesses served at the memory side, and neighbours in one line queue on one channel
-    int* gprog = gprog_all + (size_t)b * GPROG_INTS;
-    volatile int* vprog = prog;
-    if (threadIdx.x < 64) {
-        float sn, cs;
-        sincospif(-2.f * (float)((threadIdx.x * W.phase_step) & 63) / 64.f, &sn, &cs);
-        ctab[threadIdx.x] = make_float2(cs, sn);
-    }
-    if (threadIdx.x < NW) prog[threadIdx.x] = 0;
-    __syncthreads();
-    const float2 st = stats[b];
-    const float mean = st.x, amax = st.y;
-    StepCtx C;
-    C.Dg = uniform_ptr(Dall + (size_t)b * rows * LANES);        // SGPRs from here on: the "s" operands of the memory instructions
-    C.Dw = uniform_ptr(Dall + (size_t)b * rows * LANES);
-    C.Ag = uniform_ptr(Aall + (size_t)b * rows * LANES);
-    C.ctab = ctab;
-    C.M = M;
-    C.trash_row = rows - 1;
-    C.lane8 = lane * 8u, C.lane4 = lane * 4u;
-    const bool dev_in = wv == 0, dev_out = wv == NW - 1;       // the stage before / after sits in another workgroup (or round)
-    C.dev_in = dev_in, C.dev_out = dev_out;
+struct StageCtx {           // where a wave sits in the chain of its utterance, and the counters of that chain
+    int wv, wg, lane, stage, stages, nb, hlast, nbp;
+    int* gprog;
+    volatile int* vprog;
+    int* status;
+    float mean, amax;
+};
+
+// the sweeps of one stage.  DIN / DOUT (first / last wave of a workgroup) are compiled in: the kernel enters one of three
+// copies of this function once, so the step loop has no branch on the wave's role and each copy its own register allocation
+template <int NW, bool STD, bool DIN, bool DOUT>
+__device__ __forceinline__ void skew_sweeps(StepCtx& C, const SkewConst& W, const AvsiLwsSchedule& sched, const StageCtx& Q) {
+    const int wv = Q.wv, wg = Q.wg, lane = Q.lane, stage = Q.stage, stages = Q.stages, nb = Q.nb, hlast = Q.hlast, nbp = Q.nbp;
+    int* gprog = Q.gprog;
+    volatile int* vprog = Q.vprog;
+    int* status = Q.status;
+    const float mean = Q.mean, amax = Q.amax;
+    constexpr bool dev_in = DIN, dev_out = DOUT;
     bool dead = false;
     int known = 0;            // last value read from the predecessor's counter
     int mine = 0;             // sweeps this stage has finished
@@ -298,8 +283,9 @@ __global__ __launch_bounds__(64 * NW) void lws_skew_kernel(float2* __restrict__ 
         for (int i = 0; i < UNR; ++i) L.R[i] = L.P[i] = L.Lb[i] = make_float2(0.f, 0.f), L.Ab[i] = 0.f;
         L.m = lane;
         L.tau = T0 - SKEW * lane;
+        L.cnext = C.ctab[L.tau & 63];
         // a stage whose predecessor sits in another workgroup polls device memory, which drains the loads in flight: it
-        // asks for QSLACK bodies more than it needs and then runs that many bodies on what it knows
+        // asks for QSLACK half bodies more than it needs and then runs that many on what it knows
         auto wait_pred = [&](int half) {           // half: index of the half body about to start
             if (pstage < 0 || dead) return;
             const int need = pbase + (half + AHEAD < hlast ? half + AHEAD : hlast);
@@ -337,15 +323,16 @@ __global__ __launch_bounds__(64 * NW) void lws_skew_kernel(float2* __restrict__ 
             // keep the count of the step loop: a store per step (scratch row)
             row_store8(false, C.Dw, C.lane8 + (unsigned)C.trash_row * (unsigned)(LANES * sizeof(float2)), make_float2(0.f, 0.f));
         }
+        constexpr std::make_integer_sequence<int, HALF> seq{};
         for (int body = 0; body < nb; ++body) {
             const int n0 = body * UNR;
             wait_pred(2 * body);
-            skew_half<STD, 0>(L, C, W, n0, std::make_integer_sequence<int, HALF>{});
+            skew_half<STD, 0, DIN, DOUT>(L, C, W, n0, seq);
             // everything issued before this half body's 18 operations is complete: the stores of the half bodies before it
             asm volatile("s_waitcnt vmcnt(18)" ::: "memory");
             publish(base + 2 * body);
             wait_pred(2 * body + 1);
-            skew_half<STD, 1>(L, C, W, n0, std::make_integer_sequence<int, HALF>{});
+            skew_half<STD, 1, DIN, DOUT>(L, C, W, n0, seq);
             asm volatile("s_waitcnt vmcnt(18)" ::: "memory");
             publish(base + 2 * body + 1);
         }
@@ -356,6 +343,51 @@ __global__ __launch_bounds__(64 * NW) void lws_skew_kernel(float2* __restrict__ 
         publish(base + hlast);
         ++mine;
     }
+}
+
+// NW waves per workgroup = NW pipeline stages of one utterance; G workgroups per utterance
+// (sixteen waves per CU whatever NW: the host counts on that many resident workgroups -- four waves per SIMD = 128 VGPRs)
+template <int NW, bool STD>
+__global__ __launch_bounds__(64 * NW, 4) void lws_skew_kernel(float2* __restrict__ Dall, const float* __restrict__ Aall, int B, int M,
+                                                          const SkewConst W, const AvsiLwsSchedule sched, int* __restrict__ status,
+                                                          const float2* __restrict__ stats, int* __restrict__ gprog_all, int G) {
+    __shared__ float2 ctab[64];
+    __shared__ int prog[NW];                    // bodies finished and visible, per stage of this workgroup (monotone)
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;      // wv: wave-uniform, and known to be
+    const int b = blockIdx.x / G, wg = blockIdx.x - b * G;
+    const int stage = wg * NW + wv, stages = G * NW;
+    const int rows = skew_rows(M);
+    const int nb = (skew_steps(M) + UNR - 1) / UNR;           // bodies per sweep
+    const int hlast = 2 * nb + AHEAD + 1;                     // published when a sweep is finished: every need is capped there
+    const int nbp = 2 * nb + 16;                              // counter values per sweep of a stage
+    // one counter per workgroup of the chain (its last stage publishes there), each on a 256-byte line of its own: polls
+    // and publications are device-scope accesses served at the memory side, and neighbours in one line queue on one channel
+    int* gprog = gprog_all + (size_t)b * GPROG_INTS;
+    volatile int* vprog = prog;
+    if (threadIdx.x < 64) {
+        float sn, cs;
+        sincospif(-2.f * (float)((threadIdx.x * W.phase_step) & 63) / 64.f, &sn, &cs);
+        ctab[threadIdx.x] = make_float2(cs, sn);
+    }
+    if (threadIdx.x < NW) prog[threadIdx.x] = 0;
+    __syncthreads();
+    const float2 st = stats[b];
+    const float mean = st.x, amax = st.y;
+    StepCtx C;
+    C.Dg = uniform_ptr(Dall + (size_t)b * rows * LANES);        // SGPRs from here on: the "s" operands of the memory instructions
+    C.Dw = uniform_ptr(Dall + (size_t)b * rows * LANES);
+    C.Ag = uniform_ptr(Aall + (size_t)b * rows * LANES);
+    C.ctab = ctab;
+    C.M = M;
+    C.trash_row = rows - 1;
+    C.lane8 = lane * 8u, C.lane4 = lane * 4u;
+    StageCtx Q;
+    Q.wv = wv, Q.wg = wg, Q.lane = lane, Q.stage = stage, Q.stages = stages, Q.nb = nb, Q.hlast = hlast, Q.nbp = nbp;
+    Q.gprog = gprog, Q.vprog = vprog, Q.status = status, Q.mean = mean, Q.amax = amax;
+    // the stage before the first wave / after the last one sits in another workgroup (or is this one in the next round)
+    if (wv == 0) skew_sweeps<NW, STD, true, false>(C, W, sched, Q);
+    else if (wv == NW - 1) skew_sweeps<NW, STD, false, true>(C, W, sched, Q);
+    else skew_sweeps<NW, STD, false, false>(C, W, sched, Q);
 }
 
 // spec [B][M][257] -> diagonal layout (bins, the five mirror positions above Nyquist, magnitudes); everything else zero
