@@ -9,7 +9,7 @@ from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int32, c_int6
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libavsi_hip.so")
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 AVSI_OK = 0
 AVSI_ERR_INVALID_ARG, AVSI_ERR_UNSUPPORTED, AVSI_ERR_LAUNCH, AVSI_ERR_WORKSPACE = -1, -2, -3, -4
@@ -55,7 +55,7 @@ class IstftArgs(Structure):
 class GemmEpilogue(Structure):
     """Mirror of ``avsi_gemm_epilogue`` (include/avsi_hip.h)."""
     _fields_ = [("bias", c_void_p), ("row_scale", c_void_p),
-                ("row_map_bp", c_int32), ("row_map_t", c_int32), ("row_map_b", c_int32)]
+                ("row_map_bp", c_int32), ("row_map_t", c_int32), ("row_map_b", c_int32), ("k_zero", c_int32 * 4)]
 
 
 # name -> (restype, argtypes); every symbol include/avsi_hip.h declares

@@ -56,6 +56,10 @@ struct GemmArgs {
     int64_t c_split_stride;  // elements between per-split partial outputs (0 = no split)
     int bnt;               // N tile width chosen by the host (128, or 64 for A . B with a narrow last tile)
     int n_group;           // N-blocks per column group of the block -> tile order (see tile_of_block)
+    // up to two 16-deep k-tiles that END in zero padding (avsi_gemm_epilogue::k_zero) and the number of their eight MFMA
+    // steps that multiply anything: step 4 q + s multiplies k = 8 q + s and 8 q + 4 + s, so a tile with kv leading real k
+    // needs its first min(kv, 4) steps, or 4 + min(kv - 8, 4) from kv = 9 on
+    int sp_kt[2], sp_steps[2];
     // implicit-GEMM convolution (gemm_dma_kernel<.., CONV = true>): A is never materialised, its rows are
     // gathered from one or two NHWC activations (tf.nn.conv2d SAME / stride 1 over concat(src0, up2x(src1)))
     const float* conv_s0;
@@ -549,25 +553,64 @@ __global__ __launch_bounds__(256, BNT == 256 ? 2 : (BK == 16 ? (NST == 3 ? 3 : 4
     __builtin_amdgcn_s_barrier();
 
     float af[2][TM][4], bf[2][TN][4];
-    for (int kt = 0; kt < nk; ++kt) {
-        // the stage being refilled was last read (tile kt-1) before the barrier of iteration kt-1
-        if (kt + NST - 1 < nk) issue(kt + NST - 1);
-        const float* a_s = sA + (kt % NST) * TILE;
-        const float* b_s = sB + (kt % NST) * TILEB;
-#pragma unroll
-        for (int h = 0; h < BK / 16; ++h) {
-            rd(2 * h, a_s, b_s, af[0], bf[0]);
-            rd(2 * h + 1, a_s, b_s, af[1], bf[1]);
-            mm(af[0], bf[0]);
-            mm(af[1], bf[1]);
-        }
-        // tile kt+1 must have landed before anyone reads it; with three stages tile kt+2's DMAs (just
-        // issued) stay in flight across the barrier
+    // tile kt+1 must have landed before anyone reads it; with three stages tile kt+2's DMAs (just issued) stay in flight
+    // across the barrier
+    auto tile_done = [&](int kt) {
         if (NST == 3 && kt + 2 < nk)
             asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(PPT) : "memory");
         else
             asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
+    };
+    // The k-tiles in order, in up to three runs of whole tiles with a tile that ENDS in zero padding (g.sp_kt, ascending;
+    // -1 = none) after the first two: such a tile runs a LOOP over its first sp_steps MFMA steps (fragments of one step
+    // read with 4-byte LDS loads).  Loops only -- any branch that selects between two straight-line versions of a tile
+    // made the compiler copy the 128 accumulator registers of the wide tile at the merge (256 VGPRs + 500 spilled).
+    int kt = 0;
+#pragma unroll 1
+    for (int seg = 0; seg < 3; ++seg) {
+        const int sp = (BK == 16 && !TA && !TB && !CONV && seg < 2) ? g.sp_kt[seg] : -1;
+        const int run_end = sp >= 0 && sp < nk ? sp : nk;
+        for (; kt < run_end; ++kt) {
+            // the stage being refilled was last read (tile kt-1) before the barrier of iteration kt-1
+            if (kt + NST - 1 < nk) issue(kt + NST - 1);
+            const float* a_s = sA + (kt % NST) * TILE;
+            const float* b_s = sB + (kt % NST) * TILEB;
+#pragma unroll
+            for (int h = 0; h < BK / 16; ++h) {
+                rd(2 * h, a_s, b_s, af[0], bf[0]);
+                rd(2 * h + 1, a_s, b_s, af[1], bf[1]);
+                mm(af[0], bf[0]);
+                mm(af[1], bf[1]);
+            }
+            tile_done(kt);
+        }
+        if (kt >= nk) break;
+        if (BK == 16 && !TA && !TB && !CONV) {
+            if (kt + NST - 1 < nk) issue(kt + NST - 1);
+            const float* a_s = sA + (kt % NST) * TILE;
+            const float* b_s = sB + (kt % NST) * TILEB;
+            const int steps = g.sp_steps[seg];
+#pragma unroll 1
+            for (int st = 0; st < steps; ++st) {          // step 4 q + s multiplies k = 8 q + s (lanes 0 .. 31) and 8 q + 4 + s
+                const int q = st >> 2, s4 = st & 3;
+                float a1[TM], b1[TN];
+#pragma unroll
+                for (int i = 0; i < TM; ++i) {
+                    const int row = wm * (32 * TM) + i * 32 + li;
+                    a1[i] = a_s[row * BK + (((2 * q + hi) ^ swz(row)) << 2) + s4];
+                }
+#pragma unroll
+                for (int j = 0; j < TN; ++j) b1[j] = b_s[(8 * q + 4 * hi + s4) * BNT + wn * (32 * TN) + j * 32 + li];
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[i], b1[j], acc[i][j], 0, 0, 0);
+            }
+            tile_done(kt);
+            ++kt;
+        }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
@@ -748,6 +791,28 @@ int avsi_gemm_launch(int transA, int transB, int M, int N, int K, float alpha, c
         g.bnt = 256;
     g.n_blocks = (int)avsi_ceil_div(N, g.bnt);
     g.c_split_stride = splits > 1 ? c_split_stride : 0;
+    g.sp_kt[0] = g.sp_kt[1] = -1, g.sp_steps[0] = g.sp_steps[1] = 8;
+    if (ep && dma_ok && !transA && splits == 1) {
+        // zero padding inside the reduction (the caller's promise): a k-tile that ends in it runs only the MFMA steps that
+        // multiply something -- up to two such tiles (the 250 -> 256 padding of each half of a BLSTM layer's input)
+        for (int k = 0; k < 4; ++k)
+            if (ep->k_zero[k] < 0 || ep->k_zero[k] > K) return AVSI_ERR_INVALID_ARG;
+        if (ep->k_zero[0] > ep->k_zero[1] || ep->k_zero[2] > ep->k_zero[3]) return AVSI_ERR_INVALID_ARG;
+        int found = 0;
+        for (int r = 0; r < 2 && found < 2; ++r) {
+            const int lo = ep->k_zero[2 * r], hi = ep->k_zero[2 * r + 1];
+            if (hi <= lo) continue;
+            // the tile that holds lo, if the range reaches that tile's end
+            const int kt = lo / 16, kv = lo - 16 * kt;
+            if (hi < 16 * (kt + 1) && hi < K) continue;
+            const int steps = kv == 0 ? 0 : (kv <= 4 ? kv : (kv <= 8 ? 4 : (kv <= 12 ? kv - 4 : 8)));
+            if (steps < 8 && (found == 0 || g.sp_kt[0] != kt)) g.sp_kt[found] = kt, g.sp_steps[found] = steps, ++found;
+        }
+        if (found == 2 && g.sp_kt[0] > g.sp_kt[1]) {          // the kernel walks them in ascending order
+            const int t0 = g.sp_kt[0], t1 = g.sp_steps[0];
+            g.sp_kt[0] = g.sp_kt[1], g.sp_steps[0] = g.sp_steps[1], g.sp_kt[1] = t0, g.sp_steps[1] = t1;
+        }
+    }
     {   // column-group width: the group's slice of op(B), k_split_len x (n_group * 128) floats, should fill about half of
         // one XCD's 4 MiB L2
 

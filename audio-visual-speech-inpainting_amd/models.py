@@ -330,8 +330,13 @@ class StackedBLSTMModel(object):
         xproj = self._buf('xproj', (T, Bp, 2 * GP))
         c['layer_in'] = []
         c['reserve'] = []
+        # zero padding inside the reductions (weight rows that are zero by construction, ParamLayout): layer 0 behind its
+        # real inputs, the other layers and the projection behind the H real units of each direction
+        H = self.layout.H
+        kz_hidden = ((H, HP), (HP + H, 2 * HP))
         for li in range(self.num_layers):
             kp = self.layout.kp[li]
+            kz = ((self.layout.input_dim, kp),) if li == 0 else kz_hidden
             if self.layout.side_dim(li):
                 # tile(side) . W_side is the same row for every frame of an utterance: one small GEMM
                 # [Bp, E] . [E, 2048] (+ bias), broadcast over time, and the layer GEMM accumulates
@@ -342,7 +347,7 @@ class StackedBLSTMModel(object):
                 eb = self._buf('side_bias', (Bp, 2 * GP))
                 ops.gemm(sp, v.p('we'), out=eb, bias=v.p('b%d' % li))
                 xproj.copy_(eb.unsqueeze(0).expand(T, Bp, 2 * GP))
-                ops.gemm(x.view(T * Bp, kp), v.p('wx%d' % li), out=xproj.view(T * Bp, 2 * GP), beta=1.0)
+                ops.gemm(x.view(T * Bp, kp), v.p('wx%d' % li), out=xproj.view(T * Bp, 2 * GP), beta=1.0, k_zero=kz)
                 c['side_p'] = sp
             elif self.precision == 'bf16x3' and not keep:
                 # the split weights are packed once per set of variables (repack() bumps the version)
@@ -352,7 +357,7 @@ class StackedBLSTMModel(object):
                     hit = self._ws[key] = (v.version, ops.pack_bf16x3_b(v.p('wx%d' % li)))
                 ops.gemm_bf16x3(x.view(T * Bp, kp), hit[1], xproj.view(T * Bp, 2 * GP), kp, bias=v.p('b%d' % li))
             else:
-                ops.gemm(x.view(T * Bp, kp), v.p('wx%d' % li), out=xproj.view(T * Bp, 2 * GP), bias=v.p('b%d' % li))
+                ops.gemm(x.view(T * Bp, kp), v.p('wx%d' % li), out=xproj.view(T * Bp, 2 * GP), bias=v.p('b%d' % li), k_zero=kz)
             hout = self._buf('h%d' % li, (T, Bp, 2 * HP))
             resv = self._buf('resv%d' % li, (T, Bp, 2, 5, HP)) if keep else None
             ops.blstm_rec_fwd(xproj, v.p('wh%d' % li), hout, resv, self.rows_per_wg)
@@ -391,10 +396,11 @@ class StackedBLSTMModel(object):
         # 257 bins = one 256-column product on the wide (128 x 256) tile + the last bin on a narrow one, instead of five
         # 64-column tiles of which the fifth carries one useful column (AVSI_PROJ_SPLIT=0: the single product)
         n_main = F - F % 256 if (_PROJ_SPLIT and F > 256 and 0 < F % 256 <= 32 and T * Bp >= 65536) else F
-        ops.gemm(x2, v.p('pw'), out=p2, n=n_main, bias=v.p('pb'), row_scale=row_scale.view(-1), row_map=(Bp, T, B))
+        ops.gemm(x2, v.p('pw'), out=p2, n=n_main, bias=v.p('pb'), row_scale=row_scale.view(-1), row_map=(Bp, T, B),
+                 k_zero=kz_hidden)
         if n_main < F:
             ops.gemm(x2, v.p('pw')[:, n_main:F], out=p2[:, n_main:], n=F - n_main, bias=v.p('pb')[n_main:F],
-                     row_scale=row_scale.view(-1), row_map=(Bp, T, B))
+                     row_scale=row_scale.view(-1), row_map=(Bp, T, B), k_zero=kz_hidden)
         c['row_scale'] = row_scale
         c['pred'] = pred
         c['kept'] = keep
@@ -403,7 +409,7 @@ class StackedBLSTMModel(object):
             lay = self.layout
             asr = torch.empty((B, T, lay.asr), dtype=torch.float32, device=self.device)
             ops.gemm(x.view(T * Bp, 2 * HP), v.p('pw')[:, lay.asr_col:lay.asr_col + lay.asr], out=asr.view(B * T, lay.asr),
-                     n=lay.asr, bias=v.p('pb')[lay.asr_col:lay.asr_col + lay.asr], row_map=(Bp, T, B))
+                     n=lay.asr, bias=v.p('pb')[lay.asr_col:lay.asr_col + lay.asr], row_map=(Bp, T, B), k_zero=kz_hidden)
             c['asr_logits'] = asr
         if self.blend:
             # prediction = seq_mask * (target * mask + logits * (1 - mask)); loss_func = loss_hole

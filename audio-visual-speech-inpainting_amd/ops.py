@@ -13,12 +13,14 @@ from . import _lib
 
 
 def gemm(a, b, out=None, trans_a=False, trans_b=False, m=None, n=None, k=None, alpha=1.0, beta=0.0,
-         bias=None, row_scale=None, row_map=None, ldc=None):
+         bias=None, row_scale=None, row_map=None, ldc=None, k_zero=None):
     """C = alpha * op(A) . op(B) + bias (+ beta * C) through avsi_gemm_f32.
 
     a, b: 2-D float32 device tensors, unit stride along their last dim (row pitch = lda/ldb).
     m, n, k default to the logical shapes implied by a/b; pass them to ignore padding columns.
-    row_map = (Bp, T, B): time-major rows -> batch-major output rows (see avsi_hip.h)."""
+    row_map = (Bp, T, B): time-major rows -> batch-major output rows (see avsi_hip.h).
+    k_zero = ((lo, hi), ...): up to two ranges of the reduction index whose rows of op(B) are zero (padding): the caller's
+    promise, which lets the 16-deep A . B tiles skip the multiply-adds that see padding only."""
     _lib.require_cuda(a, b, out, bias, row_scale)
     L = _lib.lib()
     for x in (a, b):
@@ -34,6 +36,9 @@ def gemm(a, b, out=None, trans_a=False, trans_b=False, m=None, n=None, k=None, a
     ep.bias, ep.row_scale = _lib.ptr(bias), _lib.ptr(row_scale)
     if row_map is not None:
         ep.row_map_bp, ep.row_map_t, ep.row_map_b = (int(v) for v in row_map)
+    if k_zero:
+        for i, (lo, hi) in enumerate(list(k_zero)[:2]):
+            ep.k_zero[2 * i], ep.k_zero[2 * i + 1] = int(lo), int(hi)
     _lib.check(L.avsi_gemm_f32(int(trans_a), int(trans_b), M, N, K, float(alpha), _lib.ptr(a), a.stride(0),
                                _lib.ptr(b), b.stride(0), float(beta), _lib.ptr(out),
                                out.stride(0) if ldc is None else ldc, ctypes.byref(ep), _lib.stream_ptr()),

@@ -109,6 +109,11 @@ typedef struct avsi_gemm_epilogue {
     const float* bias;        /* [N] or null */
     const float* row_scale;   /* [M] or null, applied after bias */
     int32_t row_map_bp, row_map_t, row_map_b;
+    /* zero padding inside the reduction: the caller's promise that rows [k_zero[0], k_zero[1]) and [k_zero[2], k_zero[3])
+     * of op(B) (or those columns of op(A)) are zero -- the 250 -> 256 padding of the two halves of a BLSTM layer's
+     * input, the 257 -> 272 padding of the network input.  A . B on the 16-deep tiles then skips the MFMA steps that
+     * multiply padding only (same result); all zeros = no promise; other forms ignore it */
+    int32_t k_zero[4];
 } avsi_gemm_epilogue;
 
 int avsi_gemm_f32(int transA, int transB, int M, int N, int K, float alpha,

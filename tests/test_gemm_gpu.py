@@ -101,6 +101,42 @@ def test_at_most_32_columns_take_the_narrow_tile(ops, N):
     assert np.abs(got.cpu().numpy() - ref).max() < 2e-6 * K * 4
 
 
+@pytest.mark.parametrize("M,N,K,ranges", [(8192, 2048, 512, ((250, 256), (506, 512))), (8192, 2048, 272, ((257, 272),)),
+                                          (300, 257, 512, ((250, 256), (506, 512))), (8192, 2048, 400, ((393, 400),)),
+                                          (4096, 256, 512, ((250, 256), (506, 512))), (640, 2048, 64, ((3, 61),)),
+                                          (640, 128, 48, ((0, 16), (40, 48)))])
+def test_zero_padding_inside_the_reduction_is_skipped_not_changed(ops, M, N, K, ranges):
+    """avsi_gemm_epilogue::k_zero: rows of B the caller knows to be zero (the 250 -> 256 padding of a BLSTM layer's two
+    input halves, models.py:95-115 has no padding at all) -- the 16-deep tiles skip the MFMA steps that would multiply
+    padding only.  A keeps NON-zero values there (the training pass puts a column of ones into the padding), so a
+    skipped step that was needed, or a needed one that was skipped, shows: equal to the plain product bit for bit."""
+    rng = np.random.default_rng(K + N)
+    A = rng.normal(size=(M, K)).astype(np.float32)
+    B = rng.normal(size=(K, N)).astype(np.float32)
+    for lo, hi in ranges:
+        B[lo:hi] = 0.0
+    bias = rng.normal(size=N).astype(np.float32)
+    a, b, bi = torch.from_numpy(A).cuda(), torch.from_numpy(_pad_cols(B, (N + 3) // 4 * 4)).cuda(), torch.from_numpy(bias).cuda()
+    plain = ops.gemm(a, b, n=N, bias=bi)
+    skipped = ops.gemm(a, b, n=N, bias=bi, k_zero=ranges)
+    assert torch.equal(plain, skipped)
+    ref = A.astype(np.float64) @ B.astype(np.float64) + bias
+    assert np.abs(skipped.cpu().numpy() - ref).max() < 2e-6 * K * 4
+    # the promise is the caller's: with a non-zero row inside a range the skipped product differs (the steps ARE skipped)
+    if (M, N, K) == (8192, 2048, 272):
+        b2 = b.clone()
+        b2[271] = 1.0
+        assert not torch.equal(ops.gemm(a, b2, n=N, bias=bi), ops.gemm(a, b2, n=N, bias=bi, k_zero=ranges))
+
+
+def test_k_zero_ranges_are_checked(ops):
+    import avsi_amd
+    a, b = torch.zeros(256, 64, device='cuda'), torch.zeros(64, 128, device='cuda')
+    for bad in (((10, 5),), ((0, 65),), ((-1, 4),)):
+        with pytest.raises(avsi_amd._lib.AvsiError):
+            ops.gemm(a, b, k_zero=bad)
+
+
 def test_rejects_unaligned(ops):
     import avsi_amd
     a = torch.zeros(8, 6, device='cuda')
