@@ -69,6 +69,29 @@ def test_run_lws_matches_oracle(L, shape):
         assert o.inconsistency(got[b].astype(np.complex128)) < 1.05 * o.inconsistency(ref[b]) + 1e-6
 
 
+@pytest.mark.parametrize("frame,hop", [(512, 256), (320, 160), (400, 200)])
+def test_other_window_geometries_match_oracle(L, frame, hop):
+    """Geometries other than the reference's 384 / 192 (inference.py:119) take the skewed kernel's general form -- the
+    consistency weights as kernel arguments instead of compile-time constants (lws_skew_kernel<8, false>) -- and the
+    frame-by-frame kernel: both against the oracle, on gapped spectrograms."""
+    kw = dict(nofuture_iterations=1, online_iterations=1, batch_iterations=10, batch_alpha=100, batch_beta=0.9)
+    o = OL.LWS(frame, hop, fftsize=512, **kw)
+    specs = []
+    for i, gap in enumerate([(6, 11), (2, 7)]):
+        S = o.stft(_speechlike(20 * hop, 30 + i))
+        S[gap[0]:gap[1]] = np.abs(S[gap[0]:gap[1]])
+        specs.append(S)
+    S0 = np.stack(specs)
+    ref = np.stack([o.run_lws(s.astype(np.complex64)) for s in S0])
+    for kernel in ('skew', 'raster'):
+        got = L.lws(frame, hop, fftsize=512, kernel=kernel, **kw).run_lws(S0.astype(np.complex64))
+        np.testing.assert_allclose(np.abs(got), np.abs(S0), rtol=2e-5, atol=1e-3)
+        err = np.abs(got - ref)
+        assert np.sqrt((err ** 2).sum() / (np.abs(ref) ** 2).sum()) < 2e-3, kernel
+        for b in range(2):
+            assert o.inconsistency(got[b].astype(np.complex128)) < 1.05 * o.inconsistency(ref[b]) + 1e-6, kernel
+
+
 def test_launch_shape_does_not_change_the_result(L):
     """Utterances per wave (1, 2, 4) and waves per group (the sweeps of an utterance pipelined over 4, 8 or 16 waves,
     each sweep trailing its predecessor by two rows, over one or several workgroups): the raster-order dependences are kept exactly, so the results
