@@ -284,10 +284,14 @@ class UNetFConvModel(object):
             return
         B, T, F = self._dims()
         m = self.masks[:, :T].contiguous()
-        x0 = self._buf('x0', (B * T * F, 4))                       # [B, T, F, 1] with channel pitch 4
         fe = ap.frontend(self.target_sources, window_size=16, step_size=8, n_fft=256, num_frames_out=T, num_bins=F,
                          mean=self.audio_feat_mean, std=self.audio_feat_std, masks=m, want_spec=True, want_feat=True)
-        x0[:, 0] = fe['feat'].reshape(-1)
+        if self.is_training or getattr(self, '_keep_for_backward', False):
+            x0 = self._buf('x0', (B * T * F, 4))                   # [B, T, F, 1] with channel pitch 4 (the backward kernels' pitch)
+            x0[:, 0] = fe['feat'].reshape(-1)
+        else:
+            # inference: the one-channel layers read the front end's output where it lies (channel pitch 1), no copy
+            x0 = fe['feat'].reshape(B * T * F, 1)
         c['target_spec_norm'], c['net_inputs'], c['x0'], c['mask_t'] = fe['spec'], fe['feat'], x0, m
 
     @property
@@ -335,6 +339,8 @@ class UNetFConvModel(object):
         y = self._buf(name + '/act', (R, ld)) if (keep or not pool) else None
         if pool:
             ops.bn_act_pool(conv, B, H, W, cout, pooled, y, *bn_args, act)
+        elif not bn and act == 0 and not keep:
+            y = conv                     # the output layer (no batch norm, no activation): nothing to apply, no copy either
         else:
             ops.bn_act(conv, cout, y, *bn_args, act)
         self._cache['saved'][name] = dict(k=k, cout=cout, bn=bn, act=act, src0=src0, c0=c0, src1=src1, c1=c1, B=B, H=H,
@@ -480,7 +486,7 @@ class UNetFConvModel(object):
             # gradients asked of a model built for inference: its forward pass kept nothing (fused pooling layers);
             # run it again in the keeping form
             self._keep_for_backward = True
-            for key in ('pred', 'inference', 'saved', 'pool', 'loss3', 'dpred', 'rowmask'):
+            for key in ('x0', 'pred', 'inference', 'saved', 'pool', 'loss3', 'dpred', 'rowmask'):
                 c.pop(key, None)
         self._loss(want_grad=True)
         B, T, F = self._dims()
