@@ -123,6 +123,9 @@ __global__ __launch_bounds__(512, 2) void blstm_rec_fwd_coop_kernel(const CoopAr
     const int member = kk % S;
     const int group = (kk / S) * AVSI_NUM_XCD + xcd;
     if (group >= a.ngroups) return;
+    // behind a launch that gave up a bounded wait every result is void (sticky status word): leave at once instead of
+    // spending 2^22 polls per wait on step counters that launch may have left behind
+    if (__hip_atomic_load(a.sync, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return;
     const int dir = group & 1;
     const int b0 = (a.tile0 + (group >> 1)) * 32;
     const int T = a.T, Bp = a.Bp;
@@ -290,6 +293,9 @@ __global__ __launch_bounds__(512, 2) void blstm_rec_fwd_coop_fine_kernel(const C
     const int member = kk % S;
     const int group = (kk / S) * AVSI_NUM_XCD + xcd;
     if (group >= a.ngroups) return;
+    // behind a launch that gave up a bounded wait every result is void (sticky status word): leave at once instead of
+    // spending 2^22 polls per wait on step counters that launch may have left behind
+    if (__hip_atomic_load(a.sync, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return;
     const int dir = group & 1;
     const int b0 = (a.tile0 + (group >> 1)) * 32;
     const int T = a.T, Bp = a.Bp;
@@ -605,6 +611,9 @@ __global__ __launch_bounds__(512, 2) void blstm_rec_bwd_coop_kernel(const CoopBw
     const int member = kk % S;
     const int group = (kk / S) * AVSI_NUM_XCD + xcd;
     if (group >= a.ngroups) return;
+    // behind a launch that gave up a bounded wait every result is void (sticky status word): leave at once instead of
+    // spending 2^22 polls per wait on step counters that launch may have left behind
+    if (__hip_atomic_load(a.sync, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return;
     const int dir = group & 1;
     const int b0 = (a.tile0 + (group >> 1)) * 32;
     const int T = a.T, Bp = a.Bp;
@@ -747,6 +756,9 @@ __global__ __launch_bounds__(512, 2) void blstm_rec_bwd_coop_fine_kernel(const C
     const int member = mem_all % S, half = mem_all / S;
     const int group = (kk / (S * RH)) * AVSI_NUM_XCD + xcd;
     if (group >= a.ngroups) return;
+    // behind a launch that gave up a bounded wait every result is void (sticky status word): leave at once instead of
+    // spending 2^22 polls per wait on step counters that launch may have left behind
+    if (__hip_atomic_load(a.sync, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return;
     const int dir = group & 1;
     const int b0 = (a.tile0 + (group >> 1)) * 32 + half * 16;
     const int T = a.T, Bp = a.Bp;

@@ -73,6 +73,9 @@ __global__ __launch_bounds__(512, 4) void blstm_rec_fwd_cs_kernel(const CsArgs a
     const int member = kk % MEMBERS;
     const int lgroup = (kk / MEMBERS) * AVSI_NUM_XCD + xcd;
     if (lgroup >= a.ngroups) return;
+    // behind a launch that gave up a bounded wait every result is void (sticky status word): leave at once instead of
+    // spending 2^22 polls per wait on step counters that launch may have left behind
+    if (__hip_atomic_load(a.sync, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return;
     const int group = a.group0 + lgroup;
     const int dir = group & 1;
     const int b0 = (group >> 1) * ROWS;

@@ -5,6 +5,8 @@
 //   - avsi_colsum_f32        : column sums of a [M][ld] matrix (bias gradients), two-stage, deterministic
 //   - avsi_sum_slabs_f32     : sum of split-K partial slabs (gemm.hip), deterministic
 //   - avsi_adam_tf_f32       : tf.train.AdamOptimizer update on flat buffers (models.py:168; App. A.7)
+//   - avsi_adam_tf_guarded_f32 / avsi_step_guard_f32 : the same update behind a device-side step guard (a non-finite loss or
+//                              a cooperative-kernel timeout on any rank voids the step before a variable is touched)
 // All are grid-stride kernels with 16-byte accesses where alignment allows.
 #include "avsi_common.h"
 
@@ -89,7 +91,10 @@ __global__ __launch_bounds__(TPB) void sum_slabs_kernel(const float* __restrict_
 __global__ __launch_bounds__(TPB) void adam_tf_kernel(float* __restrict__ p, const float* __restrict__ g,
                                                       float* __restrict__ m, float* __restrict__ v, int64_t n,
                                                       float lr_t, float b1, float b2, float eps, float gscale,
-                                                      float l2) {
+                                                      float l2, const float* __restrict__ skip, int n_skip) {
+    // step guard: any word that is not exactly zero (NaN included) voids the step -- nothing is read or written
+    for (int k = 0; k < n_skip; ++k)
+        if (!(skip[k] == 0.f)) return;
     const int64_t n4 = n >> 2;
     for (int64_t i = (int64_t)blockIdx.x * TPB + threadIdx.x; i < n4; i += (int64_t)gridDim.x * TPB) {
         float4 pv = reinterpret_cast<float4*>(p)[i];
@@ -116,6 +121,16 @@ __global__ __launch_bounds__(TPB) void adam_tf_kernel(float* __restrict__ p, con
         m[i] = b1 * m[i] + (1.f - b1) * gk;
         v[i] = b2 * v[i] + (1.f - b2) * gk * gk;
         p[i] -= lr_t * m[i] / (__builtin_amdgcn_sqrtf(v[i]) + eps);
+    }
+}
+
+// out[0] = NaN unless *loss is finite, out[1] = 1 if a cooperative status word is set (else 0): the two words of the
+// step guard, summed over the data-parallel ranks inside the last gradient bucket
+__global__ void step_guard_kernel(const float* loss, const int* status_a, const int* status_b, float* out) {
+    if (threadIdx.x == 0) {
+        const bool finite = !loss || (*loss - *loss == 0.f);
+        out[0] = finite ? 0.f : __builtin_nanf("");
+        out[1] = ((status_a && *status_a != 0) || (status_b && *status_b != 0)) ? 1.f : 0.f;
     }
 }
 
@@ -223,9 +238,23 @@ int avsi_sum_slabs_launch(const float* slabs, int64_t n, int count, int64_t stri
     return avsi_launch_status();
 }
 
+extern "C" int avsi_step_guard_f32(const float* loss, const int* status_a, const int* status_b, float* out2, void* stream) {
+    if (!out2) return AVSI_ERR_INVALID_ARG;
+    avsi_clear_error();
+    hipLaunchKernelGGL(step_guard_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, loss, status_a, status_b, out2);
+    return avsi_launch_status();
+}
+
 extern "C" int avsi_adam_tf_f32(float* param, const float* grad, float* m, float* v, int64_t n, float lr, float beta1,
                                 float beta2, float eps, int64_t step, float grad_scale, float l2, void* stream) {
+    return avsi_adam_tf_guarded_f32(param, grad, m, v, n, lr, beta1, beta2, eps, step, grad_scale, l2, nullptr, 0, stream);
+}
+
+extern "C" int avsi_adam_tf_guarded_f32(float* param, const float* grad, float* m, float* v, int64_t n, float lr, float beta1,
+                                        float beta2, float eps, int64_t step, float grad_scale, float l2, const float* skip,
+                                        int n_skip, void* stream) {
     if (!param || !grad || !m || !v || n <= 0 || step < 1) return AVSI_ERR_INVALID_ARG;
+    if (n_skip < 0 || n_skip > 8 || (n_skip > 0 && !skip)) return AVSI_ERR_INVALID_ARG;
     if ((reinterpret_cast<uintptr_t>(param) | reinterpret_cast<uintptr_t>(grad) | reinterpret_cast<uintptr_t>(m) |
          reinterpret_cast<uintptr_t>(v)) & 15)
         return AVSI_ERR_UNSUPPORTED;
@@ -233,6 +262,6 @@ extern "C" int avsi_adam_tf_f32(float* param, const float* grad, float* m, float
     const double lr_t = (double)lr * sqrt(1.0 - pow((double)beta2, (double)step)) / (1.0 - pow((double)beta1, (double)step));
     avsi_clear_error();
     hipLaunchKernelGGL(adam_tf_kernel, dim3(grid_for(n >> 2, TPB)), dim3(TPB), 0, (hipStream_t)stream, param, grad, m, v,
-                       n, (float)lr_t, beta1, beta2, eps, grad_scale, l2);
+                       n, (float)lr_t, beta1, beta2, eps, grad_scale, l2, skip, n_skip);
     return avsi_launch_status();
 }

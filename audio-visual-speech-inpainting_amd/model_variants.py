@@ -80,6 +80,9 @@ class TwoStepVariables(object):
     def __getattr__(self, name):            # flat, layout, global_step, adam_m, ... of the trained network
         return getattr(self.av, name)
 
+    def rewind_step(self):
+        self.av.rewind_step()
+
     def save(self, path):
         self.video.save(path + '.vnet')
         return self.av.save(path)
@@ -167,8 +170,8 @@ class StackedBLSTM2StepsModel(object):
         # everything else the drivers fetch is the second step's (models.py:280-294)
         if name in ('target_spec_norm', 'inference', 'prediction', 'loss', 'loss_func', 'loss_hole', 'loss_valid',
                     'train_op', 'learning_rate', 'global_step', 'enhanced_sources', 'enhanced_sources_oracle_phase',
-                    'all_vars', 'train_vars', 'gradients', 'nonfinite_flag', 'net_inputs', 'target_stft', 'sequence_lengths', 'masks',
-                    'target_sources'):
+                    'all_vars', 'train_vars', 'gradients', 'nonfinite_flag', 'step_guard', 'net_inputs', 'target_stft',
+                    'sequence_lengths', 'masks', 'target_sources'):
             return getattr(self._chain(), name)
         raise AttributeError(name)
 

@@ -152,6 +152,11 @@ class BLSTMVariables:
         self.adam_m = torch.from_numpy(ck['__adam_m__']).to(self.device) if '__adam_m__' in ck else None
         self.adam_v = torch.from_numpy(ck['__adam_v__']).to(self.device) if '__adam_v__' in ck else None
 
+    def rewind_step(self):
+        """Take back the count of ONE optimiser step that the device-side step guard voided (the variables and slots
+        were left alone by it; the host counted it before the verdict arrived)."""
+        self.global_step -= 1
+
     def unpack_grads(self, gpacked, out=None):
         """reference-layout gradient <- gather(gradient buffer written by the backward kernels)."""
         return torch.index_select(gpacked, 0, self._grad_index, out=out)
@@ -537,11 +542,12 @@ class StackedBLSTMModel(object):
         v, lay = self.variables, self.layout
         F, ldp = self.audio_feat_dim, self.layout.ldp
         M = T * Bp
-        # one slot behind the gradients carries this rank's "my loss is not finite" word through the LAST all-reduce
-        # bucket (loss * 0: NaN for a NaN or infinite loss, and NaN survives the sum over ranks) -- the trainer reads
-        # it one step late together with the loss, so the rank-synchronous abort costs neither a collective of its
-        # own nor a host synchronisation (`nonfinite_flag`)
-        gp = self._buf('gpacked', (lay.gpacked_size + 1,), zero=True)
+        # two slots behind the gradients carry this rank's STEP GUARD through the LAST all-reduce bucket: "my loss is not
+        # finite" (NaN, and NaN survives the sum over ranks) and "a cooperative recurrent launch of mine timed out" (1;
+        # the sum counts the ranks).  The fused Adam reads the summed words on the device and leaves the variables
+        # alone when either is set; the trainer reads them one step late together with the loss, so the
+        # rank-synchronous abort / fall-back costs neither a collective of its own nor a host synchronisation
+        gp = self._buf('gpacked', (lay.gpacked_size + 2,), zero=True)
         # d logits, time-major + padded, sequence mask folded in (rows of padded utterances stay 0)
         dlog = self._buf('dlog', (T, Bp, ldp), zero=True)
         ops.relayout_rows(c['dpred'], dlog, B, T, F, ldp, (T * F, F), (ldp, Bp * ldp),
@@ -574,7 +580,7 @@ class StackedBLSTMModel(object):
         def reduce_from(name, upto=None):
             if reduce:
                 lo = lay.gpacked[name][0]
-                hi = lay.gpacked_size + 1 if upto is None else lay.gpacked[upto][0]
+                hi = lay.gpacked_size + 2 if upto is None else lay.gpacked[upto][0]
                 works.append(parallel.all_reduce_sum_async(gp[lo:hi]))
 
         # Three side streams when nothing orders the products of a layer among themselves (no all-reduce behind
@@ -671,14 +677,14 @@ class StackedBLSTMModel(object):
             for st in sides:
                 main.wait_stream(st)
         if reduce:
-            torch.mul(c['loss3'][0:1], 0.0, out=gp[lay.gpacked_size:])
-        reduce_from('dpw')                       # projection head (+ the speaker-embedding MLP of the SSNN variant) + the flag
+            ops.step_guard(c['loss3'][0:1], gp[lay.gpacked_size:])
+        reduce_from('dpw')                       # projection head (+ the speaker-embedding MLP of the SSNN variant) + the guard
         for w in works:
             if w is not None:
                 w.wait()
         c['grads_reduced'] = reduce
         if reduce:
-            c['nonfinite'] = gp[lay.gpacked_size:].clone()        # gp is this model's buffer for the next step too
+            c['guard'] = gp[lay.gpacked_size:].clone()        # gp is this model's buffer for the next step too
         if ops.coop_split(Bp):
             ops.coop_poll(self.device)
         grads = v.unpack_grads(gp, out=self._buf('grads', (lay.ref_size,)))
@@ -710,27 +716,30 @@ class StackedBLSTMModel(object):
         v = self.variables
         world = parallel.world_size()
         if not c.get('grads_reduced'):
-            parallel.all_reduce_sum_(g)          # gradients were fetched (unreduced) before train_op: one flat all-reduce
+            # single process, or gradients that were fetched (unreduced) before train_op: one flat all-reduce + the guard's
+            parallel.all_reduce_sum_(g)
             c['grads_reduced'] = world > 1
-            if world > 1:
-                c['nonfinite'] = parallel.all_reduce_sum_(c['loss3'][0:1] * 0.0)
+            c['guard'] = parallel.all_reduce_sum_(ops.step_guard(c['loss3'][0:1], torch.empty(2, device=self.device)))
+        guard = c['guard']
         step = v.global_step + 1
         l2 = float(self.regularization or 0.0)
         if self.optimizer_choice == 'adam':
             if v.adam_m is None:
                 v.adam_m = torch.zeros_like(v.flat)
                 v.adam_v = torch.zeros_like(v.flat)
-            ops.adam_tf(v.flat, g, v.adam_m, v.adam_v, step, self.starter_learning_rate, grad_scale=1.0 / world, l2=l2)
+            ops.adam_tf(v.flat, g, v.adam_m, v.adam_v, step, self.starter_learning_rate, grad_scale=1.0 / world, l2=l2,
+                        skip=guard)
         elif self.optimizer_choice in ('sgd', 'momentum'):
             lr = self.learning_rate
+            ok = (guard == 0).all()                   # device scalar: a void step leaves the variables alone
             gg = g / world + l2 * v.flat if (world > 1 or l2) else g
             if self.optimizer_choice == 'momentum':
                 if v.adam_m is None:
                     v.adam_m = torch.zeros_like(v.flat)
-                v.adam_m.mul_(0.9).add_(gg)
-                v.flat.sub_(lr * v.adam_m)
+                v.adam_m.copy_(torch.where(ok, 0.9 * v.adam_m + gg, v.adam_m))
+                v.flat.copy_(torch.where(ok, v.flat - lr * v.adam_m, v.flat))
             else:
-                v.flat.sub_(lr * gg)
+                v.flat.copy_(torch.where(ok, v.flat - lr * gg, v.flat))
         else:
             print('Optimizer must be either sgd, momentum or adam. Closing...')
             sys.exit(1)
@@ -740,16 +749,23 @@ class StackedBLSTMModel(object):
         return None
 
     @property
-    def nonfinite_flag(self):
-        """One-element device tensor: 0 while the loss of this step is finite on EVERY data-parallel rank, NaN otherwise
-        (after ``train_op`` under torch.distributed it has been summed over the ranks inside the last gradient bucket;
-        before, or on a single process, it is this rank's own ``loss_func * 0``).  The trainer's NaN / Inf abort
-        (training_emb.py:244-249) reads it one step late with the loss -- no collective or host wait of its own."""
+    def step_guard(self):
+        """Two-element device tensor, the verdict on this step that the optimiser update itself obeyed (no reference
+        counterpart; the reference aborts on a NaN / Inf loss AFTER the update, training_emb.py:244-249):
+        [0] 0 while the loss is finite on EVERY data-parallel rank, NaN otherwise; [1] the number of ranks on which a
+        cooperative recurrent launch gave up waiting for residency (results void).  After ``train_op`` the words have
+        been summed over the ranks inside the last gradient bucket and the update was SKIPPED on the device if either is
+        set; before it they are this rank's own.  The trainer reads them one step late with the loss."""
         c = self._cache
-        if c.get('nonfinite') is not None:
-            return c['nonfinite']
+        if c.get('guard') is not None:
+            return c['guard']
         self._loss()
-        return c['loss3'][0:1] * 0.0
+        return ops.step_guard(c['loss3'][0:1], torch.empty(2, device=self.device))
+
+    @property
+    def nonfinite_flag(self):
+        """step_guard[0:1] (kept for callers of round 3)."""
+        return self.step_guard[0:1]
 
     @property
     def global_step(self):

@@ -4,6 +4,7 @@ No arithmetic happens here: each wrapper validates layout, passes raw device poi
 current stream to libavsi_hip.so, and returns the output tensor."""
 import ctypes
 import os
+import sys
 
 import numpy as np
 
@@ -171,7 +172,7 @@ def rec_fwd_parts(Bp):
     CU budget (a reserved-CU run keeps the single-kernel form)."""
     split = coop_split(Bp)
     single = [(0, Bp, split)]
-    if coop_cu_budget() < 256 or os.environ.get('AVSI_COOP_SPLIT_FWD') or os.environ.get('AVSI_REC_COOP', '1') == '0':
+    if coop_cu_budget() < 256 or os.environ.get('AVSI_COOP_SPLIT_FWD') or coop_disabled():
         return single
     if split == 0:
         if 4096 < Bp <= 4096 + REC_TAIL_MAX and os.environ.get('AVSI_REC_CS', '1') != '0':
@@ -183,9 +184,47 @@ def rec_fwd_parts(Bp):
 
 
 _COOP_WS, _COOP_HOST = {}, {}      # keyed by (device index, stream)
+_COOP_FALLBACKS = []               # reasons, one per fall-back of this process (coop_fall_back)
+
+
+def coop_disabled():
+    """True when the recurrence runs on the batch-stationary kernels only: AVSI_REC_COOP=0, or this process fell back to
+    them after a cooperative launch gave up waiting for residency (coop_fall_back)."""
+    return bool(_COOP_FALLBACKS) or os.environ.get('AVSI_REC_COOP', '1') == '0'
+
+
+def coop_fallbacks():
+    """How many times this process fell back from the cooperative kernels (0 or 1: the fall-back is not undone)."""
+    return len(_COOP_FALLBACKS)
+
+
+def coop_fall_back(device=None, reason='a cooperative recurrent launch timed out waiting for residency'):
+    """Recovery from a cooperative-kernel timeout, in this process: wait for the device, put the workspaces (status
+    words and step counters) back to zero and route every later recurrence through the batch-stationary kernels, which
+    need no co-residency of their workgroups.  Logged once.  The caller repeats the batches whose steps the step guard
+    voided (training.train) -- the variables were not touched by them (avsi_adam_tf_guarded_f32)."""
+    idx = torch.cuda.current_device() if device is None else torch.device(device).index
+    _coop_recover(idx)
+    if not _COOP_FALLBACKS:
+        print('avsi: %s; falling back to the batch-stationary recurrent kernels for the rest of this process' % reason,
+              file=sys.stderr, flush=True)
+    _COOP_FALLBACKS.append(reason)
+
+
+def coop_fall_back_reset():
+    """Tests only: allow the cooperative kernels again."""
+    del _COOP_FALLBACKS[:]
+
 _COOP_EXCHANGE = os.environ.get('AVSI_COOP_EXCHANGE', '1') != '0'
 COOP_EXCHANGE_OFFSET = 1 << 20       # AVSI_COOP_EXCHANGE_OFFSET of include/avsi_hip.h
 _COOP_MSG = "cooperative recurrent kernel timed out waiting for a peer workgroup; results are invalid"
+COOP_POLL_RAISES = True     # training.train() turns the host-side polls off: the step guard decides there, on every rank alike
+
+
+class CoopTimeout(_lib.AvsiError):
+    """A cooperative recurrent launch gave up a bounded wait (its workgroups were not all resident): the results of
+    everything behind it are void.  Recoverable: coop_fall_back()."""
+
 
 
 def _coop_ws(device, Bp, need=None):
@@ -256,7 +295,7 @@ def coop_split(Bp, backward=False):
     the fewer utterances there are, the finer the hidden state is cut.  Measured per layer, T = 250, ms (forward):
     Bp = 32: 1.81 at 8, 1.02 at 16, 0.82 at 32; 256: 1.87 / 1.09 / 2.11; 512: 1.91 at 8, 1.55 column-split by 16;
     1024: 2.97 at 4, 2.78 column-split by 32."""
-    if os.environ.get('AVSI_REC_COOP', '1') == '0':
+    if coop_disabled():
         return 0
     if backward:
         # BPTT: 16 unit slices x 2 halves of 16 utterances up to four tiles (0.97 ms per layer at Bp = 32
@@ -299,6 +338,8 @@ def coop_poll(device=None):
     """Non-blocking form of coop_check: raises if a failure has ALREADY been observed on the host, then queues
     the next asynchronous copy of the status words to pinned memory (the flag travels behind the launches).
     Never synchronises, so independent small batches can be in flight on several streams."""
+    if not COOP_POLL_RAISES:
+        return
     idx = torch.cuda.current_device() if device is None else torch.device(device).index
     cur = _lib.stream_ptr().value
     for (dev, st), (host, event) in _COOP_HOST.items():
@@ -306,7 +347,7 @@ def coop_poll(device=None):
             continue
         if event.query() and int(host[0]) != 0:
             _coop_recover(idx)
-            raise _lib.AvsiError(_COOP_MSG)
+            raise CoopTimeout(_COOP_MSG)
         if st == cur and event.query():
             host.copy_(_COOP_WS[(dev, st)][:1], non_blocking=True)
             event.record()
@@ -330,7 +371,7 @@ def coop_check(device=None):
     flags = [ws[:1] for (dev, _), ws in _COOP_WS.items() if dev == idx]
     if flags and int(torch.cat(flags).max().item()) != 0:
         _coop_recover(idx)
-        raise _lib.AvsiError(_COOP_MSG)
+        raise CoopTimeout(_COOP_MSG)
 
 
 def _coop_recover(idx):
@@ -556,13 +597,32 @@ def colsum(x, out, m=None, n=None):
     return out
 
 
-def adam_tf(param, grad, m, v, step, lr, beta1=0.9, beta2=0.999, eps=1e-8, grad_scale=1.0, l2=0.0):
-    """In-place tf.train.AdamOptimizer step on flat float32 buffers (avsi_adam_tf_f32)."""
-    _lib.require_cuda(param, grad, m, v)
+def adam_tf(param, grad, m, v, step, lr, beta1=0.9, beta2=0.999, eps=1e-8, grad_scale=1.0, l2=0.0, skip=None):
+    """In-place tf.train.AdamOptimizer step on flat float32 buffers (avsi_adam_tf_guarded_f32).  ``skip``: device float32
+    words (<= 8, the step guard); the update does nothing when any of them is not exactly zero."""
+    _lib.require_cuda(param, grad, m, v, skip)
     n = param.numel()
-    _lib.check(_lib.lib().avsi_adam_tf_f32(_lib.ptr(param), _lib.ptr(grad), _lib.ptr(m), _lib.ptr(v), n, float(lr),
-                                           float(beta1), float(beta2), float(eps), int(step), float(grad_scale),
-                                           float(l2), _lib.stream_ptr()), "avsi_adam_tf_f32")
+    if skip is not None and (skip.dtype != torch.float32 or not skip.is_contiguous() or skip.numel() > 8):
+        raise _lib.AvsiError("adam_tf: skip must be at most 8 contiguous float32 words")
+    _lib.check(_lib.lib().avsi_adam_tf_guarded_f32(_lib.ptr(param), _lib.ptr(grad), _lib.ptr(m), _lib.ptr(v), n, float(lr),
+                                                   float(beta1), float(beta2), float(eps), int(step), float(grad_scale),
+                                                   float(l2), _lib.ptr(skip), 0 if skip is None else skip.numel(),
+                                                   _lib.stream_ptr()), "avsi_adam_tf_guarded_f32")
+
+
+def step_guard(loss, out, device=None):
+    """out[0:2] <- [NaN unless `loss` (one-element device tensor, or None) is finite, 1 if a cooperative recurrent launch
+    issued so far on the device has given up a bounded wait else 0] (avsi_step_guard_f32), on the current stream."""
+    _lib.require_cuda(loss, out)
+    idx = out.device.index
+    flags = [ws for (dev, _), ws in _COOP_WS.items() if dev == idx]
+    if len(flags) > 2:
+        flags = [coop_status(out.device)]
+    a = flags[0] if flags else None
+    b = flags[1] if len(flags) > 1 else None
+    _lib.check(_lib.lib().avsi_step_guard_f32(_lib.ptr(loss), _lib.ptr(a), _lib.ptr(b), _lib.ptr(out), _lib.stream_ptr()),
+               "avsi_step_guard_f32")
+    return out
 
 
 # ---------------------------------------------------------------------------- U-Net building blocks

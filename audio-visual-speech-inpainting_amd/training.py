@@ -187,9 +187,13 @@ def train(config_file, checkpoint_format=None):
     torch.set_num_threads(max(1, int(os.environ.get('AVSI_HOST_THREADS', min(torch.get_num_threads(), 4)))))
     device = torch.device('cuda', torch.cuda.current_device())       # the reader uploads batches from its prefetch thread
     train_files = sorted(glob(os.path.join(data_path_train, '*.tfrecord')))
-    random.Random(0 if world > 1 else None).shuffle(train_files)      # same order on every rank
+    # data parallel: the same order on every rank.  AVSI_SHUFFLE_SEED makes a single-process run repeatable too.
+    shuffle_seed = os.environ.get('AVSI_SHUFFLE_SEED')
+    shuffle_seed = int(shuffle_seed) if shuffle_seed is not None else (0 if world > 1 else None)
+    random.Random(shuffle_seed).shuffle(train_files)
     train_dm, val_dm = manager(), manager()
-    _, train_it = train_dm.get_iterator(train_dm.get_dataset(train_files, shuffle=True, seed=1234 if world > 1 else None),
+    _, train_it = train_dm.get_iterator(train_dm.get_dataset(train_files, shuffle=True,
+                                                             seed=None if shuffle_seed is None else 1234 + shuffle_seed),
                                         batch_size=config['batch_size'], n_epochs=1, shard=(rank, world), device=device,
                                         even_rounds=True, count_gaps=True)
     val_files = sorted(glob(os.path.join(data_path_val, '*.tfrecord')))
@@ -300,16 +304,36 @@ def train(config_file, checkpoint_format=None):
         return [model.loss_func] * 2
 
     late = _LateScalars()
+    coop_fallbacks = 0
+    # inside the loop the step guard decides about a cooperative-kernel timeout, on every rank at the same step; a
+    # host-side poll that raised on one rank alone would leave its peers in the next collective
+    ops.COOP_POLL_RAISES = False
     # AVSI_TRAIN_TIMING=1: host time of the phases of a training iteration, printed at the end (diagnostics)
-    timing = [0.0] * 6 if os.environ.get('AVSI_TRAIN_TIMING') else None
+    timing = [0.0] * 4 if os.environ.get('AVSI_TRAIN_TIMING') else None
 
     def resolve(vals):
         """Device scalars -> floats, synchronously (validation loop).  The training loop reads its scalars one step
         late through `late` instead (see _LateScalars); the NaN / Inf abort therefore fires one step after the
         offending batch."""
         vals = [float(x) for x in vals]
-        ops.coop_check()                # the float() above synchronised; a cooperative-kernel timeout aborts here
+        ops.coop_check()                # the float() above synchronised; a cooperative-kernel timeout raises CoopTimeout
         return vals
+
+    def validate(feed):
+        """The reference's validation fetch for one batch (training_emb.py:312-327).  A cooperative-kernel timeout
+        here costs the batch one repetition on the batch-stationary kernels (no collective runs inside this loop, so
+        a rank may fall back alone)."""
+        nonlocal coop_fallbacks
+        for attempt in (0, 1):
+            model.set_dropout_rate(0.0)                             # training_emb.py:314,326
+            model.feed(**feed)
+            try:
+                return resolve(fetch(False))
+            except ops.CoopTimeout:
+                if attempt:
+                    raise
+                ops.coop_fall_back(device)
+                coop_fallbacks += 1
 
     def accumulate(avg, vals, nframe_sum, frames, first):
         if first:
@@ -319,6 +343,16 @@ def train(config_file, checkpoint_format=None):
         # reference: (avg * prev + value * count // dim) / total, floor division included
         return [(a * prev + v * frames // feat_dim) / nframe_sum for a, v in zip(avg, vals)], nframe_sum
 
+    def launch(item):
+        """Enqueue one training step (reference fetch list [loss, loss_func, ..., train_op], training_emb.py:244-251) and
+        the asynchronous copy of its scalars: losses, gap elements of the batch, the two step-guard words."""
+        model.set_dropout_rate(config['dropout_rate'])          # training_emb.py:251
+        model.feed(**item['feed'])
+        vals, item['lr'] = fetch(True), model.learning_rate
+        model.train_op
+        guard = model.step_guard
+        item['vals'] = late.push(list(vals) + [gap_elements(item['batch']), guard[0], guard[1]])
+
     for _ in range(config['max_n_epochs']):
         epoch_counter += 1
         n_step = 0
@@ -327,25 +361,28 @@ def train(config_file, checkpoint_format=None):
         if chief:
             print('-> Epoch {:d}'.format(epoch_counter))
         nframe_sum = 0
-        pending = None
+        inflight = []             # steps enqueued but not yet booked, oldest first (at most two)
 
-        def book(vals, frames, n_step, tot_step, lr):
+        def book(item):
             """Bookkeeping of one finished training step (reference training_emb.py:244-262)."""
             nonlocal train_avg, nframe_sum
-            # [losses ..., (non-finite word of all ranks,) gap elements, cooperative-kernel status word] of that step
-            vals = _LateScalars.get(vals)
-            if vals.pop() != 0.0:
-                raise ops._lib.AvsiError(ops._COOP_MSG)
+            n_step, tot_step, lr = item['n_step'], item['tot_step'], item['lr']
+            # [losses ..., gap elements, guard: non-finite word of all ranks, cooperative timeouts of all ranks]
+            vals = _LateScalars.get(item['vals'])
+            timeouts, nonfinite = vals.pop(), vals.pop()
+            if timeouts != 0.0:
+                # the update of this step (and of every step enqueued behind it: the status word is sticky) was
+                # skipped on the device, on every rank alike: recoverable, see `recover`
+                raise ops.CoopTimeout(ops._COOP_MSG)
             frames = int(vals.pop())
-            if world > 1:
-                # every rank must leave at the SAME step (a rank that exits alone leaves its peers waiting in the
-                # next gradient all-reduce).  The verdict came with the gradients: the last all-reduce bucket of the
-                # step carries 'my loss is not finite' of every rank (model.nonfinite_flag), and it is read here, one
-                # step late like the loss -- no collective and no host wait of its own
-                bad = not np.isfinite(vals.pop())
-                if bad and np.isfinite(vals[0]):
-                    print('GOT INSTABILITY on another rank: loss is not finite there. Leaving...')
-                    sys.exit(1)
+            # The verdict came with the gradients: the last all-reduce bucket of the step carries 'my loss is not
+            # finite' of every rank (model.step_guard), the fused Adam obeyed it on the device -- the variables
+            # are those of the last good step -- and it is read here, one step late like the loss: no collective and
+            # no host wait of its own.  Every rank leaves at the SAME step (a rank that exits alone leaves its peers
+            # waiting in the next gradient all-reduce).
+            if not np.isfinite(nonfinite) and np.isfinite(vals[0]):
+                print('GOT INSTABILITY on another rank: loss is not finite there. Leaving...')
+                sys.exit(1)
             if np.isnan(vals[0]):
                 print('GOT INSTABILITY: loss is NaN. Leaving...')
                 sys.exit(1)
@@ -361,7 +398,35 @@ def train(config_file, checkpoint_format=None):
                     print('Step[{:7d}] Loss[{:3.5f}|{:3.5f}] LR[{:.6f}] Epoch training time[{:.2f}]'.format(
                         tot_step, train_avg[0], train_avg[1], lr, time() - epoch_start_time))
             if chief and n_step % 1000 == 0:
+                # booked before the next step is enqueued (see `settle`): the variables are those after step n_step
+                # exactly, as in the reference (training_emb.py:266-268)
                 print('Model checkpoint saved in file %s' % save_checkpoint(os.path.join(checkpoints_dir, 'ckpt')))
+
+        def recover(items):
+            """A cooperative recurrent launch timed out (another resident of the GPU -- e.g. RCCL's kernels -- left its
+            workgroups no room): every step from the first void one on was skipped on the device.  Fall back to the
+            batch-stationary kernels IN THIS PROCESS, take the skipped steps' counts back and repeat their batches.
+            All ranks read the same summed guard words, so all of them arrive here at the same step."""
+            nonlocal coop_fallbacks
+            ops.coop_fall_back(device)
+            coop_fallbacks += 1
+            for item in items:
+                model.variables.rewind_step()
+            for item in items:
+                launch(item)
+                book(item)
+
+        def settle(keep):
+            """Book the steps in flight, oldest first, until at most `keep` are left."""
+            while len(inflight) > keep:
+                try:
+                    book(inflight[0])
+                except ops.CoopTimeout:
+                    items = list(inflight)
+                    del inflight[:]
+                    recover(items)
+                    return
+                inflight.pop(0)
 
         while True:
             if timing is not None:
@@ -370,9 +435,7 @@ def train(config_file, checkpoint_format=None):
                 batch = train_it.get_next()
                 feed, _ = unpack_batch(batch, uses_embeddings(config), ctc)
             except OutOfRangeError:
-                if pending is not None:
-                    book(*pending)
-                    pending = None
+                settle(0)
                 if chief:
                     if ctc:
                         print('Completed epoch {:d} at step {:d} --> Training loss: {:3.5f} - {:3.5f} - {:3.5f}; PER: {:3.5f}'
@@ -388,27 +451,19 @@ def train(config_file, checkpoint_format=None):
             tot_step += 1
             if timing is not None:
                 t_b = time()
-            model.set_dropout_rate(config['dropout_rate'])          # training_emb.py:251
-            model.feed(**feed)
-            vals, lr = fetch(True), model.learning_rate
-            if timing is not None:
-                t_c = time()
-            model.train_op
-            if timing is not None:
-                t_d = time()
-            if world > 1:
-                vals = list(vals) + [model.nonfinite_flag]
-            vals = late.push(list(vals) + [gap_elements(batch), ops.coop_status(device)])
-            step_done, pending = pending, (vals, None, n_step, tot_step, lr)
+            item = dict(batch=batch, feed=feed, n_step=n_step, tot_step=tot_step)
+            launch(item)
+            inflight.append(item)
             if timing is not None:
                 t_e = time()
-            if step_done is not None:
-                book(*step_done)
+            # one step stays in flight while the next is enqueued -- except in front of a periodic checkpoint, which
+            # must hold the variables after ITS step and no later one
+            settle(0 if n_step % 1000 == 0 else 1)
             if timing is not None:
                 t_f = time()
-                for i, dt_ in enumerate((t_b - t_a, t_c - t_b, t_d - t_c, t_e - t_d, t_f - t_e)):
+                for i, dt_ in enumerate((t_b - t_a, t_e - t_b, t_f - t_e)):
                     timing[i] += dt_
-                timing[5] += 1
+                timing[3] += 1
         if chief:
             print('Start validation set evaluation...')
         model.is_training = False          # validation: no BPTT reserve, no gradient stream
@@ -422,9 +477,7 @@ def train(config_file, checkpoint_format=None):
             except OutOfRangeError:
                 break
             n_step += 1
-            model.set_dropout_rate(0.0)                             # training_emb.py:314,326
-            model.feed(**feed)
-            val_avg, nframe_sum = accumulate(val_avg, resolve(fetch(False)), nframe_sum, int(gap_elements(batch)), n_step == 1)
+            val_avg, nframe_sum = accumulate(val_avg, validate(feed), nframe_sum, int(gap_elements(batch)), n_step == 1)
             if chief and (n_step % 200 == 0 or n_step == 1):
                 print('Step[{:7d}] Loss[{:3.5f}]'.format(n_step, val_avg[1]))
         model.is_training = True
@@ -464,9 +517,11 @@ def train(config_file, checkpoint_format=None):
             break
 
     log.close()
-    if timing is not None and timing[5]:
-        print('host ms per training iteration: next batch %.2f, feed + forward launches %.2f, backward + update launches %.2f, '
-              'scalars %.2f, wait for the step before %.2f' % tuple(1e3 * t / timing[5] for t in timing[:5]), file=sys.stderr)
+    if timing is not None and timing[3]:
+        print('host ms per training iteration: next batch %.2f, launches of the step + its scalars %.2f, wait for the step '
+              'before %.2f' % tuple(1e3 * t / timing[3] for t in timing[:3]), file=sys.stderr)
+    ops.COOP_POLL_RAISES = True
+    model.coop_fallbacks = coop_fallbacks
     if prev_stream is not None:
         torch.cuda.current_stream(device).synchronize()
         torch.cuda.set_stream(prev_stream)

@@ -201,7 +201,14 @@ class UNetFConvModel(object):
     AUTO_GRAPH_MAX_CLIPS = 128
 
     def _auto_graph(self, sequence_lengths, target_sources, masks):
-        if self.is_training or os.environ.get('AVSI_UNET_GRAPH', '1') == '0' or getattr(self, '_graph_manual', False):
+        if self.is_training:
+            # a model that goes back to training (train() validates with is_training = False, then resumes) must not
+            # replay the inference-form step: its cache keeps no activation for the backward pass
+            if getattr(self, '_graph', None) is not None:
+                self.release_graph()
+            self._auto_shape, self._auto_count = None, 0
+            return
+        if os.environ.get('AVSI_UNET_GRAPH', '1') == '0' or getattr(self, '_graph_manual', False):
             return
         shape = (None if sequence_lengths is None else (len(sequence_lengths), int(np.max(np.asarray(
                      sequence_lengths.cpu() if isinstance(sequence_lengths, torch.Tensor) else sequence_lengths)))),
@@ -251,7 +258,10 @@ class UNetFConvModel(object):
         torch.cuda.current_stream().wait_stream(side)
         self._cache = {}
         graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
+        # thread_local: other threads of this process (the reader's upload thread, a collective's watchdog) keep making
+        # capture-unsafe calls (allocations, pinned memory) while this thread captures; in the default global mode those
+        # calls fail THERE and invalidate the capture
+        with torch.cuda.graph(graph, capture_error_mode='thread_local'):
             self._loss()
         self._graph, self._graph_cache = graph, dict(self._cache)
         graph.replay()
@@ -520,13 +530,17 @@ class UNetFConvModel(object):
         return g + self.regularization * self.variables.flat if self.regularization else g
 
     @property
-    def nonfinite_flag(self):
-        """See StackedBLSTMModel.nonfinite_flag."""
+    def step_guard(self):
+        """See StackedBLSTMModel.step_guard (this model launches no cooperative kernel: word 1 is always 0)."""
         c = self._cache
-        if c.get('nonfinite') is not None:
-            return c['nonfinite']
+        if c.get('guard') is not None:
+            return c['guard']
         self._loss()
-        return c['loss3'][0:1] * 0.0
+        return ops.step_guard(c['loss3'][0:1], torch.empty(2, device=self.device))
+
+    @property
+    def nonfinite_flag(self):
+        return self.step_guard[0:1]
 
     @property
     def global_step(self):
@@ -546,14 +560,16 @@ class UNetFConvModel(object):
         v = self.variables
         world = parallel.world_size()
         if world > 1:
-            # one flat all-reduce; the word behind the gradients is this rank's "my loss is not finite" flag
-            # (loss * 0, NaN survives the sum): see StackedBLSTMModel.nonfinite_flag
-            gf = self._buf('grads+flag', (self.layout.ref_size + 1,))
-            gf[:-1].copy_(g)
-            torch.mul(c['loss3'][0:1], 0.0, out=gf[-1:])
+            # one flat all-reduce; the two words behind the gradients are this rank's step guard ("my loss is not
+            # finite": NaN survives the sum): see StackedBLSTMModel.step_guard
+            gf = self._buf('grads+guard', (self.layout.ref_size + 2,))
+            gf[:-2].copy_(g)
+            ops.step_guard(c['loss3'][0:1], gf[-2:])
             parallel.all_reduce_sum_(gf)
-            g = gf[:-1]
-            c['nonfinite'] = gf[-1:].clone()
+            g = gf[:-2]
+            c['guard'] = gf[-2:].clone()
+        else:
+            c['guard'] = ops.step_guard(c['loss3'][0:1], torch.empty(2, device=self.device))
         step = v.global_step + 1
         if self.optimizer_choice != 'adam':
             print('Optimizer must be adam on the MI355X U-Net path. Closing...')
@@ -561,7 +577,7 @@ class UNetFConvModel(object):
         if v.adam_m is None:
             v.adam_m, v.adam_v = torch.zeros_like(v.flat), torch.zeros_like(v.flat)
         ops.adam_tf(v.flat, g, v.adam_m, v.adam_v, step, self.starter_learning_rate, grad_scale=1.0 / world,
-                    l2=float(self.regularization or 0.0))
+                    l2=float(self.regularization or 0.0), skip=c['guard'])
         v.global_step = step
         v.repack()
         c['trained'] = True

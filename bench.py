@@ -356,10 +356,26 @@ def dp_train_block(torch, dist, models, ops, ap_mod, cfg, device, rank, world):
     wav, masks, video = av_batch(torch, G, 4242, device)          # the same seed, i.e. the same global batch, on every rank
     sl = slice(rank * per, (rank + 1) * per)
 
+    out["coop_fallbacks"] = 0
+
+    def fell_back(m):
+        """True (after falling back to the batch-stationary kernels, in this process) when the step guard of `m`'s last
+        step reports a cooperative-kernel timeout.  The guard words are summed over the ranks inside the last gradient
+        bucket and the status word is sticky, so every rank of a data-parallel run takes the same branch; the updates of
+        the void steps were skipped on the device.  The caller repeats the measurement."""
+        if float(m.step_guard[1]) == 0.0:
+            return False
+        ops.coop_fall_back(device)
+        out["coop_fallbacks"] += 1
+        return True
+
     def three_steps(n, w, m_, v):
-        m, step = build(n, w, m_, v)
-        init = m.variables.flat.clone()
-        losses = torch.stack([step() for _ in range(3)])
+        for attempt in (0, 1):
+            m, step = build(n, w, m_, v)
+            init = m.variables.flat.clone()
+            losses = torch.stack([step() for _ in range(3)])
+            if not (attempt == 0 and fell_back(m)):
+                break
         ops.coop_check(device)
         return m.variables.flat.clone(), init, losses
 
@@ -394,11 +410,15 @@ def dp_train_block(torch, dist, models, ops, ap_mod, cfg, device, rank, world):
         m, step = build(per_b, w, m_, v, seed=7)
         steps, warm = (30, 5) if per_b <= 64 else (12, 3)
         ms = time_steps_all_ranks(torch, dist, world, step, steps, warm)
+        if fell_back(m):                  # a residency conflict (e.g. with RCCL's kernels) costs a repetition, not the entry
+            m, step = build(per_b, w, m_, v, seed=7)
+            ms = time_steps_all_ranks(torch, dist, world, step, steps, warm)
         ops.coop_check(device)
         entry = {"workload": "configs[3] AV training step (front end + forward + BPTT + %sTF-Adam), %d utterances per GPU"
                              % ("RCCL gradient all-reduce + " if world > 1 else "", per_b),
                  "scaling": scaling, "per_gpu_batch": per_b, "global_batch": per_b * world, "ms_per_step": ms,
                  "value": per_b * world / ms * 1e3, "unit": "utterances/s"}
+        entry["recurrent_kernels"] = "batch-stationary (fell back)" if ops.coop_disabled() else "default policy"
         if world > 1:
             with parallel.solo():
                 entry["ms_per_step_no_collective"] = time_steps_all_ranks(torch, dist, world, step, steps, 2)

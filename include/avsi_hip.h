@@ -327,6 +327,18 @@ int avsi_colsum_f32(const float* x, int64_t ld, int64_t M, int N, float* out,
 int avsi_adam_tf_f32(float* param, const float* grad, float* m, float* v, int64_t n,
                      float lr, float beta1, float beta2, float eps, int64_t step,
                      float grad_scale, float l2, void* stream);
+/* Step guard (no reference counterpart: the reference's only failure rule is the host-side NaN / Inf abort AFTER the
+ * update, training.py:244-249; here the variables are never touched by a void gradient).
+ * avsi_step_guard_f32: out2[0] = 0 if *loss is finite (or loss is NULL) else NaN; out2[1] = 1 if *status_a or
+ *   *status_b (device int32 words, either may be NULL: the sticky status words of the cooperative recurrent
+ *   launches) is non-zero, else 0.  Data-parallel ranks carry the two words through the last gradient all-reduce
+ *   bucket (sum), so every rank sees the same verdict.
+ * avsi_adam_tf_guarded_f32: avsi_adam_tf_f32 that reads `n_skip` (<= 8) device floats first and does NOTHING when any
+ *   of them is not exactly 0 (NaN counts): param, m, v stay as they were. */
+int avsi_step_guard_f32(const float* loss, const int* status_a, const int* status_b, float* out2, void* stream);
+int avsi_adam_tf_guarded_f32(float* param, const float* grad, float* m, float* v, int64_t n,
+                             float lr, float beta1, float beta2, float eps, int64_t step,
+                             float grad_scale, float l2, const float* skip, int n_skip, void* stream);
 
 /* ------------------------------------------------------------------------------------
  * Inverse STFT / waveform reconstruction: tf.contrib.signal.inverse_stft with

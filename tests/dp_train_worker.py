@@ -18,12 +18,33 @@ if __name__ == '__main__':
             feed['masks'] = feed['masks'] * float('nan')
             return feed, paths
         training.unpack_batch = poisoned
+    park = os.environ.get('AVSI_TEST_PARK_RANK')
+    if park is not None and int(park) == int(os.environ.get('RANK', '0')):
+        # while this rank's second batch runs, 240 of the GPU's 256 CUs are parked for 12 s (the stand-in for another
+        # resident of the chip): cooperative launches time out, every rank must fall back at the same step and go on
+        import torch
+        from avsi_amd import ops
+        plain_unpack = training.unpack_batch
+        state = {'n': 0}
+
+        def parking(*a, **kw):
+            state['n'] += 1
+            if state['n'] == 2:
+                state['release'] = torch.zeros(1, dtype=torch.int32, device='cuda')
+                state['side'] = torch.cuda.Stream()
+                with torch.cuda.stream(state['side']):
+                    ops.occupy_cus(240, state['release'], max_ms=12000)
+            return plain_unpack(*a, **kw)
+        training.unpack_batch = parking
     try:
         model = training.train(sys.argv[1])
     except SystemExit as e:
         open(os.path.join(os.path.dirname(sys.argv[1]), 'exit_rank%s' % os.environ.get('RANK', '0')), 'w').write(str(e.code))
         raise
     import torch.distributed as dist
-    print('RANK %d STEPS %d' % (dist.get_rank(), model.global_step), flush=True)
+    import hashlib
+    print('RANK %d STEPS %d FALLBACKS %d VARS %s' % (dist.get_rank(), model.global_step, model.coop_fallbacks,
+                                                    hashlib.sha1(model.variables.flat.cpu().numpy().tobytes()).hexdigest()),
+          flush=True)
     dist.barrier()
     dist.destroy_process_group()

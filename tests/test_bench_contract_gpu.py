@@ -72,8 +72,8 @@ def test_train_and_unet_modes():
     assert u["unit"] == "clips/s" and u["value"] > 0 and u["vs_baseline"] is None
 
 
-@pytest.mark.parametrize("mode", ["infer", "train"])
-def test_multi_rank_launch_as_the_driver_does(mode):
+@pytest.mark.parametrize("mode,ranks", [("infer", 2), ("train", 2), ("infer", 4)])
+def test_multi_rank_launch_as_the_driver_does(mode, ranks):
     """`python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 ... bench.py --gpus 2`: rank 0 alone prints
     the line, the value is the whole-job aggregate, no CPU baseline leg.  The two ranks share this box's one GPU, so
     the process group is gloo here (AVSI_DIST_BACKEND); the driver's 8-GPU node uses RCCL."""
@@ -82,31 +82,32 @@ def test_multi_rank_launch_as_the_driver_does(mode):
     s.bind(('127.0.0.1', 0))
     port = s.getsockname()[1]
     s.close()
-    env = dict(os.environ, AVSI_DIST_BACKEND='gloo', HSA_ENABLE_IPC_MODE_LEGACY='0', AVSI_COOP_CUS='128')
-    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
-           '--master-port', str(port), os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '2', '--warmup', '1',
-           '--batch', '64', '--mode', mode]
-    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    env = dict(os.environ, AVSI_DIST_BACKEND='gloo', HSA_ENABLE_IPC_MODE_LEGACY='0', AVSI_COOP_CUS=str(256 // ranks))
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(ranks), '--master-addr',
+           '127.0.0.1', '--master-port', str(port), os.path.join(ROOT, 'bench.py'), '--gpus', str(ranks), '--steps', '2',
+           '--warmup', '1', '--batch', '64', '--mode', mode]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=1500, cwd=ROOT)
     assert out.returncode == 0, out.stderr[-3000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, out.stdout[-2000:]
     d = json.loads(lines[0])
-    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["config"]["global_batch"] == 128
-    assert d["config"]["parallelism"] == "dp2"
-    assert abs(d["value"] - 2 * 64 * 2 / (d["ms_per_step"] * 2e-3)) < 1e-6 * d["value"]
+    assert d["n_gpus"] == ranks and d["scaling"] == "weak" and d["config"]["global_batch"] == 64 * ranks
+    assert d["config"]["parallelism"] == "dp%d" % ranks
+    assert abs(d["value"] - ranks * 64 * 2 / (d["ms_per_step"] * 2e-3)) < 1e-6 * d["value"]
     assert "cpu_baseline" not in d or d["cpu_baseline"] is None
     if mode == "infer":
         assert "error" not in d["also"], d["also"]
-        assert d["also"]["train_b32"]["global_batch"] == 64 and d["also"]["train_b32"]["ms_per_step"] > 0
+        assert d["also"]["train_b32"]["global_batch"] == 32 * ranks and d["also"]["train_b32"]["ms_per_step"] > 0
         # the data-parallel self-check of the bench line: every rank ends with the same bits, equal to one process at
         # the global batch up to summation order (gloo here; the driver's multi-GPU run is the same code over RCCL)
         dp = d["dp_train"]
         assert "error" not in dp, dp
-        assert dp["rccl_ranks"] == 2 and dp["backend"] == "gloo"
+        assert dp["rccl_ranks"] == ranks and dp["backend"] == "gloo" and dp["coop_fallbacks"] == 0
         c = dp["check"]
-        assert c["ranks_bit_identical"] is True and c["global_batch"] == 64 and c["frames"] == 250
+        assert c["ranks_bit_identical"] is True and c["global_batch"] == 32 * ranks and c["frames"] == 250
         assert c["max_abs_diff_vs_single_process"] < 2e-5 < 1e-3 < c["max_abs_update"] and c["ok"] is True
         assert c["loss_max_rel_diff_vs_single_process"] < 2e-4
-        assert dp["weak_32_per_gpu"]["global_batch"] == 64 and dp["fixed_global_256"]["per_gpu_batch"] == 128
+        assert dp["weak_32_per_gpu"]["global_batch"] == 32 * ranks and dp["fixed_global_256"]["per_gpu_batch"] == 256 // ranks
+        assert dp["fixed_global_256"]["global_batch"] == 256
         for k in ("weak_32_per_gpu", "fixed_global_256"):
             assert dp[k]["ms_per_step"] > 0 and dp[k]["ms_per_step_no_collective"] > 0

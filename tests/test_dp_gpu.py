@@ -63,6 +63,30 @@ def test_two_ranks_at_config_4_shape_equal_one_process(tmp_path):
     np.testing.assert_allclose((l0 + l1) / 2, ref_losses, rtol=2e-4)
 
 
+@pytest.mark.parametrize("ranks,N", [(4, 48000), (6, 9600)])
+def test_four_and_six_ranks_at_32_per_rank_equal_one_process(tmp_path, ranks, N):
+    """configs[3]'s per-GPU share (32 utterances, AV model) at world 4 (3 s clips, T = 250) and world 6 (T = 50) -- the
+    most processes this box allows on its one GPU; world 8 is rehearsed on the CPU (tests/test_parallel_gloo.py).  Every
+    rank holds the same bits after two Adam steps, equal to one process at 32 x ranks utterances up to summation order.
+    Each rank sizes its cooperative launches for its share of the chip (AVSI_COOP_CUS = 256 // ranks)."""
+    G = 32 * ranks
+    env = dict(os.environ, AVSI_DIST_BACKEND='gloo', HSA_ENABLE_IPC_MODE_LEGACY='0', AVSI_COOP_CUS=str(256 // ranks // 8 * 8))
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(ranks), '--master-addr',
+           '127.0.0.1', '--master-port', str(_free_port()), os.path.join(HERE, 'dp_worker.py'), str(tmp_path), str(G), str(N), '2']
+    run = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=1200)
+    assert run.returncode == 0, run.stderr[-3000:]
+    flats = [np.load(str(tmp_path / ('flat_rank%d.npy' % r))) for r in range(ranks)]
+    assert all(np.array_equal(flats[0], f) for f in flats[1:])
+    sys.path.insert(0, HERE)
+    import dp_worker
+    ref, ref_losses = dp_worker.run(0, 1, steps=2, B_global=G, N=N)
+    init, _ = dp_worker.run(0, 1, steps=0, B_global=G, N=N)
+    assert np.abs(ref - init).max() > 1e-3
+    np.testing.assert_allclose(flats[0], ref, rtol=0, atol=2e-5)
+    losses = np.mean([np.load(str(tmp_path / ('loss_rank%d.npy' % r))) for r in range(ranks)], axis=0)
+    np.testing.assert_allclose(losses, ref_losses, rtol=2e-4)
+
+
 def _gpu_count():
     try:
         import torch

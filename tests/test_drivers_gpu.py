@@ -290,58 +290,87 @@ def test_reader_uploads_batches_from_its_prefetch_thread(experiment):
     assert n == 3
 
 
-def test_data_parallel_training_through_the_driver(experiment, tmp_path):
-    """train() under torch.distributed.run with two ranks (sharing this box's GPU: gloo process group): batches are
-    dealt in whole rounds, every rank takes the same number of steps, gradients are all-reduced inside train_op,
-    rank 0 alone writes the log and the checkpoints."""
+def _launch_dp_training(cfg, ranks, extra_env=None, timeout=1200):
     import socket
     import subprocess
     import sys
-    base, data, cfg0 = experiment
-    exp = tmp_path / "logs" / "dp_exp"
-    text = open(cfg0).read().replace("exp_folder = %s" % (base / "logs" / "av_exp0"), "exp_folder = %s" % exp)
-    text = text.replace("max_n_epochs = 3", "max_n_epochs = 2")
-    cfg = tmp_path / "dp.config"
-    cfg.write_text(text)
     s = socket.socket()
     s.bind(('127.0.0.1', 0))
     port = s.getsockname()[1]
     s.close()
-    env = dict(os.environ, AVSI_DIST_BACKEND='gloo', HSA_ENABLE_IPC_MODE_LEGACY='0', AVSI_COOP_CUS='128')
+    env = dict(os.environ, AVSI_DIST_BACKEND='gloo', HSA_ENABLE_IPC_MODE_LEGACY='0', AVSI_COOP_CUS=str(256 // ranks // 8 * 8))
+    env.update(extra_env or {})
     here = os.path.dirname(os.path.abspath(__file__))
-    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
-           '--master-port', str(port), os.path.join(here, 'dp_train_worker.py'), str(cfg)]
-    run = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(ranks), '--master-addr',
+           '127.0.0.1', '--master-port', str(port), os.path.join(here, 'dp_train_worker.py'), str(cfg)]
+    return subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=timeout)
+
+
+def _rank_lines(stdout, ranks):
+    import re
+    found = {int(m.group(1)): (int(m.group(2)), int(m.group(3)), m.group(4))
+             for m in re.finditer(r'RANK (\d+) STEPS (\d+) FALLBACKS (\d+) VARS ([0-9a-f]+)', stdout)}
+    assert sorted(found) == list(range(ranks)), stdout[-2000:]
+    return found
+
+
+@pytest.mark.parametrize("ranks,batch_size,steps", [(2, 4, 2), (4, 2, 2), (6, 1, 4)])
+def test_data_parallel_training_through_the_driver(experiment, tmp_path, ranks, batch_size, steps):
+    """train() under torch.distributed.run with 2, 4 and 6 ranks (sharing this box's GPU: gloo process group; the box
+    allows at most 6 processes on its card, so world 8 itself is rehearsed on the CPU: tests/test_parallel_gloo.py,
+    test_tfrecord_io.py::test_even_rounds_with_eight_readers): batches are dealt in whole rounds, every rank takes the
+    same number of steps, gradients are all-reduced inside train_op, every rank ends with the same bits, rank 0 alone
+    writes the log and the checkpoints.
+    12 training samples: 2 ranks x batches of 4 = 3 batches = one whole round + one left over (dropped): one step per
+    epoch; 4 ranks x batches of 2 = 6 batches = one round + two left over: one step per epoch; 6 ranks x batches of 1 =
+    two rounds: two steps per epoch -- and the 4 validation samples leave ranks 4 and 5 without a validation batch."""
+    base, data, cfg0 = experiment
+    exp = tmp_path / "logs" / "dp_exp"
+    text = open(cfg0).read().replace("exp_folder = %s" % (base / "logs" / "av_exp0"), "exp_folder = %s" % exp)
+    text = text.replace("max_n_epochs = 3", "max_n_epochs = 2").replace("batch_size = 4", "batch_size = %d" % batch_size)
+    cfg = tmp_path / "dp.config"
+    cfg.write_text(text)
+    run = _launch_dp_training(cfg, ranks)
     assert run.returncode == 0, run.stderr[-3000:]
-    # 12 training samples in batches of 4 = 3 batches = one whole round of two + one left over (dropped): one step per epoch
-    assert 'RANK 0 STEPS 2' in run.stdout and 'RANK 1 STEPS 2' in run.stdout
+    found = _rank_lines(run.stdout, ranks)
+    assert all(v[0] == steps and v[1] == 0 for v in found.values()), found
+    assert len({v[2] for v in found.values()}) == 1, found             # the same variables, bit for bit, on every rank
     log = (exp / "training_log.txt").read_text().splitlines()
     assert len([l for l in log if l[:1].isdigit()]) == 2 and log[0] == "+-- EXPERIMENT NAME - dp_exp --+"
     assert (exp / "netmodel" / "sinet.npz").is_file()
     assert run.stdout.count('+---- Done training: epoch limit reached ----+') == 1      # rank 0 only
 
 
+def test_cooperative_timeout_on_one_rank_falls_back_on_every_rank(experiment, tmp_path):
+    """Rank 1 parks 240 CUs of the shared GPU during its second batch: cooperative launches give up their bounded wait,
+    the guard words summed inside the last gradient bucket void that step's update on BOTH ranks, both fall back to the
+    batch-stationary kernels at the same step, repeat the skipped batches and finish the run with identical variables
+    and the full number of steps."""
+    base, data, cfg0 = experiment
+    exp = tmp_path / "logs" / "dp_park"
+    text = open(cfg0).read().replace("exp_folder = %s" % (base / "logs" / "av_exp0"), "exp_folder = %s" % exp)
+    text = text.replace("max_n_epochs = 3", "max_n_epochs = 2").replace("batch_size = 4", "batch_size = 2")
+    cfg = tmp_path / "dp_park.config"
+    cfg.write_text(text)
+    run = _launch_dp_training(cfg, 2, {'AVSI_TEST_PARK_RANK': '1', 'AVSI_COOP_CUS': '256'})
+    assert run.returncode == 0, run.stderr[-3000:]
+    found = _rank_lines(run.stdout, 2)
+    # 12 samples in batches of 2 over 2 ranks: 3 rounds per epoch, 2 epochs
+    assert all(v[0] == 6 and v[1] == 1 for v in found.values()), (found, run.stderr[-2000:])
+    assert found[0][2] == found[1][2]
+    assert run.stderr.count('falling back to the batch-stationary recurrent kernels') == 2
+
+
 def test_non_finite_loss_on_one_rank_stops_every_rank(experiment, tmp_path):
     """The NaN / Inf abort of the trainer (training_emb.py:244-249, exit code 1) under data parallelism: the verdict
     travels in the last gradient all-reduce bucket (model.nonfinite_flag), so the rank whose loss is fine leaves at the
     same step as the rank whose loss is NaN -- nobody is left waiting in the next collective."""
-    import socket
-    import subprocess
-    import sys
     base, data, cfg0 = experiment
     exp = tmp_path / "logs" / "dp_nan"
     text = open(cfg0).read().replace("exp_folder = %s" % (base / "logs" / "av_exp0"), "exp_folder = %s" % exp)
     cfg = tmp_path / "dp_nan.config"
     cfg.write_text(text)
-    s = socket.socket()
-    s.bind(('127.0.0.1', 0))
-    port = s.getsockname()[1]
-    s.close()
-    env = dict(os.environ, AVSI_DIST_BACKEND='gloo', HSA_ENABLE_IPC_MODE_LEGACY='0', AVSI_COOP_CUS='128', AVSI_TEST_NAN_RANK='1')
-    here = os.path.dirname(os.path.abspath(__file__))
-    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
-           '--master-port', str(port), os.path.join(here, 'dp_train_worker.py'), str(cfg)]
-    run = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    run = _launch_dp_training(cfg, 2, {'AVSI_TEST_NAN_RANK': '1'})
     assert run.returncode != 0
     assert 'GOT INSTABILITY: loss is NaN. Leaving...' in run.stdout
     assert 'GOT INSTABILITY on another rank: loss is not finite there. Leaving...' in run.stdout

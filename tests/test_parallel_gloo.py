@@ -1,6 +1,6 @@
-"""Data-parallel contract on CPU with gloo, world_size 2 (no GPU): summing per-rank gradients of
+"""Data-parallel contract on CPU with gloo, world_size 2 and 8 (no GPU): summing per-rank gradients of
 equal shards and dividing by the world size, then the TF-Adam update, reproduces the single-process
-step on the global batch; shard helpers partition the work."""
+step on the global batch; shard helpers partition the work; the step-guard words of one rank reach every rank."""
 import os
 import socket
 
@@ -23,9 +23,9 @@ def _free_port():
     return p
 
 
-def _problem():
+def _problem(B=4):
     rng = np.random.default_rng(0)
-    B, N = 4, 1536
+    N = 1536
     wav = np.round(rng.normal(0, 3000, size=(B, N)))
     T = N // 192
     masks = np.ones((B, T, 257))
@@ -40,20 +40,30 @@ def _grads(wav, masks, mean, std, seq, params):
     return np.concatenate([v.reshape(-1) for _, v in O.flatten_params(g)]), fwd['loss']
 
 
-def _worker(rank, world, port, out):
+def _worker(rank, world, port, out, B=4):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
                       LOCAL_RANK=str(rank))
+    torch.set_num_threads(1)
     r, w = parallel.init(backend="gloo")
     assert (r, w) == (rank, world) and parallel.world_size() == world and parallel.rank() == rank
-    wav, masks, mean, std, seq, params = _problem()
+    wav, masks, mean, std, seq, params = _problem(B)
     lo, hi = parallel.shard_range(len(wav), rank, world)
     g, loss = _grads(wav[lo:hi], masks[lo:hi], mean, std, seq[lo:hi], params)
     flat = torch.from_numpy(g)
     parallel.all_reduce_sum_(flat)
     flat /= world
     (mean_loss,) = parallel.all_reduce_mean_scalars([loss])
+    # the step guard of models.StackedBLSTMModel travels as two words behind the gradients: rank 5 (world 8) reports a
+    # non-finite loss and rank 3 a cooperative timeout -- every rank must read NaN and 1 after the sum
+    guard = torch.tensor([float('nan') if rank == 5 else 0.0, 1.0 if rank == 3 else 0.0])
+    parallel.all_reduce_sum_(guard)
+    with parallel.solo():
+        assert parallel.world_size() == 1 and parallel.rank() == 0
+        alone = parallel.all_reduce_sum_(torch.tensor([float(rank)]))       # no collective under solo()
+        assert float(alone) == float(rank)
     if rank == 0:
         np.save(out, np.concatenate([flat.numpy(), [mean_loss]]))
+    np.save(out + ".guard%d.npy" % rank, guard.numpy())
     dist.barrier()
     dist.destroy_process_group()
 
@@ -72,6 +82,22 @@ def test_two_rank_gradient_average_equals_global_batch(tmp_path):
     O.adam_tf_step(p1, ref, np.zeros_like(p1), np.zeros_like(p1), 1)
     O.adam_tf_step(p2, got[:-1], np.zeros_like(p2), np.zeros_like(p2), 1)
     np.testing.assert_allclose(p1, p2, rtol=0, atol=1e-12)
+
+
+def test_eight_ranks_at_global_batch_256_equal_the_global_batch(tmp_path):
+    """BASELINE configs[3]'s world: 8 ranks x 32 utterances = global batch 256 (a narrow network and short clips keep
+    the float64 oracle quick): the averaged gradient equals the single-process gradient of all 256, and the guard words
+    of ranks 5 and 3 arrive on every rank."""
+    out = str(tmp_path / "g8.npy")
+    mp.spawn(_worker, args=(8, _free_port(), out, 256), nprocs=8, join=True)
+    got = np.load(out)
+    wav, masks, mean, std, seq, params = _problem(256)
+    ref, loss = _grads(wav, masks, mean, std, seq, params)
+    np.testing.assert_allclose(got[:-1], ref, rtol=1e-9, atol=1e-13)
+    assert got[-1] == pytest.approx(loss, rel=1e-12)
+    for rank in range(8):
+        guard = np.load(out + ".guard%d.npy" % rank)
+        assert np.isnan(guard[0]) and guard[1] == 1.0, rank
 
 
 def test_shard_range_partitions_everything():

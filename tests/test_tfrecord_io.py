@@ -306,6 +306,21 @@ def test_even_rounds_give_every_rank_the_same_number_of_batches(tmp_path):
     assert [len(b[0]) for b in single] == [2, 2, 2, 1]     # one process: nothing to even out
 
 
+def test_even_rounds_with_eight_readers(tmp_path):
+    """BASELINE configs[3]'s world size: 8 readers over 21 batches of 1 = two whole rounds of 8 + 5 left over.  Every rank
+    gets exactly two batches, rank r the batches r and 8 + r; the 5 left over are dropped on every rank alike."""
+    files, truth = _write_dataset(tmp_path, 21)
+    dm = dr.DataManager(2304, 257, 136, buffer_size=2)
+    ds = dm.get_dataset(files, shuffle=False)
+    seen = []
+    for rank in range(8):
+        _, it = dm.get_iterator(ds, batch_size=1, n_epochs=1, shard=(rank, 8), even_rounds=True)
+        got = [list(b[3]) for b in it]
+        assert got == [[truth[rank][6]], [truth[8 + rank][6]]], rank
+        seen += [g[0] for g in got]
+    assert len(set(seen)) == 16
+
+
 def test_whole_file_reader_matches_the_framed_path(tmp_path, monkeypatch):
     """One-record files are read, checked and parsed natively on parallel threads (avsi_tfrecord_file_decode_fixed_host):
     same batches, same shuffle order as the Python framing loop + in-memory decoder (AVSI_READER_FILES=0), with and

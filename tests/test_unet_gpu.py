@@ -433,3 +433,47 @@ def test_inference_model_captures_its_step_by_itself(monkeypatch):
     ref = models.UNetFConvModel(seq[:2], wavs[1][:2], masks[:2], mean, std, 0.0, dict(cfg, batch_size=2), is_training=False,
                                 variables=m_auto.variables)
     assert torch.equal(m_auto.prediction, ref.prediction)
+
+
+def test_training_resumes_after_a_validation_pass_that_captured_a_graph(monkeypatch):
+    """train() validates with model.is_training = False and then goes back to training (training.py).  Five same-shape
+    validation feeds make the model capture its inference step; the captured graph must be gone when training resumes:
+    the training steps after the validation pass equal those of a model that never validated in between."""
+    import torch
+    import avsi_amd  # noqa: F401
+    from avsi_amd import models
+    monkeypatch.delenv('AVSI_UNET_GRAPH', raising=False)
+    B, N = 4, 16384
+    cfg = dict(audio_feat_dim=128, audio_len=N, net_dim=[250, 250, 250], optimizer_type='adam', starter_learning_rate=1e-3,
+               lr_updating_steps=10000, lr_decay=1.0, batch_size=B, l2=0.0)
+    g = torch.Generator(device='cuda')
+    g.manual_seed(4)
+    wavs = [torch.round(torch.randn(B, N, generator=g, device='cuda') * 3000) for _ in range(3)]
+    masks = torch.ones(B, 128, 128, device='cuda')
+    masks[:, 40:52] = 0
+    mean, std = torch.zeros(128, device='cuda') + 6, torch.ones(128, device='cuda') * 2
+    seq = np.full(B, 128)
+
+    def run(validate):
+        m = models.UNetFConvModel(seq, wavs[0], masks, mean, std, 0.0, cfg, is_training=True, seed=5)
+        losses = []
+        for epoch in range(2):
+            for w in wavs[:2]:
+                m.feed(seq, w, masks)
+                losses.append(float(m.loss_func))
+                m.train_op
+            if validate:
+                m.is_training = False
+                for _ in range(5):
+                    m.feed(seq, wavs[2], masks)
+                    float(m.loss_func)
+                assert getattr(m, '_graph', None) is not None          # the validation pass did capture its step
+                m.is_training = True
+        return m, losses
+    m_plain, plain = run(False)
+    m_val, val = run(True)
+    assert getattr(m_val, '_graph', None) is not None                  # still held after the LAST validation pass ...
+    m_val.feed(seq, wavs[0], masks)                                    # ... and dropped by the next training feed
+    assert getattr(m_val, '_graph', None) is None
+    assert plain == val and m_val.global_step == 4
+    assert torch.equal(m_plain.variables.flat, m_val.variables.flat)
