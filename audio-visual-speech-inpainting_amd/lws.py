@@ -170,10 +170,14 @@ class lws(object):
 
     # ------------------------------------------------------------------------------------------------ inference.py:141-154
     def status_word(self):
-        """Device int32[1]: non-zero once a pipeline stage of a run on this object has given up waiting (see check())."""
+        """Device int32[1], a COPY taken on the current stream right behind the runs enqueued so far: non-zero if a
+        pipeline stage of the last run on this object gave up waiting (see check()).  A copy, not a view: every run
+        resets word 0 of the workspace at its start and the workspace is replaced when a batch outgrows it, so a consumer
+        on another stream (inference._WavWriter) that read the word itself could see the NEXT run's reset, or freed
+        memory, instead of this run's verdict."""
         if self._status is None:
             return torch.zeros(1, dtype=torch.int32, device='cuda')
-        return self._status[:1]
+        return self._status[:1].clone()
 
     def refine_enhanced(self, enhanced, masks, num_samples=None, check=True):
         """The reference's per-utterance block, batched on the device: ``enhanced`` [B, n] (output of
