@@ -190,8 +190,8 @@ class _Uploader(object):
             prio = os.environ.get('AVSI_UPLOAD_PRIORITY')
             prio = int(prio) if prio is not None else (-1 if nbytes >= (64 << 20) else 0)
             self.stream = torch.cuda.Stream(device=self.device, priority=prio)
-        out = Batch(batch)
-        out.device_arrays = {}
+        device_arrays = {}
+        host = list(batch)
         pinned = (arena or {}).get('_pinned', {})
         with torch.cuda.stream(self.stream):
             for i in sorted(f % len(batch) for f in self.fields):
@@ -199,11 +199,16 @@ class _Uploader(object):
                 if isinstance(a, np.ndarray) and a.dtype != object and a.size:
                     t = pinned.get(a.ctypes.data)           # the pinned tensor this array is a view of, if any
                     if t is not None:
-                        out.device_arrays[i] = t[:a.shape[0]].to(self.device, non_blocking=True)
+                        device_arrays[i] = t[:a.shape[0]].to(self.device, non_blocking=True)
+                        # the host view points into an arena the reader recycles two batches later: a consumer that read
+                        # it then would silently get ANOTHER batch's data -- the device copy is the field (to_device)
+                        host[i] = None
                     else:
-                        out.device_arrays[i] = torch.from_numpy(np.ascontiguousarray(a)).to(self.device)
-            out.ready = torch.cuda.Event()
-            out.ready.record(self.stream)
+                        device_arrays[i] = torch.from_numpy(np.ascontiguousarray(a)).to(self.device)
+            ready = torch.cuda.Event()
+            ready.record(self.stream)
+        out = Batch(host)
+        out.device_arrays, out.ready = device_arrays, ready
         if arena is not None:
             arena['_event'] = out.ready             # the arena's next user waits for these copies (BatchIterator._make)
         return out
@@ -280,7 +285,7 @@ class BatchIterator(object):
         self.prefetch = int(prefetch)
         self.upload = _Uploader(device, upload_fields, count_gaps) if device is not None else None
         # with a device the consumer works on the uploaded copies, so the host arrays of the bulky fields (audio, video,
-        # mask, embedding) are recycled: they are valid only until the reader moves on -- use Batch.to_device()
+        # mask, embedding) are recycled and the batch tuple holds None in their places -- use Batch.to_device()
         # ... two arenas when they are page-locked: one is parsed into while the other's copies run (its next user waits for
         # their event); pinning is the expensive part of a short run (~0.3 s per GB), so no more of them than needed
         self._arenas = [{'_pin': True} for _ in range(2)] if device is not None else None
@@ -418,6 +423,8 @@ class DataManager:
                 return np.empty(shape, dtype=dtype)
             a = arena.get(name)
             if a is None or a.dtype != dtype or a.shape[1:] != tuple(shape[1:]) or a.shape[0] < shape[0]:
+                if a is not None:
+                    arena.get('_pinned', {}).pop(a.ctypes.data, None)       # the outgrown page-locked block goes with its array
                 if arena.get('_pin') and int(np.prod(shape)) > 0:
                     # page-locked: the uploader's copies then run at the link's rate and asynchronously (_Uploader)
                     import torch

@@ -283,8 +283,9 @@ def test_reader_uploads_batches_from_its_prefetch_thread(experiment):
         np.testing.assert_array_equal(feed['target_sources'].cpu().numpy(), r[2])
         np.testing.assert_array_equal(feed['video_features'].cpu().numpy(), r[5])
         np.testing.assert_array_equal(feed['masks'].cpu().numpy(), r[6])
-        # (the HOST arrays of the bulky fields are views of two page-locked arenas the reader recycles: only valid until it
-        # moves on, which it already may have -- consumers use the device copies; the small fields are copies)
+        # the host views of the uploaded fields pointed into two page-locked arenas the reader recycles: the tuple holds
+        # None there, consumers use the device copies; the small fields are copies
+        assert b[2] is None and b[5] is None and b[6] is None
         np.testing.assert_array_equal(b[0], r[0])
         assert list(paths) == list(r[3])
     assert n == 3
