@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include "../../include/avsi_hip.h"
 
 #define AVSI_ABI_VERSION 9   // 9: step guard + guarded Adam (8: avsi_gemm_epilogue::k_zero (7: skewed-frame LWS sweeps (6: row-range forms of the cooperative forward entries (5: column-split recurrent kernel (4: LWS phase reconstruction (3: CTC loss + beam-search decoder (2: cooperative recurrence, implicit-GEMM / thin convolutions, blend loss)))))))
@@ -26,3 +27,35 @@ static inline int64_t avsi_round_up(int64_t a, int64_t b) { return avsi_ceil_div
 // flight -- which is exactly the latency the pipelined loops keep in flight on purpose
 // (tools/mfma_f32_lds.hip: 155 -> 56-89 TFLOP/s with four in-flight loads per barrier).
 #define AVSI_LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+
+// Bounded wait of the cooperative recurrent kernels, in WALL-CLOCK time.  A member normally sees its peers within
+// microseconds; at the start of a launch it may wait for them to become resident behind whatever else occupies the
+// chip (milliseconds).  Beyond AVSI_COOP_TIMEOUT_MS (default 2000, 10 .. 60000) the launch is taken to be
+// over-subscribed -- another resident of the GPU left its workgroups no room -- and gives up (sticky status word).  A
+// poll COUNT was used before: 2^22 polls turned out to be more than 30 s once sleeping polls of 30+ workgroups queue on
+// one memory channel.  The clock (s_memrealtime, 100 MHz) is read on every 128th poll only.
+static inline long long avsi_coop_spin_ticks() {
+    static long long ticks = 0;
+    if (!ticks) {
+        const char* e = getenv("AVSI_COOP_TIMEOUT_MS");
+        long long ms = e ? atoll(e) : 2000;
+        ms = ms < 10 ? 10 : (ms > 60000 ? 60000 : ms);
+        ticks = ms * 100000LL;
+    }
+    return ticks;
+}
+#if defined(__HIPCC__)
+__device__ __forceinline__ bool avsi_spin_expired(unsigned& polls, long long& t0, long long limit_ticks,
+                                                  const unsigned* status) {
+    if ((++polls & 127u) != 0) return false;
+    // somebody else of this launch (or of one before it) has given up already: everything is void, do not wait out a
+    // bound of one's own behind it (members that become resident one after the other would otherwise chain their waits)
+    if (__hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return true;
+    const long long now = wall_clock64();
+    if (polls == 128u) {
+        t0 = now;
+        return false;
+    }
+    return now - t0 > limit_ticks;
+}
+#endif

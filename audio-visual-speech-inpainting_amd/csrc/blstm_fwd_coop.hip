@@ -21,7 +21,7 @@
 //     placed S blocks of 8 apart (round-robin dispatch then tends to put them on one XCD), but that
 //     is a locality hint only: nothing is assumed about placement -- an experiment with L2-scope
 //     (sc0) atomics between the members never saw its peers' increments, so every exchange uses
-//     device scope.  The spin is bounded: a group that does not see its peers within ~2^22 polls marks
+//     device scope.  The spin is bounded: a group that does not see its peers within AVSI_COOP_TIMEOUT_MS (2 s of wall clock) marks
 //     the status word, stops waiting and runs to the end, so the grid always drains.
 // The launch needs all S members of a group resident together; groups are contiguous windows of
 // 8 S block ids and the kernel uses one workgroup per CU, so in-order dispatch guarantees that for
@@ -37,7 +37,6 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 constexpr int HP = 256, GP = 4 * HP;
 constexpr int PSTRIDE = 36;                          // LDS pitch of one unit's 32 rows (+4: conflict-free b128)
 constexpr int PART_FLOATS = 8 * 4 * 32 * PSTRIDE;    // [wave][gate][unit][row]
-constexpr unsigned SPIN_LIMIT = 1u << 22;
 // One 256-byte line per step counter.  Packed counters (16 to a line) made every poller and every increment of
 // 16 groups queue on one memory channel: at 512 workgroups that, not the exchange itself, set the step time
 // (column-split kernel, 1024 utterances: 5.9 -> 3.0 ms per layer from this alone).
@@ -54,6 +53,7 @@ struct CoopArgs {
     float* xch;        // fine kernels: h in exchange layout [T][group][member][32 utterances][units of the member], or null
     int xtile0, xtiles;   // ... of the tiles [xtile0, xtile0 + xtiles) of the CALL (a row-range call covers part of the batch)
     int coherent;      // AVSI_COOP_COHERENT=1: every load of exchanged bytes at device scope, whatever the invariants allow
+    long long spin_ticks;   // bound of every wait for a peer, 100 MHz ticks (avsi_coop_spin_ticks)
 };
 
 __device__ __forceinline__ float sigmoidf_fast(float x) { return __builtin_amdgcn_rcpf(1.f + __expf(-x)); }
@@ -92,11 +92,12 @@ __device__ __forceinline__ void agent_load4_issue(v4f& dst, const float* p, int 
 // counter any more) and puts the counter back to zero: the workspace is left as it was found, so the next launch on
 // it needs no memset in front (a 5 us kernel and two launch gaps per recurrent launch -- 0.12 ms of a 7 ms training
 // step at 32 utterances).  Not after a bounded wait has given up: the status word says so and the caller re-zeroes.
-__device__ __forceinline__ void reset_counter_when_done(unsigned* ctr, unsigned total) {
+__device__ __forceinline__ void reset_counter_when_done(unsigned* ctr, unsigned total, long long spin_ticks, const unsigned* status) {
     unsigned polls = 0;
+    long long t0 = 0;
     while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < total) {
         __builtin_amdgcn_s_sleep(2);
-        if (++polls > SPIN_LIMIT) return;
+        if (avsi_spin_expired(polls, t0, spin_ticks, status)) return;
     }
     __hip_atomic_store(ctr, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
@@ -124,7 +125,7 @@ __global__ __launch_bounds__(512, 2) void blstm_rec_fwd_coop_kernel(const CoopAr
     const int group = (kk / S) * AVSI_NUM_XCD + xcd;
     if (group >= a.ngroups) return;
     // behind a launch that gave up a bounded wait every result is void (sticky status word): leave at once instead of
-    // spending 2^22 polls per wait on step counters that launch may have left behind
+    // waiting out the time bound on step counters that launch may have left behind
     if (__hip_atomic_load(a.sync, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return;
     const int dir = group & 1;
     const int b0 = (a.tile0 + (group >> 1)) * 32;
@@ -185,9 +186,10 @@ __global__ __launch_bounds__(512, 2) void blstm_rec_fwd_coop_kernel(const CoopAr
             if (tid == 0 && !dead) {
                 const unsigned want = (unsigned)S * (unsigned)step;
                 unsigned polls = 0;
+                long long t0 = 0;
                 while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
                     __builtin_amdgcn_s_sleep(2);
-                    if (++polls > SPIN_LIMIT) {
+                    if (avsi_spin_expired(polls, t0, a.spin_ticks, a.sync)) {
                         dead = 1;
                         atomicExch(a.sync, 1u);
                         break;
@@ -262,7 +264,7 @@ __global__ __launch_bounds__(512, 2) void blstm_rec_fwd_coop_kernel(const CoopAr
         __syncthreads();      // also: nobody overwrites `part` before all cells of this step are read
         if (tid == 0) __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    if (member == 0 && tid == 0 && !dead) reset_counter_when_done(ctr, (unsigned)S * (unsigned)T);
+    if (member == 0 && tid == 0 && !dead) reset_counter_when_done(ctr, (unsigned)S * (unsigned)T, a.spin_ticks, a.sync);
 }
 
 // Finer split for the smallest batches (S = 16 or 32 workgroups per (tile, direction)): at S = 8 the 128
@@ -294,7 +296,7 @@ __global__ __launch_bounds__(512, 2) void blstm_rec_fwd_coop_fine_kernel(const C
     const int group = (kk / S) * AVSI_NUM_XCD + xcd;
     if (group >= a.ngroups) return;
     // behind a launch that gave up a bounded wait every result is void (sticky status word): leave at once instead of
-    // spending 2^22 polls per wait on step counters that launch may have left behind
+    // waiting out the time bound on step counters that launch may have left behind
     if (__hip_atomic_load(a.sync, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return;
     const int dir = group & 1;
     const int b0 = (a.tile0 + (group >> 1)) * 32;
@@ -363,9 +365,10 @@ __global__ __launch_bounds__(512, 2) void blstm_rec_fwd_coop_fine_kernel(const C
             if (tid == 0 && !dead) {
                 const unsigned want = (unsigned)S * (unsigned)step;
                 unsigned polls = 0;
+                long long t0 = 0;
                 while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
                     __builtin_amdgcn_s_sleep(1);
-                    if (++polls > SPIN_LIMIT) {
+                    if (avsi_spin_expired(polls, t0, a.spin_ticks, a.sync)) {
                         dead = 1;
                         atomicExch(a.sync, 1u);
                         break;
@@ -460,7 +463,7 @@ __global__ __launch_bounds__(512, 2) void blstm_rec_fwd_coop_fine_kernel(const C
         __syncthreads();
         if (tid == 0) __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    if (member == 0 && tid == 0 && !dead) reset_counter_when_done(ctr, (unsigned)S * (unsigned)T);
+    if (member == 0 && tid == 0 && !dead) reset_counter_when_done(ctr, (unsigned)S * (unsigned)T, a.spin_ticks, a.sync);
 }
 
 template <int NT, bool SAVE, bool XCH>
@@ -552,7 +555,7 @@ extern "C" int avsi_blstm_rec_fwd_coop_rows_f32(const float* xproj, const float*
     if (xch && avsi_blstm_rec_fwd_coop_workspace_bytes(Bp) > AVSI_COOP_EXCHANGE_OFFSET) return AVSI_ERR_WORKSPACE;
     for (int tile0 = tbeg; tile0 < tiles; tile0 += per) {
         const int nt = tiles - tile0 < per ? tiles - tile0 : per;
-        CoopArgs a{xproj, whp, hout, reserve, (unsigned*)workspace, T, Bp, 2 * nt, tile0, xch, tbeg, rows / 32, coop_coherent()};
+        CoopArgs a{xproj, whp, hout, reserve, (unsigned*)workspace, T, Bp, 2 * nt, tile0, xch, tbeg, rows / 32, coop_coherent(), avsi_coop_spin_ticks()};
         int rc;
         if (split == 32)
             rc = reserve ? launch_coop_fine<1, true>(a, st) : launch_coop_fine<1, false>(a, st);
@@ -595,6 +598,7 @@ struct CoopBwdArgs {
     int tile0;
     float* xch;        // fine kernel: dz in exchange layout [step][group x half][member][gate][rows][16 units], or null
     int coherent;      // AVSI_COOP_COHERENT=1 (see CoopArgs)
+    long long spin_ticks;
 };
 
 constexpr int BPART_FLOATS = 8 * 32 * PSTRIDE;      // [wave][unit][row]
@@ -612,7 +616,7 @@ __global__ __launch_bounds__(512, 2) void blstm_rec_bwd_coop_kernel(const CoopBw
     const int group = (kk / S) * AVSI_NUM_XCD + xcd;
     if (group >= a.ngroups) return;
     // behind a launch that gave up a bounded wait every result is void (sticky status word): leave at once instead of
-    // spending 2^22 polls per wait on step counters that launch may have left behind
+    // waiting out the time bound on step counters that launch may have left behind
     if (__hip_atomic_load(a.sync, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return;
     const int dir = group & 1;
     const int b0 = (a.tile0 + (group >> 1)) * 32;
@@ -667,9 +671,10 @@ __global__ __launch_bounds__(512, 2) void blstm_rec_bwd_coop_kernel(const CoopBw
             if (tid == 0 && !dead) {
                 const unsigned want = (unsigned)S * (unsigned)s;
                 unsigned polls = 0;
+                long long t0 = 0;
                 while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
                     __builtin_amdgcn_s_sleep(2);
-                    if (++polls > SPIN_LIMIT) {
+                    if (avsi_spin_expired(polls, t0, a.spin_ticks, a.sync)) {
                         dead = 1;
                         atomicExch(a.sync, 1u);
                         break;
@@ -726,7 +731,7 @@ __global__ __launch_bounds__(512, 2) void blstm_rec_bwd_coop_kernel(const CoopBw
         __syncthreads();
         if (tid == 0) __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    if (member == 0 && tid == 0 && !dead) reset_counter_when_done(ctr, (unsigned)S * (unsigned)T);
+    if (member == 0 && tid == 0 && !dead) reset_counter_when_done(ctr, (unsigned)S * (unsigned)T, a.spin_ticks, a.sync);
 }
 
 // Finer split of the BPTT kernel (S = 16: a workgroup owns 16 units of dh), the counterpart of
@@ -757,7 +762,7 @@ __global__ __launch_bounds__(512, 2) void blstm_rec_bwd_coop_fine_kernel(const C
     const int group = (kk / (S * RH)) * AVSI_NUM_XCD + xcd;
     if (group >= a.ngroups) return;
     // behind a launch that gave up a bounded wait every result is void (sticky status word): leave at once instead of
-    // spending 2^22 polls per wait on step counters that launch may have left behind
+    // waiting out the time bound on step counters that launch may have left behind
     if (__hip_atomic_load(a.sync, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return;
     const int dir = group & 1;
     const int b0 = (a.tile0 + (group >> 1)) * 32 + half * 16;
@@ -824,9 +829,10 @@ __global__ __launch_bounds__(512, 2) void blstm_rec_bwd_coop_fine_kernel(const C
             if (tid == 0 && !dead) {
                 const unsigned want = (unsigned)S * (unsigned)s;
                 unsigned polls = 0;
+                long long t0 = 0;
                 while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
                     __builtin_amdgcn_s_sleep(1);
-                    if (++polls > SPIN_LIMIT) {
+                    if (avsi_spin_expired(polls, t0, a.spin_ticks, a.sync)) {
                         dead = 1;
                         atomicExch(a.sync, 1u);
                         break;
@@ -921,7 +927,7 @@ __global__ __launch_bounds__(512, 2) void blstm_rec_bwd_coop_fine_kernel(const C
         __syncthreads();
         if (tid == 0) __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    if (member == 0 && tid == 0 && !dead) reset_counter_when_done(ctr, (unsigned)S * (unsigned)T);
+    if (member == 0 && tid == 0 && !dead) reset_counter_when_done(ctr, (unsigned)S * (unsigned)T, a.spin_ticks, a.sync);
 }
 
 }  // namespace
@@ -951,7 +957,7 @@ extern "C" int avsi_blstm_rec_bwd_coop_f32(const float* dhout, const float* rese
     const int tiles = Bp / 32, per = coop_tiles_per_launch(split, max_cus);
     for (int tile0 = 0; tile0 < tiles; tile0 += per) {
         const int nt = tiles - tile0 < per ? tiles - tile0 : per;
-        CoopBwdArgs a{dhout, reserve, whbT, dz, (unsigned*)workspace, T, Bp, 2 * nt, tile0, xch, coop_coherent()};
+        CoopBwdArgs a{dhout, reserve, whbT, dz, (unsigned*)workspace, T, Bp, 2 * nt, tile0, xch, coop_coherent(), avsi_coop_spin_ticks()};
         const int blocks = (int)avsi_ceil_div(2 * nt, AVSI_NUM_XCD) * AVSI_NUM_XCD * split;
         if (split == 32 && xch)     // 16 unit slices x 2 row halves
             hipLaunchKernelGGL((blstm_rec_bwd_coop_fine_kernel<2, true>), dim3(blocks), dim3(512), 96 * 1024, st, a);

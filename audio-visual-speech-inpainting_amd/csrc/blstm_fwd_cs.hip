@@ -28,7 +28,6 @@ typedef float v4f __attribute__((ext_vector_type(4)));
 
 constexpr int HP = 256, GP = 4 * HP;
 constexpr int HPITCH = HP + 4;                       // LDS pitch of one utterance's h (conflict-free b128 rows)
-constexpr unsigned SPIN_LIMIT = 1u << 22;
 constexpr int MEMBERS = 8;
 constexpr int CTR_STRIDE = 64;                       // one 256-byte line per counter: 8 pollers each, spread over the channels
 
@@ -41,6 +40,7 @@ struct CsArgs {
     int T, Bp, ngroups;
     int group0;        // first (row tile, direction) group of this launch
     unsigned long long* stamps;   // diagnostics (STAMPS): [block < 32][step 64 .. 71][wave 0 / 1][8 phases] wall clock
+    long long spin_ticks;         // bound of every wait for a peer, 100 MHz ticks (avsi_coop_spin_ticks)
 };
 
 __device__ __forceinline__ float sigmoidf_fast(float x) { return __builtin_amdgcn_rcpf(1.f + __expf(-x)); }
@@ -74,7 +74,7 @@ __global__ __launch_bounds__(512, 4) void blstm_rec_fwd_cs_kernel(const CsArgs a
     const int lgroup = (kk / MEMBERS) * AVSI_NUM_XCD + xcd;
     if (lgroup >= a.ngroups) return;
     // behind a launch that gave up a bounded wait every result is void (sticky status word): leave at once instead of
-    // spending 2^22 polls per wait on step counters that launch may have left behind
+    // waiting out the time bound on step counters that launch may have left behind
     if (__hip_atomic_load(a.sync, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return;
     const int group = a.group0 + lgroup;
     const int dir = group & 1;
@@ -140,9 +140,10 @@ __global__ __launch_bounds__(512, 4) void blstm_rec_fwd_cs_kernel(const CsArgs a
             if (tid == 0 && !wg_dead) {
                 const unsigned want = (unsigned)MEMBERS * (unsigned)step;
                 unsigned polls = 0;
+                long long t0 = 0;
                 while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
                     __builtin_amdgcn_s_sleep(1);
-                    if (++polls > SPIN_LIMIT) {
+                    if (avsi_spin_expired(polls, t0, a.spin_ticks, a.sync)) {
                         wg_dead = 1;
                         atomicExch(a.sync, 1u);
                         break;
@@ -245,9 +246,10 @@ __global__ __launch_bounds__(512, 4) void blstm_rec_fwd_cs_kernel(const CsArgs a
     // leave the counter at zero for the next launch on this workspace (see blstm_fwd_coop.hip)
     if (member == 0 && tid == 0 && !wg_dead) {
         unsigned polls = 0;
+        long long t0 = 0;
         while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)MEMBERS * (unsigned)T) {
             __builtin_amdgcn_s_sleep(2);
-            if (++polls > SPIN_LIMIT) return;
+            if (avsi_spin_expired(polls, t0, a.spin_ticks, a.sync)) return;
         }
         __hip_atomic_store(ctr, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
@@ -279,7 +281,7 @@ int launch_cs(const float* xproj, const float* whp, float* hout, float* reserve,
     const int gbeg = 2 * (first_row / (16 * RT)), groups = gbeg + 2 * (rows / (16 * RT));
     for (int g0 = gbeg; g0 < groups; g0 += per) {
         const int ng = groups - g0 < per ? groups - g0 : per;
-        CsArgs a{xproj, whp, hout, reserve, sync, T, Bp, ng, g0, g_cs_stamps};
+        CsArgs a{xproj, whp, hout, reserve, sync, T, Bp, ng, g0, g_cs_stamps, avsi_coop_spin_ticks()};
         const int blocks = (int)avsi_ceil_div(ng, AVSI_NUM_XCD) * AVSI_NUM_XCD * MEMBERS;
         if (g_cs_stamps)
             hipLaunchKernelGGL((blstm_rec_fwd_cs_kernel<RT, SAVE, true>), dim3(blocks), dim3(512), 0, st, a);

@@ -116,13 +116,14 @@ def blstm_rec_fwd(xproj, whp, hout, reserve=None, rows_per_wg=0, split=None):
                                             T, Bp, int(rows_per_wg), _lib.stream_ptr()), "avsi_blstm_rec_fwd_f32")
         return hout
     need = max(L.avsi_blstm_rec_fwd_cs_workspace_bytes(Bp), L.avsi_blstm_rec_fwd_coop_workspace_bytes(Bp))
-    fine = [rows for _, rows, sp in parts if sp >= 16]
+    fine = [rows for _, rows, sp in parts if (_cap_split(sp) if auto else sp) >= 16]
     if _COOP_EXCHANGE and fine:
         # fine splits: room for the exchange copy of h (of THEIR rows) at its fixed offset (AVSI_COOP_EXCHANGE=0:
         # exchange through hout)
         need = max(need, COOP_EXCHANGE_OFFSET + L.avsi_blstm_rec_fwd_coop_exchange_bytes(T, max(fine)))
     ws = _coop_ws(xproj.device, Bp, need)
     for first, rows, sp in parts:
+        sp = _cap_split(sp) if auto else sp
         if sp == 0:
             _lib.check(L.avsi_blstm_rec_fwd_rows_f32(_lib.ptr(xproj), _lib.ptr(whp), _lib.ptr(hout), _lib.ptr(reserve), T, Bp,
                                                      0, first, rows, _lib.stream_ptr()), "avsi_blstm_rec_fwd_rows_f32")
@@ -185,35 +186,57 @@ def rec_fwd_parts(Bp):
 
 _COOP_WS, _COOP_HOST = {}, {}      # keyed by (device index, stream)
 _COOP_FALLBACKS = []               # reasons, one per fall-back of this process (coop_fall_back)
+COOP_FALLBACK_MAX_SPLIT = 8        # first fall-back: reduction splits capped here (see coop_fall_back)
+
+
+def coop_level():
+    """0: the default policy.  1: after one fall-back -- the cooperative kernels that need a whole XCD to themselves are
+    out.  2: after two (or AVSI_REC_COOP=0) -- the batch-stationary kernels only."""
+    return 2 if os.environ.get('AVSI_REC_COOP', '1') == '0' else min(2, len(_COOP_FALLBACKS))
 
 
 def coop_disabled():
-    """True when the recurrence runs on the batch-stationary kernels only: AVSI_REC_COOP=0, or this process fell back to
-    them after a cooperative launch gave up waiting for residency (coop_fall_back)."""
-    return bool(_COOP_FALLBACKS) or os.environ.get('AVSI_REC_COOP', '1') == '0'
+    """True when the recurrence runs on the batch-stationary kernels only: AVSI_REC_COOP=0, or this process fell back
+    twice after cooperative launches gave up waiting for residency (coop_fall_back)."""
+    return coop_level() >= 2
 
 
 def coop_fallbacks():
-    """How many times this process fell back from the cooperative kernels (0 or 1: the fall-back is not undone)."""
+    """How many times this process fell back from its cooperative kernels (0, 1 or 2: a fall-back is not undone)."""
     return len(_COOP_FALLBACKS)
+
+
+def _cap_split(split):
+    """Level 1: the 16- and 32-way kernels hold 96 KB of LDS per workgroup ON PURPOSE (one member per CU) and keep the
+    S members of a group on ONE XCD (their exchange stays in that XCD's L2): a 32-way group needs all 32 CUs of its XCD,
+    so any other resident that takes LDS there starves it (tools/coop_timeout_probe.py: 16 parked CUs are enough).  The
+    4- and 8-way kernels run two members to a CU on 32 KB and the column-split kernel four: they only need room
+    somewhere."""
+    if coop_level() == 1 and split > COOP_FALLBACK_MAX_SPLIT:
+        return COOP_FALLBACK_MAX_SPLIT
+    return split
 
 
 def coop_fall_back(device=None, reason='a cooperative recurrent launch timed out waiting for residency'):
     """Recovery from a cooperative-kernel timeout, in this process: wait for the device, put the workspaces (status
-    words and step counters) back to zero and route every later recurrence through the batch-stationary kernels, which
-    need no co-residency of their workgroups.  Logged once.  The caller repeats the batches whose steps the step guard
-    voided (training.train) -- the variables were not touched by them (avsi_adam_tf_guarded_f32)."""
+    words and step counters) back to zero and take the next step down: first to the cooperative kernels that tolerate
+    neighbours (8-way reduction split, column split: 1.8 instead of 0.8 ms per layer at 32 utterances), then to the
+    batch-stationary kernels, which need no co-residency of their workgroups at all (~10 ms per layer whatever the
+    batch).  Logged each time.  The caller repeats the batches whose steps the step guard voided (training.train) --
+    the variables were not touched by them (avsi_adam_tf_guarded_f32)."""
     idx = torch.cuda.current_device() if device is None else torch.device(device).index
     _coop_recover(idx)
-    if not _COOP_FALLBACKS:
-        print('avsi: %s; falling back to the batch-stationary recurrent kernels for the rest of this process' % reason,
-              file=sys.stderr, flush=True)
-    _COOP_FALLBACKS.append(reason)
+    if len(_COOP_FALLBACKS) < 2:
+        _COOP_FALLBACKS.append(reason)
+        print('avsi: %s; falling back to %s for the rest of this process' % (
+            reason, 'the cooperative kernels that tolerate neighbours (splits <= %d, column split)' % COOP_FALLBACK_MAX_SPLIT
+            if len(_COOP_FALLBACKS) == 1 else 'the batch-stationary recurrent kernels'), file=sys.stderr, flush=True)
 
 
 def coop_fall_back_reset():
-    """Tests only: allow the cooperative kernels again."""
+    """Tests only: the default policy again."""
     del _COOP_FALLBACKS[:]
+
 
 _COOP_EXCHANGE = os.environ.get('AVSI_COOP_EXCHANGE', '1') != '0'
 COOP_EXCHANGE_OFFSET = 1 << 20       # AVSI_COOP_EXCHANGE_OFFSET of include/avsi_hip.h
@@ -327,6 +350,7 @@ def coop_split(Bp, backward=False):
         if split == -16 and 2 * (Bp // 16) * 8 > 2 * budget:      # by 16 does not fit one launch, by 32 does
             split = -32
         return split
+    split = _cap_split(split)
     while split > 4 and 2 * (Bp // 32) * split > budget:
         split //= 2
     while split > 4 and 2 * split > budget:       # not even one tile fits at this split
@@ -376,8 +400,12 @@ def coop_check(device=None):
 
 def _coop_recover(idx):
     """A launch that gave up waiting may have left step counters behind (the kernels zero them only on a clean
-    end): start over with clean workspaces once the failure has been reported."""
-    torch.cuda.synchronize(idx)
+    end): start over with clean workspaces once the failure has been reported.  Waits for the streams that own a
+    workspace (whatever else is resident on the device -- the neighbour that caused the timeout -- is not waited for)."""
+    for (dev, st) in list(_COOP_WS):
+        if dev == idx:
+            (torch.cuda.ExternalStream(st, device=torch.device('cuda', dev)) if st
+             else torch.cuda.default_stream(torch.device('cuda', dev))).synchronize()
     for (dev, _), ws in _COOP_WS.items():
         if dev == idx:
             ws.zero_()

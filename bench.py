@@ -370,11 +370,11 @@ def dp_train_block(torch, dist, models, ops, ap_mod, cfg, device, rank, world):
         return True
 
     def three_steps(n, w, m_, v):
-        for attempt in (0, 1):
+        for attempt in range(3):              # at most two fall-backs: tolerant cooperative kernels, then batch-stationary
             m, step = build(n, w, m_, v)
             init = m.variables.flat.clone()
             losses = torch.stack([step() for _ in range(3)])
-            if not (attempt == 0 and fell_back(m)):
+            if not fell_back(m):
                 break
         ops.coop_check(device)
         return m.variables.flat.clone(), init, losses
@@ -410,7 +410,7 @@ def dp_train_block(torch, dist, models, ops, ap_mod, cfg, device, rank, world):
         m, step = build(per_b, w, m_, v, seed=7)
         steps, warm = (30, 5) if per_b <= 64 else (12, 3)
         ms = time_steps_all_ranks(torch, dist, world, step, steps, warm)
-        if fell_back(m):                  # a residency conflict (e.g. with RCCL's kernels) costs a repetition, not the entry
+        while fell_back(m):               # a residency conflict (e.g. with RCCL's kernels) costs a repetition, not the entry
             m, step = build(per_b, w, m_, v, seed=7)
             ms = time_steps_all_ranks(torch, dist, world, step, steps, warm)
         ops.coop_check(device)
@@ -418,7 +418,8 @@ def dp_train_block(torch, dist, models, ops, ap_mod, cfg, device, rank, world):
                              % ("RCCL gradient all-reduce + " if world > 1 else "", per_b),
                  "scaling": scaling, "per_gpu_batch": per_b, "global_batch": per_b * world, "ms_per_step": ms,
                  "value": per_b * world / ms * 1e3, "unit": "utterances/s"}
-        entry["recurrent_kernels"] = "batch-stationary (fell back)" if ops.coop_disabled() else "default policy"
+        entry["recurrent_kernels"] = ("default policy", "cooperative, splits <= 8 (fell back once)",
+                                      "batch-stationary (fell back twice)")[ops.coop_level()]
         if world > 1:
             with parallel.solo():
                 entry["ms_per_step_no_collective"] = time_steps_all_ranks(torch, dist, world, step, steps, 2)

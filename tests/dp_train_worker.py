@@ -20,8 +20,9 @@ if __name__ == '__main__':
         training.unpack_batch = poisoned
     park = os.environ.get('AVSI_TEST_PARK_RANK')
     if park is not None and int(park) == int(os.environ.get('RANK', '0')):
-        # while this rank's second batch runs, 240 of the GPU's 256 CUs are parked for 12 s (the stand-in for another
-        # resident of the chip): cooperative launches time out, every rank must fall back at the same step and go on
+        # from this rank's second batch on, 16 of the GPU's 256 CUs are parked for 10 s with all their LDS taken (the stand-in
+        # for another resident of the chip): the 32-way cooperative groups cannot have their XCD to themselves and time out,
+        # every rank must fall back at the same step and go on
         import torch
         from avsi_amd import ops
         plain_unpack = training.unpack_batch
@@ -31,9 +32,9 @@ if __name__ == '__main__':
             state['n'] += 1
             if state['n'] == 2:
                 state['release'] = torch.zeros(1, dtype=torch.int32, device='cuda')
-                state['side'] = torch.cuda.Stream()
+                state['side'] = torch.cuda.Stream(priority=0)       # the trainer launches on a high-priority stream
                 with torch.cuda.stream(state['side']):
-                    ops.occupy_cus(240, state['release'], max_ms=12000)
+                    ops.occupy_cus(16, state['release'], max_ms=10000)
             return plain_unpack(*a, **kw)
         training.unpack_batch = parking
     try:

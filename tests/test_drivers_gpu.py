@@ -343,10 +343,10 @@ def test_data_parallel_training_through_the_driver(experiment, tmp_path, ranks, 
 
 
 def test_cooperative_timeout_on_one_rank_falls_back_on_every_rank(experiment, tmp_path):
-    """Rank 1 parks 240 CUs of the shared GPU during its second batch: cooperative launches give up their bounded wait,
-    the guard words summed inside the last gradient bucket void that step's update on BOTH ranks, both fall back to the
-    batch-stationary kernels at the same step, repeat the skipped batches and finish the run with identical variables
-    and the full number of steps."""
+    """Rank 1 parks 16 CUs of the shared GPU from its second batch on: 32-way cooperative launches give up their bounded
+    wait, the guard words summed inside the last gradient bucket void that step's update on BOTH ranks, both fall back to
+    the neighbour-tolerant cooperative kernels at the same step, repeat the skipped batches and finish the run with
+    identical variables and the full number of steps."""
     base, data, cfg0 = experiment
     exp = tmp_path / "logs" / "dp_park"
     text = open(cfg0).read().replace("exp_folder = %s" % (base / "logs" / "av_exp0"), "exp_folder = %s" % exp)
@@ -357,9 +357,9 @@ def test_cooperative_timeout_on_one_rank_falls_back_on_every_rank(experiment, tm
     assert run.returncode == 0, run.stderr[-3000:]
     found = _rank_lines(run.stdout, 2)
     # 12 samples in batches of 2 over 2 ranks: 3 rounds per epoch, 2 epochs
-    assert all(v[0] == 6 and v[1] == 1 for v in found.values()), (found, run.stderr[-2000:])
-    assert found[0][2] == found[1][2]
-    assert run.stderr.count('falling back to the batch-stationary recurrent kernels') == 2
+    assert all(v[0] == 6 and v[1] >= 1 for v in found.values()), (found, run.stderr[-2000:])
+    assert found[0][1] == found[1][1] and found[0][2] == found[1][2]
+    assert run.stderr.count('falling back to the cooperative kernels that tolerate neighbours') == 2
 
 
 def test_non_finite_loss_on_one_rank_stops_every_rank(experiment, tmp_path):

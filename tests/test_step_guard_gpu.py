@@ -90,10 +90,13 @@ def test_a_non_finite_loss_never_reaches_the_variables(optimizer):
     assert m.step_guard.cpu().tolist() == [0.0, 0.0] and not torch.equal(v.flat, before[0])
 
 
-def _park(cus, ms):
+def _park(cus, ms, priority=-1):
+    """Park `cus` whole compute units (160 KB of LDS each) on a stream of ANOTHER priority level than the stream the model
+    runs on: HIP maps its streams onto a few hardware queues per priority level, and a parked kernel that shares the
+    model's queue would simply hold the model's kernels back in order (tools/coop_timeout_probe.py)."""
     from avsi_amd import ops
     release = torch.zeros(1, dtype=torch.int32, device='cuda')
-    side = torch.cuda.Stream()
+    side = torch.cuda.Stream(priority=priority)
     torch.cuda.synchronize()
     with torch.cuda.stream(side):
         ops.occupy_cus(cus, release, max_ms=ms)
@@ -101,52 +104,55 @@ def _park(cus, ms):
 
 
 def test_a_cooperative_timeout_voids_the_step_and_the_fall_back_repeats_it(monkeypatch):
-    """240 of the 256 CUs are parked (the stand-in for another resident of the GPU, e.g. RCCL's kernels): the 64
-    workgroups of a 32-utterance cooperative launch cannot all be resident, the bounded wait gives up, the guard voids
-    the update.  After ops.coop_fall_back() the same model repeats the step on the batch-stationary kernels; the
-    variables then equal a run that never used the cooperative kernels (AVSI_REC_COOP=0), to rounding."""
+    """16 of the 256 CUs are parked with all their LDS taken (the stand-in for another resident of the GPU): a 32-way
+    cooperative group needs the 32 CUs of ITS XCD, cannot become resident, the bounded wait gives up after 2 s and the
+    guard voids the update.  After ops.coop_fall_back() the same model repeats the step on the 8-way kernels WHILE THE
+    NEIGHBOUR IS STILL THERE; a second fall-back leads to the batch-stationary kernels.  The variables in the end equal
+    a run that never used the cooperative kernels (AVSI_REC_COOP=0), to rounding."""
     from avsi_amd import ops
-    for name in ('AVSI_REC_COOP', 'AVSI_COOP_CUS', 'AVSI_COOP_SPLIT_FWD', 'AVSI_COOP_SPLIT_BWD'):
+    for name in ('AVSI_REC_COOP', 'AVSI_COOP_CUS', 'AVSI_COOP_SPLIT_FWD', 'AVSI_COOP_SPLIT_BWD', 'AVSI_COOP_TIMEOUT_MS'):
         monkeypatch.delenv(name, raising=False)
     ops.coop_fall_back_reset()
     ops.set_coop_cu_budget(None)
+    monkeypatch.setattr(ops, 'COOP_POLL_RAISES', False)         # the guard decides, as in the trainer
     B = 32
-    assert ops.coop_split(B) > 0 and ops.coop_split(B, backward=True) > 0
+    assert ops.coop_split(B) == 32 and ops.coop_split(B, backward=True) == 32
     m, feed = _model(B)
     m.feed(**feed)
-    m.train_op                                  # step 1: cooperative kernels, nothing in their way
+    m.train_op                                  # step 1: 32-way cooperative kernels, nothing in their way
     assert m.step_guard.cpu().tolist() == [0.0, 0.0]
     v1 = m.variables.flat.clone()
     m1, s1 = m.variables.adam_m.clone(), m.variables.global_step
 
-    release, side = _park(240, 30000)
+    release, side = _park(16, 40000)
     try:
         m.feed(**feed)
-        m.train_op                              # step 2: the forward launch of layer 0 times out; every launch behind it
-        guard = m.step_guard.cpu().numpy()      # leaves at once (sticky status word)
-        parked_during = not side.query()
-    finally:
-        release.fill_(1)
-        torch.cuda.synchronize()
-    assert parked_during
-    assert guard[1] == 1.0
-    assert torch.equal(m.variables.flat, v1) and torch.equal(m.variables.adam_m, m1)       # untouched
-    assert m.variables.global_step == s1 + 1                                               # the host counted it ...
-    with pytest.raises(ops.CoopTimeout):
-        ops.coop_check()
-    ops.coop_fall_back()
-    try:
-        m.variables.rewind_step()                                                           # ... and takes it back
-        assert ops.coop_disabled() and ops.coop_split(B) == 0 and ops.coop_split(B, backward=True) == 0
-        assert ops.coop_fallbacks() == 1
-        for _ in range(2):                                                                  # steps 2 (again) and 3
-            m.feed(**feed)
-            m.train_op
-            assert m.step_guard.cpu().tolist() == [0.0, 0.0]
+        m.train_op                              # step 2: the forward launch of layer 0 gives up after 2 s; every launch
+        guard = m.step_guard.cpu().numpy()      # behind it leaves at once (sticky status word)
+        assert guard[1] == 1.0
+        assert torch.equal(m.variables.flat, v1) and torch.equal(m.variables.adam_m, m1)       # untouched
+        assert m.variables.global_step == s1 + 1                                               # the host counted it ...
+        with pytest.raises(ops.CoopTimeout):
+            ops.coop_check()
+        ops.coop_fall_back()
+        m.variables.rewind_step()                                                              # ... and takes it back
+        assert ops.coop_level() == 1 and ops.coop_fallbacks() == 1 and not ops.coop_disabled()
+        assert ops.coop_split(B) == 8 and ops.coop_split(B, backward=True) == 8
+        m.feed(**feed)                                                                         # step 2 again
+        m.train_op
+        assert m.step_guard.cpu().tolist() == [0.0, 0.0]
+        assert not side.query()                                  # the neighbour was there all the time
+        ops.coop_fall_back()                                     # a second conflict would end here
+        assert ops.coop_level() == 2 and ops.coop_disabled() and ops.coop_split(B) == 0 and ops.coop_split(B, backward=True) == 0
+        m.feed(**feed)                                                                         # step 3
+        m.train_op
+        assert m.step_guard.cpu().tolist() == [0.0, 0.0]
         ops.coop_check()
         assert m.variables.global_step == 3
         got = m.variables.flat.clone()
     finally:
+        release.fill_(1)
+        torch.cuda.synchronize()
         ops.coop_fall_back_reset()
 
     monkeypatch.setenv('AVSI_REC_COOP', '0')
@@ -159,13 +165,14 @@ def test_a_cooperative_timeout_voids_the_step_and_the_fall_back_repeats_it(monke
 
 
 def test_trainer_recovers_from_a_cooperative_timeout(tmp_path, monkeypatch, capsys):
-    """training.train() end to end: during the third batch of the first epoch 240 CUs are parked for a few seconds.  The
-    run must go on (one fall-back, logged once), take exactly as many optimiser steps as there are batches, and end with
-    the variables of a run on the batch-stationary kernels, to rounding."""
+    """training.train() end to end: from the third batch of the first epoch on, 16 CUs are parked for 10 s.  The run must
+    go on (one fall-back, logged once), take exactly as many optimiser steps as there are batches, and end with the
+    variables of a run on the batch-stationary kernels, to rounding."""
     import avsi_amd  # noqa: F401
     from avsi_amd import ops, training
     from test_drivers_gpu import _make_dataset
-    for name in ('AVSI_REC_COOP', 'AVSI_COOP_CUS', 'AVSI_COOP_SPLIT_FWD', 'AVSI_COOP_SPLIT_BWD'):
+    for name in ('AVSI_REC_COOP', 'AVSI_COOP_CUS', 'AVSI_COOP_SPLIT_FWD', 'AVSI_COOP_SPLIT_BWD', 'AVSI_COOP_TIMEOUT_MS',
+                 'AVSI_TRAIN_STREAM'):
         monkeypatch.delenv(name, raising=False)
     ops.coop_fall_back_reset()
     ops.set_coop_cu_budget(None)
@@ -192,14 +199,15 @@ def test_trainer_recovers_from_a_cooperative_timeout(tmp_path, monkeypatch, caps
     def parking(*a, **kw):
         calls['n'] += 1
         if calls['n'] == 3:
-            calls['parked'] = _park(240, 12000)          # leaves by itself after 12 s
+            # the trainer launches on a high-priority stream: the neighbour sits on a normal one; it leaves by itself
+            calls['parked'] = _park(16, 10000, priority=0)
         return plain(*a, **kw)
     monkeypatch.setattr(training, 'unpack_batch', parking)
     try:
         model = training.train(config("guarded"))
         text = capsys.readouterr()
-        assert model.coop_fallbacks == 1 and ops.coop_fallbacks() == 1
-        assert text.err.count('falling back to the batch-stationary recurrent kernels') == 1
+        assert model.coop_fallbacks == 1 and ops.coop_fallbacks() == 1 and ops.coop_level() == 1
+        assert text.err.count('falling back to the cooperative kernels that tolerate neighbours') == 1
         assert model.global_step == 10                    # 5 batches x 2 epochs: no step lost, none counted twice
         assert '+---- Done training: epoch limit reached ----+' in text.out
         got = model.variables.flat.clone()
@@ -212,5 +220,5 @@ def test_trainer_recovers_from_a_cooperative_timeout(tmp_path, monkeypatch, caps
     monkeypatch.setenv('AVSI_REC_COOP', '0')
     ref = training.train(config("stationary"))
     assert ref.coop_fallbacks == 0 and ref.global_step == 10
-    # same batches in the same order (AVSI_SHUFFLE_SEED): the two runs differ by the kernels of the first two steps only
+    # same batches in the same order (AVSI_SHUFFLE_SEED): the two runs differ by the kernels they ran on only
     assert (got - ref.variables.flat).abs().max().item() < 1e-4
