@@ -94,6 +94,7 @@ class _WavWriter(object):
             slot[1].zero_()
             for i, st in enumerate(status[:2]):
                 slot[1][i:i + 1].copy_(st.reshape(-1)[:1], non_blocking=True)
+                st.record_stream(self.stream)      # a copy taken on the launch stream: its block must outlive this read
             slot[2].record(self.stream)
         wavs.record_stream(self.stream)
         paths = [os.path.join(self.audio_path, d.decode(), 'enhanced', self.prefix + '.wav').encode() for d in sample_dirs]

@@ -34,11 +34,21 @@ def run(rank, world, steps, B_global=4, N=2880):
     sl = slice(rank * per, (rank + 1) * per)
     m = models.StackedBLSTMModel(np.full(per, T), wav[sl], masks[sl], mean, std, 0.0, config(wav.shape[1], per),
                                  video_features=video[sl], input='av', seed=7)
+    from avsi_amd import ops
     losses = []
     for _ in range(steps):
-        m.feed(sequence_lengths=np.full(per, T), target_sources=wav[sl], masks=masks[sl], video_features=video[sl])
-        losses.append(float(m.loss_func))
-        m.train_op
+        while True:
+            m.feed(sequence_lengths=np.full(per, T), target_sources=wav[sl], masks=masks[sl], video_features=video[sl])
+            loss = float(m.loss_func)
+            m.train_op
+            # what training.train does with the step guard: ranks that share ONE GPU can starve each other's 32-way
+            # cooperative groups (every rank wants all of XCD 0 and 1; the bounded waits resolve the stand-off after 2 s).
+            # The guard words are summed over the ranks, so every rank repeats the void step together.
+            if float(m.step_guard[1]) == 0.0:
+                break
+            ops.coop_fall_back()
+            m.variables.rewind_step()
+        losses.append(loss)
     return m.variables.flat.cpu().numpy(), losses
 
 

@@ -63,10 +63,11 @@ def test_two_ranks_at_config_4_shape_equal_one_process(tmp_path):
     np.testing.assert_allclose((l0 + l1) / 2, ref_losses, rtol=2e-4)
 
 
-@pytest.mark.parametrize("ranks,N", [(4, 48000), (6, 9600)])
-def test_four_and_six_ranks_at_32_per_rank_equal_one_process(tmp_path, ranks, N):
-    """configs[3]'s per-GPU share (32 utterances, AV model) at world 4 (3 s clips, T = 250) and world 6 (T = 50) -- the
-    most processes this box allows on its one GPU; world 8 is rehearsed on the CPU (tests/test_parallel_gloo.py).  Every
+@pytest.mark.parametrize("ranks,N", [(4, 48000), (3, 9600)])
+def test_four_and_three_ranks_at_32_per_rank_equal_one_process(tmp_path, ranks, N):
+    """configs[3]'s per-GPU share (32 utterances, AV model) at world 4 (3 s clips, T = 250; with this process and the
+    launcher the most the box allows on its one GPU) and at an odd world of 3 (T = 50); world 8 is rehearsed on the CPU
+    (tests/test_parallel_gloo.py).  Every
     rank holds the same bits after two Adam steps, equal to one process at 32 x ranks utterances up to summation order.
     Each rank sizes its cooperative launches for its share of the chip (AVSI_COOP_CUS = 256 // ranks)."""
     G = 32 * ranks

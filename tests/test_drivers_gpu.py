@@ -315,16 +315,16 @@ def _rank_lines(stdout, ranks):
     return found
 
 
-@pytest.mark.parametrize("ranks,batch_size,steps", [(2, 4, 2), (4, 2, 2), (6, 1, 4)])
+@pytest.mark.parametrize("ranks,batch_size,steps", [(2, 4, 2), (4, 2, 2), (3, 1, 8)])
 def test_data_parallel_training_through_the_driver(experiment, tmp_path, ranks, batch_size, steps):
-    """train() under torch.distributed.run with 2, 4 and 6 ranks (sharing this box's GPU: gloo process group; the box
-    allows at most 6 processes on its card, so world 8 itself is rehearsed on the CPU: tests/test_parallel_gloo.py,
-    test_tfrecord_io.py::test_even_rounds_with_eight_readers): batches are dealt in whole rounds, every rank takes the
+    """train() under torch.distributed.run with 2, 4 and 3 ranks (sharing this box's GPU: gloo process group; the box
+    allows at most 6 processes on its card -- this one, the launcher and 4 ranks -- so world 8 itself is rehearsed on the
+    CPU: tests/test_parallel_gloo.py, test_tfrecord_io.py::test_even_rounds_with_eight_readers): batches are dealt in whole rounds, every rank takes the
     same number of steps, gradients are all-reduced inside train_op, every rank ends with the same bits, rank 0 alone
     writes the log and the checkpoints.
     12 training samples: 2 ranks x batches of 4 = 3 batches = one whole round + one left over (dropped): one step per
-    epoch; 4 ranks x batches of 2 = 6 batches = one round + two left over: one step per epoch; 6 ranks x batches of 1 =
-    two rounds: two steps per epoch -- and the 4 validation samples leave ranks 4 and 5 without a validation batch."""
+    epoch; 4 ranks x batches of 2 = 6 batches = one round + two left over: one step per epoch -- and the 2 validation
+    batches leave ranks 2 and 3 without one; 3 ranks x batches of 1 = four rounds: four steps per epoch."""
     base, data, cfg0 = experiment
     exp = tmp_path / "logs" / "dp_exp"
     text = open(cfg0).read().replace("exp_folder = %s" % (base / "logs" / "av_exp0"), "exp_folder = %s" % exp)
