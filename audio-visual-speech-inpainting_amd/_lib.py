@@ -49,6 +49,7 @@ class IstftArgs(Structure):
         ("batch", c_int32), ("num_frames", c_int32), ("num_bins", c_int32), ("frame_len", c_int32),
         ("hop", c_int32), ("nfft", c_int32),
         ("table", c_void_p), ("out", c_void_p), ("out_stride_b", c_int64), ("num_samples", c_int64),
+        ("wav", c_void_p), ("wav_stride_b", c_int64), ("wav_samples", c_int64),
     ]
 
 

@@ -203,11 +203,11 @@ def enclosing_power_of_two(n):
 
 
 def _istft(mode, in0, in1, in2, mean, std, B, T, F, num_samples, sample_rate, window_size, step_size,
-           in_strides, in1_strides=(0, 0), in2_strides=(0, 0), nfft=None):
+           in_strides, in1_strides=(0, 0), in2_strides=(0, 0), nfft=None, wav=None):
     """``nfft=None`` follows TF 1.x: fft length = enclosing power of two of the frame length (the reference never
     passes one, audio_processing.py:149-151), and irfft crops / zero-pads the bin axis to nfft / 2 + 1 -- the
     kernel reads ``min(F, nfft / 2 + 1)`` bins of each row and treats the rest of the grid as zero."""
-    _lib.require_cuda(in0, in1, in2, mean, std)
+    _lib.require_cuda(in0, in1, in2, mean, std, wav)
     frame_len = ms_to_samples(window_size, sample_rate)
     hop = ms_to_samples(step_size, sample_rate)
     if nfft is None:
@@ -230,6 +230,8 @@ def _istft(mode, in0, in1, in2, mean, std, B, T, F, num_samples, sample_rate, wi
     tab = _istft_tables(dev, frame_len, hop, nfft)
     a.table = _lib.ptr(tab)
     a.out, a.out_stride_b, a.num_samples = _lib.ptr(out), out.stride(0), n_out
+    if wav is not None:
+        a.wav, a.wav_stride_b, a.wav_samples = _lib.ptr(wav), wav.stride(0), wav.shape[1]
     _lib.check(_lib.lib().avsi_istft_f32(ctypes.byref(a), _lib.stream_ptr()), "avsi_istft_f32")
     return out
 
@@ -265,6 +267,23 @@ def enhanced_from_prediction(prediction, mean, std, target_stft, masks=None, num
     return _istft(2, pred, st, m, None if mean is None else mean.contiguous(), None if std is None else std.contiguous(),
                   B, T, F, num_samples, sample_rate, window_size, step_size, (pred.stride(0), pred.stride(1)),
                   (st.stride(0), st.stride(1)), (0, 0) if m is None else (m.stride(0), m.stride(1)), nfft=n_fft)
+
+
+def enhanced_from_prediction_wav(prediction, mean, std, target_sources, masks=None, num_samples=48000, sample_rate=16000,
+                                 window_size=24, step_size=12, n_fft=512):
+    """enhanced_from_prediction with the target WAVEFORM [B, n] in place of its STFT (avsi_istft_f32 mode 3): the frames
+    of every tile are transformed forward inside the kernel -- get_stft's framing and window, audio_processing.py:25-42 --
+    and only their phase is used, so the complex spectrogram (514 kB per utterance written by the front end, then read
+    here) never exists.  Same result as enhanced_from_prediction(prediction, mean, std, get_stft(target_sources), masks)."""
+    pred = prediction.contiguous()
+    wav = target_sources.to(torch.float32)
+    if wav.dim() != 2 or wav.stride(1) != 1:
+        wav = wav.contiguous()
+    B, T, F = pred.shape
+    m = None if masks is None else masks.to(torch.float32).contiguous()
+    return _istft(3, pred, None, m, None if mean is None else mean.contiguous(), None if std is None else std.contiguous(),
+                  B, T, F, num_samples, sample_rate, window_size, step_size, (pred.stride(0), pred.stride(1)),
+                  (0, 0), (0, 0) if m is None else (m.stride(0), m.stride(1)), nfft=n_fft, wav=wav)
 
 
 # ---------------------------------------------------------------------------- per-op API (reference names)

@@ -8,6 +8,9 @@
 //     X   = mag (cos phi + j sin phi)                                  (audio_processing.py:160-164)
 // cos/sin(angle(S)) are Re S / |S| and Im S / |S| (angle(0) = 0 => X = mag), so no atan2 / sincos
 // is evaluated.  The generic modes take a complex spectrogram or (magnitude, phase) planes.
+// Mode 3 is mode 2 WITHOUT the complex target spectrogram: the tile's 16 frames of the target WAVEFORM (13 KB instead
+// of 33 KB of complex bins, which the front end would have had to write first) are transformed forward in the kernel --
+// the front end's own 16 x 16 FFT and arithmetic (frontend.hip) -- and only their phase is used.
 //
 // Tile = 15 output hops of one utterance: the workgroup inverse-transforms the 16 frames that touch
 // them (one halo frame) with the same 16 x 16 in-register FFT as the front end
@@ -29,7 +32,8 @@ constexpr int XS = 258;  // complex per frame in the X tile
 constexpr int TAB_WIN = 0;  // synthesis window [512] (zero past frame_len)
 constexpr int TAB_TW256 = 512;
 constexpr int TAB_TW512 = 1024;
-constexpr int TAB_FLOATS = 512 + 512 + 2 * 257 + 2;
+constexpr int TAB_AWIN = 512 + 512 + 2 * 257 + 2;      // analysis window [512] (periodic Hann, zero past frame_len): mode 3
+constexpr int TAB_FLOATS = TAB_AWIN + 512;
 
 __global__ void istft_tables_kernel(float* tab, int frame_len, int hop) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -45,6 +49,7 @@ __global__ void istft_tables_kernel(float* tab, int frame_len, int hop) {
             v = (float)((0.5 - 0.5 * cospi(2.0 * i / frame_len)) / den);
         }
         tab[TAB_WIN + i] = v;
+        tab[TAB_AWIN + i] = i < frame_len ? (float)(0.5 - 0.5 * cospi(2.0 * i / frame_len)) : 0.f;     // frontend.hip's window
     }
     if (i < 256) {
         tab[TAB_TW256 + 2 * i] = (float)cospi(2.0 * i / 256.0);
@@ -70,12 +75,15 @@ __global__ __launch_bounds__(TPB) void istft_kernel(const avsi_istft_args a, con
     cf* s_z = s_x;                                                     // [FR][ZSTRIDE] FFT scratch (aliases s_x)
     float* s_f = reinterpret_cast<float*>(s_x + FR * ZSTRIDE);         // [FR][fs]   windowed frames
     __shared__ float2 s_tw[16][16];                                    // per-lane twiddles of the 16 x 16 FFT: [k2][lane]
+    __shared__ float2 s_awin[MODE == 3 ? 16 : 1][16];                  // mode 3: analysis window [n2][lane] (samples 2 ln + 32 n2 ..)
+    float* s_wav = s_f;                                                // mode 3: the tile's samples (dead before s_f is written)
 
     const int tid = threadIdx.x, f = tid >> 4, ln = tid & 15;
     const int S = a.hop, L = a.frame_len, T = a.num_frames, F = a.num_bins;
     const int fs = (L + 3) & ~3;                                       // pitch of a windowed frame in LDS
     const float* __restrict__ tab = a.table;
     s_tw[tid >> 4][tid & 15] = *reinterpret_cast<const float2*>(tab + TAB_TW256 + 2 * (((tid & 15) * (tid >> 4)) & 255));
+    if (MODE == 3) s_awin[tid >> 4][tid & 15] = *reinterpret_cast<const float2*>(tab + TAB_AWIN + 2 * (tid & 15) + 32 * (tid >> 4));
     const bool have_norm = a.mean != nullptr;
 
     // one spectrum element from the raw loaded values (r0 .. r3 as loaded by `fetch` below)
@@ -121,8 +129,10 @@ __global__ __launch_bounds__(TPB) void istft_kernel(const avsi_istft_args a, con
             r0 = a.in0[o + k], r1 = a.in1[o + k];
         } else {
             r0 = a.in0[o + k];
-            const int64_t os = (int64_t)b * a.in1_stride_b + (int64_t)t * a.in1_stride_t;
-            r1 = a.in1[os + 2 * k], r2 = a.in1[os + 2 * k + 1];
+            if (MODE == 2) {
+                const int64_t os = (int64_t)b * a.in1_stride_b + (int64_t)t * a.in1_stride_t;
+                r1 = a.in1[os + 2 * k], r2 = a.in1[os + 2 * k + 1];
+            }
             if (HAS_MASK) r3 = a.in2[(int64_t)b * a.in2_stride_b + (int64_t)t * a.in2_stride_t + k];
         }
     };
@@ -142,6 +152,31 @@ __global__ __launch_bounds__(TPB) void istft_kernel(const avsi_istft_args a, con
             const bool kok = (kk % step == 0) && k < F;
             const float mean_k = (have_norm && kok) ? a.mean[k] : 0.f, std_k = (have_norm && kok) ? a.stdev[k] : 1.f;
             float r0[FR], r1[FR], r2[FR], r3[FR];
+            if (MODE == 3) {
+                // ---- 1a. the 16 frames' samples [t0 S, t0 S + 15 S + L) -> LDS, zero outside [0, wav_samples)
+                const int seg = (FR - 1) * S + L;
+                const int64_t s0 = (int64_t)t0 * S, NW = a.wav_samples;
+                const float* src = a.wav + (int64_t)b * a.wav_stride_b;
+                // whole 16-byte groups lie inside or outside the signal (wave-uniform test)
+                const bool vec = ((reinterpret_cast<uintptr_t>(src) & 15) == 0) && ((S & 3) == 0) && ((NW & 3) == 0) && ((seg & 3) == 0);
+                // (32 zeros behind the segment: the last column group of a frame whose length is no multiple of 32 reads them
+                //  under zero window taps, and stale LDS could hold a NaN)
+                if (vec) {
+                    for (int i = 4 * tid; i < seg + 32; i += 4 * TPB) {
+                        const int64_t n = s0 + i;
+                        const bool ok = n >= 0 && n + 3 < NW && i < seg;
+                        const float4 v4 = *reinterpret_cast<const float4*>(src + (ok ? n : 0));
+                        *reinterpret_cast<float4*>(s_wav + i) = ok ? v4 : make_float4(0.f, 0.f, 0.f, 0.f);
+                    }
+                } else {
+                    for (int i = tid; i < seg + 32; i += TPB) {
+                        const int64_t n = s0 + i;
+                        const bool ok = n >= 0 && n < NW && i < seg;
+                        const float x = src[ok ? n : 0];
+                        s_wav[i] = ok ? x : 0.f;
+                    }
+                }
+            }
 #pragma unroll
             for (int ff = 0; ff < FR; ++ff) {
                 // BRANCH-FREE: a load inside a per-lane `if` is closed by the compiler with s_waitcnt vmcnt(0) -- the 16
@@ -152,19 +187,69 @@ __global__ __launch_bounds__(TPB) void istft_kernel(const avsi_istft_args a, con
                 r0[ff] = r1[ff] = r2[ff] = 0.f, r3[ff] = 1.f;
                 fetch(b, ok ? t : 0, ok ? k : 0, r0[ff], r1[ff], r2[ff], r3[ff]);
             }
+            float q0 = 0.f, q1 = 0.f, q2 = 0.f, q3 = 1.f;     // the Nyquist column: one frame per thread (tid < FR)
+            const int tn = t0 + (tid & (FR - 1)), kn = 256 / step;
+            const bool nok = tid < FR && (256 % step == 0) && kn < F && tn >= 0 && tn < T;
+            if (tid < FR) fetch(b, nok ? tn : 0, nok ? kn : 0, q0, q1, q2, q3);
+            if (MODE == 3) {
+                // ---- 1b. forward transform of the 16 frames (frontend.hip steps 2 - 4: window, 16 x 16 FFT of
+                //          z[n] = x[2n] + j x[2n+1], natural-order Z with Z[256] := Z[0]); one frame per 16-lane group
+                __syncthreads();
+                cf v[16];
+                {
+                    const float* fr = s_wav + f * S + 2 * ln;
+#pragma unroll
+                    for (int n2 = 0; n2 < 16; ++n2) {
+                        if (32 * n2 < L) {        // wave-uniform
+                            const float2 x = *reinterpret_cast<const float2*>(fr + 32 * n2);
+                            const float2 wn = s_awin[n2][ln];
+                            v[n2] = {x.x * wn.x, x.y * wn.y};
+                        } else {
+                            v[n2] = {0.f, 0.f};
+                        }
+                    }
+                }
+                fft16(v);
+                cf* zf = s_z + f * ZSTRIDE;
+                zf[ln] = v[pos16(0)];
+#pragma unroll
+                for (int k2 = 1; k2 < 16; ++k2) {
+                    const float2 w = s_tw[k2][ln];
+                    zf[k2 * 17 + ln] = cmul(v[pos16(k2)], cf{w.x, w.y});
+                }
+                asm volatile("" ::: "memory");      // a frame lives in one wave: its LDS accesses execute in order
+#pragma unroll
+                for (int n1 = 0; n1 < 16; ++n1) v[n1] = zf[ln * 17 + n1];
+                asm volatile("" ::: "memory");
+                fft16(v);
+#pragma unroll
+                for (int k1 = 0; k1 < 16; ++k1) zf[16 * k1 + ln] = v[pos16(k1)];
+                if (ln == 0) zf[256] = v[pos16(0)];
+                __syncthreads();
+                // ---- 1c. thread <-> bin: S[k] = E[k] + W512^k O[k] from Z[k] and Z[256 - k] (frontend.hip step 5)
+                const float2 wk = *reinterpret_cast<const float2*>(tab + TAB_TW512 + 2 * kk);
+#pragma unroll
+                for (int ff = 0; ff < FR; ++ff) {
+                    const cf zk = s_z[ff * ZSTRIDE + kk], zm = s_z[ff * ZSTRIDE + 256 - kk];
+                    const cf e{0.5f * (zk.r + zm.r), 0.5f * (zk.i - zm.i)};
+                    const cf o{0.5f * (zk.i + zm.i), -0.5f * (zk.r - zm.r)};
+                    r1[ff] = e.r + (o.r * wk.x - o.i * wk.y);
+                    r2[ff] = e.i + (o.r * wk.y + o.i * wk.x);
+                }
+                if (tid < FR) {     // S[256] = Re Z[0] - Im Z[0], real
+                    const cf z0 = s_z[tid * ZSTRIDE];
+                    q1 = z0.r - z0.i, q2 = 0.f;
+                }
+                __syncthreads();    // every Z has been read: the storage becomes the spectrum tile
+            }
 #pragma unroll
             for (int ff = 0; ff < FR; ++ff) {
                 const int t = t0 + ff;
                 s_x[ff * XS + kk] = (kok && t >= 0 && t < T) ? make_x(kk, r0[ff], r1[ff], r2[ff], r3[ff], mean_k, std_k) : cf{0.f, 0.f};
             }
-            if (tid < FR) {     // the Nyquist column: one frame per thread
-                const int t = t0 + tid, kn = 256 / step;
-                const bool ok = (256 % step == 0) && kn < F && t >= 0 && t < T;
-                float q0 = 0.f, q1 = 0.f, q2 = 0.f, q3 = 1.f;
-                fetch(b, ok ? t : 0, ok ? kn : 0, q0, q1, q2, q3);
-                s_x[tid * XS + 256] = ok ? make_x(256, q0, q1, q2, q3, have_norm ? a.mean[kn] : 0.f, have_norm ? a.stdev[kn] : 1.f)
-                                         : cf{0.f, 0.f};
-            }
+            if (tid < FR)
+                s_x[tid * XS + 256] = nok ? make_x(256, q0, q1, q2, q3, have_norm ? a.mean[kn] : 0.f, have_norm ? a.stdev[kn] : 1.f)
+                                          : cf{0.f, 0.f};
         }
         __syncthreads();
 
@@ -254,7 +339,8 @@ extern "C" int avsi_istft_f32(const avsi_istft_args* args, void* stream) {
     const avsi_istft_args& a = *args;
     if (!a.in0 || !a.out || !a.table || a.batch <= 0 || a.num_frames <= 0 || a.num_samples <= 0)
         return AVSI_ERR_INVALID_ARG;
-    if (a.mode < 0 || a.mode > 2 || (a.mode >= 1 && !a.in1)) return AVSI_ERR_INVALID_ARG;
+    if (a.mode < 0 || a.mode > 3 || ((a.mode == 1 || a.mode == 2) && !a.in1)) return AVSI_ERR_INVALID_ARG;
+    if (a.mode == 3 && (!a.wav || a.wav_samples <= 0)) return AVSI_ERR_INVALID_ARG;
     if ((a.mean == nullptr) != (a.stdev == nullptr)) return AVSI_ERR_INVALID_ARG;
     if ((a.nfft != 512 && a.nfft != 256) || a.frame_len <= 0 || a.frame_len > a.nfft || (a.frame_len & 1) ||
         a.hop <= 0 || a.hop > a.frame_len || a.frame_len > 2 * a.hop)
@@ -267,7 +353,10 @@ extern "C" int avsi_istft_f32(const avsi_istft_args* args, void* stream) {
     const int tiles_per_utt = (int)avsi_ceil_div(n_hops, FR - 1);
     const int64_t n_tiles64 = (int64_t)a.batch * tiles_per_utt;
     if (n_tiles64 > INT32_MAX) return AVSI_ERR_UNSUPPORTED;
-    const size_t lds = (size_t)FR * ZSTRIDE * 8 + (size_t)FR * ((a.frame_len + 3) & ~3) * 4;     // ZSTRIDE >= XS: shared storage
+    size_t lds_f = (size_t)FR * ((a.frame_len + 3) & ~3) * 4;
+    if (a.mode == 3 && lds_f < (size_t)((FR - 1) * a.hop + a.frame_len + 32) * 4)      // the samples of a tile share the frames' storage
+        lds_f = (size_t)((FR - 1) * a.hop + a.frame_len + 32) * 4;
+    const size_t lds = (size_t)FR * ZSTRIDE * 8 + lds_f;     // ZSTRIDE >= XS: shared storage
     const int n_tiles = (int)n_tiles64;
     const int grid = n_tiles < AVSI_NUM_CU * 2 ? n_tiles : AVSI_NUM_CU * 2;
     avsi_clear_error();
@@ -279,8 +368,10 @@ extern "C" int avsi_istft_f32(const avsi_istft_args* args, void* stream) {
     } while (0)
     if (a.mode == 0) AVSI_ISTFT_LAUNCH(0, false);
     else if (a.mode == 1) AVSI_ISTFT_LAUNCH(1, false);
-    else if (a.in2) AVSI_ISTFT_LAUNCH(2, true);
-    else AVSI_ISTFT_LAUNCH(2, false);
+    else if (a.mode == 2 && a.in2) AVSI_ISTFT_LAUNCH(2, true);
+    else if (a.mode == 2) AVSI_ISTFT_LAUNCH(2, false);
+    else if (a.in2) AVSI_ISTFT_LAUNCH(3, true);
+    else AVSI_ISTFT_LAUNCH(3, false);
 #undef AVSI_ISTFT_LAUNCH
     return avsi_launch_status();
 }

@@ -517,8 +517,14 @@ class StackedBLSTMModel(object):
         if key not in c:
             pred = self.prediction
             masks = None if oracle_phase else self.masks[:, :pred.shape[1]]
-            c[key] = ap.enhanced_from_prediction(pred, self.audio_feat_mean, self.audio_feat_std, self.target_stft,
-                                                 masks, num_samples=self.audio_len)
+            if 'target_stft' in c or os.environ.get('AVSI_ISTFT_FROM_WAV', '1') == '0':
+                c[key] = ap.enhanced_from_prediction(pred, self.audio_feat_mean, self.audio_feat_std, self.target_stft,
+                                                     masks, num_samples=self.audio_len)
+            else:
+                # the phase of the target comes from its WAVEFORM, transformed tile by tile inside the inverse-STFT kernel:
+                # the complex spectrogram is neither written by the front end nor read here
+                c[key] = ap.enhanced_from_prediction_wav(pred, self.audio_feat_mean, self.audio_feat_std, self.target_sources,
+                                                         masks, num_samples=self.audio_len)
         return c[key]
 
     @property

@@ -599,9 +599,15 @@ class UNetFConvModel(object):
         if key not in c:
             # the reference calls get_sources with its 24 / 12 ms defaults here (App. B9); the STFT geometry of
             # this model (16 / 8 ms, n_fft 256) is used instead
-            c[key] = ap.enhanced_from_prediction(self.prediction, self.audio_feat_mean, self.audio_feat_std,
-                                                 self.target_stft, None if oracle_phase else self._cache['mask_t'],
-                                                 num_samples=self.audio_len, window_size=16, step_size=8, n_fft=256)
+            mask = None if oracle_phase else self._cache['mask_t']
+            if 'target_stft' in c or os.environ.get('AVSI_ISTFT_FROM_WAV', '1') == '0':
+                c[key] = ap.enhanced_from_prediction(self.prediction, self.audio_feat_mean, self.audio_feat_std,
+                                                     self.target_stft, mask, num_samples=self.audio_len, window_size=16,
+                                                     step_size=8, n_fft=256)
+            else:       # phase from the target waveform inside the kernel (see StackedBLSTMModel._enhanced)
+                c[key] = ap.enhanced_from_prediction_wav(self.prediction, self.audio_feat_mean, self.audio_feat_std,
+                                                         self.target_sources, mask, num_samples=self.audio_len,
+                                                         window_size=16, step_size=8, n_fft=256)
         return c[key]
 
     @property

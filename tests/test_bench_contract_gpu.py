@@ -102,7 +102,10 @@ def test_multi_rank_launch_as_the_driver_does(mode, ranks):
         # the global batch up to summation order (gloo here; the driver's multi-GPU run is the same code over RCCL)
         dp = d["dp_train"]
         assert "error" not in dp, dp
-        assert dp["rccl_ranks"] == ranks and dp["backend"] == "gloo" and dp["coop_fallbacks"] == 0
+        assert dp["rccl_ranks"] == ranks and dp["backend"] == "gloo"
+        # ranks that share ONE GPU can starve each other's 32-way cooperative groups (each wants XCD 0 and 1 to itself): the
+        # bench then falls back like the trainer does and still delivers every number
+        assert dp["coop_fallbacks"] in (0, 1, 2)
         c = dp["check"]
         assert c["ranks_bit_identical"] is True and c["global_batch"] == 32 * ranks and c["frames"] == 250
         assert c["max_abs_diff_vs_single_process"] < 2e-5 < 1e-3 < c["max_abs_update"] and c["ok"] is True

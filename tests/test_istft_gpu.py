@@ -88,3 +88,86 @@ def test_fft_length_follows_the_frame_length_not_the_bin_count(ap, bins, ws, ss)
     got = got.cpu().numpy()
     assert got.shape == ref.shape
     assert np.abs(got - ref).max() < 1e-5 * np.abs(ref).max() + 1e-4
+
+
+@pytest.mark.parametrize("oracle_phase", [False, True])
+@pytest.mark.parametrize("B,N,ws,ss,nfft,F", [(2, 9600, 24, 12, 512, 257), (3, 48000, 24, 12, 512, 257), (2, 192 * 31 + 7, 24, 12, 512, 257),
+                                              (2, 16384, 16, 8, 256, 128), (1, 5001, 16, 8, 256, 129)])
+def test_enhanced_sources_from_the_waveform_matches_oracle(ap, oracle_phase, B, N, ws, ss, nfft, F):
+    """avsi_istft_f32 mode 3 (models.py:181-197 with the target STFT computed inside the kernel, tile by tile, from the
+    target waveform): against the float64 oracle, and against the two-kernel path (front end writes the complex STFT,
+    mode 2 reads it) -- same arithmetic, so the two agree far inside the oracle tolerance.  One utterance carries a silent
+    stretch: STFT bins that are exactly zero take tf.angle(0) = 0."""
+    hop = 16 * ss
+    T = -(-N // hop)
+    wav = _wav(B, N, 4)
+    wav[0, 2000:4000] = 0.0
+    rng = np.random.default_rng(5)
+    masks = np.ones((B, T, F), dtype=np.float32)
+    masks[:, T // 3: T // 3 + 9] = 0
+    mean = rng.normal(6, 1, F).astype(np.float32)
+    std = rng.uniform(1, 2, F).astype(np.float32)
+    pred = rng.normal(0, 0.5, size=(B, T, F)).astype(np.float32)
+    X = OF.get_stft(wav, window_size=ws, step_size=ss, n_fft=nfft)[:, :, :F]
+    ref = OB.enhanced_sources(pred.astype(np.float64), mean, std, X, None if oracle_phase else masks, num_samples=N,
+                              window_size=ws, step_size=ss) if nfft == 512 else None
+    tw, tm = torch.from_numpy(wav).cuda(), None if oracle_phase else torch.from_numpy(masks).cuda()
+    tp, tmean, tstd = torch.from_numpy(pred).cuda(), torch.from_numpy(mean).cuda(), torch.from_numpy(std).cuda()
+    got = ap.enhanced_from_prediction_wav(tp, tmean, tstd, tw, tm, num_samples=N, window_size=ws, step_size=ss, n_fft=nfft)
+    st = ap.frontend(tw, window_size=ws, step_size=ss, n_fft=nfft, num_frames_out=T, num_bins=F, want_stft=True)['stft']
+    two = ap.enhanced_from_prediction(tp, tmean, tstd, st, tm, num_samples=N, window_size=ws, step_size=ss, n_fft=nfft)
+    assert got.shape == two.shape == (B, N)
+    scale = two.abs().max().item()
+    assert (got - two).abs().max().item() < 2e-5 * scale
+    if ref is not None:
+        g = got.cpu().numpy()
+        assert np.sqrt(np.mean((g - ref) ** 2)) < 1e-4 * np.abs(ref).max()
+        assert np.abs(g - ref).max() < 1e-3 * np.abs(ref).max()
+
+
+def test_enhanced_sources_from_an_unaligned_waveform_view(ap):
+    """Rows that do not start on 16 bytes and a length that is no multiple of four take the kernel's element-wise loads."""
+    B, N, T = 2, 9601, 51
+    base = torch.from_numpy(_wav(B, N + 3, 8)).cuda()
+    wav = base[:, 1:N + 1]                       # a view: row pitch N + 3, first sample 4 bytes into the row
+    rng = np.random.default_rng(9)
+    masks = torch.ones(B, T, 257, device='cuda')
+    masks[:, 10:20] = 0
+    pred = torch.from_numpy(rng.normal(0, 0.5, size=(B, T, 257)).astype(np.float32)).cuda()
+    got = ap.enhanced_from_prediction_wav(pred, None, None, wav, masks, num_samples=N)
+    st = ap.frontend(wav.contiguous(), window_size=24, step_size=12, n_fft=512, num_frames_out=T, num_bins=257, want_stft=True)['stft']
+    two = ap.enhanced_from_prediction(pred, None, None, st, masks, num_samples=N)
+    assert (got - two).abs().max().item() < 2e-5 * two.abs().max().item()
+
+
+def test_model_enhanced_sources_never_asks_for_the_complex_stft(ap, monkeypatch):
+    """StackedBLSTMModel.enhanced_sources / _oracle_phase (models.py:181-197) go through mode 3: no front-end launch with a
+    complex output, same waveform as the two-kernel path (AVSI_ISTFT_FROM_WAV=0)."""
+    import avsi_amd  # noqa: F401
+    from avsi_amd import models
+    B, N = 3, 9600
+    T = N // 192
+    wav = torch.from_numpy(_wav(B, N, 11)).cuda()
+    masks = torch.ones(B, T, 257, device='cuda')
+    masks[:, 12:20] = 0
+    cfg = dict(audio_feat_dim=257, video_feat_dim=136, audio_len=N, net_dim=[250, 250, 250], optimizer_type='adam',
+               starter_learning_rate=1e-3, lr_updating_steps=10000, lr_decay=1.0, batch_size=B, l2=0.0)
+    mean, std = torch.full((257,), 6.0, device='cuda'), torch.full((257,), 2.0, device='cuda')
+    m = models.StackedBLSTMModel(np.full(B, T), wav, masks, mean, std, 0.0, cfg, input='a', is_training=False, seed=2)
+    asked = []
+    plain = ap.frontend
+
+    def spy(*a, **kw):
+        asked.append(bool(kw.get('want_stft')))
+        return plain(*a, **kw)
+    monkeypatch.setattr(ap, 'frontend', spy)
+    monkeypatch.delenv('AVSI_ISTFT_FROM_WAV', raising=False)
+    a, b = m.enhanced_sources.clone(), m.enhanced_sources_oracle_phase.clone()
+    assert not any(asked)
+    monkeypatch.setenv('AVSI_ISTFT_FROM_WAV', '0')
+    m.feed(sequence_lengths=np.full(B, T), target_sources=wav, masks=masks)
+    a2, b2 = m.enhanced_sources, m.enhanced_sources_oracle_phase
+    assert any(asked)
+    for x, y in ((a, a2), (b, b2)):
+        assert (x - y).abs().max().item() < 2e-5 * y.abs().max().item()
+    assert (a - b).abs().max().item() > 1.0          # the masked and the oracle phase do differ inside the gap
