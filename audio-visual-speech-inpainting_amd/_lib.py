@@ -139,6 +139,7 @@ PROTOTYPES = {
     "avsi_diag_cs_stamps": (c_int, [c_void_p]),
     "avsi_stream_delay_us": (c_int, [c_int, c_void_p]),
     "avsi_diag_occupy_cus": (c_int, [c_int, c_void_p, c_int, c_void_p]),
+    "avsi_diag_copy_f32": (c_int, [c_void_p, c_void_p, c_int64, c_void_p]),
     "avsi_conv2d_f32": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_int,
                                 c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p]),
     "avsi_conv2d_splitk_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int]),

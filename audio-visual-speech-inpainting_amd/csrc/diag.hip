@@ -22,7 +22,29 @@ __global__ __launch_bounds__(64) void stream_delay_kernel(long long ticks) {
     while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(32);
 }
 
+// Streaming copy, the yardstick of the HBM-bound kernels: 16 bytes per lane and access, four accesses in flight per lane,
+// a grid sized to the chip (8 workgroups of 256 per CU) walking the buffer with a grid stride.
+__global__ __launch_bounds__(256) void copy4_kernel(const float4* __restrict__ src, float4* __restrict__ dst, long long n4) {
+    const long long stride = (long long)gridDim.x * 256;
+    long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    for (; i + 3 * stride < n4; i += 4 * stride) {
+        const float4 a = src[i], b = src[i + stride], c = src[i + 2 * stride], d = src[i + 3 * stride];
+        dst[i] = a, dst[i + stride] = b, dst[i + 2 * stride] = c, dst[i + 3 * stride] = d;
+    }
+    for (; i < n4; i += stride) dst[i] = src[i];
+}
+
 }  // namespace
+
+// dst[0 .. n) = src[0 .. n) (n a multiple of 4, both 16-byte aligned): bench.py's `device_copy_GB/s`.
+extern "C" int avsi_diag_copy_f32(const float* src, float* dst, int64_t n, void* stream) {
+    if (!src || !dst || n <= 0 || (n & 3) || ((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(dst)) & 15))
+        return AVSI_ERR_INVALID_ARG;
+    avsi_clear_error();
+    hipLaunchKernelGGL(copy4_kernel, dim3(AVSI_NUM_CU * 8), dim3(256), 0, (hipStream_t)stream,
+                       reinterpret_cast<const float4*>(src), reinterpret_cast<float4*>(dst), (long long)(n >> 2));
+    return avsi_launch_status();
+}
 
 // Holds `stream` back for `microseconds` (<= 1000): one idle wave.  The trainer puts it in front of the weight-gradient
 // GEMMs of a side stream that become ready at the same instant as a cooperative recurrent kernel on the main stream:

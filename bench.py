@@ -41,16 +41,26 @@ FP32_MFMA_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, d
 HBM_PEAK_GBS = 8000.0
 
 
-def device_copy_rate(torch, device, mib=2048, reps=5):
-    """Read + write bytes per second of a plain tensor copy of `mib` MiB (torch's copy kernel): what a pure streaming
-    kernel reaches on this GPU, the practical ceiling for the HBM-bound kernels next to the 8 TB/s of the data sheet."""
+def device_copy_rate(torch, device, mib=2048, reps=5, kernel="float4"):
+    """Read + write bytes per second of a streaming copy of `mib` MiB: what a pure streaming kernel reaches on this GPU,
+    the practical ceiling for the HBM-bound kernels next to the 8 TB/s of the data sheet.  kernel = "float4": the C ABI's
+    avsi_diag_copy_f32 (16 bytes per lane, four accesses in flight, a grid sized to the chip -- the shape
+    MI355X_MICROARCH.md quotes 6.29 TB/s for); "torch": torch's own copy kernel (round 3's yardstick, ~20 % lower)."""
+    from avsi_amd import _lib
     src = torch.empty(mib << 18, dtype=torch.float32, device=device).normal_()
     dst = torch.empty_like(src)
-    dst.copy_(src)
+
+    def copy():
+        if kernel == "torch":
+            dst.copy_(src)
+        else:
+            _lib.check(_lib.lib().avsi_diag_copy_f32(_lib.ptr(src), _lib.ptr(dst), src.numel(), _lib.stream_ptr()),
+                       "avsi_diag_copy_f32")
+    copy()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(reps):
-        dst.copy_(src)
+        copy()
     e1.record()
     torch.cuda.synchronize(device)
     return 2.0 * src.numel() * 4 * reps / (e0.elapsed_time(e1) * 1e-3) / 1e9
@@ -504,7 +514,8 @@ def unet_setup(torch, models, ap_mod, B, seed, device, is_training=False):
 UNET_FLOPS_PER_CLIP = 0.52e9          # 2 k^2 Cin Cout H W over the 13 layers
 AV_FWD_FLOPS = 2.207e9                # forward, AV model (D = 393), per utterance
 AV_WGRAD_FLOPS = 2.0 * ((393 + 500 + 500) * 2000 * 250 + 6 * 250 * 1000 * 249 + 500 * 257 * 250)   # dWx + dWh + dW_proj
-ISTFT_BYTES = 250 * 257 * 4 * 2 + 250 * 257 * 8 + 48000 * 4     # prediction + mask + complex target STFT in, waveform out
+ISTFT_BYTES = 250 * 257 * 4 * 2 + 48000 * 4 + 48000 * 4          # prediction + mask + target waveform in, waveform out
+ISTFT_BYTES_FROM_STFT = 250 * 257 * 4 * 2 + 250 * 257 * 8 + 48000 * 4     # round 3's form: complex target STFT in instead
 
 
 def e2e_workloads(torch, device):
@@ -675,18 +686,43 @@ def extra_workloads(torch, models, ops, ap_mod, cfg, mean, std, device):
     guarded("unet_b512", unet(512, 10, 3))
     guarded("unet_b32", unet(32, 30, 5))
 
+    def unet_train(B, steps, warm):
+        def run():
+            m, _ = unet_setup(torch, models, ap_mod, B, 4321, device, is_training=True)
+            seq, wav, masks = m.sequence_lengths, m.target_sources, m.masks
+
+            def step():
+                m.feed(sequence_lengths=seq, target_sources=wav, masks=masks)
+                loss = m.loss_func
+                m.train_op
+                return loss
+            ms = time_steps(torch, step, steps, warm)
+            tf = 3.0 * UNET_FLOPS_PER_CLIP * B / (ms * 1e-3) / 1e12
+            return {"workload": "configs[4]: U-Net training step (front end + forward + backward + TF-Adam, models.py:688-702), "
+                                "%d clips per step" % B, "per_gpu_batch": B, "ms_per_step": ms, "value": B / ms * 1e3,
+                    "unit": "clips/s", "algorithmic_TFLOP/s": tf, "frac_of_fp32_mfma_peak": tf / FP32_MFMA_PEAK_TFLOPS,
+                    "algorithmic_flops_per_clip": 3.0 * UNET_FLOPS_PER_CLIP}
+        return run
+    guarded("unet_train_b512", unet_train(512, 6, 2))
+    guarded("unet_train_b32", unet_train(32, 20, 4))
+
     def istft_b4096():
         B = 4096
         wav, masks = synth_batch(torch, B, 555, device)
         fe = ap_mod.frontend(wav, want_spec=True, want_stft=True)
         pred, stft = fe['spec'], fe['stft']
         zero, one = torch.zeros(F_BINS, device=device), torch.ones(F_BINS, device=device)
-        ms = time_steps(torch, lambda: ap_mod.enhanced_from_prediction(pred, zero, one, stft, masks, num_samples=N_SAMPLES), 10, 3)
-        gbs = ISTFT_BYTES * B / (ms * 1e-3) / 1e9
-        return {"workload": "row f1: enhanced_sources (exp(pred std + mean), phase of the masked target STFT, inverse STFT, "
-                            "models.py:181-197), 4096 utterances", "per_gpu_batch": B, "ms_per_step": ms,
+        ms = time_steps(torch, lambda: ap_mod.enhanced_from_prediction_wav(pred, zero, one, wav, masks, num_samples=N_SAMPLES), 10, 3)
+        ms2 = time_steps(torch, lambda: ap_mod.enhanced_from_prediction(pred, zero, one, stft, masks, num_samples=N_SAMPLES), 10, 3)
+        gbs, gbs2 = ISTFT_BYTES * B / (ms * 1e-3) / 1e9, ISTFT_BYTES_FROM_STFT * B / (ms2 * 1e-3) / 1e9
+        return {"workload": "row f1: enhanced_sources (exp(pred std + mean), phase of the masked target -- its STFT taken "
+                            "inside the kernel from the target waveform --, inverse STFT, models.py:181-197), 4096 utterances",
+                "per_gpu_batch": B, "ms_per_step": ms,
                 "value": B / ms * 1e3, "unit": "utterances/s", "GB/s": gbs, "frac_of_hbm_peak": gbs / HBM_PEAK_GBS,
-                "algorithmic_bytes_per_utterance": ISTFT_BYTES}
+                "algorithmic_bytes_per_utterance": ISTFT_BYTES,
+                "from_stored_stft": {"ms_per_step": ms2, "GB/s": gbs2, "frac_of_hbm_peak": gbs2 / HBM_PEAK_GBS,
+                                     "algorithmic_bytes_per_utterance": ISTFT_BYTES_FROM_STFT,
+                                     "note": "round 3's form (mode 2): reads the 514 kB complex STFT the front end had to write"}}
     guarded("istft_b4096", istft_b4096)
 
     def lws_b1024():
@@ -939,7 +975,8 @@ def main():
                                 # the model's call also writes the un-masked target spectrogram (257,000 B more per
                                 # utterance), and a plain device copy on this GPU is the practical ceiling beside 8 TB/s
                                 "GB/s_with_target_output_at_median": 963000.0 * B / (fe_ms[len(fe_ms) // 2] * 1e-3) / 1e9,
-                                "device_copy_GB/s": device_copy_rate(torch, device)},
+                                "device_copy_GB/s": device_copy_rate(torch, device),
+                                "device_copy_GB/s_torch_copy_kernel": device_copy_rate(torch, device, kernel="torch")},
         }
         cpu, rms = (None, None)
         if not args.no_cpu_baseline and world == 1:     # the CPU leg is reported at N = 1 only

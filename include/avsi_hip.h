@@ -240,6 +240,9 @@ int avsi_stream_delay_us(int microseconds, void* stream);
  * *release (device int32) becomes non-zero or ~`max_ms` milliseconds have passed (every workgroup leaves by itself).
  * Stands in for the CUs an RCCL collective holds while the cooperative kernels run (tests/test_coop_residency_gpu.py). */
 int avsi_diag_occupy_cus(int num_cus, const int* release, int max_ms, void* stream);
+/* dst[0 .. n) = src[0 .. n) with 16-byte accesses and a chip-sized grid: the streaming-copy yardstick bench.py quotes
+ * the HBM-bound kernels against (`device_copy_GB/s`).  n a multiple of 4, both pointers 16-byte aligned. */
+int avsi_diag_copy_f32(const float* src, float* dst, int64_t n, void* stream);
 
 /* Loss of the speaker-embedding model variants (reference models.py:1006-1029 StackedBLSTMSSNNModel,
  * :1367-1394 StackedBLSTMEmbeddingModel): the prediction keeps the known bins,

@@ -44,7 +44,8 @@ def test_default_mode_line():
         assert abs(also[k]["value"] - b / also[k]["ms_per_step"] * 1e3) < 1e-6 * also[k]["value"]
     assert abs(d["value"] - 256 * 2 / (d["ms_per_step"] * 2e-3)) < 1e-6 * d["value"]
     # the other configurations and the steps either side of the path (N = 1 only), each with an algorithmic roofline figure
-    for k, b in (("train_b8192", 8192), ("unet_b512", 512), ("unet_b32", 32), ("istft_b4096", 4096), ("lws_b1024", 1024),
+    for k, b in (("train_b8192", 8192), ("unet_b512", 512), ("unet_b32", 32), ("unet_train_b512", 512), ("unet_train_b32", 32),
+                 ("istft_b4096", 4096), ("lws_b1024", 1024),
                  ("infer_b8192_hostfed", 8192)):
         assert "error" not in also[k], also[k]
         assert also[k]["per_gpu_batch"] == b and also[k]["ms_per_step"] > 0 and also[k]["value"] > 0
@@ -54,6 +55,7 @@ def test_default_mode_line():
         assert also[k]["value"] > 0 and also[k]["ms_per_step"] > 0, k
     assert 0 < also["train_b8192"]["kernels"]["blstm_rec_bwd_kh_kernel"]["frac"] < 1
     assert 0 < also["unet_b512"]["frac_of_fp32_mfma_peak"] < 1 and 0 < also["istft_b4096"]["frac_of_hbm_peak"] < 1
+    assert 0 < also["unet_train_b512"]["frac_of_fp32_mfma_peak"] < 1 and also["istft_b4096"]["from_stored_stft"]["ms_per_step"] > 0
     assert also["infer_b8192_hostfed"]["serial_upload_then_compute"]["ms_per_step"] >= also["infer_b8192_hostfed"]["ms_per_step"] * 0.9
     # configs[3], the same keys at every N: weak (32 per GPU) and fixed global 256 (256 / N per GPU)
     dp = d["dp_train"]
