@@ -356,6 +356,20 @@ __global__ __launch_bounds__(512, 4) void blstm_rec_bwd_kh_kernel(const BwdArgs 
 
 }  // namespace
 
+// blstm_bwd_pp.hip
+int avsi_blstm_rec_bwd_pp_launch(const float* dhout, const float* reserve, const float* whbT, float* dz, int T, int Bp,
+                                 hipStream_t st);
+
+// Which batch-stationary BPTT kernel runs a batch of Bp utterances (AVSI_BWD_PP = 1 / 0 forces / forbids the ping-pong
+// kernel).  The ping-pong kernel owns 64 utterances per workgroup and one workgroup per CU: it needs Bp / 32 >= 256
+// workgroups' worth of work to fill the chip (the K-halved kernel, 32 utterances per workgroup and two per CU, fills it
+// from 4096 utterances on and is the one for everything below).
+static bool bwd_use_pp(int Bp) {
+    static const char* e = getenv("AVSI_BWD_PP");
+    if (e) return atoi(e) != 0;
+    return Bp >= 64 * AVSI_NUM_CU / 2 * 3 / 2;       // from 12288 / 2 = 6144 utterances on: >= 192 workgroups of 64
+}
+
 extern "C" int avsi_blstm_rec_bwd_f32(const float* dhout, const float* reserve, const float* whbT, float* dz, int T,
                                       int Bp, void* stream) {
     if (!dhout || !reserve || !whbT || !dz || T <= 0 || Bp <= 0) return AVSI_ERR_INVALID_ARG;
@@ -365,6 +379,7 @@ extern "C" int avsi_blstm_rec_bwd_f32(const float* dhout, const float* reserve, 
     avsi_clear_error();
     // K-halved kernel (two workgroups per CU) by default; AVSI_BWD_KH=0 selects the whole-tile kernel (A/B runs)
     static const bool whole_tile = getenv("AVSI_BWD_KH") && atoi(getenv("AVSI_BWD_KH")) == 0;
+    if (!whole_tile && bwd_use_pp(Bp)) return avsi_blstm_rec_bwd_pp_launch(dhout, reserve, whbT, dz, T, Bp, (hipStream_t)stream);
     if (!whole_tile) {
         const size_t lds = (size_t)32 * ZH * 4;
         (void)hipFuncSetAttribute((const void*)blstm_rec_bwd_kh_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

@@ -180,8 +180,13 @@ int avsi_l1_loss_f32(const float* target, const float* pred, const float* mask, 
  * The workspace is zeroed ONCE by the caller, when it is allocated: word 0 is a STICKY status that no call clears,
  * the counters behind it (one 256-byte line each) are put back to zero by the kernels themselves when a launch ends,
  * so consecutive calls on one stream need nothing in between.  Once the stream has drained, a non-zero word 0 means
- * some launch since the allocation had a workgroup stop waiting for its peers (bounded spin): its outputs are
- * invalid and it may have left counters behind -- zero the whole workspace before using it again. */
+ * some launch since the allocation had a workgroup stop waiting for its peers: its outputs are invalid and it may
+ * have left counters behind -- zero the whole workspace before using it again.  Every wait is bounded in WALL-CLOCK
+ * time (AVSI_COOP_TIMEOUT_MS, default 2000: a group whose members cannot all be resident -- another kernel holds the
+ * LDS of a CU it needs; the 16- and 32-way splits keep a group on ONE XCD and need its CUs to themselves -- gives up
+ * after that long), a waiting workgroup also leaves as soon as any other has given up, and a launch that finds word 0
+ * already set returns at once without touching its outputs: one conflict costs one bound, whatever is enqueued
+ * behind it.  avsi_step_guard_f32 / avsi_adam_tf_guarded_f32 keep such a step away from the variables. */
 size_t avsi_blstm_rec_fwd_coop_workspace_bytes(int Bp);
 /* Optional: a workspace of AVSI_COOP_EXCHANGE_OFFSET + avsi_blstm_rec_fwd_coop_exchange_bytes(T, Bp) bytes lets the
  * forward call with split 16 / 32 exchange h through a copy in a layout of its own (whole-line stores, contiguous

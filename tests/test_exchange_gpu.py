@@ -9,8 +9,10 @@ pytestmark = pytest.mark.gpu
 
 
 def test_status_word_is_sticky_and_counters_are_left_at_zero():
-    """The caller zeroes the counter workspace once (include/avsi_hip.h); word 0 is a sticky status no launch clears,
-    and every launch puts its step counters back to zero itself, so calls follow each other without a memset."""
+    """The caller zeroes the counter workspace once (include/avsi_hip.h); every launch puts its step counters back to zero
+    itself, so calls follow each other without a memset.  Word 0 is a sticky status no launch clears -- and a launch that
+    finds it set does NOTHING (its results would be void anyway: the launch that set it may have left step counters
+    behind, and waiting out the time bound on them again would turn one timeout into a dozen)."""
     import torch
     import avsi_amd  # noqa: F401
     from avsi_amd import _lib, ops
@@ -24,17 +26,25 @@ def test_status_word_is_sticky_and_counters_are_left_at_zero():
     ops.blstm_rec_fwd(xproj, whp, ref, None, split=0)
     need = max(L.avsi_blstm_rec_fwd_coop_workspace_bytes(Bp), L.avsi_blstm_rec_fwd_cs_workspace_bytes(Bp))
     ws = torch.zeros(need // 4, dtype=torch.int32, device='cuda')
-    ws[0] = 7                                                   # a failure recorded earlier
+    families = ((L.avsi_blstm_rec_fwd_coop_f32, 32), (L.avsi_blstm_rec_fwd_cs_f32, 16), (L.avsi_blstm_rec_fwd_coop_f32, 16),
+                (L.avsi_blstm_rec_fwd_cs_f32, 32), (L.avsi_blstm_rec_fwd_coop_f32, 8), (L.avsi_blstm_rec_fwd_coop_f32, 4))
     # the same workspace through every forward kernel family, back to back
-    for entry, split in ((L.avsi_blstm_rec_fwd_coop_f32, 32), (L.avsi_blstm_rec_fwd_cs_f32, 16), (L.avsi_blstm_rec_fwd_coop_f32, 16),
-                         (L.avsi_blstm_rec_fwd_cs_f32, 32), (L.avsi_blstm_rec_fwd_coop_f32, 8), (L.avsi_blstm_rec_fwd_coop_f32, 4)):
+    for entry, split in families:
+        hout = torch.zeros(T, Bp, 512, device='cuda')
+        rc = entry(_lib.ptr(xproj), _lib.ptr(whp), _lib.ptr(hout), None, T, Bp, split, 0, _lib.ptr(ws), need, _lib.stream_ptr())
+        assert rc == 0
+        torch.cuda.synchronize()
+        assert int(ws.abs().max()) == 0                         # status clean, every counter back at zero
+        np.testing.assert_allclose(hout.cpu().numpy(), ref.cpu().numpy(), rtol=0, atol=2e-5)
+    ws[0] = 7                                                   # a failure recorded earlier
+    for entry, split in families:
         hout = torch.zeros(T, Bp, 512, device='cuda')
         rc = entry(_lib.ptr(xproj), _lib.ptr(whp), _lib.ptr(hout), None, T, Bp, split, 0, _lib.ptr(ws), need, _lib.stream_ptr())
         assert rc == 0
         torch.cuda.synchronize()
         assert int(ws[0]) == 7                                  # sticky: the call did not touch it
-        assert int(ws[1:].abs().max()) == 0                     # every counter is back at zero
-        np.testing.assert_allclose(hout.cpu().numpy(), ref.cpu().numpy(), rtol=0, atol=2e-5)
+        assert int(ws[1:].abs().max()) == 0                     # ... nor any counter
+        assert float(hout.abs().max()) == 0.0                   # ... nor the output: a launch behind a failure is void
 
 
 def test_column_split_residency_query_and_workspace():
