@@ -361,13 +361,15 @@ int avsi_blstm_rec_bwd_pp_launch(const float* dhout, const float* reserve, const
                                  hipStream_t st);
 
 // Which batch-stationary BPTT kernel runs a batch of Bp utterances (AVSI_BWD_PP = 1 / 0 forces / forbids the ping-pong
-// kernel).  The ping-pong kernel owns 64 utterances per workgroup and one workgroup per CU: it needs Bp / 32 >= 256
-// workgroups' worth of work to fill the chip (the K-halved kernel, 32 utterances per workgroup and two per CU, fills it
-// from 4096 utterances on and is the one for everything below).
+// kernel).  The ping-pong kernel owns 64 utterances per workgroup and one workgroup per CU; the K-halved kernel 32
+// utterances per workgroup and two per CU.  Measured per layer, T = 250, ms (ping-pong / K-halved): 6144 utterances
+// 16.8 / 19.4, 8192: 18.5 / 19.7 (115.9 / 109.1 TFLOP/s), 12288: 36.4 / 29.8 -- the ping-pong kernel wins where its
+// Bp / 64 x 2 workgroups fit the chip in ONE round and the K-halved kernel's Bp / 32 x 2 no longer fit half of its 512
+// slots; beyond 8192 its second round costs more than it gains.
 static bool bwd_use_pp(int Bp) {
-    static const char* e = getenv("AVSI_BWD_PP");
-    if (e) return atoi(e) != 0;
-    return Bp >= 64 * AVSI_NUM_CU / 2 * 3 / 2;       // from 12288 / 2 = 6144 utterances on: >= 192 workgroups of 64
+    const char* e = getenv("AVSI_BWD_PP");       // read at every call: the tests switch it
+    if (e && *e) return atoi(e) != 0;
+    return Bp > 32 * AVSI_NUM_CU / 2 && Bp <= 64 * AVSI_NUM_CU / 2;       // 4096 < Bp <= 8192
 }
 
 extern "C" int avsi_blstm_rec_bwd_f32(const float* dhout, const float* reserve, const float* whbT, float* dz, int T,

@@ -31,8 +31,8 @@ typedef __amdgpu_buffer_rsrc_t rsrc_t;
 constexpr int HP = 256, GP = 4 * HP, NWAVE = 8;
 constexpr int ZS = GP + 4;     // LDS row stride of the dz tile (conflict-free b128 reads)
 constexpr int HROW = 2 * HP * 4, RROW = 2 * 5 * HP * 4, ZROW = 2 * GP * 4;      // row pitches, bytes
-constexpr int RING = 16;       // Wh^T fragment registers (float4 each)
-constexpr int AHEAD = 14;      // Wh^T fragments in flight, in groups of 4 MFMAs
+constexpr int RING = 8;        // Wh^T fragment registers (float4 each)
+constexpr int AHEAD = 6;       // Wh^T fragments in flight, in groups of 4 MFMAs (14 of a ring of 16 measured the same)
 
 struct BwdArgs {
     const float* dhout;
@@ -71,7 +71,7 @@ __device__ __forceinline__ float4 ldg4(gptr4 p, int idx) {
 
 constexpr int CH = 2;      // row-registers per chunk of cell inputs (eight chunks per cell)
 struct RowsC {
-    float dh[CH], gi[CH], gj[CH], gf[CH], go[CH], c[CH], cp[CH];
+    float dh[CH], gi[CH], gj[CH], gf[CH], go[CH], cp[CH];      // (c_t itself is last step's c_prev: carried in registers)
 };
 
 // Where a (tile, step) lives.  The buffer descriptors are built from these few scalars AT EVERY USE (a dozen scalar
@@ -126,13 +126,22 @@ __device__ __forceinline__ rsrc_t rsrc_z(const Ctx& c, const Step& w) {
 // DIAG (diagnostic builds of the kernel, AVSI_BWD_PP_DIAG; results are then WRONG): 1 = no cell arithmetic / dz stores,
 // 2 = no cell input loads, 4 = no dz stores, 8 = Wh^T fragments loaded once per phase, 16 = no publish.
 template <int X, bool DO_MFMA, bool DO_CELL, int DIAG>
-__device__ __forceinline__ void bwd_pp_phase(f32x16 (&dhrec)[2], float (&dcn)[2][16], float (&dzh)[64], RowsC& ca, RowsC& cb,
+__device__ __forceinline__ void bwd_pp_phase(f32x16 (&dhrec)[2], float (&dcn)[2][16], float (&ccar)[2][16], float (&dzh)[64],
+                                             RowsC& ca, RowsC& cb,
                                              const float* __restrict__ zbuf, const float4* __restrict__ wb, const int lane,
                                              const int li, const int hi, const Ctx ctx, const Step cy, const Step nx,
                                              const int voff_h, const int voff_r, const int voff_z) {
     constexpr int Y = 1 - X;
     auto loadc = [&](RowsC& in, const Step& who0, int r0) {
-        if (DIAG & 2) return;
+        if (DIAG & 2) {          // no loads: opaque register values instead (the arithmetic stays)
+#pragma unroll
+            for (int e = 0; e < CH; ++e) {
+                float v = 0.25f + 0.001f * (r0 + e);
+                asm volatile("v_mov_b32 %0, %0" : "+v"(v));
+                in.dh[e] = v, in.gi[e] = v, in.gj[e] = v, in.gf[e] = v, in.go[e] = v, in.cp[e] = v;
+            }
+            return;
+        }
         const Step who = (DIAG & 64) ? Step{who0.tile, who0.s & 1, who0.on} : who0;      // 64: always the same two steps (cache hits)
         struct {
             rsrc_t rh, rr, rp;
@@ -142,11 +151,22 @@ __device__ __forceinline__ void bwd_pp_phase(f32x16 (&dhrec)[2], float (&dcn)[2]
             const int r = r0 + e;
             const int rowc = (r & 3) + 8 * (r >> 2);
             in.dh[e] = buf_load(d.rh, voff_h, rowc * HROW);
+            if (DIAG & 128) {       // one array of seven from memory
+                float v = 0.25f + 0.001f * r;
+                asm volatile("v_mov_b32 %0, %0" : "+v"(v));
+                in.gi[e] = v, in.gj[e] = v, in.gf[e] = v, in.go[e] = v, in.cp[e] = v;
+                continue;
+            }
             in.gi[e] = buf_load(d.rr, voff_r, rowc * RROW + 0 * HP * 4);
             in.gj[e] = buf_load(d.rr, voff_r, rowc * RROW + 1 * HP * 4);
             in.gf[e] = buf_load(d.rr, voff_r, rowc * RROW + 2 * HP * 4);
             in.go[e] = buf_load(d.rr, voff_r, rowc * RROW + 3 * HP * 4);
-            in.c[e] = buf_load(d.rr, voff_r, rowc * RROW + 4 * HP * 4);
+            if (DIAG & 256) {       // five of seven
+                float v = 0.25f + 0.001f * r;
+                asm volatile("v_mov_b32 %0, %0" : "+v"(v));
+                in.cp[e] = v;
+                continue;
+            }
             in.cp[e] = buf_load(d.rp, voff_r, rowc * RROW + 4 * HP * 4);
         }
     };
@@ -157,6 +177,9 @@ __device__ __forceinline__ void bwd_pp_phase(f32x16 (&dhrec)[2], float (&dcn)[2]
     struct {
         float dh, x, rc, tc, dc, dzi, dzj, dzf, dzo;
     } st;
+    // (pure arithmetic has no place of its own: the optimiser sinks it to its first use with a side effect -- the stores of
+    // stages 6 / 7 -- and the stages collapse into one burst again.  `pin` makes a value opaque where its stage ends.)
+    auto pin = [](float& v) { asm volatile("" : "+v"(v)); };
     auto cell_stage = [&](const RowsC& in, int r, int stage) {
         const int e = r & (CH - 1);
         const int rowl = (r & 3) + 8 * (r >> 2);
@@ -167,20 +190,27 @@ __device__ __forceinline__ void bwd_pp_phase(f32x16 (&dhrec)[2], float (&dcn)[2]
         const float ig = in.gi[e], jg = in.gj[e], fg = in.gf[e], og = in.go[e];
         if (stage == 0) {
             st.dh = in.dh[e] + dhrec[Y][r];
-            st.x = (DIAG & 32) ? in.c[e] : __expf(-2.f * in.c[e]);
+            st.x = (DIAG & 32) ? ccar[Y][r] : __expf(-2.f * ccar[Y][r]);
+            pin(st.dh), pin(st.x);
         } else if (stage == 1) {
             st.rc = (DIAG & 32) ? st.x : __builtin_amdgcn_rcpf(1.f + st.x);
+            pin(st.rc);
         } else if (stage == 2) {
             st.tc = 2.f * st.rc - 1.f;
             st.dc = st.dh * og * (1.f - st.tc * st.tc) + dcn[Y][r];
+            pin(st.tc), pin(st.dc);
         } else if (stage == 3) {
             dcn[Y][r] = st.dc * fg;
             st.dzo = st.dh * st.tc * og * (1.f - og);
+            pin(dcn[Y][r]), pin(st.dzo);
         } else if (stage == 4) {
             st.dzi = st.dc * jg * ig * (1.f - ig);
             st.dzj = st.dc * ig * (1.f - jg * jg);
+            pin(st.dzi), pin(st.dzj);
         } else if (stage == 5) {
             st.dzf = st.dc * in.cp[e] * fg * (1.f - fg);
+            ccar[Y][r] = in.cp[e];          // the c_t of this tile's next backward step
+            pin(st.dzf);
             dzh[4 * r + 0] = st.dzi, dzh[4 * r + 1] = st.dzj, dzh[4 * r + 2] = st.dzf, dzh[4 * r + 3] = st.dzo;
         } else if (!(DIAG & 4)) {
             const rsrc_t rz = rsrc_z(ctx, cy);
@@ -277,6 +307,13 @@ __global__ __launch_bounds__(512, 2) void blstm_rec_bwd_pp_kernel(const BwdArgs 
 #pragma unroll
         for (int r = 0; r < 16; ++r) dhrec[m][r] = 0.f, dcn[m][r] = 0.f;
 
+    float ccar[2][16];        // c_t of each tile's NEXT cell: loaded once for step 0, afterwards the c_prev of the step before
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+        const rsrc_t rr = rsrc_r(ctx, Step{m, 0, 1});
+#pragma unroll
+        for (int r = 0; r < 16; ++r) ccar[m][r] = buf_load(rr, voff_r, ((r & 3) + 8 * (r >> 2)) * RROW + 4 * HP * 4);
+    }
     RowsC ca, cb;
     {   // first chunk of the prologue's cell (tile 0, step 0)
         const Step first{0, 0, 1};
@@ -291,31 +328,30 @@ __global__ __launch_bounds__(512, 2) void blstm_rec_bwd_pp_kernel(const BwdArgs 
             ca.gj[e] = buf_load(d.rr, voff_r, rowc * RROW + 1 * HP * 4);
             ca.gf[e] = buf_load(d.rr, voff_r, rowc * RROW + 2 * HP * 4);
             ca.go[e] = buf_load(d.rr, voff_r, rowc * RROW + 3 * HP * 4);
-            ca.c[e] = buf_load(d.rr, voff_r, rowc * RROW + 4 * HP * 4);
             ca.cp[e] = buf_load(d.rp, voff_r, rowc * RROW + 4 * HP * 4);
         }
     }
     // prologue: cell tile 0, step 0 (dhrec = 0), no MFMA; then request the first chunk of tile 1, step 0
-    bwd_pp_phase<1, false, true, DIAG>(dhrec, dcn, dzh, ca, cb, zbuf, wb, lane, li, hi, ctx, Step{0, 0, 1}, Step{1, 0, 1}, voff_h,
+    bwd_pp_phase<1, false, true, DIAG>(dhrec, dcn, ccar, dzh, ca, cb, zbuf, wb, lane, li, hi, ctx, Step{0, 0, 1}, Step{1, 0, 1}, voff_h,
                                  voff_r, voff_z);
     publish();
     AVSI_LDS_BARRIER();
     for (int s = 0; s + 1 < T; ++s) {
         // phase A: MFMA tile 0 (dz_0(s) -> dhrec_0 for step s + 1) || cell tile 1, step s
-        bwd_pp_phase<0, true, true, DIAG>(dhrec, dcn, dzh, ca, cb, zbuf, wb, lane, li, hi, ctx, Step{1, s, 1}, Step{0, s + 1, 1},
+        bwd_pp_phase<0, true, true, DIAG>(dhrec, dcn, ccar, dzh, ca, cb, zbuf, wb, lane, li, hi, ctx, Step{1, s, 1}, Step{0, s + 1, 1},
                                     voff_h, voff_r, voff_z);
         AVSI_LDS_BARRIER();       // every wave is done reading dz_0(s)
         publish();                // dz_1(s)
         AVSI_LDS_BARRIER();
         // phase B: MFMA tile 1 (dz_1(s) -> dhrec_1 for step s + 1) || cell tile 0, step s + 1
-        bwd_pp_phase<1, true, true, DIAG>(dhrec, dcn, dzh, ca, cb, zbuf, wb, lane, li, hi, ctx, Step{0, s + 1, 1}, Step{1, s + 1, 1},
+        bwd_pp_phase<1, true, true, DIAG>(dhrec, dcn, ccar, dzh, ca, cb, zbuf, wb, lane, li, hi, ctx, Step{0, s + 1, 1}, Step{1, s + 1, 1},
                                     voff_h, voff_r, voff_z);
         AVSI_LDS_BARRIER();
         publish();                // dz_0(s + 1)
         AVSI_LDS_BARRIER();
     }
     // epilogue: cell tile 1, step T - 1 (its dhrec comes from the last phase B; for T = 1 it is zero)
-    bwd_pp_phase<0, false, true, DIAG>(dhrec, dcn, dzh, ca, cb, zbuf, wb, lane, li, hi, ctx, Step{1, T - 1, 1}, Step{0, T, 0}, voff_h,
+    bwd_pp_phase<0, false, true, DIAG>(dhrec, dcn, ccar, dzh, ca, cb, zbuf, wb, lane, li, hi, ctx, Step{1, T - 1, 1}, Step{0, T, 0}, voff_h,
                                  voff_r, voff_z);
     if (DIAG && T < 0) {        // never true: the diagnostic variants must not lose their arithmetic to dead-code elimination
         float s = 0.f;
@@ -347,6 +383,8 @@ int avsi_blstm_rec_bwd_pp_launch(const float* dhout, const float* reserve, const
         case 31: AVSI_PP_LAUNCH(31); break;
         case 2: AVSI_PP_LAUNCH(2); break;
         case 64: AVSI_PP_LAUNCH(64); break;
+        case 128: AVSI_PP_LAUNCH(128); break;
+        case 256: AVSI_PP_LAUNCH(256); break;
         case 68: AVSI_PP_LAUNCH(68); break;
         case 6: AVSI_PP_LAUNCH(6); break;
         case 32: AVSI_PP_LAUNCH(32); break;

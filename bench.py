@@ -668,7 +668,7 @@ def extra_workloads(torch, models, ops, ap_mod, cfg, mean, std, device):
                 "per_gpu_batch": B, "ms_per_step": ms, "value": B / ms * 1e3, "unit": "utterances/s",
                 "algorithmic_TFLOP/s": 3 * AV_FWD_FLOPS * B / (ms * 1e-3) / 1e12,
                 "frac_of_fp32_mfma_peak": 3 * AV_FWD_FLOPS * B / (ms * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS,
-                "kernels": {"blstm_rec_bwd_kh_kernel": {"avg_launch_ms": t_bwd / n_bwd, "TFLOP/s": bwd_tf,
+                "kernels": {"blstm_rec_bwd_pp_kernel": {"avg_launch_ms": t_bwd / n_bwd, "TFLOP/s": bwd_tf,
                                                         "frac": bwd_tf / FP32_MFMA_PEAK_TFLOPS},
                             "gemm_dma_kernel<true,...> (weight gradients, split-K A^T.B)": {
                                 "ms_per_step": t_wg / 2, "TFLOP/s": wg_tf, "frac": wg_tf / FP32_MFMA_PEAK_TFLOPS}}}

@@ -53,7 +53,7 @@ def test_default_mode_line():
     assert "e2e" not in also, also.get("e2e")
     for k in ("e2e_train_b32", "e2e_infer_b1024_oracle_phase", "e2e_infer_b1024", "e2e_infer_b32_oracle_phase", "e2e_infer_b32"):
         assert also[k]["value"] > 0 and also[k]["ms_per_step"] > 0, k
-    assert 0 < also["train_b8192"]["kernels"]["blstm_rec_bwd_kh_kernel"]["frac"] < 1
+    assert 0 < also["train_b8192"]["kernels"]["blstm_rec_bwd_pp_kernel"]["frac"] < 1
     assert 0 < also["unet_b512"]["frac_of_fp32_mfma_peak"] < 1 and 0 < also["istft_b4096"]["frac_of_hbm_peak"] < 1
     assert 0 < also["unet_train_b512"]["frac_of_fp32_mfma_peak"] < 1 and also["istft_b4096"]["from_stored_stft"]["ms_per_step"] > 0
     assert also["infer_b8192_hostfed"]["serial_upload_then_compute"]["ms_per_step"] >= also["infer_b8192_hostfed"]["ms_per_step"] * 0.9

@@ -78,14 +78,19 @@ def test_forward_kernel_families_match_oracle(mods, B, split, rows_per_wg, save)
                     np.testing.assert_allclose(r[t, :B, d, gi, :H], want, rtol=0, atol=3e-5)
 
 
-@pytest.mark.parametrize("B,split", [(37, 0), (70, 0), (37, 4), (70, 8), (37, 16), (70, 32)])
-def test_bptt_kernel_families_match_oracle(mods, B, split, monkeypatch):
-    """dz of one layer, both directions: blstm_rec_bwd_kh_kernel (split 0: what every training step above 2048
-    utterances runs) and the cooperative BPTT kernels, against the float64 manual BPTT of the oracle.  The reserve
-    comes from the forward kernel of the same family, as in a training step."""
+@pytest.mark.parametrize("B,split,T", [(37, 0, 11), (70, 0, 11), (37, 4, 11), (70, 8, 11), (37, 16, 11), (70, 32, 11),
+                                       (37, 'pp', 11), (70, 'pp', 11), (130, 'pp', 2), (33, 'pp', 1)])
+def test_bptt_kernel_families_match_oracle(mods, B, split, T, monkeypatch):
+    """dz of one layer, both directions: blstm_rec_bwd_kh_kernel (split 0: the batch-stationary kernel of batches up to
+    4096 and beyond 8192 utterances), blstm_rec_bwd_pp_kernel ('pp': the ping-pong kernel of 4096 < batch <= 8192, forced
+    here with AVSI_BWD_PP=1 -- 37 utterances: one workgroup, both 32-row tiles; 70: the second workgroup has one tile only;
+    one- and two-step recurrences) and the cooperative BPTT kernels, against the float64 manual BPTT of the oracle.  The
+    reserve comes from the forward kernel of the same family, as in a training step."""
     models, ops, bl = mods
     monkeypatch.delenv('AVSI_BWD_KH', raising=False)
-    T, D = 11, 40
+    monkeypatch.setenv('AVSI_BWD_PP', '1' if split == 'pp' else '0')
+    split = 0 if split == 'pp' else split
+    D = 40
     lay, p64, packed, x, xproj, Bp = _one_layer(bl, ops, B, T, D, 300 + B + split)
     hout = torch.empty(T, Bp, 512, device='cuda')
     resv = torch.empty(T, Bp, 2, 5, 256, device='cuda')
