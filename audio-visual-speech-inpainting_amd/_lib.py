@@ -101,6 +101,10 @@ PROTOTYPES = {
                                   c_void_p]),
     "avsi_bn_act_pool_f32": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
                                      c_void_p, c_void_p, c_void_p]),
+    "avsi_conv2d_bn_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int, c_int, c_int]),
+    "avsi_conv2d_bn_f32": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_int,
+                                   c_void_p, c_int, c_void_p, c_int, c_void_p, c_float, c_void_p, c_void_p, c_void_p, c_size_t,
+                                   c_void_p]),
     "avsi_conv2d_thin_mfma_supported": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int]),
     "avsi_conv2d_thin_mfma_f32": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p,
                                           c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p]),
@@ -146,6 +150,10 @@ PROTOTYPES = {
     "avsi_conv2d_splitk_suggest": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, c_int]),
     "avsi_conv2d_splitk_f32": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p,
                                        c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_size_t, c_void_p]),
+    "avsi_unet_tail_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
+    "avsi_unet_tail_f32": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p,
+                                   c_void_p, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                   c_size_t, c_void_p]),
     "avsi_conv2d_thin_f32": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_int,
                                      c_void_p, c_int, c_void_p, c_int, c_void_p]),
     "avsi_split_sumpool_f32": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_int, c_int, c_int,

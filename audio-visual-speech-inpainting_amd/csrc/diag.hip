@@ -24,25 +24,38 @@ __global__ __launch_bounds__(64) void stream_delay_kernel(long long ticks) {
 
 // Streaming copy, the yardstick of the HBM-bound kernels: 16 bytes per lane and access, four accesses in flight per lane,
 // a grid sized to the chip (8 workgroups of 256 per CU) walking the buffer with a grid stride.
-__global__ __launch_bounds__(256) void copy4_kernel(const float4* __restrict__ src, float4* __restrict__ dst, long long n4) {
+typedef float v4f __attribute__((ext_vector_type(4)));
+template <bool NT>
+__global__ __launch_bounds__(256) void copy4_kernel(const v4f* __restrict__ src, v4f* __restrict__ dst, long long n4) {
     const long long stride = (long long)gridDim.x * 256;
     long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    auto ld = [&](long long j) { return NT ? __builtin_nontemporal_load(src + j) : src[j]; };
+    auto st = [&](long long j, v4f v) {
+        if (NT) __builtin_nontemporal_store(v, dst + j);
+        else dst[j] = v;
+    };
     for (; i + 3 * stride < n4; i += 4 * stride) {
-        const float4 a = src[i], b = src[i + stride], c = src[i + 2 * stride], d = src[i + 3 * stride];
-        dst[i] = a, dst[i + stride] = b, dst[i + 2 * stride] = c, dst[i + 3 * stride] = d;
+        const v4f a = ld(i), b = ld(i + stride), c = ld(i + 2 * stride), d = ld(i + 3 * stride);
+        st(i, a), st(i + stride, b), st(i + 2 * stride, c), st(i + 3 * stride, d);
     }
-    for (; i < n4; i += stride) dst[i] = src[i];
+    for (; i < n4; i += stride) st(i, ld(i));
 }
 
 }  // namespace
 
 // dst[0 .. n) = src[0 .. n) (n a multiple of 4, both 16-byte aligned): bench.py's `device_copy_GB/s`.
+// AVSI_DIAG_COPY_NT=1: non-temporal loads and stores.
 extern "C" int avsi_diag_copy_f32(const float* src, float* dst, int64_t n, void* stream) {
     if (!src || !dst || n <= 0 || (n & 3) || ((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(dst)) & 15))
         return AVSI_ERR_INVALID_ARG;
     avsi_clear_error();
-    hipLaunchKernelGGL(copy4_kernel, dim3(AVSI_NUM_CU * 8), dim3(256), 0, (hipStream_t)stream,
-                       reinterpret_cast<const float4*>(src), reinterpret_cast<float4*>(dst), (long long)(n >> 2));
+    const char* e = getenv("AVSI_DIAG_COPY_NT");
+    if (e && e[0] == '1')
+        hipLaunchKernelGGL(copy4_kernel<true>, dim3(AVSI_NUM_CU * 8), dim3(256), 0, (hipStream_t)stream,
+                           reinterpret_cast<const v4f*>(src), reinterpret_cast<v4f*>(dst), (long long)(n >> 2));
+    else
+        hipLaunchKernelGGL(copy4_kernel<false>, dim3(AVSI_NUM_CU * 8), dim3(256), 0, (hipStream_t)stream,
+                           reinterpret_cast<const v4f*>(src), reinterpret_cast<v4f*>(dst), (long long)(n >> 2));
     return avsi_launch_status();
 }
 

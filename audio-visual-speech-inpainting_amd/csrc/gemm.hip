@@ -66,6 +66,9 @@ struct GemmArgs {
     const float* conv_s1;
     const float* conv_zeros;   // >= 64 bytes of zeros: the source of out-of-image taps
     int cH, cW, cC0, cld0, cC1, cld1, ck;
+    // CONV only: per (M-block, wave row) partial column sums of the OUTPUT, [parts][2][N] (sum, sum of squares) -- the batch-norm
+    // statistics of a convolution taken where its accumulators are, instead of a pass over its output (avsi_conv2d_bn_f32)
+    float* stats;
 };
 
 // Block -> tile map.  Two things are arranged here:
@@ -644,6 +647,9 @@ __global__ __launch_bounds__(256, BNT == 256 ? 2 : (BK == 16 ? (NST == 3 ? 3 : 4
         }
         return;
     }
+    float st1[TN], st2[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) st1[j] = st2[j] = 0.f;
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
 #pragma unroll
@@ -665,7 +671,18 @@ __global__ __launch_bounds__(256, BNT == 256 ? 2 : (BK == 16 ? (NST == 3 ? 3 : 4
                 float v = (g.alpha * acc[i][j][r] + bv[j]) * rsc;
                 if (accumulate) v += g.beta * *c;
                 *c = v;
+                if (CONV) st1[j] += v, st2[j] += v * v;
             }
+        }
+    }
+    if (CONV && g.stats) {       // wave-uniform.  Rows in a fixed order per lane, the two row halves by one shuffle: deterministic
+        constexpr int WMV = 4 / WN;          // wave rows of the block
+        float* part = g.stats + ((int64_t)(bm * WMV + wm) * 2) * g.N;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const float t1 = st1[j] + __shfl_xor(st1[j], 32, 64), t2 = st2[j] + __shfl_xor(st2[j], 32, 64);
+            const int col = n0 + wn * (32 * TN) + j * 32 + li;
+            if (hi == 0 && col < g.N) part[col] = t1, part[g.N + col] = t2;
         }
     }
 }
@@ -837,9 +854,26 @@ int avsi_gemm_launch(int transA, int transB, int M, int N, int K, float alpha, c
 }
 
 // Convolution as an implicit GEMM: out[(b,h,w)][n] = bias[n] + sum_{tap,c} in(b, h+dh, w+dw, c) filter[(tap, c)][n].
+// number of [2][Cout] partial-statistics rows the launch below writes when `stats` is given
+int avsi_conv2d_stats_parts(int B, int H, int W, int Cout) {
+    const int64_t m_blocks = avsi_ceil_div((int64_t)B * H * W, 128);
+    return (int)(m_blocks * (Cout <= 32 ? 4 : 2));
+}
+
+int avsi_conv2d_launch(const float* src0, int C0, int ld0, const float* src1_coarse, int C1, int ld1, int B, int H, int W, int k,
+                       const float* filter, int ldf, const float* bias, int Cout, float* out, int ldo, const float* zeros64,
+                       float* stats, void* stream);
+
 extern "C" int avsi_conv2d_f32(const float* src0, int C0, int ld0, const float* src1_coarse, int C1, int ld1, int B, int H,
                                int W, int k, const float* filter, int ldf, const float* bias, int Cout, float* out,
                                int ldo, const float* zeros64, void* stream) {
+    return avsi_conv2d_launch(src0, C0, ld0, src1_coarse, C1, ld1, B, H, W, k, filter, ldf, bias, Cout, out, ldo, zeros64, nullptr,
+                              stream);
+}
+
+int avsi_conv2d_launch(const float* src0, int C0, int ld0, const float* src1_coarse, int C1, int ld1, int B, int H, int W, int k,
+                       const float* filter, int ldf, const float* bias, int Cout, float* out, int ldo, const float* zeros64,
+                       float* stats, void* stream) {
     if (!filter || !out || !zeros64 || B <= 0 || H <= 0 || W <= 0 || k < 1 || !(k & 1) || Cout <= 0 || C0 < 0 || C1 < 0)
         return AVSI_ERR_INVALID_ARG;
     if ((C0 && !src0) || (C1 && !src1_coarse) || ldf < Cout || ldo < Cout || (C0 && ld0 < C0) || (C1 && ld1 < C1))
@@ -862,6 +896,7 @@ extern "C" int avsi_conv2d_f32(const float* src0, int C0, int ld0, const float* 
     g.k_split_len = g.K, g.c_split_stride = 0, g.n_group = g.n_blocks;
     g.conv_s0 = src0, g.conv_s1 = src1_coarse, g.conv_zeros = zeros64;
     g.cH = H, g.cW = W, g.cC0 = C0, g.cld0 = ld0, g.cC1 = C1, g.cld1 = ld1, g.ck = k;
+    g.stats = stats;
     if ((int64_t)g.m_blocks * g.n_blocks > INT32_MAX) return AVSI_ERR_UNSUPPORTED;
     avsi_clear_error();
     const dim3 grid(g.m_blocks * g.n_blocks), block(256);

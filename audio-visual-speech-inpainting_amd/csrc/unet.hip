@@ -20,6 +20,7 @@
 namespace {
 
 __device__ __attribute__((aligned(16))) float g_zero_pixel[64];      // zero-initialised: the out-of-image pixel
+__device__ __forceinline__ float bn_act_one(float v, float sc, float sh, int act);
 
 constexpr int TPB = 256;
 
@@ -227,11 +228,14 @@ __global__ __launch_bounds__(256) void conv7_c1_mfma_kernel(const float* __restr
 // group is a 16 x (KS^2 CT) by (KS^2 CT) x COUT product in k-steps of four channels of one tap: lane l supplies
 // A[pixel l % 16][channel 4 kk' + l / 16] (one ds_read_b32 from the patch) and B[.][output channel l % 16] (one from
 // the filter); D[pixel 4 (l / 16) + i][channel l % 16].
-template <int KS, int C0, int C1, int COUT>
+// STATS: the block also leaves per-channel sums and sums of squares of its 128 output pixels in part[blk][2][COUT]
+// (batch-norm statistics taken where the accumulators are; fixed reduction order: deterministic).
+template <int KS, int C0, int C1, int COUT, bool STATS>
 __global__ __launch_bounds__(256) void thin_mfma_conv_kernel(const float* __restrict__ s0, int ld0, const float* __restrict__ s1,
                                                              int ld1, const float* __restrict__ filt, int ldf,
                                                              const float* __restrict__ bias, float* __restrict__ out, int ldo,
-                                                             int H, int W, const float* __restrict__ zeros) {
+                                                             int H, int W, const float* __restrict__ zeros,
+                                                             float* __restrict__ part) {
     constexpr int P = KS / 2, CT = C0 + C1, CP = CT + 1, TH = 4, TW = 32, PH = TH + KS - 1, PWD = TW + KS - 1;
     constexpr int NCG = COUT / 16, KSTEPS = KS * KS * CT / 4, CQ = CT / 4;
     extern __shared__ __attribute__((aligned(16))) float smem_f[];
@@ -300,6 +304,27 @@ __global__ __launch_bounds__(256) void thin_mfma_conv_kernel(const float* __rest
 #pragma unroll
             for (int i = 0; i < 4; ++i) out[(pix0 + i) * ldo + 16 * n + px] = acc[g][n][i];
     }
+    if (STATS) {
+        // lane (px, kq) holds channel 16 n + px of 8 pixels: sum them, then the four kq groups (shuffles), then the four waves
+        __syncthreads();                                 // the patch is dead: its storage carries the wave sums
+        float* red = smem_f;                             // [4 waves][2][COUT]
+#pragma unroll
+        for (int n = 0; n < NCG; ++n) {
+            float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+            for (int g = 0; g < 2; ++g)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) t1 += acc[g][n][i], t2 += acc[g][n][i] * acc[g][n][i];
+            t1 += __shfl_xor(t1, 16, 64), t2 += __shfl_xor(t2, 16, 64);
+            t1 += __shfl_xor(t1, 32, 64), t2 += __shfl_xor(t2, 32, 64);
+            if (kq == 0) red[(wv * 2 + 0) * COUT + 16 * n + px] = t1, red[(wv * 2 + 1) * COUT + 16 * n + px] = t2;
+        }
+        __syncthreads();
+        if (tid < 2 * COUT) {
+            const float v = (red[tid] + red[2 * COUT + tid]) + (red[4 * COUT + tid] + red[6 * COUT + tid]);
+            part[(int64_t)blockIdx.x * 2 * COUT + tid] = v;
+        }
+    }
 }
 
 template <int K, int C0, int C1, int COUT>
@@ -366,10 +391,13 @@ __global__ __launch_bounds__(TPB) void direct_conv_kernel(const float* __restric
 // fine channel and the coarse (half-resolution) 16-channel pixels it up-samples from -- and the 153 weights go through
 // LDS once, then every thread owns one pixel: 9 taps x (1 + 4 x 16-byte) LDS reads.  The per-pixel form above fetched
 // every coarse pixel 36 times through the L1 (0.31 ms at batch 512 for 2.6 GFLOP).
+// STATS: the block also leaves the sum and the sum of squares of its 256 outputs in part[2 blk], part[2 blk + 1] (fixed
+// reduction tree: deterministic) -- the batch statistics of the layer's one channel without a pass over its output.
+template <bool STATS>
 __global__ __launch_bounds__(256) void conv3_c17_out1_kernel(const float* __restrict__ s0, int ld0, const float* __restrict__ s1,
                                                              int ld1, const float* __restrict__ filt, int ldf,
                                                              const float* __restrict__ bias, float* __restrict__ out, int ldo,
-                                                             int H, int W) {
+                                                             int H, int W, float* __restrict__ part) {
     constexpr int TH = 8, TW = 32, FH = TH + 2, FW = TW + 2, CH = TH / 2 + 2, CW = TW / 2 + 2, CP = 20, WP = 20;
     __shared__ float fine[FH * FW];
     __shared__ __attribute__((aligned(16))) float coarse[CH * CW * CP];     // pitch 20: conflict-free 16-byte reads
@@ -419,6 +447,41 @@ __global__ __launch_bounds__(256) void conv3_c17_out1_kernel(const float* __rest
             }
         }
     out[(((int64_t)b * H + h0 + r) * W + w0 + c) * ldo] = acc;
+    if (STATS) {
+        __shared__ float red[2][4];
+        float t1 = acc, t2 = acc * acc;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) t1 += __shfl_xor(t1, o, 64), t2 += __shfl_xor(t2, o, 64);
+        if ((tid & 63) == 0) red[0][tid >> 6] = t1, red[1][tid >> 6] = t2;
+        __syncthreads();
+        if (tid == 0) {
+            part[2 * (int64_t)blockIdx.x + 0] = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
+            part[2 * (int64_t)blockIdx.x + 1] = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
+        }
+    }
+}
+
+// The rest of the network behind that convolution, one pass (inference form): batch norm of the one channel, LeakyReLU(0.2),
+// the 1 x 1 output convolution (a scalar weight and bias: models.py:607) and the sequence mask of `prediction` (models.py:609-615).
+__global__ __launch_bounds__(TPB) void unet_tail_kernel(const float* __restrict__ x, const float* __restrict__ mean,
+                                                        const float* __restrict__ rstd, const float* __restrict__ gamma,
+                                                        const float* __restrict__ beta, const float* __restrict__ w_out,
+                                                        const float* __restrict__ b_out, const long long* __restrict__ seq_len,
+                                                        float* __restrict__ logits, float* __restrict__ pred, int64_t n4, int T,
+                                                        int F) {
+    const float sc = gamma[0] * rstd[0], sh = beta[0] - mean[0] * sc, w = w_out[0], bo = b_out ? b_out[0] : 0.f;
+    const int64_t tf4 = (int64_t)T * F / 4;
+    for (int64_t e = (int64_t)blockIdx.x * TPB + threadIdx.x; e < n4; e += (int64_t)gridDim.x * TPB) {
+        const float4 v = reinterpret_cast<const float4*>(x)[e];
+        const int64_t b = e / tf4;
+        const int t = (int)((e - b * tf4) * 4 / F);              // F is a multiple of 4: the four values share a frame
+        const float m = t < seq_len[b] ? 1.f : 0.f;
+        float4 y;
+        y.x = w * bn_act_one(v.x, sc, sh, 2) + bo, y.y = w * bn_act_one(v.y, sc, sh, 2) + bo;
+        y.z = w * bn_act_one(v.z, sc, sh, 2) + bo, y.w = w * bn_act_one(v.w, sc, sh, 2) + bo;
+        if (logits) reinterpret_cast<float4*>(logits)[e] = y;
+        reinterpret_cast<float4*>(pred)[e] = make_float4(y.x * m, y.y * m, y.z * m, y.w * m);
+    }
 }
 
 // Filter gradient of the thin layers, direct form: dW[(tap, c)][n] = sum over pixels of in(p + off(tap), c) dY[p][n].
@@ -935,8 +998,8 @@ extern "C" int avsi_conv2d_thin_f32(const float* src0, int C0, int ld0, const fl
         hipLaunchKernelGGL((direct_conv_kernel<7, 1, 0, 16>), grid, block, 0, st, src0, ld0, src1_coarse, ld1, filter, ldf, bias,
                            out, ldo, B, H, W);
     else if (k == 3 && C0 == 1 && C1 == 16 && Cout == 1 && H % 8 == 0 && W % 32 == 0)
-        hipLaunchKernelGGL(conv3_c17_out1_kernel, dim3(B * (H / 8) * (W / 32)), dim3(256), 0, st, src0, ld0, src1_coarse, ld1,
-                           filter, ldf, bias, out, ldo, H, W);
+        hipLaunchKernelGGL(conv3_c17_out1_kernel<false>, dim3(B * (H / 8) * (W / 32)), dim3(256), 0, st, src0, ld0, src1_coarse, ld1,
+                           filter, ldf, bias, out, ldo, H, W, (float*)nullptr);
     else if (k == 3 && C0 == 1 && C1 == 16 && Cout == 1)
         hipLaunchKernelGGL((direct_conv_kernel<3, 1, 16, 1>), grid, block, 0, st, src0, ld0, src1_coarse, ld1, filter, ldf, bias,
                            out, ldo, B, H, W);
@@ -945,6 +1008,40 @@ extern "C" int avsi_conv2d_thin_f32(const float* src0, int C0, int ld0, const fl
                            out, ldo, B, H, W);
     else
         return AVSI_ERR_UNSUPPORTED;
+    return avsi_launch_status();
+}
+
+// Inference tail of the U-Net (models.py:605-615 in one call, three launches): d6 = conv3x3(concat(src0, up2x(src1)), 17 -> 1)
+// with its batch statistics taken in the convolution's own epilogue, then ONE pass: batch norm + LeakyReLU(0.2) + the 1 x 1
+// output convolution (scalar w_out, b_out) + the sequence mask.  `conv` [B*H*W] (pitch 1) is scratch; `logits` may be null.
+extern "C" size_t avsi_unet_tail_workspace_bytes(int B, int H, int W) {
+    if (B <= 0 || H <= 0 || W <= 0 || H % 8 || W % 32) return 0;
+    return (size_t)B * (H / 8) * (W / 32) * 2 * sizeof(float) + 2 * sizeof(float);
+}
+
+extern "C" int avsi_unet_tail_f32(const float* src0, int ld0, const float* src1_coarse, int ld1, int B, int H, int W,
+                                  const float* filter, int ldf, const float* bias, const float* gamma, const float* beta, float eps,
+                                  const float* w_out, const float* b_out, const long long* seq_len, float* conv, float* logits,
+                                  float* pred, void* workspace, size_t workspace_bytes, void* stream) {
+    if (!src0 || !src1_coarse || !filter || !gamma || !beta || !w_out || !seq_len || !conv || !pred || B <= 0 || ld0 < 1 || ld1 < 16 ||
+        ldf < 1)
+        return AVSI_ERR_INVALID_ARG;
+    if (H % 8 || W % 32 || (ld1 & 3) || ((reinterpret_cast<uintptr_t>(src1_coarse) | reinterpret_cast<uintptr_t>(conv) |
+                                           reinterpret_cast<uintptr_t>(pred) | reinterpret_cast<uintptr_t>(logits)) & 15))
+        return AVSI_ERR_UNSUPPORTED;
+    const size_t need = avsi_unet_tail_workspace_bytes(B, H, W);
+    if (!workspace || workspace_bytes < need) return AVSI_ERR_WORKSPACE;
+    const int blocks = B * (H / 8) * (W / 32);
+    float* part = static_cast<float*>(workspace);
+    float* mean = part + 2 * (size_t)blocks;
+    const hipStream_t st = (hipStream_t)stream;
+    const int64_t R = (int64_t)B * H * W;
+    avsi_clear_error();
+    hipLaunchKernelGGL(conv3_c17_out1_kernel<true>, dim3(blocks), dim3(256), 0, st, src0, ld0, src1_coarse, ld1, filter, ldf, bias,
+                       conv, 1, H, W, part);
+    hipLaunchKernelGGL(colpair_final_kernel<0>, dim3(1), dim3(64), 0, st, (const float*)part, blocks, 1, R, eps, mean, mean + 1);
+    hipLaunchKernelGGL(unet_tail_kernel, dim3(grid_for(R / 4)), dim3(TPB), 0, st, (const float*)conv, (const float*)mean,
+                       (const float*)(mean + 1), gamma, beta, w_out, b_out, seq_len, logits, pred, R / 4, H, W);
     return avsi_launch_status();
 }
 
@@ -1092,9 +1189,20 @@ extern "C" int avsi_conv2d_thin_mfma_supported(int k, int C0, int C1, int Cout, 
     return (H % 4 == 0 && W % 32 == 0) && ((k == 3 && C0 == 16 && C1 == 32 && Cout == 16) || (k == 5 && C0 == 16 && C1 == 0 && Cout == 32));
 }
 
+static int conv2d_thin_mfma_launch(const float* src0, int C0, int ld0, const float* src1_coarse, int C1, int ld1, int B, int H,
+                                   int W, int k, const float* filter, int ldf, const float* bias, int Cout, float* out,
+                                   int ldo, const float* zeros64, float* part, void* stream);
+
 extern "C" int avsi_conv2d_thin_mfma_f32(const float* src0, int C0, int ld0, const float* src1_coarse, int C1, int ld1, int B, int H,
                                          int W, int k, const float* filter, int ldf, const float* bias, int Cout, float* out,
                                          int ldo, const float* zeros64, void* stream) {
+    return conv2d_thin_mfma_launch(src0, C0, ld0, src1_coarse, C1, ld1, B, H, W, k, filter, ldf, bias, Cout, out, ldo, zeros64,
+                                   nullptr, stream);
+}
+
+static int conv2d_thin_mfma_launch(const float* src0, int C0, int ld0, const float* src1_coarse, int C1, int ld1, int B, int H,
+                                   int W, int k, const float* filter, int ldf, const float* bias, int Cout, float* out,
+                                   int ldo, const float* zeros64, float* part, void* stream) {
     if (!src0 || !filter || !out || !zeros64 || B <= 0 || (C1 && !src1_coarse) || ldf < Cout || ldo < Cout || ld0 < C0 ||
         (C1 && ld1 < C1))
         return AVSI_ERR_INVALID_ARG;
@@ -1105,19 +1213,61 @@ extern "C" int avsi_conv2d_thin_mfma_f32(const float* src0, int C0, int ld0, con
     const dim3 grid(B * (H / 4) * (W / 32)), block(256);
     const hipStream_t st = (hipStream_t)stream;
     avsi_clear_error();
+#define AVSI_THIN_MFMA(KS, CA, CB, CO, ST, LDS)                                                                                 \
+    do {                                                                                                                      \
+        (void)hipFuncSetAttribute((const void*)thin_mfma_conv_kernel<KS, CA, CB, CO, ST>,                                      \
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)(LDS));                                     \
+        hipLaunchKernelGGL((thin_mfma_conv_kernel<KS, CA, CB, CO, ST>), grid, block, (LDS), st, src0, ld0, src1_coarse, ld1,   \
+                           filter, ldf, bias, out, ldo, H, W, zeros64, part);                                                 \
+    } while (0)
     if (k == 3) {
         constexpr size_t lds = ((size_t)6 * 34 * 49 + 9 * 48 * 16) * 4;
-        (void)hipFuncSetAttribute((const void*)thin_mfma_conv_kernel<3, 16, 32, 16>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  (int)lds);
-        hipLaunchKernelGGL((thin_mfma_conv_kernel<3, 16, 32, 16>), grid, block, lds, st, src0, ld0, src1_coarse, ld1, filter, ldf, bias,
-                           out, ldo, H, W, zeros64);
+        if (part) AVSI_THIN_MFMA(3, 16, 32, 16, true, lds);
+        else AVSI_THIN_MFMA(3, 16, 32, 16, false, lds);
     } else {
         constexpr size_t lds = ((size_t)8 * 36 * 17 + 25 * 16 * 32) * 4;
-        (void)hipFuncSetAttribute((const void*)thin_mfma_conv_kernel<5, 16, 0, 32>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  (int)lds);
-        hipLaunchKernelGGL((thin_mfma_conv_kernel<5, 16, 0, 32>), grid, block, lds, st, src0, ld0, src1_coarse, ld1, filter, ldf, bias,
-                           out, ldo, H, W, zeros64);
+        if (part) AVSI_THIN_MFMA(5, 16, 0, 32, true, lds);
+        else AVSI_THIN_MFMA(5, 16, 0, 32, false, lds);
     }
+#undef AVSI_THIN_MFMA
+    return avsi_launch_status();
+}
+
+// gemm.hip
+int avsi_conv2d_stats_parts(int B, int H, int W, int Cout);
+int avsi_conv2d_launch(const float* src0, int C0, int ld0, const float* src1_coarse, int C1, int ld1, int B, int H, int W, int k,
+                       const float* filter, int ldf, const float* bias, int Cout, float* out, int ldo, const float* zeros64,
+                       float* stats, void* stream);
+
+// Convolution + the batch statistics of its output (tf.layers.batch_normalization(training=True), unet_layers.py:14,33) in one
+// call: the convolution's epilogue leaves per-tile partial sums, one small launch turns them into mean and 1 / sqrt(var + eps)
+// -- no pass over the output.  Route: the 16-wide-MFMA kernel where it applies, else the implicit GEMM.
+static int conv_bn_parts(int B, int H, int W, int k, int C0, int C1, int Cout) {
+    if (avsi_conv2d_thin_mfma_supported(k, C0, C1, Cout, H, W)) return B * (H / 4) * (W / 32);
+    return avsi_conv2d_stats_parts(B, H, W, Cout);
+}
+extern "C" size_t avsi_conv2d_bn_workspace_bytes(int B, int H, int W, int k, int C0, int C1, int Cout) {
+    if (B <= 0 || H <= 0 || W <= 0 || Cout <= 0) return 0;
+    return (size_t)conv_bn_parts(B, H, W, k, C0, C1, Cout) * 2 * (size_t)Cout * sizeof(float);
+}
+extern "C" int avsi_conv2d_bn_f32(const float* src0, int C0, int ld0, const float* src1_coarse, int C1, int ld1, int B, int H, int W,
+                                  int k, const float* filter, int ldf, const float* bias, int Cout, float* out, int ldo,
+                                  const float* zeros64, float eps, float* mean, float* rstd, void* workspace,
+                                  size_t workspace_bytes, void* stream) {
+    if (!mean || !rstd || B <= 0 || H <= 0 || W <= 0 || Cout <= 0) return AVSI_ERR_INVALID_ARG;
+    if (!workspace || workspace_bytes < avsi_conv2d_bn_workspace_bytes(B, H, W, k, C0, C1, Cout)) return AVSI_ERR_WORKSPACE;
+    float* part = static_cast<float*>(workspace);
+    const int parts = conv_bn_parts(B, H, W, k, C0, C1, Cout);
+    int rc;
+    if (avsi_conv2d_thin_mfma_supported(k, C0, C1, Cout, H, W))
+        rc = conv2d_thin_mfma_launch(src0, C0, ld0, src1_coarse, C1, ld1, B, H, W, k, filter, ldf, bias, Cout, out, ldo, zeros64, part,
+                                     stream);
+    else
+        rc = avsi_conv2d_launch(src0, C0, ld0, src1_coarse, C1, ld1, B, H, W, k, filter, ldf, bias, Cout, out, ldo, zeros64, part,
+                                stream);
+    if (rc != AVSI_OK) return rc;
+    hipLaunchKernelGGL(colpair_final_kernel<0>, dim3(Cout), dim3(64), 0, (hipStream_t)stream, (const float*)part, parts, Cout,
+                       (int64_t)B * H * W, eps, mean, rstd);
     return avsi_launch_status();
 }
 

@@ -693,6 +693,36 @@ def conv2d(src0, c0, src1, c1, B, H, W, k, filt, bias, out, cout):
     return out
 
 
+_CONV_BN = os.environ.get('AVSI_CONV_BN', '1') != '0'
+
+
+def conv2d_bn_supported(k, c0, c1, cout, B, H, W, ldo):
+    """Layers whose batch statistics come out of the convolution's epilogue (avsi_conv2d_bn_f32): the 16-wide-MFMA layers and
+    the implicit-GEMM layers that fill the chip without a split reduction (a split launch holds partial sums only)."""
+    if not _CONV_BN:
+        return False
+    if conv2d_thin_mfma_supported(k, c0, c1, cout, H, W):
+        return True
+    if not conv2d_supported(c0, c1):
+        return False
+    return not (_CONV_SPLITK and ldo == cout and _lib.lib().avsi_conv2d_splitk_suggest(B, H, W, k, c0, c1, cout) > 1)
+
+
+def conv2d_bn(src0, c0, src1, c1, B, H, W, k, filt, bias, out, cout, mean, rstd, eps=1e-3):
+    """out = conv2d(concat(src0, up2x(src1)), filt) + bias AND mean / rstd of its cout channels over all B*H*W rows."""
+    _lib.require_cuda(src0, src1, filt, out, mean, rstd)
+    z = _ZEROS.get(out.device.index)
+    if z is None:
+        z = _ZEROS[out.device.index] = torch.zeros(64, dtype=torch.float32, device=out.device)
+    L = _lib.lib()
+    ws = _workspace(out.device, L.avsi_conv2d_bn_workspace_bytes(B, H, W, k, c0, c1, cout))
+    _lib.check(L.avsi_conv2d_bn_f32(_lib.ptr(src0), c0, src0.stride(0) if src0 is not None else 0, _lib.ptr(src1), c1,
+                                    src1.stride(0) if src1 is not None else 0, B, H, W, k, _lib.ptr(filt), filt.stride(0),
+                                    _lib.ptr(bias), cout, _lib.ptr(out), out.stride(0), _lib.ptr(z), float(eps), _lib.ptr(mean),
+                                    _lib.ptr(rstd), _lib.ptr(ws), ws.numel() * 4, _lib.stream_ptr()), "avsi_conv2d_bn_f32")
+    return out
+
+
 def conv2d_thin_mfma_supported(k, c0, c1, cout, H, W):
     """Few-channel layers the 16-wide-MFMA convolution takes (avsi_conv2d_thin_mfma_f32)."""
     return os.environ.get('AVSI_CONV_THIN_MFMA', '1') != '0' and \
@@ -726,6 +756,25 @@ def conv2d_thin(src0, c0, src1, c1, B, H, W, k, filt, bias, out, cout):
                                                filt.stride(0), _lib.ptr(bias), cout, _lib.ptr(out), out.stride(0),
                                                _lib.stream_ptr()), "avsi_conv2d_thin_f32")
     return out
+
+
+def unet_tail_supported(H, W):
+    return os.environ.get('AVSI_UNET_TAIL', '1') != '0' and H % 8 == 0 and W % 32 == 0
+
+
+def unet_tail(src0, src1, B, H, W, filt, bias, gamma, beta, w_out, b_out, seq_len, conv, pred, logits=None, eps=1e-3):
+    """Inference tail of the U-Net (avsi_unet_tail_f32): 3 x 3 convolution 1 + 16 -> 1 with its batch statistics, then batch
+    norm + LeakyReLU + the 1 x 1 output convolution + the sequence mask in one pass.  conv / pred / logits: [B*H*W] floats."""
+    _lib.require_cuda(src0, src1, filt, conv, pred, logits, seq_len)
+    L = _lib.lib()
+    if seq_len.dtype != torch.int64 or not seq_len.is_contiguous():
+        raise _lib.AvsiError("unet_tail: seq_len must be a contiguous int64 device tensor")
+    ws = _workspace(pred.device, L.avsi_unet_tail_workspace_bytes(B, H, W))
+    _lib.check(L.avsi_unet_tail_f32(_lib.ptr(src0), src0.stride(0), _lib.ptr(src1), src1.stride(0), B, H, W, _lib.ptr(filt),
+                                    filt.stride(0), _lib.ptr(bias), _lib.ptr(gamma), _lib.ptr(beta), float(eps), _lib.ptr(w_out),
+                                    _lib.ptr(b_out), _lib.ptr(seq_len), _lib.ptr(conv), _lib.ptr(logits), _lib.ptr(pred),
+                                    _lib.ptr(ws), ws.numel() * 4, _lib.stream_ptr()), "avsi_unet_tail_f32")
+    return pred
 
 
 def im2col(src0, c0, src1, c1, B, H, W, k, col, kc):

@@ -329,7 +329,13 @@ class UNetFConvModel(object):
             ops.conv2d_thin_relu_pool(src0, B, H, W, k, v.p(name + '/w'), v.p(name + '/b'), pooled, cout)
             return pooled
         conv = self._buf(name + '/conv', (R, ld))
-        if ops.conv2d_thin_mfma_supported(k, c0, c1, cout, H, W):
+        st = None
+        if bn and ops.conv2d_bn_supported(k, c0, c1, cout, B, H, W, ld):
+            # batch statistics from the convolution's own epilogue (per-tile partial sums + one small finishing launch): no
+            # pass over the output
+            st = (self._buf(name + '/mean', (ld,)), self._buf(name + '/rstd', (ld,)))
+            ops.conv2d_bn(src0, c0, src1, c1, B, H, W, k, v.p(name + '/w'), v.p(name + '/b'), conv, cout, st[0], st[1])
+        elif ops.conv2d_thin_mfma_supported(k, c0, c1, cout, H, W):
             # few channels at high resolution: 16-wide MFMA from an LDS patch (the 128 x 32 GEMM tile wastes half of it)
             ops.conv2d_thin_mfma(src0, c0, src1, c1, B, H, W, k, v.p(name + '/w'), v.p(name + '/b'), conv, cout)
         elif ops.conv2d_supported(c0, c1):
@@ -341,8 +347,7 @@ class UNetFConvModel(object):
             col = self._buf('col', (self._col_floats,))[: R * kc].view(R, kc)
             ops.im2col(src0, c0, src1, c1, B, H, W, k, col, kc)
             ops.gemm(col, v.p(name + '/w'), out=conv, n=cout, bias=v.p(name + '/b'))
-        st = None
-        if bn:
+        if bn and st is None:
             st = (self._buf(name + '/mean', (ld,)), self._buf(name + '/rstd', (ld,)))
             ops.colstats(conv, cout, st[0], st[1])
         bn_args = (*(st or (None, None)), v.p(name + '/bn/gamma') if bn else None, v.p(name + '/bn/beta') if bn else None)
@@ -374,21 +379,45 @@ class UNetFConvModel(object):
             c['pool'][name] = pooled
             h, H, W, ch = pooled, H // 2, W // 2, co
             skips.append((pooled, co, H, W))
+        keep = bool(self.is_training) or bool(getattr(self, '_keep_for_backward', False))
+        fused_tail = not keep and ops.unet_tail_supported(T, F) and c['x0'].stride(0) == 1
         for i, (k, ci, co) in enumerate(DECODER):
             name = 'd%d' % (i + 1)
             skip, cs, Hs, Ws = skips[5 - i]
+            if fused_tail and name == 'd6':
+                break
             h = self._conv_fwd(name, k, co, True, 2, skip, cs, h, ch, B, Hs, Ws)
             H, W, ch = Hs, Ws, co
-        logits = self._conv_fwd('out', 1, 1, False, 0, h, 1, None, 0, B, T, F)
         seq = self._seq_dev
+        if fused_tail:
+            # inference form: the last two layers and the sequence mask are one call -- the 17 -> 1 convolution leaves its
+            # batch statistics behind, then ONE pass applies batch norm, LeakyReLU, the 1 x 1 output convolution and the mask
+            # (five passes over the full-resolution tensor before: normalise, convolve, mask, two copies)
+            c['tail'] = (h, B, T, F)
+            c['pred'] = self._tail(False)
+            return
+        logits = self._conv_fwd('out', 1, 1, False, 0, h, 1, None, 0, B, T, F)
         rowmask = (torch.arange(T, device=self.device)[None, :] < seq[:, None]).to(torch.float32)
         c['rowmask'] = rowmask
         c['inference'] = logits[:, 0].reshape(B, T, F)
         c['pred'] = (c['inference'] * rowmask[:, :, None]).contiguous()
 
+    def _tail(self, want_logits):
+        c, v = self._cache, self.variables
+        h, B, T, F = c['tail']
+        pred = torch.empty((B, T, F), dtype=torch.float32, device=self.device)       # a result: never a recycled buffer
+        logits = torch.empty((B, T, F), dtype=torch.float32, device=self.device) if want_logits else None
+        ops.unet_tail(c['x0'], h, B, T, F, v.p('d6/w'), v.p('d6/b'), v.p('d6/bn/gamma'), v.p('d6/bn/beta'), v.p('out/w'),
+                      v.p('out/b'), self._seq_dev, self._buf('tail/conv', (B * T * F,), zero=False), pred, logits)
+        if want_logits:
+            c['inference'] = logits
+        return pred
+
     @property
     def inference(self):
         self._forward()
+        if 'inference' not in self._cache:          # the fused inference tail writes the un-masked logits on request only
+            self._tail(True)
         return self._cache['inference']
 
     @property

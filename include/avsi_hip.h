@@ -477,6 +477,16 @@ int avsi_conv2d_splitk_suggest(int B, int H, int W, int k, int C0, int C1, int C
 int avsi_conv2d_splitk_f32(const float* src0, int C0, int ld0, const float* src1_coarse, int C1, int ld1, int B, int H,
                            int W, int k, const float* filter, int ldf, const float* bias, int Cout, float* out, int ldo,
                            const float* zeros64, int splits, void* workspace, size_t workspace_bytes, void* stream);
+/* Inference tail of the U-Net in one call: d6 = conv3x3(concat(src0 [1 channel], up2x(src1 [16 channels])), 17 -> 1) with the
+ * batch statistics of its one channel taken in the convolution's epilogue, then one pass: batch norm (gamma, beta, eps) +
+ * LeakyReLU(0.2) (unet_layers.py:33-35) + the 1 x 1 output convolution (w_out[0], b_out[0]: models.py:607) + the sequence
+ * mask of `prediction` (seq_len int64 [B], frames >= seq_len[b] zeroed: models.py:609-615).  conv [B*H*W] is scratch,
+ * logits [B*H*W] (the un-masked `inference`) may be NULL, pred [B*H*W].  H % 8 == 0, W % 32 == 0. */
+size_t avsi_unet_tail_workspace_bytes(int B, int H, int W);
+int avsi_unet_tail_f32(const float* src0, int ld0, const float* src1_coarse, int ld1, int B, int H, int W,
+                       const float* filter, int ldf, const float* bias, const float* gamma, const float* beta, float eps,
+                       const float* w_out, const float* b_out, const long long* seq_len, float* conv, float* logits,
+                       float* pred, void* workspace, size_t workspace_bytes, void* stream);
 /* Direct form for the thin full-resolution layers no MFMA shape fits: (k, C0, C1, Cout) in
  * {(7, 1, 0, 16), (3, 1, 16, 1), (1, 1, 0, 1)} (unet_layers.py / models.py:592,605,607);
  * AVSI_ERR_UNSUPPORTED for anything else. */
@@ -522,6 +532,15 @@ int avsi_colstats_f32(const float* x, int64_t R, int C, int ld, float eps, float
  * the full-resolution activation (training keeps it for the backward pass).  ld % 4 == 0, 16-byte aligned. */
 int avsi_bn_act_pool_f32(const float* x, int B, int H, int W, int C, int ld, const float* mean, const float* rstd,
                          const float* gamma, const float* beta, int act, float* y, float* pooled, void* stream);
+/* Convolution (operands as avsi_conv2d_f32) + the batch statistics of its output, tf.layers.batch_normalization(training=True)
+ * (unet_layers.py:14,33): mean[Cout] and rstd[Cout] = 1 / sqrt(var + eps) come from partial sums the convolution's own
+ * epilogue leaves per output tile (deterministic order) and one small finishing launch -- no pass over the output.  Takes the
+ * 16-wide-MFMA route where avsi_conv2d_thin_mfma_supported says so, the implicit GEMM otherwise (same support rules). */
+size_t avsi_conv2d_bn_workspace_bytes(int B, int H, int W, int k, int C0, int C1, int Cout);
+int avsi_conv2d_bn_f32(const float* src0, int C0, int ld0, const float* src1_coarse, int C1, int ld1, int B, int H, int W,
+                       int k, const float* filter, int ldf, const float* bias, int Cout, float* out, int ldo,
+                       const float* zeros64, float eps, float* mean, float* rstd, void* workspace, size_t workspace_bytes,
+                       void* stream);
 /* Few-channel convolutions at high resolution on the 16-wide fp32 MFMA, input patch and filter in LDS (same operands as
  * avsi_conv2d_f32): the U-Net's decoder layer 16 + 32 -> 16 (3 x 3) and encoder layer 16 -> 32 (5 x 5); H % 4 == 0,
  * W % 32 == 0.  avsi_conv2d_thin_mfma_supported returns 1 for the shapes it takes. */

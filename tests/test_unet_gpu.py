@@ -361,6 +361,9 @@ def test_inference_model_fused_layers_match_training_form(mods):
     pt, pi = mt.prediction.cpu().numpy(), mi.prediction.cpu().numpy()
     assert 'e1' not in mi._cache['saved'] and mi._cache['saved']['e2']['y'] is None      # nothing kept
     assert np.abs(pt - pi).max() < 1e-5
+    assert 'inference' not in mi._cache                       # the fused tail wrote the masked prediction only ...
+    assert np.abs(mi.inference.cpu().numpy() - mt.inference.cpu().numpy()).max() < 1e-5      # ... the logits on request
+    assert np.all(pi[2, T - 5:] == 0) and np.abs(mi.inference.cpu().numpy()[2, T - 5:]).max() > 0
     assert float(mi.loss_func) == pytest.approx(float(mt.loss_func), rel=1e-6)
     st = OF.get_stft(wav, window_size=16, step_size=8, n_fft=256)[:, :, :128]
     ref_norm = (OF.get_spectrogram(st, log=True) - mean) / std
@@ -477,3 +480,38 @@ def test_training_resumes_after_a_validation_pass_that_captured_a_graph(monkeypa
     assert getattr(m_val, '_graph', None) is None
     assert plain == val and m_val.global_step == 4
     assert torch.equal(m_plain.variables.flat, m_val.variables.flat)
+
+
+@pytest.mark.parametrize("k,c0,c1,cout,B,H,W", [(3, 16, 32, 16, 3, 64, 64), (5, 16, 0, 32, 2, 64, 64),       # 16-wide MFMA route
+                                               (3, 32, 64, 32, 3, 8, 16), (5, 32, 0, 64, 2, 32, 32), (3, 128, 128, 128, 5, 4, 6),
+                                               (3, 64, 0, 128, 1, 16, 16)])                                # implicit GEMM, N tiles 32 / 64 / 128
+def test_conv_with_statistics_from_its_epilogue(k, c0, c1, cout, B, H, W):
+    """avsi_conv2d_bn_f32: the same output as the plain convolution of the same route, bit for bit, and the batch statistics
+    of that output (tf.layers.batch_normalization(training=True), unet_layers.py:14,33) equal to a float64 mean / variance
+    over it -- taken from per-tile partial sums in the convolution's epilogue, not from a pass over the output."""
+    import avsi_amd  # noqa: F401
+    from avsi_amd import ops
+    g = torch.Generator(device='cuda')
+    g.manual_seed(k * 100 + cout)
+    ld0, ld1 = -(-c0 // 4) * 4, -(-max(c1, 1) // 4) * 4
+    s0 = torch.randn(B * H * W, ld0, generator=g, device='cuda')
+    s1 = torch.randn(B * (H // 2) * (W // 2), ld1, generator=g, device='cuda') if c1 else None
+    filt = torch.randn(k * k * (c0 + c1), cout, generator=g, device='cuda') * 0.05
+    bias = torch.randn(cout, generator=g, device='cuda')
+    plain = torch.zeros(B * H * W, cout, device='cuda')
+    if ops.conv2d_thin_mfma_supported(k, c0, c1, cout, H, W):
+        ops.conv2d_thin_mfma(s0, c0, s1, c1, B, H, W, k, filt, bias, plain, cout)
+    else:
+        ops.conv2d(s0, c0, s1, c1, B, H, W, k, filt, bias, plain, cout)
+    out = torch.zeros_like(plain)
+    mean, rstd = torch.zeros(cout, device='cuda'), torch.zeros(cout, device='cuda')
+    ops.conv2d_bn(s0, c0, s1, c1, B, H, W, k, filt, bias, out, cout, mean, rstd, eps=1e-3)
+    assert torch.equal(out, plain)
+    x = plain.double()
+    m = x.mean(dim=0)
+    var = (x * x).mean(dim=0) - m * m
+    np.testing.assert_allclose(mean.cpu().numpy(), m.cpu().numpy(), rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(rstd.cpu().numpy(), (1.0 / torch.sqrt(var + 1e-3)).cpu().numpy(), rtol=1e-5)
+    mean2, rstd2 = torch.zeros(cout, device='cuda'), torch.zeros(cout, device='cuda')
+    ops.conv2d_bn(s0, c0, s1, c1, B, H, W, k, filt, bias, out, cout, mean2, rstd2, eps=1e-3)
+    assert torch.equal(mean, mean2) and torch.equal(rstd, rstd2)           # deterministic
