@@ -102,7 +102,7 @@ PROTOTYPES = {
     "avsi_bn_act_pool_f32": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
                                      c_void_p, c_void_p, c_void_p]),
     "avsi_conv2d_bn_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int, c_int, c_int]),
-    "avsi_conv2d_bn_f32": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_int,
+    "avsi_conv2d_bn_f32": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int,
                                    c_void_p, c_int, c_void_p, c_int, c_void_p, c_float, c_void_p, c_void_p, c_void_p, c_size_t,
                                    c_void_p]),
     "avsi_conv2d_thin_mfma_supported": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int]),
@@ -151,7 +151,7 @@ PROTOTYPES = {
     "avsi_conv2d_splitk_f32": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p,
                                        c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_size_t, c_void_p]),
     "avsi_unet_tail_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
-    "avsi_unet_tail_f32": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p,
+    "avsi_unet_tail_f32": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p,
                                    c_void_p, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                    c_size_t, c_void_p]),
     "avsi_conv2d_thin_f32": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_int,

@@ -230,12 +230,20 @@ __global__ __launch_bounds__(256) void conv7_c1_mfma_kernel(const float* __restr
 // the filter); D[pixel 4 (l / 16) + i][channel l % 16].
 // STATS: the block also leaves per-channel sums and sums of squares of its 128 output pixels in part[blk][2][COUT]
 // (batch-norm statistics taken where the accumulators are; fixed reduction order: deterministic).
-template <int KS, int C0, int C1, int COUT, bool STATS>
+// BN1: s1 is the RAW convolution output of the layer below; its batch norm + LeakyReLU(0.2) (bn1 = mean, rstd, gamma, beta)
+// are applied while the patch is staged -- that layer's own normalise / activate pass over its output does not exist.
+struct Bn4 {
+    const float* mean;
+    const float* rstd;
+    const float* gamma;
+    const float* beta;
+};
+template <int KS, int C0, int C1, int COUT, bool STATS, bool BN1>
 __global__ __launch_bounds__(256) void thin_mfma_conv_kernel(const float* __restrict__ s0, int ld0, const float* __restrict__ s1,
                                                              int ld1, const float* __restrict__ filt, int ldf,
                                                              const float* __restrict__ bias, float* __restrict__ out, int ldo,
                                                              int H, int W, const float* __restrict__ zeros,
-                                                             float* __restrict__ part) {
+                                                             float* __restrict__ part, const Bn4 bn1) {
     constexpr int P = KS / 2, CT = C0 + C1, CP = CT + 1, TH = 4, TW = 32, PH = TH + KS - 1, PWD = TW + KS - 1;
     constexpr int NCG = COUT / 16, KSTEPS = KS * KS * CT / 4, CQ = CT / 4;
     extern __shared__ __attribute__((aligned(16))) float smem_f[];
@@ -246,6 +254,12 @@ __global__ __launch_bounds__(256) void thin_mfma_conv_kernel(const float* __rest
     const int tile = blockIdx.x % (tiles_w * tiles_h), b = blockIdx.x / (tiles_w * tiles_h);
     const int h0 = (tile / tiles_w) * TH, w0 = (tile % tiles_w) * TW;
     const int H2 = H >> 1, W2 = W >> 1;
+    __shared__ float s_sc[BN1 ? C1 : 1], s_sh[BN1 ? C1 : 1];
+    if (BN1 && tid < C1) {
+        const float sc = bn1.gamma[tid] * bn1.rstd[tid];
+        s_sc[tid] = sc, s_sh[tid] = bn1.beta[tid] - bn1.mean[tid] * sc;
+    }
+    if (BN1) __syncthreads();
     // filter -> LDS (rows of COUT floats, 16-byte pieces)
     for (int i = tid; i < KS * KS * CT * (COUT / 4); i += 256) {
         const int row = i / (COUT / 4), q = i - row * (COUT / 4);
@@ -262,7 +276,12 @@ __global__ __launch_bounds__(256) void thin_mfma_conv_kernel(const float* __rest
             if (c4 < C0) src = s0 + (((int64_t)b * H + hh) * W + ww) * ld0 + c4;
             else src = s1 + (((int64_t)b * H2 + (hh >> 1)) * W2 + (ww >> 1)) * ld1 + (c4 - C0);
         }
-        const float4 v = *reinterpret_cast<const float4*>(src);
+        float4 v = *reinterpret_cast<const float4*>(src);
+        if (BN1 && ok && c4 >= C0) {
+            const int c = c4 - C0;
+            v.x = bn_act_one(v.x, s_sc[c], s_sh[c], 2), v.y = bn_act_one(v.y, s_sc[c + 1], s_sh[c + 1], 2);
+            v.z = bn_act_one(v.z, s_sc[c + 2], s_sh[c + 2], 2), v.w = bn_act_one(v.w, s_sc[c + 3], s_sh[c + 3], 2);
+        }
         float* d = patch + pix * CP + c4;
         d[0] = v.x, d[1] = v.y, d[2] = v.z, d[3] = v.w;
     }
@@ -393,11 +412,11 @@ __global__ __launch_bounds__(TPB) void direct_conv_kernel(const float* __restric
 // every coarse pixel 36 times through the L1 (0.31 ms at batch 512 for 2.6 GFLOP).
 // STATS: the block also leaves the sum and the sum of squares of its 256 outputs in part[2 blk], part[2 blk + 1] (fixed
 // reduction tree: deterministic) -- the batch statistics of the layer's one channel without a pass over its output.
-template <bool STATS>
+template <bool STATS, bool BN1>
 __global__ __launch_bounds__(256) void conv3_c17_out1_kernel(const float* __restrict__ s0, int ld0, const float* __restrict__ s1,
                                                              int ld1, const float* __restrict__ filt, int ldf,
                                                              const float* __restrict__ bias, float* __restrict__ out, int ldo,
-                                                             int H, int W, float* __restrict__ part) {
+                                                             int H, int W, float* __restrict__ part, const Bn4 bn1) {
     constexpr int TH = 8, TW = 32, FH = TH + 2, FW = TW + 2, CH = TH / 2 + 2, CW = TW / 2 + 2, CP = 20, WP = 20;
     __shared__ float fine[FH * FW];
     __shared__ __attribute__((aligned(16))) float coarse[CH * CW * CP];     // pitch 20: conflict-free 16-byte reads
@@ -412,6 +431,13 @@ __global__ __launch_bounds__(256) void conv3_c17_out1_kernel(const float* __rest
         const int tap = tid / 17, c = tid - tap * 17;
         wts[tap * WP + (c == 0 ? 0 : 3 + c)] = filt[(int64_t)(tap * 17 + c) * ldf];
     }
+    __shared__ float s_sc[16], s_sh[16];
+    if (BN1 && tid >= 192 && tid < 208) {       // (the raw 16-channel output of the layer below: see thin_mfma_conv_kernel)
+        const int c = tid - 192;
+        const float sc = bn1.gamma[c] * bn1.rstd[c];
+        s_sc[c] = sc, s_sh[c] = bn1.beta[c] - bn1.mean[c] * sc;
+    }
+    if (BN1) __syncthreads();
     for (int i = tid; i < FH * FW; i += 256) {
         const int r = i / FW, c = i - r * FW;
         const int hh = h0 + r - 1, ww = w0 + c - 1;
@@ -423,7 +449,12 @@ __global__ __launch_bounds__(256) void conv3_c17_out1_kernel(const float* __rest
         const int r = pix / CW, c = pix - r * CW;
         const int hh = ch0 + r, ww = cw0 + c;
         const bool ok = hh >= 0 && hh < H2 && ww >= 0 && ww < W2;
-        const float4 v = *reinterpret_cast<const float4*>(ok ? s1 + (((int64_t)b * H2 + hh) * W2 + ww) * ld1 + 4 * q : g_zero_pixel);
+        float4 v = *reinterpret_cast<const float4*>(ok ? s1 + (((int64_t)b * H2 + hh) * W2 + ww) * ld1 + 4 * q : g_zero_pixel);
+        if (BN1 && ok) {
+            const int c = 4 * q;
+            v.x = bn_act_one(v.x, s_sc[c], s_sh[c], 2), v.y = bn_act_one(v.y, s_sc[c + 1], s_sh[c + 1], 2);
+            v.z = bn_act_one(v.z, s_sc[c + 2], s_sh[c + 2], 2), v.w = bn_act_one(v.w, s_sc[c + 3], s_sh[c + 3], 2);
+        }
         *reinterpret_cast<float4*>(coarse + pix * CP + 4 * q) = v;
     }
     __syncthreads();
@@ -776,9 +807,20 @@ __global__ __launch_bounds__(64) void colpair_final_kernel(const float* __restri
                                                            float* __restrict__ out1) {
     const int c = blockIdx.x, lane = threadIdx.x;
     double s1 = 0.0, s2 = 0.0;
-    for (int p = lane; p < parts; p += 64) {
-        s1 += (double)part[((int64_t)p * 2 + 0) * C + c];
-        s2 += (double)part[((int64_t)p * 2 + 1) * C + c];
+    // eight partials per lane and trip, their sixteen loads in flight together (one by one a lane's strided loads were
+    // sixteen memory latencies in a row at 512 partials: 16 us per launch, eleven launches per U-Net step); added in index order
+    for (int p0 = lane; p0 < parts; p0 += 512) {
+        float a[8], b[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int p = p0 + 64 * u;
+            const int pc = p < parts ? p : p0;
+            a[u] = part[((int64_t)pc * 2 + 0) * C + c];
+            b[u] = part[((int64_t)pc * 2 + 1) * C + c];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            if (p0 + 64 * u < parts) s1 += (double)a[u], s2 += (double)b[u];
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
@@ -998,8 +1040,8 @@ extern "C" int avsi_conv2d_thin_f32(const float* src0, int C0, int ld0, const fl
         hipLaunchKernelGGL((direct_conv_kernel<7, 1, 0, 16>), grid, block, 0, st, src0, ld0, src1_coarse, ld1, filter, ldf, bias,
                            out, ldo, B, H, W);
     else if (k == 3 && C0 == 1 && C1 == 16 && Cout == 1 && H % 8 == 0 && W % 32 == 0)
-        hipLaunchKernelGGL(conv3_c17_out1_kernel<false>, dim3(B * (H / 8) * (W / 32)), dim3(256), 0, st, src0, ld0, src1_coarse, ld1,
-                           filter, ldf, bias, out, ldo, H, W, (float*)nullptr);
+        hipLaunchKernelGGL((conv3_c17_out1_kernel<false, false>), dim3(B * (H / 8) * (W / 32)), dim3(256), 0, st, src0, ld0, src1_coarse,
+                           ld1, filter, ldf, bias, out, ldo, H, W, (float*)nullptr, Bn4{});
     else if (k == 3 && C0 == 1 && C1 == 16 && Cout == 1)
         hipLaunchKernelGGL((direct_conv_kernel<3, 1, 16, 1>), grid, block, 0, st, src0, ld0, src1_coarse, ld1, filter, ldf, bias,
                            out, ldo, B, H, W);
@@ -1019,10 +1061,10 @@ extern "C" size_t avsi_unet_tail_workspace_bytes(int B, int H, int W) {
     return (size_t)B * (H / 8) * (W / 32) * 2 * sizeof(float) + 2 * sizeof(float);
 }
 
-extern "C" int avsi_unet_tail_f32(const float* src0, int ld0, const float* src1_coarse, int ld1, int B, int H, int W,
-                                  const float* filter, int ldf, const float* bias, const float* gamma, const float* beta, float eps,
-                                  const float* w_out, const float* b_out, const long long* seq_len, float* conv, float* logits,
-                                  float* pred, void* workspace, size_t workspace_bytes, void* stream) {
+extern "C" int avsi_unet_tail_f32(const float* src0, int ld0, const float* src1_coarse, int ld1, const float* const* src1_bn, int B,
+                                  int H, int W, const float* filter, int ldf, const float* bias, const float* gamma,
+                                  const float* beta, float eps, const float* w_out, const float* b_out, const long long* seq_len,
+                                  float* conv, float* logits, float* pred, void* workspace, size_t workspace_bytes, void* stream) {
     if (!src0 || !src1_coarse || !filter || !gamma || !beta || !w_out || !seq_len || !conv || !pred || B <= 0 || ld0 < 1 || ld1 < 16 ||
         ldf < 1)
         return AVSI_ERR_INVALID_ARG;
@@ -1037,8 +1079,14 @@ extern "C" int avsi_unet_tail_f32(const float* src0, int ld0, const float* src1_
     const hipStream_t st = (hipStream_t)stream;
     const int64_t R = (int64_t)B * H * W;
     avsi_clear_error();
-    hipLaunchKernelGGL(conv3_c17_out1_kernel<true>, dim3(blocks), dim3(256), 0, st, src0, ld0, src1_coarse, ld1, filter, ldf, bias,
-                       conv, 1, H, W, part);
+    if (src1_bn) {
+        if (!src1_bn[0] || !src1_bn[1] || !src1_bn[2] || !src1_bn[3]) return AVSI_ERR_INVALID_ARG;
+        hipLaunchKernelGGL((conv3_c17_out1_kernel<true, true>), dim3(blocks), dim3(256), 0, st, src0, ld0, src1_coarse, ld1, filter, ldf,
+                           bias, conv, 1, H, W, part, Bn4{src1_bn[0], src1_bn[1], src1_bn[2], src1_bn[3]});
+    } else {
+        hipLaunchKernelGGL((conv3_c17_out1_kernel<true, false>), dim3(blocks), dim3(256), 0, st, src0, ld0, src1_coarse, ld1, filter, ldf,
+                           bias, conv, 1, H, W, part, Bn4{});
+    }
     hipLaunchKernelGGL(colpair_final_kernel<0>, dim3(1), dim3(64), 0, st, (const float*)part, blocks, 1, R, eps, mean, mean + 1);
     hipLaunchKernelGGL(unet_tail_kernel, dim3(grid_for(R / 4)), dim3(TPB), 0, st, (const float*)conv, (const float*)mean,
                        (const float*)(mean + 1), gamma, beta, w_out, b_out, seq_len, logits, pred, R / 4, H, W);
@@ -1191,18 +1239,20 @@ extern "C" int avsi_conv2d_thin_mfma_supported(int k, int C0, int C1, int Cout, 
 
 static int conv2d_thin_mfma_launch(const float* src0, int C0, int ld0, const float* src1_coarse, int C1, int ld1, int B, int H,
                                    int W, int k, const float* filter, int ldf, const float* bias, int Cout, float* out,
-                                   int ldo, const float* zeros64, float* part, void* stream);
+                                   int ldo, const float* zeros64, float* part, const float* const* src1_bn, void* stream);
 
 extern "C" int avsi_conv2d_thin_mfma_f32(const float* src0, int C0, int ld0, const float* src1_coarse, int C1, int ld1, int B, int H,
                                          int W, int k, const float* filter, int ldf, const float* bias, int Cout, float* out,
                                          int ldo, const float* zeros64, void* stream) {
     return conv2d_thin_mfma_launch(src0, C0, ld0, src1_coarse, C1, ld1, B, H, W, k, filter, ldf, bias, Cout, out, ldo, zeros64,
-                                   nullptr, stream);
+                                   nullptr, nullptr, stream);
 }
 
 static int conv2d_thin_mfma_launch(const float* src0, int C0, int ld0, const float* src1_coarse, int C1, int ld1, int B, int H,
                                    int W, int k, const float* filter, int ldf, const float* bias, int Cout, float* out,
-                                   int ldo, const float* zeros64, float* part, void* stream) {
+                                   int ldo, const float* zeros64, float* part, const float* const* src1_bn, void* stream) {
+    if (src1_bn && (k != 3 || !src1_bn[0] || !src1_bn[1] || !src1_bn[2] || !src1_bn[3])) return AVSI_ERR_UNSUPPORTED;
+    const Bn4 bn1 = src1_bn ? Bn4{src1_bn[0], src1_bn[1], src1_bn[2], src1_bn[3]} : Bn4{};
     if (!src0 || !filter || !out || !zeros64 || B <= 0 || (C1 && !src1_coarse) || ldf < Cout || ldo < Cout || ld0 < C0 ||
         (C1 && ld1 < C1))
         return AVSI_ERR_INVALID_ARG;
@@ -1213,21 +1263,23 @@ static int conv2d_thin_mfma_launch(const float* src0, int C0, int ld0, const flo
     const dim3 grid(B * (H / 4) * (W / 32)), block(256);
     const hipStream_t st = (hipStream_t)stream;
     avsi_clear_error();
-#define AVSI_THIN_MFMA(KS, CA, CB, CO, ST, LDS)                                                                                 \
+#define AVSI_THIN_MFMA(KS, CA, CB, CO, ST, BN, LDS)                                                                             \
     do {                                                                                                                      \
-        (void)hipFuncSetAttribute((const void*)thin_mfma_conv_kernel<KS, CA, CB, CO, ST>,                                      \
+        (void)hipFuncSetAttribute((const void*)thin_mfma_conv_kernel<KS, CA, CB, CO, ST, BN>,                                  \
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)(LDS));                                     \
-        hipLaunchKernelGGL((thin_mfma_conv_kernel<KS, CA, CB, CO, ST>), grid, block, (LDS), st, src0, ld0, src1_coarse, ld1,   \
-                           filter, ldf, bias, out, ldo, H, W, zeros64, part);                                                 \
+        hipLaunchKernelGGL((thin_mfma_conv_kernel<KS, CA, CB, CO, ST, BN>), grid, block, (LDS), st, src0, ld0, src1_coarse,    \
+                           ld1, filter, ldf, bias, out, ldo, H, W, zeros64, part, bn1);                                       \
     } while (0)
     if (k == 3) {
         constexpr size_t lds = ((size_t)6 * 34 * 49 + 9 * 48 * 16) * 4;
-        if (part) AVSI_THIN_MFMA(3, 16, 32, 16, true, lds);
-        else AVSI_THIN_MFMA(3, 16, 32, 16, false, lds);
+        if (part && src1_bn) AVSI_THIN_MFMA(3, 16, 32, 16, true, true, lds);
+        else if (part) AVSI_THIN_MFMA(3, 16, 32, 16, true, false, lds);
+        else if (src1_bn) AVSI_THIN_MFMA(3, 16, 32, 16, false, true, lds);
+        else AVSI_THIN_MFMA(3, 16, 32, 16, false, false, lds);
     } else {
         constexpr size_t lds = ((size_t)8 * 36 * 17 + 25 * 16 * 32) * 4;
-        if (part) AVSI_THIN_MFMA(5, 16, 0, 32, true, lds);
-        else AVSI_THIN_MFMA(5, 16, 0, 32, false, lds);
+        if (part) AVSI_THIN_MFMA(5, 16, 0, 32, true, false, lds);
+        else AVSI_THIN_MFMA(5, 16, 0, 32, false, false, lds);
     }
 #undef AVSI_THIN_MFMA
     return avsi_launch_status();
@@ -1239,6 +1291,27 @@ int avsi_conv2d_launch(const float* src0, int C0, int ld0, const float* src1_coa
                        const float* filter, int ldf, const float* bias, int Cout, float* out, int ldo, const float* zeros64,
                        float* stats, void* stream);
 
+// parts rows of `row` floats -> G rows: row g sums rows g, g + G, ... in that order (deterministic).  The per-tile partial
+// statistics of a convolution are thousands of rows (16384 for the 64 x 64 layers at 512 clips); the one-wave-per-channel
+// finishing kernel walks them with a stride of a whole row -- every access its own cache line, 0.25 ms for those layers --
+// so they are folded first, rows read whole and coalesced.
+__global__ __launch_bounds__(256) void fold_partials_kernel(const float* __restrict__ part, int parts, int row, float* __restrict__ out) {
+    const int G = gridDim.x, g = blockIdx.x;
+    const int rpp = 256 / row;                                // rows a pass of the block covers (row <= 256)
+    const int e = threadIdx.x % row, rl = threadIdx.x / row;
+    __shared__ float red[256];
+    float s = 0.f;
+    if (rl < rpp)
+        for (int p = g + rl * G; p < parts; p += rpp * G) s += part[(int64_t)p * row + e];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    if (threadIdx.x < row) {
+        float t = 0.f;
+        for (int j = 0; j < rpp; ++j) t += red[j * row + threadIdx.x];
+        out[(int64_t)g * row + threadIdx.x] = t;
+    }
+}
+
 // Convolution + the batch statistics of its output (tf.layers.batch_normalization(training=True), unet_layers.py:14,33) in one
 // call: the convolution's epilogue leaves per-tile partial sums, one small launch turns them into mean and 1 / sqrt(var + eps)
 // -- no pass over the output.  Route: the 16-wide-MFMA kernel where it applies, else the implicit GEMM.
@@ -1246,14 +1319,15 @@ static int conv_bn_parts(int B, int H, int W, int k, int C0, int C1, int Cout) {
     if (avsi_conv2d_thin_mfma_supported(k, C0, C1, Cout, H, W)) return B * (H / 4) * (W / 32);
     return avsi_conv2d_stats_parts(B, H, W, Cout);
 }
+constexpr int FOLD_ROWS = 256;
 extern "C" size_t avsi_conv2d_bn_workspace_bytes(int B, int H, int W, int k, int C0, int C1, int Cout) {
     if (B <= 0 || H <= 0 || W <= 0 || Cout <= 0) return 0;
-    return (size_t)conv_bn_parts(B, H, W, k, C0, C1, Cout) * 2 * (size_t)Cout * sizeof(float);
+    return ((size_t)conv_bn_parts(B, H, W, k, C0, C1, Cout) + FOLD_ROWS) * 2 * (size_t)Cout * sizeof(float);
 }
-extern "C" int avsi_conv2d_bn_f32(const float* src0, int C0, int ld0, const float* src1_coarse, int C1, int ld1, int B, int H, int W,
-                                  int k, const float* filter, int ldf, const float* bias, int Cout, float* out, int ldo,
-                                  const float* zeros64, float eps, float* mean, float* rstd, void* workspace,
-                                  size_t workspace_bytes, void* stream) {
+extern "C" int avsi_conv2d_bn_f32(const float* src0, int C0, int ld0, const float* src1_coarse, int C1, int ld1,
+                                  const float* const* src1_bn, int B, int H, int W, int k, const float* filter, int ldf,
+                                  const float* bias, int Cout, float* out, int ldo, const float* zeros64, float eps, float* mean,
+                                  float* rstd, void* workspace, size_t workspace_bytes, void* stream) {
     if (!mean || !rstd || B <= 0 || H <= 0 || W <= 0 || Cout <= 0) return AVSI_ERR_INVALID_ARG;
     if (!workspace || workspace_bytes < avsi_conv2d_bn_workspace_bytes(B, H, W, k, C0, C1, Cout)) return AVSI_ERR_WORKSPACE;
     float* part = static_cast<float*>(workspace);
@@ -1261,13 +1335,23 @@ extern "C" int avsi_conv2d_bn_f32(const float* src0, int C0, int ld0, const floa
     int rc;
     if (avsi_conv2d_thin_mfma_supported(k, C0, C1, Cout, H, W))
         rc = conv2d_thin_mfma_launch(src0, C0, ld0, src1_coarse, C1, ld1, B, H, W, k, filter, ldf, bias, Cout, out, ldo, zeros64, part,
-                                     stream);
+                                     src1_bn, stream);
+    else if (src1_bn)
+        return AVSI_ERR_UNSUPPORTED;          // the implicit GEMM gathers its operand by DMA: nothing can be applied on the way
     else
         rc = avsi_conv2d_launch(src0, C0, ld0, src1_coarse, C1, ld1, B, H, W, k, filter, ldf, bias, Cout, out, ldo, zeros64, part,
                                 stream);
     if (rc != AVSI_OK) return rc;
-    hipLaunchKernelGGL(colpair_final_kernel<0>, dim3(Cout), dim3(64), 0, (hipStream_t)stream, (const float*)part, parts, Cout,
-                       (int64_t)B * H * W, eps, mean, rstd);
+    const float* fin = part;
+    int nfin = parts;
+    if (parts > 4 * FOLD_ROWS && 2 * Cout <= 256) {
+        float* folded = part + (size_t)parts * 2 * Cout;
+        hipLaunchKernelGGL(fold_partials_kernel, dim3(FOLD_ROWS), dim3(256), 0, (hipStream_t)stream, (const float*)part, parts, 2 * Cout,
+                           folded);
+        fin = folded, nfin = FOLD_ROWS;
+    }
+    hipLaunchKernelGGL(colpair_final_kernel<0>, dim3(Cout), dim3(64), 0, (hipStream_t)stream, fin, nfin, Cout, (int64_t)B * H * W, eps,
+                       mean, rstd);
     return avsi_launch_status();
 }
 

@@ -708,16 +708,27 @@ def conv2d_bn_supported(k, c0, c1, cout, B, H, W, ldo):
     return not (_CONV_SPLITK and ldo == cout and _lib.lib().avsi_conv2d_splitk_suggest(B, H, W, k, c0, c1, cout) > 1)
 
 
-def conv2d_bn(src0, c0, src1, c1, B, H, W, k, filt, bias, out, cout, mean, rstd, eps=1e-3):
-    """out = conv2d(concat(src0, up2x(src1)), filt) + bias AND mean / rstd of its cout channels over all B*H*W rows."""
+def _bn4(src1_bn):
+    """(mean, rstd, gamma, beta) device tensors -> a C array of four pointers (kept alive by the caller's tuple)."""
+    if src1_bn is None:
+        return None
+    _lib.require_cuda(*src1_bn)
+    return (ctypes.c_void_p * 4)(*[t.data_ptr() for t in src1_bn])
+
+
+def conv2d_bn(src0, c0, src1, c1, B, H, W, k, filt, bias, out, cout, mean, rstd, eps=1e-3, src1_bn=None):
+    """out = conv2d(concat(src0, up2x(src1)), filt) + bias AND mean / rstd of its cout channels over all B*H*W rows.
+    src1_bn = (mean, rstd, gamma, beta): src1 is the RAW convolution output of the layer below, normalised and activated
+    (LeakyReLU 0.2) while it is staged (16-wide-MFMA route only)."""
     _lib.require_cuda(src0, src1, filt, out, mean, rstd)
     z = _ZEROS.get(out.device.index)
     if z is None:
         z = _ZEROS[out.device.index] = torch.zeros(64, dtype=torch.float32, device=out.device)
     L = _lib.lib()
     ws = _workspace(out.device, L.avsi_conv2d_bn_workspace_bytes(B, H, W, k, c0, c1, cout))
+    bn4 = _bn4(src1_bn)
     _lib.check(L.avsi_conv2d_bn_f32(_lib.ptr(src0), c0, src0.stride(0) if src0 is not None else 0, _lib.ptr(src1), c1,
-                                    src1.stride(0) if src1 is not None else 0, B, H, W, k, _lib.ptr(filt), filt.stride(0),
+                                    src1.stride(0) if src1 is not None else 0, bn4, B, H, W, k, _lib.ptr(filt), filt.stride(0),
                                     _lib.ptr(bias), cout, _lib.ptr(out), out.stride(0), _lib.ptr(z), float(eps), _lib.ptr(mean),
                                     _lib.ptr(rstd), _lib.ptr(ws), ws.numel() * 4, _lib.stream_ptr()), "avsi_conv2d_bn_f32")
     return out
@@ -762,7 +773,8 @@ def unet_tail_supported(H, W):
     return os.environ.get('AVSI_UNET_TAIL', '1') != '0' and H % 8 == 0 and W % 32 == 0
 
 
-def unet_tail(src0, src1, B, H, W, filt, bias, gamma, beta, w_out, b_out, seq_len, conv, pred, logits=None, eps=1e-3):
+def unet_tail(src0, src1, B, H, W, filt, bias, gamma, beta, w_out, b_out, seq_len, conv, pred, logits=None, eps=1e-3,
+              src1_bn=None):
     """Inference tail of the U-Net (avsi_unet_tail_f32): 3 x 3 convolution 1 + 16 -> 1 with its batch statistics, then batch
     norm + LeakyReLU + the 1 x 1 output convolution + the sequence mask in one pass.  conv / pred / logits: [B*H*W] floats."""
     _lib.require_cuda(src0, src1, filt, conv, pred, logits, seq_len)
@@ -770,7 +782,7 @@ def unet_tail(src0, src1, B, H, W, filt, bias, gamma, beta, w_out, b_out, seq_le
     if seq_len.dtype != torch.int64 or not seq_len.is_contiguous():
         raise _lib.AvsiError("unet_tail: seq_len must be a contiguous int64 device tensor")
     ws = _workspace(pred.device, L.avsi_unet_tail_workspace_bytes(B, H, W))
-    _lib.check(L.avsi_unet_tail_f32(_lib.ptr(src0), src0.stride(0), _lib.ptr(src1), src1.stride(0), B, H, W, _lib.ptr(filt),
+    _lib.check(L.avsi_unet_tail_f32(_lib.ptr(src0), src0.stride(0), _lib.ptr(src1), src1.stride(0), _bn4(src1_bn), B, H, W, _lib.ptr(filt),
                                     filt.stride(0), _lib.ptr(bias), _lib.ptr(gamma), _lib.ptr(beta), float(eps), _lib.ptr(w_out),
                                     _lib.ptr(b_out), _lib.ptr(seq_len), _lib.ptr(conv), _lib.ptr(logits), _lib.ptr(pred),
                                     _lib.ptr(ws), ws.numel() * 4, _lib.stream_ptr()), "avsi_unet_tail_f32")

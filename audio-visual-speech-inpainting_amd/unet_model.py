@@ -28,6 +28,7 @@ from . import _lib, ops, parallel
 from . import audio_processing as ap
 from .blstm_layout import round_up
 
+_DEFER_BN = os.environ.get('AVSI_UNET_DEFER_BN', '1') != '0'
 ENCODER = [(7, 1, 16, False), (5, 16, 32, True), (5, 32, 64, True), (3, 64, 128, True), (3, 128, 128, True),
            (3, 128, 128, True)]
 DECODER = [(3, 256, 128), (3, 256, 128), (3, 192, 64), (3, 96, 32), (3, 48, 16), (3, 17, 1)]
@@ -315,7 +316,7 @@ class UNetFConvModel(object):
         return self._cache['net_inputs']
 
     # ------------------------------------------------------------------ network (models.py:582-607)
-    def _conv_fwd(self, name, k, cout, bn, act, src0, c0, src1, c1, B, H, W, pool=False):
+    def _conv_fwd(self, name, k, cout, bn, act, src0, c0, src1, c1, B, H, W, pool=False, src1_bn=None, defer=False):
         """One layer: convolution, batch statistics, normalisation + activation -- and, for the encoder layers
         (``pool``), the 2 x 2 max pooling in the same pass as the activation.  A model built for inference
         (``is_training=False``) keeps nothing it does not need: the pooled layers never write their full-resolution
@@ -334,7 +335,13 @@ class UNetFConvModel(object):
             # batch statistics from the convolution's own epilogue (per-tile partial sums + one small finishing launch): no
             # pass over the output
             st = (self._buf(name + '/mean', (ld,)), self._buf(name + '/rstd', (ld,)))
-            ops.conv2d_bn(src0, c0, src1, c1, B, H, W, k, v.p(name + '/w'), v.p(name + '/b'), conv, cout, st[0], st[1])
+            ops.conv2d_bn(src0, c0, src1, c1, B, H, W, k, v.p(name + '/w'), v.p(name + '/b'), conv, cout, st[0], st[1],
+                          src1_bn=src1_bn)
+            if defer:
+                # inference form: this layer's normalise + activate pass does not run -- the layer above applies them while it
+                # stages its operand (ops.conv2d_bn / ops.unet_tail with src1_bn)
+                self._cache['saved'][name] = dict(k=k, cout=cout, bn=bn, act=act, conv=conv, stats=st, y=None, kc=kc, ld=ld)
+                return conv, (st[0], st[1], v.p(name + '/bn/gamma'), v.p(name + '/bn/beta'))
         elif ops.conv2d_thin_mfma_supported(k, c0, c1, cout, H, W):
             # few channels at high resolution: 16-wide MFMA from an LDS patch (the 128 x 32 GEMM tile wastes half of it)
             ops.conv2d_thin_mfma(src0, c0, src1, c1, B, H, W, k, v.p(name + '/w'), v.p(name + '/b'), conv, cout)
@@ -381,19 +388,31 @@ class UNetFConvModel(object):
             skips.append((pooled, co, H, W))
         keep = bool(self.is_training) or bool(getattr(self, '_keep_for_backward', False))
         fused_tail = not keep and ops.unet_tail_supported(T, F) and c['x0'].stride(0) == 1
+        pending = None            # (mean, rstd, gamma, beta) of a layer whose batch norm + activation the NEXT layer applies
         for i, (k, ci, co) in enumerate(DECODER):
             name = 'd%d' % (i + 1)
             skip, cs, Hs, Ws = skips[5 - i]
             if fused_tail and name == 'd6':
                 break
-            h = self._conv_fwd(name, k, co, True, 2, skip, cs, h, ch, B, Hs, Ws)
+            # inference form: d4 and d5 leave their output raw when the layer above reads it through registers (the
+            # 16-wide-MFMA route of d5, the fused tail of d6) -- two of the largest normalise / activate passes disappear
+            nk, _, nco = DECODER[i + 1] if i + 1 < len(DECODER) else (0, 0, 0)
+            Hn, Wn = (skips[4 - i][2], skips[4 - i][3]) if i + 1 < len(DECODER) else (0, 0)
+            defer = (not keep and _DEFER_BN and ops.conv2d_bn_supported(k, cs, ch, co, B, Hs, Ws, round_up(co, 4))
+                     and ((name == 'd5' and fused_tail)
+                          or (name == 'd4' and ops.conv2d_thin_mfma_supported(nk, skips[4 - i][1], co, nco, Hn, Wn)
+                              and ops.conv2d_bn_supported(nk, skips[4 - i][1], co, nco, B, Hn, Wn, round_up(nco, 4)))))
+            if pending is not None and not ops.conv2d_bn_supported(k, cs, ch, co, B, Hs, Ws, round_up(co, 4)):
+                raise _lib.AvsiError("internal: a deferred batch norm has no consumer")      # (the test above guarantees one)
+            out = self._conv_fwd(name, k, co, True, 2, skip, cs, h, ch, B, Hs, Ws, src1_bn=pending, defer=defer)
+            h, pending = out if defer else (out, None)
             H, W, ch = Hs, Ws, co
         seq = self._seq_dev
         if fused_tail:
             # inference form: the last two layers and the sequence mask are one call -- the 17 -> 1 convolution leaves its
             # batch statistics behind, then ONE pass applies batch norm, LeakyReLU, the 1 x 1 output convolution and the mask
             # (five passes over the full-resolution tensor before: normalise, convolve, mask, two copies)
-            c['tail'] = (h, B, T, F)
+            c['tail'] = (h, B, T, F, pending)
             c['pred'] = self._tail(False)
             return
         logits = self._conv_fwd('out', 1, 1, False, 0, h, 1, None, 0, B, T, F)
@@ -404,11 +423,12 @@ class UNetFConvModel(object):
 
     def _tail(self, want_logits):
         c, v = self._cache, self.variables
-        h, B, T, F = c['tail']
+        h, B, T, F, pending = c['tail']
         pred = torch.empty((B, T, F), dtype=torch.float32, device=self.device)       # a result: never a recycled buffer
         logits = torch.empty((B, T, F), dtype=torch.float32, device=self.device) if want_logits else None
         ops.unet_tail(c['x0'], h, B, T, F, v.p('d6/w'), v.p('d6/b'), v.p('d6/bn/gamma'), v.p('d6/bn/beta'), v.p('out/w'),
-                      v.p('out/b'), self._seq_dev, self._buf('tail/conv', (B * T * F,), zero=False), pred, logits)
+                      v.p('out/b'), self._seq_dev, self._buf('tail/conv', (B * T * F,), zero=False), pred, logits,
+                      src1_bn=pending)
         if want_logits:
             c['inference'] = logits
         return pred

@@ -480,11 +480,12 @@ int avsi_conv2d_splitk_f32(const float* src0, int C0, int ld0, const float* src1
 /* Inference tail of the U-Net in one call: d6 = conv3x3(concat(src0 [1 channel], up2x(src1 [16 channels])), 17 -> 1) with the
  * batch statistics of its one channel taken in the convolution's epilogue, then one pass: batch norm (gamma, beta, eps) +
  * LeakyReLU(0.2) (unet_layers.py:33-35) + the 1 x 1 output convolution (w_out[0], b_out[0]: models.py:607) + the sequence
- * mask of `prediction` (seq_len int64 [B], frames >= seq_len[b] zeroed: models.py:609-615).  conv [B*H*W] is scratch,
+ * mask of `prediction` (seq_len int64 [B], frames >= seq_len[b] zeroed: models.py:609-615).  src1_bn as in
+ * avsi_conv2d_bn_f32 (src1_coarse = the raw 16-channel output of the layer below).  conv [B*H*W] is scratch,
  * logits [B*H*W] (the un-masked `inference`) may be NULL, pred [B*H*W].  H % 8 == 0, W % 32 == 0. */
 size_t avsi_unet_tail_workspace_bytes(int B, int H, int W);
-int avsi_unet_tail_f32(const float* src0, int ld0, const float* src1_coarse, int ld1, int B, int H, int W,
-                       const float* filter, int ldf, const float* bias, const float* gamma, const float* beta, float eps,
+int avsi_unet_tail_f32(const float* src0, int ld0, const float* src1_coarse, int ld1, const float* const* src1_bn, int B, int H,
+                       int W, const float* filter, int ldf, const float* bias, const float* gamma, const float* beta, float eps,
                        const float* w_out, const float* b_out, const long long* seq_len, float* conv, float* logits,
                        float* pred, void* workspace, size_t workspace_bytes, void* stream);
 /* Direct form for the thin full-resolution layers no MFMA shape fits: (k, C0, C1, Cout) in
@@ -535,12 +536,15 @@ int avsi_bn_act_pool_f32(const float* x, int B, int H, int W, int C, int ld, con
 /* Convolution (operands as avsi_conv2d_f32) + the batch statistics of its output, tf.layers.batch_normalization(training=True)
  * (unet_layers.py:14,33): mean[Cout] and rstd[Cout] = 1 / sqrt(var + eps) come from partial sums the convolution's own
  * epilogue leaves per output tile (deterministic order) and one small finishing launch -- no pass over the output.  Takes the
- * 16-wide-MFMA route where avsi_conv2d_thin_mfma_supported says so, the implicit GEMM otherwise (same support rules). */
+ * 16-wide-MFMA route where avsi_conv2d_thin_mfma_supported says so, the implicit GEMM otherwise (same support rules).
+ * src1_bn (NULL, or four device pointers mean, rstd, gamma, beta of C1 floats): src1_coarse is then the RAW convolution output
+ * of the layer below and its batch norm + LeakyReLU(0.2) are applied while the operand is staged -- that layer's own
+ * normalise / activate pass never runs (16-wide-MFMA route, k = 3, only: AVSI_ERR_UNSUPPORTED otherwise). */
 size_t avsi_conv2d_bn_workspace_bytes(int B, int H, int W, int k, int C0, int C1, int Cout);
-int avsi_conv2d_bn_f32(const float* src0, int C0, int ld0, const float* src1_coarse, int C1, int ld1, int B, int H, int W,
-                       int k, const float* filter, int ldf, const float* bias, int Cout, float* out, int ldo,
-                       const float* zeros64, float eps, float* mean, float* rstd, void* workspace, size_t workspace_bytes,
-                       void* stream);
+int avsi_conv2d_bn_f32(const float* src0, int C0, int ld0, const float* src1_coarse, int C1, int ld1,
+                       const float* const* src1_bn, int B, int H, int W, int k, const float* filter, int ldf,
+                       const float* bias, int Cout, float* out, int ldo, const float* zeros64, float eps, float* mean,
+                       float* rstd, void* workspace, size_t workspace_bytes, void* stream);
 /* Few-channel convolutions at high resolution on the 16-wide fp32 MFMA, input patch and filter in LDS (same operands as
  * avsi_conv2d_f32): the U-Net's decoder layer 16 + 32 -> 16 (3 x 3) and encoder layer 16 -> 32 (5 x 5); H % 4 == 0,
  * W % 32 == 0.  avsi_conv2d_thin_mfma_supported returns 1 for the shapes it takes. */

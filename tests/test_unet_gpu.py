@@ -485,7 +485,7 @@ def test_training_resumes_after_a_validation_pass_that_captured_a_graph(monkeypa
 @pytest.mark.parametrize("k,c0,c1,cout,B,H,W", [(3, 16, 32, 16, 3, 64, 64), (5, 16, 0, 32, 2, 64, 64),       # 16-wide MFMA route
                                                (3, 32, 64, 32, 3, 8, 16), (5, 32, 0, 64, 2, 32, 32), (3, 128, 128, 128, 5, 4, 6),
                                                (3, 64, 0, 128, 1, 16, 16)])                                # implicit GEMM, N tiles 32 / 64 / 128
-def test_conv_with_statistics_from_its_epilogue(k, c0, c1, cout, B, H, W):
+def test_conv_with_statistics_from_its_epilogue(k, c0, c1, cout, B, H, W, monkeypatch):
     """avsi_conv2d_bn_f32: the same output as the plain convolution of the same route, bit for bit, and the batch statistics
     of that output (tf.layers.batch_normalization(training=True), unet_layers.py:14,33) equal to a float64 mean / variance
     over it -- taken from per-tile partial sums in the convolution's epilogue, not from a pass over the output."""
@@ -502,6 +502,7 @@ def test_conv_with_statistics_from_its_epilogue(k, c0, c1, cout, B, H, W):
     if ops.conv2d_thin_mfma_supported(k, c0, c1, cout, H, W):
         ops.conv2d_thin_mfma(s0, c0, s1, c1, B, H, W, k, filt, bias, plain, cout)
     else:
+        monkeypatch.setattr(ops, '_CONV_SPLITK', False)          # the plain launch: these small shapes would split the reduction
         ops.conv2d(s0, c0, s1, c1, B, H, W, k, filt, bias, plain, cout)
     out = torch.zeros_like(plain)
     mean, rstd = torch.zeros(cout, device='cuda'), torch.zeros(cout, device='cuda')
