@@ -103,19 +103,28 @@ __global__ __launch_bounds__(TPB) void istft_kernel(const avsi_istft_args a, con
                 // models.py:186 casts the mask to complex64 and takes a FULL complex product
                 // (a + bj)(m + 0j) = (a m - b 0) + (a 0 + b m) j; in a gap the signed zeros
                 // decide tf.angle = atan2: (-0, +0) -> pi, everything else -> 0.  Kept as is.
+                // (1 / |S| by v_rsq_f32: the kernel is bound by its instruction count -- ~4000 VALU instructions per wave and
+                //  tile at two waves per SIMD -- and sqrt + two IEEE divisions per bin were a quarter of them.  The squares are
+                //  scaled so that neither the 1e9-sized products of int16-range audio overflow nor tiny bins flush to zero.)
                 const float zero = 0.f;
                 const float pr = r1 * r3 - r2 * zero, pi = r1 * zero + r2 * r3;
-                const float r = sqrtf(pr * pr + pi * pi);
-                if (r > 0.f)
-                    x = {m * (pr / r), m * (pi / r)};
-                else
+                const float big = fmaxf(fabsf(pr), fabsf(pi));
+                if (big > 0.f) {
+                    const float sc = __builtin_amdgcn_rcpf(big), a = pr * sc, b2 = pi * sc;      // max(|a|, |b|) = 1
+                    const float inv = __builtin_amdgcn_rsqf(a * a + b2 * b2);
+                    x = {m * (a * inv), m * (b2 * inv)};
+                } else {
                     x = {(__builtin_signbitf(pr) && !__builtin_signbitf(pi)) ? -m : m, 0.f};
+                }
             } else {
-                const float r = sqrtf(r1 * r1 + r2 * r2);
-                if (r > 0.f)
-                    x = {m * (r1 / r), m * (r2 / r)};
-                else
+                const float big = fmaxf(fabsf(r1), fabsf(r2));
+                if (big > 0.f) {
+                    const float sc = __builtin_amdgcn_rcpf(big), a = r1 * sc, b2 = r2 * sc;
+                    const float inv = __builtin_amdgcn_rsqf(a * a + b2 * b2);
+                    x = {m * (a * inv), m * (b2 * inv)};
+                } else {
                     x = {__builtin_signbitf(r1) && !__builtin_signbitf(r2) ? -m : m, 0.f};  // atan2(+0,-0) = pi
+                }
             }
         }
         if (kk == 0 || kk == 256) x.i = 0.f;  // irfft ignores the imaginary part of DC / Nyquist
@@ -138,6 +147,8 @@ __global__ __launch_bounds__(TPB) void istft_kernel(const avsi_istft_args a, con
     };
     __syncthreads();
 
+    // (LDS-only barriers inside the tile loop: __syncthreads() also drains vmcnt, i.e. waits for the previous tile's output
+    //  stores and, in mode 3, holds this tile's spectrum loads back behind them)
     for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
         const int b = tile / tiles_per_utt;
         const int h0 = (tile - b * tiles_per_utt) * (FR - 1);  // first output hop of the tile
@@ -194,7 +205,7 @@ __global__ __launch_bounds__(TPB) void istft_kernel(const avsi_istft_args a, con
             if (MODE == 3) {
                 // ---- 1b. forward transform of the 16 frames (frontend.hip steps 2 - 4: window, 16 x 16 FFT of
                 //          z[n] = x[2n] + j x[2n+1], natural-order Z with Z[256] := Z[0]); one frame per 16-lane group
-                __syncthreads();
+                AVSI_LDS_BARRIER();
                 cf v[16];
                 {
                     const float* fr = s_wav + f * S + 2 * ln;
@@ -225,7 +236,7 @@ __global__ __launch_bounds__(TPB) void istft_kernel(const avsi_istft_args a, con
 #pragma unroll
                 for (int k1 = 0; k1 < 16; ++k1) zf[16 * k1 + ln] = v[pos16(k1)];
                 if (ln == 0) zf[256] = v[pos16(0)];
-                __syncthreads();
+                AVSI_LDS_BARRIER();
                 // ---- 1c. thread <-> bin: S[k] = E[k] + W512^k O[k] from Z[k] and Z[256 - k] (frontend.hip step 5)
                 const float2 wk = *reinterpret_cast<const float2*>(tab + TAB_TW512 + 2 * kk);
 #pragma unroll
@@ -240,7 +251,7 @@ __global__ __launch_bounds__(TPB) void istft_kernel(const avsi_istft_args a, con
                     const cf z0 = s_z[tid * ZSTRIDE];
                     q1 = z0.r - z0.i, q2 = 0.f;
                 }
-                __syncthreads();    // every Z has been read: the storage becomes the spectrum tile
+                AVSI_LDS_BARRIER();    // every Z has been read: the storage becomes the spectrum tile
             }
 #pragma unroll
             for (int ff = 0; ff < FR; ++ff) {
@@ -251,7 +262,7 @@ __global__ __launch_bounds__(TPB) void istft_kernel(const avsi_istft_args a, con
                 s_x[tid * XS + 256] = nok ? make_x(256, q0, q1, q2, q3, have_norm ? a.mean[kn] : 0.f, have_norm ? a.stdev[kn] : 1.f)
                                           : cf{0.f, 0.f};
         }
-        __syncthreads();
+        AVSI_LDS_BARRIER();
 
         // ---- 2. Z[k] = E[k] + j O[k] (conjugated for the forward-FFT trick), first 16-point FFT
         cf v[16];
@@ -270,7 +281,7 @@ __global__ __launch_bounds__(TPB) void istft_kernel(const avsi_istft_args a, con
             }
         }
         fft16(v);
-        __syncthreads();        // every lane has read its s_x inputs: the storage becomes s_z
+        AVSI_LDS_BARRIER();        // every lane has read its s_x inputs: the storage becomes s_z
         cf* zf = s_z + f * ZSTRIDE;
         zf[ln] = v[pos16(0)];
 #pragma unroll
@@ -278,10 +289,10 @@ __global__ __launch_bounds__(TPB) void istft_kernel(const avsi_istft_args a, con
             const float2 w = s_tw[n2][ln];
             zf[n2 * 17 + ln] = cmul(v[pos16(n2)], cf{w.x, w.y});
         }
-        __syncthreads();
+        AVSI_LDS_BARRIER();
 #pragma unroll
         for (int k1 = 0; k1 < 16; ++k1) v[k1] = zf[ln * 17 + k1];
-        __syncthreads();
+        AVSI_LDS_BARRIER();
         fft16(v);
         // ---- 3. z[16 n1 + ln] = conj(.) / 256 -> x[2n], x[2n+1]; synthesis window; store frame
         {
@@ -295,26 +306,28 @@ __global__ __launch_bounds__(TPB) void istft_kernel(const avsi_istft_args a, con
                 if (2 * n < L) *reinterpret_cast<float2*>(ffr + 2 * n) = make_float2(z.r * sc * w.x, -z.i * sc * w.y);
             }
         }
-        __syncthreads();
+        AVSI_LDS_BARRIER();
 
         // ---- 4. overlap-add: every sample of the 15 hops sums the frames that cover it, stored once
-        const int cover = (L + S - 1) / S;  // frames covering a sample (2 for 384 / 192)
+        // (frame_len <= 2 hop: a sample is covered by the frame of its own hop and the one before -- the halo frame for the
+        //  tile's first hop.  Hop by hop, lanes along the hop: no integer division per sample.)
         const int64_t n_out = a.num_samples;
-        for (int i = tid; i < (FR - 1) * S; i += TPB) {
-            const int hop_i = i / S, r = i - hop_i * S;
+        float* orow = a.out + (int64_t)b * a.out_stride_b;
+#pragma unroll 1
+        for (int hop_i = 0; hop_i < FR - 1; ++hop_i) {
             const int h = h0 + hop_i;
             if (h >= n_hops) break;
-            const int64_t n = (int64_t)h * S + r;
-            if (n >= n_out) continue;
-            float acc = 0.f;
-            for (int c = 0; c < cover; ++c) {
-                const int ff = hop_i + 1 - c;  // frame index inside the tile (frame t = h - c)
-                const int off = r + c * S;
-                if (ff >= 0 && off < L) acc += s_f[ff * fs + off];
+            const float* f1 = s_f + (hop_i + 1) * fs;       // frame t = h
+            const float* f0 = s_f + hop_i * fs + S;         // frame t = h - 1, second part
+            for (int r = tid; r < S; r += TPB) {
+                const int64_t n = (int64_t)h * S + r;
+                if (n >= n_out) break;
+                float acc = f1[r];
+                if (r + S < L) acc += f0[r];
+                orow[n] = acc;
             }
-            a.out[(int64_t)b * a.out_stride_b + n] = acc;
         }
-        __syncthreads();
+        AVSI_LDS_BARRIER();
     }
 }
 
