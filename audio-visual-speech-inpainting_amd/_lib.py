@@ -63,6 +63,7 @@ class GemmEpilogue(Structure):
 PROTOTYPES = {
     "avsi_abi_version": (c_int, []),
     "avsi_status_string": (c_char_p, [c_int]),
+    "avsi_blstm_net_supported": (c_int, [POINTER(c_int), c_int]),
     "avsi_frontend_table_floats": (c_size_t, [c_int, c_int]),
     "avsi_frontend_init_tables": (c_int, [c_void_p, c_int, c_int, c_void_p]),
     "avsi_frontend_f32": (c_int, [POINTER(FrontendArgs), c_void_p]),

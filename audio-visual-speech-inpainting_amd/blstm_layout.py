@@ -59,8 +59,14 @@ class ParamLayout:
     def __init__(self, input_dim, net_dim=(250, 250, 250), audio_feat_dim=257, side=None, mlp=None, mlp_in_pitch=None,
                  asr=None):
         net_dim = tuple(int(h) for h in net_dim)
-        if len(set(net_dim)) != 1 or net_dim[0] > HP or net_dim[0] < 1:
-            raise ValueError("the gfx950 BLSTM kernels need equal layer sizes <= %d, got %r" % (HP, net_dim))
+        # the C ABI says which stacks its kernels take (avsi_blstm_net_supported: equal widths of 1 .. 256 units; the
+        # reference takes any, models.py:95-99,107) -- the host layer has no rule of its own
+        import ctypes
+        from . import _lib
+        rc = _lib.lib().avsi_blstm_net_supported((ctypes.c_int * len(net_dim))(*net_dim), len(net_dim)) if net_dim else -1
+        if rc != _lib.AVSI_OK:
+            raise _lib.AvsiError("net_dim = %r: %s (%d) -- the gfx950 BLSTM kernels take equal layer widths of 1 .. %d units"
+                                 % (list(net_dim), _lib.lib().avsi_status_string(rc).decode(), rc, HP))
         self.input_dim = int(input_dim)
         self.H = H = net_dim[0]
         self.num_layers = len(net_dim)

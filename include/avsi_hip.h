@@ -35,6 +35,10 @@ typedef enum avsi_status {
 /* ABI version (bumped on any signature change) and a static string for a status code. */
 int avsi_abi_version(void);
 const char* avsi_status_string(int status);
+/* Host-only: AVSI_OK if the recurrent kernels take a stack of `num_layers` bidirectional LSTM layers of net_dim[l] units per
+ * direction (config key net_dim; the reference takes any widths, models.py:95-99,107): equal widths of 1 .. 256 units.
+ * AVSI_ERR_UNSUPPORTED for unequal widths or more than 256 units. */
+int avsi_blstm_net_supported(const int* net_dim, int num_layers);
 
 /* ------------------------------------------------------------------------------------
  * Front end: framing + periodic-Hann window + rFFT + |.| + log + z-norm + mask (+ log-mel)

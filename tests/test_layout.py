@@ -202,3 +202,19 @@ def test_asr_head_shares_the_packed_projection():
     assert lay.signature()[-1] == -100034
     with np.testing.assert_raises(ValueError):
         ParamLayout(257, asr=1)
+
+
+def test_net_dim_support_is_decided_by_the_c_abi():
+    """The reference takes any num_units per layer (models.py:95-99,107); the recurrent kernels equal widths of 1 .. 256 units.
+    The rule lives in the C ABI (avsi_blstm_net_supported) and the host layer reports ITS status."""
+    import ctypes
+    import pytest
+    from avsi_amd import _lib
+    L = _lib.lib()
+    for dims, want in (([250, 250, 250], _lib.AVSI_OK), ([256], _lib.AVSI_OK), ([7, 7], _lib.AVSI_OK), ([250, 128], _lib.AVSI_ERR_UNSUPPORTED),
+                       ([257, 257], _lib.AVSI_ERR_UNSUPPORTED), ([0], _lib.AVSI_ERR_INVALID_ARG)):
+        assert L.avsi_blstm_net_supported((ctypes.c_int * len(dims))(*dims), len(dims)) == want, dims
+    assert ParamLayout(257, (64, 64)).H == 64
+    for bad in ((250, 128, 250), (300, 300)):
+        with pytest.raises(_lib.AvsiError, match="unsupported shape"):
+            ParamLayout(257, bad)
