@@ -30,10 +30,16 @@ def per_kernel(path, counter):
 
 
 def main():
+    if len(sys.argv) > 6:       # other commands: "kernel substring=launches per step, ..." and the command line for the record
+        KERNELS.clear()
+        for item in sys.argv[6].split(';'):
+            k, n = item.rsplit('=', 1)
+            KERNELS[k] = int(n)
     fetch = per_kernel(sys.argv[1], 'FETCH_SIZE')
     write = per_kernel(sys.argv[2], 'WRITE_SIZE')
-    out = {"command": "rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE --kernel-trace -- python3 bench.py --batch 8192 --steps 1 "
-                      "--warmup 1 --no-cpu-baseline --no-also (two separate passes)",
+    out = {"command": sys.argv[7] if len(sys.argv) > 7 else
+           "rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE --kernel-trace -- python3 bench.py --batch 8192 --steps 1 "
+           "--warmup 1 --no-cpu-baseline --no-also (two separate passes)",
            "units": "bytes per launch; FETCH_SIZE (KB) doubled per MI355X_MICROARCH.md (gfx950 tallies 128-B requests at "
                     "64 B for 16-B-per-lane streams; dword-per-lane streams uncalibrated), WRITE_SIZE (KB) as read",
            "commit": sys.argv[4] if len(sys.argv) > 4 else None,        # the tree the counters were collected on
