@@ -228,7 +228,7 @@ __global__ __launch_bounds__(256) void conv7_c1_mfma_kernel(const float* __restr
 // group is a 16 x (KS^2 CT) by (KS^2 CT) x COUT product in k-steps of four channels of one tap: lane l supplies
 // A[pixel l % 16][channel 4 kk' + l / 16] (one ds_read_b32 from the patch) and B[.][output channel l % 16] (one from
 // the filter); D[pixel 4 (l / 16) + i][channel l % 16].
-// STATS: the block also leaves per-channel sums and sums of squares of its 128 output pixels in part[blk][2][COUT]
+// STATS: the workgroup also leaves per-channel sums and sums of squares of ALL its output pixels in part[blk][2][COUT]
 // (batch-norm statistics taken where the accumulators are; fixed reduction order: deterministic).
 // BN1: s1 is the RAW convolution output of the layer below; its batch norm + LeakyReLU(0.2) (bn1 = mean, rstd, gamma, beta)
 // are applied while the patch is staged -- that layer's own normalise / activate pass over its output does not exist.
@@ -238,102 +238,131 @@ struct Bn4 {
     const float* gamma;
     const float* beta;
 };
+// PERSISTENT over tiles (round 4): a tile's MFMA work is ~3 us (216 - 400 MFMAs per wave) but staging its patch AND the whole
+// filter (27 - 51 KB, the same for every tile) took 11 us more, one workgroup per tile.  Now a workgroup stages the filter
+// ONCE, walks tiles blockIdx.x, + gridDim.x, ..., and fetches the NEXT tile's patch into registers (5 - 10 float4 per thread,
+// branch-free) while the current tile's MFMAs run; statistics are carried in registers over the workgroup's tiles and
+// reduced once at the end (gridDim.x partial rows instead of one per tile).
 template <int KS, int C0, int C1, int COUT, bool STATS, bool BN1>
 __global__ __launch_bounds__(256) void thin_mfma_conv_kernel(const float* __restrict__ s0, int ld0, const float* __restrict__ s1,
                                                              int ld1, const float* __restrict__ filt, int ldf,
                                                              const float* __restrict__ bias, float* __restrict__ out, int ldo,
                                                              int H, int W, const float* __restrict__ zeros,
-                                                             float* __restrict__ part, const Bn4 bn1) {
+                                                             float* __restrict__ part, const Bn4 bn1, const int n_tiles) {
     constexpr int P = KS / 2, CT = C0 + C1, CP = CT + 1, TH = 4, TW = 32, PH = TH + KS - 1, PWD = TW + KS - 1;
-    constexpr int NCG = COUT / 16, KSTEPS = KS * KS * CT / 4, CQ = CT / 4;
+    constexpr int NCG = COUT / 16, CQ = CT / 4;
+    constexpr int ITEMS = PH * PWD * CQ, NPRE = (ITEMS + 255) / 256;       // float4 items of a patch, per thread
     extern __shared__ __attribute__((aligned(16))) float smem_f[];
     float* patch = smem_f;                           // [PH][PWD][CP]
     float* wts = smem_f + PH * PWD * CP;             // [KS * KS * CT][COUT]
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int tiles_w = W / TW, tiles_h = H / TH;
-    const int tile = blockIdx.x % (tiles_w * tiles_h), b = blockIdx.x / (tiles_w * tiles_h);
-    const int h0 = (tile / tiles_w) * TH, w0 = (tile % tiles_w) * TW;
+    const int tiles_w = W / TW, tiles_img = tiles_w * (H / TH);
     const int H2 = H >> 1, W2 = W >> 1;
     __shared__ float s_sc[BN1 ? C1 : 1], s_sh[BN1 ? C1 : 1];
     if (BN1 && tid < C1) {
         const float sc = bn1.gamma[tid] * bn1.rstd[tid];
         s_sc[tid] = sc, s_sh[tid] = bn1.beta[tid] - bn1.mean[tid] * sc;
     }
-    if (BN1) __syncthreads();
-    // filter -> LDS (rows of COUT floats, 16-byte pieces)
+    // filter -> LDS (rows of COUT floats, 16-byte pieces), once per workgroup
     for (int i = tid; i < KS * KS * CT * (COUT / 4); i += 256) {
         const int row = i / (COUT / 4), q = i - row * (COUT / 4);
         *reinterpret_cast<float4*>(wts + row * COUT + 4 * q) = *reinterpret_cast<const float4*>(filt + (int64_t)row * ldf + 4 * q);
     }
-    // patch -> LDS: one float4 (four channels of one pixel) per item; pixels outside the image read a page of zeros
-    for (int i = tid; i < PH * PWD * CQ; i += 256) {
-        const int pix = i / CQ, c4 = (i - pix * CQ) * 4;
-        const int pr = pix / PWD, pc = pix - pr * PWD;
-        const int hh = h0 + pr - P, ww = w0 + pc - P;
-        const bool ok = hh >= 0 && hh < H && ww >= 0 && ww < W;
-        const float* src = zeros;
-        if (ok) {
-            if (c4 < C0) src = s0 + (((int64_t)b * H + hh) * W + ww) * ld0 + c4;
-            else src = s1 + (((int64_t)b * H2 + (hh >> 1)) * W2 + (ww >> 1)) * ld1 + (c4 - C0);
+    // a tile's patch: one float4 (four channels of one pixel) per item; pixels outside the image read a page of zeros
+    float4 pre[NPRE];
+    unsigned okbits = 0;
+    auto fetch = [&](int tile) {
+        const int b = tile / tiles_img, tl = tile - b * tiles_img;
+        const int h0 = (tl / tiles_w) * TH, w0 = (tl - (tl / tiles_w) * tiles_w) * TW;
+        okbits = 0;
+#pragma unroll
+        for (int j = 0; j < NPRE; ++j) {
+            const int i = tid + 256 * j;
+            const int ic = i < ITEMS ? i : 0;                     // (threads past the last item re-read item 0: never stored)
+            const int pix = ic / CQ, c4 = (ic - pix * CQ) * 4;
+            const int pr = pix / PWD, pc = pix - pr * PWD;
+            const int hh = h0 + pr - P, ww = w0 + pc - P;
+            const bool ok = hh >= 0 && hh < H && ww >= 0 && ww < W;
+            const float* src = zeros;
+            if (ok) {
+                if (c4 < C0) src = s0 + (((int64_t)b * H + hh) * W + ww) * ld0 + c4;
+                else src = s1 + (((int64_t)b * H2 + (hh >> 1)) * W2 + (ww >> 1)) * ld1 + (c4 - C0);
+            }
+            pre[j] = *reinterpret_cast<const float4*>(src);
+            okbits |= (unsigned)ok << j;
         }
-        float4 v = *reinterpret_cast<const float4*>(src);
-        if (BN1 && ok && c4 >= C0) {
-            const int c = c4 - C0;
-            v.x = bn_act_one(v.x, s_sc[c], s_sh[c], 2), v.y = bn_act_one(v.y, s_sc[c + 1], s_sh[c + 1], 2);
-            v.z = bn_act_one(v.z, s_sc[c + 2], s_sh[c + 2], 2), v.w = bn_act_one(v.w, s_sc[c + 3], s_sh[c + 3], 2);
-        }
-        float* d = patch + pix * CP + c4;
-        d[0] = v.x, d[1] = v.y, d[2] = v.z, d[3] = v.w;
-    }
-    __syncthreads();
+    };
     const int px = lane & 15, kq = lane >> 4;
     typedef float f32x4v __attribute__((ext_vector_type(4)));
-    f32x4v acc[2][NCG];
+    float bv[NCG], st1[NCG], st2[NCG];
 #pragma unroll
-    for (int g = 0; g < 2; ++g)
-#pragma unroll
-        for (int n = 0; n < NCG; ++n) {
-            const float bv = bias ? bias[16 * n + px] : 0.f;
-            acc[g][n] = (f32x4v){bv, bv, bv, bv};
-        }
+    for (int n = 0; n < NCG; ++n) bv[n] = bias ? bias[16 * n + px] : 0.f, st1[n] = 0.f, st2[n] = 0.f;
     const float* prow = patch + (wv * PWD + px) * CP + kq;       // row wv of the tile, tap (0, 0), this lane's channel
     const float* wlan = wts + kq * COUT + px;
-#pragma unroll 1
-    for (int tap = 0; tap < KS * KS; ++tap) {
-        const int dh = tap / KS, dw = tap - dh * KS;
-        const float* pa = prow + (dh * PWD + dw) * CP;
-        const float* pw = wlan + tap * CT * COUT;
+    if ((int)blockIdx.x < n_tiles) fetch(blockIdx.x);
+    __syncthreads();                                             // filter and batch-norm constants in LDS
+    for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        // ---- the patch this thread fetched -> LDS (the batch norm + activation of a raw source applied on the way)
 #pragma unroll
-        for (int cq = 0; cq < CQ; ++cq) {
-            const float a0 = pa[4 * cq], a1 = pa[16 * CP + 4 * cq];          // the wave's two pixel groups
-#pragma unroll
-            for (int n = 0; n < NCG; ++n) {
-                const float wv_ = pw[4 * cq * COUT + 16 * n];
-                acc[0][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, wv_, acc[0][n], 0, 0, 0);
-                acc[1][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, wv_, acc[1][n], 0, 0, 0);
+        for (int j = 0; j < NPRE; ++j) {
+            const int i = tid + 256 * j;
+            if (i < ITEMS) {
+                const int pix = i / CQ, c4 = (i - pix * CQ) * 4;
+                float4 v = pre[j];
+                if (BN1 && ((okbits >> j) & 1u) && c4 >= C0) {
+                    const int c = c4 - C0;
+                    v.x = bn_act_one(v.x, s_sc[c], s_sh[c], 2), v.y = bn_act_one(v.y, s_sc[c + 1], s_sh[c + 1], 2);
+                    v.z = bn_act_one(v.z, s_sc[c + 2], s_sh[c + 2], 2), v.w = bn_act_one(v.w, s_sc[c + 3], s_sh[c + 3], 2);
+                }
+                float* d = patch + pix * CP + c4;
+                d[0] = v.x, d[1] = v.y, d[2] = v.z, d[3] = v.w;
             }
         }
-    }
-    (void)KSTEPS;
+        AVSI_LDS_BARRIER();
+        if (tile + (int)gridDim.x < n_tiles) fetch(tile + gridDim.x);      // in flight during the MFMAs below
+        const int b = tile / tiles_img, tl = tile - b * tiles_img;
+        const int h0 = (tl / tiles_w) * TH, w0 = (tl - (tl / tiles_w) * tiles_w) * TW;
+        f32x4v acc[2][NCG];
 #pragma unroll
-    for (int g = 0; g < 2; ++g) {
-        const int64_t pix0 = ((int64_t)b * H + h0 + wv) * W + w0 + 16 * g + 4 * kq;
+        for (int g = 0; g < 2; ++g)
 #pragma unroll
-        for (int n = 0; n < NCG; ++n)
+            for (int n = 0; n < NCG; ++n) acc[g][n] = (f32x4v){bv[n], bv[n], bv[n], bv[n]};
+#pragma unroll 1
+        for (int tap = 0; tap < KS * KS; ++tap) {
+            const int dh = tap / KS, dw = tap - dh * KS;
+            const float* pa = prow + (dh * PWD + dw) * CP;
+            const float* pw = wlan + tap * CT * COUT;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) out[(pix0 + i) * ldo + 16 * n + px] = acc[g][n][i];
+            for (int cq = 0; cq < CQ; ++cq) {
+                const float a0 = pa[4 * cq], a1 = pa[16 * CP + 4 * cq];          // the wave's two pixel groups
+#pragma unroll
+                for (int n = 0; n < NCG; ++n) {
+                    const float wv_ = pw[4 * cq * COUT + 16 * n];
+                    acc[0][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, wv_, acc[0][n], 0, 0, 0);
+                    acc[1][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, wv_, acc[1][n], 0, 0, 0);
+                }
+            }
+        }
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+            const int64_t pix0 = ((int64_t)b * H + h0 + wv) * W + w0 + 16 * g + 4 * kq;
+#pragma unroll
+            for (int n = 0; n < NCG; ++n)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float v = acc[g][n][i];
+                    out[(pix0 + i) * ldo + 16 * n + px] = v;
+                    if (STATS) st1[n] += v, st2[n] += v * v;
+                }
+        }
+        AVSI_LDS_BARRIER();                              // every wave is done reading the patch
     }
     if (STATS) {
-        // lane (px, kq) holds channel 16 n + px of 8 pixels: sum them, then the four kq groups (shuffles), then the four waves
-        __syncthreads();                                 // the patch is dead: its storage carries the wave sums
-        float* red = smem_f;                             // [4 waves][2][COUT]
+        // lane (px, kq) holds channel 16 n + px of its pixels of every tile: the four kq groups (shuffles), then the four waves
+        float* red = smem_f;                             // [4 waves][2][COUT] (the patch is dead)
 #pragma unroll
         for (int n = 0; n < NCG; ++n) {
-            float t1 = 0.f, t2 = 0.f;
-#pragma unroll
-            for (int g = 0; g < 2; ++g)
-#pragma unroll
-                for (int i = 0; i < 4; ++i) t1 += acc[g][n][i], t2 += acc[g][n][i] * acc[g][n][i];
+            float t1 = st1[n], t2 = st2[n];
             t1 += __shfl_xor(t1, 16, 64), t2 += __shfl_xor(t2, 16, 64);
             t1 += __shfl_xor(t1, 32, 64), t2 += __shfl_xor(t2, 32, 64);
             if (kq == 0) red[(wv * 2 + 0) * COUT + 16 * n + px] = t1, red[(wv * 2 + 1) * COUT + 16 * n + px] = t2;
@@ -1240,6 +1269,8 @@ extern "C" int avsi_conv2d_thin_mfma_supported(int k, int C0, int C1, int Cout, 
 static int conv2d_thin_mfma_launch(const float* src0, int C0, int ld0, const float* src1_coarse, int C1, int ld1, int B, int H,
                                    int W, int k, const float* filter, int ldf, const float* bias, int Cout, float* out,
                                    int ldo, const float* zeros64, float* part, const float* const* src1_bn, void* stream);
+// persistent grid of the 16-wide-MFMA convolution: two workgroups per CU (68 - 71 KB of LDS each), fewer for few tiles
+static int thin_mfma_blocks(int n_tiles) { return n_tiles < 2 * AVSI_NUM_CU ? n_tiles : 2 * AVSI_NUM_CU; }
 
 extern "C" int avsi_conv2d_thin_mfma_f32(const float* src0, int C0, int ld0, const float* src1_coarse, int C1, int ld1, int B, int H,
                                          int W, int k, const float* filter, int ldf, const float* bias, int Cout, float* out,
@@ -1260,7 +1291,8 @@ static int conv2d_thin_mfma_launch(const float* src0, int C0, int ld0, const flo
         ((reinterpret_cast<uintptr_t>(src0) | reinterpret_cast<uintptr_t>(src1_coarse) | reinterpret_cast<uintptr_t>(filter) |
           reinterpret_cast<uintptr_t>(zeros64)) & 15))
         return AVSI_ERR_UNSUPPORTED;
-    const dim3 grid(B * (H / 4) * (W / 32)), block(256);
+    const int n_tiles = B * (H / 4) * (W / 32);
+    const dim3 grid(thin_mfma_blocks(n_tiles)), block(256);
     const hipStream_t st = (hipStream_t)stream;
     avsi_clear_error();
 #define AVSI_THIN_MFMA(KS, CA, CB, CO, ST, BN, LDS)                                                                             \
@@ -1268,7 +1300,7 @@ static int conv2d_thin_mfma_launch(const float* src0, int C0, int ld0, const flo
         (void)hipFuncSetAttribute((const void*)thin_mfma_conv_kernel<KS, CA, CB, CO, ST, BN>,                                  \
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)(LDS));                                     \
         hipLaunchKernelGGL((thin_mfma_conv_kernel<KS, CA, CB, CO, ST, BN>), grid, block, (LDS), st, src0, ld0, src1_coarse,    \
-                           ld1, filter, ldf, bias, out, ldo, H, W, zeros64, part, bn1);                                       \
+                           ld1, filter, ldf, bias, out, ldo, H, W, zeros64, part, bn1, n_tiles);                              \
     } while (0)
     if (k == 3) {
         constexpr size_t lds = ((size_t)6 * 34 * 49 + 9 * 48 * 16) * 4;
@@ -1316,7 +1348,7 @@ __global__ __launch_bounds__(256) void fold_partials_kernel(const float* __restr
 // call: the convolution's epilogue leaves per-tile partial sums, one small launch turns them into mean and 1 / sqrt(var + eps)
 // -- no pass over the output.  Route: the 16-wide-MFMA kernel where it applies, else the implicit GEMM.
 static int conv_bn_parts(int B, int H, int W, int k, int C0, int C1, int Cout) {
-    if (avsi_conv2d_thin_mfma_supported(k, C0, C1, Cout, H, W)) return B * (H / 4) * (W / 32);
+    if (avsi_conv2d_thin_mfma_supported(k, C0, C1, Cout, H, W)) return thin_mfma_blocks(B * (H / 4) * (W / 32));
     return avsi_conv2d_stats_parts(B, H, W, Cout);
 }
 constexpr int FOLD_ROWS = 256;
