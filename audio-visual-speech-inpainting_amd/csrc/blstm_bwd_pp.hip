@@ -157,10 +157,20 @@ __device__ __forceinline__ void bwd_pp_phase(f32x16 (&dhrec)[2], float (&dcn)[2]
                 in.gi[e] = v, in.gj[e] = v, in.gf[e] = v, in.go[e] = v, in.cp[e] = v;
                 continue;
             }
-            in.gi[e] = buf_load(d.rr, voff_r, rowc * RROW + 0 * HP * 4);
-            in.gj[e] = buf_load(d.rr, voff_r, rowc * RROW + 1 * HP * 4);
-            in.gf[e] = buf_load(d.rr, voff_r, rowc * RROW + 2 * HP * 4);
-            in.go[e] = buf_load(d.rr, voff_r, rowc * RROW + 3 * HP * 4);
+            if (DIAG & 512) {
+                // timing experiment (results WRONG): the four gates by ONE 16-byte load at a 32-byte lane stride -- what a
+                // reserve laid out [row][unit][i, j, f, o, c, pad x 3] would cost
+                const int unit = ((voff_r >> 2) & 255) % 160, hi4 = (voff_r >> 2) / (2 * 5 * HP);
+                const size_t row0 = (size_t)time_of(ctx, who) * ctx.Bp + ctx.b0 + 32 * who.tile;
+                const v4f* gp = reinterpret_cast<const v4f*>(ctx.resv + (row0 + rowc + hi4) * (2 * 5 * HP) + ctx.dir * 5 * HP + unit * 8);
+                const v4f g4 = __builtin_nontemporal_load(gp);
+                in.gi[e] = g4.x, in.gj[e] = g4.y, in.gf[e] = g4.z, in.go[e] = g4.w;
+            } else {
+                in.gi[e] = buf_load(d.rr, voff_r, rowc * RROW + 0 * HP * 4);
+                in.gj[e] = buf_load(d.rr, voff_r, rowc * RROW + 1 * HP * 4);
+                in.gf[e] = buf_load(d.rr, voff_r, rowc * RROW + 2 * HP * 4);
+                in.go[e] = buf_load(d.rr, voff_r, rowc * RROW + 3 * HP * 4);
+            }
             if (DIAG & 256) {       // five of seven
                 float v = 0.25f + 0.001f * r;
                 asm volatile("v_mov_b32 %0, %0" : "+v"(v));
@@ -384,6 +394,8 @@ int avsi_blstm_rec_bwd_pp_launch(const float* dhout, const float* reserve, const
         case 2: AVSI_PP_LAUNCH(2); break;
         case 64: AVSI_PP_LAUNCH(64); break;
         case 128: AVSI_PP_LAUNCH(128); break;
+        case 512: AVSI_PP_LAUNCH(512); break;
+        case 516: AVSI_PP_LAUNCH(516); break;
         case 256: AVSI_PP_LAUNCH(256); break;
         case 68: AVSI_PP_LAUNCH(68); break;
         case 6: AVSI_PP_LAUNCH(6); break;
