@@ -146,6 +146,21 @@ __device__ __forceinline__ void bwd_pp_phase(f32x16 (&dhrec)[2], float (&dcn)[2]
         struct {
             rsrc_t rh, rr, rp;
         } d{rsrc_h(ctx, who), rsrc_r(ctx, who), rsrc_p(ctx, who)};
+        if (DIAG & 1024) {
+            // timing experiment (results WRONG): the chunk's 12 values per lane by THREE 16-byte loads whose lanes run along
+            // the unit axis (8 lanes per 128-byte row segment) -- the vector-memory side of a cell that is fed through LDS
+            const size_t row0 = (size_t)time_of(ctx, who) * ctx.Bp + ctx.b0 + 32 * who.tile;
+            const int l = (voff_r >> 2) & 31, hi4 = (voff_r >> 2) / (2 * 5 * HP), wq = ((voff_r >> 2) & 255) >> 5;
+            const int lane64 = l + 8 * hi4;                      // 0 .. 63
+            const int trow = ((r0 >> 1) * 8 + (lane64 >> 3)) & 31;      // inside the tile's own 32 rows
+            const float* base = ctx.resv + (row0 + trow) * (2 * 5 * HP) + ctx.dir * 5 * HP + wq * 32 + (lane64 & 7) * 4;
+            const v4f a = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(base));
+            const v4f b = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(base + 2 * HP));
+            const v4f c = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(base + 4 * HP));
+            in.dh[0] = a.x, in.gi[0] = a.y, in.gj[0] = a.z, in.gf[0] = a.w, in.go[0] = b.x, in.cp[0] = b.y;
+            in.dh[1] = b.z, in.gi[1] = b.w, in.gj[1] = c.x, in.gf[1] = c.y, in.go[1] = c.z, in.cp[1] = c.w;
+            return;
+        }
 #pragma unroll
         for (int e = 0; e < CH; ++e) {
             const int r = r0 + e;
@@ -222,6 +237,19 @@ __device__ __forceinline__ void bwd_pp_phase(f32x16 (&dhrec)[2], float (&dcn)[2]
             ccar[Y][r] = in.cp[e];          // the c_t of this tile's next backward step
             pin(st.dzf);
             dzh[4 * r + 0] = st.dzi, dzh[4 * r + 1] = st.dzj, dzh[4 * r + 2] = st.dzf, dzh[4 * r + 3] = st.dzo;
+        } else if (DIAG & 2048) {
+            // timing experiment (results WRONG): the cell's four dz values by one 16-byte store every FOURTH row-register,
+            // lanes along the packed gate columns (a quarter of the store instructions, whole 128-byte segments)
+            if (stage == 6 && (r & 3) == 3) {
+                const size_t row0 = (size_t)time_of(ctx, cy) * ctx.Bp + ctx.b0 + 32 * cy.tile;
+                const int l = (voff_z >> 2) & 31, hi4 = (voff_z >> 2) / (2 * GP), wq = ((voff_z >> 2) & 1023) >> 7;
+                const int lane64 = l + 8 * hi4;
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    float* p = ctx.dz + (row0 + (r >> 2) * 8 + (lane64 >> 5) + 2 * u) * (2 * GP) + ctx.dir * GP + wq * 128 + (lane64 & 31) * 4;
+                    __builtin_nontemporal_store((v4f){st.dzi, st.dzj, st.dzf, st.dzo}, reinterpret_cast<v4f*>(p));
+                }
+            }
         } else if (!(DIAG & 4)) {
             const rsrc_t rz = rsrc_z(ctx, cy);
             if (stage == 6) {
@@ -395,6 +423,9 @@ int avsi_blstm_rec_bwd_pp_launch(const float* dhout, const float* reserve, const
         case 64: AVSI_PP_LAUNCH(64); break;
         case 128: AVSI_PP_LAUNCH(128); break;
         case 512: AVSI_PP_LAUNCH(512); break;
+        case 1024: AVSI_PP_LAUNCH(1024); break;
+        case 2048: AVSI_PP_LAUNCH(2048); break;
+        case 3072: AVSI_PP_LAUNCH(3072); break;
         case 516: AVSI_PP_LAUNCH(516); break;
         case 256: AVSI_PP_LAUNCH(256); break;
         case 68: AVSI_PP_LAUNCH(68); break;
