@@ -300,12 +300,19 @@ class StackedBLSTMModel(object):
                              time_major=True, feat_cols=Kp if self.input_type == 'a' else F,
                              _feat_out=x0 if self.input_type != 'v' else None)
             c['target_spec_norm'] = fe['spec']
+        def place(src, col, width):
+            """x0[t, b, col : col + width] = src[b, t, :width]: batch-major fed features into the time-major padded input
+            (avsi_relayout_rows_f32 -- the one device step of the AV models that used to be a torch strided copy)."""
+            src = src.to(torch.float32)
+            if src.stride(2) != 1:
+                src = src.contiguous()
+            ops.relayout_rows(src, x0.view(-1)[col:], B, T, width, width, (src.stride(0), src.stride(1)), (Kp, Bp * Kp))
         if self.input_type != 'v' and self.fed_audio_features is not None:
-            x0[:, :B, :F] = self.fed_audio_features[:, :T].transpose(0, 1)
+            place(self.fed_audio_features, 0, F)
         if self.input_type == 'v':
-            x0[:, :B, :self.video_feat_dim] = self.video_features[:, :T].transpose(0, 1)
+            place(self.video_features, 0, self.video_feat_dim)
         elif self.input_type == 'av':
-            x0[:, :B, F:F + self.video_feat_dim] = self.video_features[:, :T].transpose(0, 1)
+            place(self.video_features, F, self.video_feat_dim)
         c['x0'] = x0
 
     @property
