@@ -41,7 +41,7 @@ FP32_MFMA_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, d
 HBM_PEAK_GBS = 8000.0
 
 
-def device_copy_rate(torch, device, mib=2048, reps=5, kernel="float4"):
+def device_copy_rate(torch, device, mib=4096, reps=5, kernel="float4"):
     """Read + write bytes per second of a streaming copy of `mib` MiB: what a pure streaming kernel reaches on this GPU,
     the practical ceiling for the HBM-bound kernels next to the 8 TB/s of the data sheet.  kernel = "float4": the C ABI's
     avsi_diag_copy_f32 (16 bytes per lane, four accesses in flight, a grid sized to the chip -- the shape
