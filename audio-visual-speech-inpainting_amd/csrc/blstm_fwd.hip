@@ -94,6 +94,19 @@ __device__ __forceinline__ float buf_load(rsrc_t r, int voff, int soff) {
 __device__ __forceinline__ void buf_store(rsrc_t r, int voff, int soff, float v) {
     __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, voff, soff, 0);
 }
+// the BPTT reserve is written once and read once, a step of the backward pass later: `nt` keeps it from displacing Wh in L2
+#ifndef AVSI_RESV_AUX
+#define AVSI_RESV_AUX 2
+#endif
+#ifndef AVSI_XPROJ_AUX
+#define AVSI_XPROJ_AUX 0
+#endif
+__device__ __forceinline__ float buf_load_x(rsrc_t r, int voff, int soff) {      // the gate pre-activations: read once
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, AVSI_XPROJ_AUX));
+}
+__device__ __forceinline__ void buf_store_nt(rsrc_t r, int voff, int soff, float v) {
+    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, voff, soff, AVSI_RESV_AUX);
+}
 // MT = 1 (32 rows) is built for TWO workgroups per CU (<= 128 VGPRs, 66.5 KB LDS each): the
 // two run out of phase, so one's xproj loads / cell epilogue / barrier hide under the other's MFMAs.
 template <int MT, bool SAVE>
@@ -149,7 +162,7 @@ __global__ __launch_bounds__(512, MT == 1 ? 4 : 2) void blstm_rec_fwd_kernel(con
             for (int g = 0; g < 4; ++g)
 #pragma unroll
                 for (int r = 0; r < 16; ++r)
-                    acc[m][g][r] = buf_load(rx, voff_x, (m * 32 + (r & 3) + 8 * (r >> 2)) * XROW + g * 128);
+                    acc[m][g][r] = buf_load_x(rx, voff_x, (m * 32 + (r & 3) + 8 * (r >> 2)) * XROW + g * 128);
 
         // ---- z += h_{t-1} . Wh : 32 k-groups of 8, Wh fragments prefetched one group ahead.
         //      Two named register sets (static indexing) ping-pong; see kgroup().
@@ -196,11 +209,11 @@ __global__ __launch_bounds__(512, MT == 1 ? 4 : 2) void blstm_rec_fwd_kernel(con
                 hn_lds[rowc * HS] = hn;
                 buf_store(rh, voff_h, rowc * HROW, hn);
                 if (SAVE) {
-                    buf_store(rr, voff_r, rowc * RROW + 0 * HP * 4, ig);
-                    buf_store(rr, voff_r, rowc * RROW + 1 * HP * 4, jg);
-                    buf_store(rr, voff_r, rowc * RROW + 2 * HP * 4, fg);
-                    buf_store(rr, voff_r, rowc * RROW + 3 * HP * 4, og);
-                    buf_store(rr, voff_r, rowc * RROW + 4 * HP * 4, cn);
+                    buf_store_nt(rr, voff_r, rowc * RROW + 0 * HP * 4, ig);
+                    buf_store_nt(rr, voff_r, rowc * RROW + 1 * HP * 4, jg);
+                    buf_store_nt(rr, voff_r, rowc * RROW + 2 * HP * 4, fg);
+                    buf_store_nt(rr, voff_r, rowc * RROW + 3 * HP * 4, og);
+                    buf_store_nt(rr, voff_r, rowc * RROW + 4 * HP * 4, cn);
                 }
             }
         }
@@ -300,11 +313,11 @@ __device__ __forceinline__ void pp_phase(f32x16 (&acc)[2][4], f32x16 (&c)[2], fl
             hy[((r & 3) + 8 * (r >> 2)) * HS] = hn;
             buf_store(rh, voff_h, rowc * HROW, hn);
             if (SAVE) {
-                buf_store(rr, voff_r, rowc * RROW + 0 * HP * 4, ig);
-                buf_store(rr, voff_r, rowc * RROW + 1 * HP * 4, jg);
-                buf_store(rr, voff_r, rowc * RROW + 2 * HP * 4, fg);
-                buf_store(rr, voff_r, rowc * RROW + 3 * HP * 4, og);
-                buf_store(rr, voff_r, rowc * RROW + 4 * HP * 4, cn);
+                buf_store_nt(rr, voff_r, rowc * RROW + 0 * HP * 4, ig);
+                buf_store_nt(rr, voff_r, rowc * RROW + 1 * HP * 4, jg);
+                buf_store_nt(rr, voff_r, rowc * RROW + 2 * HP * 4, fg);
+                buf_store_nt(rr, voff_r, rowc * RROW + 3 * HP * 4, og);
+                buf_store_nt(rr, voff_r, rowc * RROW + 4 * HP * 4, cn);
             }
         } else if (q < 24) {
             // second half: acc[Y] is dead, its registers take the next step's pre-activations
@@ -314,7 +327,7 @@ __device__ __forceinline__ void pp_phase(f32x16 (&acc)[2][4], f32x16 (&c)[2], fl
                 const int r = 2 * (q - 16) + e;
                 const int rowc = Y * 32 + (r & 3) + 8 * (r >> 2);
 #pragma unroll
-                for (int g = 0; g < 4; ++g) nx[g][r] = buf_load(rx_next, voff_x, rowc * XROW + g * 128);
+                for (int g = 0; g < 4; ++g) nx[g][r] = buf_load_x(rx_next, voff_x, rowc * XROW + g * 128);
             }
         }
     }
@@ -360,7 +373,7 @@ __global__ __launch_bounds__(512, 2) void blstm_rec_fwd_pp_kernel(const RecArgs 
             for (int g = 0; g < 4; ++g)
 #pragma unroll
                 for (int r = 0; r < 16; ++r)
-                    acc[m][g][r] = buf_load(rx, voff_x, (m * 32 + (r & 3) + 8 * (r >> 2)) * XROW + g * 128);
+                    acc[m][g][r] = buf_load_x(rx, voff_x, (m * 32 + (r & 3) + 8 * (r >> 2)) * XROW + g * 128);
     }
     __syncthreads();
     auto out_rsrc = [&](int step, rsrc_t& rh, rsrc_t& rr) {
