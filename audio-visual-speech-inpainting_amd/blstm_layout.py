@@ -65,10 +65,13 @@ class ParamLayout:
         from . import _lib
         rc = _lib.lib().avsi_blstm_net_supported((ctypes.c_int * len(net_dim))(*net_dim), len(net_dim)) if net_dim else -1
         if rc != _lib.AVSI_OK:
-            raise _lib.AvsiError("net_dim = %r: %s (%d) -- the gfx950 BLSTM kernels take equal layer widths of 1 .. %d units"
+            raise _lib.AvsiError("net_dim = %r: %s (%d) -- the gfx950 BLSTM kernels take layer widths of 1 .. %d units"
                                  % (list(net_dim), _lib.lib().avsi_status_string(rc).decode(), rc, HP))
         self.input_dim = int(input_dim)
-        self.H = H = net_dim[0]
+        # units per direction of every layer (the reference takes any, models.py:95-99,107; the kernels keep 256 per
+        # direction, so every width is padded to HP with zero weights); H = the TOP layer's: what the projection reads
+        self.Hs = net_dim
+        self.H = H = net_dim[-1]
         self.num_layers = len(net_dim)
         self.F = F = int(audio_feat_dim)
         self.asr = int(asr) if asr else 0
@@ -93,11 +96,12 @@ class ParamLayout:
         for li in range(self.num_layers):
             self.in_dims.append(d)
             e = self.side_dim(li)
+            Hl = net_dim[li]
             for dname in ('fw', 'bw'):
-                for vname, shape in (('kernel', (d + e + H, 4 * H)), ('bias', (4 * H,))):
+                for vname, shape in (('kernel', (d + e + Hl, 4 * Hl)), ('bias', (4 * Hl,))):
                     self.ref_entries.append(('cell_%d/%s/%s' % (li, dname, vname), shape, off))
                     off += int(np.prod(shape))
-            d = 2 * H
+            d = 2 * Hl
         self.ref_entries.append(('logits/weights', (2 * H, F), off))
         off += 2 * H * F
         self.ref_entries.append(('logits/biases', (F,), off))
@@ -123,7 +127,7 @@ class ParamLayout:
         # dZ -- the bias gradient -- for free inside the weight-gradient GEMM.  -1: no padded column to spare
         # (input width a multiple of 16), that layer's bias gradient is a separate column sum.
         self.ones_col = [self.input_dim if self.kp[0] > self.input_dim else -1] + \
-            [H if H < HP else -1] * (self.num_layers - 1)
+            [net_dim[li - 1] if net_dim[li - 1] < HP else -1 for li in range(1, self.num_layers)]
         self.ones_col_top = H if H < HP else -1
         self.packed = {}                               # name -> (offset, shape)
         poff = 0
@@ -181,8 +185,11 @@ class ParamLayout:
 
     def signature(self):
         """Shape signature stored in checkpoints."""
-        return ([self.input_dim, self.H, self.num_layers, self.F] + (list(self.side) if self.side else [])
-                + ([-self.mlp] if self.mlp else []) + ([-100000 - self.asr] if self.asr else []))
+        sig = ([self.input_dim, self.H, self.num_layers, self.F] + (list(self.side) if self.side else [])
+               + ([-self.mlp] if self.mlp else []) + ([-100000 - self.asr] if self.asr else []))
+        if len(set(self.Hs)) > 1:                      # unequal widths: spelled out behind a marker (equal: round 1's form)
+            sig += [-200000] + list(self.Hs)
+        return sig
 
     def _mlp_map(self):
         """[(packed name, reference name, row offset in the reference matrix, rows)] of the dense MLP entries."""
@@ -196,7 +203,7 @@ class ParamLayout:
     # ------------------------------------------------------------------------------
     def input_row_map(self, li):
         """Padded input column k of layer li -> row of the reference kernel (or -1)."""
-        H = self.H
+        H = self.Hs[li - 1] if li > 0 else 0           # units per direction of the layer below
         k = np.arange(self.kp[li])
         if li == 0:
             return np.where(k < self.input_dim, k, -1)
@@ -206,29 +213,37 @@ class ParamLayout:
         return r
 
     def _build_pack_index(self):
-        H, F, Z = self.H, self.F, self.ref_size
+        F, Z = self.F, self.ref_size
         idx = np.full(self.packed_size, Z, dtype=np.int64)
-        u = np.arange(H)
-        # the two fragment orders of the recurrent kernel do not depend on layer, direction or gate: positions and
-        # (k, unit) of the cells that hold a weight, once
+        # the two fragment orders of the recurrent kernel do not depend on direction or gate, and on the layer only through
+        # its width: positions and (k, unit) of the cells that hold a weight, once per width
         #   forward  [d][w][q][g][lane][s]:  Wh[k = 8q + 4(lane >> 5) + s][unit = 32w + (lane & 31)] of gate g
-        w_, q_, lane_, s_ = np.meshgrid(np.arange(8), np.arange(32), np.arange(64), np.arange(4), indexing='ij')
-        kk, uu = 8 * q_ + 4 * (lane_ >> 5) + s_, 32 * w_ + (lane_ & 31)
-        ok = (kk < H) & (uu < H)
-        f_pos, f_k, f_u = (((w_ * 32 + q_) * 4) * 256 + lane_ * 4 + s_)[ok], kk[ok], uu[ok]
+        fw_, fq_, flane_, fs_ = np.meshgrid(np.arange(8), np.arange(32), np.arange(64), np.arange(4), indexing='ij')
+        kk, uu = 8 * fq_ + 4 * (flane_ >> 5) + fs_, 32 * fw_ + (flane_ & 31)
+        fposall = ((fw_ * 32 + fq_) * 4) * 256 + flane_ * 4 + fs_
         #   transposed product [d][w][q 128][lane][s]:  Wh[unit' = 32w + (lane & 31)][packed col = 8q + 4(lane >> 5) + s]
         w_, q_, lane_, s_ = np.meshgrid(np.arange(8), np.arange(128), np.arange(64), np.arange(4), indexing='ij')
         col = 8 * q_ + 4 * (lane_ >> 5) + s_              # packed col inside this direction
         up = 32 * w_ + (lane_ & 31)                       # unit' (row of Wh)
         cg = (col % 128) // 32                            # gate of that column
         cu = (col // 128) * 32 + col % 32                 # hidden unit of that column
-        okb = (up < H) & (cu < H)
         posb = ((w_ * 128 + q_) * 64 + lane_) * 4 + s_
-        t_pos, t_up, t_cu = [], [], []
-        for g in range(4):
-            sel = okb & (cg == g)
-            t_pos.append(posb[sel]), t_up.append(up[sel]), t_cu.append(cu[sel])
+        frag = {}
+
+        def fragments(H):
+            if H not in frag:
+                ok = (kk < H) & (uu < H)
+                okb = (up < H) & (cu < H)
+                t_pos, t_up, t_cu = [], [], []
+                for g in range(4):
+                    sel = okb & (cg == g)
+                    t_pos.append(posb[sel]), t_up.append(up[sel]), t_cu.append(cu[sel])
+                frag[H] = (fposall[ok], kk[ok], uu[ok], t_pos, t_up, t_cu)
+            return frag[H]
         for li in range(self.num_layers):
+            H = self.Hs[li]
+            u = np.arange(H)
+            f_pos, f_k, f_u, t_pos, t_up, t_cu = fragments(H)
             E = self.side_dim(li)
             D = self.in_dims[li] + E                                    # first recurrent row of the TF kernel
             rmap = self.input_row_map(li)
@@ -255,6 +270,7 @@ class ParamLayout:
                     # transposed-product fragment order [d][w][q 128][lane][s]
                     whb_off, _ = self.packed['whb%d' % li]
                     idx[whb_off + d * (8 * 128 * 256) + t_pos[g]] = k_off + (D + t_up[g]) * (4 * H) + g * H + t_cu[g]
+        H = self.H                                       # the top layer feeds the projection
         pw_off, _ = self.packed['pw']
         pb_off, _ = self.packed['pb']
         rmap = np.full(2 * HP, -1, dtype=np.int64)
@@ -285,10 +301,11 @@ class ParamLayout:
 
     def _build_grad_index(self):
         """Position of every reference parameter's gradient inside the gpacked buffer."""
-        H, F = self.H, self.F
+        F = self.F
         gi = np.full(self.ref_size, -1, dtype=np.int64)
-        u = np.arange(H)
         for li in range(self.num_layers):
+            H = self.Hs[li]
+            u = np.arange(H)
             E = self.side_dim(li)
             Dm = self.in_dims[li]
             D = Dm + E
@@ -316,6 +333,7 @@ class ParamLayout:
                         gi[bias_off + g * H + u] = dwx_off + self.ones_col[li] * (2 * GP) + cols
                     else:
                         gi[bias_off + g * H + u] = db_off + cols
+        H = self.H
         dpw_off, _ = self.gpacked['dpw']
         dpb_off, _ = self.gpacked['dpb']
         prow = np.concatenate([np.arange(H), HP + np.arange(H)])

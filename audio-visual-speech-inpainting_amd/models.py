@@ -345,10 +345,11 @@ class StackedBLSTMModel(object):
         # zero padding inside the reductions (weight rows that are zero by construction, ParamLayout): layer 0 behind its
         # real inputs, the other layers and the projection behind the H real units of each direction
         H = self.layout.H
-        kz_hidden = ((H, HP), (HP + H, 2 * HP))
+        kz_hidden = ((H, HP), (HP + H, 2 * HP))            # behind the top layer's units (the projection's input)
         for li in range(self.num_layers):
             kp = self.layout.kp[li]
-            kz = ((self.layout.input_dim, kp),) if li == 0 else kz_hidden
+            Hin = self.layout.Hs[li - 1] if li else 0      # units per direction of the layer below
+            kz = ((self.layout.input_dim, kp),) if li == 0 else ((Hin, HP), (HP + Hin, 2 * HP))
             if self.layout.side_dim(li):
                 # tile(side) . W_side is the same row for every frame of an utterance: one small GEMM
                 # [Bp, E] . [E, 2048] (+ bias), broadcast over time, and the layer GEMM accumulates

@@ -36,8 +36,8 @@ typedef enum avsi_status {
 int avsi_abi_version(void);
 const char* avsi_status_string(int status);
 /* Host-only: AVSI_OK if the recurrent kernels take a stack of `num_layers` bidirectional LSTM layers of net_dim[l] units per
- * direction (config key net_dim; the reference takes any widths, models.py:95-99,107): equal widths of 1 .. 256 units.
- * AVSI_ERR_UNSUPPORTED for unequal widths or more than 256 units. */
+ * direction (config key net_dim; the reference takes any widths, models.py:95-99,107): any widths of 1 .. 256 units.
+ * AVSI_ERR_UNSUPPORTED for more than 256 units. */
 int avsi_blstm_net_supported(const int* net_dim, int num_layers);
 
 /* ------------------------------------------------------------------------------------

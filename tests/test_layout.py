@@ -205,16 +205,58 @@ def test_asr_head_shares_the_packed_projection():
 
 
 def test_net_dim_support_is_decided_by_the_c_abi():
-    """The reference takes any num_units per layer (models.py:95-99,107); the recurrent kernels equal widths of 1 .. 256 units.
-    The rule lives in the C ABI (avsi_blstm_net_supported) and the host layer reports ITS status."""
+    """The reference takes any num_units per layer (models.py:95-99,107); the recurrent kernels any widths of 1 .. 256 units
+    (each padded to 256).  The rule lives in the C ABI (avsi_blstm_net_supported) and the host layer reports ITS status."""
     import ctypes
     import pytest
     from avsi_amd import _lib
     L = _lib.lib()
-    for dims, want in (([250, 250, 250], _lib.AVSI_OK), ([256], _lib.AVSI_OK), ([7, 7], _lib.AVSI_OK), ([250, 128], _lib.AVSI_ERR_UNSUPPORTED),
-                       ([257, 257], _lib.AVSI_ERR_UNSUPPORTED), ([0], _lib.AVSI_ERR_INVALID_ARG)):
+    for dims, want in (([250, 250, 250], _lib.AVSI_OK), ([256], _lib.AVSI_OK), ([7, 7], _lib.AVSI_OK), ([250, 128], _lib.AVSI_OK),
+                       ([257, 257], _lib.AVSI_ERR_UNSUPPORTED), ([250, 300], _lib.AVSI_ERR_UNSUPPORTED), ([0], _lib.AVSI_ERR_INVALID_ARG)):
         assert L.avsi_blstm_net_supported((ctypes.c_int * len(dims))(*dims), len(dims)) == want, dims
     assert ParamLayout(257, (64, 64)).H == 64
-    for bad in ((250, 128, 250), (300, 300)):
+    for bad in ((250, 257, 250), (300, 300)):
         with pytest.raises(_lib.AvsiError, match="unsupported shape"):
             ParamLayout(257, bad)
+
+
+def test_unequal_layer_widths_pack_layer_by_layer():
+    """net_dim = (96, 250, 40): every layer's kernel is (d + H_l, 4 H_l) with d = 2 H_{l-1} (models.py:95-99,107); each is padded
+    to 256 units of its own, the ones column of a layer's input sits behind the units of the layer BELOW, the projection reads
+    the TOP layer's 2 x 40."""
+    dims = (96, 250, 40)
+    lay = ParamLayout(257, dims)
+    assert (lay.H, lay.Hs, lay.in_dims) == (40, dims, [257, 192, 500])
+    assert lay.ones_col == [257, 96, 250] and lay.ones_col_top == 40
+    p = O.init_params(5, 257, net_dim=dims)
+    flat = lay.flatten_oracle_params(p)
+    assert flat.size == lay.ref_size
+    packed = np.concatenate([flat, [0.0]])[lay.pack_index]
+    for li, H in enumerate(dims):
+        kf, kb = p['layers'][li]['fw']['kernel'], p['layers'][li]['bw']['kernel']
+        D = lay.in_dims[li]
+        assert kf.shape == (D + H, 4 * H)
+        wx = lay.packed_view(packed, 'wx%d' % li)
+        rm = lay.input_row_map(li)
+        g, u = 2, H - 1
+        for k in np.flatnonzero(rm >= 0)[[0, 1, -1]]:
+            assert wx[k, packed_gate_col(0, g, u)] == kf[rm[k], g * H + u]
+            assert wx[k, packed_gate_col(1, g, u)] == kb[rm[k], g * H + u]
+        # the constant-1 column of the layer's input: zero weights forward, the bias gradient's row in the gradient layout
+        if lay.ones_col[li] >= 0:
+            assert not wx[lay.ones_col[li]].any()
+            off, shape = lay.gpacked['dwx%d' % li]
+            gb = lay.ref_view(lay.grad_index, 'cell_%d/fw/bias' % li)
+            assert gb[g * H + u] == off + lay.ones_col[li] * shape[1] + packed_gate_col(0, g, u)
+        if H < HP:
+            assert not wx[:, packed_gate_col(0, g, H)].any()        # a unit past the layer's width: no weights at all
+        # recurrent fragments: count of non-zeros = 2 directions x 4 gates x H x H in both orders
+        assert np.count_nonzero(lay.packed_view(packed, 'wh%d' % li)) == 2 * 4 * H * H
+        assert np.count_nonzero(lay.packed_view(packed, 'whb%d' % li)) == 2 * 4 * H * H
+    pw = lay.packed_view(packed, 'pw')
+    np.testing.assert_array_equal(pw[:40, :257], p['proj']['weights'][:40])
+    np.testing.assert_array_equal(pw[HP:HP + 40, :257], p['proj']['weights'][40:])
+    assert not pw[40:HP].any() and not pw[HP + 40:].any()
+    assert len(np.unique(lay.grad_index)) == lay.ref_size and lay.grad_index.max() < lay.gpacked_size
+    assert lay.signature() == [257, 40, 3, 257, -200000, 96, 250, 40]
+    assert ParamLayout(257, (250, 250, 250)).signature() == [257, 250, 3, 257]

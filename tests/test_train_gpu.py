@@ -157,3 +157,37 @@ def test_three_adam_steps_track_oracle(mods):
     # Adam normalises the step to ~lr, so parameters agree to a small fraction of 3 * lr
     assert np.abs(got_flat - ref_flat).max() < 5e-4
     assert np.sqrt(np.mean((got_flat - ref_flat) ** 2)) < 2e-5
+
+
+@pytest.mark.parametrize("net_dim", [(96, 250, 40), (256, 17), (8,)])
+def test_unequal_layer_widths_match_oracle(mods, net_dim):
+    """The reference takes any num_units per layer (models.py:95-99,107: one LSTMCell per entry of net_dim, the next layer reads
+    2 x the width below).  Every layer is packed to 256 units of its own (ParamLayout.Hs); prediction, loss and every variable's
+    gradient against the oracle, which builds the same stack from the same net_dim."""
+    models, ops, bl = mods
+    B, N = 5, 2880
+    wav, masks, mean, std, video, T = _inputs(B, N, 77)
+    p = _rand_biases(O.init_params(13, 257, net_dim=net_dim), 14)
+    seq_len = np.full(B, T)
+    seq_len[1] = T - 3
+    m = models.StackedBLSTMModel(seq_len, wav, masks, mean, std, 0.0, _config(audio_len=N, net_dim=list(net_dim)), input='a')
+    assert m.layout.Hs == tuple(net_dim) and m.layout.H == net_dim[-1]
+    m.variables.load_flat(m.layout.flatten_oracle_params(p))
+    fwd = O.model_forward(wav, masks, mean, std, seq_len, p, input_type='a', keep=True)
+    np.testing.assert_allclose(m.prediction.cpu().numpy(), fwd['prediction'], rtol=0, atol=2e-4)
+    assert m.rnn_outputs.shape == (B, T, 2 * net_dim[-1])
+    got = m.gradients.cpu().numpy().astype(np.float64)
+    ref = _flat_grads(m.layout, O.model_backward(fwd, masks.astype(np.float64), seq_len))
+    assert got.shape == ref.shape
+    for name, shape, off in m.layout.ref_entries:
+        n = int(np.prod(shape))
+        g, r = got[off:off + n], ref[off:off + n]
+        scale = np.abs(r).max()
+        assert np.abs(g - r).max() <= 2e-3 * scale + 1e-9, (name, np.abs(g - r).max(), scale)
+    # one Adam step moves only real weights: the packed padding stays exactly zero
+    m.train_op
+    torch.cuda.synchronize()
+    packed = m.variables.packed.cpu().numpy()
+    keep = np.zeros(packed.size, dtype=bool)
+    keep[np.flatnonzero(m.layout.pack_index < m.layout.ref_size)] = True
+    assert not packed[~keep].any()
