@@ -9,7 +9,7 @@ from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int32, c_int6
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libavsi_hip.so")
-ABI_VERSION = 9
+ABI_VERSION = 10
 
 AVSI_OK = 0
 AVSI_ERR_INVALID_ARG, AVSI_ERR_UNSUPPORTED, AVSI_ERR_LAUNCH, AVSI_ERR_WORKSPACE = -1, -2, -3, -4
@@ -198,6 +198,9 @@ PROTOTYPES = {
     "avsi_lws_run_skew_workspace_bytes": (c_size_t, [c_int, c_int]),
     "avsi_lws_skew_launch_shape": (c_int, [c_int, c_int, c_int, ctypes.POINTER(c_int), ctypes.POINTER(c_int)]),
     "avsi_lws_run_skew_f32": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_int, c_float, c_int,
+                                      c_float, c_float, c_float, c_int, c_int, c_void_p, c_size_t, c_void_p]),
+    "avsi_lws_run_duo_workspace_bytes": (c_size_t, [c_int, c_int]),
+    "avsi_lws_run_duo_f32": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_int, c_float, c_int,
                                       c_float, c_float, c_float, c_int, c_int, c_void_p, c_size_t, c_void_p]),
     "avsi_lws_istft_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
     "avsi_lws_istft_f32": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_int64, c_int, c_void_p,

@@ -196,7 +196,7 @@ __device__ __forceinline__ void skew_step(LaneState& L, const StepCtx& C, const 
     float2 T = own;
     T.x = fmaf(c.x, upr.x, fmaf(-c.y, upr.y, T.x)), T.y = fmaf(c.x, upr.y, fmaf(c.y, upr.x, T.y));          // c . up
     T.x = fmaf(c.x, dnr.x, fmaf(c.y, dnr.y, T.x)), T.y = fmaf(c.x, dnr.y, fmaf(-c.y, dnr.x, T.y));          // conj(c) . down
-    const float n2 = T.x * T.x + T.y * T.y;
+    const float n2 = fmaf(T.x, T.x, T.y * T.y);          // (written as the fused form: the compiler's own choice differs from copy to copy)
     const bool valid = tau >= 0 && tau <= KB - 1 && m < C.M;
     const bool upd = valid && amp > C.thr && n2 > 0.f;
     const float sc = amp * __builtin_amdgcn_rsqf(n2);
@@ -405,7 +405,7 @@ __global__ __launch_bounds__(256) void lws_to_diag_kernel(const float2* __restri
             const float2* sp = spec + ((int64_t)b * M + m) * KB;
             if (x < KB) {
                 v = sp[x];
-                a = sqrtf(v.x * v.x + v.y * v.y);
+                a = sqrtf(fmaf(v.x, v.x, v.y * v.y));      // (the fused form, spelled out: lws_duo.hip takes the same)
             } else {
                 v = conjf2(sp[2 * (KB - 1) - x]);
             }

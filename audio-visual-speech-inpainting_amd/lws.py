@@ -46,10 +46,12 @@ class lws(object):
                  online_iterations=0, online_alpha=1, batch_iterations=100, batch_alpha=100, batch_beta=0.1, batch_gamma=1,
                  symmetric_win=True, mode=None, fftsize=None, utterances_per_wave=0, waves_per_group=0,
                  groups_per_utterance=0, kernel=None):
-        """``kernel``: 'skew' (default; AVSI_LWS_KERNEL overrides) = the sweeps with frames in the lanes of a wave
-        (csrc/lws_skew.hip), 'raster' = the frame-by-frame kernel of csrc/lws.hip (``utterances_per_wave`` > 0 selects it
-        too: that argument only exists there).  ``waves_per_group`` / ``groups_per_utterance`` shape the pipeline of sweeps
-        of either kernel; results do not depend on them."""
+        """``kernel``: 'auto' (default; AVSI_LWS_KERNEL overrides) = 'duo' from AVSI_LWS_DUO_MIN utterances of the
+        reference's geometry, 'skew' below; 'skew' = the sweeps with the frames of ONE utterance in the lanes of a wave
+        (csrc/lws_skew.hip), 'duo' = two utterances per wave, every lane busy (csrc/lws_duo.hip; bit-identical to
+        'skew'), 'raster' = the frame-by-frame kernel of csrc/lws.hip (``utterances_per_wave`` > 0 selects it too: that
+        argument only exists there).  ``waves_per_group`` / ``groups_per_utterance`` (per pair of utterances for 'duo')
+        shape the pipeline of sweeps of any kernel; results do not depend on them."""
         if not isinstance(awin_or_fsize, (int, np.integer)) or swin is not None or not symmetric_win:
             raise _lib.AvsiError("lws: only the window-length form with the default sqrt-Hann windows is implemented")
         if mode == 'speech':
@@ -69,9 +71,10 @@ class lws(object):
         self.batch_alpha, self.batch_beta, self.batch_gamma = float(batch_alpha), float(batch_beta), float(batch_gamma)
         self.utterances_per_wave, self.waves_per_group = int(utterances_per_wave), int(waves_per_group)
         self.groups_per_utterance = int(groups_per_utterance)
-        self.kernel = kernel or ('raster' if self.utterances_per_wave else os.environ.get('AVSI_LWS_KERNEL', 'skew'))
-        if self.kernel not in ('skew', 'raster'):
-            raise ValueError("kernel must be 'skew' or 'raster'")
+        self.kernel = kernel or ('raster' if self.utterances_per_wave else os.environ.get('AVSI_LWS_KERNEL', 'auto'))
+        if self.kernel not in ('auto', 'skew', 'duo', 'raster'):
+            raise ValueError("kernel must be 'auto', 'skew', 'duo' or 'raster'")
+        self.duo_min = int(os.environ.get('AVSI_LWS_DUO_MIN', '256'))
         self._status = None
         if _lib.lib().avsi_lws_table_floats(self.fsize, self.fshift, self.fftsize) == 0:
             raise _lib.AvsiError("unsupported LWS geometry: window %d, shift %d, fft %d" % (self.fsize, self.fshift, self.fftsize))
@@ -120,19 +123,30 @@ class lws(object):
         out = out[0] if single else out
         return out.cpu().numpy() if host else out
 
+    def _standard_geometry(self):
+        return (self.fsize, self.fshift, self.fftsize, self.L) == (384, 192, 512, 5)
+
+    def kernel_for(self, batch):
+        """The kernel a batch of this size takes: 'auto' = two utterances per wave once the batch fills the chip that way."""
+        if self.kernel != 'auto':
+            return self.kernel
+        return 'duo' if batch >= self.duo_min and self._standard_geometry() else 'skew'
+
     def _run(self, s):
         B, M = s.shape[0], s.shape[1]
-        if self.kernel == 'skew':
-            need = _lib.lib().avsi_lws_run_skew_workspace_bytes(B, M)
+        kernel = self.kernel_for(B)
+        if kernel in ('skew', 'duo'):
+            L = _lib.lib()
+            size, run = ((L.avsi_lws_run_duo_workspace_bytes, L.avsi_lws_run_duo_f32) if kernel == 'duo' else
+                         (L.avsi_lws_run_skew_workspace_bytes, L.avsi_lws_run_skew_f32))
+            need = size(B, M)
             if self._status is None or self._status.device != s.device or self._status.numel() * 4 < need:
-                self._status = None                 # (drop the old workspace first: they are ~1.4 MB per utterance)
+                self._status = None                 # (drop the old workspace first: they are 1.4 - 1.7 MB per utterance)
                 self._status = torch.zeros((need + 3) // 4, dtype=torch.int32, device=s.device)
-            _lib.check(_lib.lib().avsi_lws_run_skew_f32(_lib.ptr(s), B, M, self.fsize, self.fshift, self.fftsize, self.L,
-                                                        self.nofuture_iterations, self.nofuture_alpha, self.online_iterations,
-                                                        self.online_alpha, self.batch_iterations, self.batch_alpha,
-                                                        self.batch_beta, self.batch_gamma, self.waves_per_group,
-                                                        self.groups_per_utterance, _lib.ptr(self._status),
-                                                        self._status.numel() * 4, _lib.stream_ptr()), "avsi_lws_run_skew_f32")
+            _lib.check(run(_lib.ptr(s), B, M, self.fsize, self.fshift, self.fftsize, self.L, self.nofuture_iterations,
+                           self.nofuture_alpha, self.online_iterations, self.online_alpha, self.batch_iterations, self.batch_alpha,
+                           self.batch_beta, self.batch_gamma, self.waves_per_group, self.groups_per_utterance,
+                           _lib.ptr(self._status), self._status.numel() * 4, _lib.stream_ptr()), "avsi_lws_run_%s_f32" % kernel)
             return
         need = _lib.lib().avsi_lws_run_workspace_bytes(B)
         if self._status is None or self._status.device != s.device or self._status.numel() * 4 < need:

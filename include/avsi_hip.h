@@ -423,6 +423,14 @@ int avsi_istft_f32(const avsi_istft_args* args, void* stream);
  *                        GPU work); results do not depend on either.  The workspace
  *                        (avsi_lws_run_skew_workspace_bytes(batch, num_frames), ~1.4 MB per utterance of 252 frames)
  *                        holds the spectrogram in the kernel's diagonal layout; word 0 is the status as above
+ *   avsi_lws_run_duo_f32   the same sweeps with TWO utterances in the lanes of a wave, 32 frames each, nine bins apart, the
+ *                        neighbour rows' sums handed on through LDS and memory (csrc/lws_duo.hip): every lane busy, against
+ *                        45 of 64 in the skewed kernel -- the large-batch form (the host layer takes it from
+ *                        AVSI_LWS_DUO_MIN utterances), bit-identical results.  The reference's geometry only
+ *                        (384 / 192 / 512, L = 5; others: AVSI_ERR_UNSUPPORTED, take avsi_lws_run_skew_f32).
+ *                        waves_per_group (4, 8, 16; 0 = 16) consecutive sweeps per workgroup, groups_per_pair workgroups
+ *                        chained per two utterances (0 = as many as fill the chip); workspace
+ *                        avsi_lws_run_duo_workspace_bytes(batch, num_frames), ~1.7 MB per utterance of 252 frames
  *   avsi_lws_istft_f32   lws.istft  (inference.py:153): out [B][out_samples], out_samples <=
  *                        (num_frames - 1) hop + nfft - 2 (nfft - hop); workspace from avsi_lws_istft_workspace_bytes
  * ------------------------------------------------------------------------------------ */
@@ -446,6 +454,11 @@ int avsi_lws_run_skew_f32(float* spec, int batch, int num_frames, int frame_len,
                           void* stream);
 size_t avsi_lws_run_skew_workspace_bytes(int batch, int num_frames);
 int avsi_lws_skew_launch_shape(int batch, int num_frames, int sweeps, int* waves_per_group, int* groups_per_utterance);
+int avsi_lws_run_duo_f32(float* spec, int batch, int num_frames, int frame_len, int hop, int nfft, int L,
+                          int nofuture_iterations, float nofuture_alpha, int online_iterations, float online_alpha,
+                          int batch_iterations, float batch_alpha, float batch_beta, float batch_gamma,
+                          int waves_per_group, int groups_per_pair, void* workspace, size_t workspace_bytes, void* stream);
+size_t avsi_lws_run_duo_workspace_bytes(int batch, int num_frames);
 size_t avsi_lws_istft_workspace_bytes(int batch, int num_frames, int nfft);
 int avsi_lws_istft_f32(const float* spec, int batch, int num_frames, const float* table, int hop, int nfft, float* out,
                        int64_t out_stride, int out_samples, void* workspace, size_t workspace_bytes, void* stream);
