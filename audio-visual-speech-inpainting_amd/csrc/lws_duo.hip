@@ -12,7 +12,7 @@
 // its next frame every 32 x 9 = 288 steps and is busy for 279 of them.  What changes against lws_skew.hip:
 //   * the old-value ring R looks 15 positions ahead instead of 11 (the row-below sum `up` that lane j makes for lane j - 1
 //     belongs to a bin nine ahead of its own, and it is made one step early): rings of 15, a 15-step unrolled body, progress
-//     published in thirds of a body (5 steps);
+//     published in fifths of a body (3 steps);
 //   * the row-above sum `dn` that lane j makes for lane j + 1 is the one of position tau - 8 (all of it two steps old:
 //     nothing of it waits for the bin of this step);
 //   * both travel through LDS -- a rotate inside 32 lanes does not exist as a DPP -- written by every lane for its
@@ -40,7 +40,7 @@ constexpr int LANES = 64, LPU = 32, UPW = LANES / LPU;      // lanes per utteran
 constexpr int SKEW = 9;                    // bins a frame runs behind the frame before it
 constexpr int PERIOD = SKEW * LPU;         // 288 steps between two frames of a lane
 constexpr int UNR = 15;                    // steps per unrolled body = ring length
-constexpr int PART = 5, PARTS = UNR / PART;                // progress is published in parts of a body
+constexpr int PART = 3, PARTS = UNR / PART;                // progress is published in parts of a body
 constexpr int T0 = -30;                    // time of step 0 (a multiple of 15, hence of 3)
 constexpr int ROW_OFF = 5;                 // row of (frame m, position x) = x + 9 m + ROW_OFF
 constexpr int LOOK = UNR;                  // the old-value ring holds positions tau + 1 .. tau + LOOK
@@ -48,10 +48,18 @@ constexpr int UP_AHEAD = SKEW + 1;         // `up` of a step is the one of the n
 constexpr int DN_LAG = SKEW - 1;           // `dn` of a step is the one of position tau - 8 (the neighbour's NEXT step)
 constexpr int TAU_LAST = 2 * (KB - 1) - (KB - 1 - LMAX);   // 261: last mirror position above Nyquist (kept in the layout)
 constexpr int TAU_END = KB - 1 + DN_LAG;   // 264: the step that makes `dn` of bin 256
-constexpr int PF = 6;                      // steps between the request of a row and its use (the landing ring has UNR slots)
+constexpr int PF = 5;                      // steps between the request of a row and its use (the landing ring has UNR slots)
 constexpr int OPS = 3;                     // memory operations per step and lane
 // a stage in part h loads rows up to t + PF + LOOK + ROW_OFF, which its predecessor stores PF + LOOK steps later
 constexpr int AHEAD = (PART - 1 + PF + LOOK) / PART + 1;
+// Inside a workgroup a stage hands its rows to the next one through a ring of RING_S rows in LDS (slot = row mod 15 = a
+// constant of the unrolled copy), requested PFL steps ahead.  Counters there count parts ISSUED (LDS operations of a CU are
+// performed in the order they are issued: a row is there when the counter written behind it is): a stage starts part h
+// when its predecessor has issued h + AHEAD_L parts, and part g when its successor has issued g - BACK (the slots it is
+// about to overwrite have been read) -- a lead of 7 .. 9 parts.
+constexpr int RING_S = UNR, PFL = 2;
+constexpr int AHEAD_L = (PART - 1 + PFL + LOOK) / PART + 1;
+constexpr int BACK = (RING_S + PFL + LOOK) / PART - 1;             // = ceil((RING_S + PFL + LOOK - (PART - 1)) / PART) - 1
 constexpr int QSLACK = 6;
 constexpr int CTR_STRIDE = 64;
 constexpr int GPROG_INTS = (MAX_SWEEPS / 4) * CTR_STRIDE;
@@ -59,7 +67,8 @@ static_assert(TAU_LAST == 261 && KB == 257 && LMAX == 5, "the edge rules below a
 static_assert(SKEW % 3 == 0 && UNR % 3 == 0 && T0 % UNR == 0, "a lane's local time must be congruent to the unrolled copy's index mod 3");
 static_assert(UP_AHEAD + LMAX == LOOK && DN_LAG + LMAX < UNR, "the windows of the two neighbour sums must lie inside the rings");
 static_assert(PERIOD >= TAU_END + 1 + (LOOK - 1), "a lane must be done with a frame before position 1 of its next one arrives");
-static_assert(AHEAD == 6 && OPS * PART < 64, "counted waits");
+static_assert(AHEAD == 8 && OPS * PART < 64, "counted waits");
+static_assert(AHEAD_L == 7 && BACK == 9 && BACK >= AHEAD_L + 1, "the lead a stage may have over the next one inside a workgroup");
 
 __host__ __device__ constexpr int duo_rows(int M) {         // + look-ahead of the last steps, + the scratch row
     return ((SKEW * (M - 1) + TAU_END + ROW_OFF + 1 + 2 * UNR + LOOK + PF + 8 + UNR - 1) / UNR) * UNR;
@@ -67,6 +76,8 @@ __host__ __device__ constexpr int duo_rows(int M) {         // + look-ahead of t
 __host__ __device__ constexpr int duo_steps(int M) { return SKEW * (M - 1) + TAU_END - T0 + 1; }
 
 __device__ __forceinline__ float2 cmadd(float2 acc, float wr, float wi, float2 x) {
+    // (a weight that is real at compile time: the two products with +-0 add nothing but the sign of a zero)
+    if (__builtin_constant_p(wi) && wi == 0.f) return make_float2(fmaf(wr, x.x, acc.x), fmaf(wr, x.y, acc.y));
     return make_float2(fmaf(wr, x.x, fmaf(-wi, x.y, acc.x)), fmaf(wr, x.y, fmaf(wi, x.x, acc.y)));
 }
 __device__ __forceinline__ float2 conjf2(float2 v) { return make_float2(v.x, -v.y); }
@@ -110,7 +121,7 @@ constexpr int ring(int i) { return ((i % UNR) + UNR) % UNR; }
 constexpr unsigned ROW8 = LANES * sizeof(float2), ROW4 = LANES * sizeof(float);
 
 struct LaneState {
-    float2 R[UNR], P[UNR], Ls[UNR];
+    float2 R[UNR], P[UNR], Ls[UNR], Lq[UNR];   // Ls / Lq: rows on their way from memory / from the predecessor's LDS ring
     float La[UNR];
     float2 cnext, unext, dnext;     // c(tau), up and dn of the coming step, requested from LDS a step ahead
     int tau, m;
@@ -121,6 +132,8 @@ struct StepCtx {
     const float* Ag;                // ... and its magnitudes
     const float2* ctab;             // LDS: c(k), k mod 64
     float2* xch;                    // LDS: this wave's exchange rows, [2][64]: up, dn
+    float2* ring_out;               // LDS: this stage's row ring [RING_S][64] (read by the next stage of the workgroup)
+    const float2* ring_in;          // LDS: the ring of the stage before (its own for the first wave: not used there)
     int trash_row;
     bool past_only, din, dout;      // (wave-uniform)
     float thr;                      // per lane: the threshold of the lane's utterance
@@ -142,9 +155,13 @@ __device__ __forceinline__ void duo_step(LaneState& L, const StepCtx& C, int n) 
     const int t = T0 + n;                                  // wave-uniform
     // ---- the operands requested PF steps ago (the wait takes the landing registers as operands: lws_skew.hip)
     asm volatile("s_waitcnt vmcnt(%3)" : "+v"(L.Ls[I].x), "+v"(L.Ls[I].y), "+v"(L.La[I]) : "n"(OPS * PF - 2) : "memory");
-    const float2 arr = L.Ls[I], upv0 = L.unext, dnv = L.dnext;
+    // (the first wave of a workgroup takes its rows from memory -- the stage before sits in another workgroup -- the others from
+    // the ring of the wave before; the memory request stays in every wave's stream, at a fixed row where it is not needed,
+    // so that the counted waits are the same for all)
+    const float2 arr = sel(C.din, L.Ls[I], L.Lq[I]), upv0 = L.unext, dnv = L.dnext;
     const float amp = L.La[I];
-    row_load8(C.din, L.Ls[ring(I + PF)], C.Sg, C.lane8 + rowpos(t + PF + LOOK + ROW_OFF) * ROW8);     // position tau + 15 of step n + PF
+    row_load8(C.din, L.Ls[ring(I + PF)], C.Sg, C.lane8 + (C.din ? rowpos(t + PF + LOOK + ROW_OFF) : 0u) * ROW8);     // position tau + 15 of step n + PF
+    L.Lq[ring(I + PFL)] = C.ring_in[ring(I + PFL + LOOK + ROW_OFF) * LANES + C.lane];                  // ... of step n + PFL: row n + PFL + 20
     row_load4(L.La[ring(I + PF)], C.Ag, C.lane4 + rowpos(t + PF + ROW_OFF) * ROW4);                   // magnitude of the bin of step n + PF
     const int tau = L.tau, m = L.m;
     const float2 old = L.R[I];                                                         // position tau: its slot takes the arrival
@@ -154,37 +171,71 @@ __device__ __forceinline__ void duo_step(LaneState& L, const StepCtx& C, int n) 
         constexpr int x = decltype(k)::value;
         L.R[ring(I - 2 * x)] = sel(tau + LOOK == x, conjf2(arr), L.R[ring(I - 2 * x)]);
     });
-    // ---- three sums over this lane's own rings (slot I - e of R: position tau + 15 - e; slot I - e of P: position tau - e)
+    // ---- three sums over this lane's own rings (slot I - e of R: position tau + 15 - e; slot I - e of P: position tau - e).
+    //      `up` and `dn` are for the NEXT step of the neighbours, and nothing of this step waits for them: their second halves
+    //      fill the issue slots of the dependent chain own -> t -> |t|^2 -> rsq -> scale -> select (a dozen levels, each
+    //      waiting for the one before: left to itself the compiler puts all the sums first and the chain bare behind them).
+    //      FENCE = nothing moves across; one multiply-add of a sum per level.
+#define UP_TAP(p) up = cmadd(up, WBU((p) + LMAX, 0), WBU((p) + LMAX, 1), L.R[ring(I - (LMAX - (p)))])               /* tau + 10 + p */
+#define DN_TAP(p) dn = cmadd(dn, WBD((p) + LMAX, 0), WBD((p) + LMAX, 1), L.P[ring(I - (DN_LAG - (p)))])            /* tau - 8 + p */
+#define FENCE __builtin_amdgcn_sched_barrier(0)
     float2 up = make_float2(0.f, 0.f), dn = up, own = up;
-#pragma unroll
-    for (int p = -LMAX; p <= LMAX; ++p) up = cmadd(up, WBU(p + LMAX, 0), WBU(p + LMAX, 1), L.R[ring(I - (LMAX - p))]);             // tau + 10 + p
+    UP_TAP(-5), UP_TAP(-4), UP_TAP(-3), UP_TAP(-2), UP_TAP(-1);
 #pragma unroll
     for (int p = 1; p <= LMAX; ++p) own = cmadd(own, WB0(LMAX + p, 0), WB0(LMAX + p, 1), L.R[ring(I - (LOOK - p))]);               // tau + p
-#pragma unroll
-    for (int p = -LMAX; p <= LMAX; ++p) dn = cmadd(dn, WBD(p + LMAX, 0), WBD(p + LMAX, 1), L.P[ring(I - (DN_LAG - p))]);           // tau - 8 + p
+    DN_TAP(-5), DN_TAP(-4), DN_TAP(-3), DN_TAP(-2), DN_TAP(-1);
 #pragma unroll
     for (int p = LMAX; p >= 1; --p) own = cmadd(own, WB0(LMAX - p, 0), WB0(LMAX - p, 1), L.P[ring(I - p)]);                        // tau - p
+    const float2 c = L.cnext;
+    float2 upv = upv0;
+    if (C.past_only) own = make_float2(0.f, 0.f), upv = own;
+    const bool live = m < C.Ml;
+    const bool valid = tau >= 0 && tau <= KB - 1 && live;
+    FENCE;
+    float2 T = own;
+    T.x = fmaf(-c.y, upv.y, T.x), T.y = fmaf(c.y, upv.x, T.y);
+    UP_TAP(0);
+    FENCE;
+    T.x = fmaf(c.x, upv.x, T.x), T.y = fmaf(c.x, upv.y, T.y);                             // c . up
+    DN_TAP(0);
+    FENCE;
+    T.x = fmaf(c.y, dnv.y, T.x), T.y = fmaf(-c.y, dnv.x, T.y);
+    UP_TAP(1);
+    FENCE;
+    T.x = fmaf(c.x, dnv.x, T.x), T.y = fmaf(c.x, dnv.y, T.y);                             // conj(c) . down
+    DN_TAP(1);
+    FENCE;
+    const float yy = T.y * T.y;
+    UP_TAP(2);
+    FENCE;
+    const float n2 = fmaf(T.x, T.x, yy);                 // (written as the fused form: the compiler's own choice differs from copy to copy)
+    DN_TAP(2);
+    FENCE;
+    const float rs = __builtin_amdgcn_rsqf(n2);
+    const bool upd = valid && amp > C.thr && n2 > 0.f;
+    UP_TAP(3), DN_TAP(3);
+    FENCE;
+    const float sc = amp * rs;
+    UP_TAP(4);
+    FENCE;
+    const float2 vs = make_float2(T.x * sc, T.y * sc);
+    DN_TAP(4);
+    FENCE;
+    const float2 v = sel(upd, vs, old);
+    UP_TAP(5), DN_TAP(5);
+    FENCE;
     // ---- exchange for the NEXT step: this frame's `up` goes to the frame before (at its bin tau + 10), its `dn` to the frame
     //      after (at its bin tau - 8); zero where there is nothing to give (no frame here, or the neighbour not at a bin)
-    const bool live = m < C.Ml;
     const bool up_ok = live && tau + UP_AHEAD >= 0 && tau + UP_AHEAD <= KB - 1;
     const bool dn_ok = live && tau - DN_LAG >= 0 && tau - DN_LAG <= KB - 1;
     C.xch[C.lane] = sel(up_ok, up, make_float2(0.f, 0.f));
     C.xch[LANES + C.lane] = sel(dn_ok, dn, make_float2(0.f, 0.f));
     L.unext = C.xch[C.next];
     L.dnext = C.xch[LANES + C.prev];
-    const float2 c = L.cnext;
     L.cnext = C.ctab[(tau + 1) & 63];
-    float2 upv = upv0;
-    if (C.past_only) own = make_float2(0.f, 0.f), upv = own;
-    float2 T = own;
-    T.x = fmaf(c.x, upv.x, fmaf(-c.y, upv.y, T.x)), T.y = fmaf(c.x, upv.y, fmaf(c.y, upv.x, T.y));          // c . up
-    T.x = fmaf(c.x, dnv.x, fmaf(c.y, dnv.y, T.x)), T.y = fmaf(c.x, dnv.y, fmaf(-c.y, dnv.x, T.y));          // conj(c) . down
-    const float n2 = fmaf(T.x, T.x, T.y * T.y);          // (written as the fused form: the compiler's own choice differs from copy to copy)
-    const bool valid = tau >= 0 && tau <= KB - 1 && live;
-    const bool upd = valid && amp > C.thr && n2 > 0.f;
-    const float sc = amp * __builtin_amdgcn_rsqf(n2);
-    const float2 v = sel(upd, make_float2(T.x * sc, T.y * sc), old);
+#undef UP_TAP
+#undef DN_TAP
+#undef FENCE
     // ---- what this lane hands on for position tau: the bin, or a mirror image
     float2 out = v;
     // below DC (tau in [-5, -1]): conj of the old bins 5 .. 1, the start values of the "new" ring
@@ -211,7 +262,9 @@ __device__ __forceinline__ void duo_step(LaneState& L, const StepCtx& C, int n) 
     });
     // ---- store (row t + 5, every lane, always: lanes with nothing to store write a scratch row)
     const bool st = tau >= 0 && tau <= TAU_LAST && live;
-    const unsigned off = C.lane8 + (unsigned)(st ? t + ROW_OFF : C.trash_row) * ROW8;
+    // (to the next stage: through this stage's ring, row n + 5; to memory only where the next stage sits in another workgroup)
+    C.ring_out[ring(I + ROW_OFF) * LANES + C.lane] = out;
+    const unsigned off = C.lane8 + (unsigned)(st && C.dout ? t + ROW_OFF : C.trash_row) * ROW8;
     row_store8(C.dout, const_cast<float2*>(C.Sg), off, out);
     // ---- next step of this lane
     const int nt = tau + 1;
@@ -238,17 +291,26 @@ struct StageCtx {
     float mean2[UPW], amax2[UPW];
 };
 
-// the sweeps of one stage (lws_skew.hip: skew_sweeps)
+// the sweeps of one stage (lws_skew.hip: skew_sweeps; here with the two-way hand-shake of the LDS rings)
 template <int NW>
 __device__ __forceinline__ void duo_sweeps(StepCtx& C, const AvsiLwsSchedule& sched, const StageCtx& Q) {
     const int wv = Q.wv, wg = Q.wg, lane = Q.lane, stage = Q.stage, stages = Q.stages, nb = Q.nb, hlast = Q.hlast, nbp = Q.nbp;
+    const int total = PARTS * nb;                 // parts of a sweep
     int* gprog = Q.gprog;
-    volatile int* vprog = Q.vprog;
+    volatile int* vprog = Q.vprog;                // parts ISSUED, per wave of this workgroup (monotone over the sweeps of a stage)
     int* status = Q.status;
     const bool dev_in = C.din, dev_out = C.dout;
     bool dead = false;
-    int known = 0, mine = 0;
+    int known = 0, known_s = 0, mine = 0;
+    int n_active = 0;
+    for (int sw = 0; sw < sched.n; ++sw) {
+        bool active = false;
+#pragma unroll
+        for (int u = 0; u < UPW; ++u) active = active || Q.amax2[u] > sched.rel[sw] * Q.mean2[u];
+        n_active += active ? 1 : 0;
+    }
     int rank_a = -1, last_active = -1;
+    int prev_succ_done = -1;                      // counter value of the next wave that says "has read all of my last sweep"
     for (int sw = 0; sw < sched.n; ++sw) {
         const float rel = sched.rel[sw];
         bool active = false;
@@ -263,26 +325,24 @@ __device__ __forceinline__ void duo_sweeps(StepCtx& C, const AvsiLwsSchedule& sc
         const int pstage = pred < 0 ? -1 : (rank_a - 1) % stages;
         const int pbase = pred < 0 ? 0 : ((rank_a - 1) / stages) * nbp;
         const int base = mine * nbp;
+        // the sweep after this one runs on the next wave of this workgroup (unless this is the last wave, or the last sweep)
+        const bool succ_here = !dev_out && rank_a + 1 < n_active;
+        C.dout = dev_out || rank_a + 1 >= n_active;           // rows go to memory for another workgroup -- or as the result
+        const int sbase = ((rank_a + 1) / stages) * nbp;
         LaneState L;
 #pragma unroll
-        for (int i = 0; i < UNR; ++i) L.R[i] = L.P[i] = L.Ls[i] = make_float2(0.f, 0.f), L.La[i] = 0.f;
+        for (int i = 0; i < UNR; ++i) L.R[i] = L.P[i] = L.Ls[i] = L.Lq[i] = make_float2(0.f, 0.f), L.La[i] = 0.f;
         L.unext = L.dnext = make_float2(0.f, 0.f);
         L.m = lane & (LPU - 1);
         L.tau = T0 - SKEW * (lane & (LPU - 1));
         L.cnext = C.ctab[L.tau & 63];
-        auto wait_pred = [&](int part) {           // part: index of the part about to start
-            if (pstage < 0 || dead) return;
-            const int need = pbase + (part + AHEAD < hlast ? part + AHEAD : hlast);
-            if (known >= need) return;
-            const int want = dev_in ? (need + QSLACK < pbase + hlast ? need + QSLACK : pbase + hlast) : need;
+        auto spin = [&](auto load, int want, int& seen) {        // bounded: a stage that never comes sets the status word
             int spins = 0;
             for (;;) {
-                known = dev_in ? __hip_atomic_load(gprog + (pstage / NW) * CTR_STRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
-                               : vprog[wv - 1];
-                known = __builtin_amdgcn_readfirstlane(known);
-                if (known >= want) break;
-                if (known + 4 < want) __builtin_amdgcn_s_sleep(127);
-                else __builtin_amdgcn_s_sleep(8);
+                seen = __builtin_amdgcn_readfirstlane(load());
+                if (seen >= want) break;
+                if (seen + 4 < want) __builtin_amdgcn_s_sleep(64);
+                else __builtin_amdgcn_s_sleep(4);
                 if (++spins > (1 << 22)) {
                     dead = true;
                     if (lane == 0 && status) atomicOr(status, 1);
@@ -290,42 +350,73 @@ __device__ __forceinline__ void duo_sweeps(StepCtx& C, const AvsiLwsSchedule& sc
                 }
             }
         };
-        auto publish = [&](int value) {
-            if (lane == 0) {
-                vprog[wv] = value;
-                if (dev_out) __hip_atomic_store(gprog + wg * CTR_STRIDE, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        auto wait_pred = [&](int part) {           // part: index of the part about to start
+            if (pstage < 0 || dead) return;
+            if (dev_in) {                          // another workgroup: parts COMPLETE, in device memory
+                const int need = pbase + (part + AHEAD < hlast ? part + AHEAD : hlast);
+                if (known >= need) return;
+                const int want = need + QSLACK < pbase + hlast ? need + QSLACK : pbase + hlast;
+                spin([&] { return __hip_atomic_load(gprog + (pstage / NW) * CTR_STRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }, want, known);
+            } else {                               // the wave before: parts ISSUED, in LDS
+                const int need = pbase + (part + AHEAD_L < total ? part + AHEAD_L : total);
+                if (known >= need) return;
+                spin([&] { return vprog[wv - 1]; }, need, known);
             }
         };
+        auto wait_succ = [&](int part) {           // the slots this part overwrites have been read by the wave after
+            if (!succ_here || dead || part < BACK) return;
+            const int need = sbase + part - BACK;
+            if (known_s >= need) return;
+            spin([&] { return vprog[wv + 1]; }, need, known_s);
+        };
+        auto issued = [&](int parts) {             // (behind the rows of these parts: LDS operations keep their order)
+            asm volatile("" ::: "memory");
+            if (lane == 0) vprog[wv] = base + parts;
+        };
+        auto completed = [&](int value) {          // (the last wave of a workgroup: its rows went to memory)
+            if (lane == 0) __hip_atomic_store(gprog + wg * CTR_STRIDE, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        };
+        // the ring is about to be written from its start again: the wave after must be through with the sweep before
+        if (prev_succ_done >= 0 && !dead) spin([&] { return vprog[wv + 1]; }, prev_succ_done, known_s);
         // prefetch: the rows of steps 0 .. PF - 1, with the step loop's three operations per (virtual) step
         wait_pred(0);
 #pragma unroll
         for (int i = 0; i < PF; ++i) {
-            row_load8(dev_in, L.Ls[i], C.Sg, C.lane8 + rowpos(T0 + i + LOOK + ROW_OFF) * ROW8);
+            row_load8(dev_in, L.Ls[i], C.Sg, C.lane8 + (dev_in ? rowpos(T0 + i + LOOK + ROW_OFF) : 0u) * ROW8);
             row_load4(L.La[i], C.Ag, C.lane4 + rowpos(T0 + i + ROW_OFF) * ROW4);
             row_store8(false, const_cast<float2*>(C.Sg), C.lane8 + (unsigned)C.trash_row * ROW8, make_float2(0.f, 0.f));
         }
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int i = 0; i < PFL; ++i) L.Lq[i] = C.ring_in[ring(i + LOOK + ROW_OFF) * LANES + lane];
         constexpr std::make_integer_sequence<int, PART> seq{};
+        auto part = [&](auto k, int body) {
+            constexpr int K = decltype(k)::value;
+            const int idx = PARTS * body + K;
+            wait_pred(idx);
+            wait_succ(idx);
+            asm volatile("" ::: "memory");
+            duo_part<K>(L, C, body * UNR, seq);
+            issued(idx + 1);
+            if (dev_out) {
+                // everything issued before this part's 9 operations is complete: the stores of the parts before it
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(OPS * PART) : "memory");
+                completed(base + idx);
+            }
+        };
         for (int body = 0; body < nb; ++body) {
-            const int n0 = body * UNR;
-            wait_pred(PARTS * body);
-            duo_part<0>(L, C, n0, seq);
-            // everything issued before this part's 15 operations is complete: the stores of the parts before it
-            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(OPS * PART) : "memory");
-            publish(base + PARTS * body);
-            wait_pred(PARTS * body + 1);
-            duo_part<1>(L, C, n0, seq);
-            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(OPS * PART) : "memory");
-            publish(base + PARTS * body + 1);
-            wait_pred(PARTS * body + 2);
-            duo_part<2>(L, C, n0, seq);
-            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(OPS * PART) : "memory");
-            publish(base + PARTS * body + 2);
+            part(std::integral_constant<int, 0>{}, body);
+            part(std::integral_constant<int, 1>{}, body);
+            part(std::integral_constant<int, 2>{}, body);
+            part(std::integral_constant<int, 3>{}, body);
+            part(std::integral_constant<int, 4>{}, body);
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         // (the requests of the last steps land in registers nobody reads any more: reserved until they have landed)
 #pragma unroll
         for (int i = 0; i < PF; ++i) asm volatile("" : "+v"(L.Ls[i].x), "+v"(L.Ls[i].y), "+v"(L.La[i]));
-        publish(base + hlast);
+        if (dev_out) completed(base + hlast);
+        prev_succ_done = succ_here ? sbase + total : -1;
         ++mine;
     }
 }
@@ -339,6 +430,7 @@ __global__ __launch_bounds__(64 * NW, 4) void lws_duo_kernel(float2* __restrict_
     __shared__ float2 ctab[64];
     __shared__ int prog[NW];
     __shared__ float2 xch[NW][2 * LANES];
+    __shared__ float2 srings[NW][RING_S * LANES];
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int q = blockIdx.x / G, wg = blockIdx.x - q * G;
     const int stage = wg * NW + wv, stages = G * NW;
@@ -371,6 +463,8 @@ __global__ __launch_bounds__(64 * NW, 4) void lws_duo_kernel(float2* __restrict_
     C.Ag = uniform_ptr(Aall + cells);
     C.ctab = ctab;
     C.xch = xch[wv];
+    C.ring_out = srings[wv];
+    C.ring_in = srings[wv > 0 ? wv - 1 : 0];
     C.Ml = bl < B ? M : 0;
     C.trash_row = rows - 1;
     C.lane8 = lane * 8u, C.lane4 = lane * 4u;

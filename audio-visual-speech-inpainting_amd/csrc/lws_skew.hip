@@ -82,6 +82,8 @@ __host__ __device__ constexpr int skew_rows(int M) { return ((SKEW * (M - 1) + T
 __host__ __device__ constexpr int skew_steps(int M) { return SKEW * (M - 1) + TAU_LAST - T0 + 1; }
 
 __device__ __forceinline__ float2 cmadd(float2 acc, float wr, float wi, float2 x) {
+    // (a weight that is real at compile time: the two products with +-0 add nothing but the sign of a zero)
+    if (__builtin_constant_p(wi) && wi == 0.f) return make_float2(fmaf(wr, x.x, acc.x), fmaf(wr, x.y, acc.y));
     return make_float2(fmaf(wr, x.x, fmaf(-wi, x.y, acc.x)), fmaf(wr, x.y, fmaf(wi, x.x, acc.y)));
 }
 __device__ __forceinline__ float2 conjf2(float2 v) { return make_float2(v.x, -v.y); }

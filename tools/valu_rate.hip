@@ -1,0 +1,83 @@
+// Issue rate of fp32 multiply-adds on gfx950 by operand form, at 1 / 2 / 4 waves per SIMD:
+//   lit : v_fmac_f32 v, <32-bit literal>, v        (8-byte VOP2: the form the LWS sweep kernels use for their weights)
+//   sgpr: v_fmac_f32 v, s, v                       (4-byte VOP2)
+//   vgpr: v_fmac_f32 v, v, v                       (4-byte VOP2)
+//   vop3: v_fma_f32 v, s, v, v                     (8-byte VOP3)
+//   pk  : v_pk_fma_f32 v[2], s[2], v[2], v[2]      (8-byte VOP3P, two multiply-adds)
+// 16 independent accumulators, 256 instructions per loop pass.  hipcc --offload-arch=gfx950 -O3 tools/valu_rate.hip -o tools/valu_rate
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#define REP16(X) X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12) X(13) X(14) X(15)
+template <int FORM>
+__global__ __launch_bounds__(256) void k(float* out, int reps, float w0, float w1) {
+    float a[16];
+    typedef float v2f __attribute__((ext_vector_type(2)));
+    v2f b[8];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) a[i] = threadIdx.x * 0.001f + i;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) b[i] = v2f{a[2 * i], a[2 * i + 1]};
+    const float x = threadIdx.x * 1e-6f;
+    v2f xx = {x, x}, ww = {w0, w1};
+    for (int r = 0; r < reps; ++r) {
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            if (FORM == 0) {
+#define L(i) asm volatile("v_fmac_f32 %0, 0x3dc53288, %1" : "+v"(a[i]) : "v"(x));
+                REP16(L)
+#undef L
+            } else if (FORM == 1) {
+#define L(i) asm volatile("v_fmac_f32 %0, %2, %1" : "+v"(a[i]) : "v"(x), "s"(w0));
+                REP16(L)
+#undef L
+            } else if (FORM == 2) {
+#define L(i) asm volatile("v_fmac_f32 %0, %2, %1" : "+v"(a[i]) : "v"(x), "v"(a[(i + 5) & 15]));
+                REP16(L)
+#undef L
+            } else if (FORM == 3) {
+#define L(i) asm volatile("v_fma_f32 %0, %2, %1, %0" : "+v"(a[i]) : "v"(x), "s"(w0));
+                REP16(L)
+#undef L
+            } else {
+#define L(i) asm volatile("v_pk_fma_f32 %0, %2, %1, %0" : "+v"(b[i & 7]) : "v"(xx), "s"(ww));
+                REP16(L)
+#undef L
+            }
+        }
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) s += a[i];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) s += b[i].x + b[i].y;
+    out[blockIdx.x * 256 + threadIdx.x] = s;
+}
+int main() {
+    const int CU = 256, reps = 4000;
+    float* out;
+    if (hipMalloc(&out, (size_t)CU * 8 * 256 * 4) != hipSuccess) return 1;
+    const char* names[5] = {"lit ", "sgpr", "vgpr", "vop3", "pk  "};
+    for (int wps : {1, 2, 4, 8}) {
+        for (int f = 0; f < 5; ++f) {
+            hipEvent_t e0, e1;
+            (void)hipEventCreate(&e0), (void)hipEventCreate(&e1);
+            float ms = 0;
+            for (int it = 0; it < 2; ++it) {
+                (void)hipEventRecord(e0, 0);
+                switch (f) {
+                    case 0: hipLaunchKernelGGL(k<0>, dim3(CU * wps), dim3(256), 0, 0, out, reps, 0.1f, 0.2f); break;
+                    case 1: hipLaunchKernelGGL(k<1>, dim3(CU * wps), dim3(256), 0, 0, out, reps, 0.1f, 0.2f); break;
+                    case 2: hipLaunchKernelGGL(k<2>, dim3(CU * wps), dim3(256), 0, 0, out, reps, 0.1f, 0.2f); break;
+                    case 3: hipLaunchKernelGGL(k<3>, dim3(CU * wps), dim3(256), 0, 0, out, reps, 0.1f, 0.2f); break;
+                    default: hipLaunchKernelGGL(k<4>, dim3(CU * wps), dim3(256), 0, 0, out, reps, 0.1f, 0.2f); break;
+                }
+                (void)hipEventRecord(e1, 0);
+                (void)hipEventSynchronize(e1);
+                (void)hipEventElapsedTime(&ms, e0, e1);
+            }
+            const double ns_per_inst_simd = ms * 1e6 / ((double)reps * 256.0 * wps);     // one SIMD runs wps waves
+            printf("%d waves/SIMD %s: %.3f ns per wave-instruction and SIMD (%.2f cycles at 2.4 GHz)\n", wps, names[f], ns_per_inst_simd, ns_per_inst_simd * 2.4);
+        }
+    }
+    return 0;
+}
