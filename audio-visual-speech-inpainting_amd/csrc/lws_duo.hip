@@ -176,14 +176,18 @@ __device__ __forceinline__ void duo_step(LaneState& L, const StepCtx& C, int n) 
     //      fill the issue slots of the dependent chain own -> t -> |t|^2 -> rsq -> scale -> select (a dozen levels, each
     //      waiting for the one before: left to itself the compiler puts all the sums first and the chain bare behind them).
     //      FENCE = nothing moves across; one multiply-add of a sum per level.
+    // (the first tap of a sum: two products and one multiply-add -- a literal weight where `fma(w, x, 0)` would need an SGPR)
+#define FIRST(w0, w1, val) make_float2(fmaf(w0, (val).x, -(w1) * (val).y), fmaf(w0, (val).y, (w1) * (val).x))
 #define UP_TAP(p) up = cmadd(up, WBU((p) + LMAX, 0), WBU((p) + LMAX, 1), L.R[ring(I - (LMAX - (p)))])               /* tau + 10 + p */
 #define DN_TAP(p) dn = cmadd(dn, WBD((p) + LMAX, 0), WBD((p) + LMAX, 1), L.P[ring(I - (DN_LAG - (p)))])            /* tau - 8 + p */
 #define FENCE __builtin_amdgcn_sched_barrier(0)
-    float2 up = make_float2(0.f, 0.f), dn = up, own = up;
-    UP_TAP(-5), UP_TAP(-4), UP_TAP(-3), UP_TAP(-2), UP_TAP(-1);
+    float2 up = FIRST(WBU(0, 0), WBU(0, 1), L.R[ring(I - 2 * LMAX)]);                                                             // tau + 5
+    UP_TAP(-4), UP_TAP(-3), UP_TAP(-2), UP_TAP(-1);
+    float2 own = FIRST(WB0(LMAX + 1, 0), WB0(LMAX + 1, 1), L.R[ring(I - (LOOK - 1))]);                                            // tau + 1
 #pragma unroll
-    for (int p = 1; p <= LMAX; ++p) own = cmadd(own, WB0(LMAX + p, 0), WB0(LMAX + p, 1), L.R[ring(I - (LOOK - p))]);               // tau + p
-    DN_TAP(-5), DN_TAP(-4), DN_TAP(-3), DN_TAP(-2), DN_TAP(-1);
+    for (int p = 2; p <= LMAX; ++p) own = cmadd(own, WB0(LMAX + p, 0), WB0(LMAX + p, 1), L.R[ring(I - (LOOK - p))]);               // tau + p
+    float2 dn = FIRST(WBD(0, 0), WBD(0, 1), L.P[ring(I - (DN_LAG + LMAX))]);                                                      // tau - 13
+    DN_TAP(-4), DN_TAP(-3), DN_TAP(-2), DN_TAP(-1);
 #pragma unroll
     for (int p = LMAX; p >= 1; --p) own = cmadd(own, WB0(LMAX - p, 0), WB0(LMAX - p, 1), L.P[ring(I - p)]);                        // tau - p
     const float2 c = L.cnext;
@@ -225,14 +229,16 @@ __device__ __forceinline__ void duo_step(LaneState& L, const StepCtx& C, int n) 
     UP_TAP(5), DN_TAP(5);
     FENCE;
     // ---- exchange for the NEXT step: this frame's `up` goes to the frame before (at its bin tau + 10), its `dn` to the frame
-    //      after (at its bin tau - 8); zero where there is nothing to give (no frame here, or the neighbour not at a bin)
-    const bool up_ok = live && tau + UP_AHEAD >= 0 && tau + UP_AHEAD <= KB - 1;
-    const bool dn_ok = live && tau - DN_LAG >= 0 && tau - DN_LAG <= KB - 1;
-    C.xch[C.lane] = sel(up_ok, up, make_float2(0.f, 0.f));
-    C.xch[LANES + C.lane] = sel(dn_ok, dn, make_float2(0.f, 0.f));
+    //      after (at its bin tau - 8).  No select "zero where there is nothing to give": a neighbour that is at a bin
+    //      (the only one that uses what it gets) finds either the right frame here, at the right position, or a lane whose rings
+    //      hold nothing but zeros -- a frame >= M (its cells are never written, by any stage: what arrives is zero, what is
+    //      handed on is what arrived), or the last lane of the half before its first frame has begun (frame -1).
+    C.xch[C.lane] = up;
+    C.xch[LANES + C.lane] = dn;
     L.unext = C.xch[C.next];
     L.dnext = C.xch[LANES + C.prev];
     L.cnext = C.ctab[(tau + 1) & 63];
+#undef FIRST
 #undef UP_TAP
 #undef DN_TAP
 #undef FENCE

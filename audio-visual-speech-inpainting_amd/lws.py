@@ -74,7 +74,7 @@ class lws(object):
         self.kernel = kernel or ('raster' if self.utterances_per_wave else os.environ.get('AVSI_LWS_KERNEL', 'auto'))
         if self.kernel not in ('auto', 'skew', 'duo', 'raster'):
             raise ValueError("kernel must be 'auto', 'skew', 'duo' or 'raster'")
-        self.duo_min = int(os.environ.get('AVSI_LWS_DUO_MIN', '256'))
+        self.duo_min = int(os.environ.get('AVSI_LWS_DUO_MIN', '128'))
         self._status = None
         if _lib.lib().avsi_lws_table_floats(self.fsize, self.fshift, self.fftsize) == 0:
             raise _lib.AvsiError("unsupported LWS geometry: window %d, shift %d, fft %d" % (self.fsize, self.fshift, self.fftsize))
