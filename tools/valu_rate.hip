@@ -64,8 +64,28 @@ __global__ __launch_bounds__(256) void k(float* out, int reps, float w0, float w
 #define L(i) asm volatile("v_mov_b32_e32 %0, %1" : "+v"(a[i]) : "v"(a[(i + 5) & 15]));
                 REP16(L)
 #undef L
-            } else {
+            } else if (FORM == 8) {
 #define L(i) asm volatile("v_xor_b32_e32 %0, 0x80000000, %0" : "+v"(a[i]));
+                REP16(L)
+#undef L
+            } else if (FORM == 9) {
+#define L(i) asm volatile("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(b[i & 7]) : "v"(xx), "v"(b[(i + 3) & 7]));
+                REP16(L)
+#undef L
+            } else if (FORM == 10) {
+#define L(i) asm volatile("v_pk_add_f32 %0, %1, %0" : "+v"(b[i & 7]) : "v"(xx));
+                REP16(L)
+#undef L
+            } else if (FORM == 11) {
+#define L(i) asm volatile("v_pk_mul_f32 %0, %1, %0" : "+v"(b[i & 7]) : "v"(xx));
+                REP16(L)
+#undef L
+            } else if (FORM == 12) {
+#define L(i) asm volatile("v_add_f32_e32 %0, %1, %0" : "+v"(a[i]) : "v"(x));
+                REP16(L)
+#undef L
+            } else {
+#define L(i) asm volatile("v_fma_f32 %0, %1, %2, %0" : "+v"(a[i]) : "v"(x), "v"(a[(i + 5) & 15]));
                 REP16(L)
 #undef L
             }
@@ -82,9 +102,9 @@ int main() {
     const int CU = 256, reps = 4000;
     float* out;
     if (hipMalloc(&out, (size_t)CU * 8 * 256 * 4) != hipSuccess) return 1;
-    const char* names[9] = {"lit ", "sgpr", "vgpr", "vop3", "pk  ", "cnd32", "cnd64", "mov ", "xor "};
-    for (int wps : {1, 4}) {
-        for (int f = 0; f < 9; ++f) {
+    const char* names[14] = {"lit ", "sgpr", "vgpr", "vop3", "pk  ", "cnd32", "cnd64", "mov ", "xor ", "pkfma_vvv", "pkadd_vv", "pkmul_vv", "add_vv", "fma_vvv(vop3)"};
+    for (int wps : {1, 2, 4}) {
+        for (int f = 0; f < 14; ++f) {
             hipEvent_t e0, e1;
             (void)hipEventCreate(&e0), (void)hipEventCreate(&e1);
             float ms = 0;
@@ -99,7 +119,12 @@ int main() {
                     case 5: hipLaunchKernelGGL(k<5>, dim3(CU * wps), dim3(256), 0, 0, out, reps, 0.1f, 0.2f); break;
                     case 6: hipLaunchKernelGGL(k<6>, dim3(CU * wps), dim3(256), 0, 0, out, reps, 0.1f, 0.2f); break;
                     case 7: hipLaunchKernelGGL(k<7>, dim3(CU * wps), dim3(256), 0, 0, out, reps, 0.1f, 0.2f); break;
-                    default: hipLaunchKernelGGL(k<8>, dim3(CU * wps), dim3(256), 0, 0, out, reps, 0.1f, 0.2f); break;
+                    case 8: hipLaunchKernelGGL(k<8>, dim3(CU * wps), dim3(256), 0, 0, out, reps, 0.1f, 0.2f); break;
+                    case 9: hipLaunchKernelGGL(k<9>, dim3(CU * wps), dim3(256), 0, 0, out, reps, 0.1f, 0.2f); break;
+                    case 10: hipLaunchKernelGGL(k<10>, dim3(CU * wps), dim3(256), 0, 0, out, reps, 0.1f, 0.2f); break;
+                    case 11: hipLaunchKernelGGL(k<11>, dim3(CU * wps), dim3(256), 0, 0, out, reps, 0.1f, 0.2f); break;
+                    case 12: hipLaunchKernelGGL(k<12>, dim3(CU * wps), dim3(256), 0, 0, out, reps, 0.1f, 0.2f); break;
+                    default: hipLaunchKernelGGL(k<13>, dim3(CU * wps), dim3(256), 0, 0, out, reps, 0.1f, 0.2f); break;
                 }
                 (void)hipEventRecord(e1, 0);
                 (void)hipEventSynchronize(e1);
