@@ -64,6 +64,14 @@ __device__ __forceinline__ gptr4 opaque_base(const float4* p) {
     asm volatile("" : "+s"(g));
     return g;
 }
+// (a running pointer, opaque after every advance: 128 bases `wb + g * 64` of a phase are loop-invariant, the compiler computed
+// them all ahead of the time loop, parked the 256 SGPR values in VGPR lanes and fetched each pair back with two v_readlane
+// per group of 4 MFMAs -- 489 of the kernel's 2900 vector instructions per pair of phases; s_add_u32 / s_addc_u32 instead)
+__device__ __forceinline__ gptr4 opaque_next(gptr4 g, int float4s) {
+    g += float4s;
+    asm volatile("" : "+s"(g));
+    return g;
+}
 __device__ __forceinline__ float4 ldg4(gptr4 p, int idx) {
     const v4f v = p[idx];
     return make_float4(v.x, v.y, v.z, v.w);
@@ -263,13 +271,14 @@ __device__ __forceinline__ void bwd_pp_phase(f32x16 (&dhrec)[2], float (&dcn)[2]
     };
 
     float4 bw[RING], af[2];
+    gptr4 wrun = opaque_base(wb);                // the fragment group requested next
     if (DO_MFMA) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) dhrec[X][r] = 0.f;
 #pragma unroll
         for (int g = 0; g < AHEAD; ++g) {
-            const gptr4 wq = opaque_base(wb + g * 64);
-            bw[g] = ldg4(wq, lane);
+            bw[g] = ldg4(wrun, lane);
+            wrun = opaque_next(wrun, 64);
         }
         af[0] = *reinterpret_cast<const float4*>(zbuf + li * ZS + 4 * hi);
     }
@@ -287,8 +296,8 @@ __device__ __forceinline__ void bwd_pp_phase(f32x16 (&dhrec)[2], float (&dcn)[2]
         if (q == 112) loadc(ca, nx, 0);          // first chunk of the next phase's cell (zero-record descriptors: none)
         if (DO_MFMA) {
             if (q + AHEAD < 128 && !((DIAG & 8) && q + AHEAD >= 8)) {
-                const gptr4 wq = opaque_base(wb + (q + AHEAD) * 64);
-                bw[(q + AHEAD) & (RING - 1)] = ldg4(wq, lane);
+                bw[(q + AHEAD) & (RING - 1)] = ldg4(wrun, lane);
+                wrun = opaque_next(wrun, 64);
             }
             if (q + 1 < 128) af[(q + 1) & 1] = *reinterpret_cast<const float4*>(zbuf + li * ZS + 8 * (q + 1) + 4 * hi);
             __builtin_amdgcn_sched_barrier(0);

@@ -255,6 +255,13 @@ __device__ __forceinline__ gptr4 opaque_base(const float4* p) {
     asm volatile("" : "+s"(g));
     return g;
 }
+// (a running pointer, opaque after every advance: the 32 bases `wb + q * 256` of a phase are loop-invariant, the compiler
+// computed them ahead of the time loop, parked them in VGPR lanes and fetched each back with two v_readlane per group)
+__device__ __forceinline__ gptr4 opaque_next(gptr4 g, int float4s) {
+    g += float4s;
+    asm volatile("" : "+s"(g));
+    return g;
+}
 __device__ __forceinline__ float4 ldg4(gptr4 p, int idx) {
     const v4f v = p[idx];
     return make_float4(v.x, v.y, v.z, v.w);
@@ -271,10 +278,11 @@ __device__ __forceinline__ void pp_phase(f32x16 (&acc)[2][4], f32x16 (&c)[2], fl
     float* hy = hbuf + Y * (32 * HS) + (4 * hi) * HS + w * 32 + li;         // tile Y: written by the cell
     float4 bw[2][4], af[2];
     f32x16 nx[4];  // tile Y's next pre-activations: loaded once acc[Y] is dead, then become acc[Y]
+    gptr4 wrun = opaque_base(wb);                // the fragment group requested next
     if (DO_MFMA) {
-        const gptr4 wq = opaque_base(wb);
 #pragma unroll
-        for (int g = 0; g < 4; ++g) bw[0][g] = ldg4(wq, g * 64 + lane);
+        for (int g = 0; g < 4; ++g) bw[0][g] = ldg4(wrun, g * 64 + lane);
+        wrun = opaque_next(wrun, 256);
         af[0] = *reinterpret_cast<const float4*>(hx + li * HS + 4 * hi);
     }
 #pragma unroll
@@ -284,9 +292,9 @@ __device__ __forceinline__ void pp_phase(f32x16 (&acc)[2][4], f32x16 (&c)[2], fl
             if (q + 1 < 32) {
                 // Without the opaque base hipcc materialises one 64-bit VGPR address per load (128 of
                 // them), hoists them out of the step loop and spills them.
-                const gptr4 wq = opaque_base(wb + (q + 1) * 256);
 #pragma unroll
-                for (int g = 0; g < 4; ++g) bw[cb ^ 1][g] = ldg4(wq, g * 64 + lane);
+                for (int g = 0; g < 4; ++g) bw[cb ^ 1][g] = ldg4(wrun, g * 64 + lane);
+                wrun = opaque_next(wrun, 256);
                 af[cb ^ 1] = *reinterpret_cast<const float4*>(hx + li * HS + 8 * (q + 1) + 4 * hi);
             }
             __builtin_amdgcn_sched_barrier(0);
