@@ -132,7 +132,8 @@ __device__ __forceinline__ rsrc_t rsrc_z(const Ctx& c, const Step& w) {
 // Cell tile Y (DO_CELL): one row-register every 8 groups, its chunk of inputs (two row-registers) requested 20 groups
 // before its first use; `nx` describes the tile whose cell runs in the NEXT phase: its first chunk is requested at group 112.
 // DIAG (diagnostic builds of the kernel, AVSI_BWD_PP_DIAG; results are then WRONG): 1 = no cell arithmetic / dz stores,
-// 2 = no cell input loads, 4 = no dz stores, 8 = Wh^T fragments loaded once per phase, 16 = no publish.
+// 2 = no cell input loads, 4 = no dz stores, 8 = Wh^T fragments loaded once per phase, 16 = no publish,
+// 4096 = the fragment pointers as 128 loop-invariant bases (what the kernel did before: results right, v_readlane pairs).
 template <int X, bool DO_MFMA, bool DO_CELL, int DIAG>
 __device__ __forceinline__ void bwd_pp_phase(f32x16 (&dhrec)[2], float (&dcn)[2][16], float (&ccar)[2][16], float (&dzh)[64],
                                              RowsC& ca, RowsC& cb,
@@ -277,6 +278,10 @@ __device__ __forceinline__ void bwd_pp_phase(f32x16 (&dhrec)[2], float (&dcn)[2]
         for (int r = 0; r < 16; ++r) dhrec[X][r] = 0.f;
 #pragma unroll
         for (int g = 0; g < AHEAD; ++g) {
+            if (DIAG & 4096) {      // (the form before: one opaque base per group, all of them loop-invariant)
+                bw[g] = ldg4(opaque_base(wb + g * 64), lane);
+                continue;
+            }
             bw[g] = ldg4(wrun, lane);
             wrun = opaque_next(wrun, 64);
         }
@@ -296,8 +301,12 @@ __device__ __forceinline__ void bwd_pp_phase(f32x16 (&dhrec)[2], float (&dcn)[2]
         if (q == 112) loadc(ca, nx, 0);          // first chunk of the next phase's cell (zero-record descriptors: none)
         if (DO_MFMA) {
             if (q + AHEAD < 128 && !((DIAG & 8) && q + AHEAD >= 8)) {
-                bw[(q + AHEAD) & (RING - 1)] = ldg4(wrun, lane);
-                wrun = opaque_next(wrun, 64);
+                if (DIAG & 4096) {
+                    bw[(q + AHEAD) & (RING - 1)] = ldg4(opaque_base(wb + (q + AHEAD) * 64), lane);
+                } else {
+                    bw[(q + AHEAD) & (RING - 1)] = ldg4(wrun, lane);
+                    wrun = opaque_next(wrun, 64);
+                }
             }
             if (q + 1 < 128) af[(q + 1) & 1] = *reinterpret_cast<const float4*>(zbuf + li * ZS + 8 * (q + 1) + 4 * hi);
             __builtin_amdgcn_sched_barrier(0);
@@ -422,6 +431,7 @@ int avsi_blstm_rec_bwd_pp_launch(const float* dhout, const float* reserve, const
         hipLaunchKernelGGL(blstm_rec_bwd_pp_kernel<D>, dim3((Bp + 63) / 64, 2), dim3(512), lds, st, a);                    \
     } while (0)
     switch (diag) {
+        case 4096: AVSI_PP_LAUNCH(4096); break;
         case 1: AVSI_PP_LAUNCH(1); break;
         case 3: AVSI_PP_LAUNCH(3); break;
         case 4: AVSI_PP_LAUNCH(4); break;

@@ -628,12 +628,14 @@ def extra_workloads(torch, models, ops, ap_mod, cfg, mean, std, device):
     out = {}
 
     def guarded(name, fn):
+        t0 = time.perf_counter()
         try:
             out[name] = fn()
         except Exception as e:        # an entry that fails says so; the others still run
             out[name] = {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
         torch.cuda.synchronize()
         torch.cuda.empty_cache()
+        print("[bench] %s: %.0f s" % (name, time.perf_counter() - t0), file=sys.stderr, flush=True)
 
     def train_b8192():
         B = 8192
@@ -808,6 +810,7 @@ def main():
                     help="infer = headline workload (configs[1]); train = configs[2]: AV model, fwd + BPTT + Adam; "
                          "unet = configs[4]: U-Net spectrogram inpainter inference (use --batch 32 .. 512)")
     args = ap.parse_args()
+    t_bench0 = time.perf_counter()
 
     import torch
     import torch.distributed as dist
@@ -979,6 +982,8 @@ def main():
                                 "device_copy_GB/s_torch_copy_kernel": device_copy_rate(torch, device, kernel="torch")},
         }
         cpu, rms = (None, None)
+        if rank == 0:
+            print("[bench +%.0f s] headline timed; CPU baseline" % (time.perf_counter() - t_bench0), file=sys.stderr, flush=True)
         if not args.no_cpu_baseline and world == 1:     # the CPU leg is reported at N = 1 only
             sample = min(args.cpu_sample, B)
             # `model` still holds the results of the last TIMED step: its prediction rows are what gets checked
@@ -1009,6 +1014,11 @@ def main():
         # the reason in `also`) and EVERY rank leaves with a non-zero status -- a hang must not read as a successful run.
         import threading
         progress = {"at": "start"}
+
+        def mark(where):           # (stderr: the one JSON line on stdout stays alone; a long silent run reads as a hang)
+            progress["at"] = where
+            if rank == 0:
+                print("[bench +%.0f s] %s" % (time.perf_counter() - t_bench0, where), file=sys.stderr, flush=True)
         if rank != 0:
             line = {}
 
@@ -1030,7 +1040,7 @@ def main():
         del wav, masks
         torch.cuda.empty_cache()
         try:
-            progress["at"] = "dp_train"
+            mark("dp_train")
             # on a high-priority stream, like training.train(): the steps' critical chain (cooperative recurrent kernels)
             # is then independent of which hardware queue the side streams and the collectives' stream happen to share,
             # and is dispatched ahead of them (tools/train_step_time.py: 6.3 .. 7.4 ms on the default stream depending on
@@ -1044,14 +1054,14 @@ def main():
             dp = {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
         line["dp_train"] = dp
         try:
-            progress["at"] = "also (inference at the named sizes, LWS at 32)"
+            mark("also (inference at the named sizes, LWS at 32)")
             also = named_workloads(torch, models, ops, model, cfg, mean, std, device, rank, world)
             if "weak_32_per_gpu" in dp:
                 also["train_b32"] = dp["weak_32_per_gpu"]
             if world == 1:
-                progress["at"] = "also (training at 8192, U-Net, inverse STFT, LWS at 1024, host-fed step)"
+                mark("also (training at 8192, U-Net, inverse STFT, LWS at 1024, host-fed step)")
                 also.update(extra_workloads(torch, models, ops, ap_mod, cfg, mean, std, device))
-                progress["at"] = "also (drivers end to end: train(), infer())"
+                mark("also (drivers end to end: train(), infer())")
                 torch.cuda.empty_cache()
                 try:
                     # in a child process of their own, as a user runs them (`speech_inpainting_main.py training / inference`):
