@@ -177,13 +177,18 @@ __device__ __forceinline__ void skew_step(LaneState& L, const StepCtx& C, const 
         if (x != NONE) L.R[ring(I - 2 * x)] = sel(tau + 11 == x, conjf2(arr), L.R[ring(I - 2 * x)]);
     }
     // ---- three sums over this lane's own rings (newest elements last: they end the dependence chain)
-    float2 up = make_float2(0.f, 0.f), dn = up, own = up;
+    // (the first tap of a sum: two products and one multiply-add -- a literal weight where `fma(w, x, 0)` would need an SGPR)
+#define FIRST(w0, w1, val) make_float2(fmaf(w0, (val).x, -(w1) * (val).y), fmaf(w0, (val).y, (w1) * (val).x))
+    float2 up = FIRST(WBU(0, 0), WBU(0, 1), L.R[ring(I - 2 * LMAX)]);
 #pragma unroll
-    for (int p = -LMAX; p <= LMAX; ++p) up = cmadd(up, WBU(p + LMAX, 0), WBU(p + LMAX, 1), L.R[ring(I - LMAX + p)]);
+    for (int p = -LMAX + 1; p <= LMAX; ++p) up = cmadd(up, WBU(p + LMAX, 0), WBU(p + LMAX, 1), L.R[ring(I - LMAX + p)]);
+    float2 own = FIRST(WB0(LMAX + 1, 0), WB0(LMAX + 1, 1), L.R[ring(I - 10)]);
 #pragma unroll
-    for (int p = 1; p <= LMAX; ++p) own = cmadd(own, WB0(LMAX + p, 0), WB0(LMAX + p, 1), L.R[ring(I - 11 + p)]);
+    for (int p = 2; p <= LMAX; ++p) own = cmadd(own, WB0(LMAX + p, 0), WB0(LMAX + p, 1), L.R[ring(I - 11 + p)]);
+    float2 dn = FIRST(WBD(0, 0), WBD(0, 1), L.P[ring(I - (SKEW + LMAX))]);
 #pragma unroll
-    for (int p = -LMAX; p <= LMAX; ++p) dn = cmadd(dn, WBD(p + LMAX, 0), WBD(p + LMAX, 1), L.P[ring(I - (SKEW - p))]);
+    for (int p = -LMAX + 1; p <= LMAX; ++p) dn = cmadd(dn, WBD(p + LMAX, 0), WBD(p + LMAX, 1), L.P[ring(I - (SKEW - p))]);
+#undef FIRST
 #pragma unroll
     for (int p = LMAX; p >= 1; --p) own = cmadd(own, WB0(LMAX - p, 0), WB0(LMAX - p, 1), L.P[ring(I - p)]);
     // ---- exchange: the row below (old values) from lane j + 1, the row above (new values) from lane j - 1
@@ -191,10 +196,10 @@ __device__ __forceinline__ void skew_step(LaneState& L, const StepCtx& C, const 
     float2 dnr = make_float2(dpp_from_prev(dn.x), dpp_from_prev(dn.y));
     const float2 c = L.cnext;
     L.cnext = C.ctab[(tau + 1) & 63];          // (a wrap to the next frame moves tau by 384 = 6 x 64: the same entry)
-    const bool has_next = m + 1 < C.M && !C.past_only, has_prev = m >= 1;
-    upr = sel(has_next, upr, make_float2(0.f, 0.f));
-    dnr = sel(has_prev, dnr, make_float2(0.f, 0.f));
-    if (C.past_only) own = make_float2(0.f, 0.f);
+    // (no select "zero where the neighbour frame does not exist": a lane with a frame >= M holds nothing but zeros -- its cells
+    // are never written, what arrives is zero, what is handed on is what arrived -- and so does lane 63 before its first frame
+    // has begun, which is frame -1 to lane 0)
+    if (C.past_only) own = make_float2(0.f, 0.f), upr = own;
     float2 T = own;
     T.x = fmaf(c.x, upr.x, fmaf(-c.y, upr.y, T.x)), T.y = fmaf(c.x, upr.y, fmaf(c.y, upr.x, T.y));          // c . up
     T.x = fmaf(c.x, dnr.x, fmaf(c.y, dnr.y, T.x)), T.y = fmaf(c.x, dnr.y, fmaf(-c.y, dnr.x, T.y));          // conj(c) . down

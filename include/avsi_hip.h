@@ -430,7 +430,7 @@ int avsi_istft_f32(const avsi_istft_args* args, void* stream);
  *                        (384 / 192 / 512, L = 5; others: AVSI_ERR_UNSUPPORTED, take avsi_lws_run_skew_f32).
  *                        waves_per_group (4, 8, 16; 0 = 16) consecutive sweeps per workgroup, groups_per_pair workgroups
  *                        chained per two utterances (0 = as many as fill the chip); workspace
- *                        avsi_lws_run_duo_workspace_bytes(batch, num_frames), ~1.7 MB per utterance of 252 frames
+ *                        avsi_lws_run_duo_workspace_bytes(batch, num_frames), ~1.0 MB per utterance of 252 frames
  *   avsi_lws_istft_f32   lws.istft  (inference.py:153): out [B][out_samples], out_samples <=
  *                        (num_frames - 1) hop + nfft - 2 (nfft - hop); workspace from avsi_lws_istft_workspace_bytes
  * ------------------------------------------------------------------------------------ */
