@@ -733,8 +733,13 @@ def extra_workloads(torch, models, ops, ap_mod, cfg, mean, std, device):
         w, m = lws_signal(torch, B, 78, device)
         proc = lws_mod.lws(384, 192, fftsize=512, mode='speech')
         ms = time_steps(torch, lambda: proc.refine_enhanced(w, m, num_samples=N_SAMPLES), 2, 1)
+        # algorithmic work of the sweeps (what bounds them is vector-instruction issue): 102 sweeps x 252 frames x
+        # 257 bins x 31 complex multiply-adds (8 flop) + the rotation, norm and scale of a bin (~30 flop)
+        gflop = 102 * 252 * 257 * (31 * 8 + 30) / 1e9
         return {"workload": "LWS phase reconstruction of 1024 enhanced utterances (inference.py:141-154)", "per_gpu_batch": B,
-                "ms_per_step": ms, "value": B / ms * 1e3, "unit": "utterances/s"}
+                "ms_per_step": ms, "value": B / ms * 1e3, "unit": "utterances/s", "kernel": proc.kernel_for(B),
+                "algorithmic_GFLOP_per_utterance": gflop, "algorithmic_TFLOP/s": gflop * B / ms,
+                "frac_of_fp32_vector_peak": gflop * B / ms / 157.3}
     guarded("lws_b1024", lws_b1024)
 
     def infer_b8192_hostfed():
