@@ -25,6 +25,7 @@
 // Memory traffic per step is lws_skew.hip's (one row of S in, one out, one row of |S| in); steps per utterance and sweep:
 // 1277 against 1792.  Same sums over the same values in the same order as lws_skew_kernel.
 #include <math.h>
+#include <stdlib.h>
 
 #include <type_traits>
 #include <utility>
@@ -297,17 +298,26 @@ struct StageCtx {
     float mean2[UPW], amax2[UPW];
 };
 
-// the sweeps of one stage (lws_skew.hip: skew_sweeps; here with the two-way hand-shake of the LDS rings)
+// What a stage carries from one pair of utterances to the next one of its workgroup (a workgroup runs the pairs slot, slot +
+// slots, ... one after the other, every wave going on to the next pair as soon as it has finished its last sweep of this one: the
+// partial last round of a pair and the filling of the pipeline overlap with the neighbour pair's sweeps).  The counters of the
+// waves are monotone over ALL sweeps a stage has run, so a stage needs how many sweeps its two neighbour stages have behind them.
+struct Carry {
+    int known, known_s, mine, prev_succ_done, done_pred, done_succ;
+    bool dead;
+};
+
+// the sweeps of one stage over one pair (lws_skew.hip: skew_sweeps; here with the two-way hand-shake of the LDS rings)
 template <int NW>
-__device__ __forceinline__ void duo_sweeps(StepCtx& C, const AvsiLwsSchedule& sched, const StageCtx& Q) {
+__device__ __forceinline__ void duo_sweeps(StepCtx& C, const AvsiLwsSchedule& sched, const StageCtx& Q, Carry& K) {
     const int wv = Q.wv, wg = Q.wg, lane = Q.lane, stage = Q.stage, stages = Q.stages, nb = Q.nb, hlast = Q.hlast, nbp = Q.nbp;
     const int total = PARTS * nb;                 // parts of a sweep
     int* gprog = Q.gprog;
     volatile int* vprog = Q.vprog;                // parts ISSUED, per wave of this workgroup (monotone over the sweeps of a stage)
     int* status = Q.status;
     const bool dev_in = C.din, dev_out = C.dout;
-    bool dead = false;
-    int known = 0, known_s = 0, mine = 0;
+    bool dead = K.dead;
+    int known = dev_in ? 0 : K.known, known_s = K.known_s, mine = K.mine;      // (a first wave polls this pair's own counters in memory)
     int n_active = 0;
     for (int sw = 0; sw < sched.n; ++sw) {
         bool active = false;
@@ -316,7 +326,7 @@ __device__ __forceinline__ void duo_sweeps(StepCtx& C, const AvsiLwsSchedule& sc
         n_active += active ? 1 : 0;
     }
     int rank_a = -1, last_active = -1;
-    int prev_succ_done = -1;                      // counter value of the next wave that says "has read all of my last sweep"
+    int prev_succ_done = K.prev_succ_done;        // counter value of the next wave that says "has read all of my last sweep"
     for (int sw = 0; sw < sched.n; ++sw) {
         const float rel = sched.rel[sw];
         bool active = false;
@@ -329,12 +339,12 @@ __device__ __forceinline__ void duo_sweeps(StepCtx& C, const AvsiLwsSchedule& sc
         C.thr = rel * Q.mean;
         C.past_only = sched.past_only[sw] != 0;
         const int pstage = pred < 0 ? -1 : (rank_a - 1) % stages;
-        const int pbase = pred < 0 ? 0 : ((rank_a - 1) / stages) * nbp;
+        const int pbase = pred < 0 ? 0 : (K.done_pred + (rank_a - 1) / stages) * nbp;
         const int base = mine * nbp;
         // the sweep after this one runs on the next wave of this workgroup (unless this is the last wave, or the last sweep)
         const bool succ_here = !dev_out && rank_a + 1 < n_active;
         C.dout = dev_out || rank_a + 1 >= n_active;           // rows go to memory for another workgroup -- or as the result
-        const int sbase = ((rank_a + 1) / stages) * nbp;
+        const int sbase = (K.done_succ + (rank_a + 1) / stages) * nbp;
         LaneState L;
 #pragma unroll
         for (int i = 0; i < UNR; ++i) L.R[i] = L.P[i] = L.Ls[i] = L.Lq[i] = make_float2(0.f, 0.f), L.La[i] = 0.f;
@@ -425,26 +435,30 @@ __device__ __forceinline__ void duo_sweeps(StepCtx& C, const AvsiLwsSchedule& sc
         prev_succ_done = succ_here ? sbase + total : -1;
         ++mine;
     }
+    // sweeps of this pair that ran on the stage before / after this one
+    auto ran_on = [&](int st) { return n_active > st ? (n_active - st - 1) / stages + 1 : 0; };
+    K.done_pred += ran_on((stage + stages - 1) % stages), K.done_succ += ran_on((stage + 1) % stages);
+    K.known = known, K.known_s = known_s, K.mine = mine, K.prev_succ_done = prev_succ_done, K.dead = dead;
 }
 
-// NW waves per workgroup = NW pipeline stages of one pair of utterances; G workgroups per pair
+// NW waves per workgroup = NW pipeline stages of a pair of utterances; G workgroups per pair; `slots` pairs at a time, the
+// workgroups of slot k running the pairs k, k + slots, ... one after the other
 template <int NW>
 __global__ __launch_bounds__(64 * NW, 4) void lws_duo_kernel(float2* __restrict__ Sall, const float* __restrict__ Aall, int B, int M,
                                                          const AvsiLwsSchedule sched, int* __restrict__ status,
                                                          const float2* __restrict__ stats, int* __restrict__ gprog_all, int G,
-                                                         int phase_step) {
+                                                         int phase_step, int pairs, int slots) {
     __shared__ float2 ctab[64];
     __shared__ int prog[NW];
     __shared__ float2 xch[NW][2 * LANES];
     __shared__ float2 srings[NW][RING_S * LANES];
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-    const int q = blockIdx.x / G, wg = blockIdx.x - q * G;
+    const int slot = blockIdx.x / G, wg = blockIdx.x - slot * G;
     const int stage = wg * NW + wv, stages = G * NW;
     const int rows = duo_rows(M);
     const int nb = (duo_steps(M) + UNR - 1) / UNR;
     const int hlast = PARTS * nb + AHEAD + 1;                 // published when a sweep is finished: every need is capped there
     const int nbp = PARTS * nb + 16;                          // counter values per sweep of a stage
-    int* gprog = gprog_all + (size_t)q * GPROG_INTS;
     volatile int* vprog = prog;
     if (threadIdx.x < 64) {
         float sn, cs;
@@ -455,33 +469,37 @@ __global__ __launch_bounds__(64 * NW, 4) void lws_duo_kernel(float2* __restrict_
     xch[wv][lane] = xch[wv][LANES + lane] = make_float2(0.f, 0.f);
     __syncthreads();
     StageCtx Q;
-#pragma unroll
-    for (int u = 0; u < UPW; ++u) {
-        const int b = q * UPW + u;
-        const float2 st = b < B ? stats[b] : make_float2(0.f, 0.f);
-        Q.mean2[u] = st.x, Q.amax2[u] = st.y;
-    }
-    const int bl = q * UPW + lane / LPU;
-    Q.mean = bl < B ? stats[bl].x : 0.f;
     StepCtx C;
-    const size_t cells = (size_t)q * rows * LANES;
-    C.Sg = uniform_ptr(Sall + cells);
-    C.Ag = uniform_ptr(Aall + cells);
     C.ctab = ctab;
     C.xch = xch[wv];
     C.ring_out = srings[wv];
     C.ring_in = srings[wv > 0 ? wv - 1 : 0];
-    C.Ml = bl < B ? M : 0;
     C.trash_row = rows - 1;
     C.lane8 = lane * 8u, C.lane4 = lane * 4u;
     C.lane = lane;
     C.prev = (lane & ~(LPU - 1)) | ((lane - 1) & (LPU - 1));
     C.next = (lane & ~(LPU - 1)) | ((lane + 1) & (LPU - 1));
-    // the stage before the first wave / after the last one sits in another workgroup (or is this one in the next round)
-    C.din = wv == 0, C.dout = wv == NW - 1;
     Q.wv = wv, Q.wg = wg, Q.lane = lane, Q.stage = stage, Q.stages = stages, Q.nb = nb, Q.hlast = hlast, Q.nbp = nbp;
-    Q.gprog = gprog, Q.vprog = vprog, Q.status = status;
-    duo_sweeps<NW>(C, sched, Q);
+    Q.vprog = vprog, Q.status = status;
+    Carry K{0, 0, 0, -1, 0, 0, false};
+    for (int q = slot; q < pairs; q += slots) {
+#pragma unroll
+        for (int u = 0; u < UPW; ++u) {
+            const int b = q * UPW + u;
+            const float2 st = b < B ? stats[b] : make_float2(0.f, 0.f);
+            Q.mean2[u] = st.x, Q.amax2[u] = st.y;
+        }
+        const int bl = q * UPW + lane / LPU;
+        Q.mean = bl < B ? stats[bl].x : 0.f;
+        Q.gprog = gprog_all + (size_t)q * GPROG_INTS;
+        const size_t cells = (size_t)q * rows * LANES;
+        C.Sg = uniform_ptr(Sall + cells);
+        C.Ag = uniform_ptr(Aall + cells);
+        C.Ml = bl < B ? M : 0;
+        // the stage before the first wave / after the last one sits in another workgroup (or is this one in the next round)
+        C.din = wv == 0, C.dout = wv == NW - 1;
+        duo_sweeps<NW>(C, sched, Q, K);
+    }
 }
 
 // spec [B][M][257] -> the diagonal layout of a pair (bins, the five mirror positions above Nyquist, magnitudes); everything
@@ -600,26 +618,22 @@ extern "C" int avsi_lws_run_duo_f32(float* spec, int batch, int num_frames, int 
     avsi_lws_launch_stats(spec, batch, num_frames, reinterpret_cast<float*>(stats), st);
     const int phase_step = 64 * hop / nfft;
     float2* sp = reinterpret_cast<float2*>(spec);
-    // every workgroup of a launch must be resident (its stages wait for each other): more pairs than the chip holds run as
-    // consecutive launches, each with the shape of what is left
-    for (int q0 = 0, nq = 0; q0 < duos; q0 += nq) {
-        int NW = waves_per_group, G = groups_per_pair;
-        if (!duo_shape(duos - q0, S.n, NW, G)) return AVSI_ERR_INVALID_ARG;
-        const int per_launch = AVSI_NUM_CU * (16 / NW) / G;
-        nq = duos - q0 < per_launch ? duos - q0 : per_launch;
-        const int b0 = q0 * UPW, nbatch = batch - b0 < nq * UPW ? batch - b0 : nq * UPW;
-        const size_t c0 = (size_t)q0 * rows * LANES;
-        hipLaunchKernelGGL(lws_to_duo_kernel, dim3((rows + 3) / 4, nq), dim3(256), 0, st, sp + (size_t)b0 * num_frames * KB, nbatch,
-                           num_frames, rows, Sd + c0, Ad + c0);
-#define AVSI_DUO_LAUNCH(NWV)                                                                                                      \
-    hipLaunchKernelGGL((lws_duo_kernel<NWV>), dim3(nq* G), dim3(64 * (NWV)), 0, st, Sd + c0, Ad + c0, nbatch, num_frames, S, status,        \
-                       stats + b0, gprog + (size_t)q0 * GPROG_INTS, G, phase_step)
-        if (NW == 16) AVSI_DUO_LAUNCH(16);
-        else if (NW == 8) AVSI_DUO_LAUNCH(8);
-        else AVSI_DUO_LAUNCH(4);
+    // every workgroup of a launch must be resident (its stages wait for each other): the chip holds `slots` pairs at a time,
+    // and the workgroups of a slot run their pairs one after the other inside the kernel
+    int NW = waves_per_group, G = groups_per_pair;
+    if (!duo_shape(duos, S.n, NW, G)) return AVSI_ERR_INVALID_ARG;
+    int slots = AVSI_NUM_CU * (16 / NW) / G;
+    if (const char* e = getenv("AVSI_LWS_DUO_SLOTS"))          // (tests: several pairs per workgroup at small batches)
+        if (atoi(e) > 0 && atoi(e) < slots) slots = atoi(e);
+    if (slots > duos) slots = duos;
+    hipLaunchKernelGGL(lws_to_duo_kernel, dim3((rows + 3) / 4, duos), dim3(256), 0, st, sp, batch, num_frames, rows, Sd, Ad);
+#define AVSI_DUO_LAUNCH(NWV)                                                                                                        \
+    hipLaunchKernelGGL((lws_duo_kernel<NWV>), dim3(slots* G), dim3(64 * (NWV)), 0, st, Sd, Ad, batch, num_frames, S, status, stats, \
+                       gprog, G, phase_step, duos, slots)
+    if (NW == 16) AVSI_DUO_LAUNCH(16);
+    else if (NW == 8) AVSI_DUO_LAUNCH(8);
+    else AVSI_DUO_LAUNCH(4);
 #undef AVSI_DUO_LAUNCH
-        hipLaunchKernelGGL(lws_from_duo_kernel, dim3((rows + 3) / 4, nq), dim3(256), 0, st, Sd + c0, nbatch, num_frames, rows,
-                           sp + (size_t)b0 * num_frames * KB);
-    }
+    hipLaunchKernelGGL(lws_from_duo_kernel, dim3((rows + 3) / 4, duos), dim3(256), 0, st, Sd, batch, num_frames, rows, sp);
     return avsi_launch_status();
 }

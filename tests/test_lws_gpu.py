@@ -131,7 +131,7 @@ def test_skewed_kernel_launch_shape_does_not_change_the_result(L):
             assert i_s < 1.5 * i_r + 1e-6 and i_r < 1.5 * i_s + 1e-6, (n, b_, i_s, i_r)
 
 
-def test_duo_kernel_is_bit_identical_to_the_skewed_kernel(L):
+def test_duo_kernel_is_bit_identical_to_the_skewed_kernel(L, monkeypatch):
     """Two utterances per wave (csrc/lws_duo.hip): frames nine bins apart instead of six, the neighbour rows' sums through LDS
     instead of DPP rotates, rings of 15 instead of 12 -- every bin still sees exactly the values the raster order gives it and
     every sum is taken in the same order (with every multiply-add that the compiler could fuse or not spelled out as fused),
@@ -152,6 +152,13 @@ def test_duo_kernel_is_bit_identical_to_the_skewed_kernel(L):
         for NW, G in ((0, 0), (4, 1), (8, 3), (16, 2), (16, 1)):
             out = L.lws(384, 192, kernel='duo', waves_per_group=NW, groups_per_utterance=G, **kw).run_lws(S0)
             assert np.array_equal(ref, out), (n, B, NW, G)
+        # more pairs than the chip holds at a time: a workgroup runs several pairs one after the other, each wave going on to
+        # the next pair as soon as it is through with this one (here: two / one slot instead of 256)
+        for slots, NW, G in ((2, 16, 1), (1, 4, 2), (2, 8, 1)):
+            monkeypatch.setenv('AVSI_LWS_DUO_SLOTS', str(slots))
+            out = L.lws(384, 192, kernel='duo', waves_per_group=NW, groups_per_utterance=G, **kw).run_lws(S0)
+            monkeypatch.delenv('AVSI_LWS_DUO_SLOTS')
+            assert np.array_equal(ref, out), (n, B, 'slots', slots, NW, G)
 
 
 def test_unsupported_geometry_is_reported_by_the_duo_kernel(L):
