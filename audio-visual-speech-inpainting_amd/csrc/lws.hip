@@ -107,40 +107,59 @@ __global__ void lws_tables_kernel(float* tab, int frame_len, int hop, int nfft) 
 // ---------------------------------------------------------------------------------------------- 512-point FFT in LDS
 __device__ __forceinline__ int bitrev9(int x) { return (int)(__brev((unsigned)x) >> 23); }
 
-// radix-2 decimation in time over s[512] (bit-reversed input order)
-__device__ __forceinline__ void fill_twiddles(float2* tw, int tid) {
-    float sn, cs;
-    sincospif(-2.f * (float)tid / 512.f, &sn, &cs);
-    tw[tid] = make_float2(cs, sn);
+// 512-point forward transform by ONE WAVE, eight values per lane: three radix-8 passes (Stockham: natural order in, natural
+// order out), the 8-point transforms in registers, the data through LDS between the passes only (a radix-2 transform moves
+// its 512 values through LDS nine times and was bound by LDS bandwidth: 24 GB for the frames of 1024 utterances in 0.6 ms).
+// No block barrier: the LDS operations of a wave are performed in program order.  Lane j holds v[r] = x[j + 64 r] on entry;
+// on return the spectrum sits in `s` at fft_slot(k).  tw[i] = exp(-2 pi j i / 512), i < 512.
+constexpr int FFT_BUF = NF + NF / 8;                                          // 576 slots: one of padding behind every eight
+__device__ __forceinline__ constexpr int fft_slot(int i) { return i + (i >> 3); }
+__device__ __forceinline__ float2 cmulf(float2 a, float2 w) { return make_float2(a.x * w.x - a.y * w.y, a.x * w.y + a.y * w.x); }
+__device__ __forceinline__ float2 caddf(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
+__device__ __forceinline__ float2 csubf(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
+__device__ __forceinline__ float2 mulmi(float2 a) { return make_float2(a.y, -a.x); }       // a . (-i)
+
+__device__ __forceinline__ void fft8(float2 (&v)[8]) {          // X[k] = sum_n v[n] exp(-2 pi j n k / 8), in place, natural order
+    constexpr float R = 0.70710678118654752f;
+    const float2 a0 = caddf(v[0], v[4]), a1 = csubf(v[0], v[4]), a2 = caddf(v[2], v[6]), a3 = mulmi(csubf(v[2], v[6]));
+    const float2 a4 = caddf(v[1], v[5]), a5 = csubf(v[1], v[5]), a6 = caddf(v[3], v[7]), a7 = mulmi(csubf(v[3], v[7]));
+    const float2 b0 = caddf(a0, a2), b2 = csubf(a0, a2), b1 = caddf(a1, a3), b3 = csubf(a1, a3);
+    const float2 b4 = caddf(a4, a6), c6 = csubf(a4, a6), c5 = caddf(a5, a7), c7 = csubf(a5, a7);
+    const float2 b5 = make_float2(R * (c5.x + c5.y), R * (c5.y - c5.x));      // . (1 - i) / sqrt 2
+    const float2 b6 = mulmi(c6);                                              // . (-i)
+    const float2 b7 = make_float2(R * (c7.y - c7.x), -R * (c7.x + c7.y));     // . (-1 - i) / sqrt 2
+    v[0] = caddf(b0, b4), v[4] = csubf(b0, b4), v[1] = caddf(b1, b5), v[5] = csubf(b1, b5);
+    v[2] = caddf(b2, b6), v[6] = csubf(b2, b6), v[3] = caddf(b3, b7), v[7] = csubf(b3, b7);
 }
 
-// The same transform by ONE WAVE (s: this wave's 512 values, bit-reversed input order): four butterflies per lane and stage,
-// and no block barrier between the stages -- the LDS operations of a wave are performed in program order, a stage's reads see
-// the stage before.  (A frame per 256-thread block spent its time in nine __syncthreads: 0.73 ms for the 258 k frames of 1024
-// utterances, 0.7 TB/s of a kernel that only writes its spectrum.)
-__device__ __forceinline__ void fft512_wave(float2* s, const float2* tw, int lane) {
+__device__ __forceinline__ void fft512_wave(float2 (&v)[8], float2* s, const float2* tw, int lane) {
 #pragma unroll
-    for (int st = 0; st < 9; ++st) {
-        const int half = 1 << st;
-        float2 a[4], t[4];
-        int i0[4];
+    for (int pass = 0; pass < 3; ++pass) {
+        const int Ns = pass == 0 ? 1 : (pass == 1 ? 8 : 64);
+        const int k = lane & (Ns - 1);
+        if (pass > 0) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int e = lane + 64 * q;
-            const int j = e & (half - 1);
-            i0[q] = ((e >> st) << (st + 1)) + j;
-            const float2 w = tw[j << (8 - st)];
-            const float2 b = s[i0[q] + half];
-            a[q] = s[i0[q]];
-            t[q] = make_float2(b.x * w.x - b.y * w.y, b.x * w.y + b.y * w.x);
+            for (int r = 0; r < 8; ++r) v[r] = s[fft_slot(lane + 64 * r)];
+#pragma unroll
+            for (int r = 1; r < 8; ++r) v[r] = cmulf(v[r], tw[r * k * (64 / Ns)]);
         }
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            s[i0[q]] = make_float2(a[q].x + t[q].x, a[q].y + t[q].y);
-            s[i0[q] + half] = make_float2(a[q].x - t[q].x, a[q].y - t[q].y);
-        }
-        asm volatile("" ::: "memory");          // (the next stage's reads stay behind these writes)
+        fft8(v);
+        const int j0 = (lane / Ns) * Ns * 8 + k;
+        asm volatile("" ::: "memory");          // (these writes stay behind the reads above, the next pass's reads behind them)
         __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int r = 0; r < 8; ++r) s[fft_slot(j0 + r * Ns)] = v[r];
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+__device__ __forceinline__ void fill_twiddles(float2* tw, int tid) {      // 512 entries, 256 threads
+#pragma unroll
+    for (int i = tid; i < NF; i += 256) {
+        float sn, cs;
+        sincospif(-2.f * (float)i / 512.f, &sn, &cs);
+        tw[i] = make_float2(cs, sn);
     }
 }
 
@@ -150,31 +169,30 @@ constexpr int FPB = 4;        // frames per 256-thread block of the two transfor
 __global__ __launch_bounds__(256) void lws_stft_kernel(const float* __restrict__ wav, int64_t wav_stride, int num_samples,
                                                        const float* __restrict__ tab, int hop, float2* __restrict__ spec,
                                                        int M) {
-    __shared__ float2 sall[FPB][NF], tw[256];
+    __shared__ float2 sall[FPB][FFT_BUF], tw[NF];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, m = blockIdx.x * FPB + wv, b = blockIdx.y;
     fill_twiddles(tw, tid);
     __syncthreads();
     if (m >= M) return;
     float2* s = sall[wv];
     const int64_t t0 = (int64_t)m * hop - (NF - hop);       // 'perfectrec': N - R zeros in front
+    float2 v[8];
 #pragma unroll
-    for (int i = 0; i < NF / 64; ++i) {
-        const int n = lane + 64 * i;
+    for (int r = 0; r < 8; ++r) {
+        const int n = lane + 64 * r;
         const int64_t t = t0 + n;
         const float x = (t >= 0 && t < num_samples) ? wav[(int64_t)b * wav_stride + t] : 0.f;
-        s[bitrev9(n)] = make_float2(x * tab[TAB_AWIN + n], 0.f);
+        v[r] = make_float2(x * tab[TAB_AWIN + n], 0.f);
     }
-    asm volatile("" ::: "memory");
-    __builtin_amdgcn_wave_barrier();
-    fft512_wave(s, tw, lane);
+    fft512_wave(v, s, tw, lane);
     float2* out = spec + ((int64_t)b * M + m) * KB;
-    for (int k = lane; k < KB; k += 64) out[k] = s[k];
+    for (int k = lane; k < KB; k += 64) out[k] = s[fft_slot(k)];
 }
 
 // frames [B][M][512] <- swin . irfft(spec)
 __global__ __launch_bounds__(256) void lws_istft_frames_kernel(const float2* __restrict__ spec, const float* __restrict__ tab,
                                                                float* __restrict__ frames, int M) {
-    __shared__ float2 sall[FPB][NF], tw[256];
+    __shared__ float2 sall[FPB][FFT_BUF], tw[NF];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, m = blockIdx.x * FPB + wv, b = blockIdx.y;
     fill_twiddles(tw, tid);
     __syncthreads();
@@ -182,26 +200,25 @@ __global__ __launch_bounds__(256) void lws_istft_frames_kernel(const float2* __r
     float2* s = sall[wv];
     const float2* in = spec + ((int64_t)b * M + m) * KB;
     // x[n] = Re FFT(conj Xfull)[n] / N, Xfull[k] = X[k] (k <= 256), conj X[512 - k] above; irfft drops Im of DC / Nyquist
+    float2 v[8];
 #pragma unroll
-    for (int i = 0; i < NF / 64; ++i) {
-        const int k = lane + 64 * i;
-        float2 v;
+    for (int r = 0; r < 8; ++r) {
+        const int k = lane + 64 * r;
+        float2 x;
         if (k <= 256) {
-            v = in[k];
-            v.y = (k == 0 || k == 256) ? 0.f : -v.y;
+            x = in[k];
+            x.y = (k == 0 || k == 256) ? 0.f : -x.y;
         } else {
-            v = in[NF - k];
+            x = in[NF - k];
         }
-        s[bitrev9(k)] = v;
+        v[r] = x;
     }
-    asm volatile("" ::: "memory");
-    __builtin_amdgcn_wave_barrier();
-    fft512_wave(s, tw, lane);
+    fft512_wave(v, s, tw, lane);
     float* out = frames + ((int64_t)b * M + m) * NF;
 #pragma unroll
     for (int i = 0; i < NF / 64; ++i) {
         const int n = lane + 64 * i;
-        out[n] = s[n].x * (1.f / NF) * tab[TAB_SWIN + n];
+        out[n] = s[fft_slot(n)].x * (1.f / NF) * tab[TAB_SWIN + n];
     }
 }
 
