@@ -503,40 +503,67 @@ __global__ __launch_bounds__(64 * NW, 4) void lws_duo_kernel(float2* __restrict_
 }
 
 // spec [B][M][257] -> the diagonal layout of a pair (bins, the five mirror positions above Nyquist, magnitudes); everything
-// else zero, every cell written
-__global__ __launch_bounds__(256) void lws_to_duo_kernel(const float2* __restrict__ spec, int B, int M, int rows, float2* __restrict__ S,
-                                                        float* __restrict__ A) {
-    const int q = blockIdx.y, l = threadIdx.x & 63, j = l & (LPU - 1), b = q * UPW + l / LPU;
-    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (r >= rows) return;
-    float2 v = make_float2(0.f, 0.f);
-    float a = 0.f;
-    const int x0 = r - ROW_OFF - SKEW * j;
-    if (x0 >= 0 && b < B && r < rows - 1) {
-        const int rnd = x0 / PERIOD, x = x0 - rnd * PERIOD, m = rnd * LPU + j;
-        if (x <= TAU_LAST && m < M) {
-            const float2* sp = spec + ((int64_t)b * M + m) * KB;
-            if (x < KB) {
-                v = sp[x];
-                a = sqrtf(fmaf(v.x, v.x, v.y * v.y));      // (the fused form, spelled out: as lws_skew.hip)
-            } else {
-                v = conjf2(sp[2 * (KB - 1) - x]);
-            }
-        }
-    }
-    const int64_t at = ((int64_t)q * rows + r) * LANES + l;
-    S[at] = v;
-    A[at] = a;
+// else zero, every cell written.  A block owns sixteen lanes (frames 32 rnd + 16 h + 0 .. 15 of one utterance) and, of each
+// lane, the 288 rows of its round: the frames come in through LDS in whole spectra (coalesced along the bins) and go out in
+// whole 128-byte pieces of rows (coalesced along the lanes) -- a thread per cell read or wrote 8 bytes at a 2 KB stride
+// (0.5 ms each way at 1024 utterances).  The first round's blocks also write the rows above a lane's first frame, the last
+// round's the rows below its last one (and the scratch row).
+constexpr int TL = 16;                          // lanes per block of the two layout kernels
+__device__ __forceinline__ void layout_span(int rnd, int h, int rounds, int rows, int& rlo, int& rhi) {
+    rlo = rnd == 0 ? 0 : PERIOD * rnd + ROW_OFF + SKEW * TL * h;
+    rhi = rnd == rounds - 1 ? rows : PERIOD * (rnd + 1) + ROW_OFF + SKEW * (TL * h + TL - 1) + 1;
 }
 
-__global__ __launch_bounds__(256) void lws_from_duo_kernel(const float2* __restrict__ S, int B, int M, int rows, float2* __restrict__ spec) {
-    const int q = blockIdx.y, l = threadIdx.x & 63, j = l & (LPU - 1), b = q * UPW + l / LPU;
-    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (r >= rows - 1 || b >= B) return;
-    const int x0 = r - ROW_OFF - SKEW * j;
-    if (x0 < 0) return;
-    const int rnd = x0 / PERIOD, x = x0 - rnd * PERIOD, m = rnd * LPU + j;
-    if (x < KB && m < M) spec[((int64_t)b * M + m) * KB + x] = S[((int64_t)q * rows + r) * LANES + l];
+__global__ __launch_bounds__(256) void lws_to_duo_kernel(const float2* __restrict__ spec, int B, int M, int rows, int rounds,
+                                                        float2* __restrict__ S, float* __restrict__ A) {
+    __shared__ float2 tile[TL][KB];
+    const int tid = threadIdx.x, rnd = blockIdx.x >> 1, h = blockIdx.x & 1, b = blockIdx.y, q = b / UPW, u = b - q * UPW;
+    const int m0 = rnd * LPU + TL * h;
+    for (int i = tid; i < TL * KB; i += 256) {
+        const int fr = i / KB, x = i - fr * KB, m = m0 + fr;
+        tile[fr][x] = (b < B && m < M) ? spec[((int64_t)b * M + m) * KB + x] : make_float2(0.f, 0.f);
+    }
+    __syncthreads();
+    int rlo, rhi;
+    layout_span(rnd, h, rounds, rows, rlo, rhi);
+    const int jj = tid & (TL - 1), j = TL * h + jj, m = m0 + jj;
+    const bool live = b < B && m < M;
+    for (int r = rlo + (tid >> 4); r < rhi; r += 256 / TL) {
+        const int x = r - ROW_OFF - SKEW * j - PERIOD * rnd;             // position inside this round's frame of the lane
+        if ((x < 0 && rnd > 0) || (x >= PERIOD && rnd < rounds - 1)) continue;          // another round's rows of this lane
+        float2 v = make_float2(0.f, 0.f);
+        float a = 0.f;
+        if (live && x >= 0 && x <= TAU_LAST && r < rows - 1) {
+            if (x < KB) {
+                v = tile[jj][x];
+                a = sqrtf(fmaf(v.x, v.x, v.y * v.y));      // (the fused form, spelled out: as lws_skew.hip)
+            } else {
+                v = conjf2(tile[jj][2 * (KB - 1) - x]);
+            }
+        }
+        const int64_t at = ((int64_t)q * rows + r) * LANES + u * LPU + j;
+        S[at] = v;
+        A[at] = a;
+    }
+}
+
+__global__ __launch_bounds__(256) void lws_from_duo_kernel(const float2* __restrict__ S, int B, int M, int rows, int rounds,
+                                                          float2* __restrict__ spec) {
+    __shared__ float2 tile[TL][KB];
+    const int tid = threadIdx.x, rnd = blockIdx.x >> 1, h = blockIdx.x & 1, b = blockIdx.y, q = b / UPW, u = b - q * UPW;
+    if (b >= B) return;
+    const int m0 = rnd * LPU + TL * h;
+    const int jj = tid & (TL - 1), j = TL * h + jj;
+    const int rlo = PERIOD * rnd + ROW_OFF + SKEW * TL * h, rhi = PERIOD * rnd + ROW_OFF + SKEW * (TL * h + TL - 1) + KB;
+    for (int r = rlo + (tid >> 4); r < rhi; r += 256 / TL) {
+        const int x = r - ROW_OFF - SKEW * j - PERIOD * rnd;
+        if (x >= 0 && x < KB && r < rows - 1) tile[jj][x] = S[((int64_t)q * rows + r) * LANES + u * LPU + j];
+    }
+    __syncthreads();
+    for (int i = tid; i < TL * KB; i += 256) {
+        const int fr = i / KB, x = i - fr * KB, m = m0 + fr;
+        if (m < M) spec[((int64_t)b * M + m) * KB + x] = tile[fr][x];
+    }
 }
 
 size_t align256(size_t n) { return (n + 255) & ~(size_t)255; }
@@ -626,7 +653,8 @@ extern "C" int avsi_lws_run_duo_f32(float* spec, int batch, int num_frames, int 
     if (const char* e = getenv("AVSI_LWS_DUO_SLOTS"))          // (tests: several pairs per workgroup at small batches)
         if (atoi(e) > 0 && atoi(e) < slots) slots = atoi(e);
     if (slots > duos) slots = duos;
-    hipLaunchKernelGGL(lws_to_duo_kernel, dim3((rows + 3) / 4, duos), dim3(256), 0, st, sp, batch, num_frames, rows, Sd, Ad);
+    const int rounds = (num_frames + LPU - 1) / LPU;
+    hipLaunchKernelGGL(lws_to_duo_kernel, dim3(2 * rounds, duos * UPW), dim3(256), 0, st, sp, batch, num_frames, rows, rounds, Sd, Ad);
 #define AVSI_DUO_LAUNCH(NWV)                                                                                                        \
     hipLaunchKernelGGL((lws_duo_kernel<NWV>), dim3(slots* G), dim3(64 * (NWV)), 0, st, Sd, Ad, batch, num_frames, S, status, stats, \
                        gprog, G, phase_step, duos, slots)
@@ -634,6 +662,6 @@ extern "C" int avsi_lws_run_duo_f32(float* spec, int batch, int num_frames, int 
     else if (NW == 8) AVSI_DUO_LAUNCH(8);
     else AVSI_DUO_LAUNCH(4);
 #undef AVSI_DUO_LAUNCH
-    hipLaunchKernelGGL(lws_from_duo_kernel, dim3((rows + 3) / 4, duos), dim3(256), 0, st, Sd, batch, num_frames, rows, sp);
+    hipLaunchKernelGGL(lws_from_duo_kernel, dim3(2 * rounds, duos * UPW), dim3(256), 0, st, Sd, batch, num_frames, rows, rounds, sp);
     return avsi_launch_status();
 }
