@@ -662,6 +662,35 @@ def extra_workloads(torch, models, ops, ap_mod, cfg, mean, std, device):
         finally:
             for n, fn in plain.items():
                 setattr(ops, n, fn)
+        # the two recurrent kernels of training ALONE on resident operands of the same shape (tools/rec_bwd_time.py,
+        # tools/rec_fwd_time.py): inside the step they share the chip with the side streams' kernels
+        del m
+        torch.cuda.empty_cache()
+        alone = {}
+        try:
+            def timed(fn):
+                for _ in range(2):
+                    fn()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(3):
+                    fn()
+                e1.record()
+                torch.cuda.synchronize()
+                t = e0.elapsed_time(e1) / 3
+                tf = 0.25e9 * B / (t * 1e-3) / 1e12
+                return {"ms": t, "TFLOP/s": tf, "frac": tf / FP32_MFMA_PEAK_TFLOPS}
+            resv = torch.rand(T_FRAMES, B, 2, 5, 256, device=device) * 0.9 + 0.05
+            wts = torch.randn(2 * 262144, device=device) * 0.05
+            dh = torch.randn(T_FRAMES, B, 512, device=device)
+            dz = torch.empty(T_FRAMES, B, 2048, device=device)
+            alone["blstm_rec_bwd_pp_kernel"] = timed(lambda: plain["blstm_rec_bwd"](dh, resv, wts, dz, split=0))
+            dz.normal_(0.0, 0.3)
+            alone["blstm_rec_fwd_pp_kernel<true> (with reserve)"] = timed(lambda: ops.blstm_rec_fwd(dz, wts, dh, resv, split=0))
+            alone["blstm_rec_fwd_pp_kernel<false>"] = timed(lambda: ops.blstm_rec_fwd(dz, wts, dh, None, split=0))
+            del resv, wts, dh, dz
+        except Exception as e:
+            alone["error"] = "%s: %s" % (type(e).__name__, str(e)[:200])
         t_bwd, n_bwd = tot["blstm_rec_bwd"]
         t_wg, _ = tot["gemm_splitk"]
         bwd_tf = 0.25e9 * B * n_bwd / (t_bwd * 1e-3) / 1e12
@@ -670,6 +699,7 @@ def extra_workloads(torch, models, ops, ap_mod, cfg, mean, std, device):
                 "per_gpu_batch": B, "ms_per_step": ms, "value": B / ms * 1e3, "unit": "utterances/s",
                 "algorithmic_TFLOP/s": 3 * AV_FWD_FLOPS * B / (ms * 1e-3) / 1e12,
                 "frac_of_fp32_mfma_peak": 3 * AV_FWD_FLOPS * B / (ms * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS,
+                "kernels_alone": alone,
                 "kernels": {"blstm_rec_bwd_pp_kernel": {"avg_launch_ms": t_bwd / n_bwd, "TFLOP/s": bwd_tf,
                                                         "frac": bwd_tf / FP32_MFMA_PEAK_TFLOPS},
                             "gemm_dma_kernel<true,...> (weight gradients, split-K A^T.B)": {
