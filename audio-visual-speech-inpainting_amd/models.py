@@ -588,7 +588,7 @@ class StackedBLSTMModel(object):
         # Data parallel (train_op sets _reduce_in_backward): the packed gradient buffer is all-reduced in buckets --
         # one per layer, started right behind that layer's weight-gradient kernels, and the head at the end -- so
         # the collectives of the upper layers run while the BPTT of the lower ones is still going
-        reduce = bool(getattr(self, '_reduce_in_backward', False)) and parallel.world_size() > 1
+        reduce = bool(getattr(self, '_reduce_in_backward', False)) and parallel.dp_active()
         works = []
 
         def reduce_from(name, upto=None):
@@ -732,7 +732,7 @@ class StackedBLSTMModel(object):
         if not c.get('grads_reduced'):
             # single process, or gradients that were fetched (unreduced) before train_op: one flat all-reduce + the guard's
             parallel.all_reduce_sum_(g)
-            c['grads_reduced'] = world > 1
+            c['grads_reduced'] = parallel.dp_active()
             c['guard'] = parallel.all_reduce_sum_(ops.step_guard(c['loss3'][0:1], torch.empty(2, device=self.device)))
         guard = c['guard']
         step = v.global_step + 1

@@ -24,10 +24,19 @@ def env_world():
             int(os.environ.get("WORLD_SIZE", "1")))
 
 
+def rehearsing():
+    """AVSI_DP_REHEARSE=1: a ONE-rank process group counts as data parallel -- the bucketed asynchronous all-reduce, the
+    guard words behind the last bucket, the CU reserve of the cooperative kernels and the 1 / world inside the fused Adam
+    all run against the communicator (backend nccl = RCCL: its stream, its events, its ordering against the launch
+    stream) on a box that has ONE GPU.  RCCL moves no data between ranks then; everything on this side of it is the
+    production path (tests/test_dp_gpu.py::test_world1_rccl_rehearsal, bench.py `dp_train`)."""
+    return os.environ.get('AVSI_DP_REHEARSE', '0') == '1'
+
+
 def init(backend=None):
-    """Initialise the default process group when launched with WORLD_SIZE > 1; returns (rank, world)."""
+    """Initialise the default process group when launched with WORLD_SIZE > 1 (or rehearsing()); returns (rank, world)."""
     rank, local_rank, world = env_world()
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or rehearsing()) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend is None:
@@ -44,8 +53,7 @@ def collectives_share_the_gpu():
     """True when this process runs RCCL collectives on its GPU (world > 1, backend nccl): their kernels hold compute
     units while the cooperative recurrent kernels run (the bucketed gradient all-reduce overlaps the BPTT of the
     layers below), so those kernels are sized to leave ops.COOP_CU_RESERVE CUs free (ops.coop_cu_budget)."""
-    return dist.is_available() and dist.is_initialized() and not _SOLO and dist.get_world_size() > 1 \
-        and dist.get_backend() == 'nccl'
+    return dp_active() and dist.get_backend() == 'nccl'
 
 
 _SOLO = 0
@@ -68,6 +76,12 @@ class solo(object):
         return False
 
 
+def dp_active():
+    """True when this process's gradients go through the process group's collectives: a group exists, this is not a
+    solo() section, and there is more than one rank (or the one-rank rehearsal is switched on)."""
+    return dist.is_available() and dist.is_initialized() and not _SOLO and (dist.get_world_size() > 1 or rehearsing())
+
+
 def world_size():
     return dist.get_world_size() if dist.is_available() and dist.is_initialized() and not _SOLO else 1
 
@@ -85,7 +99,7 @@ def shard_range(n, rank_, world):
 
 def all_reduce_sum_(flat):
     """In-place sum over ranks of one flat buffer (no-op on a single process)."""
-    if world_size() > 1:
+    if dp_active():
         if flat.is_cuda and dist.get_backend() != 'nccl':
             host = flat.cpu()
             dist.all_reduce(host, op=dist.ReduceOp.SUM)
@@ -97,7 +111,7 @@ def all_reduce_sum_(flat):
 
 def all_reduce_mean_scalars(values):
     """Mean over ranks of a few python floats (validation losses); returns a list of floats."""
-    if world_size() == 1:
+    if not dp_active():
         return list(values)
     dev = 'cuda' if dist.get_backend() == 'nccl' else 'cpu'
     t = torch.tensor(list(values), dtype=torch.float64, device=dev)
@@ -107,7 +121,7 @@ def all_reduce_mean_scalars(values):
 
 def all_reduce_sum_scalars(values):
     """Sum over ranks of a few python floats; returns a list of floats."""
-    if world_size() == 1:
+    if not dp_active():
         return list(values)
     dev = 'cuda' if dist.get_backend() == 'nccl' else 'cpu'
     t = torch.tensor(list(values), dtype=torch.float64, device=dev)
@@ -117,7 +131,7 @@ def all_reduce_sum_scalars(values):
 
 def all_reduce_max_scalar(value):
     """Maximum over ranks of one python float (the 'some rank saw a non-finite loss' verdict of the trainer)."""
-    if world_size() == 1:
+    if not dp_active():
         return float(value)
     dev = 'cuda' if dist.get_backend() == 'nccl' else 'cpu'
     t = torch.tensor([float(value)], dtype=torch.float64, device=dev)
@@ -130,7 +144,7 @@ def all_reduce_sum_async(flat):
     to wait for).  With RCCL the collective runs on the communicator's stream, ordered after the work already
     enqueued on the current stream: called right after the kernels that produced `flat`, it overlaps with whatever
     the caller enqueues next (the BPTT of the layers below)."""
-    if world_size() == 1:
+    if not dp_active():
         return None
     if flat.is_cuda and dist.get_backend() == 'nccl':
         return dist.all_reduce(flat, op=dist.ReduceOp.SUM, async_op=True)

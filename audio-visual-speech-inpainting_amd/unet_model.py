@@ -608,7 +608,7 @@ class UNetFConvModel(object):
         g = self._backward()
         v = self.variables
         world = parallel.world_size()
-        if world > 1:
+        if parallel.dp_active():
             # one flat all-reduce; the two words behind the gradients are this rank's step guard ("my loss is not
             # finite": NaN survives the sum): see StackedBLSTMModel.step_guard
             gf = self._buf('grads+guard', (self.layout.ref_size + 2,))

@@ -340,8 +340,12 @@ def dp_train_block(torch, dist, models, ops, ap_mod, cfg, device, rank, world):
     step of 32 utterances costs a third of a step of 256).  `ms_per_step_no_collective` is the same
     per-GPU step with the all-reduce switched off (every rank on its own), so the price of the collective is visible."""
     from avsi_amd import parallel
-    out = {"n_gpus": world, "backend": dist.get_backend() if world > 1 else None,
-           "rccl_ranks": dist.get_world_size() if world > 1 else 1}
+    grouped = dist.is_initialized()          # world > 1, or the one-rank rehearsal (AVSI_DP_REHEARSE=1)
+    out = {"n_gpus": world, "backend": dist.get_backend() if grouped else None,
+           "rccl_ranks": dist.get_world_size() if grouped else 1}
+    if grouped and world == 1:
+        out["rehearsal"] = ("one-rank %s communicator: bucketed asynchronous all-reduce, guard words, %d-CU cooperative "
+                            "budget and 1 / world in the fused Adam all ran against it" % (dist.get_backend(), ops.coop_cu_budget()))
 
     # normalisation statistics from a seeded batch that is the same on every rank (the headline's are per-rank data)
     spec = ap_mod.frontend(synth_batch(torch, 64, 4242, device)[0], want_spec=True)['spec']
@@ -392,7 +396,7 @@ def dp_train_block(torch, dist, models, ops, ap_mod, cfg, device, rank, world):
     flat, init, losses = three_steps(per, wav[sl].contiguous(), masks[sl].contiguous(), video[sl].contiguous())
     check = {"steps": 3, "per_gpu_batch": per, "global_batch": G, "frames": T_FRAMES,
              "max_abs_update": float((flat - init).abs().max())}
-    if world > 1:
+    if grouped:
         bits = flat.view(torch.int32)
         hi = _all_reduce(torch, dist, bits.clone(), dist.ReduceOp.MAX)
         lo = _all_reduce(torch, dist, bits.clone(), dist.ReduceOp.MIN)
@@ -430,7 +434,7 @@ def dp_train_block(torch, dist, models, ops, ap_mod, cfg, device, rank, world):
                  "value": per_b * world / ms * 1e3, "unit": "utterances/s"}
         entry["recurrent_kernels"] = ("default policy", "cooperative, splits <= 8 (fell back once)",
                                       "batch-stationary (fell back twice)")[ops.coop_level()]
-        if world > 1:
+        if grouped:
             with parallel.solo():
                 entry["ms_per_step_no_collective"] = time_steps_all_ranks(torch, dist, world, step, steps, 2)
         out[key] = entry
@@ -827,6 +831,38 @@ def extra_workloads(torch, models, ops, ap_mod, cfg, mean, std, device):
     return out
 
 
+def free_port():
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def self_launch(n):
+    """`python bench.py --gpus N` without a launcher around it: start `python -m torch.distributed.run --nnodes=1
+    --nproc-per-node N --master-addr 127.0.0.1 --master-port <free> bench.py <the same arguments>` as a CHILD process in
+    a process group of its own, pass its stdout (rank 0's one JSON line) and stderr through, forward SIGTERM / SIGINT to
+    the whole group, and return its exit status.  Called before this process imports torch: it never initialises a GPU."""
+    import signal
+    import subprocess
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr",
+           "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: RCCL's intra-node transport needs it on this image
+    env.setdefault("OMP_NUM_THREADS", "1")
+    child = subprocess.Popen(cmd, env=env, start_new_session=True)
+
+    def forward(signum, _frame):
+        try:
+            os.killpg(child.pid, signum)
+        except ProcessLookupError:
+            pass
+    for sig in (signal.SIGTERM, signal.SIGINT):
+        signal.signal(sig, forward)
+    rc = child.wait()
+    return rc if rc >= 0 else 128 - rc
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -846,6 +882,10 @@ def main():
                          "unet = configs[4]: U-Net spectrogram inpainter inference (use --batch 32 .. 512)")
     args = ap.parse_args()
     t_bench0 = time.perf_counter()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ and "RANK" not in os.environ:
+        # plain `python bench.py --gpus N`, the form the driver uses at N = 1: this process becomes the launcher of N ranks
+        # (a CHILD torch.distributed.run; nothing here has imported torch or touched a GPU, and nothing is exec'ed)
+        sys.exit(self_launch(args.gpus))
 
     import torch
     import torch.distributed as dist
@@ -856,13 +896,16 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            sys.exit("bench.py --gpus %d must be launched with torch.distributed.run (one rank per GPU)" % args.gpus)
+        sys.exit("bench.py --gpus %d inside a launch of %d ranks (WORLD_SIZE): the two must agree" % (args.gpus, world))
     local_rank %= torch.cuda.device_count()        # ranks sharing a GPU (gloo rehearsal) all map onto it
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
-    if world > 1:
+    from avsi_amd import parallel
+    if world > 1 or parallel.rehearsing():
+        # AVSI_DP_REHEARSE=1 at N = 1: a one-rank RCCL communicator, so that `dp_train` runs the bucketed asynchronous
+        # all-reduce, the guard words and the CU reserve against RCCL's stream on a one-GPU box (parallel.rehearsing)
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", str(free_port()))
         # RCCL (backend "nccl") in production; AVSI_DIST_BACKEND=gloo lets several ranks share one GPU to rehearse
         # the multi-rank path on a single-GPU box (tests/test_bench_contract_gpu.py)
         backend = os.environ.get("AVSI_DIST_BACKEND", "nccl")
@@ -1103,8 +1146,11 @@ def main():
                     # by now this process has created two dozen streams, and which hardware queue the trainer's streams
                     # share with them decides its step time (8.2 ms here against 6.7 in a fresh process)
                     import subprocess
+                    # (a single-process run of the drivers: no rendezvous variables of this process in its environment)
+                    env_e2e = {k: v for k, v in os.environ.items()
+                               if k not in ("AVSI_DP_REHEARSE", "MASTER_PORT", "MASTER_ADDR", "RANK", "LOCAL_RANK", "WORLD_SIZE")}
                     child = subprocess.run([sys.executable, os.path.abspath(__file__), "--mode", "e2e"], capture_output=True,
-                                           text=True, timeout=max(60, args.also_timeout - 120))
+                                           text=True, env=env_e2e, timeout=max(60, args.also_timeout - 120))
                     lines_ = [l for l in child.stdout.splitlines() if l.startswith("{")]
                     if child.returncode != 0 or not lines_:
                         raise RuntimeError("child exited with %d: %s" % (child.returncode, child.stderr[-300:]))
@@ -1117,7 +1163,7 @@ def main():
         line["also"] = also
     if rank == 0 and not train:
         print(json.dumps(line))
-    if world > 1:
+    if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
 

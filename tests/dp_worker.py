@@ -56,10 +56,21 @@ if __name__ == '__main__':
     out = sys.argv[1]
     from avsi_amd import parallel
     rank, world = parallel.init()
+    import torch.distributed as dist
+    calls = {'sync': 0, 'async': 0}
+    plain_all_reduce = dist.all_reduce
+
+    def counted(t, *a, **kw):
+        calls['async' if kw.get('async_op') else 'sync'] += 1
+        return plain_all_reduce(t, *a, **kw)
+    dist.all_reduce = counted
     flat, losses = run(rank, world, steps=int(sys.argv[4]) if len(sys.argv) > 4 else 3,
                        B_global=int(sys.argv[2]) if len(sys.argv) > 2 else 4, N=int(sys.argv[3]) if len(sys.argv) > 3 else 2880)
     np.save(os.path.join(out, 'flat_rank%d.npy' % rank), flat)
     np.save(os.path.join(out, 'loss_rank%d.npy' % rank), np.array(losses))
-    import torch.distributed as dist
+    from avsi_amd import ops
+    print('RANK %d BACKEND %s SHARES_GPU %s COOP_CUS %d ALL_REDUCE async %d sync %d' % (
+        rank, dist.get_backend(), parallel.collectives_share_the_gpu(), ops.coop_cu_budget(), calls['async'], calls['sync']),
+        flush=True)
     dist.barrier()
     dist.destroy_process_group()

@@ -116,3 +116,51 @@ def test_multi_rank_launch_as_the_driver_does(mode, ranks):
         assert dp["fixed_global_256"]["global_batch"] == 256
         for k in ("weak_32_per_gpu", "fixed_global_256"):
             assert dp[k]["ms_per_step"] > 0 and dp[k]["ms_per_step_no_collective"] > 0
+
+
+def test_plain_launch_with_gpus_2_starts_its_own_ranks():
+    """`python bench.py --gpus 2 ...` exactly as the driver launches N = 1 (no torch.distributed.run around it): the
+    process starts its two ranks as a child launcher before it touches a GPU, relays rank 0's one line and its status."""
+    env = dict(os.environ, AVSI_DIST_BACKEND='gloo', HSA_ENABLE_IPC_MODE_LEGACY='0', AVSI_COOP_CUS='128')
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT"):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--batch", "64", "--steps", "2",
+                          "--warmup", "1"], env=env, capture_output=True, text=True, timeout=1500, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 128 and d["config"]["parallelism"] == "dp2"
+    dp = d["dp_train"]
+    assert "error" not in dp, dp
+    assert dp["rccl_ranks"] == 2 and dp["check"]["ok"] is True and dp["check"]["ranks_bit_identical"] is True
+
+
+def test_plain_launch_passes_a_failing_status_on():
+    """Ranks that exit non-zero make the plain form exit non-zero too (here: a process-group backend that does not exist)."""
+    env = dict(os.environ, AVSI_DIST_BACKEND='no-such-backend')
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT"):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--batch", "64", "--steps", "1",
+                          "--warmup", "0"], env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert out.returncode != 0
+    assert not [l for l in out.stdout.splitlines() if l.startswith("{")]
+
+
+def test_world1_rccl_rehearsal_in_the_bench_line():
+    """AVSI_DP_REHEARSE=1 at N = 1: `dp_train` runs over a one-rank RCCL communicator (backend nccl) -- the asynchronous
+    buckets, the guard words and the reduced cooperative CU budget against RCCL's stream -- and its self-check compares
+    that run with the same process without collectives."""
+    env = dict(os.environ, AVSI_DP_REHEARSE='1', HSA_ENABLE_IPC_MODE_LEGACY='0')
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "AVSI_DIST_BACKEND"):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--batch", "64", "--steps", "2", "--warmup", "1",
+                          "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-3000:]
+    d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    dp = d["dp_train"]
+    assert "error" not in dp, dp
+    assert dp["backend"] == "nccl" and dp["rccl_ranks"] == 1 and "rehearsal" in dp
+    c = dp["check"]
+    assert c["ranks_bit_identical"] is True and c["ok"] is True and c["max_abs_diff_vs_single_process"] < 2e-5
+    assert dp["weak_32_per_gpu"]["ms_per_step_no_collective"] > 0

@@ -117,3 +117,33 @@ def test_two_ranks_over_rccl_equal_one_process(tmp_path, B_global):
     np.testing.assert_allclose(f0, ref, rtol=0, atol=2e-5)
     l0, l1 = np.load(str(tmp_path / 'loss_rank0.npy')), np.load(str(tmp_path / 'loss_rank1.npy'))
     np.testing.assert_allclose((l0 + l1) / 2, ref_losses, rtol=2e-4)
+
+
+@pytest.mark.parametrize("B", [32, 192])
+def test_world1_rccl_rehearsal(tmp_path, B):
+    """The `nccl` branch on a ONE-GPU box: a one-rank RCCL communicator with AVSI_DP_REHEARSE=1 (parallel.rehearsing), so that
+    the per-layer asynchronous all-reduce buckets (issued from the side stream at 32 utterances, from the main stream at
+    192), the two guard words behind the last bucket, the guarded Adam's 1 / world and the cooperative kernels' CU budget
+    of 256 - COOP_CU_RESERVE all run against RCCL's communicator, its stream and its event ordering.  RCCL has no peer to
+    move data to, so the result must equal a process without any group -- to summation order only where the smaller CU
+    budget cuts a launch differently."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0', AVSI_DP_REHEARSE='1', MASTER_ADDR='127.0.0.1',
+               MASTER_PORT=str(_free_port()), RANK='0', LOCAL_RANK='0', WORLD_SIZE='1')
+    env.pop('AVSI_DIST_BACKEND', None)
+    cmd = [sys.executable, os.path.join(HERE, 'dp_worker.py'), str(tmp_path), str(B), '48000', '3']
+    run = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert run.returncode == 0, run.stderr[-3000:]
+    import re
+    m = re.search(r'RANK 0 BACKEND nccl SHARES_GPU True COOP_CUS (\d+) ALL_REDUCE async (\d+) sync (\d+)', run.stdout)
+    assert m, run.stdout[-2000:]
+    from avsi_amd import ops
+    assert int(m.group(1)) == 256 - ops.COOP_CU_RESERVE
+    assert int(m.group(2)) >= 3 * 4                      # three layers' buckets and the head's, every step
+    f0 = np.load(str(tmp_path / 'flat_rank0.npy'))
+    sys.path.insert(0, HERE)
+    import dp_worker
+    ref, ref_losses = dp_worker.run(0, 1, steps=3, B_global=B, N=48000)
+    init, _ = dp_worker.run(0, 1, steps=0, B_global=B, N=48000)
+    assert np.abs(ref - init).max() > 1e-3
+    np.testing.assert_allclose(f0, ref, rtol=0, atol=2e-5)
+    np.testing.assert_allclose(np.load(str(tmp_path / 'loss_rank0.npy')), ref_losses, rtol=2e-4)

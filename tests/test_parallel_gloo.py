@@ -136,3 +136,58 @@ def test_weighted_combination_ignores_ranks_without_batches(tmp_path):
     out = str(tmp_path / "sums.npy")
     mp.spawn(_sum_worker, args=(2, _free_port(), out), nprocs=2, join=True)
     np.testing.assert_allclose(np.load(out), [0.5, 0.25])
+
+
+def _rehearsal_worker(port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0",
+                      AVSI_DP_REHEARSE="1")
+    assert parallel.dp_active() is False            # no group yet
+    r, w = parallel.init(backend="gloo")
+    assert (r, w) == (0, 1) and dist.is_initialized() and parallel.world_size() == 1
+    # a one-rank group counts as data parallel while rehearsing: the collectives are issued, and sum over one rank is identity
+    assert parallel.dp_active() is True and parallel.collectives_share_the_gpu() is False      # gloo: no kernels on the GPU
+    calls = []
+    plain = dist.all_reduce
+    dist.all_reduce = lambda t, *a, **kw: (calls.append(t.numel()), plain(t, *a, **kw))[1]
+    flat = torch.arange(10, dtype=torch.float32)
+    parallel.all_reduce_sum_(flat)
+    assert parallel.all_reduce_sum_async(flat[:4]) is None and torch.equal(flat, torch.arange(10, dtype=torch.float32))
+    assert parallel.all_reduce_sum_scalars([1.5, 2.0]) == [1.5, 2.0] and parallel.all_reduce_max_scalar(3.0) == 3.0
+    assert calls == [10, 4, 2, 1]
+    with parallel.solo():
+        assert parallel.dp_active() is False
+        parallel.all_reduce_sum_(flat)
+    assert calls == [10, 4, 2, 1]
+    os.environ["AVSI_DP_REHEARSE"] = "0"
+    assert parallel.dp_active() is False             # a one-rank group without the switch: a plain single process
+    dist.destroy_process_group()
+    q.put("ok")
+
+
+def test_one_rank_rehearsal_switch():
+    """AVSI_DP_REHEARSE=1 (parallel.rehearsing): a one-rank process group issues every collective of the data-parallel
+    path; without the switch, or inside solo(), it issues none."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_rehearsal_worker, args=(_free_port(), q))
+    p.start()
+    p.join(120)
+    assert p.exitcode == 0 and q.get(timeout=5) == "ok"
+
+
+def test_bench_plain_launch_starts_a_child_launcher_and_relays_its_status():
+    """`python bench.py --gpus 2` with no launcher around it (the form the driver uses at N = 1) must start its ranks
+    itself instead of exiting with a usage message.  Without a GPU the ranks cannot get far: what is checked here is that
+    the parent started `torch.distributed.run` with two ranks, that both reached bench.py's own code (each fails at the
+    first GPU call), that the parent neither imported torch nor hung, and that it passes the failure on as its status."""
+    import subprocess
+    import sys
+    if torch.cuda.is_available():
+        pytest.skip("covered on the GPU by tests/test_bench_contract_gpu.py")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--batch", "64", "--steps", "1",
+                          "--warmup", "0"], env=env, capture_output=True, text=True, timeout=300, cwd=root)
+    assert out.returncode != 0
+    assert "must be launched with" not in out.stderr
+    assert "local_rank: 0" in out.stderr and "local_rank: 1" in out.stderr, out.stderr[-2000:]       # torchrun's failure report
