@@ -9,7 +9,7 @@ from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int32, c_int6
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libavsi_hip.so")
-ABI_VERSION = 10
+ABI_VERSION = 11
 
 AVSI_OK = 0
 AVSI_ERR_INVALID_ARG, AVSI_ERR_UNSUPPORTED, AVSI_ERR_LAUNCH, AVSI_ERR_WORKSPACE = -1, -2, -3, -4
@@ -64,6 +64,7 @@ PROTOTYPES = {
     "avsi_abi_version": (c_int, []),
     "avsi_status_string": (c_char_p, [c_int]),
     "avsi_blstm_net_supported": (c_int, [POINTER(c_int), c_int]),
+    "avsi_blstm_rec_bwd_kernel_name": (c_char_p, [c_int]),
     "avsi_frontend_table_floats": (c_size_t, [c_int, c_int]),
     "avsi_frontend_init_tables": (c_int, [c_void_p, c_int, c_int, c_void_p]),
     "avsi_frontend_f32": (c_int, [POINTER(FrontendArgs), c_void_p]),

@@ -59,8 +59,8 @@ class ParamLayout:
     def __init__(self, input_dim, net_dim=(250, 250, 250), audio_feat_dim=257, side=None, mlp=None, mlp_in_pitch=None,
                  asr=None):
         net_dim = tuple(int(h) for h in net_dim)
-        # the C ABI says which stacks its kernels take (avsi_blstm_net_supported: equal widths of 1 .. 256 units; the
-        # reference takes any, models.py:95-99,107) -- the host layer has no rule of its own
+        # the C ABI says which stacks its kernels take (avsi_blstm_net_supported: any per-layer widths of 1 .. 256 units,
+        # each layer padded to 256 of its own; the reference takes any width, models.py:95-99,107) -- the host layer has no rule of its own
         import ctypes
         from . import _lib
         rc = _lib.lib().avsi_blstm_net_supported((ctypes.c_int * len(net_dim))(*net_dim), len(net_dim)) if net_dim else -1

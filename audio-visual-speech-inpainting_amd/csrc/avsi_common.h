@@ -5,7 +5,7 @@
 #include <stdlib.h>
 #include "../../include/avsi_hip.h"
 
-#define AVSI_ABI_VERSION 10  // 10: two-utterances-per-wave LWS sweeps (9: step guard + guarded Adam (8: avsi_gemm_epilogue::k_zero (7: skewed-frame LWS sweeps (6: row-range forms of the cooperative forward entries (5: column-split recurrent kernel (4: LWS phase reconstruction (3: CTC loss + beam-search decoder (2: cooperative recurrence, implicit-GEMM / thin convolutions, blend loss))))))))
+#define AVSI_ABI_VERSION 11  // 11: avsi_blstm_rec_bwd_kernel_name (10: two-utterances-per-wave LWS sweeps) (9: step guard + guarded Adam (8: avsi_gemm_epilogue::k_zero (7: skewed-frame LWS sweeps (6: row-range forms of the cooperative forward entries (5: column-split recurrent kernel (4: LWS phase reconstruction (3: CTC loss + beam-search decoder (2: cooperative recurrence, implicit-GEMM / thin convolutions, blend loss))))))))
 
 // Launch-status helpers.  hipGetLastError() is per-thread and also reports errors left behind
 // by OTHER users of the runtime in this thread (e.g. the caller's framework), so every entry
@@ -57,5 +57,15 @@ __device__ __forceinline__ bool avsi_spin_expired(unsigned& polls, long long& t0
         return false;
     }
     return now - t0 > limit_ticks;
+}
+
+// The sticky status word as ONE verdict per workgroup (thread 0 reads it, every thread branches on that value): read per
+// thread, a word that flips between the reads of two waves would send some waves of the workgroup into its barriers and
+// LDS exchanges and let the others leave.  One barrier, once per launch.
+__device__ __forceinline__ bool avsi_launch_is_void(const unsigned* status) {
+    __shared__ unsigned verdict;
+    if (threadIdx.x == 0) verdict = __hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    return verdict != 0;
 }
 #endif

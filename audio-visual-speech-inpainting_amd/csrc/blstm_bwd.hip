@@ -372,6 +372,17 @@ static bool bwd_use_pp(int Bp) {
     return Bp > 32 * AVSI_NUM_CU / 2 && Bp <= 64 * AVSI_NUM_CU / 2;       // 4096 < Bp <= 8192
 }
 
+// K-halved kernel (two workgroups per CU) by default; AVSI_BWD_KH=0 selects the whole-tile kernel (A/B runs)
+static bool bwd_whole_tile() {
+    static const bool whole_tile = getenv("AVSI_BWD_KH") && atoi(getenv("AVSI_BWD_KH")) == 0;
+    return whole_tile;
+}
+
+extern "C" const char* avsi_blstm_rec_bwd_kernel_name(int Bp) {
+    if (bwd_whole_tile()) return "blstm_rec_bwd_kernel";
+    return bwd_use_pp(Bp) ? "blstm_rec_bwd_pp_kernel" : "blstm_rec_bwd_kh_kernel";
+}
+
 extern "C" int avsi_blstm_rec_bwd_f32(const float* dhout, const float* reserve, const float* whbT, float* dz, int T,
                                       int Bp, void* stream) {
     if (!dhout || !reserve || !whbT || !dz || T <= 0 || Bp <= 0) return AVSI_ERR_INVALID_ARG;
@@ -379,8 +390,7 @@ extern "C" int avsi_blstm_rec_bwd_f32(const float* dhout, const float* reserve, 
     if (reinterpret_cast<uintptr_t>(whbT) & 15) return AVSI_ERR_UNSUPPORTED;
     BwdArgs a{dhout, reserve, whbT, dz, T, Bp};
     avsi_clear_error();
-    // K-halved kernel (two workgroups per CU) by default; AVSI_BWD_KH=0 selects the whole-tile kernel (A/B runs)
-    static const bool whole_tile = getenv("AVSI_BWD_KH") && atoi(getenv("AVSI_BWD_KH")) == 0;
+    const bool whole_tile = bwd_whole_tile();
     if (!whole_tile && bwd_use_pp(Bp)) return avsi_blstm_rec_bwd_pp_launch(dhout, reserve, whbT, dz, T, Bp, (hipStream_t)stream);
     if (!whole_tile) {
         const size_t lds = (size_t)32 * ZH * 4;

@@ -19,6 +19,7 @@
 // than it -- cell inputs, dz stores -- to stay in flight, and the cell inputs requested just before a fragment have
 // fourteen groups to arrive from HBM before that fragment is waited for (with six groups ahead the kernel spent 20 % of
 // its time in exactly those waits; with the cell's loads switched off it ran at 138 TFLOP/s).
+#include <stdio.h>
 #include <stdlib.h>
 
 #include "avsi_common.h"
@@ -424,12 +425,20 @@ int avsi_blstm_rec_bwd_pp_launch(const float* dhout, const float* reserve, const
                                  hipStream_t st) {
     BwdArgs a{dhout, reserve, whbT, dz, T, Bp};
     const size_t lds = (size_t)32 * ZS * 4;
-    static const int diag = getenv("AVSI_BWD_PP_DIAG") ? atoi(getenv("AVSI_BWD_PP_DIAG")) : 0;
 #define AVSI_PP_LAUNCH(D)                                                                                                  \
     do {                                                                                                                   \
         (void)hipFuncSetAttribute((const void*)blstm_rec_bwd_pp_kernel<D>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
         hipLaunchKernelGGL(blstm_rec_bwd_pp_kernel<D>, dim3((Bp + 63) / 64, 2), dim3(512), lds, st, a);                    \
     } while (0)
+#ifdef AVSI_DIAG_KERNELS
+    // `make EXTRA=-DAVSI_DIAG_KERNELS` only: AVSI_BWD_PP_DIAG selects variants with parts of the work taken out (HISTORY.md
+    // 4.3g) -- their results are WRONG by design, so the production library does not contain them
+    const int diag = getenv("AVSI_BWD_PP_DIAG") ? atoi(getenv("AVSI_BWD_PP_DIAG")) : 0;
+    static bool warned = false;
+    if (diag && !warned) {
+        warned = true;
+        fprintf(stderr, "avsi: AVSI_BWD_PP_DIAG=%d -- a diagnostic BPTT variant is active, its results are not valid\n", diag);
+    }
     switch (diag) {
         case 4096: AVSI_PP_LAUNCH(4096); break;
         case 1: AVSI_PP_LAUNCH(1); break;
@@ -454,6 +463,9 @@ int avsi_blstm_rec_bwd_pp_launch(const float* dhout, const float* reserve, const
         case 22: AVSI_PP_LAUNCH(22); break;
         default: AVSI_PP_LAUNCH(0); break;
     }
+#else
+    AVSI_PP_LAUNCH(0);
+#endif
 #undef AVSI_PP_LAUNCH
     return avsi_launch_status();
 }

@@ -126,7 +126,7 @@ __global__ __launch_bounds__(512, 2) void blstm_rec_fwd_coop_kernel(const CoopAr
     if (group >= a.ngroups) return;
     // behind a launch that gave up a bounded wait every result is void (sticky status word): leave at once instead of
     // waiting out the time bound on step counters that launch may have left behind
-    if (__hip_atomic_load(a.sync, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return;
+    if (avsi_launch_is_void(a.sync)) return;
     const int dir = group & 1;
     const int b0 = (a.tile0 + (group >> 1)) * 32;
     const int T = a.T, Bp = a.Bp;
@@ -297,7 +297,7 @@ __global__ __launch_bounds__(512, 2) void blstm_rec_fwd_coop_fine_kernel(const C
     if (group >= a.ngroups) return;
     // behind a launch that gave up a bounded wait every result is void (sticky status word): leave at once instead of
     // waiting out the time bound on step counters that launch may have left behind
-    if (__hip_atomic_load(a.sync, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return;
+    if (avsi_launch_is_void(a.sync)) return;
     const int dir = group & 1;
     const int b0 = (a.tile0 + (group >> 1)) * 32;
     const int T = a.T, Bp = a.Bp;
@@ -617,7 +617,7 @@ __global__ __launch_bounds__(512, 2) void blstm_rec_bwd_coop_kernel(const CoopBw
     if (group >= a.ngroups) return;
     // behind a launch that gave up a bounded wait every result is void (sticky status word): leave at once instead of
     // waiting out the time bound on step counters that launch may have left behind
-    if (__hip_atomic_load(a.sync, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return;
+    if (avsi_launch_is_void(a.sync)) return;
     const int dir = group & 1;
     const int b0 = (a.tile0 + (group >> 1)) * 32;
     const int T = a.T, Bp = a.Bp;
@@ -763,7 +763,7 @@ __global__ __launch_bounds__(512, 2) void blstm_rec_bwd_coop_fine_kernel(const C
     if (group >= a.ngroups) return;
     // behind a launch that gave up a bounded wait every result is void (sticky status word): leave at once instead of
     // waiting out the time bound on step counters that launch may have left behind
-    if (__hip_atomic_load(a.sync, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return;
+    if (avsi_launch_is_void(a.sync)) return;
     const int dir = group & 1;
     const int b0 = (a.tile0 + (group >> 1)) * 32 + half * 16;
     const int T = a.T, Bp = a.Bp;

@@ -75,7 +75,7 @@ __global__ __launch_bounds__(512, 4) void blstm_rec_fwd_cs_kernel(const CsArgs a
     if (lgroup >= a.ngroups) return;
     // behind a launch that gave up a bounded wait every result is void (sticky status word): leave at once instead of
     // waiting out the time bound on step counters that launch may have left behind
-    if (__hip_atomic_load(a.sync, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return;
+    if (avsi_launch_is_void(a.sync)) return;
     const int group = a.group0 + lgroup;
     const int dir = group & 1;
     const int b0 = (group >> 1) * ROWS;

@@ -638,12 +638,14 @@ def adam_tf(param, grad, m, v, step, lr, beta1=0.9, beta2=0.999, eps=1e-8, grad_
                                                    _lib.stream_ptr()), "avsi_adam_tf_guarded_f32")
 
 
-def step_guard(loss, out, device=None):
+def step_guard(loss, out, device=None, coop=True):
     """out[0:2] <- [NaN unless `loss` (one-element device tensor, or None) is finite, 1 if a cooperative recurrent launch
-    issued so far on the device has given up a bounded wait else 0] (avsi_step_guard_f32), on the current stream."""
+    issued so far on the device has given up a bounded wait else 0] (avsi_step_guard_f32), on the current stream.
+    ``coop=False``: a model that launches no cooperative kernel (the U-Net) -- word 1 is 0 whatever an earlier BLSTM
+    model of this process left in the sticky status words; a stale timeout there must not void its steps."""
     _lib.require_cuda(loss, out)
     idx = out.device.index
-    flags = [ws for (dev, _), ws in _COOP_WS.items() if dev == idx]
+    flags = [ws for (dev, _), ws in _COOP_WS.items() if dev == idx] if coop else []
     if len(flags) > 2:
         flags = [coop_status(out.device)]
     a = flags[0] if flags else None

@@ -159,6 +159,16 @@ def train(config_file, checkpoint_format=None):
     variable names, readable by tf.train.Saver (also selectable with AVSI_CHECKPOINT_FORMAT).
     Restoring (``model_ckp``) accepts either format.
     """
+    polls = ops.COOP_POLL_RAISES
+    try:
+        return _train(config_file, checkpoint_format)
+    finally:
+        # whatever way the loop is left (return, sys.exit of the NaN abort, an exception): the host-side polls of the
+        # cooperative kernels raise again for whoever uses this process next
+        ops.COOP_POLL_RAISES = polls
+
+
+def _train(config_file, checkpoint_format):
     checkpoint_format = checkpoint_format or os.environ.get('AVSI_CHECKPOINT_FORMAT', 'npz')
     if checkpoint_format not in ('npz', 'tf'):
         raise ValueError("checkpoint_format must be 'npz' or 'tf', got %r" % (checkpoint_format,))
@@ -321,17 +331,19 @@ def train(config_file, checkpoint_format=None):
 
     def validate(feed):
         """The reference's validation fetch for one batch (training_emb.py:312-327).  A cooperative-kernel timeout
-        here costs the batch one repetition on the batch-stationary kernels (no collective runs inside this loop, so
-        a rank may fall back alone)."""
+        here costs the batch a repetition one level down (first the cooperative kernels that tolerate neighbours, then
+        the batch-stationary ones, which cannot time out: the third attempt always returns).  No collective runs inside
+        this loop, so a rank falls back alone and never leaves its peers waiting in the all-reduce of the validation
+        means behind it; the levels of the ranks may then differ -- they choose kernels, not results."""
         nonlocal coop_fallbacks
-        for attempt in (0, 1):
+        while True:
             model.set_dropout_rate(0.0)                             # training_emb.py:314,326
             model.feed(**feed)
             try:
                 return resolve(fetch(False))
             except ops.CoopTimeout:
-                if attempt:
-                    raise
+                if ops.coop_level() >= 2:
+                    raise                       # no cooperative kernel is left to have timed out: not a residency matter
                 ops.coop_fall_back(device)
                 coop_fallbacks += 1
 
@@ -408,13 +420,23 @@ def train(config_file, checkpoint_format=None):
             batch-stationary kernels IN THIS PROCESS, take the skipped steps' counts back and repeat their batches.
             All ranks read the same summed guard words, so all of them arrive here at the same step."""
             nonlocal coop_fallbacks
-            ops.coop_fall_back(device)
-            coop_fallbacks += 1
-            for item in items:
-                model.variables.rewind_step()
-            for item in items:
-                launch(item)
-                book(item)
+            counted = len(items)                # steps whose optimiser count is ahead of the variables
+            while True:
+                if ops.coop_level() >= 2:
+                    raise ops.CoopTimeout(ops._COOP_MSG)      # batch-stationary already: not a residency matter
+                ops.coop_fall_back(device)
+                coop_fallbacks += 1
+                for _ in range(counted):
+                    model.variables.rewind_step()
+                try:
+                    # one at a time: level 1 can still time out, and a void step takes every step enqueued behind it along
+                    while items:
+                        launch(items[0])
+                        book(items[0])
+                        items.pop(0)
+                    return
+                except ops.CoopTimeout:
+                    counted = 1                 # the step just launched: counted, not applied, still first in `items`
 
         def settle(keep):
             """Book the steps in flight, oldest first, until at most `keep` are left."""
@@ -520,7 +542,6 @@ def train(config_file, checkpoint_format=None):
     if timing is not None and timing[3]:
         print('host ms per training iteration: next batch %.2f, launches of the step + its scalars %.2f, wait for the step '
               'before %.2f' % tuple(1e3 * t / timing[3] for t in timing[:3]), file=sys.stderr)
-    ops.COOP_POLL_RAISES = True
     model.coop_fallbacks = coop_fallbacks
     if prev_stream is not None:
         torch.cuda.current_stream(device).synchronize()

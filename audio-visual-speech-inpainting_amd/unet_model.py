@@ -585,7 +585,7 @@ class UNetFConvModel(object):
         if c.get('guard') is not None:
             return c['guard']
         self._loss()
-        return ops.step_guard(c['loss3'][0:1], torch.empty(2, device=self.device))
+        return ops.step_guard(c['loss3'][0:1], torch.empty(2, device=self.device), coop=False)
 
     @property
     def nonfinite_flag(self):
@@ -613,12 +613,12 @@ class UNetFConvModel(object):
             # finite": NaN survives the sum): see StackedBLSTMModel.step_guard
             gf = self._buf('grads+guard', (self.layout.ref_size + 2,))
             gf[:-2].copy_(g)
-            ops.step_guard(c['loss3'][0:1], gf[-2:])
+            ops.step_guard(c['loss3'][0:1], gf[-2:], coop=False)
             parallel.all_reduce_sum_(gf)
             g = gf[:-2]
             c['guard'] = gf[-2:].clone()
         else:
-            c['guard'] = ops.step_guard(c['loss3'][0:1], torch.empty(2, device=self.device))
+            c['guard'] = ops.step_guard(c['loss3'][0:1], torch.empty(2, device=self.device), coop=False)
         step = v.global_step + 1
         if self.optimizer_choice != 'adam':
             print('Optimizer must be adam on the MI355X U-Net path. Closing...')

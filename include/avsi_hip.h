@@ -318,6 +318,10 @@ int avsi_gemm_splitk_f32(int transA, int transB, int M, int N, int K, float alph
  * ------------------------------------------------------------------------------------ */
 int avsi_blstm_rec_bwd_f32(const float* dhout, const float* reserve, const float* whbT, float* dz,
                            int T, int Bp, void* stream);
+/* Host-only: the name of the kernel avsi_blstm_rec_bwd_f32 launches for a padded batch of Bp utterances under the current
+ * environment (AVSI_BWD_PP, AVSI_BWD_KH) -- "blstm_rec_bwd_pp_kernel", "blstm_rec_bwd_kh_kernel" or "blstm_rec_bwd_kernel" --
+ * so that a profile or a bench line names what actually ran.  A static string, never null. */
+const char* avsi_blstm_rec_bwd_kernel_name(int Bp);
 
 /* ------------------------------------------------------------------------------------
  * Memory-bound helpers.

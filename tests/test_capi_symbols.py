@@ -35,9 +35,14 @@ def test_ctypes_prototypes_cover_header(built_lib):
 
 
 def test_abi_version_and_status_strings(built_lib):
-    assert built_lib.avsi_abi_version() == 10
+    assert built_lib.avsi_abi_version() == 11
     assert built_lib.avsi_status_string(0) == b"ok"
     assert b"unsupported" in built_lib.avsi_status_string(-2)
+    import ctypes
+    built_lib.avsi_blstm_rec_bwd_kernel_name.restype = ctypes.c_char_p
+    if not os.environ.get("AVSI_BWD_PP") and not os.environ.get("AVSI_BWD_KH"):
+        assert built_lib.avsi_blstm_rec_bwd_kernel_name(8192) == b"blstm_rec_bwd_pp_kernel"      # 4096 < Bp <= 8192
+        assert built_lib.avsi_blstm_rec_bwd_kernel_name(4096) == b"blstm_rec_bwd_kh_kernel"
 
 
 def test_table_size_query_is_host_only(built_lib):

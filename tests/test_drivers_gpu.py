@@ -376,3 +376,42 @@ def test_non_finite_loss_on_one_rank_stops_every_rank(experiment, tmp_path):
     assert 'GOT INSTABILITY: loss is NaN. Leaving...' in run.stdout
     assert 'GOT INSTABILITY on another rank: loss is not finite there. Leaving...' in run.stdout
     assert (tmp_path / "exit_rank0").read_text() == "1" and (tmp_path / "exit_rank1").read_text() == "1"
+
+
+def test_training_survives_two_fall_backs_in_a_row_and_restores_the_polls(experiment, tmp_path, monkeypatch, capsys):
+    """A step whose guard reports a cooperative timeout, and whose repetition one level down reports one AGAIN (level 1
+    kernels can still time out), ends on the batch-stationary kernels: train() goes on, counts every batch once, and
+    leaves ops.COOP_POLL_RAISES as it found it -- also when the loop is left by the NaN abort's sys.exit.
+    (The guard words are faked on the host here: the device did apply the updates, so only the counts are checked.)"""
+    from avsi_amd import ops, training
+    base, data, cfg0 = experiment
+    exp = tmp_path / "logs" / "twice"
+    text = open(cfg0).read().replace("exp_folder = %s" % (base / "logs" / "av_exp0"), "exp_folder = %s" % exp)
+    cfg = tmp_path / "twice.config"
+    cfg.write_text(text.replace("max_n_epochs = 3", "max_n_epochs = 1"))
+    ops.coop_fall_back_reset()
+    plain_get = training._LateScalars.get
+    state = {'n': 0}
+
+    def faulty(handle):
+        vals = plain_get(handle)
+        state['n'] += 1
+        if state['n'] in (2, 3):            # the second step, and its first repetition
+            vals[-1] = 1.0
+        return vals
+    monkeypatch.setattr(training._LateScalars, 'get', staticmethod(faulty))
+    try:
+        model = training.train(str(cfg))
+        assert model.coop_fallbacks == 2 and ops.coop_level() == 2
+        assert model.global_step == 3                      # 12 clips in batches of 4, one epoch: no batch lost, none twice
+        assert ops.COOP_POLL_RAISES is True
+        err = capsys.readouterr().err
+        assert 'the cooperative kernels that tolerate neighbours' in err and 'the batch-stationary recurrent kernels' in err
+        # a third timeout at level 2 is not a residency matter any more: it surfaces
+        state['n'] = -100
+        monkeypatch.setattr(training._LateScalars, 'get', staticmethod(lambda h: plain_get(h)[:-1] + [1.0]))
+        with pytest.raises(ops.CoopTimeout):
+            training.train(str(cfg))
+        assert ops.COOP_POLL_RAISES is True
+    finally:
+        ops.coop_fall_back_reset()
