@@ -116,6 +116,12 @@ PROTOTYPES = {
                                 c_void_p]),
     "avsi_bn_act_bwd_f32": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
                                     c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "avsi_conv2d_thin_mfma_wgrad_supported": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int]),
+    "avsi_conv2d_thin_mfma_wgrad_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int, c_int, c_int]),
+    "avsi_conv2d_thin_mfma_wgrad_f32": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p,
+                                                c_int, c_int, c_void_p, c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "avsi_bn_act_pool_bwd_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p,
+                                         c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "avsi_maxpool2_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "avsi_maxpool2_bwd_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "avsi_spectrogram_f32": (c_int, [c_void_p, c_void_p, c_int64, c_float, c_int, c_float, c_void_p]),

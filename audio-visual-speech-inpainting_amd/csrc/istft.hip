@@ -64,8 +64,10 @@ __global__ void istft_tables_kernel(float* tab, int frame_len, int hop) {
 // MODE / HAS_MASK are compile-time so that the 16 frames' loads of a tile are straight-line code: with the mode
 // tested at run time each frame's loads sat in their own blocks, closed by s_waitcnt vmcnt(0) -- sixteen memory
 // latencies in a row per tile.
-template <int MODE, bool HAS_MASK>
-__global__ __launch_bounds__(TPB) void istft_kernel(const avsi_istft_args a, const int tiles_per_utt, const int n_tiles,
+// OCC3: built for three waves per SIMD (<= 168 registers); LATE (mode 3): the prediction / mask loads of a tile are issued
+// behind the forward transform instead of in front of it (32 registers less across the transform; other waves cover the latency)
+template <int MODE, bool HAS_MASK, bool OCC3 = true, bool LATE = false>
+__global__ __launch_bounds__(TPB, OCC3 ? 3 : 2) void istft_kernel(const avsi_istft_args a, const int tiles_per_utt, const int n_tiles,
                                                     const int n_hops, const int step) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     // s_x (spectrum tile) and s_z (FFT transposition scratch) share storage: s_x is dead once every lane has
@@ -73,10 +75,14 @@ __global__ __launch_bounds__(TPB) void istft_kernel(const avsi_istft_args a, con
     // is 59 KB per workgroup instead of 100 KB: two workgroups per CU.
     cf* s_x = reinterpret_cast<cf*>(smem);                             // [FR][XS]   spectrum tile
     cf* s_z = s_x;                                                     // [FR][ZSTRIDE] FFT scratch (aliases s_x)
-    float* s_f = reinterpret_cast<float*>(s_x + FR * ZSTRIDE);         // [FR][fs]   windowed frames
+    // round 5: the windowed frames share that storage too -- they are written from registers after the last read of s_z
+    // (the barrier in front of the second FFT) and are dead before the next tile writes s_x / s_z (the barrier behind the
+    // overlap-add).  35 KB per workgroup (48 KB in mode 3, whose samples need a place of their own while s_z is written)
+    // instead of 59: THREE workgroups per CU, and the kernel is bound by vector-instruction issue at two waves per SIMD.
+    float* s_f = reinterpret_cast<float*>(s_x);                        // [FR][fs]   windowed frames (aliases s_x / s_z)
     __shared__ float2 s_tw[16][16];                                    // per-lane twiddles of the 16 x 16 FFT: [k2][lane]
     __shared__ float2 s_awin[MODE == 3 ? 16 : 1][16];                  // mode 3: analysis window [n2][lane] (samples 2 ln + 32 n2 ..)
-    float* s_wav = s_f;                                                // mode 3: the tile's samples (dead before s_f is written)
+    float* s_wav = reinterpret_cast<float*>(s_x + FR * ZSTRIDE);       // mode 3: the tile's samples, behind the shared storage
 
     const int tid = threadIdx.x, f = tid >> 4, ln = tid & 15;
     const int S = a.hop, L = a.frame_len, T = a.num_frames, F = a.num_bins;
@@ -188,20 +194,23 @@ __global__ __launch_bounds__(TPB) void istft_kernel(const avsi_istft_args a, con
                     }
                 }
             }
-#pragma unroll
-            for (int ff = 0; ff < FR; ++ff) {
-                // BRANCH-FREE: a load inside a per-lane `if` is closed by the compiler with s_waitcnt vmcnt(0) -- the 16
-                // frames were fetched one memory latency after the other.  Out-of-range lanes read element (0, 0)
-                // of the utterance instead; their value is never used (the select below).
-                const int t = t0 + ff;
-                const bool ok = kok && t >= 0 && t < T;
-                r0[ff] = r1[ff] = r2[ff] = 0.f, r3[ff] = 1.f;
-                fetch(b, ok ? t : 0, ok ? k : 0, r0[ff], r1[ff], r2[ff], r3[ff]);
-            }
             float q0 = 0.f, q1 = 0.f, q2 = 0.f, q3 = 1.f;     // the Nyquist column: one frame per thread (tid < FR)
             const int tn = t0 + (tid & (FR - 1)), kn = 256 / step;
             const bool nok = tid < FR && (256 % step == 0) && kn < F && tn >= 0 && tn < T;
-            if (tid < FR) fetch(b, nok ? tn : 0, nok ? kn : 0, q0, q1, q2, q3);
+            auto fetch_tile = [&]() {
+#pragma unroll
+                for (int ff = 0; ff < FR; ++ff) {
+                    // BRANCH-FREE: a load inside a per-lane `if` is closed by the compiler with s_waitcnt vmcnt(0) -- the 16
+                    // frames were fetched one memory latency after the other.  Out-of-range lanes read element (0, 0)
+                    // of the utterance instead; their value is never used (the select below).
+                    const int t = t0 + ff;
+                    const bool ok = kok && t >= 0 && t < T;
+                    r0[ff] = r1[ff] = r2[ff] = 0.f, r3[ff] = 1.f;
+                    fetch(b, ok ? t : 0, ok ? k : 0, r0[ff], r1[ff], r2[ff], r3[ff]);
+                }
+                if (tid < FR) fetch(b, nok ? tn : 0, nok ? kn : 0, q0, q1, q2, q3);
+            };
+            if (!(MODE == 3 && LATE)) fetch_tile();
             if (MODE == 3) {
                 // ---- 1b. forward transform of the 16 frames (frontend.hip steps 2 - 4: window, 16 x 16 FFT of
                 //          z[n] = x[2n] + j x[2n+1], natural-order Z with Z[256] := Z[0]); one frame per 16-lane group
@@ -237,6 +246,7 @@ __global__ __launch_bounds__(TPB) void istft_kernel(const avsi_istft_args a, con
                 for (int k1 = 0; k1 < 16; ++k1) zf[16 * k1 + ln] = v[pos16(k1)];
                 if (ln == 0) zf[256] = v[pos16(0)];
                 AVSI_LDS_BARRIER();
+                if (LATE) fetch_tile();
                 // ---- 1c. thread <-> bin: S[k] = E[k] + W512^k O[k] from Z[k] and Z[256 - k] (frontend.hip step 5)
                 const float2 wk = *reinterpret_cast<const float2*>(tab + TAB_TW512 + 2 * kk);
 #pragma unroll
@@ -366,25 +376,37 @@ extern "C" int avsi_istft_f32(const avsi_istft_args* args, void* stream) {
     const int tiles_per_utt = (int)avsi_ceil_div(n_hops, FR - 1);
     const int64_t n_tiles64 = (int64_t)a.batch * tiles_per_utt;
     if (n_tiles64 > INT32_MAX) return AVSI_ERR_UNSUPPORTED;
-    size_t lds_f = (size_t)FR * ((a.frame_len + 3) & ~3) * 4;
-    if (a.mode == 3 && lds_f < (size_t)((FR - 1) * a.hop + a.frame_len + 32) * 4)      // the samples of a tile share the frames' storage
-        lds_f = (size_t)((FR - 1) * a.hop + a.frame_len + 32) * 4;
-    const size_t lds = (size_t)FR * ZSTRIDE * 8 + lds_f;     // ZSTRIDE >= XS: shared storage
+    // spectrum tile, FFT scratch and windowed frames share one region (ZSTRIDE >= XS; 16 frames of <= 512 floats fit in it);
+    // mode 3 keeps the tile's samples behind it
+    size_t lds = (size_t)FR * ZSTRIDE * 8;
+    if (lds < (size_t)FR * ((a.frame_len + 3) & ~3) * 4) return AVSI_ERR_UNSUPPORTED;
+    if (a.mode == 3) lds += (size_t)((FR - 1) * a.hop + a.frame_len + 32) * 4;
     const int n_tiles = (int)n_tiles64;
-    const int grid = n_tiles < AVSI_NUM_CU * 2 ? n_tiles : AVSI_NUM_CU * 2;
+    // A/B switches of round 5 (mode 3): AVSI_ISTFT_OCC = 2 | 3 waves per SIMD the kernel is built for, AVSI_ISTFT_LATE = 0 | 1
+    static const int occ = getenv("AVSI_ISTFT_OCC") ? atoi(getenv("AVSI_ISTFT_OCC")) : 3;
+    static const int late = getenv("AVSI_ISTFT_LATE") ? atoi(getenv("AVSI_ISTFT_LATE")) : 0;
+    const int per_cu = (a.mode == 3 && occ == 2) ? 2 : 3;    // workgroups per CU: 35 - 48 KB of LDS, <= 168 registers
+    const int grid = n_tiles < AVSI_NUM_CU * per_cu ? n_tiles : AVSI_NUM_CU * per_cu;
     avsi_clear_error();
-#define AVSI_ISTFT_LAUNCH(MV, HM)                                                                                       \
+#define AVSI_ISTFT_LAUNCH(...)                                                                                          \
     do {                                                                                                                \
-        (void)hipFuncSetAttribute((const void*)istft_kernel<MV, HM>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-        hipLaunchKernelGGL((istft_kernel<MV, HM>), dim3(grid), dim3(TPB), lds, (hipStream_t)stream, a, tiles_per_utt, n_tiles, \
+        (void)hipFuncSetAttribute((const void*)istft_kernel<__VA_ARGS__>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        hipLaunchKernelGGL((istft_kernel<__VA_ARGS__>), dim3(grid), dim3(TPB), lds, (hipStream_t)stream, a, tiles_per_utt, n_tiles, \
                            n_hops, step);                                                                               \
     } while (0)
     if (a.mode == 0) AVSI_ISTFT_LAUNCH(0, false);
     else if (a.mode == 1) AVSI_ISTFT_LAUNCH(1, false);
     else if (a.mode == 2 && a.in2) AVSI_ISTFT_LAUNCH(2, true);
     else if (a.mode == 2) AVSI_ISTFT_LAUNCH(2, false);
-    else if (a.in2) AVSI_ISTFT_LAUNCH(3, true);
-    else AVSI_ISTFT_LAUNCH(3, false);
+    else if (a.in2) {
+        if (occ == 2 && late) AVSI_ISTFT_LAUNCH(3, true, false, true);
+        else if (occ == 2) AVSI_ISTFT_LAUNCH(3, true, false, false);
+        else if (late) AVSI_ISTFT_LAUNCH(3, true, true, true);
+        else AVSI_ISTFT_LAUNCH(3, true, true, false);
+    } else {
+        if (occ == 2) AVSI_ISTFT_LAUNCH(3, false, false, false);
+        else AVSI_ISTFT_LAUNCH(3, false, true, false);
+    }
 #undef AVSI_ISTFT_LAUNCH
     return avsi_launch_status();
 }

@@ -375,6 +375,137 @@ __global__ __launch_bounds__(256) void thin_mfma_conv_kernel(const float* __rest
     }
 }
 
+// Filter gradient of the few-channel layers on the 16-wide MFMA (round 5): dW[(tap, c)][n] = sum over pixels of
+// in(p + off(tap), c) dY[p][n].  As a split-K implicit GEMM (gemm_dma_kernel<true, ..., 32>) the three thin layers gathered
+// every input value once PER TAP through the DMA -- 3.6 GB for 29 GFLOP at the 16 + 32 -> 16 layer -- and ran at 30 - 57
+// TFLOP/s: 2.8 of 17 ms per training step at 512 clips.  Here the tile's input patch goes through LDS once (the staging of
+// thin_mfma_conv_kernel: same 4 x 32-pixel tiles, same patch, the next tile's prefetched into registers) next to the
+// tile's dY; the (tap, 16-channel group) pairs are dealt to the four waves, and a pair's 16 x COUT block of dW is
+// v_mfma_f32_16x16x4_f32 accumulators that live in registers over ALL the tiles of the (persistent) workgroup:
+//   A[row = channel l % 16][k = pixel l / 16]  -- one ds_read_b32 from the patch at the tap's offset,
+//   B[k = pixel l / 16][col = output channel l % 16] -- one from the dY tile, shared by all pairs of the wave,
+//   D[row = channel 4 (l / 16) + i][col = output channel l % 16].
+// One partial filter per workgroup in `part` [gridDim.x][KS^2 CT][COUT]; the caller sums them in order (deterministic).
+template <int KS, int C0, int C1, int COUT>
+__global__ __launch_bounds__(256) void thin_mfma_wgrad_kernel(const float* __restrict__ s0, int ld0, const float* __restrict__ s1,
+                                                              int ld1, const float* __restrict__ dy, int ldy,
+                                                              float* __restrict__ part, int H, int W,
+                                                              const float* __restrict__ zeros, const int n_tiles) {
+    constexpr int P = KS / 2, CT = C0 + C1, CP = CT + 1, TH = 4, TW = 32, PH = TH + KS - 1, PWD = TW + KS - 1;
+    constexpr int NCG = COUT / 16, MCG = CT / 16, CQ = CT / 4, DP = COUT + 1;
+    constexpr int ITEMS = PH * PWD * CQ, NPRE = (ITEMS + 255) / 256;       // float4 items of a patch, per thread
+    constexpr int DITEMS = TH * TW * (COUT / 4), NDY = DITEMS / 256;       // float4 items of the dY tile, per thread
+    constexpr int NT = KS * KS * MCG, TPW = (NT + 3) / 4;                  // (tap, channel group) pairs, per wave
+    static_assert(DITEMS % 256 == 0 && CT % 16 == 0 && COUT % 16 == 0, "tile shapes");
+    extern __shared__ __attribute__((aligned(16))) float smem_f[];
+    float* patch = smem_f;                           // [PH][PWD][CP]
+    float* dyt = smem_f + PH * PWD * CP;             // [TH * TW][DP]
+    const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tiles_w = W / TW, tiles_img = tiles_w * (H / TH);
+    const int H2 = H >> 1, W2 = W >> 1;
+    float4 pre[NPRE], dpre[NDY];
+    auto fetch = [&](int tile) {
+        const int b = tile / tiles_img, tl = tile - b * tiles_img;
+        const int h0 = (tl / tiles_w) * TH, w0 = (tl - (tl / tiles_w) * tiles_w) * TW;
+#pragma unroll
+        for (int j = 0; j < NPRE; ++j) {
+            const int i = tid + 256 * j;
+            const int ic = i < ITEMS ? i : 0;                     // (threads past the last item re-read item 0: never stored)
+            const int pix = ic / CQ, c4 = (ic - pix * CQ) * 4;
+            const int pr = pix / PWD, pc = pix - pr * PWD;
+            const int hh = h0 + pr - P, ww = w0 + pc - P;
+            const bool ok = hh >= 0 && hh < H && ww >= 0 && ww < W;
+            const float* src = zeros;                             // pixels outside the image read a page of zeros
+            if (ok) {
+                if (c4 < C0) src = s0 + (((int64_t)b * H + hh) * W + ww) * ld0 + c4;
+                else src = s1 + (((int64_t)b * H2 + (hh >> 1)) * W2 + (ww >> 1)) * ld1 + (c4 - C0);
+            }
+            pre[j] = *reinterpret_cast<const float4*>(src);
+        }
+#pragma unroll
+        for (int j = 0; j < NDY; ++j) {
+            const int i = tid + 256 * j;
+            const int pix = i / (COUT / 4), q = i - pix * (COUT / 4);
+            const int r = pix / TW, c = pix - r * TW;
+            dpre[j] = *reinterpret_cast<const float4*>(dy + (((int64_t)b * H + h0 + r) * W + w0 + c) * ldy + 4 * q);
+        }
+    };
+    const int px = lane & 15, kq = lane >> 4;
+    typedef float f32x4v __attribute__((ext_vector_type(4)));
+    f32x4v acc[TPW][NCG];
+    int aoff[TPW];                                   // patch offset of pair j of this wave: its tap and channel group
+#pragma unroll
+    for (int j = 0; j < TPW; ++j) {
+        const int t = wv * TPW + j, tc = t < NT ? t : 0;
+        const int tap = tc / MCG, cg = tc - tap * MCG;
+        const int dh = tap / KS, dw = tap - dh * KS;
+        aoff[j] = (dh * PWD + dw) * CP + 16 * cg;
+#pragma unroll
+        for (int n = 0; n < NCG; ++n) acc[j][n] = (f32x4v){0.f, 0.f, 0.f, 0.f};
+    }
+    if ((int)blockIdx.x < n_tiles) fetch(blockIdx.x);
+    for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+#pragma unroll
+        for (int j = 0; j < NPRE; ++j) {
+            const int i = tid + 256 * j;
+            if (i < ITEMS) {
+                const int pix = i / CQ, c4 = (i - pix * CQ) * 4;
+                float* d = patch + pix * CP + c4;
+                d[0] = pre[j].x, d[1] = pre[j].y, d[2] = pre[j].z, d[3] = pre[j].w;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < NDY; ++j) {
+            const int i = tid + 256 * j;
+            const int pix = i / (COUT / 4), q = i - pix * (COUT / 4);
+            float* d = dyt + pix * DP + 4 * q;
+            d[0] = dpre[j].x, d[1] = dpre[j].y, d[2] = dpre[j].z, d[3] = dpre[j].w;
+        }
+        AVSI_LDS_BARRIER();
+        if (tile + (int)gridDim.x < n_tiles) fetch(tile + gridDim.x);      // in flight during the MFMAs below
+        // Straight-line over the 32 k-steps of the tile, the fragments of step kk + 1 read while the MFMAs of step kk run
+        // (first version: a branch, a read and s_waitcnt lgkmcnt(0) in front of EVERY MFMA -- 35 TFLOP/s).  A wave whose
+        // last slot has no pair (NT is no multiple of 4) accumulates pair 0 once more there and never stores it.
+        const float* pa0 = patch + kq * CP + px;
+        const float* pb0 = dyt + kq * DP + px;
+        float af[2][TPW], bf[2][NCG];
+#pragma unroll
+        for (int n = 0; n < NCG; ++n) bf[0][n] = pb0[16 * n];
+#pragma unroll
+        for (int j = 0; j < TPW; ++j) af[0][j] = pa0[aoff[j]];
+#pragma unroll
+        for (int kk = 0; kk < TH * TW / 4; ++kk) {
+            constexpr int KSTEPS = TH * TW / 4;
+            const int cur = kk & 1, nxt = cur ^ 1;
+            if (kk + 1 < KSTEPS) {
+                const int r = (kk + 1) >> 3, c = ((kk + 1) & 7) << 2;      // compile-time: the loop is unrolled
+#pragma unroll
+                for (int n = 0; n < NCG; ++n) bf[nxt][n] = pb0[(r * TW + c) * DP + 16 * n];
+#pragma unroll
+                for (int j = 0; j < TPW; ++j) af[nxt][j] = pa0[(r * PWD + c) * CP + aoff[j]];
+            }
+#pragma unroll
+            for (int j = 0; j < TPW; ++j)
+#pragma unroll
+                for (int n = 0; n < NCG; ++n)
+                    acc[j][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[cur][j], bf[cur][n], acc[j][n], 0, 0, 0);
+        }
+        AVSI_LDS_BARRIER();                              // every wave is done reading the patch and the dY tile
+    }
+    float* prow = part + (int64_t)blockIdx.x * (KS * KS * CT * COUT);
+#pragma unroll
+    for (int j = 0; j < TPW; ++j) {
+        const int t = wv * TPW + j;
+        if (t < NT) {
+            const int tap = t / MCG, cg = t - tap * MCG;
+#pragma unroll
+            for (int n = 0; n < NCG; ++n)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) prow[(tap * CT + 16 * cg + 4 * kq + i) * COUT + 16 * n + px] = acc[j][n][i];
+        }
+    }
+}
+
 template <int K, int C0, int C1, int COUT>
 __global__ __launch_bounds__(TPB) void direct_conv_kernel(const float* __restrict__ s0, int ld0, const float* __restrict__ s1,
                                                           int ld1, const float* __restrict__ filt, int ldf,
@@ -969,6 +1100,108 @@ __global__ __launch_bounds__(TPB) void bn_act_bwd_apply_kernel(const BnArgs a, c
     }
 }
 
+// Backward of an ENCODER layer in one piece: act(bn(conv)) was max-pooled 2 x 2 (bn_act4_kernel<true>), and the gradient
+// arrives for the POOLED output.  The full-resolution activation and its gradient are never materialised: a thread takes
+// four channels of one pooled pixel, recomputes the four activations of its window from `conv` exactly as the forward
+// pass did (bn_act_one: the same bits, so the same first-maximum-wins choice as maxpool2_bwd_kernel), and routes the
+// pooled gradient to that pixel.
+//   APPLY = false: partial sums (sum g, sum g xhat) over the thread's pixels -> part [parts][2][C]   (d beta, d gamma)
+//   APPLY = true : dx = gamma rstd (g - sum_g / N - xhat sum_gx / N) for the four pixels (without batch norm: dx = g), and
+//                  the partial column sums of dx -> part [parts][2][C] (row 0; the bias gradient of a layer without batch norm)
+// Replaces maxpool2_bwd + colpair_partial<1> + bn_act_bwd_apply + the column sum, which between them read the activation
+// once, wrote and read its gradient three times and read dx once more: 1.0 of 19 ms per training step at 512 clips.
+template <bool APPLY>
+__global__ __launch_bounds__(TPB) void bn_act_pool_bwd_kernel(const BnArgs a, int B, int H, int W,
+                                                              const float* __restrict__ sum_g,
+                                                              const float* __restrict__ sum_gx, float* __restrict__ dx,
+                                                              float* __restrict__ part) {
+    __shared__ float red[2][TPB * 4];
+    const int q4 = a.ld >> 2;
+    const int rp = TPB / q4;
+    const int cq = threadIdx.x % q4, rl = threadIdx.x / q4;
+    const int H2 = H >> 1, W2 = W >> 1;
+    const int64_t P = (int64_t)B * H2 * W2;                 // pooled pixels
+    const int64_t chunk = (P + gridDim.y - 1) / gridDim.y;
+    const int64_t p0 = (int64_t)blockIdx.y * chunk, p1 = min(P, p0 + chunk);
+    const float invn = 1.f / (float)a.R;
+    float sc[4], sh[4], mu[4], rs[4], ga[4], be[4], mg[4], mgx[4];
+    bool live[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int c = 4 * cq + k;
+        live[k] = c < a.C;
+        sc[k] = live[k] ? 1.f : 0.f, sh[k] = 0.f, mu[k] = 0.f, rs[k] = 1.f, ga[k] = 1.f, be[k] = 0.f, mg[k] = 0.f, mgx[k] = 0.f;
+        if (a.has_bn && live[k]) {
+            mu[k] = a.mean[c], rs[k] = a.rstd[c], ga[k] = a.gamma[c], be[k] = a.beta[c];
+            sc[k] = ga[k] * rs[k];
+            sh[k] = be[k] - mu[k] * sc[k];
+            if (APPLY) mg[k] = sum_g[c] * invn, mgx[k] = sum_gx[c] * invn;
+        }
+    }
+    float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+    if (rl < rp) {
+        for (int64_t pix = p0 + rl; pix < p1; pix += rp) {
+            const int w2 = (int)(pix % W2);
+            const int64_t bh = pix / W2;
+            const int h2 = (int)(bh % H2);
+            const int64_t b = bh / H2;
+            const int64_t o00 = ((b * H + 2 * h2) * W + 2 * w2) * a.ld + 4 * cq;
+            const int64_t offs[4] = {0, a.ld, (int64_t)W * a.ld, (int64_t)W * a.ld + a.ld};
+            float4 in4[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) in4[q] = *reinterpret_cast<const float4*>(a.x + o00 + offs[q]);
+            const float4 d4 = *reinterpret_cast<const float4*>(a.dy + pix * a.ld + 4 * cq);
+            const float d[4] = {d4.x, d4.y, d4.z, d4.w};
+            float out[4][4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float xv[4] = {(&in4[0].x)[k], (&in4[1].x)[k], (&in4[2].x)[k], (&in4[3].x)[k]};
+                int best = 0;
+                float bv = bn_act_one(xv[0], sc[k], sh[k], a.act);
+#pragma unroll
+                for (int q = 1; q < 4; ++q) {
+                    const float y = bn_act_one(xv[q], sc[k], sh[k], a.act);
+                    if (y > bv) bv = y, best = q;           // first maximum in row-major window order wins ties
+                }
+                const float xb = best == 0 ? xv[0] : (best == 1 ? xv[1] : (best == 2 ? xv[2] : xv[3]));
+                const float xhb = (xb - mu[k]) * rs[k];
+                const float g = live[k] ? d[k] * act_grad(a.has_bn ? ga[k] * xhb + be[k] : xb, a.act) : 0.f;
+                if (!APPLY) {
+                    s1[k] += g, s2[k] += g * xhb;
+                } else {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const float gq = q == best ? g : 0.f;
+                        float v = gq;
+                        if (a.has_bn) v = live[k] ? sc[k] * (gq - mg[k] - (xv[q] - mu[k]) * rs[k] * mgx[k]) : 0.f;
+                        out[q][k] = v;
+                        s1[k] += v;
+                    }
+                }
+            }
+            if (APPLY) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    *reinterpret_cast<float4*>(dx + o00 + offs[q]) = make_float4(out[q][0], out[q][1], out[q][2], out[q][3]);
+            }
+        }
+    }
+    if (!part) return;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) red[0][threadIdx.x * 4 + k] = s1[k], red[1][threadIdx.x * 4 + k] = s2[k];
+    __syncthreads();
+    const int c = threadIdx.x;
+    if (c < a.C) {
+        float t1 = 0.f, t2 = 0.f;
+        for (int j = 0; j < rp; ++j) {
+            const int src = (j * q4 + (c >> 2)) * 4 + (c & 3);
+            t1 += red[0][src], t2 += red[1][src];
+        }
+        part[((int64_t)blockIdx.y * 2 + 0) * a.C + c] = t1;
+        part[((int64_t)blockIdx.y * 2 + 1) * a.C + c] = t2;
+    }
+}
+
 __global__ __launch_bounds__(TPB) void maxpool2_kernel(const float* __restrict__ x, float* __restrict__ y, int B, int H,
                                                        int W, int C, int ld) {
     const int H2 = H >> 1, W2 = W >> 1;
@@ -1171,6 +1404,59 @@ extern "C" int avsi_conv2d_thin_wgrad_f32(const float* src0, int C0, int ld0, co
     return AVSI_OK;
 }
 
+// Filter gradient on the 16-wide MFMA (thin_mfma_wgrad_kernel): the U-Net's three few-channel layers with batch norm,
+// (k, C0, C1, Cout) = (3, 16, 32, 16), (5, 16, 0, 32), (3, 32, 64, 32); H % 4 == 0, W % 32 == 0.
+extern "C" int avsi_conv2d_thin_mfma_wgrad_supported(int k, int C0, int C1, int Cout, int H, int W) {
+    return (H % 4 == 0 && W % 32 == 0) && ((k == 3 && C0 == 16 && C1 == 32 && Cout == 16) ||
+                                           (k == 5 && C0 == 16 && C1 == 0 && Cout == 32) ||
+                                           (k == 3 && C0 == 32 && C1 == 64 && Cout == 32));
+}
+
+static int thin_mfma_wgrad_blocks(int k, int C0, int C1, int n_tiles) {
+    // LDS per workgroup: 23 / 35 KB (two per CU), 96 KB for the 96-channel layer (one per CU)
+    const int per_cu = (C0 + C1 > 48) ? 1 : 2;
+    return n_tiles < per_cu * AVSI_NUM_CU ? n_tiles : per_cu * AVSI_NUM_CU;
+}
+
+extern "C" size_t avsi_conv2d_thin_mfma_wgrad_workspace_bytes(int C0, int C1, int k, int Cout, int B, int H, int W) {
+    if (B <= 0 || H <= 0 || W <= 0) return 0;
+    return (size_t)thin_mfma_wgrad_blocks(k, C0, C1, B * (H / 4) * (W / 32)) * (size_t)(k * k * (C0 + C1) * Cout) * sizeof(float);
+}
+
+extern "C" int avsi_conv2d_thin_mfma_wgrad_f32(const float* src0, int C0, int ld0, const float* src1_coarse, int C1, int ld1, int B,
+                                               int H, int W, int k, const float* dy, int ldy, int Cout, float* dw, int ldw,
+                                               const float* zeros64, void* workspace, size_t workspace_bytes, void* stream) {
+    if (!src0 || !dy || !dw || !zeros64 || B <= 0 || H <= 0 || W <= 0 || (C1 && !src1_coarse) || ldy < Cout || ld0 < C0 ||
+        (C1 && ld1 < C1))
+        return AVSI_ERR_INVALID_ARG;
+    if (!avsi_conv2d_thin_mfma_wgrad_supported(k, C0, C1, Cout, H, W) || ldw != Cout || (ld0 & 3) || (ld1 & 3) || (ldy & 3) ||
+        ((reinterpret_cast<uintptr_t>(src0) | reinterpret_cast<uintptr_t>(src1_coarse) | reinterpret_cast<uintptr_t>(dy) |
+          reinterpret_cast<uintptr_t>(zeros64) | reinterpret_cast<uintptr_t>(dw)) & 15))
+        return AVSI_ERR_UNSUPPORTED;
+    if (!workspace || workspace_bytes < avsi_conv2d_thin_mfma_wgrad_workspace_bytes(C0, C1, k, Cout, B, H, W)) return AVSI_ERR_WORKSPACE;
+    const int n_tiles = B * (H / 4) * (W / 32);
+    const int blocks = thin_mfma_wgrad_blocks(k, C0, C1, n_tiles);
+    const int na = k * k * (C0 + C1) * Cout;
+    const hipStream_t st = (hipStream_t)stream;
+    float* part = (float*)workspace;
+    avsi_clear_error();
+#define AVSI_THIN_WGRAD(KS, CA, CB, CO)                                                                                        \
+    do {                                                                                                                      \
+        constexpr size_t lds = ((size_t)(4 + KS - 1) * (32 + KS - 1) * (CA + CB + 1) + (size_t)128 * (CO + 1)) * 4;           \
+        (void)hipFuncSetAttribute((const void*)thin_mfma_wgrad_kernel<KS, CA, CB, CO>,                                         \
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                                       \
+        hipLaunchKernelGGL((thin_mfma_wgrad_kernel<KS, CA, CB, CO>), dim3(blocks), dim3(256), lds, st, src0, ld0, src1_coarse, \
+                           ld1, dy, ldy, part, H, W, zeros64, n_tiles);                                                       \
+    } while (0)
+    if (k == 3 && C0 == 16) AVSI_THIN_WGRAD(3, 16, 32, 16);
+    else if (k == 5) AVSI_THIN_WGRAD(5, 16, 0, 32);
+    else AVSI_THIN_WGRAD(3, 32, 64, 32);
+#undef AVSI_THIN_WGRAD
+    const int rc = avsi_launch_status();
+    if (rc != AVSI_OK) return rc;
+    return avsi_sum_slabs_launch(part, na, blocks, na, dw, 1.f, st);
+}
+
 extern "C" int avsi_conv2d_thin_dx_coarse_f32(const float* dy, int ldy, const float* filter, int ldf, float* dsrc1_coarse, int ld1,
                                               int accumulate, int B, int H, int W, void* stream) {
     if (!dy || !filter || !dsrc1_coarse || B <= 0 || H <= 0 || W <= 0 || ldy < 1 || ldf < 1 || ld1 < 16) return AVSI_ERR_INVALID_ARG;
@@ -1213,7 +1499,7 @@ extern "C" int avsi_col2im_f32(const float* dcol, int Kc, float* dsrc0, int C0, 
     return avsi_launch_status();
 }
 
-extern "C" size_t avsi_unet_workspace_bytes(int C) { return (size_t)MAXPARTS * 2 * (size_t)C * sizeof(float); }
+extern "C" size_t avsi_unet_workspace_bytes(int C) { return ((size_t)MAXPARTS * 2 + 1) * (size_t)C * sizeof(float); }
 
 extern "C" int avsi_colstats_f32(const float* x, int64_t R, int C, int ld, float eps, float* mean, float* rstd,
                                  void* workspace, size_t workspace_bytes, void* stream) {
@@ -1422,6 +1708,37 @@ extern "C" int avsi_bn_act_bwd_f32(const float* x, const float* dy, int64_t R, i
                            (const float*)workspace, parts, C, R, 0.f, dbeta, dgamma);
     }
     hipLaunchKernelGGL(bn_act_bwd_apply_kernel, dim3(grid_for(R * ld)), dim3(TPB), 0, st, a, dbeta, dgamma, dx);
+    return avsi_launch_status();
+}
+
+extern "C" int avsi_bn_act_pool_bwd_f32(const float* x, const float* dpooled, int B, int H, int W, int C, int ld,
+                                        const float* mean, const float* rstd, const float* gamma, const float* beta, int act,
+                                        float* dx, float* dgamma, float* dbeta, float* dbias, void* workspace,
+                                        size_t workspace_bytes, void* stream) {
+    if (!x || !dpooled || !dx || B <= 0 || H <= 0 || W <= 0 || ((H | W) & 1) || C <= 0 || ld < C || act < 0 || act > 3)
+        return AVSI_ERR_INVALID_ARG;
+    const int has_bn = mean != nullptr;
+    if (has_bn && (!rstd || !gamma || !beta || !dgamma || !dbeta)) return AVSI_ERR_INVALID_ARG;
+    if ((ld & 3) || ld > 256 ||
+        ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(dpooled) | reinterpret_cast<uintptr_t>(dx)) & 15))
+        return AVSI_ERR_UNSUPPORTED;
+    if ((has_bn || dbias) && (!workspace || workspace_bytes < avsi_unet_workspace_bytes(C))) return AVSI_ERR_WORKSPACE;
+    const int64_t R = (int64_t)B * H * W;
+    BnArgs a{x, dpooled, mean, rstd, gamma, beta, R, C, ld, act, has_bn};
+    const hipStream_t st = (hipStream_t)stream;
+    const int parts = parts_for(R / 4);
+    float* part = (float*)workspace;
+    avsi_clear_error();
+    if (has_bn) {
+        hipLaunchKernelGGL(bn_act_pool_bwd_kernel<false>, dim3(1, parts), dim3(TPB), 0, st, a, B, H, W, (const float*)nullptr,
+                           (const float*)nullptr, (float*)nullptr, part);
+        hipLaunchKernelGGL(colpair_final_kernel<1>, dim3(C), dim3(64), 0, st, (const float*)part, parts, C, R, 0.f, dbeta, dgamma);
+    }
+    hipLaunchKernelGGL(bn_act_pool_bwd_kernel<true>, dim3(1, parts), dim3(TPB), 0, st, a, B, H, W, (const float*)dbeta,
+                       (const float*)dgamma, dx, dbias ? part : (float*)nullptr);
+    if (dbias)   // column sums of dx; the second row of the pairs is zero and lands behind the first in the workspace
+        hipLaunchKernelGGL(colpair_final_kernel<1>, dim3(C), dim3(64), 0, st, (const float*)part, parts, C, R, 0.f, dbias,
+                           part + (size_t)parts * 2 * C);
     return avsi_launch_status();
 }
 

@@ -429,8 +429,18 @@ class StackedBLSTMModel(object):
             tgt = self.target_spec_norm
             mask = self.masks[:, :T].contiguous()
             rs_bm = row_scale[:, :B].t().contiguous()
-            out3, dlog = ops.l1_loss_blend(tgt, pred, mask, rs_bm, want_grad=keep)
+            out3, dlog, inv_gap = ops.l1_loss_blend(tgt, pred, mask, rs_bm, want_grad=keep)
             c['loss3'] = torch.stack([out3[1], out3[1], out3[2]])
+            if keep and parallel.dp_active():
+                # Data parallel: the objective is the ratio of GLOBAL sums, sum_r num_r / sum_r gap_r, and its
+                # gradient sum_r d num_r / G.  The kernel left d num_r / gap_r; with the ranks' gap element counts summed (one
+                # float, on the device) each rank rescales by gap_r * world / G, and the 1 / world of the fused Adam over the
+                # summed buckets gives exactly the single-process gradient of the global batch -- whatever the ranks' shares
+                # of the gap frames (tests/test_dp_gpu.py::test_two_ranks_with_unequal_gaps_train_the_global_loss_hole)
+                gap = 1.0 / inv_gap
+                total = parallel.all_reduce_sum_(gap.clone())
+                dlog.mul_(gap * float(parallel.world_size()) / total)
+                c['hole_sums'] = (out3[1] * gap, gap, total)          # num_r, gap_r, G: loss_hole_global
             c['dpred'] = dlog
             self._extra_loss(keep)
 
@@ -496,6 +506,21 @@ class StackedBLSTMModel(object):
     def loss_valid(self):
         self._loss()
         return self._cache['loss3'][2]
+
+    @property
+    def loss_hole_global(self):
+        """loss_hole of the GLOBAL batch of a data-parallel step: sum over ranks of sum|err|(1 - m) over sum over ranks of
+        sum(1 - m), numerator and denominator all-reduced separately.  Equal to loss_hole in a single process."""
+        self._loss()
+        c = self._cache
+        if not parallel.dp_active():
+            return c['loss3'][1]
+        if 'hole_sums' in c:
+            num, gap, total = c['hole_sums']
+            return parallel.all_reduce_sum_(num.clone().reshape(1))[0] / total.reshape(-1)[0]
+        gap = (1.0 - self.masks[:, :self._dims()[1]]).sum().reshape(1)
+        both = parallel.all_reduce_sum_(torch.cat([c['loss3'][1:2] * gap, gap]))
+        return both[0] / both[1]
 
     @property
     def reg_loss(self):

@@ -444,7 +444,8 @@ def l1_loss(target, pred, mask, want_grad=False, grad_scale=None):
 
 def l1_loss_blend(target, pred_inout, mask, row_scale=None, want_grad=False):
     """Speaker-embedding variants: blends the known bins into ``pred_inout`` IN PLACE
-    (seq_mask * logits -> prediction) and returns (out3, dlogits) for loss_func = loss_hole."""
+    (seq_mask * logits -> prediction) and returns (out3, dlogits, 1 / sum(1 - mask) as a one-element device tensor) for
+    loss_func = loss_hole."""
     _lib.require_cuda(target, pred_inout, mask)
     L = _lib.lib()
     for x in (target, pred_inout, mask):
@@ -467,7 +468,7 @@ def l1_loss_blend(target, pred_inout, mask, row_scale=None, want_grad=False):
     _lib.check(L.avsi_l1_loss_blend_f32(_lib.ptr(target), _lib.ptr(pred_inout), _lib.ptr(mask), _lib.ptr(row_scale),
                                         row_len, n, _lib.ptr(out4), _lib.ptr(dlog), _lib.ptr(ws), ws.numel() * 4,
                                         _lib.stream_ptr()), "avsi_l1_loss_blend_f32")
-    return out4[:3], dlog
+    return out4[:3], dlog, out4[3:4]
 
 
 _CTC_WS = {}
@@ -819,6 +820,26 @@ def conv2d_wgrad(src0, c0, src1, c1, B, H, W, k, dy, cout, dw, splits):
     return dw
 
 
+def conv2d_thin_mfma_wgrad_supported(k, c0, c1, cout, H, W, dw=None):
+    return bool(_lib.lib().avsi_conv2d_thin_mfma_wgrad_supported(k, c0, c1, cout, H, W)) and (dw is None or dw.stride(0) == cout) \
+        and os.environ.get('AVSI_THIN_MFMA_WGRAD', '1') != '0'
+
+
+def conv2d_thin_mfma_wgrad(src0, c0, src1, c1, B, H, W, k, dy, cout, dw):
+    """Filter gradient of a few-channel layer on the 16-wide MFMA (avsi_conv2d_thin_mfma_wgrad_f32)."""
+    _lib.require_cuda(src0, src1, dy, dw)
+    L = _lib.lib()
+    z = _ZEROS.get(dw.device.index)
+    if z is None:
+        z = _ZEROS[dw.device.index] = torch.zeros(64, dtype=torch.float32, device=dw.device)
+    ws = _workspace(dw.device, L.avsi_conv2d_thin_mfma_wgrad_workspace_bytes(c0, c1, k, cout, B, H, W))
+    _lib.check(L.avsi_conv2d_thin_mfma_wgrad_f32(_lib.ptr(src0), c0, src0.stride(0), _lib.ptr(src1), c1,
+                                                 src1.stride(0) if src1 is not None else 0, B, H, W, k, _lib.ptr(dy), dy.stride(0),
+                                                 cout, _lib.ptr(dw), dw.stride(0), _lib.ptr(z), _lib.ptr(ws), ws.numel() * 4,
+                                                 _lib.stream_ptr()), "avsi_conv2d_thin_mfma_wgrad_f32")
+    return dw
+
+
 def conv2d_thin_wgrad(src0, c0, src1, c1, B, H, W, k, dy, cout, dw):
     """Direct filter gradient of a thin layer (avsi_conv2d_thin_wgrad_f32)."""
     _lib.require_cuda(src0, src1, dy, dw)
@@ -895,6 +916,20 @@ def bn_act_bwd(x, dy, C, dx, mean=None, rstd=None, gamma=None, beta=None, act=0,
                                      _lib.ptr(rstd), _lib.ptr(gamma), _lib.ptr(beta), int(act), _lib.ptr(dx),
                                      _lib.ptr(dgamma), _lib.ptr(dbeta), _lib.ptr(ws), ws.numel() * 4,
                                      _lib.stream_ptr()), "avsi_bn_act_bwd_f32")
+    return dx
+
+
+def bn_act_pool_bwd(x, dpooled, B, H, W, C, dx, mean=None, rstd=None, gamma=None, beta=None, act=0, dgamma=None, dbeta=None,
+                    dbias=None):
+    """Backward of bn_act_pool from the POOLED gradient (avsi_bn_act_pool_bwd_f32): dx, and dgamma / dbeta (batch norm) or
+    dbias (no batch norm).  The full-resolution activation and its gradient are not needed."""
+    _lib.require_cuda(x, dpooled, dx)
+    L = _lib.lib()
+    ws = _workspace(x.device, L.avsi_unet_workspace_bytes(C))
+    _lib.check(L.avsi_bn_act_pool_bwd_f32(_lib.ptr(x), _lib.ptr(dpooled), B, H, W, C, x.stride(0), _lib.ptr(mean), _lib.ptr(rstd),
+                                          _lib.ptr(gamma), _lib.ptr(beta), int(act), _lib.ptr(dx), _lib.ptr(dgamma),
+                                          _lib.ptr(dbeta), _lib.ptr(dbias), _lib.ptr(ws), ws.numel() * 4, _lib.stream_ptr()),
+               "avsi_bn_act_pool_bwd_f32")
     return dx
 
 

@@ -7,9 +7,12 @@ overlap with the backward pass (StackedBLSTMModel._backward).
 The loss is a mean over B*T*F, so summing per-rank gradients and dividing by the world size
 reproduces the single-GPU gradient of the global batch when ranks hold equal batches of equal padded
 length -- the plain a / v / av models on fixed-length clips, which is what BASELINE config 4 trains.
-It is an APPROXIMATION (a mean of per-rank ratios instead of the ratio of global sums) for the variants whose
-objective is ``loss_hole = sum|err|(1-m) / sum(1-m)`` (-ssnn / -emb / -ctc: the denominator is per rank) and for
-ragged batches (T = the rank's own longest clip); ranks then weigh equally, not by their gap frames.
+The variants whose objective is ``loss_hole = sum|err|(1-m) / sum(1-m)`` (-ssnn / -emb / -ctc) all-reduce the
+denominator -- the ranks' gap element counts, one float before the backward pass -- and rescale their gradient by
+``gap_r * world / G``, so the summed buckets divided by the world size are the gradient of the GLOBAL ratio of sums
+whatever the ranks' shares of the gap frames (``model.loss_hole_global`` reports that ratio).  What stays an
+approximation: ragged batches of the plain models (T = the rank's own longest clip, so the ranks' means are over
+different element counts; the ranks then weigh equally) -- knowing the global count would cost a host round trip per step.
 ``model.gradients`` is the LOCAL gradient before ``train_op`` and the world-SUM (not yet divided) after it.
 """
 import os

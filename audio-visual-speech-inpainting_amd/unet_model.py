@@ -358,7 +358,9 @@ class UNetFConvModel(object):
             st = (self._buf(name + '/mean', (ld,)), self._buf(name + '/rstd', (ld,)))
             ops.colstats(conv, cout, st[0], st[1])
         bn_args = (*(st or (None, None)), v.p(name + '/bn/gamma') if bn else None, v.p(name + '/bn/beta') if bn else None)
-        y = self._buf(name + '/act', (R, ld)) if (keep or not pool) else None
+        # (pooled layers: the backward pass recomputes the window's activations from `conv`, ops.bn_act_pool_bwd -- the
+        # full-resolution activation is not written in training either)
+        y = self._buf(name + '/act', (R, ld)) if not pool else None
         if pool:
             ops.bn_act_pool(conv, B, H, W, cout, pooled, y, *bn_args, act)
         elif not bn and act == 0 and not keep:
@@ -480,16 +482,26 @@ class UNetFConvModel(object):
         return self.loss_func + self.regularization * self.reg_loss if self.regularization else self.loss_func
 
     # ------------------------------------------------------------------ gradients / optimiser
-    def _conv_bwd(self, name, dy, gp, dsrc0, acc0, dsrc1, acc1):
+    def _conv_bwd(self, name, dy, gp, dsrc0, acc0, dsrc1, acc1, pooled=False):
+        """``pooled``: `dy` is the gradient of the layer's 2 x 2 max-POOLED output (encoder layers): pooling, activation
+        and batch norm go backwards in one kernel pair that recomputes the window from the convolution output."""
         s, v, lay = self._cache['saved'][name], self.variables, self.layout
         R, kc, ld, cout = s['B'] * s['H'] * s['W'], s['kc'], s['ld'], s['cout']
         dconv = self._buf(name + '/dconv', (R, ld))
         st = s['stats'] or (None, None)
-        ops.bn_act_bwd(s['conv'], dy, cout, dconv, st[0], st[1], v.p(name + '/bn/gamma') if s['bn'] else None,
-                       v.p(name + '/bn/beta') if s['bn'] else None, s['act'],
-                       lay.gpacked_view(gp, name + '/bn/gamma') if s['bn'] else None,
-                       lay.gpacked_view(gp, name + '/bn/beta') if s['bn'] else None)
-        ops.colsum(dconv, lay.gpacked_view(gp, name + '/b'), m=R, n=ld)
+        bn_args = (st[0], st[1], v.p(name + '/bn/gamma') if s['bn'] else None, v.p(name + '/bn/beta') if s['bn'] else None,
+                   s['act'], lay.gpacked_view(gp, name + '/bn/gamma') if s['bn'] else None,
+                   lay.gpacked_view(gp, name + '/bn/beta') if s['bn'] else None)
+        # The bias gradient, sum of dconv over the pixels: under batch norm dconv = gamma rstd (g - mean g - xhat mean(g xhat))
+        # sums to zero identically (the normalisation removes any bias), so it IS zero -- the buffer's zeros stay; a column
+        # sum would return rounding noise (13 passes over the gradients per step).  Layers without batch norm (e1, out) sum.
+        if pooled:
+            ops.bn_act_pool_bwd(s['conv'], dy, s['B'], s['H'], s['W'], cout, dconv, *bn_args,
+                                dbias=None if s['bn'] else lay.gpacked_view(gp, name + '/b'))
+        else:
+            ops.bn_act_bwd(s['conv'], dy, cout, dconv, *bn_args)
+            if not s['bn']:
+                ops.colsum(dconv, lay.gpacked_view(gp, name + '/b'), m=R, n=ld)
         # reduction slabs: enough workgroups (output tiles x slabs ~ 1024) even when the filter is one 128 x 128 tile
         tiles = -(-kc // 128) * -(-ld // 128)
         splits = max(1, min(R // 2048, max(64, 1024 // tiles)))
@@ -504,7 +516,11 @@ class UNetFConvModel(object):
             if dsrc1 is not None:
                 ops.conv2d_thin_dx_coarse(dconv, v.p(name + '/w'), dsrc1, acc1, s['B'], s['H'], s['W'])
             return
-        if implicit_w:
+        dwv = lay.gpacked_view(gp, name + '/w')
+        if ops.conv2d_thin_mfma_wgrad_supported(s['k'], s['c0'], s['c1'], cout, s['H'], s['W'], dwv):
+            # few channels at high resolution: patch + dY through LDS once, the filter gradient in MFMA accumulators
+            ops.conv2d_thin_mfma_wgrad(s['src0'], s['c0'], s['src1'], s['c1'], s['B'], s['H'], s['W'], s['k'], dconv, cout, dwv)
+        elif implicit_w:
             ops.conv2d_wgrad(s['src0'], s['c0'], s['src1'], s['c1'], s['B'], s['H'], s['W'], s['k'], dconv, cout,
                              lay.gpacked_view(gp, name + '/w'), splits)
         else:
@@ -553,7 +569,7 @@ class UNetFConvModel(object):
         gp = self._buf('gpacked', (lay.gpacked_size,))
         dlog = self._buf('dlog', (B * T * F, 4))
         dlog[:, 0] = (c['dpred'] * c['rowmask'][:, :, None]).reshape(-1)
-        g = {n: self._buf(n + '/dy', saved[n]['y'].shape) for n in saved}       # d loss / d activated output
+        g = {n: self._buf(n + '/dy', saved[n]['y'].shape) for n in saved if saved[n]['y'] is not None}   # d loss / d activated output (decoder)
         gpool = {n: self._buf(n + '/dpool', c['pool'][n].shape) for n in c['pool']}  # d loss / d pooled encoder outputs
         self._conv_bwd('out', dlog, gp, g['d6'], False, None, False)
         prev = None
@@ -565,10 +581,8 @@ class UNetFConvModel(object):
             self._conv_bwd(name, g[name], gp, dsrc0, False, coarse, False)
         for i in range(5, -1, -1):                                      # e6 .. e1
             name = 'e%d' % (i + 1)
-            s = saved[name]
-            ops.maxpool2_bwd(s['y'], gpool[name], g[name], s['B'], s['H'], s['W'], s['cout'])
             dsrc0 = gpool['e%d' % i] if i >= 1 else None                 # e(i) pooled output also fed a decoder: accumulate
-            self._conv_bwd(name, g[name], gp, dsrc0, True, None, False)
+            self._conv_bwd(name, gpool[name], gp, dsrc0, True, None, False, pooled=True)
         grads = self.variables.unpack_grads(gp, out=self._buf('grads', (lay.ref_size,)))
         c['grads'] = grads
         return grads

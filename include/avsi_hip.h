@@ -573,6 +573,15 @@ int avsi_conv2d_thin_mfma_supported(int k, int C0, int C1, int Cout, int H, int 
 int avsi_conv2d_thin_mfma_f32(const float* src0, int C0, int ld0, const float* src1_coarse, int C1, int ld1, int B, int H, int W,
                               int k, const float* filter, int ldf, const float* bias, int Cout, float* out, int ldo,
                               const float* zeros64, void* stream);
+/* Filter gradient of the same few-channel layers (and of the 32 + 64 -> 32 decoder layer) on the 16-wide MFMA: the tile's
+ * input patch and its dY go through LDS once, the filter gradient accumulates in registers over all the tiles of a workgroup,
+ * one partial filter per workgroup in the workspace, summed in order (deterministic).  dw [k*k*(C0+C1)][Cout], ldw == Cout.
+ * Same results as avsi_conv2d_wgrad_f32 up to summation order (reference: tf.gradients of unet_layers.py:11,31). */
+int avsi_conv2d_thin_mfma_wgrad_supported(int k, int C0, int C1, int Cout, int H, int W);
+size_t avsi_conv2d_thin_mfma_wgrad_workspace_bytes(int C0, int C1, int k, int Cout, int B, int H, int W);
+int avsi_conv2d_thin_mfma_wgrad_f32(const float* src0, int C0, int ld0, const float* src1_coarse, int C1, int ld1, int B, int H,
+                                    int W, int k, const float* dy, int ldy, int Cout, float* dw, int ldw, const float* zeros64,
+                                    void* workspace, size_t workspace_bytes, void* stream);
 /* The first encoder layer at inference: 7 x 7 convolution of the one-channel input, bias, ReLU and 2 x 2 max pooling
  * fused (the full-resolution 16-channel activation is never written). */
 int avsi_conv2d_thin_relu_pool_f32(const float* src0, int ld0, int B, int H, int W, int k, const float* filter, int ldf,
@@ -582,6 +591,16 @@ int avsi_bn_act_f32(const float* x, int64_t R, int C, int ld, const float* mean,
 int avsi_bn_act_bwd_f32(const float* x, const float* dy, int64_t R, int C, int ld, const float* mean,
                         const float* rstd, const float* gamma, const float* beta, int act, float* dx,
                         float* dgamma, float* dbeta, void* workspace, size_t workspace_bytes, void* stream);
+/* Backward of an encoder layer whose activation act(bn(x)) was max-pooled 2 x 2 (avsi_bn_act_pool_f32; reference
+ * unet_layers.py:6-20 + models.py:592-597 under tf.gradients): dpooled [B][H/2][W/2][ld] is the gradient of the POOLED output,
+ * x [B][H][W][ld] the convolution output.  The window's activations are recomputed from x (same arithmetic as the forward
+ * pass, first maximum wins ties), so neither the full-resolution activation nor its gradient exists in memory:
+ *   dx = d loss / d x; dgamma, dbeta as avsi_bn_act_bwd_f32 (mean == null: no batch norm, dx = routed gradient * act');
+ *   dbias (optional) = column sums of dx, the bias gradient of a layer without batch norm.
+ * workspace: avsi_unet_workspace_bytes(C).  ld % 4 == 0, ld <= 256, 16-byte aligned operands. */
+int avsi_bn_act_pool_bwd_f32(const float* x, const float* dpooled, int B, int H, int W, int C, int ld, const float* mean,
+                             const float* rstd, const float* gamma, const float* beta, int act, float* dx, float* dgamma,
+                             float* dbeta, float* dbias, void* workspace, size_t workspace_bytes, void* stream);
 int avsi_maxpool2_f32(const float* x, float* y, int B, int H, int W, int C, int ld, void* stream);
 int avsi_maxpool2_bwd_f32(const float* x, const float* dy, float* dx, int B, int H, int W, int C, int ld, void* stream);
 

@@ -52,8 +52,51 @@ def run(rank, world, steps, B_global=4, N=2880):
     return m.variables.flat.cpu().numpy(), losses
 
 
+def run_variant(rank, world, steps, B_global=4, N=2880):
+    """The external-embedding variant (objective loss_hole = sum|err|(1-m) / sum(1-m)) on a batch whose gap frames are
+    spread UNEVENLY over the ranks' shards: utterance b has a gap of 2 + 3 b frames.  Returns the variables, the per-step
+    local loss_hole and the per-step loss_hole_global."""
+    import avsi_amd  # noqa: F401
+    from avsi_amd import ops
+    from avsi_amd.model_variants import StackedBLSTMEmbeddingModel
+    wav, masks, video, mean, std, T = make_inputs(B_global, N)
+    masks[:] = 1
+    for b in range(B_global):
+        masks[b, 1: 3 + 3 * b] = 0
+    emb = np.random.default_rng(9).normal(size=(B_global, 512)).astype(np.float32)
+    per = B_global // world
+    sl = slice(rank * per, (rank + 1) * per)
+    cfg = dict(config(N, per), integration_layer=1)
+    m = StackedBLSTMEmbeddingModel(np.full(per, T), wav[sl], masks[sl], mean, std, 0.0, cfg, video_features=video[sl],
+                                   embeddings=emb[sl], input='av', seed=7)
+    local, glob = [], []
+    for _ in range(steps):
+        while True:
+            m.feed(sequence_lengths=np.full(per, T), target_sources=wav[sl], masks=masks[sl], video_features=video[sl])
+            m.feed_embeddings(emb[sl])
+            hole, hole_g = float(m.loss_hole), float(m.loss_hole_global)
+            m.train_op
+            if float(m.step_guard[1]) == 0.0:
+                break
+            ops.coop_fall_back()
+            m.variables.rewind_step()
+        local.append(hole)
+        glob.append(hole_g)
+    return m.variables.flat.cpu().numpy(), local, glob
+
+
 if __name__ == '__main__':
     out = sys.argv[1]
+    if len(sys.argv) > 5 and sys.argv[5] == 'emb':
+        from avsi_amd import parallel
+        rank, world = parallel.init()
+        flat, local, glob = run_variant(rank, world, int(sys.argv[4]), int(sys.argv[2]), int(sys.argv[3]))
+        np.save(os.path.join(out, 'flat_rank%d.npy' % rank), flat)
+        np.save(os.path.join(out, 'loss_rank%d.npy' % rank), np.array([local, glob]))
+        import torch.distributed as dist
+        dist.barrier()
+        dist.destroy_process_group()
+        sys.exit(0)
     from avsi_amd import parallel
     rank, world = parallel.init()
     import torch.distributed as dist

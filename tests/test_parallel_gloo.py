@@ -191,3 +191,49 @@ def test_bench_plain_launch_starts_a_child_launcher_and_relays_its_status():
     assert out.returncode != 0
     assert "must be launched with" not in out.stderr
     assert "local_rank: 0" in out.stderr and "local_rank: 1" in out.stderr, out.stderr[-2000:]       # torchrun's failure report
+
+
+def _hole_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    torch.set_num_threads(1)
+    parallel.init(backend="gloo")
+    err, m, w = _hole_problem()
+    lo, hi = parallel.shard_range(len(err), rank, world)
+    wr = w.clone().requires_grad_(True)
+    num = ((err[lo:hi] * wr).abs() * (1 - m[lo:hi])).sum()
+    gap = (1 - m[lo:hi]).sum()
+    (num / gap).backward()                                 # what the loss kernel leaves: d num_r / gap_r
+    # models.StackedBLSTMModel._forward (blend variants): rescale by gap_r * world / G, sum the buckets, 1 / world in Adam
+    total = parallel.all_reduce_sum_(gap.clone().reshape(1))
+    g = wr.grad * (gap * world / total)
+    parallel.all_reduce_sum_(g)
+    g /= world
+    both = parallel.all_reduce_sum_(torch.stack([num.detach(), gap]))
+    if rank == 0:
+        np.savez(out, g=g.numpy(), loss=float(both[0] / both[1]), local=float(num / gap))
+    dist.destroy_process_group()
+
+
+def _hole_problem():
+    gen = torch.Generator().manual_seed(3)
+    err = torch.randn(4, 6, 5, generator=gen, dtype=torch.float64)
+    m = torch.ones(4, 6, 5, dtype=torch.float64)
+    for b, n in enumerate((1, 2, 4, 5)):                   # gap frames per utterance: 3 on rank 0, 9 on rank 1
+        m[b, :n] = 0
+    return err, m, torch.rand(5, generator=gen, dtype=torch.float64) + 0.5
+
+
+def test_loss_hole_objective_is_the_ratio_of_global_sums(tmp_path):
+    """under data parallelism loss_hole's numerator and denominator are summed over the ranks separately.  Two
+    ranks with 3 against 9 gap frames reproduce the single-process gradient and loss of the four utterances; the mean of
+    the ranks' own ratios differs."""
+    out = str(tmp_path / "hole.npz")
+    mp.spawn(_hole_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    got = np.load(out)
+    err, m, w = _hole_problem()
+    wr = w.clone().requires_grad_(True)
+    loss = ((err * wr).abs() * (1 - m)).sum() / (1 - m).sum()
+    loss.backward()
+    np.testing.assert_allclose(got["g"], wr.grad.numpy(), rtol=1e-12)
+    np.testing.assert_allclose(got["loss"], float(loss.detach()), rtol=1e-12)
+    assert abs(float(got["local"]) - float(loss.detach())) > 1e-3 * float(loss.detach())

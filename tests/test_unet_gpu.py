@@ -114,6 +114,57 @@ def test_bn_act_and_pool_kernels(mods):
     np.testing.assert_array_equal(dxp[:, :C].cpu().view(B, H, W, C).permute(0, 3, 1, 2).numpy(), xt.grad.numpy())
 
 
+@pytest.mark.parametrize("C,ld,bn,act", [(6, 8, True, 1), (16, 16, False, 1), (32, 32, True, 2), (128, 128, True, 1)])
+def test_pooled_bn_act_backward_is_the_chain_of_its_parts(mods, C, ld, bn, act):
+    """ops.bn_act_pool_bwd (the encoder layers' backward from the POOLED gradient, window recomputed from the convolution
+    output) against torch autograd in float64 on the same chain: batch norm with batch statistics -> activation -> 2 x 2 max
+    pooling; and against the three kernels it replaces (maxpool2_bwd on the kept activation, bn_act_bwd, colsum)."""
+    models, ops = mods
+    rng = np.random.default_rng(C)
+    B, H, W = 3, 8, 12
+    R = B * H * W
+    x = torch.zeros(R, ld, device='cuda'); x[:, :C] = torch.from_numpy(rng.normal(0.3, 1.5, size=(R, C)).astype(np.float32)).cuda()
+    gamma = torch.zeros(ld, device='cuda'); gamma[:C] = torch.from_numpy(rng.uniform(0.5, 1.5, C).astype(np.float32)).cuda()
+    beta = torch.zeros(ld, device='cuda'); beta[:C] = torch.from_numpy(rng.normal(0, 0.5, size=C).astype(np.float32)).cuda()
+    mean, rstd = torch.empty(ld, device='cuda'), torch.empty(ld, device='cuda')
+    ops.colstats(x, C, mean, rstd)
+    bn_args = (mean, rstd, gamma, beta) if bn else (None, None, None, None)
+    P = R // 4
+    dpool = torch.zeros(P, ld, device='cuda'); dpool[:, :C] = torch.from_numpy(rng.normal(size=(P, C)).astype(np.float32)).cuda()
+    # the fused kernel
+    dx = torch.full((R, ld), 7.0, device='cuda')
+    dg, db, dbias = torch.zeros(ld, device='cuda'), torch.zeros(ld, device='cuda'), torch.zeros(ld, device='cuda')
+    ops.bn_act_pool_bwd(x, dpool, B, H, W, C, dx, *bn_args, act, dg if bn else None, db if bn else None, dbias=None if bn else dbias)
+    # the three kernels it replaces, on the kept activation
+    y, pooled = torch.empty_like(x), torch.empty(P, ld, device='cuda')
+    ops.bn_act_pool(x, B, H, W, C, pooled, y, *bn_args, act)
+    dy = torch.empty_like(x)
+    ops.maxpool2_bwd(y, dpool, dy, B, H, W, C)
+    dx2, dg2, db2 = torch.empty_like(x), torch.zeros(ld, device='cuda'), torch.zeros(ld, device='cuda')
+    ops.bn_act_bwd(x, dy, C, dx2, *bn_args, act, dg2 if bn else None, db2 if bn else None)
+    np.testing.assert_allclose(dx.cpu().numpy(), dx2.cpu().numpy(), atol=1e-5)
+    assert torch.all(dx[:, C:] == 0)
+    if bn:
+        np.testing.assert_allclose(dg[:C].cpu().numpy(), dg2[:C].cpu().numpy(), rtol=1e-4, atol=1e-4)
+        np.testing.assert_allclose(db[:C].cpu().numpy(), db2[:C].cpu().numpy(), rtol=1e-4, atol=1e-4)
+    else:
+        np.testing.assert_allclose(dbias[:C].cpu().numpy(), dx2[:, :C].double().sum(0).cpu().numpy(), rtol=1e-4, atol=1e-4)
+    # torch autograd, float64
+    xt = x[:, :C].double().cpu().view(B, H, W, C).permute(0, 3, 1, 2).clone().requires_grad_(True)
+    g_t, b_t = gamma[:C].double().cpu().requires_grad_(True), beta[:C].double().cpu().requires_grad_(True)
+    z = xt
+    if bn:
+        mu = xt.mean((0, 2, 3), keepdim=True)
+        var = xt.var((0, 2, 3), unbiased=False, keepdim=True)
+        z = g_t.view(1, C, 1, 1) * (xt - mu) / torch.sqrt(var + 1e-3) + b_t.view(1, C, 1, 1)
+    a = torch.relu(z) if act == 1 else torch.nn.functional.leaky_relu(z, 0.2)
+    torch.nn.functional.max_pool2d(a, 2).backward(dpool[:, :C].double().cpu().view(B, H // 2, W // 2, C).permute(0, 3, 1, 2))
+    np.testing.assert_allclose(dx[:, :C].cpu().view(B, H, W, C).permute(0, 3, 1, 2).numpy(), xt.grad.numpy(), atol=3e-5)
+    if bn:
+        np.testing.assert_allclose(dg[:C].cpu().numpy(), g_t.grad.numpy(), rtol=2e-4, atol=1e-3)
+        np.testing.assert_allclose(db[:C].cpu().numpy(), b_t.grad.numpy(), rtol=2e-4, atol=1e-3)
+
+
 @pytest.mark.parametrize("N", [16384, 8192])
 def test_unet_forward_backward_matches_oracle(mods, N):
     """N = 16384 is the reference's own size (scripts/config/unet.config:6): 128 frames x 128 bins (config 5);
@@ -281,6 +332,36 @@ def test_tiled_output_layer_matches_im2col_gemm():
     got = torch.zeros(R, 4, device='cuda')
     ops.conv2d_thin(src0, c0, src1, c1, B, H, W, k, filt, bias, got, cout)
     np.testing.assert_allclose(got[:, :cout].cpu().numpy(), want[:, :cout].cpu().numpy(), rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize("c0,c1,k,cout,B,H,W", [(16, 32, 3, 16, 3, 8, 32), (16, 0, 5, 32, 2, 12, 64), (32, 64, 3, 32, 5, 4, 32),
+                                                (16, 32, 3, 16, 70, 64, 64), (32, 64, 3, 32, 9, 32, 32)])
+def test_thin_mfma_filter_gradient_matches_im2col_gemm(c0, c1, k, cout, B, H, W):
+    """avsi_conv2d_thin_mfma_wgrad_f32 (patch and dY through LDS, filter gradient in 16-wide MFMA accumulators over all the
+    tiles of a persistent workgroup) against the explicit im2col^T . dY product; the larger cases give every workgroup
+    several tiles (B = 70 at 64 x 64: 2240 tiles on 512 workgroups) and put image borders inside a workgroup's walk."""
+    import torch
+    import avsi_amd  # noqa: F401
+    from avsi_amd import ops
+    g = torch.Generator(device='cuda')
+    g.manual_seed(c0 + c1 + k + B)
+    R = B * H * W
+    src0 = torch.randn(R, c0 + 4, generator=g, device='cuda')
+    src1 = torch.randn(B * (H // 2) * (W // 2), c1, generator=g, device='cuda') if c1 else None
+    kc = k * k * (c0 + c1)
+    dy = torch.randn(R, cout, generator=g, device='cuda')
+    col = torch.empty(R, kc, device='cuda')
+    ops.im2col(src0, c0, src1, c1, B, H, W, k, col, kc)
+    want = (col.double().t() @ dy.double()).cpu().numpy()
+    got = torch.full((kc, cout), 3.0, device='cuda')
+    assert ops.conv2d_thin_mfma_wgrad_supported(k, c0, c1, cout, H, W, got)
+    assert not ops.conv2d_thin_mfma_wgrad_supported(k, c0, c1, cout, H, W + 16) and not ops.conv2d_thin_mfma_wgrad_supported(3, 16, 16, 16, H, W)
+    ops.conv2d_thin_mfma_wgrad(src0, c0, src1, c1, B, H, W, k, dy, cout, got)
+    np.testing.assert_allclose(got.cpu().numpy(), want, rtol=2e-4, atol=2e-4 * np.abs(want).max())
+    # the same bits on a second run (fixed order of the partial sums)
+    again = torch.empty_like(got)
+    ops.conv2d_thin_mfma_wgrad(src0, c0, src1, c1, B, H, W, k, dy, cout, again)
+    assert torch.equal(got, again)
 
 
 @pytest.mark.parametrize("c0,c1,k,cout,B,H,W,splits", [(16, 0, 5, 32, 2, 12, 8, 3), (32, 64, 3, 32, 3, 8, 16, 1), (128, 128, 3, 128, 1, 4, 4, 2),
