@@ -116,6 +116,7 @@ PROTOTYPES = {
                                 c_void_p]),
     "avsi_bn_act_bwd_f32": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
                                     c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "avsi_conv2d_thin_mfma_plain_supported": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int]),
     "avsi_conv2d_thin_mfma_wgrad_supported": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int]),
     "avsi_conv2d_thin_mfma_wgrad_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int, c_int, c_int]),
     "avsi_conv2d_thin_mfma_wgrad_f32": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p,

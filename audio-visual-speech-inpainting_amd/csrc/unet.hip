@@ -506,6 +506,82 @@ __global__ __launch_bounds__(256) void thin_mfma_wgrad_kernel(const float* __res
     }
 }
 
+// Filter gradient of the FIRST layer (7 x 7, one input channel -> 16) on the 16-wide MFMA: with one channel the M side of the
+// product is the TAPS -- dW[tap][n] = sum_p x(p + off(tap)) dY[p][n], 49 taps in four groups of 16 (one per wave; the 15 slots
+// past tap 48 multiply by a zero weight and are not stored).  A[row = tap][k = pixel]: every lane gathers its own tap's
+// offset from the 14 x 38 one-channel patch of an 8 x 32-pixel tile; B = the dY tile as in thin_mfma_wgrad_kernel.  The
+// direct form (thin_wgrad_kernel<7, 1, 0, 16>: 784 accumulators per thread, seven workgroup rows) ran at 17 TFLOP/s, 0.78 ms.
+__global__ __launch_bounds__(256) void conv7_c1_wgrad_mfma_kernel(const float* __restrict__ s0, int ld0, const float* __restrict__ dy,
+                                                                 int ldy, float* __restrict__ part, int H, int W,
+                                                                 const int n_tiles) {
+    constexpr int KS = 7, P = 3, TH = 8, TW = 32, PH = TH + KS - 1, PWD = TW + KS - 1, COUT = 16, DP = COUT + 1;
+    constexpr int PITEMS = PH * PWD, NPRE = (PITEMS + 255) / 256, NDY = TH * TW * (COUT / 4) / 256, KSTEPS = TH * TW / 4;
+    __shared__ float patch[PH * PWD + 8];
+    __shared__ float dyt[TH * TW * DP];
+    const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tiles_w = W / TW, tiles_img = tiles_w * (H / TH);
+    float pre[NPRE];
+    float4 dpre[NDY];
+    auto fetch = [&](int tile) {
+        const int b = tile / tiles_img, tl = tile - b * tiles_img;
+        const int h0 = (tl / tiles_w) * TH, w0 = (tl - (tl / tiles_w) * tiles_w) * TW;
+#pragma unroll
+        for (int j = 0; j < NPRE; ++j) {
+            const int i = tid + 256 * j;
+            const int ic = i < PITEMS ? i : 0;
+            const int pr = ic / PWD, pc = ic - pr * PWD;
+            const int hh = h0 + pr - P, ww = w0 + pc - P;
+            const bool ok = hh >= 0 && hh < H && ww >= 0 && ww < W;
+            pre[j] = *(ok ? s0 + (((int64_t)b * H + hh) * W + ww) * ld0 : g_zero_pixel);       // unconditional loads
+        }
+#pragma unroll
+        for (int j = 0; j < NDY; ++j) {
+            const int i = tid + 256 * j;
+            const int pix = i >> 2, q = i & 3;
+            const int r = pix / TW, c = pix - r * TW;
+            dpre[j] = *reinterpret_cast<const float4*>(dy + (((int64_t)b * H + h0 + r) * W + w0 + c) * ldy + 4 * q);
+        }
+    };
+    const int px = lane & 15, kq = lane >> 4;
+    const int tap = 16 * wv + px;
+    const bool live = tap < KS * KS;
+    const int tc = live ? tap : 0;
+    const int toff = (tc / KS) * PWD + (tc % KS) + kq;           // this lane's tap offset + its pixel of a k-step
+    typedef float f32x4v __attribute__((ext_vector_type(4)));
+    f32x4v acc = {0.f, 0.f, 0.f, 0.f};
+    if ((int)blockIdx.x < n_tiles) fetch(blockIdx.x);
+    for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+#pragma unroll
+        for (int j = 0; j < NPRE; ++j) {
+            const int i = tid + 256 * j;
+            if (i < PITEMS) patch[i] = pre[j];
+        }
+#pragma unroll
+        for (int j = 0; j < NDY; ++j) {
+            const int i = tid + 256 * j;
+            float* d = dyt + (i >> 2) * DP + 4 * (i & 3);
+            d[0] = dpre[j].x, d[1] = dpre[j].y, d[2] = dpre[j].z, d[3] = dpre[j].w;
+        }
+        AVSI_LDS_BARRIER();
+        if (tile + (int)gridDim.x < n_tiles) fetch(tile + gridDim.x);
+        const float* pa = patch + toff;
+        const float* pb = dyt + kq * DP + px;
+#pragma unroll
+        for (int kk = 0; kk < KSTEPS; ++kk) {
+            const int r = kk >> 3, c = (kk & 7) << 2;
+            const float a = live ? pa[r * PWD + c] : 0.f;
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a, pb[(r * TW + c) * DP], acc, 0, 0, 0);
+        }
+        AVSI_LDS_BARRIER();
+    }
+    float* prow = part + (int64_t)blockIdx.x * (KS * KS * COUT);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int t = 16 * wv + 4 * kq + i;
+        if (t < KS * KS) prow[t * COUT + px] = acc[i];
+    }
+}
+
 template <int K, int C0, int C1, int COUT>
 __global__ __launch_bounds__(TPB) void direct_conv_kernel(const float* __restrict__ s0, int ld0, const float* __restrict__ s1,
                                                           int ld1, const float* __restrict__ filt, int ldf,
@@ -1140,6 +1216,7 @@ __global__ __launch_bounds__(TPB) void bn_act_pool_bwd_kernel(const BnArgs a, in
     }
     float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
     if (rl < rp) {
+#pragma unroll 2
         for (int64_t pix = p0 + rl; pix < p1; pix += rp) {
             const int w2 = (int)(pix % W2);
             const int64_t bh = pix / W2;
@@ -1379,7 +1456,13 @@ extern "C" int avsi_conv2d_thin_wgrad_f32(const float* src0, int C0, int ld0, co
     const hipStream_t st = (hipStream_t)stream;
     float* part = (float*)workspace;
     avsi_clear_error();
-    if (k == 7 && C0 == 1 && C1 == 0 && Cout == 16)
+    static const bool c7_mfma = !(getenv("AVSI_CONV7_WGRAD_MFMA") && atoi(getenv("AVSI_CONV7_WGRAD_MFMA")) == 0);
+    if (k == 7 && C0 == 1 && C1 == 0 && Cout == 16 && c7_mfma && H % 8 == 0 && W % 32 == 0 && !(ldy & 3) &&
+        !(reinterpret_cast<uintptr_t>(dy) & 15) && B * (H / 8) * (W / 32) >= blocks)
+        // (one partial filter per workgroup, `blocks` of them -- the workspace and the sum below are sized for that)
+        hipLaunchKernelGGL(conv7_c1_wgrad_mfma_kernel, dim3(blocks), dim3(256), 0, st, src0, ld0, dy, ldy, part, H, W,
+                           B * (H / 8) * (W / 32));
+    else if (k == 7 && C0 == 1 && C1 == 0 && Cout == 16)
         hipLaunchKernelGGL((thin_wgrad_kernel<7, 1, 0, 16>), dim3(blocks, 7), dim3(TPB), 0, st, src0, ld0, src1_coarse, ld1, dy, ldy,
                            part, B, H, W);
     else if (k == 3 && C0 == 1 && C1 == 16 && Cout == 1)
@@ -1552,6 +1635,14 @@ extern "C" int avsi_conv2d_thin_mfma_supported(int k, int C0, int C1, int Cout, 
     return (H % 4 == 0 && W % 32 == 0) && ((k == 3 && C0 == 16 && C1 == 32 && Cout == 16) || (k == 5 && C0 == 16 && C1 == 0 && Cout == 32));
 }
 
+// The plain form (no statistics, no deferred batch norm) also takes the two INPUT-GRADIENT convolutions of those layers
+// (tap-flipped transposed filters): 32 -> 16, 5 x 5 (dX of the 16 -> 32 encoder layer) and 16 -> 48, 3 x 3 (dX of the decoder
+// layer).  As implicit GEMMs they gathered their input once per tap: 6.7 GB for 54 GFLOP.
+extern "C" int avsi_conv2d_thin_mfma_plain_supported(int k, int C0, int C1, int Cout, int H, int W) {
+    if (avsi_conv2d_thin_mfma_supported(k, C0, C1, Cout, H, W)) return 1;
+    return (H % 4 == 0 && W % 32 == 0) && ((k == 5 && C0 == 32 && C1 == 0 && Cout == 16) || (k == 3 && C0 == 16 && C1 == 0 && Cout == 48));
+}
+
 static int conv2d_thin_mfma_launch(const float* src0, int C0, int ld0, const float* src1_coarse, int C1, int ld1, int B, int H,
                                    int W, int k, const float* filter, int ldf, const float* bias, int Cout, float* out,
                                    int ldo, const float* zeros64, float* part, const float* const* src1_bn, void* stream);
@@ -1573,12 +1664,16 @@ static int conv2d_thin_mfma_launch(const float* src0, int C0, int ld0, const flo
     if (!src0 || !filter || !out || !zeros64 || B <= 0 || (C1 && !src1_coarse) || ldf < Cout || ldo < Cout || ld0 < C0 ||
         (C1 && ld1 < C1))
         return AVSI_ERR_INVALID_ARG;
-    if (!avsi_conv2d_thin_mfma_supported(k, C0, C1, Cout, H, W) || (ld0 & 3) || (ld1 & 3) || (ldf & 3) ||
+    const bool plain_only = !avsi_conv2d_thin_mfma_supported(k, C0, C1, Cout, H, W);
+    if (plain_only && (part || src1_bn)) return AVSI_ERR_UNSUPPORTED;
+    if (!avsi_conv2d_thin_mfma_plain_supported(k, C0, C1, Cout, H, W) || (ld0 & 3) || (ld1 & 3) || (ldf & 3) ||
         ((reinterpret_cast<uintptr_t>(src0) | reinterpret_cast<uintptr_t>(src1_coarse) | reinterpret_cast<uintptr_t>(filter) |
           reinterpret_cast<uintptr_t>(zeros64)) & 15))
         return AVSI_ERR_UNSUPPORTED;
     const int n_tiles = B * (H / 4) * (W / 32);
-    const dim3 grid(thin_mfma_blocks(n_tiles)), block(256);
+    // (the 32 -> 16, 5 x 5 input gradient holds 89 KB of patch + filter: one workgroup per CU)
+    const int blocks = (k == 5 && C0 == 32) ? (n_tiles < AVSI_NUM_CU ? n_tiles : AVSI_NUM_CU) : thin_mfma_blocks(n_tiles);
+    const dim3 grid(blocks), block(256);
     const hipStream_t st = (hipStream_t)stream;
     avsi_clear_error();
 #define AVSI_THIN_MFMA(KS, CA, CB, CO, ST, BN, LDS)                                                                             \
@@ -1588,7 +1683,13 @@ static int conv2d_thin_mfma_launch(const float* src0, int C0, int ld0, const flo
         hipLaunchKernelGGL((thin_mfma_conv_kernel<KS, CA, CB, CO, ST, BN>), grid, block, (LDS), st, src0, ld0, src1_coarse,    \
                            ld1, filter, ldf, bias, out, ldo, H, W, zeros64, part, bn1, n_tiles);                              \
     } while (0)
-    if (k == 3) {
+    if (k == 5 && C0 == 32) {
+        constexpr size_t lds = ((size_t)8 * 36 * 33 + 25 * 32 * 16) * 4;
+        AVSI_THIN_MFMA(5, 32, 0, 16, false, false, lds);
+    } else if (k == 3 && C1 == 0) {
+        constexpr size_t lds = ((size_t)6 * 34 * 17 + 9 * 16 * 48) * 4;
+        AVSI_THIN_MFMA(3, 16, 0, 48, false, false, lds);
+    } else if (k == 3) {
         constexpr size_t lds = ((size_t)6 * 34 * 49 + 9 * 48 * 16) * 4;
         if (part && src1_bn) AVSI_THIN_MFMA(3, 16, 32, 16, true, true, lds);
         else if (part) AVSI_THIN_MFMA(3, 16, 32, 16, true, false, lds);

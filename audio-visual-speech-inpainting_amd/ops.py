@@ -743,6 +743,12 @@ def conv2d_thin_mfma_supported(k, c0, c1, cout, H, W):
         bool(_lib.lib().avsi_conv2d_thin_mfma_supported(int(k), int(c0), int(c1), int(cout), int(H), int(W)))
 
 
+def conv2d_thin_mfma_plain_supported(k, c0, c1, cout, H, W):
+    """Shapes the plain 16-wide-MFMA convolution takes: the forward layers above and their input-gradient convolutions."""
+    return os.environ.get('AVSI_CONV_THIN_MFMA', '1') != '0' and \
+        bool(_lib.lib().avsi_conv2d_thin_mfma_plain_supported(int(k), int(c0), int(c1), int(cout), int(H), int(W)))
+
+
 def conv2d_thin_mfma(src0, c0, src1, c1, B, H, W, k, filt, bias, out, cout):
     _lib.require_cuda(src0, src1, filt, out)
     z = _ZEROS.get(out.device.index)

@@ -533,7 +533,11 @@ class UNetFConvModel(object):
             # dX = conv2d(dY, tap-flipped transposed filter): implicit GEMM again, then split / 2x2-sum into the sources
             ct = s['c0'] + s['c1']
             dxc = self._buf('dxcat', (self._dx_floats,))[: R * ct].view(R, ct)
-            ops.conv2d(dconv, cout, None, 0, s['B'], s['H'], s['W'], s['k'], self._flipped_filter(name, s), None, dxc, ct)
+            if ops.conv2d_thin_mfma_plain_supported(s['k'], cout, 0, ct, s['H'], s['W']) and dxc.stride(0) == ct:
+                ops.conv2d_thin_mfma(dconv, cout, None, 0, s['B'], s['H'], s['W'], s['k'], self._flipped_filter(name, s), None,
+                                     dxc, ct)
+            else:
+                ops.conv2d(dconv, cout, None, 0, s['B'], s['H'], s['W'], s['k'], self._flipped_filter(name, s), None, dxc, ct)
             ops.split_sumpool(dxc, dsrc0, s['c0'], acc0, dsrc1, s['c1'], acc1, s['B'], s['H'], s['W'])
             return
         col = self._buf('col', (self._col_floats,))[: R * kc].view(R, kc)

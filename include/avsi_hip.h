@@ -570,6 +570,9 @@ int avsi_conv2d_bn_f32(const float* src0, int C0, int ld0, const float* src1_coa
  * avsi_conv2d_f32): the U-Net's decoder layer 16 + 32 -> 16 (3 x 3) and encoder layer 16 -> 32 (5 x 5); H % 4 == 0,
  * W % 32 == 0.  avsi_conv2d_thin_mfma_supported returns 1 for the shapes it takes. */
 int avsi_conv2d_thin_mfma_supported(int k, int C0, int C1, int Cout, int H, int W);
+/* avsi_conv2d_thin_mfma_f32 itself (no statistics, no deferred batch norm) also takes the input-gradient convolutions of those
+ * two layers -- (k, C0, C1, Cout) = (5, 32, 0, 16) and (3, 16, 0, 48) with tap-flipped transposed filters: 1 for every shape it takes. */
+int avsi_conv2d_thin_mfma_plain_supported(int k, int C0, int C1, int Cout, int H, int W);
 int avsi_conv2d_thin_mfma_f32(const float* src0, int C0, int ld0, const float* src1_coarse, int C1, int ld1, int B, int H, int W,
                               int k, const float* filter, int ldf, const float* bias, int Cout, float* out, int ldo,
                               const float* zeros64, void* stream);

@@ -364,6 +364,53 @@ def test_thin_mfma_filter_gradient_matches_im2col_gemm(c0, c1, k, cout, B, H, W)
     assert torch.equal(got, again)
 
 
+@pytest.mark.parametrize("k,c0,c1,cout,B,H,W", [(7, 1, 0, 16, 2, 16, 64), (7, 1, 0, 16, 40, 64, 64), (7, 1, 0, 16, 3, 20, 14),
+                                                (3, 1, 16, 1, 3, 20, 14), (1, 1, 0, 1, 2, 16, 64)])
+def test_thin_filter_gradients_match_im2col_gemm(k, c0, c1, cout, B, H, W):
+    """avsi_conv2d_thin_wgrad_f32: the one-channel layers' filter gradients -- the first layer on the 16-wide MFMA with the taps
+    as the M side (H % 8 == 0, W % 32 == 0: the first two cases; 40 x 64 x 64 gives the 80 workgroups eight tiles each), the
+    direct kernels otherwise -- against im2col^T . dY."""
+    import torch
+    import avsi_amd  # noqa: F401
+    from avsi_amd import ops
+    g = torch.Generator(device='cuda')
+    g.manual_seed(k + B)
+    R = B * H * W
+    src0 = torch.randn(R, 4, generator=g, device='cuda')
+    src1 = torch.randn(B * (H // 2) * (W // 2), c1, generator=g, device='cuda') if c1 else None
+    kc = k * k * (c0 + c1)
+    ld = -(-cout // 4) * 4
+    dy = torch.zeros(R, ld, device='cuda')
+    dy[:, :cout] = torch.randn(R, cout, generator=g, device='cuda')
+    kcp = -(-kc // 4) * 4
+    col = torch.empty(R, kcp, device='cuda')
+    ops.im2col(src0, c0, src1, c1, B, H, W, k, col, kcp)
+    want = (col[:, :kc].double().t() @ dy[:, :cout].double()).cpu().numpy()
+    got = torch.full((kcp, ld), 3.0, device='cuda')
+    ops.conv2d_thin_wgrad(src0, c0, src1, c1, B, H, W, k, dy, cout, got)
+    np.testing.assert_allclose(got[:kc, :cout].cpu().numpy(), want, rtol=2e-4, atol=2e-4 * np.abs(want).max())
+
+
+@pytest.mark.parametrize("c0,c1,k,cout,B,H,W", [(32, 0, 5, 16, 2, 8, 32), (16, 0, 3, 48, 3, 12, 64), (32, 0, 5, 16, 40, 64, 64)])
+def test_thin_mfma_input_gradient_convolutions_match_implicit_gemm(c0, c1, k, cout, B, H, W):
+    """The plain 16-wide-MFMA convolution on the shapes of the two input-gradient convolutions it takes since round 5
+    (avsi_conv2d_thin_mfma_plain_supported), against the implicit GEMM; statistics are refused for them."""
+    import torch
+    import avsi_amd  # noqa: F401
+    from avsi_amd import ops
+    g = torch.Generator(device='cuda')
+    g.manual_seed(c0 + k + B)
+    R = B * H * W
+    src0 = torch.randn(R, c0, generator=g, device='cuda')
+    filt = torch.randn(k * k * c0, cout, generator=g, device='cuda') * 0.2
+    assert ops.conv2d_thin_mfma_plain_supported(k, c0, c1, cout, H, W) and not ops.conv2d_thin_mfma_supported(k, c0, c1, cout, H, W)
+    want = torch.empty(R, cout, device='cuda')
+    ops.conv2d(src0, c0, None, 0, B, H, W, k, filt, None, want, cout)
+    got = torch.full((R, cout), 5.0, device='cuda')
+    ops.conv2d_thin_mfma(src0, c0, None, 0, B, H, W, k, filt, None, got, cout)
+    np.testing.assert_allclose(got.cpu().numpy(), want.cpu().numpy(), rtol=2e-5, atol=2e-5 * float(want.abs().max()))
+
+
 @pytest.mark.parametrize("c0,c1,k,cout,B,H,W,splits", [(16, 0, 5, 32, 2, 12, 8, 3), (32, 64, 3, 32, 3, 8, 16, 1), (128, 128, 3, 128, 1, 4, 4, 2),
                                                        (16, 32, 3, 16, 2, 64, 8, 5), (4, 0, 3, 7, 1, 8, 8, 1)])
 def test_implicit_filter_gradient_matches_im2col_gemm(c0, c1, k, cout, B, H, W, splits):
