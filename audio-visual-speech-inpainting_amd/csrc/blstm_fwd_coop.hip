@@ -54,6 +54,7 @@ struct CoopArgs {
     int xtile0, xtiles;   // ... of the tiles [xtile0, xtile0 + xtiles) of the CALL (a row-range call covers part of the batch)
     int coherent;      // AVSI_COOP_COHERENT=1: every load of exchanged bytes at device scope, whatever the invariants allow
     long long spin_ticks;   // bound of every wait for a peer, 100 MHz ticks (avsi_coop_spin_ticks)
+    unsigned long long* stamps;   // diagnostics (STAMPS, avsi_diag_cs_stamps): [block < 32][step 64 .. 71][wave 0 / 1][8 phases]
 };
 
 __device__ __forceinline__ float sigmoidf_fast(float x) { return __builtin_amdgcn_rcpf(1.f + __expf(-x)); }
@@ -280,7 +281,10 @@ __global__ __launch_bounds__(512, 2) void blstm_rec_fwd_coop_kernel(const CoopAr
 // real step has), a reading wave's fragment load is one contiguous block, and the invariant of cacheable loads holds
 // (coherent_load4_issue): nothing touches a line before it is complete.  hout is written beside it with plain stores
 // nobody waits for.  Without XCH the exchange runs through hout itself: device-scope loads, lines touched ahead.
-template <int NT, bool SAVE, bool XCH>
+// STAMPS (diagnostic instantiation, selected while avsi_diag_cs_stamps holds a buffer; tools/rec_fine_stamps.py): waves 0 and 1
+// of the first 32 workgroups record the 100 MHz wall clock at eight points of steps 64 .. 71 -- top of the step, counter seen,
+// barrier passed, h fragments landed, MFMAs + park + barrier, cell done and stores issued, h store acknowledged, published.
+template <int NT, bool SAVE, bool XCH, bool STAMPS = false>
 __global__ __launch_bounds__(512, 2) void blstm_rec_fwd_coop_fine_kernel(const CoopArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* part = reinterpret_cast<float*>(smem);      // [wave][tile][column][row]
@@ -331,10 +335,15 @@ __global__ __launch_bounds__(512, 2) void blstm_rec_fwd_coop_fine_kernel(const C
     float* xbase = XCH ? a.xch + (size_t)(2 * (a.tile0 - a.xtile0) + group) * (32 * HP) : nullptr;
     __syncthreads();
 
+    auto stamp = [&](int step, int phase) {
+        if (STAMPS && (tid & 63) == 0 && tid < 128 && blockIdx.x < 32 && step >= 64 && step < 72)
+            a.stamps[((blockIdx.x * 8 + (step - 64)) * 2 + (tid >> 6)) * 8 + phase] = wall_clock64();
+    };
     for (int step = 0; step < T; ++step) {
         const int t = dir ? (T - 1 - step) : step;
         const int tprev = dir ? t + 1 : t - 1;
         const size_t row0 = (size_t)t * Bp + b0;
+        stamp(step, 0);
 
         float xz[4];
         float touched = 0.f;
@@ -375,7 +384,9 @@ __global__ __launch_bounds__(512, 2) void blstm_rec_fwd_coop_fine_kernel(const C
                     }
                 }
             }
+            stamp(step, 1);
             __syncthreads();
+            stamp(step, 2);
             v4f af[4];
             if (XCH) {
                 // k group q of this wave = units 32 ks + 8 q ..: block of member (32 ks + 8 q) / UW, offset (8 q) % UW
@@ -399,6 +410,7 @@ __global__ __launch_bounds__(512, 2) void blstm_rec_fwd_coop_fine_kernel(const C
                 for (int q = 0; q < 4; ++q) agent_load4_issue(af[q], hp + 8 * ks * QPW, 32 * q);
             }
             coherent_wait(af);
+            stamp(step, 3);
 #pragma unroll
             for (int q = 0; q < 4; ++q)
 #pragma unroll
@@ -420,6 +432,7 @@ __global__ __launch_bounds__(512, 2) void blstm_rec_fwd_coop_fine_kernel(const C
                 *reinterpret_cast<float4*>(part + ((ks * NT + tl) * 32 + li) * PSTRIDE + 8 * j + 4 * hi) =
                     make_float4(acc[tl][4 * j], acc[tl][4 * j + 1], acc[tl][4 * j + 2], acc[tl][4 * j + 3]);
         __syncthreads();
+        stamp(step, 4);
 
         if (fin) {
             float z[4];
@@ -455,13 +468,18 @@ __global__ __launch_bounds__(512, 2) void blstm_rec_fwd_coop_fine_kernel(const C
         // Only the h store has to be complete before the counter moves.  Stores complete in issue order, so with the
         // five reserve stores issued BEHIND it the wait leaves those in flight.  (Measured: no difference, neither on
         // warm buffers nor inside a training step -- kept because it is the weaker, sufficient condition.)
-        if (SAVE && XCH) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        stamp(step, 5);
+        // (STAMPS: the stamps' own stores sit in the same queue -- the diagnostic build waits for everything)
+        if (STAMPS) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else if (SAVE && XCH) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
         else if (SAVE) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
         else if (XCH) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         asm volatile("" ::"v"(touched));
+        stamp(step, 6);
         __syncthreads();
         if (tid == 0) __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        stamp(step, 7);
     }
     if (member == 0 && tid == 0 && !dead) reset_counter_when_done(ctr, (unsigned)S * (unsigned)T, a.spin_ticks, a.sync);
 }
@@ -475,6 +493,12 @@ int launch_coop_fine_x(const CoopArgs& a, hipStream_t st) {
     (void)hipFuncSetAttribute((const void*)blstm_rec_fwd_coop_fine_kernel<NT, SAVE, XCH>,
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     const int blocks = (int)avsi_ceil_div(a.ngroups, AVSI_NUM_XCD) * AVSI_NUM_XCD * S;
+    if (a.stamps && NT == 1 && !SAVE && XCH) {        // diagnostic instantiation (avsi_diag_cs_stamps): the 32-way inference kernel
+        (void)hipFuncSetAttribute((const void*)blstm_rec_fwd_coop_fine_kernel<1, false, true, true>,
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL((blstm_rec_fwd_coop_fine_kernel<1, false, true, true>), dim3(blocks), dim3(512), lds, st, a);
+        return avsi_launch_status();
+    }
     hipLaunchKernelGGL((blstm_rec_fwd_coop_fine_kernel<NT, SAVE, XCH>), dim3(blocks), dim3(512), lds, st, a);
     return avsi_launch_status();
 }
@@ -494,6 +518,8 @@ int launch_coop(const CoopArgs& a, hipStream_t st) {
 }
 
 }  // namespace
+
+unsigned long long* avsi_cs_stamps_buffer();     // blstm_fwd_cs.hip: the diagnostic buffer of avsi_diag_cs_stamps (null: no stamps)
 
 // word 0: status, then step counters: one per (tile, direction), two for the half-tile BPTT kernel
 extern "C" size_t avsi_blstm_rec_fwd_coop_workspace_bytes(int Bp) {
@@ -555,7 +581,7 @@ extern "C" int avsi_blstm_rec_fwd_coop_rows_f32(const float* xproj, const float*
     if (xch && avsi_blstm_rec_fwd_coop_workspace_bytes(Bp) > AVSI_COOP_EXCHANGE_OFFSET) return AVSI_ERR_WORKSPACE;
     for (int tile0 = tbeg; tile0 < tiles; tile0 += per) {
         const int nt = tiles - tile0 < per ? tiles - tile0 : per;
-        CoopArgs a{xproj, whp, hout, reserve, (unsigned*)workspace, T, Bp, 2 * nt, tile0, xch, tbeg, rows / 32, coop_coherent(), avsi_coop_spin_ticks()};
+        CoopArgs a{xproj, whp, hout, reserve, (unsigned*)workspace, T, Bp, 2 * nt, tile0, xch, tbeg, rows / 32, coop_coherent(), avsi_coop_spin_ticks(), avsi_cs_stamps_buffer()};
         int rc;
         if (split == 32)
             rc = reserve ? launch_coop_fine<1, true>(a, st) : launch_coop_fine<1, false>(a, st);

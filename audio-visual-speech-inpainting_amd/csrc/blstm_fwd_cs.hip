@@ -310,6 +310,9 @@ extern "C" int avsi_blstm_rec_fwd_cs_groups_per_launch(int rows_per_group, int w
 
 // Diagnostic: while `buffer` (32 * 8 * 2 * 8 uint64, device memory) is set, launches record the wall clock of eight
 // phases of steps 64 .. 71 for waves 0 and 1 of the first 32 workgroups (tools/rec_cs_stamps.py); null switches it off.
+// internal (blstm_fwd_coop.hip: the 32-way kernel's diagnostic instantiation records into the same buffer)
+unsigned long long* avsi_cs_stamps_buffer() { return g_cs_stamps; }
+
 extern "C" int avsi_diag_cs_stamps(void* buffer) {
     g_cs_stamps = (unsigned long long*)buffer;
     return AVSI_OK;

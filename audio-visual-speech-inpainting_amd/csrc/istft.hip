@@ -64,10 +64,11 @@ __global__ void istft_tables_kernel(float* tab, int frame_len, int hop) {
 // MODE / HAS_MASK are compile-time so that the 16 frames' loads of a tile are straight-line code: with the mode
 // tested at run time each frame's loads sat in their own blocks, closed by s_waitcnt vmcnt(0) -- sixteen memory
 // latencies in a row per tile.
-// OCC3: built for three waves per SIMD (<= 168 registers); LATE (mode 3): the prediction / mask loads of a tile are issued
-// behind the forward transform instead of in front of it (32 registers less across the transform; other waves cover the latency)
-template <int MODE, bool HAS_MASK, bool OCC3 = true, bool LATE = false>
-__global__ __launch_bounds__(TPB, OCC3 ? 3 : 2) void istft_kernel(const avsi_istft_args a, const int tiles_per_utt, const int n_tiles,
+// Built for three waves per SIMD (<= 168 registers; mode 3 spills ~30 of its 197 to scratch and still gains: 2.30 -> 1.99 ms at
+// 4096 utterances, measured against the two-wave build on one box).  LATE (mode 3): the prediction / mask loads of a tile are
+// issued behind the forward transform instead of in front of it (the other waves cover their latency: 2.03 -> 1.99 ms).
+template <int MODE, bool HAS_MASK, bool LATE = (MODE == 3)>
+__global__ __launch_bounds__(TPB, 3) void istft_kernel(const avsi_istft_args a, const int tiles_per_utt, const int n_tiles,
                                                     const int n_hops, const int step) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     // s_x (spectrum tile) and s_z (FFT transposition scratch) share storage: s_x is dead once every lane has
@@ -382,10 +383,7 @@ extern "C" int avsi_istft_f32(const avsi_istft_args* args, void* stream) {
     if (lds < (size_t)FR * ((a.frame_len + 3) & ~3) * 4) return AVSI_ERR_UNSUPPORTED;
     if (a.mode == 3) lds += (size_t)((FR - 1) * a.hop + a.frame_len + 32) * 4;
     const int n_tiles = (int)n_tiles64;
-    // A/B switches of round 5 (mode 3): AVSI_ISTFT_OCC = 2 | 3 waves per SIMD the kernel is built for, AVSI_ISTFT_LATE = 0 | 1
-    static const int occ = getenv("AVSI_ISTFT_OCC") ? atoi(getenv("AVSI_ISTFT_OCC")) : 3;
-    static const int late = getenv("AVSI_ISTFT_LATE") ? atoi(getenv("AVSI_ISTFT_LATE")) : 0;
-    const int per_cu = (a.mode == 3 && occ == 2) ? 2 : 3;    // workgroups per CU: 35 - 48 KB of LDS, <= 168 registers
+    const int per_cu = 3;                                    // workgroups per CU: 35 - 48 KB of LDS, <= 168 registers
     const int grid = n_tiles < AVSI_NUM_CU * per_cu ? n_tiles : AVSI_NUM_CU * per_cu;
     avsi_clear_error();
 #define AVSI_ISTFT_LAUNCH(...)                                                                                          \
@@ -398,15 +396,8 @@ extern "C" int avsi_istft_f32(const avsi_istft_args* args, void* stream) {
     else if (a.mode == 1) AVSI_ISTFT_LAUNCH(1, false);
     else if (a.mode == 2 && a.in2) AVSI_ISTFT_LAUNCH(2, true);
     else if (a.mode == 2) AVSI_ISTFT_LAUNCH(2, false);
-    else if (a.in2) {
-        if (occ == 2 && late) AVSI_ISTFT_LAUNCH(3, true, false, true);
-        else if (occ == 2) AVSI_ISTFT_LAUNCH(3, true, false, false);
-        else if (late) AVSI_ISTFT_LAUNCH(3, true, true, true);
-        else AVSI_ISTFT_LAUNCH(3, true, true, false);
-    } else {
-        if (occ == 2) AVSI_ISTFT_LAUNCH(3, false, false, false);
-        else AVSI_ISTFT_LAUNCH(3, false, true, false);
-    }
+    else if (a.in2) AVSI_ISTFT_LAUNCH(3, true);
+    else AVSI_ISTFT_LAUNCH(3, false);
 #undef AVSI_ISTFT_LAUNCH
     return avsi_launch_status();
 }

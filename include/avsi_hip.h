@@ -237,8 +237,9 @@ int avsi_blstm_rec_fwd_cs_rows_f32(const float* xproj, const float* whp, float* 
                                    int T, int Bp, int rows_per_group, int first_row, int rows, int max_cus,
                                    void* workspace, size_t workspace_bytes, void* stream);
 
-/* Diagnostic: while `buffer` (device memory, 32 * 8 * 2 * 8 uint64) is set, avsi_blstm_rec_fwd_cs_f32 records the
- * 100 MHz wall clock at eight phases of steps 64 .. 71 for waves 0 and 1 of its first 32 workgroups; NULL ends it. */
+/* Diagnostic: while `buffer` (device memory, 32 * 8 * 2 * 8 uint64) is set, avsi_blstm_rec_fwd_cs_f32 and the 32-way
+ * cooperative forward kernel without reserve (avsi_blstm_rec_fwd_coop_f32, split 32) record the
+ * 100 MHz wall clock at eight phases of steps 64 .. 71 for waves 0 and 1 of their first 32 workgroups; NULL ends it. */
 int avsi_diag_cs_stamps(void* buffer);
 
 /* Holds `stream` back for `microseconds` (0 .. 1000) with one idle wave: lets a kernel on another stream that becomes
