@@ -582,6 +582,100 @@ __global__ __launch_bounds__(256) void conv7_c1_wgrad_mfma_kernel(const float* _
     }
 }
 
+// Filter gradient of the LAST 3 x 3 layer (1 skip channel ++ 16 up-sampled channels -> 1) on the 16-wide MFMA.  One output
+// channel would leave 15 of 16 MFMA columns empty, so the sum is turned around: dW[tap][c] = sum_q in(q, c) dY(q - off(tap)) --
+// the M side are the 16 coarse channels of input pixel q, the N side the nine taps (a per-lane gather from the one-channel dY
+// patch, columns 9 .. 15 multiply by zero), K the pixels.  The skip channel's nine sums are plain multiply-adds (one pixel per
+// thread).  8 x 32-pixel tiles, persistent workgroups, the four waves take 16 of a tile's 64 k-steps each.
+// The direct form (thin_wgrad_kernel<3, 1, 16, 1>) took 0.33 - 0.58 ms at 512 clips.
+__global__ __launch_bounds__(256) void conv3_c17_wgrad_mfma_kernel(const float* __restrict__ s0, int ld0, const float* __restrict__ s1,
+                                                                  int ld1, const float* __restrict__ dy, int ldy,
+                                                                  float* __restrict__ part, int H, int W, const int n_tiles) {
+    constexpr int TH = 8, TW = 32, CH = TH / 2, CW = TW / 2, CP = 17, DH = TH + 2, DW = TW + 2, KSTEPS = TH * TW / 4;
+    __shared__ float coarse[CH * CW * CP];
+    __shared__ float dyp[DH * DW + 6];
+    __shared__ float fine[TH * TW];
+    __shared__ float red[4][16 * 16 + 16];
+    const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tiles_w = W / TW, tiles_img = tiles_w * (H / TH);
+    const int H2 = H >> 1, W2 = W >> 1;
+    float4 cpre;
+    float dpre[2], fpre;
+    auto fetch = [&](int tile) {
+        const int b = tile / tiles_img, tl = tile - b * tiles_img;
+        const int h0 = (tl / tiles_w) * TH, w0 = (tl - (tl / tiles_w) * tiles_w) * TW;
+        {   // coarse pixels of the tile: 4 x 16, four float4 each
+            const int pix = tid >> 2, q = tid & 3;
+            const int r = pix / CW, c = pix - r * CW;
+            cpre = *reinterpret_cast<const float4*>(s1 + (((int64_t)b * H2 + (h0 >> 1) + r) * W2 + (w0 >> 1) + c) * ld1 + 4 * q);
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int i = tid + 256 * j;
+            const int ic = i < DH * DW ? i : 0;
+            const int r = ic / DW, c = ic - r * DW;
+            const int hh = h0 + r - 1, ww = w0 + c - 1;
+            const bool ok = hh >= 0 && hh < H && ww >= 0 && ww < W;
+            dpre[j] = *(ok ? dy + (((int64_t)b * H + hh) * W + ww) * ldy : g_zero_pixel);
+        }
+        fpre = s0[(((int64_t)b * H + h0 + (tid >> 5)) * W + w0 + (tid & 31)) * ld0];
+    };
+    const int px = lane & 15, kq = lane >> 4;
+    const bool tap_live = px < 9;
+    const int tp = tap_live ? px : 0;
+    const int boff = (2 - tp / 3) * DW + (2 - tp % 3) + kq;      // dY(q - off(tap)) in the patch (origin -1, -1), this lane's pixel
+    typedef float f32x4v __attribute__((ext_vector_type(4)));
+    f32x4v acc = {0.f, 0.f, 0.f, 0.f};
+    float facc[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) facc[t] = 0.f;
+    if ((int)blockIdx.x < n_tiles) fetch(blockIdx.x);
+    for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        {
+            float* d = coarse + (tid >> 2) * CP + 4 * (tid & 3);
+            d[0] = cpre.x, d[1] = cpre.y, d[2] = cpre.z, d[3] = cpre.w;
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+            if (tid + 256 * j < DH * DW) dyp[tid + 256 * j] = dpre[j];
+        fine[tid] = fpre;
+        AVSI_LDS_BARRIER();
+        if (tile + (int)gridDim.x < n_tiles) fetch(tile + gridDim.x);
+#pragma unroll
+        for (int k = 0; k < KSTEPS / 4; ++k) {
+            const int kk = wv * (KSTEPS / 4) + k;
+            const int r = kk >> 3, c = ((kk & 7) << 2) + kq;
+            const float a = coarse[((r >> 1) * CW + (c >> 1)) * CP + px];
+            const float bq = dyp[r * DW + ((kk & 7) << 2) + boff];
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a, tap_live ? bq : 0.f, acc, 0, 0, 0);
+        }
+        {   // the skip channel: pixel (tid / 32, tid % 32) of the tile
+            const int r = tid >> 5, c = tid & 31;
+            const float x = fine[tid];
+#pragma unroll
+            for (int t = 0; t < 9; ++t) facc[t] += x * dyp[(r + 2 - t / 3) * DW + c + 2 - t % 3];
+        }
+        AVSI_LDS_BARRIER();
+    }
+    // ---- the workgroup's partial filter: waves added in order, then [tap][17]
+#pragma unroll
+    for (int i = 0; i < 4; ++i) red[wv][(4 * kq + i) * 16 + px] = acc[i];            // [channel][tap]
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+        float v = facc[t];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+        if (lane == 0) red[wv][256 + t] = v;
+    }
+    __syncthreads();
+    float* prow = part + (int64_t)blockIdx.x * 153;
+    if (tid < 153) {
+        const int tap = tid / 17, c = tid - tap * 17;
+        const int src = c == 0 ? 256 + tap : (c - 1) * 16 + tap;
+        prow[tid] = (red[0][src] + red[1][src]) + (red[2][src] + red[3][src]);
+    }
+}
+
 template <int K, int C0, int C1, int COUT>
 __global__ __launch_bounds__(TPB) void direct_conv_kernel(const float* __restrict__ s0, int ld0, const float* __restrict__ s1,
                                                           int ld1, const float* __restrict__ filt, int ldf,
@@ -1330,7 +1424,7 @@ __global__ __launch_bounds__(TPB) void maxpool2_bwd_kernel(const float* __restri
 // one memory latency per pass: 1.3 TB/s on the 134 MB activation of the widest decoder layer).
 constexpr int MAXPARTS = 1024;
 inline int parts_for(int64_t R) {
-    int64_t p = avsi_ceil_div(R, 512);
+    int64_t p = avsi_ceil_div(R, 128);      // (512 until round 5: the deep layers' 8192 rows were 16 workgroups)
     return (int)(p < 1 ? 1 : (p > MAXPARTS ? MAXPARTS : p));
 }
 }  // namespace
@@ -1465,6 +1559,10 @@ extern "C" int avsi_conv2d_thin_wgrad_f32(const float* src0, int C0, int ld0, co
     else if (k == 7 && C0 == 1 && C1 == 0 && Cout == 16)
         hipLaunchKernelGGL((thin_wgrad_kernel<7, 1, 0, 16>), dim3(blocks, 7), dim3(TPB), 0, st, src0, ld0, src1_coarse, ld1, dy, ldy,
                            part, B, H, W);
+    else if (k == 3 && C0 == 1 && C1 == 16 && Cout == 1 && c7_mfma && H % 8 == 0 && W % 32 == 0 && !(ld1 & 3) &&
+             !(reinterpret_cast<uintptr_t>(src1_coarse) & 15) && B * (H / 8) * (W / 32) >= blocks)
+        hipLaunchKernelGGL(conv3_c17_wgrad_mfma_kernel, dim3(blocks), dim3(256), 0, st, src0, ld0, src1_coarse, ld1, dy, ldy, part, H, W,
+                           B * (H / 8) * (W / 32));
     else if (k == 3 && C0 == 1 && C1 == 16 && Cout == 1)
         hipLaunchKernelGGL((thin_wgrad_kernel<3, 1, 16, 1>), dim3(blocks, 3), dim3(TPB), 0, st, src0, ld0, src1_coarse, ld1, dy, ldy,
                            part, B, H, W);
@@ -1827,7 +1925,11 @@ extern "C" int avsi_bn_act_pool_bwd_f32(const float* x, const float* dpooled, in
     const int64_t R = (int64_t)B * H * W;
     BnArgs a{x, dpooled, mean, rstd, gamma, beta, R, C, ld, act, has_bn};
     const hipStream_t st = (hipStream_t)stream;
-    const int parts = parts_for(R / 4);
+    // row slabs: a workgroup passes over TPB / (ld / 4) pooled pixels at a time; four passes each at least, so that the deep
+    // layers (2048 pooled pixels of 128 channels: 4 workgroups by parts_for) still spread over the chip
+    const int64_t per_pass = TPB / (ld >> 2);
+    int64_t want = avsi_ceil_div(R / 4, per_pass * 4);
+    const int parts = (int)(want < 1 ? 1 : (want > MAXPARTS ? MAXPARTS : want));
     float* part = (float*)workspace;
     avsi_clear_error();
     if (has_bn) {

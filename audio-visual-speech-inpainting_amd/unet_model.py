@@ -230,9 +230,11 @@ class UNetFConvModel(object):
         if self._auto_count >= self.AUTO_GRAPH_AFTER and shape[0][0] <= self.AUTO_GRAPH_MAX_CLIPS:
             try:
                 self.capture_graph(_auto=True)
-            except Exception:              # never a reason to fail a step: stay with plain launches
+            except Exception as e:         # never a reason to fail a step: stay with plain launches -- but say so, once
                 self.release_graph()
                 self._auto_count = -(1 << 30)
+                print('avsi: the U-Net inference step was not captured into a HIP graph (%s: %s); plain launches from here on'
+                      % (type(e).__name__, str(e)[:200]), file=sys.stderr, flush=True)
 
     # ------------------------------------------------------------------ HIP graph of the inference step
     def capture_graph(self, _auto=False):
@@ -297,12 +299,9 @@ class UNetFConvModel(object):
         m = self.masks[:, :T].contiguous()
         fe = ap.frontend(self.target_sources, window_size=16, step_size=8, n_fft=256, num_frames_out=T, num_bins=F,
                          mean=self.audio_feat_mean, std=self.audio_feat_std, masks=m, want_spec=True, want_feat=True)
-        if self.is_training or getattr(self, '_keep_for_backward', False):
-            x0 = self._buf('x0', (B * T * F, 4))                   # [B, T, F, 1] with channel pitch 4 (the backward kernels' pitch)
-            x0[:, 0] = fe['feat'].reshape(-1)
-        else:
-            # inference: the one-channel layers read the front end's output where it lies (channel pitch 1), no copy
-            x0 = fe['feat'].reshape(B * T * F, 1)
+        # the one-channel layers -- forward, filter gradients, the skip into the last 3 x 3 layer -- read the front end's output
+        # where it lies (channel pitch 1): no copy (until round 5 the training form kept a pitch-4 copy, a strided copy per step)
+        x0 = fe['feat'].reshape(B * T * F, 1)
         c['target_spec_norm'], c['net_inputs'], c['x0'], c['mask_t'] = fe['spec'], fe['feat'], x0, m
 
     @property
@@ -495,7 +494,10 @@ class UNetFConvModel(object):
         # The bias gradient, sum of dconv over the pixels: under batch norm dconv = gamma rstd (g - mean g - xhat mean(g xhat))
         # sums to zero identically (the normalisation removes any bias), so it IS zero -- the buffer's zeros stay; a column
         # sum would return rounding noise (13 passes over the gradients per step).  Layers without batch norm (e1, out) sum.
-        if pooled:
+        if not s['bn'] and s['act'] == 0 and not pooled and dy.shape == dconv.shape:
+            dconv = dy                  # the output layer: no batch norm, no activation -- its gradient IS the incoming one
+            ops.colsum(dconv, lay.gpacked_view(gp, name + '/b'), m=R, n=ld)
+        elif pooled:
             ops.bn_act_pool_bwd(s['conv'], dy, s['B'], s['H'], s['W'], cout, dconv, *bn_args,
                                 dbias=None if s['bn'] else lay.gpacked_view(gp, name + '/b'))
         else:

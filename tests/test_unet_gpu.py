@@ -365,11 +365,12 @@ def test_thin_mfma_filter_gradient_matches_im2col_gemm(c0, c1, k, cout, B, H, W)
 
 
 @pytest.mark.parametrize("k,c0,c1,cout,B,H,W", [(7, 1, 0, 16, 2, 16, 64), (7, 1, 0, 16, 40, 64, 64), (7, 1, 0, 16, 3, 20, 14),
-                                                (3, 1, 16, 1, 3, 20, 14), (1, 1, 0, 1, 2, 16, 64)])
+                                                (3, 1, 16, 1, 3, 20, 14), (3, 1, 16, 1, 2, 16, 64), (3, 1, 16, 1, 40, 64, 64),
+                                                (1, 1, 0, 1, 2, 16, 64)])
 def test_thin_filter_gradients_match_im2col_gemm(k, c0, c1, cout, B, H, W):
     """avsi_conv2d_thin_wgrad_f32: the one-channel layers' filter gradients -- the first layer on the 16-wide MFMA with the taps
-    as the M side (H % 8 == 0, W % 32 == 0: the first two cases; 40 x 64 x 64 gives the 80 workgroups eight tiles each), the
-    direct kernels otherwise -- against im2col^T . dY."""
+    as the M side, the last 3 x 3 layer with the taps as the N side and dY shifted instead of the input (H % 8 == 0, W % 32 == 0;
+    40 x 64 x 64 gives the 80 workgroups eight tiles each), the direct kernels otherwise -- against im2col^T . dY."""
     import torch
     import avsi_amd  # noqa: F401
     from avsi_amd import ops
