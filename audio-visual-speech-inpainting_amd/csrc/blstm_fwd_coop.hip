@@ -55,7 +55,18 @@ struct CoopArgs {
     int coherent;      // AVSI_COOP_COHERENT=1: every load of exchanged bytes at device scope, whatever the invariants allow
     long long spin_ticks;   // bound of every wait for a peer, 100 MHz ticks (avsi_coop_spin_ticks)
     unsigned long long* stamps;   // diagnostics (STAMPS, avsi_diag_cs_stamps): [block < 32][step 64 .. 71][wave 0 / 1][8 phases]
+    int noack;         // fine kernels with xch: publish WITHOUT waiting for the acknowledgement of the h store; the exchange copy
+                       // was filled with COOP_POISON words before the launch and a reader that meets one loads again (see below)
 };
+
+// Poisoned exchange (AVSI_COOP_NOACK, round 5).  The per-step protocol store -> acknowledgement -> counter -> poll -> load pays
+// the acknowledgement (0.2 - 0.3 us of a 2.7 us step at 32 utterances, tools/rec_fine_stamps.py) only so that the counter cannot
+// overtake the data.  With every word of the launch's exchange copy preset to a bit pattern no h can have (all ones: a NaN
+// the arithmetic never produces -- its NaNs are the canonical 0x7fc00000 or carry their operand's payload), the counter MAY
+// overtake: a reader checks the 16 words it loaded and, if one is still the preset, loads again at device scope (an
+// incomplete line may sit in its L1 / L2 by then) until the data is there, bounded like every other wait.  Each word is
+// written once per launch, so "not the preset" means "final".
+constexpr unsigned COOP_POISON = 0xFFFFFFFFu;
 
 __device__ __forceinline__ float sigmoidf_fast(float x) { return __builtin_amdgcn_rcpf(1.f + __expf(-x)); }
 __device__ __forceinline__ float tanhf_fast(float x) { return 2.f * __builtin_amdgcn_rcpf(1.f + __expf(-2.f * x)) - 1.f; }
@@ -410,6 +421,31 @@ __global__ __launch_bounds__(512, 2) void blstm_rec_fwd_coop_fine_kernel(const C
                 for (int q = 0; q < 4; ++q) agent_load4_issue(af[q], hp + 8 * ks * QPW, 32 * q);
             }
             coherent_wait(af);
+            if (XCH && a.noack) {
+                auto poisoned = [&]() {
+                    bool bad = false;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        bad |= __float_as_uint(af[q].x) == COOP_POISON || __float_as_uint(af[q].y) == COOP_POISON ||
+                               __float_as_uint(af[q].z) == COOP_POISON || __float_as_uint(af[q].w) == COOP_POISON;
+                    return __builtin_amdgcn_ballot_w64(bad) != 0;       // one verdict per wave
+                };
+                unsigned polls = 0;
+                long long t0 = 0;
+                while (poisoned()) {
+                    const float* xp = xbase + (size_t)(step - 1) * xgroups * (32 * HP);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int unit0 = 32 * ks + 8 * q;
+                        coherent_load4_issue<false>(af[q], xp + ((unit0 / UW) * 32 + li) * UW + unit0 % UW + 4 * hi, 0);
+                    }
+                    coherent_wait(af);
+                    if (avsi_spin_expired(polls, t0, a.spin_ticks, a.sync)) {
+                        atomicExch(a.sync, 1u);       // results are void from here on; the step counters still move, nobody hangs
+                        break;
+                    }
+                }
+            }
             stamp(step, 3);
 #pragma unroll
             for (int q = 0; q < 4; ++q)
@@ -470,7 +506,10 @@ __global__ __launch_bounds__(512, 2) void blstm_rec_fwd_coop_fine_kernel(const C
         // warm buffers nor inside a training step -- kept because it is the weaker, sufficient condition.)
         stamp(step, 5);
         // (STAMPS: the stamps' own stores sit in the same queue -- the diagnostic build waits for everything)
-        if (STAMPS) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (XCH && a.noack) {
+            // no wait: the stores are issued (the barrier below orders the ISSUE of every lane's store before the counter),
+            // their acknowledgement is collected by the next step's wait for its fragment loads
+        } else if (STAMPS) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         else if (SAVE && XCH) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
         else if (SAVE) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
         else if (XCH) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
@@ -579,9 +618,14 @@ extern "C" int avsi_blstm_rec_fwd_coop_rows_f32(const float* xproj, const float*
                      ? reinterpret_cast<float*>(static_cast<char*>(workspace) + AVSI_COOP_EXCHANGE_OFFSET) : nullptr;
     // the exchange copy sits at a fixed offset: the counters of this batch must end in front of it
     if (xch && avsi_blstm_rec_fwd_coop_workspace_bytes(Bp) > AVSI_COOP_EXCHANGE_OFFSET) return AVSI_ERR_WORKSPACE;
+    // AVSI_COOP_NOACK=1 (read at every call): the exchange copy of this call preset to the poison pattern, publication without
+    // the store acknowledgement (see COOP_POISON)
+    const char* na = getenv("AVSI_COOP_NOACK");
+    const int noack = (xch && na && na[0] == '1' && !coop_coherent()) ? 1 : 0;
+    if (noack && hipMemsetAsync(xch, 0xFF, avsi_blstm_rec_fwd_coop_exchange_bytes(T, rows), st) != hipSuccess) return AVSI_ERR_LAUNCH;
     for (int tile0 = tbeg; tile0 < tiles; tile0 += per) {
         const int nt = tiles - tile0 < per ? tiles - tile0 : per;
-        CoopArgs a{xproj, whp, hout, reserve, (unsigned*)workspace, T, Bp, 2 * nt, tile0, xch, tbeg, rows / 32, coop_coherent(), avsi_coop_spin_ticks(), avsi_cs_stamps_buffer()};
+        CoopArgs a{xproj, whp, hout, reserve, (unsigned*)workspace, T, Bp, 2 * nt, tile0, xch, tbeg, rows / 32, coop_coherent(), avsi_coop_spin_ticks(), avsi_cs_stamps_buffer(), noack};
         int rc;
         if (split == 32)
             rc = reserve ? launch_coop_fine<1, true>(a, st) : launch_coop_fine<1, false>(a, st);
