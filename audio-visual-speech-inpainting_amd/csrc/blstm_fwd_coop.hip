@@ -523,6 +523,161 @@ __global__ __launch_bounds__(512, 2) void blstm_rec_fwd_coop_fine_kernel(const C
     if (member == 0 && tid == 0 && !dead) reset_counter_when_done(ctr, (unsigned)S * (unsigned)T, a.spin_ticks, a.sync);
 }
 
+// Half-row form of the 32-way kernel (round 5, split code 64; up to 64 utterances, where CUs are idle anyway): the 32 utterances
+// of a tile are two independent groups of 16 rows with 32 members each.  The stamps of the 32-row kernel
+// (tools/rec_fine_stamps.py) put the MFMA phase at 0.85 - 1.0 us of a 2.7 us step -- a CU issues 128 v_mfma_f32_32x32x2 per step,
+// two waves to a SIMD -- and a member cannot be made narrower than 8 units without doubling the fan-in of the exchange.  With 16
+// rows the product is 16 x 32 per member: v_mfma_f32_16x16x4_f32, two column tiles (gates (i, j) and (f, o) of the 8 units),
+// 16 short MFMAs per wave and step instead of 16 long ones.  Lane l = (row or column l % 16, k slot l / 16); a lane's eight k
+// values are eight CONSECUTIVE units (two 16-byte fragment loads from the exchange copy; any bijection of k works as long as
+// A and B agree), its weights 2 x 8 registers gathered once from the packed Wh.  Exchange layout [step][group][member][16 rows]
+// [8 units]; always through the exchange copy (no hout-exchange form).  128 finishing lanes: one cell each.
+template <bool SAVE>
+__global__ __launch_bounds__(512, 2) void blstm_rec_fwd_coop_half_kernel(const CoopArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* part = reinterpret_cast<float*>(smem);      // [wave][tile][column 16][row 16 (+4)]
+    __shared__ int dead;
+    constexpr int S = 32, UW = 8, PER = 4, RP = 20;
+    typedef float f32x4v __attribute__((ext_vector_type(4)));
+
+    const int xcd = blockIdx.x % AVSI_NUM_XCD, kk_ = blockIdx.x / AVSI_NUM_XCD;
+    const int member = kk_ % S;
+    const int group = (kk_ / S) * AVSI_NUM_XCD + xcd;          // (tile, half, direction) of this launch
+    if (group >= a.ngroups) return;
+    if (avsi_launch_is_void(a.sync)) return;
+    const int dir = group & 1, half = (group >> 1) & 1;
+    const int b0 = (a.tile0 + (group >> 2)) * 32 + 16 * half;
+    const int T = a.T, Bp = a.Bp;
+    const int w = member / PER, u0 = (member % PER) * UW;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int ks = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int c16 = lane & 15, kq = lane >> 4;
+    if (tid == 0) dead = 0;
+
+    // this lane's weights: Wh[k = 32 ks + 8 kq + kk][gate 2 tl + c16 / 8][unit 32 w + u0 + c16 % 8], kk = 0 .. 7
+    // whp [2][8 w][32 q][4 g][64 lane][4 s] = Wh[k = 8 q + 4 (lane / 32) + s][gate g][unit 32 w + lane % 32]
+    float4 wreg[2][2];                                  // [tile][k half]
+    {
+        const float4* wp = reinterpret_cast<const float4*>(a.whp) + (size_t)(dir * 8 + w) * (32 * 4 * 64);
+#pragma unroll
+        for (int tl = 0; tl < 2; ++tl)
+#pragma unroll
+            for (int kh = 0; kh < 2; ++kh)
+                wreg[tl][kh] = wp[((4 * ks + kq) * 4 + 2 * tl + c16 / UW) * 64 + kh * 32 + u0 + c16 % UW];
+    }
+
+    // finishing role: one cell (row frow, unit fu) per lane of the first two waves
+    const int fu = tid % UW, frow = tid / UW;
+    const bool fin = frow < 16;
+    float cstate = 0.f;
+
+    unsigned* ctr = a.sync + CTR_STRIDE * (1 + 4 * a.tile0 + group);
+    // exchange layout: [step][global group = (tile, half, direction)][32 members][16 rows][8 units]
+    const size_t xgroups = (size_t)4 * a.xtiles;
+    float* xbase = a.xch + (size_t)(4 * (a.tile0 - a.xtile0) + group) * (16 * HP);
+    __syncthreads();
+
+    for (int step = 0; step < T; ++step) {
+        const int t = dir ? (T - 1 - step) : step;
+        const size_t row0 = (size_t)t * Bp + b0;
+
+        float xz[4];
+        if (fin) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+                xz[g] = a.xproj[(row0 + frow) * (2 * GP) + dir * GP + w * 128 + g * 32 + u0 + fu];
+        }
+
+        f32x4v acc[2];
+        acc[0] = acc[1] = (f32x4v){0.f, 0.f, 0.f, 0.f};
+        if (step > 0) {
+            if (tid == 0 && !dead) {
+                const unsigned want = (unsigned)S * (unsigned)step;
+                unsigned polls = 0;
+                long long t0 = 0;
+                while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
+                    __builtin_amdgcn_s_sleep(1);
+                    if (avsi_spin_expired(polls, t0, a.spin_ticks, a.sync)) {
+                        dead = 1;
+                        atomicExch(a.sync, 1u);
+                        break;
+                    }
+                }
+            }
+            __syncthreads();
+            // units 32 ks + 8 kq .. + 7 of row c16 = block of member 4 ks + kq, row c16: 32 contiguous bytes
+            const float* xp = xbase + (size_t)(step - 1) * xgroups * (16 * HP) + ((4 * ks + kq) * 16 + c16) * UW;
+            v4f af[2];
+            if (a.coherent) {
+                coherent_load4_issue<false>(af[0], xp, 0);
+                coherent_load4_issue<false>(af[1], xp, 16);
+            } else {
+                coherent_load4_issue<true>(af[0], xp, 0);
+                coherent_load4_issue<true>(af[1], xp, 16);
+            }
+            coherent_wait(af);
+#pragma unroll
+            for (int kh = 0; kh < 2; ++kh)
+#pragma unroll
+                for (int s4 = 0; s4 < 4; ++s4) {
+                    const float av = s4 == 0 ? af[kh].x : s4 == 1 ? af[kh].y : s4 == 2 ? af[kh].z : af[kh].w;
+#pragma unroll
+                    for (int tl = 0; tl < 2; ++tl) {
+                        const float4 b = wreg[tl][kh];
+                        const float bv = s4 == 0 ? b.x : s4 == 1 ? b.y : s4 == 2 ? b.z : b.w;
+                        acc[tl] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc[tl], 0, 0, 0);
+                    }
+                }
+        }
+        // park: D[row 4 kq + i][column c16] -> part[(ks * 2 + tl) * 16 + c16][row]
+#pragma unroll
+        for (int tl = 0; tl < 2; ++tl)
+            *reinterpret_cast<float4*>(part + ((ks * 2 + tl) * 16 + c16) * RP + 4 * kq) =
+                make_float4(acc[tl][0], acc[tl][1], acc[tl][2], acc[tl][3]);
+        __syncthreads();
+
+        if (fin) {
+            float z[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                float sum = xz[g];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) sum += part[((k * 2 + g / 2) * 16 + (g % 2) * UW + fu) * RP + frow];
+                z[g] = sum;
+            }
+            const float ig = sigmoidf_fast(z[0]), jg = tanhf_fast(z[1]), fg = sigmoidf_fast(z[2]), og = sigmoidf_fast(z[3]);
+            const float cn = fg * cstate + ig * jg;
+            cstate = cn;
+            const float hn = og * tanhf_fast(cn);
+            const int unit = w * 32 + u0 + fu;
+            __hip_atomic_store(xbase + (size_t)step * xgroups * (16 * HP) + (member * 16 + frow) * UW + fu, hn, __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
+            asm volatile("" ::: "memory");      // the exchange store is ISSUED before the plain stores (counted wait below)
+            a.hout[(row0 + frow) * (2 * HP) + dir * HP + unit] = hn;
+            if (SAVE) {
+                float* rv = a.resv + (row0 + frow) * (2 * 5 * HP) + dir * 5 * HP + unit;
+                rv[0 * HP] = ig, rv[1 * HP] = jg, rv[2 * HP] = fg, rv[3 * HP] = og, rv[4 * HP] = cn;
+            }
+        }
+        if (SAVE) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (member == 0 && tid == 0 && !dead) reset_counter_when_done(ctr, (unsigned)S * (unsigned)T, a.spin_ticks, a.sync);
+}
+
+template <bool SAVE>
+int launch_coop_half(const CoopArgs& a, hipStream_t st) {
+    const size_t lds = 96 * 1024;       // > half of the CU's LDS on purpose: one workgroup per CU (the members of a group on 32 CUs)
+    (void)hipFuncSetAttribute((const void*)blstm_rec_fwd_coop_half_kernel<SAVE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    const int blocks = (int)avsi_ceil_div(a.ngroups, AVSI_NUM_XCD) * AVSI_NUM_XCD * 32;
+    hipLaunchKernelGGL((blstm_rec_fwd_coop_half_kernel<SAVE>), dim3(blocks), dim3(512), lds, st, a);
+    return avsi_launch_status();
+}
+
 template <int NT, bool SAVE, bool XCH>
 int launch_coop_fine_x(const CoopArgs& a, hipStream_t st) {
     constexpr int S = 32 / NT;
@@ -600,7 +755,7 @@ extern "C" int avsi_blstm_rec_fwd_coop_rows_f32(const float* xproj, const float*
                                                 int split, int first_row, int rows, int max_cus, void* workspace,
                                                 size_t workspace_bytes, void* stream) {
     if (!xproj || !whp || !hout || T <= 0 || Bp <= 0 || (Bp & 31)) return AVSI_ERR_INVALID_ARG;
-    if (split != 4 && split != 8 && split != 16 && split != 32) return AVSI_ERR_INVALID_ARG;
+    if (split != 4 && split != 8 && split != 16 && split != 32 && split != 64) return AVSI_ERR_INVALID_ARG;
     if (first_row < 0 || rows <= 0 || (first_row & 31) || (rows & 31) || first_row + rows > Bp) return AVSI_ERR_INVALID_ARG;
     if (!workspace || workspace_bytes < avsi_blstm_rec_fwd_coop_workspace_bytes(Bp)) return AVSI_ERR_WORKSPACE;
     if (coop_tiles_per_launch(split, max_cus) < 1) return AVSI_ERR_UNSUPPORTED;   // 2 * split workgroups do not fit max_cus
@@ -618,6 +773,7 @@ extern "C" int avsi_blstm_rec_fwd_coop_rows_f32(const float* xproj, const float*
                      ? reinterpret_cast<float*>(static_cast<char*>(workspace) + AVSI_COOP_EXCHANGE_OFFSET) : nullptr;
     // the exchange copy sits at a fixed offset: the counters of this batch must end in front of it
     if (xch && avsi_blstm_rec_fwd_coop_workspace_bytes(Bp) > AVSI_COOP_EXCHANGE_OFFSET) return AVSI_ERR_WORKSPACE;
+    if (split == 64 && !xch) return AVSI_ERR_WORKSPACE;        // the half-row kernel has no form that exchanges through hout
     // AVSI_COOP_NOACK=1 (read at every call): the exchange copy of this call preset to the poison pattern, publication without
     // the store acknowledgement (see COOP_POISON)
     const char* na = getenv("AVSI_COOP_NOACK");
@@ -627,7 +783,11 @@ extern "C" int avsi_blstm_rec_fwd_coop_rows_f32(const float* xproj, const float*
         const int nt = tiles - tile0 < per ? tiles - tile0 : per;
         CoopArgs a{xproj, whp, hout, reserve, (unsigned*)workspace, T, Bp, 2 * nt, tile0, xch, tbeg, rows / 32, coop_coherent(), avsi_coop_spin_ticks(), avsi_cs_stamps_buffer(), noack};
         int rc;
-        if (split == 32)
+        if (split == 64) {
+            a.ngroups = 4 * nt;                               // (tile, half, direction)
+            a.noack = 0;
+            rc = reserve ? launch_coop_half<true>(a, st) : launch_coop_half<false>(a, st);
+        } else if (split == 32)
             rc = reserve ? launch_coop_fine<1, true>(a, st) : launch_coop_fine<1, false>(a, st);
         else if (split == 16)
             rc = reserve ? launch_coop_fine<2, true>(a, st) : launch_coop_fine<2, false>(a, st);

@@ -326,6 +326,10 @@ def coop_split(Bp, backward=False):
         # (beyond 2048 the 4-way kernel's launches of 1024 utterances, ~6.5 ms each per layer, add up to what the
         # batch-stationary BPTT kernel takes for any batch up to 8192: 3072 utterances 179.6 against 178.5 ms per step)
         split = 32 if Bp <= 128 else (16 if Bp <= 256 else (8 if Bp <= 512 else (4 if Bp <= 2048 else 0)))
+    elif Bp <= 64 and _COOP_EXCHANGE and os.environ.get('AVSI_REC_HALF', '1') != '0':
+        # round 5: the 32-way kernel on 16-row halves (two groups per tile and direction: 128 workgroups per 32 utterances) --
+        # the MFMA phase of a step halves; up to 64 utterances the CUs are there (0.68 -> 0.58 ms per layer at 32)
+        split = 64
     elif Bp <= 128:
         split = 32
     elif Bp <= 256:

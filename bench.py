@@ -331,8 +331,8 @@ def dp_train_block(torch, dist, models, ops, ap_mod, cfg, device, rank, world):
     asynchronous all-reduce buckets behind each layer's weight-gradient kernels, 1 / world inside the fused Adam).
     `ranks_bit_identical`: elementwise MAX and MIN over ranks of the int32 view of every rank's variables agree, i.e.
     all ranks hold the same bits.  Then rank 0 repeats the same global batch ALONE (parallel.solo(): no collective;
-    its peers wait at a barrier): `max_abs_diff_vs_single_process` must stay under 2e-5 (summation order only, the bar of
-    tests/test_dp_gpu.py), `max_abs_update` shows the three steps moved the weights by two orders of magnitude more.
+    its peers wait at a barrier): `max_abs_diff_vs_single_process` must stay under `bar` (summation order only; tests/test_dp_gpu.py
+    holds the same-kernel-family case to 2e-5), `max_abs_update` shows the three steps moved the weights by two orders of magnitude more.
 
     Timings, each the driver's way (barrier + synchronize on both sides, max over ranks), same keys at every N:
     `weak_32_per_gpu` (per-GPU batch fixed at 32: global 32 N -- what north_star's >= 0.85 scaling is claimed for) and
@@ -407,10 +407,15 @@ def dp_train_block(torch, dist, models, ops, ap_mod, cfg, device, rank, world):
             with parallel.solo():
                 ref, _, ref_losses = three_steps(G, wav, masks, video)
             check["max_abs_diff_vs_single_process"] = float((ref - flat).abs().max())
-            check["bar"] = 2e-5
+            # 2e-4 since round 5 (2e-5 before): the ranks' 32 utterances run the forward recurrence on the half-row kernel
+            # (v_mfma_f32_16x16x4), the single process at 32 x world utterances on the 32- / 16-way kernels (32x32x2): another
+            # order of the 256-long sums, and three Adam steps amplify the last bits of small gradients (measured 5.5e-5 at
+            # world 2; 3e-8 when both sides run the same kernel family).  A wrong 1 / world or a missed bucket moves the
+            # weights by the size of an update, >= 1e-3
+            check["bar"] = 2e-4
             check["loss_max_rel_diff_vs_single_process"] = float(((mean_losses - ref_losses.double()).abs()
                                                                   / ref_losses.double().abs()).max())
-            check["ok"] = bool(check["ranks_bit_identical"] and check["max_abs_diff_vs_single_process"] < 2e-5)
+            check["ok"] = bool(check["ranks_bit_identical"] and check["max_abs_diff_vs_single_process"] < check["bar"])
             del ref
         dist.barrier()
     else:

@@ -181,6 +181,9 @@ int avsi_l1_loss_f32(const float* target, const float* pred, const float* mask, 
  * number of compute units the caller grants one launch: a process that keeps other kernels in flight beside the
  * recurrence (RCCL collectives of data-parallel training, batches on other streams) passes what is left, and the
  * launches are cut to fit; AVSI_ERR_UNSUPPORTED when not even one tile (2 * split workgroups) fits.
+ * `split` = 64: the 32-way form on two independent 16-row halves per tile (64 workgroups per (tile, direction): two tiles per
+ * launch on the whole chip; v_mfma_f32_16x16x4_f32, half the matrix work per workgroup and step).  It exchanges through the
+ * exchange copy only: AVSI_ERR_WORKSPACE without the optional part of the workspace described below.
  * The workspace is zeroed ONCE by the caller, when it is allocated: word 0 is a STICKY status that no call clears,
  * the counters behind it (one 256-byte line each) are put back to zero by the kernels themselves when a launch ends,
  * so consecutive calls on one stream need nothing in between.  Once the stream has drained, a non-zero word 0 means
@@ -195,7 +198,9 @@ size_t avsi_blstm_rec_fwd_coop_workspace_bytes(int Bp);
 /* Optional: a workspace of AVSI_COOP_EXCHANGE_OFFSET + avsi_blstm_rec_fwd_coop_exchange_bytes(T, Bp) bytes lets the
  * forward call with split 16 / 32 exchange h through a copy in a layout of its own (whole-line stores, contiguous
  * fragment loads: 0.86 -> 0.78 ms per layer at 32 utterances on buffers no cache holds).  The copy lives at that FIXED
- * offset, clear of the counters of any batch size, and needs no initialisation.  Results are identical. */
+ * offset, clear of the counters of any batch size, and needs no initialisation.  Results are identical.
+ * (AVSI_COOP_NOACK=1 in the environment, opt-in: the call presets the copy to an all-ones pattern itself and the members
+ * publish without waiting for their store's acknowledgement -- a reader re-loads words that still hold the pattern.) */
 #define AVSI_COOP_EXCHANGE_OFFSET ((size_t)1 << 20)
 size_t avsi_blstm_rec_fwd_coop_exchange_bytes(int T, int Bp);
 /* The same for avsi_blstm_rec_bwd_coop_f32 with split 16 / 32 (dz in exchange layout; same offset, the two calls may

@@ -206,6 +206,7 @@ def test_feed_reuses_model_and_variables(mods):
                                            (1056, 4, False), (544, 8, True),    # these two: more than one resident-sized launch
                                            (32, 16, False), (256, 16, True), (288, 16, False),   # finer splits: 16 / 8 units per
                                            (64, 32, True), (160, 32, False),                      # workgroup (288, 160: two launches)
+                                           (32, 64, False), (64, 64, True), (160, 64, False),     # 32-way on 16-row halves (160: three launches)
                                            # column-split kernel (avsi_blstm_rec_fwd_cs_f32): 16 / 32 utterances per group
                                            (32, -32, False), (64, -16, True), (512, -16, False), (1024, -32, True),
                                            (1088, -32, False), (544, -16, True),                  # these two: two launches
@@ -234,7 +235,7 @@ def test_cooperative_small_batch_kernel_matches_batch_stationary(Bp, split, save
         np.testing.assert_allclose(outs[1][1].cpu().numpy(), outs[0][1].cpu().numpy(), rtol=0, atol=5e-5)
     for name in ('AVSI_REC_CS', 'AVSI_COOP_CUS', 'AVSI_REC_COOP'):      # the default policy, whatever the caller's switches
         monkeypatch.delenv(name, raising=False)
-    assert ops.coop_split(32) == 32 and ops.coop_split(32, backward=True) == 32 and ops.coop_split(256) == 16
+    assert ops.coop_split(32) == 64 and ops.coop_split(128) == 32 and ops.coop_split(32, backward=True) == 32 and ops.coop_split(256) == 16
     assert ops.coop_split(256, backward=True) == 16 and ops.coop_split(512, backward=True) == 8
     assert ops.coop_split(512) == -16 and ops.coop_split(1024) == -32 and ops.coop_split(2048) == -32 and ops.coop_split(4096) == 0
 

@@ -133,6 +133,59 @@ def test_exchange_layout_gives_the_same_result(Bp, split, save, monkeypatch):
     np.testing.assert_allclose(outs[0][0].cpu().numpy(), ref.cpu().numpy(), rtol=0, atol=2e-5)
 
 
+@pytest.mark.parametrize("Bp,save", [(32, False), (64, True), (96, False)])
+def test_half_row_kernel_equals_the_32_way_kernel(Bp, save):
+    """Split code 64 (the 32-way kernel on two independent 16-row halves per tile, v_mfma_f32_16x16x4_f32): the same reduction
+    order per (row, unit) as the 32-row kernel -- eight waves' partial sums added in wave order -- but another MFMA shape, so
+    equal to 2e-6, not to the bit; 96 utterances run as two launches (two tiles, then one).  Twice into the same buffers."""
+    import torch
+    import avsi_amd  # noqa: F401
+    from avsi_amd import ops
+    T = 21
+    g = torch.Generator(device='cuda')
+    g.manual_seed(Bp)
+    xproj = torch.randn(T, Bp, 2048, generator=g, device='cuda')
+    whp = torch.randn(2 * 262144, generator=g, device='cuda') * 0.05
+    outs = []
+    for split in (64, 32):
+        hout = torch.full((T, Bp, 512), 7.0, device='cuda')
+        resv = torch.full((T, Bp, 2, 5, 256), 7.0, device='cuda') if save else None
+        for k in range(2):
+            ops.blstm_rec_fwd(xproj if k else xproj * 0.5, whp, hout, resv, split=split)
+        outs.append((hout, resv))
+    ops.coop_check()
+    np.testing.assert_allclose(outs[0][0].cpu().numpy(), outs[1][0].cpu().numpy(), rtol=0, atol=2e-6)
+    if save:
+        np.testing.assert_allclose(outs[0][1].cpu().numpy(), outs[1][1].cpu().numpy(), rtol=0, atol=5e-6)
+
+
+@pytest.mark.parametrize("Bp,split,save", [(32, 32, False), (96, 32, True), (64, 16, False), (288, 16, True)])
+def test_publication_without_the_store_acknowledgement_is_bit_identical(Bp, split, save, monkeypatch):
+    """AVSI_COOP_NOACK=1 (opt-in, round 5): the exchange copy is preset to a poison pattern, members publish without waiting for
+    the acknowledgement of their h store, a reader that meets a poisoned word loads again at device scope.  Same arithmetic,
+    same order: identical bits, also into buffers that hold another input's results (no stale line, no stale poison)."""
+    import torch
+    import avsi_amd  # noqa: F401
+    from avsi_amd import ops
+    T = 23
+    g = torch.Generator(device='cuda')
+    g.manual_seed(Bp + split + 1)
+    xproj = torch.randn(T, Bp, 2048, generator=g, device='cuda')
+    whp = torch.randn(2 * 262144, generator=g, device='cuda') * 0.05
+    outs = []
+    for noack in ('0', '1'):
+        monkeypatch.setenv('AVSI_COOP_NOACK', noack)
+        hout = torch.full((T, Bp, 512), 7.0, device='cuda')
+        resv = torch.full((T, Bp, 2, 5, 256), 7.0, device='cuda') if save else None
+        for k in range(3):
+            ops.blstm_rec_fwd(xproj if k == 2 else xproj * (0.25 + 0.25 * k), whp, hout, resv, split=split)
+        outs.append((hout, resv))
+    ops.coop_check()
+    assert torch.equal(outs[0][0], outs[1][0])
+    if save:
+        assert torch.equal(outs[0][1], outs[1][1])
+
+
 @pytest.mark.parametrize("Bp,split", [(32, 32), (160, 32), (64, 16), (288, 16)])
 def test_exchange_layout_gives_the_same_bptt_result(Bp, split, monkeypatch):
     """The fine BPTT kernels with dz exchanged through the copy in exchange layout against the same kernels exchanging

@@ -10,8 +10,12 @@ def test_cooperative_split_policy(monkeypatch):
     fwd = {b: ops.coop_split(b) for b in (32, 64, 96, 128, 160, 256, 288, 512, 544, 2048, 2080, 3584, 3616)}
     # < 0: the column-split kernel, that many utterances per group of 8 workgroups, two workgroups to a CU
     # ... up to 3584 utterances, in resident-sized launches: beyond, the batch-stationary kernels fill the chip
-    assert fwd == {32: 32, 64: 32, 96: 32, 128: 32, 160: 16, 256: 16, 288: -16, 512: -16, 544: -32, 2048: -32, 2080: -32,
+    # 64: the 32-way kernel on 16-row halves (128 workgroups per 32 utterances), up to 64 utterances
+    assert fwd == {32: 64, 64: 64, 96: 32, 128: 32, 160: 16, 256: 16, 288: -16, 512: -16, 544: -32, 2048: -32, 2080: -32,
                    3584: -32, 3616: 0}
+    monkeypatch.setenv('AVSI_REC_HALF', '0')
+    assert ops.coop_split(32) == 32 and ops.coop_split(64) == 32
+    monkeypatch.delenv('AVSI_REC_HALF')
     bwd = {b: ops.coop_split(b, backward=True) for b in (32, 128, 160, 512, 544, 2048, 2080, 4096)}
     assert bwd == {32: 32, 128: 32, 160: 16, 512: 8, 544: 4, 2048: 4, 2080: 0, 4096: 0}
     # every single-launch choice fits the chip: members = 2 directions x tiles x split <= 256 CUs
@@ -41,7 +45,7 @@ def test_cu_budget_leaves_room_for_concurrent_collectives(monkeypatch):
         for b in range(32, 2049, 32):
             for back in (False, True):
                 s = ops.coop_split(b, back)
-                assert s in (4, 8, 16, 32, -16, -32) and 2 * abs(s) <= 224
+                assert s in (4, 8, 16, 32, 64, -16, -32) and 2 * abs(s) <= 224
                 if b <= 384:
                     assert (2 * (b // 32) * s <= 224) if s > 0 else (2 * (b // -s) * 8 <= 2 * 224), (b, back, s)
         ops.set_coop_cu_budget(40)
@@ -125,7 +129,7 @@ def test_fall_back_levels_cap_the_split_then_disable_the_cooperative_kernels(mon
         monkeypatch.delenv(name, raising=False)
     ops.set_coop_cu_budget(256)
     try:
-        assert ops.coop_level() == 0 and ops.coop_split(32) == 32 and ops.coop_split(256) == 16
+        assert ops.coop_level() == 0 and ops.coop_split(32) == 64 and ops.coop_split(128) == 32 and ops.coop_split(256) == 16
         assert ops.coop_split(32, backward=True) == 32 and ops.coop_split(512) == -16
         ops._COOP_FALLBACKS.append('test')
         assert ops.coop_level() == 1 and not ops.coop_disabled()

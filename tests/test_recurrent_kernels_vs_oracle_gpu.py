@@ -1,6 +1,6 @@
 """Every recurrent kernel family against the CPU oracle DIRECTLY (oracle/blstm.py: the explicit per-step loop of
 reference models.py:106-115 in float64, and its manual BPTT), not through another HIP kernel: the batch-stationary
-kernels, the reduction-split cooperative kernels (4, 8, 16, 32 workgroups per tile), the column-split kernel (16 / 32
+kernels, the reduction-split cooperative kernels (4, 8, 16, 32 workgroups per tile, 32 per 16-row half-tile), the column-split kernel (16 / 32
 utterances per group), forward and BPTT -- the kernels `ops.coop_split` / `ops.rec_fwd_parts` choose between 32 and 8192
 utterances -- and the whole model at batch sizes that take the column-split kernel and the pieces path."""
 import numpy as np
@@ -53,7 +53,8 @@ def _packed_gate_columns(dz_dir):
 
 # (utterances, split): 0 = batch-stationary (rows_per_wg picks the 32-row or the 64-row ping-pong kernel), > 0 = workgroups per
 # tile of the reduction-split cooperative kernels, < 0 = column-split kernel with that many utterances per group
-FWD_KINDS = [(37, 0, 32), (70, 0, 64), (37, 4, 0), (70, 8, 0), (37, 16, 0), (70, 32, 0), (37, -16, 0), (70, -32, 0)]
+FWD_KINDS = [(37, 0, 32), (70, 0, 64), (37, 4, 0), (70, 8, 0), (37, 16, 0), (70, 32, 0), (37, -16, 0), (70, -32, 0),
+             (37, 64, 0), (70, 64, 0)]        # 64: the 32-way kernel on 16-row halves (round 5)
 
 
 @pytest.mark.parametrize("B,split,rows_per_wg", FWD_KINDS)

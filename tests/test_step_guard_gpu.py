@@ -116,7 +116,7 @@ def test_a_cooperative_timeout_voids_the_step_and_the_fall_back_repeats_it(monke
     ops.set_coop_cu_budget(None)
     monkeypatch.setattr(ops, 'COOP_POLL_RAISES', False)         # the guard decides, as in the trainer
     B = 32
-    assert ops.coop_split(B) == 32 and ops.coop_split(B, backward=True) == 32
+    assert ops.coop_split(B) == 64 and ops.coop_split(B, backward=True) == 32      # forward: the 32-way kernel on 16-row halves
     m, feed = _model(B)
     m.feed(**feed)
     m.train_op                                  # step 1: 32-way cooperative kernels, nothing in their way
