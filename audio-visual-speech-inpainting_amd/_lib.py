@@ -68,6 +68,9 @@ PROTOTYPES = {
     "avsi_frontend_table_floats": (c_size_t, [c_int, c_int]),
     "avsi_frontend_init_tables": (c_int, [c_void_p, c_int, c_int, c_void_p]),
     "avsi_frontend_f32": (c_int, [POINTER(FrontendArgs), c_void_p]),
+    "avsi_frontend_l1_loss_supported": (c_int, [POINTER(FrontendArgs)]),
+    "avsi_frontend_l1_loss_f32": (c_int, [POINTER(FrontendArgs), c_void_p, c_int64, c_int64, c_void_p, c_float, c_void_p, c_void_p, c_size_t,
+                                          c_void_p]),
     "avsi_gemm_f32": (c_int, [c_int, c_int, c_int, c_int, c_int, c_float, c_void_p, c_int64, c_void_p, c_int64,
                               c_float, c_void_p, c_int64, POINTER(GemmEpilogue), c_void_p]),
     "avsi_pack_bf16x3_b_bytes": (c_size_t, [c_int, c_int]),

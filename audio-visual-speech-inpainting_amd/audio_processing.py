@@ -82,6 +82,57 @@ def _mel_bands(device, num_mel_bins, num_spec_bins, sample_rate, lower, upper):
     return hit
 
 
+_FE_LOSS_WS = {}
+
+
+def frontend_l1_loss(sources, pred, masks, mean, std, sample_rate=16000, window_size=24, step_size=12, n_fft=512,
+                     want_grad=False, grad_scale=None, eps=1e-6):
+    """(out3, dpred) as ops.l1_loss(target_spec_norm, pred, masks) -- with the normalised target spectrogram recomputed from the
+    waveform INSIDE the kernel (avsi_frontend_l1_loss_f32) instead of read from memory: the step's front-end call then has no
+    reason to write it.  pred [B, T, 257] (last dimension contiguous), masks [B, >= T, 257].  Returns None when the C side does
+    not take the geometry (the caller uses the stored target then)."""
+    _lib.require_cuda(sources, pred, masks, mean, std)
+    L = _lib.lib()
+    if sources.dtype != torch.float32 or sources.dim() != 2 or pred.dtype != torch.float32 or pred.dim() != 3:
+        raise _lib.AvsiError("frontend_l1_loss: sources float32 [B, N], pred float32 [B, T, 257]")
+    if sources.stride(1) != 1:
+        sources = sources.contiguous()
+    if pred.stride(2) != 1:
+        pred = pred.contiguous()
+    dev = sources.device
+    B, N = sources.shape
+    T, F = int(pred.shape[1]), int(pred.shape[2])
+    a = _lib.FrontendArgs()
+    a.wav, a.batch, a.num_samples, a.wav_stride = _lib.ptr(sources), B, N, sources.stride(0) if B > 1 else N
+    a.frame_len, a.hop = ms_to_samples(window_size, sample_rate), ms_to_samples(step_size, sample_rate)
+    a.nfft, a.num_frames, a.num_bins = n_fft, T, F
+    tab = _tables(dev, a.frame_len, n_fft)
+    a.table = _lib.ptr(tab)
+    mean, std = mean.to(torch.float32).contiguous(), std.to(torch.float32).contiguous()
+    a.mean, a.stdev = _lib.ptr(mean), _lib.ptr(std)
+    if masks.dtype != torch.float32 or masks.stride(2) != 1:
+        masks = masks.to(torch.float32).contiguous()
+    a.mask, a.mask_stride_b, a.mask_stride_t = _lib.ptr(masks), masks.stride(0), masks.stride(1)
+    a.spec_power, a.log_spec, a.eps = 1.0, 1, float(eps)
+    if pred.shape[0] != B or masks.shape[0] != B or masks.shape[1] < T or masks.shape[2] != F \
+            or not L.avsi_frontend_l1_loss_supported(ctypes.byref(a)):
+        return None
+    key = (dev.index, _lib.stream_ptr().value)
+    ws = _FE_LOSS_WS.get(key)
+    need = L.avsi_l1_loss_workspace_bytes(B * T * F)
+    if ws is None or ws.numel() * 4 < need:
+        ws = _FE_LOSS_WS[key] = torch.empty((need + 3) // 4, dtype=torch.float32, device=dev)
+    out3 = torch.empty(3, dtype=torch.float32, device=dev)
+    dpred = torch.empty((B, T, F), dtype=torch.float32, device=dev) if want_grad else None
+    if dpred is not None and (dpred.stride(0), dpred.stride(1)) != (pred.stride(0), pred.stride(1)):
+        pred = pred.contiguous()               # dpred shares pred's strides in the kernel
+    gs = (1.0 / (B * T * F)) if grad_scale is None else float(grad_scale)
+    _lib.check(L.avsi_frontend_l1_loss_f32(ctypes.byref(a), _lib.ptr(pred), pred.stride(0), pred.stride(1), _lib.ptr(dpred), gs,
+                                           _lib.ptr(out3), _lib.ptr(ws), ws.numel() * 4, _lib.stream_ptr()),
+               "avsi_frontend_l1_loss_f32")
+    return out3, dpred
+
+
 def frontend(sources, sample_rate=16000, window_size=24, step_size=12, n_fft=512,
              num_frames_out=None, num_bins=None, mean=None, std=None, masks=None,
              want_stft=False, want_spec=False, want_feat=False, want_logmel=False,

@@ -60,9 +60,26 @@ __global__ void frontend_tables_kernel(float* tab, int frame_len) {
 // MODEL: the inpainter's own call (models.py:30-35) -- nfft 512, >= 256 bins, normalised log-magnitude spectrum AND
 // masked features out, mask given, no complex / log-mel output: every store and every mask load of the epilogue is
 // unconditional, so the compiler sees straight-line code and can count the stores it may leave in flight.
-template <int NB, int WR, int OCC, bool STEP1, bool MODEL>
+// MD (round 5): 0 = the generic kernel; 1 = MODEL as above; 2 = MODEL without the un-masked target output -- the masked
+// features are the ONLY store, the kernel moves exactly its 706 kB per utterance; 3 = the L1 loss of the step taken HERE
+// (avsi_frontend_l1_loss_f32): the same transform of the same samples, but instead of storing anything the epilogue loads
+// the prediction where the target would have gone and accumulates sum|t - p|, sum|t - p|(1 - m), sum(1 - m), sum|t - p| m,
+// sum m (and stores d loss / d prediction when asked).  Together, modes 2 and 3 replace "write the target (257 kB per
+// utterance) at the start of the step, read it back in the loss kernel at its end" by a second read of the waveform (192 kB).
+struct FeLoss {
+    const float* pred;        // [B][T][257] prediction (mode 3)
+    int64_t stride_b, stride_t;
+    float* dpred;             // same layout, optional: sign(p - t) * gscale
+    float gscale;
+    float* part;              // [gridDim.x][5] partial sums
+};
+
+template <int NB, int WR, int OCC, bool STEP1, int MD>
 __global__ __launch_bounds__(TPB, OCC) void frontend_kernel(const avsi_frontend_args a, const int tiles_per_utt,
-                                                         const int n_tiles, const int seg_floats, const int step_arg) {
+                                                         const int n_tiles, const int seg_floats, const int step_arg,
+                                                         const FeLoss lo) {
+    constexpr bool MODEL = MD != 0;
+    constexpr bool LOSS = MD == 3;
     const int step = STEP1 ? 1 : step_arg;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* s_wav = reinterpret_cast<float*>(smem);
@@ -125,8 +142,8 @@ __global__ __launch_bounds__(TPB, OCC) void frontend_kernel(const avsi_frontend_
     const float istd_n = (have_norm && F > col_n) ? 1.f / a.stdev[col_n] : 1.f;
     const bool want_pow = !MODEL && a.out_logmel != nullptr;
     const bool has_stft = !MODEL && a.out_stft != nullptr;
-    const bool has_spec = MODEL || a.out_spec != nullptr;
-    const bool has_feat = MODEL || a.out_feat != nullptr;
+    const bool has_spec = MD == 1 || (!MODEL && a.out_spec != nullptr);
+    const bool has_feat = MODEL || a.out_feat != nullptr;        // (mode 3 stores no features but wants their mask values)
     const bool has_mask = MODEL || a.mask != nullptr;
     const float spec_power = MODEL ? 1.f : a.spec_power;
     const bool log_spec = MODEL || a.log_spec;
@@ -134,6 +151,7 @@ __global__ __launch_bounds__(TPB, OCC) void frontend_kernel(const avsi_frontend_
     // Software pipeline over tiles: the NEXT tile's samples are fetched into registers while the
     // current tile is transformed, and the current tile's mask values are fetched before the FFT and
     // consumed after it, so neither HBM latency sits on the critical path of a tile.
+    float ls_all = 0.f, ls_hole = 0.f, ln_hole = 0.f, ls_valid = 0.f, ln_valid = 0.f;      // mode 3: this thread's partial sums
     float4 wreg[WR];
     // BRANCH-FREE on purpose: with a per-lane `if (in range) load` the loads sat in divergent blocks and the
     // compiler closed every one of them with s_waitcnt vmcnt(0) -- four serialised HBM round trips per tile
@@ -215,12 +233,24 @@ __global__ __launch_bounds__(TPB, OCC) void frontend_kernel(const avsi_frontend_
         // this tile's mask values: requested here, in flight during the second FFT and the barrier, consumed by the
         // epilogue (requested before the first FFT they were 16 more registers alive across both)
         float mk[4][4], mkn[4];
+        float pp[4][4], ppn[4];                    // mode 3: the prediction at this thread's bins, fetched like the mask
 #pragma unroll
         for (int fi = 0; fi < 4; ++fi) {
             const int t = t0 + fg * 4 + fi;
             mkn[fi] = 1.f;
+            ppn[fi] = 0.f;
             if (MODEL && t < T)       // Nyquist column of the mask (one address per frame: a broadcast load)
                 mkn[fi] = a.mask[(int64_t)b * a.mask_stride_b + (int64_t)t * a.mask_stride_t + 256];
+            if (LOSS) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) pp[fi][j] = 0.f;
+                if (t < T) {
+                    const float* pr = lo.pred + (int64_t)b * lo.stride_b + (int64_t)t * lo.stride_t;
+                    ppn[fi] = pr[256];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) pp[fi][j] = pr[kq + 64 * j];
+                }
+            }
 #pragma unroll
             for (int j = 0; j < 4; ++j) mk[fi][j] = 1.f;
             if (has_feat && has_mask && t < T) {       // wave-uniform; the loads themselves branch-free
@@ -252,6 +282,14 @@ __global__ __launch_bounds__(TPB, OCC) void frontend_kernel(const avsi_frontend_
             if (MODEL) {
 #pragma unroll
                 for (int fi = 0; fi < 4; ++fi) asm volatile("v_mov_b32 %0, %0" : "+v"(mkn[fi])::"memory");
+            }
+            if (LOSS) {
+#pragma unroll
+                for (int fi = 0; fi < 4; ++fi) {
+                    asm volatile("v_mov_b32 %0, %0" : "+v"(ppn[fi])::"memory");
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) asm volatile("v_mov_b32 %0, %0" : "+v"(pp[fi][j])::"memory");
+                }
             }
         }
         const bool all_live = MODEL || (STEP1 && F >= 256);        // wave-uniform: every bin of every lane is stored
@@ -295,7 +333,7 @@ __global__ __launch_bounds__(TPB, OCC) void frontend_kernel(const avsi_frontend_
 #pragma unroll
                     for (int j = 0; j < 4; ++j) o1[kq + 64 * j] = sp[j];
                 }
-                if (has_feat) {
+                if (has_feat && !LOSS) {
 #pragma unroll
                     for (int j = 0; j < 4; ++j) o3[kq + 64 * j] = sp[j] * mk[fi][j];
                 }
@@ -304,8 +342,22 @@ __global__ __launch_bounds__(TPB, OCC) void frontend_kernel(const avsi_frontend_
                     // by the frame's own wave: lane 0 owns column 256, lanes 1 .. feat_cols - 257 the padding
                     const cf z0 = zrow[0];
                     const float svn = (__logf(fabsf(z0.r - z0.i) + a.eps) - mean_n) * istd_n;
-                    if (kq == 0) o1[256] = svn;
-                    if (kq < a.feat_cols - 256) o3[256 + kq] = kq == 0 ? svn * mkn[fi] : 0.f;
+                    if (MD == 1 && kq == 0) o1[256] = svn;
+                    if (!LOSS && kq < a.feat_cols - 256) o3[256 + kq] = kq == 0 ? svn * mkn[fi] : 0.f;
+                    if (LOSS) {
+                        float* dp = lo.dpred ? lo.dpred + (int64_t)b * lo.stride_b + (int64_t)t * lo.stride_t : nullptr;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const float d = pp[fi][j] - sp[j], e = fabsf(d), m = mk[fi][j];
+                            ls_all += e, ls_hole += e * (1.f - m), ln_hole += 1.f - m, ls_valid += e * m, ln_valid += m;
+                            if (dp) dp[kq + 64 * j] = d > 0.f ? lo.gscale : (d < 0.f ? -lo.gscale : 0.f);
+                        }
+                        if (kq == 0) {
+                            const float d = ppn[fi] - svn, e = fabsf(d), m = mkn[fi];
+                            ls_all += e, ls_hole += e * (1.f - m), ln_hole += 1.f - m, ls_valid += e * m, ln_valid += m;
+                            if (dp) dp[256] = d > 0.f ? lo.gscale : (d < 0.f ? -lo.gscale : 0.f);
+                        }
+                    }
                 }
             } else {
                 if (a.out_stft) {
@@ -373,6 +425,20 @@ __global__ __launch_bounds__(TPB, OCC) void frontend_kernel(const avsi_frontend_
         }
         AVSI_LDS_BARRIER();  // LDS is re-staged by the next tile
     }
+    if (LOSS) {
+        // one partial row per workgroup: wave shuffle trees, then the four waves in order (fixed order: deterministic)
+        __shared__ float red[TPB / 64][5];
+        float v5[5] = {ls_all, ls_hole, ln_hole, ls_valid, ln_valid};
+#pragma unroll
+        for (int k = 0; k < 5; ++k)
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) v5[k] += __shfl_xor(v5[k], o, 64);
+        if ((tid & 63) == 0)
+#pragma unroll
+            for (int k = 0; k < 5; ++k) red[tid >> 6][k] = v5[k];
+        __syncthreads();
+        if (tid < 5) lo.part[blockIdx.x * 5 + tid] = (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
+    }
 }
 
 }  // namespace
@@ -390,9 +456,11 @@ extern "C" int avsi_frontend_init_tables(float* table, int frame_len, int nfft, 
     return avsi_launch_status();
 }
 
-extern "C" int avsi_frontend_f32(const avsi_frontend_args* args, void* stream) {
-    if (!args) return AVSI_ERR_INVALID_ARG;
-    const avsi_frontend_args& a = *args;
+// internal (loss.hip): out3 <- the five sums of `nblocks` partial rows (double, fixed order)
+int avsi_l1_final_launch(const float* part, int nblocks, int64_t n, float* out3, hipStream_t st);
+
+// mode: 0 = what the arguments ask for (avsi_frontend_f32); 3 = the loss form (avsi_frontend_l1_loss_f32)
+static int frontend_launch(const avsi_frontend_args& a, int mode, const FeLoss& lo, int* grid_out, void* stream) {
     if (!a.wav || !a.table || a.batch <= 0 || a.num_samples <= 0 || a.wav_stride < a.num_samples)
         return AVSI_ERR_INVALID_ARG;
     if ((a.nfft != 512 && a.nfft != 256) || a.frame_len <= 0 || a.frame_len > a.nfft || (a.frame_len & 1) ||
@@ -411,7 +479,7 @@ extern "C" int avsi_frontend_f32(const avsi_frontend_args* args, void* stream) {
     if (a.out_logmel) {
         if (a.num_mel <= 0 || !a.mel_start || !a.mel_len || !a.mel_w || a.mel_w_stride <= 0) return AVSI_ERR_INVALID_ARG;
     }
-    if (!a.out_stft && !a.out_spec && !a.out_feat && !a.out_logmel) return AVSI_OK;
+    if (mode != 3 && !a.out_stft && !a.out_spec && !a.out_feat && !a.out_logmel) return AVSI_OK;
 
     const int nb_need = (a.frame_len + 31) / 32;
     const int nb = nb_need <= 8 ? 8 : (nb_need <= 12 ? 12 : 16);  // template instance actually launched
@@ -427,14 +495,19 @@ extern "C" int avsi_frontend_f32(const avsi_frontend_args* args, void* stream) {
     // traffic (two outputs + mask + samples), and a third workgroup per CU only adds concurrent streams.
     // AVSI_FE_OCC=3: diagnostics.
     const bool small = seg <= 4 * TPB * 4;
-    // the inpainter's own call (see the MODEL template flag)
-    const bool model = small && step == 1 && a.num_bins == 257 && a.out_spec && a.out_feat && a.mask && a.mean && !a.out_stft &&
-                       !a.out_logmel && a.spec_power == 1.f && a.log_spec && a.feat_cols >= 257 && a.feat_cols <= 256 + 64;
+    // the inpainter's own shapes (see the MD template flag); which outputs are asked for picks the mode
+    const bool model_shape = small && step == 1 && a.num_bins == 257 && a.mask && a.mean && !a.out_stft && !a.out_logmel &&
+                             a.spec_power == 1.f && a.log_spec;
+    const bool feat_ok = a.out_feat && a.feat_cols >= 257 && a.feat_cols <= 256 + 64;
+    const bool model = mode != 3 && model_shape && a.out_spec && feat_ok;
+    const bool model_feat_only = mode != 3 && model_shape && !a.out_spec && feat_ok && nb == 12;     // mode 2: 24 ms frames only
+    if (mode == 3 && !(model_shape && nb == 12)) return AVSI_ERR_UNSUPPORTED;
     static const bool env_occ3 = getenv("AVSI_FE_OCC") && atoi(getenv("AVSI_FE_OCC")) == 3;      // diagnostics, read once
     const int occ = (model && nb == 12 && env_occ3) ? 3 : 2;
     const int by_lds = (int)(156 * 1024 / (lds + 4352));       // + the static constant tables
     const int wg_per_cu = by_lds > occ ? occ : (by_lds < 1 ? 1 : by_lds);
     const int grid = n_tiles < AVSI_NUM_CU * wg_per_cu ? n_tiles : AVSI_NUM_CU * wg_per_cu;
+    if (grid_out) *grid_out = grid;
     const hipStream_t st = (hipStream_t)stream;
     avsi_clear_error();
 
@@ -444,20 +517,50 @@ extern "C" int avsi_frontend_f32(const avsi_frontend_args* args, void* stream) {
             (void)hipFuncSetAttribute((const void*)frontend_kernel<NBV, WRV, OCCV, S1V, MDV>,                                \
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                           \
         hipLaunchKernelGGL((frontend_kernel<NBV, WRV, OCCV, S1V, MDV>), dim3(grid), dim3(TPB), lds, st, a, tiles_per_utt,    \
-                           n_tiles, seg, step);                                                                        \
+                           n_tiles, seg, step, lo);                                                                    \
     } while (0)
 #define AVSI_FE_LAUNCH(NBV)                   \
     do {                                      \
-        if (model && occ == 3) AVSI_FE_LAUNCH1(NBV, 4, 3, true, true); \
-        else if (model) AVSI_FE_LAUNCH1(NBV, 4, 2, true, true); \
-        else if (small && step == 1) AVSI_FE_LAUNCH1(NBV, 4, 2, true, false); \
-        else if (small) AVSI_FE_LAUNCH1(NBV, 4, 2, false, false); \
-        else AVSI_FE_LAUNCH1(NBV, 8, 2, false, false);      \
+        if (model && occ == 3) AVSI_FE_LAUNCH1(NBV, 4, 3, true, 1); \
+        else if (model) AVSI_FE_LAUNCH1(NBV, 4, 2, true, 1); \
+        else if (small && step == 1) AVSI_FE_LAUNCH1(NBV, 4, 2, true, 0); \
+        else if (small) AVSI_FE_LAUNCH1(NBV, 4, 2, false, 0); \
+        else AVSI_FE_LAUNCH1(NBV, 8, 2, false, 0);      \
     } while (0)
-    if (nb == 8) AVSI_FE_LAUNCH(8);
+    if (mode == 3) AVSI_FE_LAUNCH1(12, 4, 2, true, 3);
+    else if (model_feat_only) AVSI_FE_LAUNCH1(12, 4, 2, true, 2);
+    else if (nb == 8) AVSI_FE_LAUNCH(8);
     else if (nb == 12) AVSI_FE_LAUNCH(12);
     else AVSI_FE_LAUNCH(16);
 #undef AVSI_FE_LAUNCH
 #undef AVSI_FE_LAUNCH1
     return avsi_launch_status();
+}
+
+extern "C" int avsi_frontend_f32(const avsi_frontend_args* args, void* stream) {
+    if (!args) return AVSI_ERR_INVALID_ARG;
+    return frontend_launch(*args, 0, FeLoss{}, nullptr, stream);
+}
+
+extern "C" int avsi_frontend_l1_loss_supported(const avsi_frontend_args* args) {
+    if (!args) return 0;
+    const avsi_frontend_args& a = *args;
+    const int nb_need = (a.frame_len + 31) / 32;
+    return a.nfft == 512 && a.num_bins == 257 && a.mask && a.mean && a.stdev && a.spec_power == 1.f && a.log_spec && nb_need > 8 &&
+           nb_need <= 12 && (int64_t)(FR - 1) * a.hop + 32 * 12 <= 4 * TPB * 4 && !(a.hop & 1) && !(a.frame_len & 1);
+}
+
+extern "C" int avsi_frontend_l1_loss_f32(const avsi_frontend_args* args, const float* pred, int64_t pred_stride_b,
+                                         int64_t pred_stride_t, float* dpred, float grad_scale, float* out3, void* workspace,
+                                         size_t workspace_bytes, void* stream) {
+    if (!args || !pred || !out3) return AVSI_ERR_INVALID_ARG;
+    if (!avsi_frontend_l1_loss_supported(args)) return AVSI_ERR_UNSUPPORTED;
+    if (!workspace || workspace_bytes < (size_t)2 * AVSI_NUM_CU * 5 * sizeof(float)) return AVSI_ERR_WORKSPACE;
+    avsi_frontend_args a = *args;
+    a.out_stft = a.out_spec = a.out_feat = a.out_logmel = nullptr;      // the loss form stores nothing but dpred
+    const FeLoss lo{pred, pred_stride_b, pred_stride_t, dpred, grad_scale, (float*)workspace};
+    int grid = 0;
+    const int rc = frontend_launch(a, 3, lo, &grid, stream);
+    if (rc != AVSI_OK) return rc;
+    return avsi_l1_final_launch((const float*)workspace, grid, (int64_t)a.batch * a.num_frames * 257, out3, (hipStream_t)stream);
 }

@@ -114,6 +114,12 @@ __global__ __launch_bounds__(LTPB) void hole_grad_kernel(const float* __restrict
 
 }  // namespace
 
+// internal (frontend.hip: the loss taken inside the front-end kernel leaves one partial row per workgroup)
+int avsi_l1_final_launch(const float* part, int nblocks, int64_t n, float* out3, hipStream_t st) {
+    hipLaunchKernelGGL(l1_final_kernel, dim3(1), dim3(64), 0, st, part, nblocks, n, out3, false);
+    return avsi_launch_status();
+}
+
 extern "C" size_t avsi_l1_loss_workspace_bytes(int64_t n) {
     (void)n;
     return (size_t)LMAXB * 5 * sizeof(float);

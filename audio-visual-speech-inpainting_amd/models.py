@@ -294,12 +294,18 @@ class StackedBLSTMModel(object):
         # zero-initialised once: padded batch rows / padded columns stay zero across calls
         x0 = self._buf('x0', (T, Bp, Kp), zero=True)
         if self.input_type in ('a', 'av') or self.target_sources is not None:
+            want_feat = self.input_type != 'v' and self.fed_audio_features is None
+            # AVSI_LOSS_FROM_WAV=1: a plain model whose loss recomputes the target from the waveform (`_loss_from_wav`) does not
+            # store it here -- the front end then writes the masked features only (706 kB per utterance: exactly its
+            # algorithmic bytes); `target_spec_norm` is produced on demand (property below)
+            want_spec = not (want_feat and self._loss_from_wav())
             fe = ap.frontend(self.target_sources, window_size=24, step_size=12, n_fft=512, num_frames_out=T,
                              num_bins=F, mean=self.audio_feat_mean, std=self.audio_feat_std, masks=self.masks,
-                             want_spec=True, want_feat=self.input_type != 'v' and self.fed_audio_features is None,
+                             want_spec=want_spec, want_feat=want_feat,
                              time_major=True, feat_cols=Kp if self.input_type == 'a' else F,
                              _feat_out=x0 if self.input_type != 'v' else None)
-            c['target_spec_norm'] = fe['spec']
+            if want_spec:
+                c['target_spec_norm'] = fe['spec']
         def place(src, col, width):
             """x0[t, b, col : col + width] = src[b, t, :width]: batch-major fed features into the time-major padded input
             (avsi_relayout_rows_f32 -- the one device step of the AV models that used to be a torch strided copy)."""
@@ -315,10 +321,25 @@ class StackedBLSTMModel(object):
             place(self.video_features, F, self.video_feat_dim)
         c['x0'] = x0
 
+    def _loss_from_wav(self):
+        """AVSI_LOSS_FROM_WAV=1 (opt-in): the step's L1 loss is taken by the front-end kernel itself from the target WAVEFORM
+        (ap.frontend_l1_loss) and the normalised target is never stored -- 257 kB per utterance less written and read back
+        (2.1 GB less resident at 8192 utterances), the front end moves exactly its algorithmic 706 kB.  Not the default: the
+        second transform costs more than the re-read saves (front end 1.68 -> 1.54 ms, loss 1.02 -> 1.56 ms at 8192 utterances;
+        DESIGN.md 4.1).  Plain models only (the blend variants need the stored target for their prediction), 257 bins."""
+        return (not self.blend and self.target_sources is not None and self.audio_feat_dim == 257
+                and self.masks is not None and os.environ.get('AVSI_LOSS_FROM_WAV', '0') == '1')
+
     @property
     def target_spec_norm(self):
         self._frontend()
-        return self._cache['target_spec_norm']
+        c = self._cache
+        if 'target_spec_norm' not in c:         # not stored by the step's front-end call (see _frontend): on demand
+            _, T, _ = self._dims()
+            c['target_spec_norm'] = ap.frontend(self.target_sources, window_size=24, step_size=12, n_fft=512, num_frames_out=T,
+                                                num_bins=self.audio_feat_dim, mean=self.audio_feat_mean,
+                                                std=self.audio_feat_std, want_spec=True)['spec']
+        return c['target_spec_norm']
 
     @property
     def net_inputs(self):
@@ -486,6 +507,13 @@ class StackedBLSTMModel(object):
         self._forward(keep=want_grad)
         if self.blend:
             return      # computed with the prediction
+        if 'target_spec_norm' not in c and self._loss_from_wav():
+            # the target recomputed from the waveform inside the front-end kernel: nothing was written for it, nothing is read
+            got = ap.frontend_l1_loss(self.target_sources, c['pred'], self.masks, self.audio_feat_mean, self.audio_feat_std,
+                                      want_grad=want_grad)
+            if got is not None:
+                c['loss3'], c['dpred'] = got
+                return
         tgt = self.target_spec_norm
         mask = self.masks[:, :tgt.shape[1]].contiguous()
         out3, dpred = ops.l1_loss(tgt, c['pred'], mask, want_grad=want_grad)

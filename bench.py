@@ -1062,7 +1062,12 @@ def main():
                                 "algorithmic_bytes_per_utterance": 706000,
                                 # the model's call also writes the un-masked target spectrogram (257,000 B more per
                                 # utterance), and a plain device copy on this GPU is the practical ceiling beside 8 TB/s
-                                "GB/s_with_target_output_at_median": 963000.0 * B / (fe_ms[len(fe_ms) // 2] * 1e-3) / 1e9,
+                                # the model's call also writes the un-masked target spectrogram (257,000 B more per utterance) for the
+                                # loss; with AVSI_LOSS_FROM_WAV=1 it stores the masked features only (its real traffic is then the
+                                # algorithmic 706 kB) and the loss recomputes the target from the waveform -- slower overall
+                                "writes_target_output": not model._loss_from_wav(),
+                                "GB/s_real_traffic_at_median": (706000.0 if model._loss_from_wav() else 963000.0) * B
+                                / (fe_ms[len(fe_ms) // 2] * 1e-3) / 1e9,
                                 "device_copy_GB/s": device_copy_rate(torch, device),
                                 "device_copy_GB/s_torch_copy_kernel": device_copy_rate(torch, device, kernel="torch")},
         }

@@ -95,6 +95,20 @@ typedef struct avsi_frontend_args {
 } avsi_frontend_args;
 
 int avsi_frontend_f32(const avsi_frontend_args* args, void* stream);
+/* With the inpainter's own shapes (nfft 512, 257 bins, mean / std, mask, log magnitude, 24 ms frames) and out_feat but NO
+ * out_spec, the call stores the masked features only: 706 kB per utterance, exactly the algorithmic bytes. */
+
+/* The L1 loss of the inpainter (reference models.py:144-151; as avsi_l1_loss_f32) with the TARGET recomputed from the waveform:
+ * the front-end transform of `args` (same wav / table / mean / stdev / mask / geometry as the step's avsi_frontend_f32 call; its
+ * out_* pointers are ignored) runs again and its epilogue compares with `pred` [batch][num_frames][257] (element strides given)
+ * instead of storing the normalised target -- which the step then never has to write (257 kB per utterance) or read back:
+ *   out3 = [mean |t - p|, sum |t - p| (1 - m) / sum (1 - m), sum |t - p| m / sum m];
+ *   dpred (optional, pred's layout) = sign(p - t) * grad_scale.
+ * workspace: avsi_l1_loss_workspace_bytes(n) bytes.  avsi_frontend_l1_loss_supported: 1 for the shapes it takes
+ * (AVSI_ERR_UNSUPPORTED otherwise: use avsi_frontend_f32 with out_spec + avsi_l1_loss_f32). */
+int avsi_frontend_l1_loss_supported(const avsi_frontend_args* args);
+int avsi_frontend_l1_loss_f32(const avsi_frontend_args* args, const float* pred, int64_t pred_stride_b, int64_t pred_stride_t,
+                              float* dpred, float grad_scale, float* out3, void* workspace, size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------
  * fp32 GEMM on the matrix cores (v_mfma_f32_32x32x2_f32, exact fp32):

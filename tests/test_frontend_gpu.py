@@ -133,3 +133,47 @@ def test_fft_length_256_unet_geometry(ap):
     rec = ap.reconstruct_sources(torch.from_numpy(ref.astype(np.complex64)).cuda(), 16384, window_size=16, step_size=8)
     ref_rec = OF.reconstruct_sources(ref, 16384, window_size=16, step_size=8)
     assert np.abs(rec.cpu().numpy() - ref_rec).max() < 2e-2
+
+
+@pytest.mark.parametrize("B,N,T", [(3, 48000, 250), (2, 47999, 250), (5, 192 * 16, 16), (2, 192 * 17 + 1, 18), (70, 9600, 50), (3, 48000, 201)])
+@pytest.mark.parametrize("want_grad", [False, True])
+def test_l1_loss_from_the_waveform_equals_the_loss_on_the_stored_target(ap, B, N, T, want_grad):
+    """ap.frontend_l1_loss (avsi_frontend_l1_loss_f32: the front-end transform run again, its epilogue comparing with the
+    prediction instead of storing the normalised target) against ops.l1_loss on the target the front end stores: the same
+    three losses to summation order, the same gradient signs element by element (a prediction equal to the target gives 0 on
+    both paths; a few elements may differ where |p - t| is a rounding of the two transforms' last bit: none here, same
+    kernel code); batch-major prediction, masks longer than T frames, partial last tiles and samples ending mid-tile."""
+    import avsi_amd  # noqa: F401
+    from avsi_amd import ops
+    rng = np.random.default_rng(B * 1000 + T)
+    wav = torch.from_numpy(_wav(B, N, 3)).cuda()
+    Tm = T + 3
+    masks = torch.ones(B, Tm, 257, device='cuda')
+    for b in range(B):
+        s0 = int(rng.integers(0, max(1, T - 5)))
+        masks[b, s0:s0 + 4] = 0
+    mean = torch.from_numpy(rng.normal(5, 1, 257).astype(np.float32)).cuda()
+    std = torch.from_numpy((1 + rng.random(257)).astype(np.float32)).cuda()
+    fe = ap.frontend(wav, num_frames_out=T, mean=mean, std=std, masks=masks, want_spec=True, want_feat=True)
+    tgt = fe['spec']
+    pred = (tgt + torch.from_numpy(rng.normal(0, 0.3, size=(B, T, 257)).astype(np.float32)).cuda()).contiguous()
+    pred[0, 0, :5] = tgt[0, 0, :5]                       # exact zeros of p - t
+    ref3, refd = ops.l1_loss(tgt, pred, masks[:, :T].contiguous(), want_grad=want_grad)
+    got = ap.frontend_l1_loss(wav, pred, masks, mean, std, want_grad=want_grad)
+    assert got is not None
+    out3, dpred = got
+    np.testing.assert_allclose(out3.cpu().numpy(), ref3.cpu().numpy(), rtol=2e-5)
+    if want_grad:
+        # sign(p - t) / n element by element; the two instantiations of the kernel may round the target's last bit differently
+        # (another fused-multiply-add contraction), which can only flip a sign where p and t agree to that bit
+        diff = dpred != refd
+        assert float(diff.float().mean()) < 1e-3          # (the five planted zeros of p - t are such places)
+        assert bool(((pred - tgt).abs()[diff] < 1e-5).all())
+        assert float(dpred.abs().max()) == float(refd.abs().max())
+    else:
+        assert dpred is None
+    # the features-only launch (no target output) writes the same masked features as the two-output launch
+    only = ap.frontend(wav, num_frames_out=T, mean=mean, std=std, masks=masks, want_feat=True)
+    assert 'spec' not in only and torch.equal(only['feat'], fe['feat'])
+    # geometries the loss form does not take: None, the caller falls back to the stored target
+    assert ap.frontend_l1_loss(wav, pred, masks, mean, std, window_size=16, step_size=8, n_fft=256) is None

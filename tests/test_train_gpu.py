@@ -191,3 +191,40 @@ def test_unequal_layer_widths_match_oracle(mods, net_dim):
     keep = np.zeros(packed.size, dtype=bool)
     keep[np.flatnonzero(m.layout.pack_index < m.layout.ref_size)] = True
     assert not packed[~keep].any()
+
+
+def test_loss_from_the_waveform_gives_the_same_step(monkeypatch):
+    """AVSI_LOSS_FROM_WAV=1 (opt-in): the front end stores the masked features only and the loss recomputes the normalised
+    target from the waveform inside the front-end kernel.  Same prediction bits (the features are the same), same losses to
+    summation order, gradients equal to 1e-6 of their scale (a sign may flip where p and t agree to the last bit), and
+    `target_spec_norm` is still there when asked for."""
+    import torch
+    import avsi_amd  # noqa: F401
+    from avsi_amd import models
+    rng = np.random.default_rng(11)
+    B, N = 6, 9600
+    T = N // 192
+    wav = np.clip(np.round(rng.normal(0, 3000, size=(B, N))), -32768, 32767).astype(np.float32)
+    masks = np.ones((B, T, 257), dtype=np.float32)
+    masks[:, 10:14] = 0
+    mean = rng.normal(5, 1, 257).astype(np.float32)
+    std = (1 + rng.random(257)).astype(np.float32)
+    cfg = dict(audio_feat_dim=257, video_feat_dim=136, audio_len=N, net_dim=[250, 250, 250], optimizer_type='adam',
+               starter_learning_rate=1e-3, lr_updating_steps=10000, lr_decay=1.0, batch_size=B, l2=0.0)
+    res = []
+    for flag in ('0', '1'):
+        monkeypatch.setenv('AVSI_LOSS_FROM_WAV', flag)
+        m = models.StackedBLSTMModel(np.full(B, T), wav, masks, mean, std, 0.0, cfg, input='a', seed=3)
+        assert m._loss_from_wav() is (flag == '1')
+        pred = m.prediction.clone()
+        losses = torch.stack([m.loss_func, m.loss_hole, m.loss_valid]).clone()
+        assert ('target_spec_norm' in m._cache) is (flag == '0')
+        grads = m.gradients.clone()
+        tgt = m.target_spec_norm.clone()
+        res.append((pred, losses, grads, tgt))
+    assert torch.equal(res[0][0], res[1][0])
+    # (the target on demand comes from the generic instantiation of the kernel: last-bit differences against the model's own)
+    np.testing.assert_allclose(res[1][3].cpu().numpy(), res[0][3].cpu().numpy(), rtol=0, atol=2e-5)
+    np.testing.assert_allclose(res[1][1].cpu().numpy(), res[0][1].cpu().numpy(), rtol=2e-5)
+    scale = float(res[0][2].abs().max())
+    assert float((res[0][2] - res[1][2]).abs().max()) < 1e-5 * scale
