@@ -143,6 +143,13 @@ _REC_PARTS = os.environ.get('AVSI_REC_PARTS', '1') != '0'
 REC_TAIL_MAX = 1536        # largest remainder (utterances) cut off a batch of more than 4096 for the small-batch kernels
 
 
+def _tail_split(r):
+    """The kernel of a remainder of r <= 256 utterances: half-row 32-way up to 64, 32-way up to 128, column split by 16 above."""
+    if r <= 64 and _COOP_EXCHANGE and os.environ.get('AVSI_REC_HALF', '1') != '0':
+        return 64
+    return 32 if r <= 128 else -16
+
+
 def _small_parts(at, r):
     """Pieces for the r utterances from row `at` on (r <= CS_MAX_BATCH), each on the cooperative kernel of its size."""
     parts = []
@@ -154,11 +161,11 @@ def _small_parts(at, r):
         parts.append((at, r, -32))
     elif r > 512:
         parts.append((at, 512, -16))
-        parts.append((at + 512, r - 512, 32 if r - 512 <= 128 else 16))
+        parts.append((at + 512, r - 512, _tail_split(r - 512)))
     elif r > 256:
         parts.append((at, r, -16))
     elif r:
-        parts.append((at, r, 32 if r <= 128 else 16))
+        parts.append((at, r, _tail_split(r)))
     return parts
 
 
@@ -166,8 +173,8 @@ def rec_fwd_parts(Bp):
     """[(first_row, rows, split)]: how the forward recurrence of a batch of Bp utterances is cut (split as coop_split: 0 =
     the batch-stationary kernel).  The cooperative launches are latency-bound -- 250 steps of 3 .. 11 us whatever the
     number of groups -- so a remainder beyond the large kernel's resident launches is cheaper on the kernel of ITS size
-    than as one more launch of the large one.  Per layer, ms: 32-way (<= 128 utterances) 0.8, 16-way (<= 256) 1.1,
-    column-split by 16 (<= 512) 1.6, by 32 (<= 1024 per launch) 2.8; batch-stationary 32-row kernel 10.3 for anything up
+    than as one more launch of the large one.  Per layer, ms: half-row 32-way (<= 64 utterances) 0.53 - 0.57, 32-way (<= 128) 0.75,
+    column-split by 16 (<= 256) 1.0, (<= 512) 1.6, by 32 (<= 1024 per launch) 2.8; batch-stationary 32-row kernel 10.3 for anything up
     to 4096, 64-row kernel 16.5 up to 8192.  1088 = 1024 by 32 + 64 32-way: 3.6 instead of 5.6; 640 = 512 by 16 + 128
     32-way: 2.4 instead of 2.8; 5120 = 4096 batch-stationary + 1024 by 32: 13.1 instead of 16.5.  Only taken at the full
     CU budget (a reserved-CU run keeps the single-kernel form)."""
@@ -332,9 +339,12 @@ def coop_split(Bp, backward=False):
         split = 64
     elif Bp <= 128:
         split = 32
-    elif Bp <= 256:
-        split = 16
+    elif Bp <= 256 and (os.environ.get('AVSI_REC_CS', '1') == '0' or coop_cu_budget() < 128):
+        split = 16            # (a small CU share: the reduction-split family, which halves its split until a tile fits)
     elif os.environ.get('AVSI_REC_CS', '1') != '0':
+        # (round 5: from 129 utterances on, not from 257 -- the column split by 16 beats the 16-way kernel at 160 .. 256 utterances
+        #  on both boxes timed, 1.02 against 1.10 - 1.11 ms per layer, with reserve 1.04 - 1.08 against 1.16 - 1.19, and it does
+        #  not need an XCD to itself)
         # 1024 < Bp: resident-sized launches one after the other.  Up to 3584 utterances that still beats the
         # batch-stationary 32-row kernel, whose Bp / 16 workgroups take one full round of the chip whether 132 or 256 of
         # them exist (whole inference step, ms: 2112: 55.7 -> 41.9, 2560: 60.2 -> 50.6, 3072: 65.3 -> 60.5; 3584: a tie)

@@ -235,7 +235,7 @@ def test_cooperative_small_batch_kernel_matches_batch_stationary(Bp, split, save
         np.testing.assert_allclose(outs[1][1].cpu().numpy(), outs[0][1].cpu().numpy(), rtol=0, atol=5e-5)
     for name in ('AVSI_REC_CS', 'AVSI_COOP_CUS', 'AVSI_REC_COOP'):      # the default policy, whatever the caller's switches
         monkeypatch.delenv(name, raising=False)
-    assert ops.coop_split(32) == 64 and ops.coop_split(128) == 32 and ops.coop_split(32, backward=True) == 32 and ops.coop_split(256) == 16
+    assert ops.coop_split(32) == 64 and ops.coop_split(128) == 32 and ops.coop_split(32, backward=True) == 32 and ops.coop_split(256) == -16
     assert ops.coop_split(256, backward=True) == 16 and ops.coop_split(512, backward=True) == 8
     assert ops.coop_split(512) == -16 and ops.coop_split(1024) == -32 and ops.coop_split(2048) == -32 and ops.coop_split(4096) == 0
 

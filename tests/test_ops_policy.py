@@ -11,7 +11,7 @@ def test_cooperative_split_policy(monkeypatch):
     # < 0: the column-split kernel, that many utterances per group of 8 workgroups, two workgroups to a CU
     # ... up to 3584 utterances, in resident-sized launches: beyond, the batch-stationary kernels fill the chip
     # 64: the 32-way kernel on 16-row halves (128 workgroups per 32 utterances), up to 64 utterances
-    assert fwd == {32: 64, 64: 64, 96: 32, 128: 32, 160: 16, 256: 16, 288: -16, 512: -16, 544: -32, 2048: -32, 2080: -32,
+    assert fwd == {32: 64, 64: 64, 96: 32, 128: 32, 160: -16, 256: -16, 288: -16, 512: -16, 544: -32, 2048: -32, 2080: -32,
                    3584: -32, 3616: 0}
     monkeypatch.setenv('AVSI_REC_HALF', '0')
     assert ops.coop_split(32) == 32 and ops.coop_split(64) == 32
@@ -24,7 +24,7 @@ def test_cooperative_split_policy(monkeypatch):
             sp = ops.coop_split(b, back)
             assert (2 * (b // 32) * sp <= 256) if sp > 0 else (2 * (b // -sp) * 8 <= 512), (b, back)
     monkeypatch.setenv('AVSI_REC_CS', '0')
-    assert ops.coop_split(512) == 8 and ops.coop_split(1024) == 4 and ops.coop_split(3584) == 4
+    assert ops.coop_split(512) == 8 and ops.coop_split(1024) == 4 and ops.coop_split(3584) == 4 and ops.coop_split(256) == 16
     monkeypatch.delenv('AVSI_REC_CS')
     # a process that shares the chip between 8 streams gives each launch 32 CUs
     monkeypatch.setenv('AVSI_COOP_CUS', '32')
@@ -63,25 +63,25 @@ def test_forward_recurrence_is_cut_into_pieces_of_their_own_size(monkeypatch):
     for name in ('AVSI_REC_CS', 'AVSI_COOP_CUS', 'AVSI_REC_COOP', 'AVSI_COOP_SPLIT_FWD'):
         monkeypatch.delenv(name, raising=False)
     assert ops.rec_fwd_parts(1024) == [(0, 1024, -32)] and ops.rec_fwd_parts(2048) == [(0, 2048, -32)]
-    assert ops.rec_fwd_parts(1088) == [(0, 1024, -32), (1024, 64, 32)]
+    assert ops.rec_fwd_parts(1088) == [(0, 1024, -32), (1024, 64, 64)]          # 64: the 32-way kernel on 16-row halves
     assert ops.rec_fwd_parts(1536) == [(0, 1024, -32), (1024, 512, -16)]
-    assert ops.rec_fwd_parts(2112) == [(0, 2048, -32), (2048, 64, 32)]
+    assert ops.rec_fwd_parts(2112) == [(0, 2048, -32), (2048, 64, 64)]
     assert ops.rec_fwd_parts(640) == [(0, 512, -16), (512, 128, 32)]
-    assert ops.rec_fwd_parts(768) == [(0, 512, -16), (512, 256, 16)]
+    assert ops.rec_fwd_parts(768) == [(0, 512, -16), (512, 256, -16)]           # 129 .. 256: the column split by 16 (round 5)
     assert ops.rec_fwd_parts(800) == [(0, 800, -32)] and ops.rec_fwd_parts(3584)[-1] == (3072, 512, -16)
     assert ops.rec_fwd_parts(512) == [(0, 512, -16)] and ops.rec_fwd_parts(128) == [(0, 128, 32)]      # single-kernel sizes
     for b in range(544, 3585, 32):
         parts = ops.rec_fwd_parts(b)
         at = 0
         for first, rows, sp in parts:
-            tile = {-32: 32, -16: 16, 32: 32, 16: 32}[sp]
+            tile = {-32: 32, -16: 16, 32: 32, 16: 32, 64: 32}[sp]
             assert first == at and rows > 0 and first % tile == 0 and rows % tile == 0, (b, parts)
-            assert rows <= {32: 128, 16: 256, -16: 512}.get(sp, 1 << 30), (b, parts)
+            assert rows <= {64: 64, 32: 128, 16: 256, -16: 512}.get(sp, 1 << 30), (b, parts)
             at += rows
         assert at == b
     # just above 4096 utterances: one round of the 32-row batch-stationary kernel + the remainder on its own kernel
     assert ops.rec_fwd_parts(4096) == [(0, 4096, 0)] and ops.rec_fwd_parts(8192) == [(0, 8192, 0)]
-    assert ops.rec_fwd_parts(4160) == [(0, 4096, 0), (4096, 64, 32)]
+    assert ops.rec_fwd_parts(4160) == [(0, 4096, 0), (4096, 64, 64)]
     assert ops.rec_fwd_parts(5120) == [(0, 4096, 0), (4096, 1024, -32)]
     assert ops.rec_fwd_parts(5632) == [(0, 4096, 0), (4096, 1024, -32), (5120, 512, -16)]
     assert ops.rec_fwd_parts(5696) == [(0, 5696, 0)]
@@ -129,11 +129,11 @@ def test_fall_back_levels_cap_the_split_then_disable_the_cooperative_kernels(mon
         monkeypatch.delenv(name, raising=False)
     ops.set_coop_cu_budget(256)
     try:
-        assert ops.coop_level() == 0 and ops.coop_split(32) == 64 and ops.coop_split(128) == 32 and ops.coop_split(256) == 16
+        assert ops.coop_level() == 0 and ops.coop_split(32) == 64 and ops.coop_split(128) == 32 and ops.coop_split(256) == -16
         assert ops.coop_split(32, backward=True) == 32 and ops.coop_split(512) == -16
         ops._COOP_FALLBACKS.append('test')
         assert ops.coop_level() == 1 and not ops.coop_disabled()
-        assert ops.coop_split(32) == 8 and ops.coop_split(256) == 8 and ops.coop_split(32, backward=True) == 8
+        assert ops.coop_split(32) == 8 and ops.coop_split(256) == -16 and ops.coop_split(32, backward=True) == 8
         assert ops.coop_split(512) == -16 and ops.coop_split(1024) == -32          # the column-split kernel stays
         assert all(abs(sp) <= 8 or sp < 0 for _, _, sp in ops.rec_fwd_parts(640)) or True
         ops._COOP_FALLBACKS.append('test')
