@@ -135,7 +135,7 @@ def _config(N, B):
 @pytest.mark.parametrize("B", [300, 1030])
 def test_model_forward_at_column_split_sizes_matches_oracle(mods, B, monkeypatch):
     """The whole model where the policy takes the column-split kernel (B = 300 -> Bp = 320: by 16) and the pieces path
-    (B = 1030 -> Bp = 1056 = 1024 column-split by 32 + 32 on the 32-way kernel): what `also.infer_b1024` of the bench times."""
+    (B = 1030 -> Bp = 1056 = 1024 column-split by 32 + 32 on the half-row 32-way kernel): what `also.infer_b1024` of the bench times."""
     models, ops, bl = mods
     for name in ('AVSI_REC_CS', 'AVSI_COOP_CUS', 'AVSI_REC_COOP', 'AVSI_COOP_SPLIT_FWD', 'AVSI_REC_PARTS'):
         monkeypatch.delenv(name, raising=False)
@@ -145,7 +145,7 @@ def test_model_forward_at_column_split_sizes_matches_oracle(mods, B, monkeypatch
     if B == 300:
         assert parts == [(0, 320, -16)]
     else:
-        assert parts == [(0, 1024, -32), (1024, 32, 32)]
+        assert parts == [(0, 1024, -32), (1024, 32, 64)]         # the remainder on the half-row 32-way kernel (round 5)
     wav, masks, mean, std, T = _model_inputs(B, N, 900 + B)
     p = _rand_biases(O.init_params(21, 257), 22)
     seq_len = np.full(B, T)
