@@ -847,9 +847,9 @@ def free_port():
 
 def self_launch(n):
     """`python bench.py --gpus N` without a launcher around it: start `python -m torch.distributed.run --nnodes=1
-    --nproc-per-node N --master-addr 127.0.0.1 --master-port <free> bench.py <the same arguments>` as a CHILD process in
-    a process group of its own, pass its stdout (rank 0's one JSON line) and stderr through, forward SIGTERM / SIGINT to
-    the whole group, and return its exit status.  Called before this process imports torch: it never initialises a GPU."""
+    --nproc-per-node N --master-addr 127.0.0.1 --master-port <free> bench.py <the same arguments>` as a CHILD process (same
+    process group), pass its stdout (rank 0's one JSON line) and stderr through, forward SIGTERM / SIGINT to the launcher,
+    and return its exit status.  Called before this process imports torch: it never initialises a GPU."""
     import signal
     import subprocess
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr",
@@ -857,11 +857,12 @@ def self_launch(n):
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: RCCL's intra-node transport needs it on this image
     env.setdefault("OMP_NUM_THREADS", "1")
-    child = subprocess.Popen(cmd, env=env, start_new_session=True)
+    # (same process group as this process: whoever stops the bench by its group -- a driver's timeout -- stops the ranks too)
+    child = subprocess.Popen(cmd, env=env)
 
-    def forward(signum, _frame):
+    def forward(signum, _frame):          # the launcher passes SIGTERM / SIGINT on to its workers
         try:
-            os.killpg(child.pid, signum)
+            child.send_signal(signum)
         except ProcessLookupError:
             pass
     for sig in (signal.SIGTERM, signal.SIGINT):
