@@ -669,9 +669,25 @@ __global__ __launch_bounds__(512, 2) void blstm_rec_fwd_coop_half_kernel(const C
     if (member == 0 && tid == 0 && !dead) reset_counter_when_done(ctr, (unsigned)S * (unsigned)T, a.spin_ticks, a.sync);
 }
 
+// LDS the fine kernels REQUEST (they use 16 - 37 KB): more than half of a CU's 160 KB so that one member sits on a CU.
+// AVSI_COOP_FINE_LDS_KB (96 .. 160) asks for more -- round-5 experiment: at 120 KB no workgroup of the weight-gradient GEMMs
+// (49 KB) that run beside the BPTT kernels on side streams fits on a member's CU, and the BPTT kernels of a training step at
+// 32 utterances do get faster (2.60 -> 2.36 ms for the three layers: a co-resident GEMM workgroup shares the member's SIMDs and
+// matrix pipes), but the GEMMs, confined to the other 192 CUs, finish so much later that the step is slower (5.68 -> 5.94 ms).
+// So 96 stays.
+static size_t fine_lds_bytes() {
+    static const size_t v = [] {
+        const char* e = getenv("AVSI_COOP_FINE_LDS_KB");
+        long kb = e ? atol(e) : 96;
+        kb = kb < 96 ? 96 : (kb > 160 ? 160 : kb);
+        return (size_t)kb * 1024;
+    }();
+    return v;
+}
+
 template <bool SAVE>
 int launch_coop_half(const CoopArgs& a, hipStream_t st) {
-    const size_t lds = 96 * 1024;       // > half of the CU's LDS on purpose: one workgroup per CU (the members of a group on 32 CUs)
+    const size_t lds = fine_lds_bytes();
     (void)hipFuncSetAttribute((const void*)blstm_rec_fwd_coop_half_kernel<SAVE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     const int blocks = (int)avsi_ceil_div(a.ngroups, AVSI_NUM_XCD) * AVSI_NUM_XCD * 32;
     hipLaunchKernelGGL((blstm_rec_fwd_coop_half_kernel<SAVE>), dim3(blocks), dim3(512), lds, st, a);
@@ -682,7 +698,7 @@ template <int NT, bool SAVE, bool XCH>
 int launch_coop_fine_x(const CoopArgs& a, hipStream_t st) {
     constexpr int S = 32 / NT;
     // > half of the CU's LDS on purpose: one workgroup per CU, so the members of a group spread over S CUs
-    const size_t lds = 96 * 1024;
+    const size_t lds = fine_lds_bytes();
     static_assert((size_t)8 * NT * 32 * PSTRIDE * sizeof(float) <= 96 * 1024, "partial tiles must fit");
     (void)hipFuncSetAttribute((const void*)blstm_rec_fwd_coop_fine_kernel<NT, SAVE, XCH>,
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -829,6 +845,7 @@ struct CoopBwdArgs {
     float* xch;        // fine kernel: dz in exchange layout [step][group x half][member][gate][rows][16 units], or null
     int coherent;      // AVSI_COOP_COHERENT=1 (see CoopArgs)
     long long spin_ticks;
+    unsigned long long* stamps;   // diagnostics (STAMPS instantiation of the half-tile fine kernel, avsi_diag_cs_stamps)
 };
 
 constexpr int BPART_FLOATS = 8 * 32 * PSTRIDE;      // [wave][unit][row]
@@ -978,7 +995,9 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // [gate][rows][16 units]: a member's four gate blocks of a step are written as whole lines (in dz it owns 64-byte pieces),
 // a reading wave's fragment load is one contiguous KB, cacheable loads are valid by construction; dz itself is written
 // beside it with plain stores nobody waits for.  Without XCH: exchange through dz, lines touched ahead, device-scope loads.
-template <int RH, bool XCH>
+// STAMPS: as in the forward kernel (tools/rec_fine_stamps.py bwd): top, counter seen, barrier, dz fragments landed, MFMAs + park +
+// barrier, cell done and stores issued, exchange stores acknowledged, published.
+template <int RH, bool XCH, bool STAMPS = false>
 __global__ __launch_bounds__(512, 2) void blstm_rec_bwd_coop_fine_kernel(const CoopBwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem_b[];
     float* part = reinterpret_cast<float*>(smem_b);    // [wave][unit 16][row 32 (+4 pad)]
@@ -1025,12 +1044,17 @@ __global__ __launch_bounds__(512, 2) void blstm_rec_bwd_coop_fine_kernel(const C
     float* xbase = XCH ? a.xch + (size_t)(RH * (2 * a.tile0 + group) + half) * (S * 4 * R * 16) : nullptr;
     __syncthreads();
 
+    auto stamp = [&](int step, int phase) {
+        if (STAMPS && (tid & 63) == 0 && tid < 128 && blockIdx.x < 32 && step >= 64 && step < 72)
+            a.stamps[((blockIdx.x * 8 + (step - 64)) * 2 + (tid >> 6)) * 8 + phase] = wall_clock64();
+    };
     for (int s = 0; s < T; ++s) {
         const int t = dir ? s : (T - 1 - s);
         const int tnext = dir ? t - 1 : t + 1;
         const int tp = dir ? t + 1 : t - 1;
         const bool has_prev = dir ? (t + 1 < T) : (t > 0);
         const size_t row0 = (size_t)t * Bp + b0;
+        stamp(s, 0);
 
         const size_t row = row0 + (fin ? frow : 0);
         const float* rv = a.resv + row * (2 * 5 * HP) + dir * 5 * HP + unit;
@@ -1069,7 +1093,9 @@ __global__ __launch_bounds__(512, 2) void blstm_rec_bwd_coop_fine_kernel(const C
                     }
                 }
             }
+            stamp(s, 1);
             __syncthreads();
+            stamp(s, 2);
             // rows l16 and 16 + l16 of the tile, columns ks * 128 + 16 j + 4 kq .. + 3
             const float* zp = a.dz + ((size_t)tnext * Bp + b0 + l16) * (2 * GP) + dir * GP + ks * 128 + 4 * kq;
             const float* zq = zp + (size_t)16 * (2 * GP);
@@ -1106,6 +1132,7 @@ __global__ __launch_bounds__(512, 2) void blstm_rec_bwd_coop_fine_kernel(const C
                 asm volatile("" : "+v"(a0[j]));
                 if (NR == 2) asm volatile("" : "+v"(a1[j]));
             }
+            stamp(s, 3);
 #pragma unroll
             for (int j = 0; j < 8; ++j)
 #pragma unroll
@@ -1124,6 +1151,7 @@ __global__ __launch_bounds__(512, 2) void blstm_rec_bwd_coop_fine_kernel(const C
             *reinterpret_cast<float4*>(part + (ks * UW + l16) * PSTRIDE + 16 * i + 4 * kq) =
                 make_float4(acc[i][0], acc[i][1], acc[i][2], acc[i][3]);
         __syncthreads();
+        stamp(s, 4);
 
         if (fin) {
             float d = dh;
@@ -1150,12 +1178,16 @@ __global__ __launch_bounds__(512, 2) void blstm_rec_bwd_coop_fine_kernel(const C
                 __hip_atomic_store(zo + 96, dzo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
         }
-        if (XCH) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");      // stores complete in issue order: the four exchange stores are done
+        stamp(s, 5);
+        if (STAMPS) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (the stamps' own stores sit in the same queue)
+        else if (XCH) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");      // stores complete in issue order: the four exchange stores are done
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
         for (int g = 0; g < 4; ++g) asm volatile("" ::"v"(touched[g]));
+        stamp(s, 6);
         __syncthreads();
         if (tid == 0) __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        stamp(s, 7);
     }
     if (member == 0 && tid == 0 && !dead) reset_counter_when_done(ctr, (unsigned)S * (unsigned)T, a.spin_ticks, a.sync);
 }
@@ -1179,24 +1211,28 @@ extern "C" int avsi_blstm_rec_bwd_coop_f32(const float* dhout, const float* rese
                      ? reinterpret_cast<float*>(static_cast<char*>(workspace) + AVSI_COOP_EXCHANGE_OFFSET) : nullptr;
     if (xch && avsi_blstm_rec_fwd_coop_workspace_bytes(Bp) > AVSI_COOP_EXCHANGE_OFFSET) return AVSI_ERR_WORKSPACE;
     if (split >= 16) {
-        (void)hipFuncSetAttribute((const void*)blstm_rec_bwd_coop_fine_kernel<1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
-        (void)hipFuncSetAttribute((const void*)blstm_rec_bwd_coop_fine_kernel<1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
-        (void)hipFuncSetAttribute((const void*)blstm_rec_bwd_coop_fine_kernel<2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
-        (void)hipFuncSetAttribute((const void*)blstm_rec_bwd_coop_fine_kernel<2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+        (void)hipFuncSetAttribute((const void*)blstm_rec_bwd_coop_fine_kernel<1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fine_lds_bytes());
+        (void)hipFuncSetAttribute((const void*)blstm_rec_bwd_coop_fine_kernel<1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fine_lds_bytes());
+        (void)hipFuncSetAttribute((const void*)blstm_rec_bwd_coop_fine_kernel<2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fine_lds_bytes());
+        (void)hipFuncSetAttribute((const void*)blstm_rec_bwd_coop_fine_kernel<2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fine_lds_bytes());
     }
     const int tiles = Bp / 32, per = coop_tiles_per_launch(split, max_cus);
     for (int tile0 = 0; tile0 < tiles; tile0 += per) {
         const int nt = tiles - tile0 < per ? tiles - tile0 : per;
-        CoopBwdArgs a{dhout, reserve, whbT, dz, (unsigned*)workspace, T, Bp, 2 * nt, tile0, xch, coop_coherent(), avsi_coop_spin_ticks()};
+        CoopBwdArgs a{dhout, reserve, whbT, dz, (unsigned*)workspace, T, Bp, 2 * nt, tile0, xch, coop_coherent(), avsi_coop_spin_ticks(),
+                      avsi_cs_stamps_buffer()};
         const int blocks = (int)avsi_ceil_div(2 * nt, AVSI_NUM_XCD) * AVSI_NUM_XCD * split;
-        if (split == 32 && xch)     // 16 unit slices x 2 row halves
-            hipLaunchKernelGGL((blstm_rec_bwd_coop_fine_kernel<2, true>), dim3(blocks), dim3(512), 96 * 1024, st, a);
+        if (split == 32 && xch && a.stamps) {     // diagnostic instantiation (avsi_diag_cs_stamps)
+            (void)hipFuncSetAttribute((const void*)blstm_rec_bwd_coop_fine_kernel<2, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fine_lds_bytes());
+            hipLaunchKernelGGL((blstm_rec_bwd_coop_fine_kernel<2, true, true>), dim3(blocks), dim3(512), (int)fine_lds_bytes(), st, a);
+        } else if (split == 32 && xch)     // 16 unit slices x 2 row halves
+            hipLaunchKernelGGL((blstm_rec_bwd_coop_fine_kernel<2, true>), dim3(blocks), dim3(512), (int)fine_lds_bytes(), st, a);
         else if (split == 32)
-            hipLaunchKernelGGL((blstm_rec_bwd_coop_fine_kernel<2, false>), dim3(blocks), dim3(512), 96 * 1024, st, a);
+            hipLaunchKernelGGL((blstm_rec_bwd_coop_fine_kernel<2, false>), dim3(blocks), dim3(512), (int)fine_lds_bytes(), st, a);
         else if (split == 16 && xch)     // 96 KiB of LDS requested on purpose: one workgroup per CU (it uses 18 KiB)
-            hipLaunchKernelGGL((blstm_rec_bwd_coop_fine_kernel<1, true>), dim3(blocks), dim3(512), 96 * 1024, st, a);
+            hipLaunchKernelGGL((blstm_rec_bwd_coop_fine_kernel<1, true>), dim3(blocks), dim3(512), (int)fine_lds_bytes(), st, a);
         else if (split == 16)
-            hipLaunchKernelGGL((blstm_rec_bwd_coop_fine_kernel<1, false>), dim3(blocks), dim3(512), 96 * 1024, st, a);
+            hipLaunchKernelGGL((blstm_rec_bwd_coop_fine_kernel<1, false>), dim3(blocks), dim3(512), (int)fine_lds_bytes(), st, a);
         else if (split == 8)
             hipLaunchKernelGGL(blstm_rec_bwd_coop_kernel<8>, dim3(blocks), dim3(512), 0, st, a);
         else
