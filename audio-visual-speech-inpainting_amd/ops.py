@@ -320,11 +320,12 @@ CS_MAX_BATCH = int(os.environ.get('AVSI_REC_CS_MAX', '3584'))     # largest batc
 
 def coop_split(Bp, backward=False):
     """Which small-batch recurrent kernel runs a layer: > 0 = workgroups per (32-utterance tile, direction) of the
-    reduction-split cooperative kernels, < 0 = the column-split kernel with that many utterances per group of 8
-    workgroups (forward only), 0 = the batch-stationary kernels.  A cooperative grid must be resident at once, and
-    the fewer utterances there are, the finer the hidden state is cut.  Measured per layer, T = 250, ms (forward):
-    Bp = 32: 1.81 at 8, 1.02 at 16, 0.82 at 32; 256: 1.87 / 1.09 / 2.11; 512: 1.91 at 8, 1.55 column-split by 16;
-    1024: 2.97 at 4, 2.78 column-split by 32."""
+    reduction-split cooperative kernels (64 = the 32-way kernel on two 16-row halves per tile, forward only), < 0 = the
+    column-split kernel with that many utterances per group of 8 workgroups (forward only), 0 = the batch-stationary
+    kernels.  A cooperative grid must be resident at once, and the fewer utterances there are, the finer the hidden state is
+    cut.  Measured per layer, T = 250, ms (forward; profiles/r05_thresholds_box*.txt): Bp = 32: 1.80 at 8, 1.00 at 16, 0.68 at
+    32, 0.53 on half rows; 64: 0.68 at 32, 0.57 on half rows; 128: 0.76 at 32, 1.05 at 16; 256: 1.11 at 16, 1.02 column-split
+    by 16; 512: 1.51 by 16, 1.63 by 32; 1024: 2.97 at 4, 2.78 by 32; 3584: 10.1 by 32 = the batch-stationary kernel."""
     if coop_disabled():
         return 0
     if backward:
@@ -335,7 +336,7 @@ def coop_split(Bp, backward=False):
         split = 32 if Bp <= 128 else (16 if Bp <= 256 else (8 if Bp <= 512 else (4 if Bp <= 2048 else 0)))
     elif Bp <= 64 and _COOP_EXCHANGE and os.environ.get('AVSI_REC_HALF', '1') != '0':
         # round 5: the 32-way kernel on 16-row halves (two groups per tile and direction: 128 workgroups per 32 utterances) --
-        # the MFMA phase of a step halves; up to 64 utterances the CUs are there (0.68 -> 0.58 ms per layer at 32)
+        # the MFMA phase of a step halves; up to 64 utterances the CUs are there (0.68 -> 0.53 ms per layer at 32, 0.57 at 64)
         split = 64
     elif Bp <= 128:
         split = 32
