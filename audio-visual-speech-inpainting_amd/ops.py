@@ -571,6 +571,7 @@ def splitk_for(rows):
     """Reduction slabs for a weight-gradient GEMM over `rows` = T * Bp rows: long reductions get 64
     slabs of >= 4096 rows; short ones (small batches) are still cut into ~1024-row slabs so that the
     few output tiles (4 x 16 for a 512 x 2048 gradient) spread over the chip."""
+    # (re-timed in round 5 at 8000 rows, training step at 32 utterances: 1024-row slabs 5.69 ms; 512: 5.84; 2048: 6.22; 256: 5.96)
     return max(1, min(64, rows // 4096)) if rows >= 65536 else max(1, min(16, rows // 1024))
 
 
