@@ -9,7 +9,7 @@ from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int32, c_int6
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libavsi_hip.so")
-ABI_VERSION = 11
+ABI_VERSION = 12
 
 AVSI_OK = 0
 AVSI_ERR_INVALID_ARG, AVSI_ERR_UNSUPPORTED, AVSI_ERR_LAUNCH, AVSI_ERR_WORKSPACE = -1, -2, -3, -4
@@ -94,6 +94,8 @@ PROTOTYPES = {
     "avsi_step_guard_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "avsi_adam_tf_guarded_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_float, c_float, c_float, c_float,
                                          c_int64, c_float, c_float, c_void_p, c_int, c_void_p]),
+    "avsi_sgd_momentum_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_float, c_float, c_float, c_float, c_void_p,
+                                      c_int, c_void_p]),
     "avsi_istft_table_floats": (c_size_t, [c_int, c_int, c_int]),
     "avsi_istft_init_tables": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p]),
     "avsi_istft_f32": (c_int, [POINTER(IstftArgs), c_void_p]),

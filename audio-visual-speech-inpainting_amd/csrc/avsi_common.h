@@ -5,7 +5,7 @@
 #include <stdlib.h>
 #include "../../include/avsi_hip.h"
 
-#define AVSI_ABI_VERSION 11  // 11: avsi_blstm_rec_bwd_kernel_name (10: two-utterances-per-wave LWS sweeps) (9: step guard + guarded Adam (8: avsi_gemm_epilogue::k_zero (7: skewed-frame LWS sweeps (6: row-range forms of the cooperative forward entries (5: column-split recurrent kernel (4: LWS phase reconstruction (3: CTC loss + beam-search decoder (2: cooperative recurrence, implicit-GEMM / thin convolutions, blend loss))))))))
+#define AVSI_ABI_VERSION 12  // 12: avsi_sgd_momentum_f32 (11: avsi_blstm_rec_bwd_kernel_name (10: two-utterances-per-wave LWS sweeps) (9: step guard + guarded Adam (8: avsi_gemm_epilogue::k_zero (7: skewed-frame LWS sweeps (6: row-range forms of the cooperative forward entries (5: column-split recurrent kernel (4: LWS phase reconstruction (3: CTC loss + beam-search decoder (2: cooperative recurrence, implicit-GEMM / thin convolutions, blend loss)))))))))
 
 // Launch-status helpers.  hipGetLastError() is per-thread and also reports errors left behind
 // by OTHER users of the runtime in this thread (e.g. the caller's framework), so every entry

@@ -180,6 +180,48 @@ __global__ __launch_bounds__(TPB) void adam_tf_kernel(float* __restrict__ p, con
     }
 }
 
+// tf.train.GradientDescentOptimizer / tf.train.MomentumOptimizer(momentum) behind the same step guard (models.py:170-176):
+// g' = g * gscale + l2 * p;  plain: p -= lr * g';  momentum: accum = momentum * accum + g', p -= lr * accum (TF's form: the
+// learning rate multiplies the accumulator at apply time, it is not folded into it; no Nesterov term -- the reference passes none).
+template <bool MOMENTUM>
+__global__ __launch_bounds__(TPB) void sgd_tf_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                     float* __restrict__ accum, int64_t n, float lr, float momentum,
+                                                     float gscale, float l2, const float* __restrict__ skip, int n_skip) {
+    for (int k = 0; k < n_skip; ++k)
+        if (!(skip[k] == 0.f)) return;
+    const int64_t n4 = n >> 2;
+    for (int64_t i = (int64_t)blockIdx.x * TPB + threadIdx.x; i < n4; i += (int64_t)gridDim.x * TPB) {
+        float4 pv = reinterpret_cast<float4*>(p)[i];
+        const float4 gv = reinterpret_cast<const float4*>(g)[i];
+        float4 av = MOMENTUM ? reinterpret_cast<float4*>(accum)[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+        float* pp = &pv.x;
+        const float* gg = &gv.x;
+        float* aa = &av.x;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float gk = gg[k] * gscale + l2 * pp[k];
+            if (MOMENTUM) {
+                aa[k] = momentum * aa[k] + gk;
+                pp[k] -= lr * aa[k];
+            } else {
+                pp[k] -= lr * gk;
+            }
+        }
+        reinterpret_cast<float4*>(p)[i] = pv;
+        if (MOMENTUM) reinterpret_cast<float4*>(accum)[i] = av;
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+        const int64_t i = (n4 << 2) + threadIdx.x;
+        const float gk = g[i] * gscale + l2 * p[i];
+        if (MOMENTUM) {
+            accum[i] = momentum * accum[i] + gk;
+            p[i] -= lr * accum[i];
+        } else {
+            p[i] -= lr * gk;
+        }
+    }
+}
+
 // out[0] = NaN unless *loss is finite, out[1] = 1 if a cooperative status word is set (else 0): the two words of the
 // step guard, summed over the data-parallel ranks inside the last gradient bucket
 __global__ void step_guard_kernel(const float* loss, const int* status_a, const int* status_b, float* out) {
@@ -334,5 +376,21 @@ extern "C" int avsi_adam_tf_guarded_f32(float* param, const float* grad, float* 
     avsi_clear_error();
     hipLaunchKernelGGL(adam_tf_kernel, dim3(grid_for(n >> 2, TPB)), dim3(TPB), 0, (hipStream_t)stream, param, grad, m, v,
                        n, (float)lr_t, beta1, beta2, eps, grad_scale, l2, skip, n_skip);
+    return avsi_launch_status();
+}
+
+extern "C" int avsi_sgd_momentum_f32(float* param, const float* grad, float* accum, int64_t n, float lr, float momentum,
+                                     float grad_scale, float l2, const float* skip, int n_skip, void* stream) {
+    if (!param || !grad || n <= 0 || !(momentum >= 0.f)) return AVSI_ERR_INVALID_ARG;
+    if (n_skip < 0 || n_skip > 8 || (n_skip > 0 && !skip)) return AVSI_ERR_INVALID_ARG;
+    if ((reinterpret_cast<uintptr_t>(param) | reinterpret_cast<uintptr_t>(grad) | reinterpret_cast<uintptr_t>(accum)) & 15)
+        return AVSI_ERR_UNSUPPORTED;
+    avsi_clear_error();
+    if (accum)
+        hipLaunchKernelGGL(sgd_tf_kernel<true>, dim3(grid_for(n >> 2, TPB)), dim3(TPB), 0, (hipStream_t)stream, param, grad,
+                           accum, n, lr, momentum, grad_scale, l2, skip, n_skip);
+    else
+        hipLaunchKernelGGL(sgd_tf_kernel<false>, dim3(grid_for(n >> 2, TPB)), dim3(TPB), 0, (hipStream_t)stream, param, grad,
+                           (float*)nullptr, n, lr, 0.f, grad_scale, l2, skip, n_skip);
     return avsi_launch_status();
 }

@@ -101,11 +101,13 @@ __global__ __launch_bounds__(64) void l1_final_kernel(const float* __restrict__ 
 }
 
 // d loss_hole / d logits = sign(p - t) (1 - m)^2 / sum(1 - m); the sequence mask is applied by the
-// caller's relayout, like for the plain loss.
+// caller's relayout, like for the plain loss.  A batch without a single gap element has out4[3] = 1 / 0 = inf and
+// (1 - m) = 0 everywhere: its gradient is zero, not inf * 0 (a data-parallel rank may hold such a shard while the
+// global objective sum num / sum gap is well defined; the loss itself stays 0 / 0 = NaN as in the reference).
 __global__ __launch_bounds__(LTPB) void hole_grad_kernel(const float* __restrict__ t, const float* __restrict__ p,
                                                          const float* __restrict__ m, int64_t n,
                                                          const float* __restrict__ out4, float* __restrict__ dlogits) {
-    const float inv = out4[3];
+    const float inv = isfinite(out4[3]) ? out4[3] : 0.f;
     for (int64_t i = (int64_t)blockIdx.x * LTPB + threadIdx.x; i < n; i += (int64_t)gridDim.x * LTPB) {
         const float d = p[i] - t[i], h = 1.f - m[i];
         dlogits[i] = (d > 0.f ? inv : (d < 0.f ? -inv : 0.f)) * h * h;

@@ -54,14 +54,16 @@ class _WavWriter(object):
     def _slot(self, shape):
         torch = self.torch
         if len(self.slots) < 3:
-            self.slots.append([None, torch.zeros(2, dtype=torch.int32).pin_memory(), torch.cuda.Event(), []])
+            self.slots.append([None, torch.zeros(2, dtype=torch.int32, pin_memory=True), torch.cuda.Event(), []])
         slot = self.slots[self.next % 3]
         self.next += 1
         for f in slot[3]:               # the files of the batch that used this buffer three batches ago are on disk
             f.result()
         slot[3] = []
         if slot[0] is None or tuple(slot[0].shape[1:]) != tuple(shape[1:]) or slot[0].shape[0] < shape[0]:
-            slot[0] = torch.empty(tuple(shape), dtype=torch.float32).pin_memory()
+            # (allocated page-locked, not `.pin_memory()` of a pageable tensor: that is a second allocation plus a copy of
+            #  pages nobody has touched yet -- 14 ms per 6 MB slot, a quarter of a 4096-utterance run at batch 32)
+            slot[0] = torch.empty(tuple(shape), dtype=torch.float32, pin_memory=True)
         return slot
 
     def _write(self, slot, lo, hi, paths, counts):
@@ -112,6 +114,12 @@ class _WavWriter(object):
 
 
 def infer(model_path, data_path_test, audio_path, out_file_prefix, norm=True, oracle_phase=False, batch_size=1):
+    from time import perf_counter
+    stamps = [('start', perf_counter())] if os.environ.get('AVSI_INFER_TIMING') else None
+
+    def stamp(name):
+        if stamps is not None:
+            stamps.append((name, perf_counter()))
     config = check_trainconfiguration(load_configfile(os.path.join(model_path, 'config.txt')))
     rank, world = parallel.init()
 
@@ -131,6 +139,7 @@ def infer(model_path, data_path_test, audio_path, out_file_prefix, norm=True, or
         audio_feat_mean = np.zeros(config['audio_feat_dim'])
         audio_feat_std = np.ones(config['audio_feat_dim'])
 
+    stamp('reader')
     print('Building speech inpainting inference model:')
     model = build_model(config, audio_feat_mean, audio_feat_std, is_training=False)
     print('Model building done.')
@@ -142,6 +151,7 @@ def infer(model_path, data_path_test, audio_path, out_file_prefix, norm=True, or
         print(str(e))
         sys.exit(2)
     print('done.\n')
+    stamp('model + checkpoint')
 
     # LWS module initialization (reference inference.py:119)
     lws_processor = lws_mod.lws(384, 192, fftsize=512, mode='speech')
@@ -153,7 +163,7 @@ def infer(model_path, data_path_test, audio_path, out_file_prefix, norm=True, or
     # The LWS sweeps are a pipeline of ~100 stages per utterance: small batches are collected until LWS_GROUP utterances
     # wait for their phase, refined in one launch and written in the order they came (32 utterances 4.8 ms, 256: 15 ms,
     # DESIGN 4.3d); the per-batch lines below are printed when their files are queued.
-    lws_group = int(os.environ.get('AVSI_LWS_GROUP', '256'))
+    lws_group = int(os.environ.get('AVSI_LWS_GROUP', '1024'))
     pending = []                    # (enhanced, masks, paths, lengths) of batches whose phase is still to be refined
 
     def written(paths, lengths):
@@ -181,9 +191,18 @@ def infer(model_path, data_path_test, audio_path, out_file_prefix, norm=True, or
         pending.clear()
 
     print('Starting inference on dataset: {:s}'.format(data_path_test))
+    stamp('lws + writer')
+    waited = 0.0
     while True:
         try:
-            feed, test_sample_path = unpack_batch(test_it.get_next(), uses_embeddings(config))
+            if stamps is not None:
+                t_w = perf_counter()
+            nxt = test_it.get_next()
+            if stamps is not None:
+                waited += perf_counter() - t_w
+                if stamps[-1][0] == 'lws + writer':
+                    stamp('first batch read')
+            feed, test_sample_path = unpack_batch(nxt, uses_embeddings(config))
             test_length = feed['sequence_lengths']
         except OutOfRangeError:
             flush()
@@ -207,7 +226,9 @@ def infer(model_path, data_path_test, audio_path, out_file_prefix, norm=True, or
             pending.append((enhanced.clone(), masks.clone(), test_sample_path, test_length))   # the model reuses its buffers
         if sum(len(p[3]) for p in pending) >= lws_group:
             flush()
+    stamp('loop (launches; %.1f ms of it waiting for the reader)' % (waited * 1e3))
     writer.close()          # every file is on disk (or its error raised) before the summary line
+    stamp('GPU drained, files written')
     ops.coop_check()
     lws_processor.check()
     loss_list = [float(x) for x in loss_list]
@@ -216,4 +237,8 @@ def infer(model_path, data_path_test, audio_path, out_file_prefix, norm=True, or
     tot, cnt = parallel.all_reduce_sum_scalars([float(np.sum(loss_list)), float(len(loss_list))])
     mean_loss = tot / cnt if cnt else 0.0
     print('Loss hole: {:.5}'.format(mean_loss))
+    if stamps is not None:
+        stamp('checks + loss')
+        print('infer() timing, ms: ' + '; '.join('%s %.1f' % (n, (t - stamps[i][1]) * 1e3) for i, (n, t) in enumerate(stamps[1:])),
+              file=sys.stderr, flush=True)
     return mean_loss

@@ -457,11 +457,18 @@ class StackedBLSTMModel(object):
                 # gradient sum_r d num_r / G.  The kernel left d num_r / gap_r; with the ranks' gap element counts summed (one
                 # float, on the device) each rank rescales by gap_r * world / G, and the 1 / world of the fused Adam over the
                 # summed buckets gives exactly the single-process gradient of the global batch -- whatever the ranks' shares
-                # of the gap frames (tests/test_dp_gpu.py::test_two_ranks_with_unequal_gaps_train_the_global_loss_hole)
-                gap = 1.0 / inv_gap
+                # of the gap frames (tests/test_dp_gpu.py::test_two_ranks_with_unequal_gaps_train_the_global_loss_hole),
+                # a share of ZERO included: that rank's kernel left inv = inf and a zero gradient (loss.hip), its
+                # gap_r and num_r are 0 here, and its LOCAL loss_hole (0 / 0) is reported as 0 so that the step guard's
+                # 'my loss is not finite' word does not void a step whose global objective is well defined
+                has_gap = torch.isfinite(inv_gap)
+                gap = torch.where(has_gap, 1.0 / inv_gap, torch.zeros_like(inv_gap))
                 total = parallel.all_reduce_sum_(gap.clone())
                 dlog.mul_(gap * float(parallel.world_size()) / total)
-                c['hole_sums'] = (out3[1] * gap, gap, total)          # num_r, gap_r, G: loss_hole_global
+                num = torch.where(has_gap[0], out3[1] * gap[0], torch.zeros_like(out3[1]))
+                # (no gap element on ANY rank: 0 / 0 as in the reference -- the NaN stays and the trainer leaves)
+                c['loss3'] = torch.where(has_gap[0] | (total[0] == 0), c['loss3'], torch.stack([num, num, out3[2]]))
+                c['hole_sums'] = (num, gap, total)          # num_r, gap_r, G: loss_hole_global
             c['dpred'] = dlog
             self._extra_loss(keep)
 
@@ -787,7 +794,16 @@ class StackedBLSTMModel(object):
             parallel.all_reduce_sum_(g)
             c['grads_reduced'] = parallel.dp_active()
             c['guard'] = parallel.all_reduce_sum_(ops.step_guard(c['loss3'][0:1], torch.empty(2, device=self.device)))
-        guard = c['guard']
+        self.apply_gradients(g, world, c['guard'])
+        c['trained'] = True
+        return None
+
+    def apply_gradients(self, g, world=1, guard=None):
+        """The optimiser update of ``train_op`` (reference models.py:168-179) with a gradient the caller hands in: ``g`` is
+        the flat reference-layout gradient SUMMED over ``world`` equal shares (the update divides by it), ``guard`` the step
+        guard's device words (any non-zero word leaves variables and slots alone).  Every optimizer_type runs as one guarded
+        HIP launch: TF-Adam with the CONSTANT starter rate, sgd / momentum 0.9 with the staircase-decayed rate."""
+        v = self.variables
         step = v.global_step + 1
         l2 = float(self.regularization or 0.0)
         if self.optimizer_choice == 'adam':
@@ -797,23 +813,18 @@ class StackedBLSTMModel(object):
             ops.adam_tf(v.flat, g, v.adam_m, v.adam_v, step, self.starter_learning_rate, grad_scale=1.0 / world, l2=l2,
                         skip=guard)
         elif self.optimizer_choice in ('sgd', 'momentum'):
-            lr = self.learning_rate
-            ok = (guard == 0).all()                   # device scalar: a void step leaves the variables alone
-            gg = g / world + l2 * v.flat if (world > 1 or l2) else g
+            # learning_rate is taken BEFORE the count moves: exponential_decay(global_step) as the step's train_op sees it
+            accum = None
             if self.optimizer_choice == 'momentum':
                 if v.adam_m is None:
-                    v.adam_m = torch.zeros_like(v.flat)
-                v.adam_m.copy_(torch.where(ok, 0.9 * v.adam_m + gg, v.adam_m))
-                v.flat.copy_(torch.where(ok, v.flat - lr * v.adam_m, v.flat))
-            else:
-                v.flat.copy_(torch.where(ok, v.flat - lr * gg, v.flat))
+                    v.adam_m = torch.zeros_like(v.flat)         # the 'Momentum' slot
+                accum = v.adam_m
+            ops.sgd_momentum(v.flat, g, accum, self.learning_rate, momentum=0.9, grad_scale=1.0 / world, l2=l2, skip=guard)
         else:
             print('Optimizer must be either sgd, momentum or adam. Closing...')
             sys.exit(1)
         v.global_step = step
         v.repack()
-        c['trained'] = True
-        return None
 
     @property
     def step_guard(self):

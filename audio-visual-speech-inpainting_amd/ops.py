@@ -619,6 +619,17 @@ def blstm_rec_bwd(dhout, reserve, whbt, dz, split=None):
     return dz
 
 
+def sgd_momentum(param, grad, accum, lr, momentum=0.9, grad_scale=1.0, l2=0.0, skip=None):
+    """In-place tf.train.GradientDescentOptimizer (``accum`` None) / tf.train.MomentumOptimizer step on flat float32 buffers
+    (avsi_sgd_momentum_f32; reference models.py:170-176).  ``skip`` as for adam_tf."""
+    _lib.require_cuda(param, grad, accum, skip)
+    if skip is not None and (skip.dtype != torch.float32 or not skip.is_contiguous() or skip.numel() > 8):
+        raise _lib.AvsiError("sgd_momentum: skip must be at most 8 contiguous float32 words")
+    _lib.check(_lib.lib().avsi_sgd_momentum_f32(_lib.ptr(param), _lib.ptr(grad), _lib.ptr(accum), param.numel(), float(lr),
+                                                float(momentum), float(grad_scale), float(l2), _lib.ptr(skip),
+                                                0 if skip is None else skip.numel(), _lib.stream_ptr()), "avsi_sgd_momentum_f32")
+
+
 def relayout_rows(src, dst, B, T, C, dst_cols, src_strides, dst_strides, row_scale=None, scale_strides=(0, 0)):
     """dst[b, t, :dst_cols] = src[b, t, :C] * row_scale[b, t] (zero beyond C); strides are (b, t) element strides."""
     _lib.require_cuda(src, dst, row_scale)

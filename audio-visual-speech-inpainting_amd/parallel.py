@@ -153,3 +153,22 @@ def all_reduce_sum_async(flat):
         return dist.all_reduce(flat, op=dist.ReduceOp.SUM, async_op=True)
     all_reduce_sum_(flat)
     return None
+
+
+def shards_step(model, feeds):
+    """One optimiser step over ``feeds`` -- one feed dict per would-be rank -- in ONE process: every shard runs through the
+    model's own forward and backward at the ranks' batch size (hence on the kernels a rank of that batch size runs), the
+    gradients are summed in rank order and applied once with 1 / len(feeds), exactly what ``train_op`` does behind the
+    all-reduce.  What differs from a data-parallel step of that world size is the collective alone (and the order in
+    which it adds the ranks' terms): the like-with-like reference of bench.py's `dp_train.check` and tests/test_dp_gpu.py.
+    Also plain gradient accumulation over micro-batches.  Call inside ``solo()`` when a process group exists.
+    Returns (the shards' loss_func values as device scalars, the summed gradient)."""
+    gsum, losses = None, []
+    for feed in feeds:
+        model.feed(**feed)
+        losses.append(model.loss_func.detach().clone())
+        g = model._backward()
+        gsum = g.clone() if gsum is None else gsum.add_(g)
+    model.apply_gradients(gsum, world=len(feeds), guard=model.step_guard)
+    model._cache['trained'] = True
+    return losses, gsum

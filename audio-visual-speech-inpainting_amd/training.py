@@ -418,14 +418,20 @@ def _train(config_file, checkpoint_format):
             """A cooperative recurrent launch timed out (another resident of the GPU -- e.g. RCCL's kernels -- left its
             workgroups no room): every step from the first void one on was skipped on the device.  Fall back to the
             batch-stationary kernels IN THIS PROCESS, take the skipped steps' counts back and repeat their batches.
-            All ranks read the same summed guard words, so all of them arrive here at the same step."""
+            All ranks read the same summed guard words, so all of them arrive here at the same step -- but their LEVELS may
+            differ (`validate` lets a rank fall back alone): a rank that is on the batch-stationary kernels already
+            rewinds and repeats with its peers without falling further, because the timeout it read may be a peer's.
+            Every attempt lowers every rank that can still fall by one level, so from the second attempt of one
+            recovery on ALL ranks run batch-stationary kernels; a timeout after that is not a residency matter and is
+            raised -- by every rank at the same attempt (they count attempts on the same summed word)."""
             nonlocal coop_fallbacks
             counted = len(items)                # steps whose optimiser count is ahead of the variables
+            attempts = 0
             while True:
-                if ops.coop_level() >= 2:
-                    raise ops.CoopTimeout(ops._COOP_MSG)      # batch-stationary already: not a residency matter
-                ops.coop_fall_back(device)
-                coop_fallbacks += 1
+                if ops.coop_level() < 2:
+                    coop_fallbacks += 1
+                ops.coop_fall_back(device)      # (at level 2 it only waits for the streams and clears the status words)
+                attempts += 1
                 for _ in range(counted):
                     model.variables.rewind_step()
                 try:
@@ -436,6 +442,8 @@ def _train(config_file, checkpoint_format):
                         items.pop(0)
                     return
                 except ops.CoopTimeout:
+                    if attempts >= 2:
+                        raise                   # every rank was at level 2 in this attempt
                     counted = 1                 # the step just launched: counted, not applied, still first in `items`
 
         def settle(keep):

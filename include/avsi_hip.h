@@ -375,6 +375,13 @@ int avsi_step_guard_f32(const float* loss, const int* status_a, const int* statu
 int avsi_adam_tf_guarded_f32(float* param, const float* grad, float* m, float* v, int64_t n,
                              float lr, float beta1, float beta2, float eps, int64_t step,
                              float grad_scale, float l2, const float* skip, int n_skip, void* stream);
+/* avsi_sgd_momentum_f32: the reference's other two optimizer_type choices behind the same guard (models.py:170-176,
+ *   tf.train.GradientDescentOptimizer(lr) / tf.train.MomentumOptimizer(lr, momentum = 0.9)): g' = grad * grad_scale + l2 * p;
+ *   accum == NULL: p -= lr * g' (sgd); otherwise TF's momentum form accum = momentum * accum + g', p -= lr * accum (the
+ *   rate multiplies the accumulator when it is applied; no Nesterov term).  `lr` is the staircase-decayed rate of the step
+ *   (tf.train.exponential_decay, models.py:165-166), computed by the caller.  `skip` as for avsi_adam_tf_guarded_f32. */
+int avsi_sgd_momentum_f32(float* param, const float* grad, float* accum, int64_t n, float lr, float momentum,
+                          float grad_scale, float l2, const float* skip, int n_skip, void* stream);
 
 /* ------------------------------------------------------------------------------------
  * Inverse STFT / waveform reconstruction: tf.contrib.signal.inverse_stft with

@@ -308,6 +308,20 @@ def adam_tf_step(param, grad, m, v, step, lr=1e-3, beta1=0.9, beta2=0.999, eps=1
     param -= lr_t * m / (np.sqrt(v) + eps)
 
 
+def sgd_tf_step(param, grad, lr):
+    """tf.train.GradientDescentOptimizer update (models.py:171): var -= lr * grad.  In place."""
+    param -= lr * grad
+
+
+def momentum_tf_step(param, grad, accum, lr, momentum=0.9):
+    """tf.train.MomentumOptimizer(lr, momentum=0.9) update (models.py:173; TF's ApplyMomentum, use_nesterov=False):
+    accum = momentum * accum + grad; var -= lr * accum -- the rate multiplies the accumulator when it is applied, so a
+    decayed rate rescales the whole history (unlike the form that folds lr into the accumulator).  In place."""
+    accum *= momentum
+    accum += grad
+    param -= lr * accum
+
+
 def exponential_decay(lr0, global_step, decay_steps, decay_rate, staircase=True):
     """tf.train.exponential_decay (models.py:165-166)."""
     e = global_step / decay_steps

@@ -37,6 +37,12 @@ if __name__ == '__main__':
                     ops.occupy_cus(16, state['release'], max_ms=10000)
             return plain_unpack(*a, **kw)
         training.unpack_batch = parking
+    level2 = os.environ.get('AVSI_TEST_LEVEL2_RANK')
+    if level2 is not None and int(level2) == int(os.environ.get('RANK', '0')):
+        # this rank is on the batch-stationary kernels already (as after two fall-backs of its own inside validate()): a
+        # timeout of a PEER must make it rewind and repeat with the others, not raise
+        from avsi_amd import ops
+        ops._COOP_FALLBACKS.extend(['test: preset', 'test: preset'])
     try:
         model = training.train(sys.argv[1])
     except SystemExit as e:

@@ -52,7 +52,7 @@ def run(rank, world, steps, B_global=4, N=2880):
     return m.variables.flat.cpu().numpy(), losses
 
 
-def run_variant(rank, world, steps, B_global=4, N=2880):
+def run_variant(rank, world, steps, B_global=4, N=2880, gaps='uneven'):
     """The external-embedding variant (objective loss_hole = sum|err|(1-m) / sum(1-m)) on a batch whose gap frames are
     spread UNEVENLY over the ranks' shards: utterance b has a gap of 2 + 3 b frames.  Returns the variables, the per-step
     local loss_hole and the per-step loss_hole_global."""
@@ -62,6 +62,8 @@ def run_variant(rank, world, steps, B_global=4, N=2880):
     wav, masks, video, mean, std, T = make_inputs(B_global, N)
     masks[:] = 1
     for b in range(B_global):
+        if gaps == 'zero' and b < B_global // 2:
+            continue                # the first half of the batch (rank 0's shard at world 2) has no gap element at all
         masks[b, 1: 3 + 3 * b] = 0
     emb = np.random.default_rng(9).normal(size=(B_global, 512)).astype(np.float32)
     per = B_global // world
@@ -90,7 +92,8 @@ if __name__ == '__main__':
     if len(sys.argv) > 5 and sys.argv[5] == 'emb':
         from avsi_amd import parallel
         rank, world = parallel.init()
-        flat, local, glob = run_variant(rank, world, int(sys.argv[4]), int(sys.argv[2]), int(sys.argv[3]))
+        flat, local, glob = run_variant(rank, world, int(sys.argv[4]), int(sys.argv[2]), int(sys.argv[3]),
+                                        gaps=sys.argv[6] if len(sys.argv) > 6 else 'uneven')
         np.save(os.path.join(out, 'flat_rank%d.npy' % rank), flat)
         np.save(os.path.join(out, 'loss_rank%d.npy' % rank), np.array([local, glob]))
         import torch.distributed as dist

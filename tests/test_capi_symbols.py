@@ -35,7 +35,7 @@ def test_ctypes_prototypes_cover_header(built_lib):
 
 
 def test_abi_version_and_status_strings(built_lib):
-    assert built_lib.avsi_abi_version() == 11
+    assert built_lib.avsi_abi_version() == 12
     assert built_lib.avsi_status_string(0) == b"ok"
     assert b"unsupported" in built_lib.avsi_status_string(-2)
     import ctypes

@@ -149,26 +149,31 @@ def test_world1_rccl_rehearsal(tmp_path, B):
     np.testing.assert_allclose(np.load(str(tmp_path / 'loss_rank0.npy')), ref_losses, rtol=2e-4)
 
 
-def test_two_ranks_with_unequal_gaps_train_the_global_loss_hole(tmp_path):
+@pytest.mark.parametrize("gaps", ["uneven", "zero"])
+def test_two_ranks_with_unequal_gaps_train_the_global_loss_hole(tmp_path, gaps):
     """The variants' objective is loss_hole = sum|err|(1-m) / sum(1-m) (models.py:1006-1029): under data parallelism numerator
     and denominator are summed over the ranks separately, not the ranks' ratios averaged.  Four utterances with
     gaps of 2, 5, 8 and 11 frames, two per rank (7 against 19 gap frames): two Adam steps on two ranks equal one process at
     the four utterances to summation order, `loss_hole_global` is the single process's loss_hole on both ranks, and the plain
-    mean of the ranks' own ratios is NOT (the test would not notice the difference otherwise)."""
+    mean of the ranks' own ratios is NOT (the test would not notice the difference otherwise).
+    ``zero``: rank 0's two utterances have NO gap element (0 against 19 gap frames): its own ratio is 0 / 0, the global one
+    is well defined -- the step must not be voided by a NaN on that rank, its local loss_hole reads 0."""
     env = dict(os.environ, AVSI_DIST_BACKEND='gloo', HSA_ENABLE_IPC_MODE_LEGACY='0', AVSI_COOP_CUS='128')
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
-           '--master-port', str(_free_port()), os.path.join(HERE, 'dp_worker.py'), str(tmp_path), '4', '2880', '2', 'emb']
+           '--master-port', str(_free_port()), os.path.join(HERE, 'dp_worker.py'), str(tmp_path), '4', '2880', '2', 'emb', gaps]
     run = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
     assert run.returncode == 0, run.stderr[-3000:]
     f0, f1 = np.load(str(tmp_path / 'flat_rank0.npy')), np.load(str(tmp_path / 'flat_rank1.npy'))
-    assert np.array_equal(f0, f1)
+    assert np.array_equal(f0, f1) and np.isfinite(f0).all()
     sys.path.insert(0, HERE)
     import dp_worker
-    ref, ref_hole, ref_hole_g = dp_worker.run_variant(0, 1, steps=2, B_global=4, N=2880)
-    init, _, _ = dp_worker.run_variant(0, 1, steps=0, B_global=4, N=2880)
+    ref, ref_hole, ref_hole_g = dp_worker.run_variant(0, 1, steps=2, B_global=4, N=2880, gaps=gaps)
+    init, _, _ = dp_worker.run_variant(0, 1, steps=0, B_global=4, N=2880, gaps=gaps)
     assert np.abs(ref - init).max() > 1e-3 and ref_hole == ref_hole_g
     np.testing.assert_allclose(f0, ref, rtol=0, atol=2e-5)
     l0, l1 = np.load(str(tmp_path / 'loss_rank0.npy')), np.load(str(tmp_path / 'loss_rank1.npy'))
     np.testing.assert_allclose(l0[1], ref_hole, rtol=2e-4)
     np.testing.assert_allclose(l1[1], ref_hole, rtol=2e-4)
+    if gaps == 'zero':
+        assert np.all(l0[0] == 0.0)
     assert np.abs((l0[0] + l1[0]) / 2 - np.array(ref_hole)).max() > 1e-3 * np.abs(ref_hole).max()

@@ -362,6 +362,25 @@ def test_cooperative_timeout_on_one_rank_falls_back_on_every_rank(experiment, tm
     assert run.stderr.count('falling back to the cooperative kernels that tolerate neighbours') == 2
 
 
+def test_cooperative_timeout_of_a_peer_is_repeated_by_a_rank_that_is_already_batch_stationary(experiment, tmp_path):
+    """The ranks' fall-back levels may differ (validate() lets a rank fall back alone).  Rank 1 starts on the
+    batch-stationary kernels (level 2), rank 0 parks 16 CUs from its second batch on and times out: the summed guard word
+    voids the step on both; rank 1 must rewind and repeat it with rank 0 -- not raise and strand rank 0 in the next
+    all-reduce -- and both finish every step with identical variables."""
+    base, data, cfg0 = experiment
+    exp = tmp_path / "logs" / "dp_levels"
+    text = open(cfg0).read().replace("exp_folder = %s" % (base / "logs" / "av_exp0"), "exp_folder = %s" % exp)
+    text = text.replace("max_n_epochs = 3", "max_n_epochs = 2").replace("batch_size = 4", "batch_size = 2")
+    cfg = tmp_path / "dp_levels.config"
+    cfg.write_text(text)
+    run = _launch_dp_training(cfg, 2, {'AVSI_TEST_PARK_RANK': '0', 'AVSI_TEST_LEVEL2_RANK': '1', 'AVSI_COOP_CUS': '256'})
+    assert run.returncode == 0, run.stderr[-3000:]
+    found = _rank_lines(run.stdout, 2)
+    assert all(v[0] == 6 for v in found.values()), (found, run.stderr[-2000:])
+    assert found[0][1] >= 1 and found[1][1] == 0, found          # rank 1 had nowhere to fall: it only repeated
+    assert found[0][2] == found[1][2]
+
+
 def test_non_finite_loss_on_one_rank_stops_every_rank(experiment, tmp_path):
     """The NaN / Inf abort of the trainer (training_emb.py:244-249, exit code 1) under data parallelism: the verdict
     travels in the last gradient all-reduce bucket (model.nonfinite_flag), so the rank whose loss is fine leaves at the

@@ -98,6 +98,90 @@ def test_adam_kernel_matches_tf_form(mods):
     np.testing.assert_allclose(tm.cpu().numpy(), m, rtol=1e-5, atol=1e-7)   # fp32 slots vs float64 oracle
 
 
+@pytest.mark.parametrize("momentum", [None, 0.9])
+def test_sgd_momentum_kernel_matches_tf_form(mods, momentum):
+    """avsi_sgd_momentum_f32 against the numpy restatement of tf.train.GradientDescentOptimizer / MomentumOptimizer
+    (models.py:170-176) over five steps with a rate that changes between steps (the decayed rate multiplies the WHOLE
+    accumulator in TF's form), a gradient scale, an l2 term, an odd length, and a void step in the middle."""
+    models, ops, bl = mods
+    rng = np.random.default_rng(2)
+    n = 10007
+    p0 = rng.normal(size=n)
+    p, acc = p0.copy(), np.zeros(n)
+    tp = torch.from_numpy(p0.astype(np.float32)).cuda()
+    ta = torch.zeros_like(tp) if momentum is not None else None
+    ok, void = torch.zeros(2, device='cuda'), torch.tensor([0.0, 1.0], device='cuda')
+    for step in range(5):
+        g = rng.normal(size=n) * 10.0 ** rng.integers(-3, 1)
+        lr = O.exponential_decay(0.05, step, 2, 0.5)
+        tg = torch.from_numpy(g.astype(np.float32)).cuda()
+        if step == 2:
+            before = tp.clone()
+            ops.sgd_momentum(tp, tg, ta, lr, momentum=momentum or 0.0, grad_scale=0.5, l2=1e-3, skip=void)
+            assert torch.equal(tp, before)                      # guarded: nothing moved
+            continue
+        gg = 0.5 * g + 1e-3 * p
+        if momentum is None:
+            O.sgd_tf_step(p, gg, lr)
+        else:
+            O.momentum_tf_step(p, gg, acc, lr, momentum)
+        ops.sgd_momentum(tp, tg, ta, lr, momentum=momentum or 0.0, grad_scale=0.5, l2=1e-3, skip=ok)
+    np.testing.assert_allclose(tp.cpu().numpy(), p, rtol=0, atol=3e-6)
+    if momentum is not None:
+        np.testing.assert_allclose(ta.cpu().numpy(), acc, rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("optimizer", ["sgd", "momentum"])
+def test_three_sgd_and_momentum_steps_track_oracle(mods, optimizer):
+    """The reference's other optimizer_type choices through train_op (models.py:165-176): staircase-decayed rate
+    (lr_updating_steps = 2, decay 0.5: the third step runs at half the rate), three steps against the oracle's forward /
+    backward and the numpy update.  Not scale-free like Adam: the variables track the oracle to the gradients' accuracy."""
+    models, ops, bl = mods
+    B, N = 4, 2880
+    wav, masks, mean, std, video, T = _inputs(B, N, 51)
+    p = _rand_biases(O.init_params(11, 257), 12)
+    seq_len = np.full(B, T)
+    cfg = _config(audio_len=N, optimizer_type=optimizer, starter_learning_rate=0.05, lr_updating_steps=2, lr_decay=0.5)
+    m = models.StackedBLSTMModel(seq_len, wav, masks, mean, std, 0.0, cfg, input='a')
+    m.variables.load_flat(m.layout.flatten_oracle_params(p))
+    p64 = O.cast_params(p, np.float64)
+    init = m.layout.flatten_oracle_params(p64).astype(np.float64)
+    flat = [v for _, v in O.flatten_params(p64)]
+    accs = [np.zeros_like(v) for v in flat]
+    rates = []
+    for step in range(3):
+        fwd = O.model_forward(wav, masks, mean, std, seq_len, p64, keep=True)
+        g = O.model_backward(fwd, masks.astype(np.float64), seq_len)
+        lr = O.exponential_decay(0.05, step, 2, 0.5)
+        for (_, gv), pv, av in zip(O.flatten_params(g), flat, accs):
+            if optimizer == 'sgd':
+                O.sgd_tf_step(pv, gv, lr)
+            else:
+                O.momentum_tf_step(pv, gv, av, lr, 0.9)
+        m.feed(sequence_lengths=seq_len, target_sources=wav, masks=masks)
+        rates.append(m.learning_rate)
+        assert m.train_op is None and m.global_step == step + 1
+    assert rates == [0.05, 0.05, 0.025]
+    ref_flat = m.layout.flatten_oracle_params(p64).astype(np.float64)
+    got_flat = m.variables.flat.cpu().numpy().astype(np.float64)
+    moved = np.abs(ref_flat - init).max()
+    assert moved > 1e-3
+    assert np.abs(got_flat - ref_flat).max() < 2e-3 * moved + 1e-7
+    if optimizer == 'momentum':
+        acc_ref = m.layout.flatten_oracle_params(_as_params(p64, accs)).astype(np.float64)
+        acc_got = m.variables.adam_m.cpu().numpy().astype(np.float64)
+        assert np.abs(acc_got - acc_ref).max() < 2e-3 * np.abs(acc_ref).max()
+
+
+def _as_params(like, arrays):
+    """The oracle's parameter structure with `arrays` (in O.flatten_params order) in place of the values."""
+    import copy
+    out = copy.deepcopy(like)
+    for (_, dst), src in zip(O.flatten_params(out), arrays):
+        dst[...] = src
+    return out
+
+
 @pytest.mark.parametrize("input_type,B,N,Dv", [('a', 5, 3840, 136), ('av', 3, 2880, 136), ('a', 34, 1920, 136),
                                               ('av', 3, 2880, 15)])
 def test_gradients_match_oracle(mods, input_type, B, N, Dv):

@@ -1,5 +1,6 @@
-"""cProfile of infer() end to end (oracle phase, then the default LWS phase).  python tools/e2e_infer_profile.py [n] [batch]"""
-import cProfile, contextlib, io, os, pstats, sys, tempfile, time
+"""cProfile of infer() end to end (oracle phase, then the default LWS phase).  python tools/e2e_infer_profile.py [n] [batch]
+AVSI_E2E_PLAIN=1: no profiler -- two plain calls per phase path with AVSI_INFER_TIMING=1 (infer()'s own stage stamps on stderr)."""
+import cProfile, contextlib, io, os, pstats, shutil, sys, tempfile, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import torch
@@ -31,7 +32,18 @@ open(os.path.join(net, "config.txt"), "w").write("\n".join([
 config = check_trainconfiguration(load_configfile(os.path.join(net, "config.txt")))
 m = training.build_model(config, np.zeros(257), np.ones(257), is_training=False)
 m.variables.save(os.path.join(net, "sinet"))
+plain = os.environ.get('AVSI_E2E_PLAIN') == '1'
 for oracle_phase in (True, False):
+    if plain:
+        os.environ['AVSI_INFER_TIMING'] = '1'
+        for rep in range(3):
+            t0 = time.time()
+            with contextlib.redirect_stdout(io.StringIO()):
+                inference.infer(net, root, os.path.join(base, "plain%d_%d" % (oracle_phase, rep)), "enh", norm=True, oracle_phase=oracle_phase, batch_size=batch)
+            dt = time.time() - t0
+            print("infer(oracle_phase=%s) call %d: %d utterances in %.3f s: %.0f utterances/s (batch %d)" % (oracle_phase, rep, n, dt, n / dt, batch), flush=True)
+            shutil.rmtree(os.path.join(base, "plain%d_%d" % (oracle_phase, rep)), ignore_errors=True)
+        continue
     with contextlib.redirect_stdout(io.StringIO()):
         inference.infer(net, root, os.path.join(base, "warm%d" % oracle_phase), "enh", norm=True, oracle_phase=oracle_phase, batch_size=batch)
     pr = cProfile.Profile()
