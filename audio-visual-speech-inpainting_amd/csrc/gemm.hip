@@ -55,6 +55,9 @@ struct GemmArgs {
     int k_split_len;       // reduction length handled per blockIdx.z (multiple of BK)
     int64_t c_split_stride;  // elements between per-split partial outputs (0 = no split)
     int bnt;               // N tile width chosen by the host (128, or 64 for A . B with a narrow last tile)
+    // N = 256 n + 1 on the 256-wide tile (the 257-bin projection): column N - 1 is not a tile of its own -- the workgroups of the
+    // last column block take it on the VALU, as a dot product of the A rows they have staged in LDS anyway (gemm_dma_kernel<.., TAIL>)
+    int tail_col;          // that column's index, or -1
     int n_group;           // N-blocks per column group of the block -> tile order (see tile_of_block)
     // up to two 16-deep k-tiles that END in zero padding (avsi_gemm_epilogue::k_zero) and the number of their eight MFMA
     // steps that multiply anything: step 4 q + s multiplies k = 8 q + s and 8 q + 4 + s, so a tile with kv leading real k
@@ -362,9 +365,10 @@ __device__ __forceinline__ void dma16(const float* src, uint32_t lds_byte_addr) 
     asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(src), "s"(lds_byte_addr) : "memory");
 }
 
-template <bool TA, bool TB, int BK, int NST, bool CONV = false, int BNT = 128>
+template <bool TA, bool TB, int BK, int NST, bool CONV = false, int BNT = 128, bool TAIL = false>
 __global__ __launch_bounds__(256, BNT == 256 ? 2 : (BK == 16 ? (NST == 3 ? 3 : 4) : 2)) void gemm_dma_kernel(const GemmArgs g) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    static_assert(!TAIL || (BNT == 256 && !TA && !TB && !CONV && BK == 16), "the folded last column exists for A . B on the 256-wide tile");
     static_assert((BK == 16 && (NST == 3 || NST == 2)) || (BK == 32 && NST == 2), "tile shapes this kernel was tuned for");
     static_assert(!CONV || (!TB && BK == 16), "the implicit-GEMM gathers are written for A . B and A^T . B with 16-deep tiles");
     static_assert(BNT == 128 || ((BNT == 64 || BNT == 32 || BNT == 256) && !TB && BK == 16 && NST == 3),
@@ -382,6 +386,7 @@ __global__ __launch_bounds__(256, BNT == 256 ? 2 : (BK == 16 ? (NST == 3 ? 3 : 4
     auto swz = [](int row) { return BK == 16 ? (row >> 2) & 3 : row & 7; };
     float* sA = reinterpret_cast<float*>(smem);
     float* sB = sA + NST * TILE;   // NST stages of TILEB floats
+    float* sW = sB + NST * TILEB;  // TAIL: column g.tail_col of B, K floats
     const uint32_t lds_a = (uint32_t)(uintptr_t)(lvoid_t)smem, lds_b = lds_a + NST * TILE * 4u;
 
     const int tid = threadIdx.x;
@@ -545,6 +550,28 @@ __global__ __launch_bounds__(256, BNT == 256 ? 2 : (BK == 16 ? (NST == 3 ? 3 : 4
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][s], b[j][s], acc[i][j], 0, 0, 0);
     };
 
+    // TAIL: the folded column of B into LDS (a strided gather of K floats per workgroup, L2 hits after the first workgroups),
+    // requested in front of the first tiles' DMAs so that it has landed when they have
+    float wcol[4] = {0.f, 0.f, 0.f, 0.f};
+    if (TAIL) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (tid + 256 * j < g.K) wcol[j] = g.B[(int64_t)(tid + 256 * j) * g.ldb + g.tail_col];
+    }
+    float tail_acc = 0.f;
+    // one 16-deep k tile of the folded column: thread (row = tid / 2, half = tid % 2) multiplies its 8 staged A values
+    auto tail_dot = [&](int kt_, const float* a_s) {
+        const int row = tid >> 1, h = tid & 1;
+        const float4 x0 = *reinterpret_cast<const float4*>(a_s + row * BK + (((2 * h) ^ swz(row)) << 2));
+        const float4 x1 = *reinterpret_cast<const float4*>(a_s + row * BK + (((2 * h + 1) ^ swz(row)) << 2));
+        const float4 w0 = *reinterpret_cast<const float4*>(sW + kt_ * BK + 8 * h);
+        const float4 w1 = *reinterpret_cast<const float4*>(sW + kt_ * BK + 8 * h + 4);
+        tail_acc = fmaf(x0.x, w0.x, tail_acc), tail_acc = fmaf(x0.y, w0.y, tail_acc);
+        tail_acc = fmaf(x0.z, w0.z, tail_acc), tail_acc = fmaf(x0.w, w0.w, tail_acc);
+        tail_acc = fmaf(x1.x, w1.x, tail_acc), tail_acc = fmaf(x1.y, w1.y, tail_acc);
+        tail_acc = fmaf(x1.z, w1.z, tail_acc), tail_acc = fmaf(x1.w, w1.w, tail_acc);
+    };
+
     // ring of NST stages: tiles kt+1 .. kt+NST-1 are in flight / landed while tile kt is computed
     constexpr int PPT = PPW + PPWB;     // DMA instructions per wave and k-tile
     if (nk > 0) issue(0);
@@ -553,6 +580,12 @@ __global__ __launch_bounds__(256, BNT == 256 ? 2 : (BK == 16 ? (NST == 3 ? 3 : 4
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPT) : "memory");
     else
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (TAIL) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (tid + 256 * j < g.K) sW[tid + 256 * j] = wcol[j];
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
     __builtin_amdgcn_s_barrier();
 
     float af[2][TM][4], bf[2][TN][4];
@@ -584,6 +617,7 @@ __global__ __launch_bounds__(256, BNT == 256 ? 2 : (BK == 16 ? (NST == 3 ? 3 : 4
                 rd(2 * h, a_s, b_s, af[0], bf[0]);
                 rd(2 * h + 1, a_s, b_s, af[1], bf[1]);
                 mm(af[0], bf[0]);
+                if (TAIL) tail_dot(kt, a_s);        // (VALU work in the shadow of the MFMAs just issued)
                 mm(af[1], bf[1]);
             }
             tile_done(kt);
@@ -611,6 +645,7 @@ __global__ __launch_bounds__(256, BNT == 256 ? 2 : (BK == 16 ? (NST == 3 ? 3 : 4
                     for (int j = 0; j < TN; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[i], b1[j], acc[i][j], 0, 0, 0);
             }
+            if (TAIL) tail_dot(kt, a_s);            // (the rows of B behind the promise are zero in this column too: the whole tile, no step count)
             tile_done(kt);
             ++kt;
         }
@@ -623,6 +658,24 @@ __global__ __launch_bounds__(256, BNT == 256 ? 2 : (BK == 16 ? (NST == 3 ? 3 : 4
     for (int j = 0; j < TN; ++j) {
         const int col = n0 + wn * (32 * TN) + j * 32 + li;
         bv[j] = (g.bias && col < g.N && blockIdx.z == 0) ? g.bias[col] : 0.f;      // (split launches: the bias goes into slab 0)
+    }
+    if (TAIL) {
+        // the folded column: the two halves of a row's dot product sit in neighbouring lanes
+        const float dot = tail_acc + __shfl_xor(tail_acc, 1, 64);
+        const int row = m0 + (tid >> 1);
+        if (!(tid & 1) && row < g.M) {
+            int64_t orow = row;
+            bool live = true;
+            if (g.row_map_bp > 0) {
+                const int t = row / g.row_map_bp, b = row - t * g.row_map_bp;
+                live = b < g.row_map_b;
+                orow = (int64_t)b * g.row_map_t + t;
+            }
+            if (live) {
+                const float rsc = g.row_scale ? g.row_scale[row] : 1.f;
+                C[orow * g.ldc + g.tail_col] = (g.alpha * dot + (g.bias ? g.bias[g.tail_col] : 0.f)) * rsc;
+            }
+        }
     }
     // Fast path of the 128 x 256 tile (whole tile inside the matrix, plain C = alpha A.B + bias): one 64-bit add per
     // store instead of the general addressing / masking / row-map code below.  Measured on the three layer GEMMs
@@ -716,6 +769,14 @@ int launch_dma(const GemmArgs& g, int splits, hipStream_t st) {
                            2 * 2 * 128 * 16 * 4, st, g);
         return avsi_launch_status();
     }
+    if (!TA && !TB && g.bnt == 256 && g.tail_col >= 0) {
+        const size_t lds_t = (size_t)3 * (128 + 256) * 16 * 4 + (size_t)g.K * 4;
+        (void)hipFuncSetAttribute((const void*)gemm_dma_kernel<false, false, 16, 3, false, 256, true>,
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_t);
+        hipLaunchKernelGGL((gemm_dma_kernel<false, false, 16, 3, false, 256, true>), dim3(g.m_blocks * g.n_blocks, 1, 1), dim3(256),
+                           lds_t, st, g);
+        return avsi_launch_status();
+    }
     if (!TB && g.bnt == 256) {
         constexpr size_t lds256 = (size_t)3 * (128 + 256) * 16 * 4;      // 72 KiB: two workgroups per CU
         (void)hipFuncSetAttribute((const void*)gemm_dma_kernel<TA, false, 16, 3, false, 256>,
@@ -806,7 +867,17 @@ int avsi_gemm_launch(int transA, int transB, int M, int N, int K, float alpha, c
     if (dma_ok && !transB && g.bnt == BN && N % 256 == 0 && (N >= 1024 || N == 256) &&
         (int64_t)g.m_blocks * (N / 256) * splits >= wide_min && env.bnt != 128)
         g.bnt = 256;
-    g.n_blocks = (int)avsi_ceil_div(N, g.bnt);
+    g.tail_col = -1;
+    // N = 257 over many rows (the projection onto the reference's 257 bins, models.py:119-122): the 256-wide tile for the first
+    // 256 columns and the last one folded into the same workgroups (gemm_dma_kernel<.., TAIL>), instead of a second launch on
+    // 32-wide tiles that reads all of A again for one column (0.87 ms of a 138 ms step at 8192 utterances).  AVSI_GEMM_FOLD_TAIL=0: off
+    static const bool fold_tail = !(getenv("AVSI_GEMM_FOLD_TAIL") && atoi(getenv("AVSI_GEMM_FOLD_TAIL")) == 0);
+    if (fold_tail && dma_ok && !transA && !transB && N == 257 && splits == 1 && beta == 0.f && K <= 1024 &&
+        (int64_t)g.m_blocks >= wide_min && env.bnt != 128) {
+        g.bnt = 256;
+        g.tail_col = 256;
+    }
+    g.n_blocks = g.tail_col >= 0 ? 1 : (int)avsi_ceil_div(N, g.bnt);
     g.c_split_stride = splits > 1 ? c_split_stride : 0;
     g.sp_kt[0] = g.sp_kt[1] = -1, g.sp_steps[0] = g.sp_steps[1] = 8;
     if (ep && dma_ok && !transA && splits == 1) {

@@ -174,12 +174,14 @@ class _Uploader(object):
         if self.device.type == 'cuda' and self.device.index is None:
             self.device = torch.device('cuda', torch.cuda.current_device())
         self.stream = None
+        self.parts = 1                      # consumer batches per uploaded batch (BatchIterator's macro reads)
 
     def __call__(self, batch, arena=None):
         torch = self.torch
         if self.stream is None:
             torch.cuda.set_device(self.device)
-            nbytes = sum(a.nbytes for a in batch if isinstance(a, np.ndarray) and a.dtype != object)
+            # (per batch the CONSUMER sees: a macro read of `parts` small batches is still small-batch work)
+            nbytes = sum(a.nbytes for a in batch if isinstance(a, np.ndarray) and a.dtype != object) // max(1, self.parts)
             # HIP maps its streams onto four hardware queues per priority level, and a normal stream created after the
             # model's side streams can land on the queue of the launch stream, where the upload and its event sit in order
             # between the step's kernels (tools/hostfed_probe.py: a 3.7 GB upload then adds its full 67 ms to a 140 ms step
@@ -282,8 +284,13 @@ class BatchIterator(object):
         self.drop_remainder = drop_remainder
         self.shard = shard
         self.decode_batch = decode_batch    # list of payloads -> batch tuple (native); None = parse + stack in Python
-        self.prefetch = int(prefetch)
+        # records per macro read of small batches (see _batches); AVSI_READER_MACRO=<records> overrides, 0 = one batch per read
+        target = int(os.environ.get('AVSI_READER_MACRO', '128'))
+        self.macro = max(1, target // self.batch_size) if self.batch_size > 0 else 1
+        self.prefetch = int(prefetch) * (self.macro if device is not None else 1)      # the thread stays a whole read ahead
         self.upload = _Uploader(device, upload_fields, count_gaps) if device is not None else None
+        if self.upload is not None and shard[1] == 1 and not self.even_rounds:
+            self.upload.parts = self.macro
         # with a device the consumer works on the uploaded copies, so the host arrays of the bulky fields (audio, video,
         # mask, embedding) are recycled and the batch tuple holds None in their places -- use Batch.to_device()
         # ... two arenas when they are page-locked: one is parsed into while the other's copies run (its next user waits for
@@ -322,12 +329,39 @@ class BatchIterator(object):
             batch = self.decode_batch(payloads)
         return self.upload(batch) if self.upload is not None else batch
 
+    def _split(self, big, sizes):
+        """The consumer's batches out of one macro read: slices of the same host arrays and of the same uploaded device
+        tensors (views: nothing is copied), all behind the one upload event."""
+        at = 0
+        for n in sizes:
+            sub = Batch(None if a is None else a[at:at + n] for a in big)
+            if getattr(big, 'device_arrays', None):
+                sub.device_arrays = {i: t[at:at + n] for i, t in big.device_arrays.items()}
+                sub.ready = big.ready
+            at += n
+            yield sub
+
     def _batches(self):
         rank, world = self.shard
+        # Small batches on one rank: `macro` consecutive batches are read, parsed and uploaded as ONE (one native call per
+        # reader thread, one arena, three copies, one event) and handed out as views.  At 32 records per batch the per-batch
+        # work of this thread -- pool hand-overs, three asynchronous copies, an event, all under the interpreter lock the
+        # launch thread also wants -- was what infer() waited for (1 ms per batch of a 2.3 ms step, DESIGN 5)
+        macro = self.macro if (world == 1 and not self.even_rounds and self.decode_batch is not None
+                               and self._arenas is not None) else 1
         batch, index, mine = [], 0, None
+        group = []
         for p in self._payloads():
             batch.append(p)
             if len(batch) == self.batch_size:
+                if macro > 1:
+                    group.append(batch)
+                    batch = []
+                    if len(group) == macro:
+                        for sub in self._split(self._make([q for b in group for q in b]), [len(b) for b in group]):
+                            yield sub
+                        group = []
+                    continue
                 if index % world == rank:
                     mine = batch
                     if not self.even_rounds:
@@ -337,6 +371,13 @@ class BatchIterator(object):
                 if self.even_rounds and index % world == 0:     # a whole round of `world` batches exists: hand out ours
                     yield self._make(mine)
                     mine = None
+        if macro > 1:
+            if batch and not self.drop_remainder:
+                group.append(batch)
+            if group:
+                for sub in self._split(self._make([q for b in group for q in b]), [len(b) for b in group]):
+                    yield sub
+            return
         if batch and not self.drop_remainder and not self.even_rounds and index % world == rank:
             yield self._make(batch)
 

@@ -427,9 +427,12 @@ class StackedBLSTMModel(object):
         pred = torch.empty((B, T, self.audio_feat_dim), dtype=torch.float32, device=self.device)
         F = self.audio_feat_dim
         x2, p2 = x.view(T * Bp, 2 * HP), pred.view(B * T, F)
-        # 257 bins = one 256-column product on the wide (128 x 256) tile + the last bin on a narrow one, instead of five
-        # 64-column tiles of which the fifth carries one useful column (AVSI_PROJ_SPLIT=0: the single product)
-        n_main = F - F % 256 if (_PROJ_SPLIT and F > 256 and 0 < F % 256 <= 32 and T * Bp >= 65536) else F
+        # 257 bins over many rows = ONE launch on the wide (128 x 256) tile whose workgroups also take the 257th bin, as a dot
+        # product on the VALU over the rows they have staged anyway (round 6, avsi_gemm_f32 does this by itself for N = 257;
+        # AVSI_GEMM_FOLD_TAIL=0: the round-3 form -- 256 bins on the wide tile + the last bin in a second launch on a narrow
+        # one, which reads all of A again; AVSI_PROJ_SPLIT=0 on top: five 64-column tiles)
+        fold = F == 257 and T * Bp >= 65536 and os.environ.get('AVSI_GEMM_FOLD_TAIL', '1') != '0'
+        n_main = F - F % 256 if (_PROJ_SPLIT and not fold and F > 256 and 0 < F % 256 <= 32 and T * Bp >= 65536) else F
         ops.gemm(x2, v.p('pw'), out=p2, n=n_main, bias=v.p('pb'), row_scale=row_scale.view(-1), row_map=(Bp, T, B),
                  k_zero=kz_hidden)
         if n_main < F:

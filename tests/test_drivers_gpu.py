@@ -261,18 +261,23 @@ def test_ctc_multitask_model_trains_and_infers(experiment, tmp_path, capsys):
     assert rate == 16000 and wav.dtype == np.int16 and wav.shape == (T * 192,)
 
 
-def test_reader_uploads_batches_from_its_prefetch_thread(experiment):
+@pytest.mark.parametrize("batch_size,macro_records,batches", [(4, 128, 3), (5, 10, 3), (5, 0, 3), (1, 5, 12)])
+def test_reader_uploads_batches_from_its_prefetch_thread(experiment, monkeypatch, batch_size, macro_records, batches):
     """get_iterator(device=...): the bulky fields arrive as device tensors equal to the numpy ones, ordered by
-    an event instead of a host synchronisation; small fields stay on the host."""
+    an event instead of a host synchronisation; small fields stay on the host.  Small batches are read several at a time
+    (AVSI_READER_MACRO records per read, round 6) and handed out as views of one upload: 12 files as 3 x 4 in one read,
+    as 5 + 5 | 2 (a short last batch, alone in the second read), one batch per read, and 12 single records in reads of 5."""
     import torch
+    monkeypatch.setenv('AVSI_READER_MACRO', str(macro_records))
     from avsi_amd.dataset_reader import DataManager
     from avsi_amd.training import unpack_batch
     base, data, cfg = experiment
     files = sorted(os.path.join(data, "training-set", f) for f in os.listdir(os.path.join(data, "training-set"))
                    if f.endswith(".tfrecord"))
     dm = DataManager(num_audio_samples=N, audio_feat_size=257, video_feat_size=136)
-    _, it = dm.get_iterator(dm.get_dataset(files, shuffle=False), batch_size=4, n_epochs=1, device='cuda')
-    _, ref = dm.get_iterator(dm.get_dataset(files, shuffle=False), batch_size=4, n_epochs=1)
+    _, it = dm.get_iterator(dm.get_dataset(files, shuffle=False), batch_size=batch_size, n_epochs=1, device='cuda')
+    assert it.macro == max(1, macro_records // batch_size)
+    _, ref = dm.get_iterator(dm.get_dataset(files, shuffle=False), batch_size=batch_size, n_epochs=1)
     n = 0
     for b, r in zip(it, ref):
         n += 1
@@ -288,7 +293,7 @@ def test_reader_uploads_batches_from_its_prefetch_thread(experiment):
         assert b[2] is None and b[5] is None and b[6] is None
         np.testing.assert_array_equal(b[0], r[0])
         assert list(paths) == list(r[3])
-    assert n == 3
+    assert n == batches
 
 
 def _launch_dp_training(cfg, ranks, extra_env=None, timeout=1200):

@@ -63,28 +63,38 @@ def test_row_scale_and_time_major_row_map(ops):
     np.testing.assert_allclose(out.cpu().numpy(), ref[:, :B].transpose(1, 0, 2), atol=1e-4)
 
 
-@pytest.mark.parametrize("T,B,Bp", [(250, 270, 288), (9, 7500, 7520)])
-def test_projection_as_256_bins_plus_tail(ops, T, B, Bp):
-    """The 257-bin projection the way the model issues it from 65536 rows on (models.py:117-123): N = 256 takes the
-    128 x 256 tile with the general epilogue (sequence mask, time-major -> batch-major rows, row pitch 257), the last
-    bin a 32-wide tile on column views of W, bias and the output -- against numpy, and bit for bit against the single
-    257-column product."""
+@pytest.mark.parametrize("T,B,Bp,padded", [(250, 270, 288, False), (9, 7500, 7520, False), (250, 270, 288, True)])
+def test_projection_with_the_last_bin_folded_into_the_wide_tile(ops, T, B, Bp, padded):
+    """The 257-bin projection the way the model issues it from 65536 rows on (models.py:117-123): ONE launch on the
+    128 x 256 tile with the general epilogue (sequence mask, time-major -> batch-major rows, row pitch 257) whose workgroups
+    take the 257th bin as a dot product on the VALU over the rows they have staged (round 6) -- against numpy, and against
+    the round-3 form: N = 256 on the wide tile (bit for bit: the same MFMA chains) + the last bin on a 32-wide tile on column
+    views of W, bias and the output (another order of the 512-long sum: to rounding).  `padded`: with the zero padding of
+    the two 250-unit halves promised (k_zero), i.e. through the short special tiles, as the model calls it."""
     K, N = 512, 257
     rng = np.random.default_rng(B)
     X = rng.normal(size=(T, Bp, K)).astype(np.float32)
     W = _pad_cols((rng.normal(size=(K, N)) * 0.05).astype(np.float32), 260)
+    kz = None
+    if padded:          # (the promise is about the ROWS OF W; X keeps values there, as the training pass's column of ones does)
+        W[250:256] = 0
+        W[506:512] = 0
+        kz = ((250, 256), (506, 512))
     bias = rng.normal(size=260).astype(np.float32)
     scale = (rng.uniform(size=(T, Bp)) > 0.3).astype(np.float32)
     x, w, b = torch.from_numpy(X).cuda().view(T * Bp, K), torch.from_numpy(W).cuda(), torch.from_numpy(bias).cuda()
     rs = torch.from_numpy(scale).cuda().view(-1)
     one = torch.full((B * T, N), 7.0, device='cuda')
     two = torch.full((B * T, N), 9.0, device='cuda')
-    ops.gemm(x, w, out=one, n=N, bias=b, row_scale=rs, row_map=(Bp, T, B))
-    ops.gemm(x, w, out=two, n=256, bias=b, row_scale=rs, row_map=(Bp, T, B))
+    ops.gemm(x, w, out=one, n=N, bias=b, row_scale=rs, row_map=(Bp, T, B), k_zero=kz)
+    ops.gemm(x, w, out=two, n=256, bias=b, row_scale=rs, row_map=(Bp, T, B), k_zero=kz)
     assert float(two[:, 256].min()) == 9.0          # the 256-bin product leaves the last column alone
-    ops.gemm(x, w[:, 256:N], out=two[:, 256:], n=1, bias=b[256:N], row_scale=rs, row_map=(Bp, T, B))
-    assert torch.equal(one, two)
+    ops.gemm(x, w[:, 256:N], out=two[:, 256:], n=1, bias=b[256:N], row_scale=rs, row_map=(Bp, T, B), k_zero=kz)
+    assert torch.equal(one[:, :256], two[:, :256])
+    assert float((one[:, 256] - two[:, 256]).abs().max()) < 2e-5
+    assert float(one[:, 256].abs().max()) > 0.5     # (the folded column was written: not the 7.0 fill, not zeros)
     ref = (X.astype(np.float64) @ W[:, :N].astype(np.float64) + bias[:N]) * scale[:, :, None]
+    np.testing.assert_allclose(one.view(B, T, N).cpu().numpy(), ref[:, :B].transpose(1, 0, 2), atol=2e-4)
     np.testing.assert_allclose(two.view(B, T, N).cpu().numpy(), ref[:, :B].transpose(1, 0, 2), atol=2e-4)
 
 

@@ -134,14 +134,14 @@ def test_sgd_momentum_kernel_matches_tf_form(mods, momentum):
 @pytest.mark.parametrize("optimizer", ["sgd", "momentum"])
 def test_three_sgd_and_momentum_steps_track_oracle(mods, optimizer):
     """The reference's other optimizer_type choices through train_op (models.py:165-176): staircase-decayed rate
-    (lr_updating_steps = 2, decay 0.5: the third step runs at half the rate), three steps against the oracle's forward /
-    backward and the numpy update.  Not scale-free like Adam: the variables track the oracle to the gradients' accuracy."""
+    (rate 1.0 -- the gradients of a mean over B*T*F are small --, lr_updating_steps = 2, decay 0.5: the third step runs at half
+    the rate), three steps against the oracle's forward / backward and the numpy update.  Not scale-free like Adam: the variables track the oracle to the gradients' accuracy."""
     models, ops, bl = mods
     B, N = 4, 2880
     wav, masks, mean, std, video, T = _inputs(B, N, 51)
     p = _rand_biases(O.init_params(11, 257), 12)
     seq_len = np.full(B, T)
-    cfg = _config(audio_len=N, optimizer_type=optimizer, starter_learning_rate=0.05, lr_updating_steps=2, lr_decay=0.5)
+    cfg = _config(audio_len=N, optimizer_type=optimizer, starter_learning_rate=1.0, lr_updating_steps=2, lr_decay=0.5)
     m = models.StackedBLSTMModel(seq_len, wav, masks, mean, std, 0.0, cfg, input='a')
     m.variables.load_flat(m.layout.flatten_oracle_params(p))
     p64 = O.cast_params(p, np.float64)
@@ -152,7 +152,7 @@ def test_three_sgd_and_momentum_steps_track_oracle(mods, optimizer):
     for step in range(3):
         fwd = O.model_forward(wav, masks, mean, std, seq_len, p64, keep=True)
         g = O.model_backward(fwd, masks.astype(np.float64), seq_len)
-        lr = O.exponential_decay(0.05, step, 2, 0.5)
+        lr = O.exponential_decay(1.0, step, 2, 0.5)
         for (_, gv), pv, av in zip(O.flatten_params(g), flat, accs):
             if optimizer == 'sgd':
                 O.sgd_tf_step(pv, gv, lr)
@@ -161,7 +161,7 @@ def test_three_sgd_and_momentum_steps_track_oracle(mods, optimizer):
         m.feed(sequence_lengths=seq_len, target_sources=wav, masks=masks)
         rates.append(m.learning_rate)
         assert m.train_op is None and m.global_step == step + 1
-    assert rates == [0.05, 0.05, 0.025]
+    assert rates == [1.0, 1.0, 0.5]
     ref_flat = m.layout.flatten_oracle_params(p64).astype(np.float64)
     got_flat = m.variables.flat.cpu().numpy().astype(np.float64)
     moved = np.abs(ref_flat - init).max()
