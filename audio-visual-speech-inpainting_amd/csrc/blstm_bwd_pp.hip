@@ -135,11 +135,11 @@ __device__ __forceinline__ rsrc_t rsrc_z(const Ctx& c, const Step& w) {
 // DIAG (diagnostic builds of the kernel, AVSI_BWD_PP_DIAG; results are then WRONG): 1 = no cell arithmetic / dz stores,
 // 2 = no cell input loads, 4 = no dz stores, 8 = Wh^T fragments loaded once per phase, 16 = no publish,
 // 4096 = the fragment pointers as 128 loop-invariant bases (what the kernel did before: results right, v_readlane pairs).
-template <int X, bool DO_MFMA, bool DO_CELL, int DIAG>
+template <int X, bool DO_MFMA, bool DO_CELL, int DIAG, bool CIRC>
 __device__ __forceinline__ void bwd_pp_phase(f32x16 (&dhrec)[2], float (&dcn)[2][16], float (&ccar)[2][16], float (&dzh)[64],
                                              RowsC& ca, RowsC& cb,
-                                             const float* __restrict__ zbuf, const float4* __restrict__ wb, const int lane,
-                                             const int li, const int hi, const Ctx ctx, const Step cy, const Step nx,
+                                             const float* __restrict__ zbuf, const float4* __restrict__ wb, float4 (&bw)[RING],
+                                             const int lane, const int li, const int hi, const Ctx ctx, const Step cy, const Step nx,
                                              const int voff_h, const int voff_r, const int voff_z) {
     constexpr int Y = 1 - X;
     auto loadc = [&](RowsC& in, const Step& who0, int r0) {
@@ -272,19 +272,21 @@ __device__ __forceinline__ void bwd_pp_phase(f32x16 (&dhrec)[2], float (&dcn)[2]
         }
     };
 
-    float4 bw[RING], af[2];
-    gptr4 wrun = opaque_base(wb);                // the fragment group requested next
+    // The fragment ring is CIRCULAR over the phases (round 6): every MFMA phase reads the same 128 groups, so the last AHEAD
+    // requests of a phase are the first AHEAD groups of the next one, already in the ring (`bw` lives in the kernel) when that
+    // phase begins behind its barrier -- a phase used to open with AHEAD loads and nothing to issue until they were back
+    // from L2 (the forward kernel's version of this, its first group kept in registers, took 4 % off a launch).
+    float4 af[2];
+    gptr4 wrun = opaque_base(wb + (CIRC ? AHEAD * 64 : 0));   // the fragment group requested next
     if (DO_MFMA) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) dhrec[X][r] = 0.f;
+        if (!CIRC) {            // (AVSI_BWD_PP_CIRC=0, A/B only: the phase requests its first groups itself, as before round 6)
 #pragma unroll
-        for (int g = 0; g < AHEAD; ++g) {
-            if (DIAG & 4096) {      // (the form before: one opaque base per group, all of them loop-invariant)
-                bw[g] = ldg4(opaque_base(wb + g * 64), lane);
-                continue;
+            for (int g = 0; g < AHEAD; ++g) {
+                bw[g] = ldg4(wrun, lane);
+                wrun = opaque_next(wrun, 64);
             }
-            bw[g] = ldg4(wrun, lane);
-            wrun = opaque_next(wrun, 64);
         }
         af[0] = *reinterpret_cast<const float4*>(zbuf + li * ZS + 4 * hi);
     }
@@ -301,9 +303,10 @@ __device__ __forceinline__ void bwd_pp_phase(f32x16 (&dhrec)[2], float (&dcn)[2]
         }
         if (q == 112) loadc(ca, nx, 0);          // first chunk of the next phase's cell (zero-record descriptors: none)
         if (DO_MFMA) {
-            if (q + AHEAD < 128 && !((DIAG & 8) && q + AHEAD >= 8)) {
+            if ((CIRC || q + AHEAD < 128) && !((DIAG & 8) && q + AHEAD >= 8)) {
+                if (q + AHEAD == 128) wrun = opaque_base(wb);           // around: the next phase's first groups
                 if (DIAG & 4096) {
-                    bw[(q + AHEAD) & (RING - 1)] = ldg4(opaque_base(wb + (q + AHEAD) * 64), lane);
+                    bw[(q + AHEAD) & (RING - 1)] = ldg4(opaque_base(wb + ((q + AHEAD) & 127) * 64), lane);
                 } else {
                     bw[(q + AHEAD) & (RING - 1)] = ldg4(wrun, lane);
                     wrun = opaque_next(wrun, 64);
@@ -325,7 +328,7 @@ __device__ __forceinline__ void bwd_pp_phase(f32x16 (&dhrec)[2], float (&dcn)[2]
     }
 }
 
-template <int DIAG>
+template <int DIAG, bool CIRC = true>
 __global__ __launch_bounds__(512, 2) void blstm_rec_bwd_pp_kernel(const BwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* zbuf = reinterpret_cast<float*>(smem);  // [32][ZS]: dz of the tile whose MFMA phase comes next
@@ -388,27 +391,30 @@ __global__ __launch_bounds__(512, 2) void blstm_rec_bwd_pp_kernel(const BwdArgs 
             ca.cp[e] = buf_load(d.rp, voff_r, rowc * RROW + 4 * HP * 4);
         }
     }
+    float4 bw[RING];          // the Wh^T fragment ring, circular over the phases: its first AHEAD groups for the first MFMA phase
+#pragma unroll
+    for (int g = 0; g < RING; ++g) bw[g] = g < AHEAD ? wb[g * 64 + lane] : make_float4(0.f, 0.f, 0.f, 0.f);
     // prologue: cell tile 0, step 0 (dhrec = 0), no MFMA; then request the first chunk of tile 1, step 0
-    bwd_pp_phase<1, false, true, DIAG>(dhrec, dcn, ccar, dzh, ca, cb, zbuf, wb, lane, li, hi, ctx, Step{0, 0, 1}, Step{1, 0, 1}, voff_h,
+    bwd_pp_phase<1, false, true, DIAG, CIRC>(dhrec, dcn, ccar, dzh, ca, cb, zbuf, wb, bw, lane, li, hi, ctx, Step{0, 0, 1}, Step{1, 0, 1}, voff_h,
                                  voff_r, voff_z);
     publish();
     AVSI_LDS_BARRIER();
     for (int s = 0; s + 1 < T; ++s) {
         // phase A: MFMA tile 0 (dz_0(s) -> dhrec_0 for step s + 1) || cell tile 1, step s
-        bwd_pp_phase<0, true, true, DIAG>(dhrec, dcn, ccar, dzh, ca, cb, zbuf, wb, lane, li, hi, ctx, Step{1, s, 1}, Step{0, s + 1, 1},
+        bwd_pp_phase<0, true, true, DIAG, CIRC>(dhrec, dcn, ccar, dzh, ca, cb, zbuf, wb, bw, lane, li, hi, ctx, Step{1, s, 1}, Step{0, s + 1, 1},
                                     voff_h, voff_r, voff_z);
         AVSI_LDS_BARRIER();       // every wave is done reading dz_0(s)
         publish();                // dz_1(s)
         AVSI_LDS_BARRIER();
         // phase B: MFMA tile 1 (dz_1(s) -> dhrec_1 for step s + 1) || cell tile 0, step s + 1
-        bwd_pp_phase<1, true, true, DIAG>(dhrec, dcn, ccar, dzh, ca, cb, zbuf, wb, lane, li, hi, ctx, Step{0, s + 1, 1}, Step{1, s + 1, 1},
+        bwd_pp_phase<1, true, true, DIAG, CIRC>(dhrec, dcn, ccar, dzh, ca, cb, zbuf, wb, bw, lane, li, hi, ctx, Step{0, s + 1, 1}, Step{1, s + 1, 1},
                                     voff_h, voff_r, voff_z);
         AVSI_LDS_BARRIER();
         publish();                // dz_0(s + 1)
         AVSI_LDS_BARRIER();
     }
     // epilogue: cell tile 1, step T - 1 (its dhrec comes from the last phase B; for T = 1 it is zero)
-    bwd_pp_phase<0, false, true, DIAG>(dhrec, dcn, ccar, dzh, ca, cb, zbuf, wb, lane, li, hi, ctx, Step{1, T - 1, 1}, Step{0, T, 0}, voff_h,
+    bwd_pp_phase<0, false, true, DIAG, CIRC>(dhrec, dcn, ccar, dzh, ca, cb, zbuf, wb, bw, lane, li, hi, ctx, Step{1, T - 1, 1}, Step{0, T, 0}, voff_h,
                                  voff_r, voff_z);
     if (DIAG && T < 0) {        // never true: the diagnostic variants must not lose their arithmetic to dead-code elimination
         float s = 0.f;
@@ -464,7 +470,14 @@ int avsi_blstm_rec_bwd_pp_launch(const float* dhout, const float* reserve, const
         default: AVSI_PP_LAUNCH(0); break;
     }
 #else
-    AVSI_PP_LAUNCH(0);
+    // AVSI_BWD_PP_CIRC=0 (A/B only): every MFMA phase requests its first fragment groups itself, as before round 6
+    static const bool circ = !(getenv("AVSI_BWD_PP_CIRC") && atoi(getenv("AVSI_BWD_PP_CIRC")) == 0);
+    if (circ) {
+        AVSI_PP_LAUNCH(0);
+    } else {
+        (void)hipFuncSetAttribute((const void*)blstm_rec_bwd_pp_kernel<0, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL((blstm_rec_bwd_pp_kernel<0, false>), dim3((Bp + 63) / 64, 2), dim3(512), lds, st, a);
+    }
 #endif
 #undef AVSI_PP_LAUNCH
     return avsi_launch_status();

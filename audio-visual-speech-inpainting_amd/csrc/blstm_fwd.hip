@@ -267,9 +267,9 @@ __device__ __forceinline__ float4 ldg4(gptr4 p, int idx) {
     return make_float4(v.x, v.y, v.z, v.w);
 }
 
-template <int X, bool DO_MFMA, bool SAVE>
+template <int X, bool DO_MFMA, bool SAVE, bool AVSI_PP_RESIDENT0>
 __device__ __forceinline__ void pp_phase(f32x16 (&acc)[2][4], f32x16 (&c)[2], float* __restrict__ hbuf,
-                                         const float4* __restrict__ wb, const int lane, const rsrc_t rx_next,
+                                         const float4* __restrict__ wb, const float4 (&bfirst)[4], const int lane, const rsrc_t rx_next,
                                          const rsrc_t rh, const rsrc_t rr, const int voff_x, const int voff_h,
                                          const int voff_r, const int w, const int li, const int hi) {
     constexpr int Y = 1 - X;
@@ -278,11 +278,14 @@ __device__ __forceinline__ void pp_phase(f32x16 (&acc)[2][4], f32x16 (&c)[2], fl
     float* hy = hbuf + Y * (32 * HS) + (4 * hi) * HS + w * 32 + li;         // tile Y: written by the cell
     float4 bw[2][4], af[2];
     f32x16 nx[4];  // tile Y's next pre-activations: loaded once acc[Y] is dead, then become acc[Y]
-    gptr4 wrun = opaque_base(wb);                // the fragment group requested next
+    // Every phase starts with the SAME fragment group (k = 0 .. 7 of this wave's columns): it stays in registers for the
+    // whole launch (AVSI_PP_RESIDENT0, round 6) -- a phase used to open with these four loads right behind its barrier and
+    // nothing to do until they came back from L2 (twice per step: ~1 us of a 64 us step)
+    gptr4 wrun = opaque_base(wb + (AVSI_PP_RESIDENT0 ? 256 : 0));                // the fragment group requested next
     if (DO_MFMA) {
 #pragma unroll
-        for (int g = 0; g < 4; ++g) bw[0][g] = ldg4(wrun, g * 64 + lane);
-        wrun = opaque_next(wrun, 256);
+        for (int g = 0; g < 4; ++g) bw[0][g] = AVSI_PP_RESIDENT0 ? bfirst[g] : ldg4(wrun, g * 64 + lane);
+        if (!AVSI_PP_RESIDENT0) wrun = opaque_next(wrun, 256);
         af[0] = *reinterpret_cast<const float4*>(hx + li * HS + 4 * hi);
     }
 #pragma unroll
@@ -343,7 +346,7 @@ __device__ __forceinline__ void pp_phase(f32x16 (&acc)[2][4], f32x16 (&c)[2], fl
     for (int g = 0; g < 4; ++g) acc[Y][g] = nx[g];
 }
 
-template <bool SAVE>
+template <bool SAVE, bool AVSI_PP_RESIDENT0 = true>
 __global__ __launch_bounds__(512, 2) void blstm_rec_fwd_pp_kernel(const RecArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* hbuf = reinterpret_cast<float*>(smem);  // [2 tiles][32][HS]
@@ -371,6 +374,9 @@ __global__ __launch_bounds__(512, 2) void blstm_rec_fwd_pp_kernel(const RecArgs 
     for (int m = 0; m < 2; ++m)
 #pragma unroll
         for (int r = 0; r < 16; ++r) c[m][r] = 0.f;
+    float4 bfirst[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) bfirst[g] = AVSI_PP_RESIDENT0 ? wb[g * 64 + lane] : make_float4(0.f, 0.f, 0.f, 0.f);
 
     auto row0_of = [&](int step) { return ((size_t)(dir ? (T - 1 - step) : step)) * Bp + b0; };
     {   // gate pre-activations of step 0 for both tiles
@@ -397,32 +403,230 @@ __global__ __launch_bounds__(512, 2) void blstm_rec_fwd_pp_kernel(const RecArgs 
     // prologue: h_{-1} = 0, so the step-0 pre-activations are final without any MFMA.
     //   cell tile 0 (step 0) -> load tile 0 (step 1)
     out_rsrc(0, rh, rr);
-    pp_phase<1, false, SAVE>(acc, c, hbuf, wb, lane, in_rsrc(T > 1 ? 1 : 0, T > 1), rh, rr, voff_x, voff_h, voff_r, w, li, hi);
+    pp_phase<1, false, SAVE, AVSI_PP_RESIDENT0>(acc, c, hbuf, wb, bfirst, lane, in_rsrc(T > 1 ? 1 : 0, T > 1), rh, rr, voff_x, voff_h, voff_r, w, li, hi);
     AVSI_LDS_BARRIER();
     for (int step = 0; step + 1 < T; ++step) {
         // phase A: MFMA tile 0 (step + 1) || cell tile 1 (step) -> load tile 1 (step + 1)
         out_rsrc(step, rh, rr);
-        pp_phase<0, true, SAVE>(acc, c, hbuf, wb, lane, in_rsrc(step + 1, true), rh, rr, voff_x, voff_h, voff_r, w, li, hi);
+        pp_phase<0, true, SAVE, AVSI_PP_RESIDENT0>(acc, c, hbuf, wb, bfirst, lane, in_rsrc(step + 1, true), rh, rr, voff_x, voff_h, voff_r, w, li, hi);
         AVSI_LDS_BARRIER();
         // phase B: MFMA tile 1 (step + 1) || cell tile 0 (step + 1) -> load tile 0 (step + 2)
         const bool more = step + 2 < T;
         out_rsrc(step + 1, rh, rr);
-        pp_phase<1, true, SAVE>(acc, c, hbuf, wb, lane, in_rsrc(more ? step + 2 : step + 1, more), rh, rr, voff_x, voff_h, voff_r,
+        pp_phase<1, true, SAVE, AVSI_PP_RESIDENT0>(acc, c, hbuf, wb, bfirst, lane, in_rsrc(more ? step + 2 : step + 1, more), rh, rr, voff_x, voff_h, voff_r,
                                 w, li, hi);
         AVSI_LDS_BARRIER();
     }
     // epilogue: cell tile 1 (step T - 1)
     out_rsrc(T - 1, rh, rr);
-    pp_phase<0, false, SAVE>(acc, c, hbuf, wb, lane, in_rsrc(T - 1, false), rh, rr, voff_x, voff_h, voff_r, w, li, hi);
+    pp_phase<0, false, SAVE, AVSI_PP_RESIDENT0>(acc, c, hbuf, wb, bfirst, lane, in_rsrc(T - 1, false), rh, rr, voff_x, voff_h, voff_r, w, li, hi);
+}
+
+// ------------------------------------------------------------------------------------------
+// Quarter-block variant (round 6; 64 rows per workgroup, Wh fetched from L2 ONCE per step and workgroup).
+// The ping-pong kernel above hides a tile's cell under the other tile's MFMAs, and pays for it with the weight stream:
+// its two tiles are in opposite phases, so every fragment of Wh comes up from L2 twice per step (128 of the 159 GB a
+// launch moves between L2 and L1; the L1's miss queue is a third full and the socket's power cap takes 4 % of the clock,
+// DESIGN 4.3).  The kernel that puts both tiles into ONE MFMA phase (blstm_rec_fwd_kernel<2>) halves the stream and
+// runs at 2.38 instead of 2.21 GHz -- but its cells run in the open (matrix pipes busy 0.72 instead of 0.89: 19.1 ms
+// against 16.3).  Here both are had: the split that makes room for the cell is over the HIDDEN UNITS, not over the rows.
+//   - wave w = (tile, v): row tile w / 4, unit blocks 2 v (set U0) and 2 v + 1 (set U1) -- 64 units x 4 gates, one row tile:
+//     the same 128 accumulator registers as a ping-pong wave.  Waves w and w + 4 share a SIMD and read the SAME
+//     fragments at the same time: one of the two requests misses in the CU's L1, the other is merged with it;
+//   - a step is four quarter products Q[cols][k set] of 256 MFMAs per wave, ordered so that every cell has matrix work
+//     of OTHER columns beside it, on h values that exist already:
+//         Q00(s)  U0 columns, k in U0   ||  cell U1 (step s - 1) -> h_{s-1}[U1], then loads x_s[U1]
+//         -- barrier --
+//         Q01(s)  U0 columns, k in U1                              (z_s[U0] complete)
+//         Q11(s)  U1 columns, k in U1   ||  cell U0 (step s)     -> h_s[U0] into the OTHER h buffer
+//         Q10(s)  U1 columns, k in U0   ||  loads x_{s+1}[U0]
+//         -- barrier --
+//     h is double buffered (133 KB: one workgroup per CU, as the ping-pong kernel at this batch size);
+//   - sums: x + (k in U0) + (k in U1) for U0 columns, x + (k in U1) + (k in U0) for U1 columns -- another order than
+//     the other kernels' 0 .. 255: equal to rounding, not to the bit.
+// ------------------------------------------------------------------------------------------
+// MODE: 0 = matrix work only, 1 = + the cell of the OTHER unit set (one element per k group), 2 = + loads of its next
+// pre-activations (two elements per k group, groups 0 .. 7), 3 = cell and loads (loads in groups 8 .. 15: behind their cells)
+template <int KSET, int MODE, bool DO_MFMA, bool SAVE>
+__device__ __forceinline__ void q_block(f32x16 (&am)[4], const float* __restrict__ hx, const float4* __restrict__ wb, const int lane,
+                                        f32x16 (&ac)[4], f32x16& cc, float* __restrict__ hy, const rsrc_t rh, const rsrc_t rr,
+                                        const rsrc_t rx_next, const int voff_h, const int voff_r, const int voff_x) {
+    constexpr int XROW = 2 * GP * 4, HROW = 2 * HP * 4, RROW = 2 * 5 * HP * 4;
+    float4 bw[2][4], af[2];
+    gptr4 wrun = opaque_base(wb + KSET * 4 * 256);       // the fragment group requested next: k groups KSET * 4 + {0..3, 8..11, ..}
+    if (DO_MFMA) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) bw[0][g] = ldg4(wrun, g * 64 + lane);
+        wrun = opaque_next(wrun, 256);
+        af[0] = *reinterpret_cast<const float4*>(hx + 8 * (KSET * 4));
+    }
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        const int cb = j & 1;
+        if (DO_MFMA) {
+            if (j + 1 < 16) {
+                const int qn = ((j + 1) >> 2) * 8 + KSET * 4 + ((j + 1) & 3);
+                if (((j + 1) & 3) == 0) wrun = opaque_next(wrun, 4 * 256);     // over the other set's four groups
+#pragma unroll
+                for (int g = 0; g < 4; ++g) bw[cb ^ 1][g] = ldg4(wrun, g * 64 + lane);
+                wrun = opaque_next(wrun, 256);
+                af[cb ^ 1] = *reinterpret_cast<const float4*>(hx + 8 * qn);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const float av = s == 0 ? af[cb].x : s == 1 ? af[cb].y : s == 2 ? af[cb].z : af[cb].w;
+                    const float4 b4 = bw[cb][g];
+                    const float bv = s == 0 ? b4.x : s == 1 ? b4.y : s == 2 ? b4.z : b4.w;
+                    am[g] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, am[g], 0, 0, 0);
+                }
+        }
+        if (MODE & 1) {
+            const int r = j;
+            const int rowc = (r & 3) + 8 * (r >> 2);
+            const float ig = sigmoidf_fast(ac[0][r]);
+            const float jg = tanhf_fast(ac[1][r]);
+            const float fg = sigmoidf_fast(ac[2][r]);
+            const float og = sigmoidf_fast(ac[3][r]);
+            const float cn = fg * cc[r] + ig * jg;
+            cc[r] = cn;
+            const float hn = og * tanhf_fast(cn);
+            hy[rowc * HS] = hn;
+            buf_store(rh, voff_h, rowc * HROW, hn);
+            if (SAVE) {
+                buf_store_nt(rr, voff_r, rowc * RROW + 0 * HP * 4, ig);
+                buf_store_nt(rr, voff_r, rowc * RROW + 1 * HP * 4, jg);
+                buf_store_nt(rr, voff_r, rowc * RROW + 2 * HP * 4, fg);
+                buf_store_nt(rr, voff_r, rowc * RROW + 3 * HP * 4, og);
+                buf_store_nt(rr, voff_r, rowc * RROW + 4 * HP * 4, cn);
+            }
+        }
+        if ((MODE & 2) && (MODE == 2 ? j < 8 : j >= 8)) {
+            // the cell's accumulators are dead from its element on: they take the next step's pre-activations
+            // (a zero-record descriptor makes these loads return 0)
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const int r = 2 * (j & 7) + e;
+                const int rowc = (r & 3) + 8 * (r >> 2);
+#pragma unroll
+                for (int g = 0; g < 4; ++g) ac[g][r] = buf_load_x(rx_next, voff_x, rowc * XROW + g * 128);
+            }
+        }
+    }
+}
+
+template <bool SAVE>
+__global__ __launch_bounds__(512, 2) void blstm_rec_fwd_q_kernel(const RecArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* hbuf = reinterpret_cast<float*>(smem);  // [2 buffers][64 rows][HS]
+    constexpr int XROW = 2 * GP * 4, HROW = 2 * HP * 4, RROW = 2 * 5 * HP * 4;
+    constexpr int HBUF = 64 * HS;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int v = w & 3, trow = (w >> 2) * 32;
+    const int li = lane & 31, hi = lane >> 5;
+    const int dir = blockIdx.y;
+    const int b0 = a.row0 + blockIdx.x * 64;
+    const int T = a.T, Bp = a.Bp;
+    // (the wave's row tile is part of the descriptors' base: row offsets stay compile-time constants, as in the kernels above;
+    //  with the tile's first row as a run-time term every one of the 64 + 64 + 16 offsets of a step became a live SGPR: 199 spilled)
+    // (readfirstlane: min / max of uniform values is matched to v_med3_i32, the descriptors then live in VGPRs and every buffer
+    //  access is wrapped in a waterfall loop -- 700 branches in this kernel)
+    const int live_rows = __builtin_amdgcn_readfirstlane(max(0, min(32, a.rend - b0 - trow)));
+
+    for (int i = tid; i < 2 * HBUF; i += 512) hbuf[i] = 0.f;
+
+    // the two unit blocks of this wave: fragments, and the lane's columns of xproj / hout / reserve
+    const float4* __restrict__ wb0 = reinterpret_cast<const float4*>(a.whp) + (size_t)(dir * NWAVE + 2 * v) * (32 * 4 * 64);
+    const float4* __restrict__ wb1 = wb0 + 32 * 4 * 64;
+    const int voff_x0 = 4 * hi * XROW + (dir * GP + (2 * v) * 128 + li) * 4, voff_x1 = voff_x0 + 128 * 4;
+    const int voff_h0 = 4 * hi * HROW + (dir * HP + (2 * v) * 32 + li) * 4, voff_h1 = voff_h0 + 32 * 4;
+    const int voff_r0 = 4 * hi * RROW + (dir * 5 * HP + (2 * v) * 32 + li) * 4, voff_r1 = voff_r0 + 32 * 4;
+    // LDS: this lane's row of the h tile for the fragment reads, its (row group, unit) for the cells' writes
+    const int hx_off = (trow + li) * HS + 4 * hi;
+    const int hy_off0 = (trow + 4 * hi) * HS + (2 * v) * 32 + li, hy_off1 = hy_off0 + 32;
+
+    f32x16 acc0[4], acc1[4], c0, c1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) c0[r] = c1[r] = 0.f;
+
+    auto row0_of = [&](int step) { return ((size_t)(dir ? (T - 1 - step) : step)) * Bp + b0 + trow; };
+    {   // gate pre-activations of step 0, both unit sets
+        const rsrc_t rx = make_rsrc(a.xproj + row0_of(0) * (2 * GP), live_rows * XROW);
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int rowc = (r & 3) + 8 * (r >> 2);
+                acc0[g][r] = buf_load_x(rx, voff_x0, rowc * XROW + g * 128);
+                acc1[g][r] = buf_load_x(rx, voff_x1, rowc * XROW + g * 128);
+            }
+    }
+    __syncthreads();
+    auto out_rsrc = [&](int step, rsrc_t& rh, rsrc_t& rr) {
+        const size_t r = row0_of(step);
+        rh = make_rsrc(a.hout + r * (2 * HP), live_rows * HROW);
+        rr = SAVE ? make_rsrc(a.resv + r * (2 * 5 * HP), live_rows * RROW) : rh;
+    };
+    auto in_rsrc = [&](int step, bool on) {
+        return make_rsrc(a.xproj + row0_of(on ? step : 0) * (2 * GP), on ? live_rows * XROW : 0);
+    };
+    rsrc_t rh, rr;
+    // prologue: h_{-1} = 0, the step-0 pre-activations are final.  cell U0 (step 0) -> buffer 0, loads x_1[U0]
+    out_rsrc(0, rh, rr);
+    q_block<0, 3, false, SAVE>(acc1, hbuf + hx_off, wb0, lane, acc0, c0, hbuf + hy_off0, rh, rr, in_rsrc(1, T > 1), voff_h0, voff_r0,
+                               voff_x0);
+    AVSI_LDS_BARRIER();
+    for (int step = 1; step < T; ++step) {
+        float* hcur = hbuf + ((step - 1) & 1) * HBUF;
+        float* hnext = hbuf + (step & 1) * HBUF;
+        // Q00 || cell U1 (step - 1) -> hcur[U1], loads x_step[U1]
+        out_rsrc(step - 1, rh, rr);
+        q_block<0, 3, true, SAVE>(acc0, hcur + hx_off, wb0, lane, acc1, c1, hcur + hy_off1, rh, rr, in_rsrc(step, true), voff_h1,
+                                  voff_r1, voff_x1);
+        AVSI_LDS_BARRIER();
+        // Q01
+        q_block<1, 0, true, SAVE>(acc0, hcur + hx_off, wb0, lane, acc1, c1, hcur + hy_off1, rh, rr, rh, voff_h1, voff_r1, voff_x1);
+        // Q11 || cell U0 (step) -> hnext[U0]
+        out_rsrc(step, rh, rr);
+        q_block<1, 1, true, SAVE>(acc1, hcur + hx_off, wb1, lane, acc0, c0, hnext + hy_off0, rh, rr, rh, voff_h0, voff_r0, voff_x0);
+        // Q10 || loads x_{step+1}[U0]
+        q_block<0, 2, true, SAVE>(acc1, hcur + hx_off, wb1, lane, acc0, c0, hnext + hy_off0, rh, rr, in_rsrc(step + 1, step + 1 < T),
+                                  voff_h0, voff_r0, voff_x0);
+        AVSI_LDS_BARRIER();
+    }
+    // epilogue: cell U1 (step T - 1)
+    out_rsrc(T - 1, rh, rr);
+    q_block<0, 1, false, SAVE>(acc0, hbuf + hx_off, wb0, lane, acc1, c1, hbuf + ((T - 1) & 1) * HBUF + hy_off1, rh, rr, rh, voff_h1,
+                               voff_r1, voff_x1);
+}
+
+template <bool SAVE>
+int launch_rec_q(const RecArgs& a, hipStream_t st) {
+    const size_t lds = (size_t)2 * 64 * HS * 4;
+    (void)hipFuncSetAttribute((const void*)blstm_rec_fwd_q_kernel<SAVE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    const int tiles = (int)avsi_ceil_div(a.rend - a.row0, 64);
+    hipLaunchKernelGGL((blstm_rec_fwd_q_kernel<SAVE>), dim3(tiles, 2), dim3(512), lds, st, a);
+    return avsi_launch_status();
 }
 
 template <bool SAVE>
 int launch_rec_pp(const RecArgs& a, hipStream_t st) {
     const size_t lds = (size_t)2 * 32 * HS * 4;
-    (void)hipFuncSetAttribute((const void*)blstm_rec_fwd_pp_kernel<SAVE>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                              (int)lds);
     const int tiles = (int)avsi_ceil_div(a.rend - a.row0, 64);
-    hipLaunchKernelGGL((blstm_rec_fwd_pp_kernel<SAVE>), dim3(tiles, 2), dim3(512), lds, st, a);
+    // AVSI_PP_RESIDENT0=0 (A/B only): every phase requests its first fragment group again, as before round 6
+    static const bool resident = !(getenv("AVSI_PP_RESIDENT0") && atoi(getenv("AVSI_PP_RESIDENT0")) == 0);
+    if (resident) {
+        (void)hipFuncSetAttribute((const void*)blstm_rec_fwd_pp_kernel<SAVE, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL((blstm_rec_fwd_pp_kernel<SAVE, true>), dim3(tiles, 2), dim3(512), lds, st, a);
+    } else {
+        (void)hipFuncSetAttribute((const void*)blstm_rec_fwd_pp_kernel<SAVE, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL((blstm_rec_fwd_pp_kernel<SAVE, false>), dim3(tiles, 2), dim3(512), lds, st, a);
+    }
     return avsi_launch_status();
 }
 
@@ -450,11 +654,12 @@ extern "C" int avsi_blstm_rec_fwd_rows_f32(const float* xproj, const float* whp,
     // round where the 64-row kernel still needs one (6144 utterances, whole inference step: 131 -> 119 ms)
     int mt = rows_per_wg;
     if (mt == 0) mt = (rows > 32 * AVSI_NUM_CU / 2 && rows % 64 == 0) ? 64 : 32;
-    if (mt != 32 && mt != 64 && mt != 65) return AVSI_ERR_INVALID_ARG;
+    if (mt != 32 && mt != 64 && mt != 65 && mt != 66) return AVSI_ERR_INVALID_ARG;
     avsi_clear_error();
     const hipStream_t st = (hipStream_t)stream;
     if (mt == 64) return reserve ? launch_rec_pp<true>(a, st) : launch_rec_pp<false>(a, st);
     if (mt == 65) return reserve ? launch_rec<2, true>(a, st) : launch_rec<2, false>(a, st);  // A/B baseline
+    if (mt == 66) return reserve ? launch_rec_q<true>(a, st) : launch_rec_q<false>(a, st);
     return reserve ? launch_rec<1, true>(a, st) : launch_rec<1, false>(a, st);
 }
 

@@ -58,6 +58,7 @@ struct GemmArgs {
     // N = 256 n + 1 on the 256-wide tile (the 257-bin projection): column N - 1 is not a tile of its own -- the workgroups of the
     // last column block take it on the VALU, as a dot product of the A rows they have staged in LDS anyway (gemm_dma_kernel<.., TAIL>)
     int tail_col;          // that column's index, or -1
+    int diag;              // AVSI_GEMM_DIAG (timing experiments, results WRONG): 1 = the wide tile's fast epilogue stores nothing
     int n_group;           // N-blocks per column group of the block -> tile order (see tile_of_block)
     // up to two 16-deep k-tiles that END in zero padding (avsi_gemm_epilogue::k_zero) and the number of their eight MFMA
     // steps that multiply anything: step 4 q + s multiplies k = 8 q + s and 8 q + 4 + s, so a tile with kv leading real k
@@ -682,6 +683,10 @@ __global__ __launch_bounds__(256, BNT == 256 ? 2 : (BK == 16 ? (NST == 3 ? 3 : 4
     // of the benchmark step (ms): 128-wide general 84.6 / fast 85.4, 256-wide general 86.1 / fast 82.9 -- so the
     // narrow tiles keep the general form.
     if (BNT == 256 && g.row_map_bp == 0 && !g.row_scale && !accumulate && m0 + BM <= g.M && n0 + BNT <= g.N) {
+        if (g.diag & 1) {                    // (timing experiment: what the stores of a tile cost; one lane keeps the arithmetic alive)
+            if (acc[0][0][0] == 12345.678f) C[0] = acc[1][3][15];
+            return;
+        }
         float* cw = C + (int64_t)(m0 + wm * (32 * TM) + 4 * hi) * g.ldc + n0 + wn * (32 * TN) + li;
         const int64_t ld4 = (int64_t)4 * g.ldc;
 #pragma unroll
@@ -743,13 +748,13 @@ __global__ __launch_bounds__(256, BNT == 256 ? 2 : (BK == 16 ? (NST == 3 ? 3 : 4
 // Diagnostic switches, read once per process (a getenv per launch is a linear scan of the environment, and a small-batch
 // step issues ten GEMMs): AVSI_GEMM_BK / _MI / _DMA / _BNT / _NGROUP, -1 = not set.
 struct GemmEnv {
-    int bk, mi, dma, bnt, ngroup;
+    int bk, mi, dma, bnt, ngroup, diag;
     static int read(const char* name) {
         const char* e = getenv(name);
         return e ? atoi(e) : -1;
     }
     GemmEnv() : bk(read("AVSI_GEMM_BK")), mi(read("AVSI_GEMM_MI")), dma(read("AVSI_GEMM_DMA")), bnt(read("AVSI_GEMM_BNT")),
-                ngroup(read("AVSI_GEMM_NGROUP")) {}
+                ngroup(read("AVSI_GEMM_NGROUP")), diag(read("AVSI_GEMM_DIAG")) {}
 };
 static const GemmEnv& gemm_env() {
     static const GemmEnv e;
@@ -867,6 +872,7 @@ int avsi_gemm_launch(int transA, int transB, int M, int N, int K, float alpha, c
     if (dma_ok && !transB && g.bnt == BN && N % 256 == 0 && (N >= 1024 || N == 256) &&
         (int64_t)g.m_blocks * (N / 256) * splits >= wide_min && env.bnt != 128)
         g.bnt = 256;
+    g.diag = env.diag > 0 ? env.diag : 0;
     g.tail_col = -1;
     // N = 257 over many rows (the projection onto the reference's 257 bins, models.py:119-122): the 256-wide tile for the first
     // 256 columns and the last one folded into the same workgroups (gemm_dma_kernel<.., TAIL>), instead of a second launch on

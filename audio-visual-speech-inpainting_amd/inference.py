@@ -47,17 +47,26 @@ class _WavWriter(object):
         self.pool = ThreadPoolExecutor(max_workers=self.threads, thread_name_prefix='avsi-wav')
         self.stream = torch.cuda.Stream(device=device, priority=-1)
         self.slots = []                 # [host buffer, status words, event, pending futures]
+        self.nslots = None              # decided by the first batch's size
         self.next = 0
         self.errors = []
         self.lock = threading.Lock()
 
     def _slot(self, shape):
         torch = self.torch
-        if len(self.slots) < 3:
+        # three page-locked buffers in rotation for large batches; small ones (32 utterances: 6 MB) get up to sixteen
+        # within the same ~64 MB, so that the launch thread, which submits the batches of a whole LWS / model group in
+        # a row, does not wait for the files of the batch three submissions back
+        nbytes = 4
+        for d in shape:
+            nbytes *= int(d)
+        if self.nslots is None:
+            self.nslots = max(3, min(16, (64 << 20) // max(1, nbytes)))
+        if len(self.slots) < self.nslots:
             self.slots.append([None, torch.zeros(2, dtype=torch.int32, pin_memory=True), torch.cuda.Event(), []])
-        slot = self.slots[self.next % 3]
+        slot = self.slots[self.next % self.nslots]
         self.next += 1
-        for f in slot[3]:               # the files of the batch that used this buffer three batches ago are on disk
+        for f in slot[3]:               # the files of the batch that used this buffer a rotation ago are on disk
             f.result()
         slot[3] = []
         if slot[0] is None or tuple(slot[0].shape[1:]) != tuple(shape[1:]) or slot[0].shape[0] < shape[0]:
@@ -111,6 +120,19 @@ class _WavWriter(object):
         self.pool.shutdown()
         if self.errors:
             raise self.errors[0]
+
+
+def _adjacent(parts):
+    """True when `parts` are consecutive row ranges, from row 0 on, of one contiguous tensor (views taken with [a:b])."""
+    base = parts[0]._base
+    if base is None or not base.is_contiguous() or any(p._base is not base or not p.is_contiguous() for p in parts):
+        return False
+    at = base.data_ptr()
+    for p in parts:
+        if p.data_ptr() != at or tuple(p.shape[1:]) != tuple(base.shape[1:]):
+            return False
+        at += p.numel() * p.element_size()
+    return True
 
 
 def infer(model_path, data_path_test, audio_path, out_file_prefix, norm=True, oracle_phase=False, batch_size=1):
@@ -176,6 +198,11 @@ def infer(model_path, data_path_test, audio_path, out_file_prefix, norm=True, or
             return
         if len(pending) == 1:
             wavs, masks = pending[0][0], pending[0][1]
+        elif _adjacent([p[0] for p in pending]) and _adjacent([p[1] for p in pending]):
+            # the reader batches of ONE model step, in order: rows of the same two tensors -- no copy
+            n = sum(p[0].shape[0] for p in pending)
+            wavs = pending[0][0]._base[:n] if pending[0][0]._base is not None else pending[0][0]
+            masks = pending[0][1]._base[:n] if pending[0][1]._base is not None else pending[0][1]
         else:
             wavs = torch.cat([p[0] for p in pending])
             masks = torch.cat([p[1] for p in pending])
@@ -190,9 +217,100 @@ def infer(model_path, data_path_test, audio_path, out_file_prefix, norm=True, or
             written(paths, lengths)
         pending.clear()
 
+    # Utterances are independent in inference, and `batch_size` only says how many of them the reference hands to one
+    # sess.run (inference.py:121-131): the model step of SEVERAL reader batches is one launch sequence here -- up to
+    # AVSI_INFER_COALESCE utterances (default 1024 = the LWS group; at 32 utterances a step is latency-bound, 67 us per
+    # utterance, at 1024 it is 20 us).  What the caller sees per batch stays per batch: the 'Written ...' lines, the files,
+    # and the loss of every reader batch in the mean over batches (taken on that batch's rows of the group's prediction:
+    # for the plain models loss = mean |prediction - target| over the batch, models.py:144-158).  The variants, whose
+    # losses are ratios of sums or carry further heads, run batch by batch as before; AVSI_INFER_COALESCE=0 does for all.
+    coalesce = int(os.environ.get('AVSI_INFER_COALESCE', '1024'))
+    plain = type(model).__name__ == 'StackedBLSTMModel' and not getattr(model, 'blend', False)
+    if not plain or coalesce < 2 * batch_size:
+        coalesce = 0
+
+    spent = [0.0, 0.0, 0.0, 0.0]          # AVSI_INFER_TIMING: host seconds in concatenation, model launches, losses, hand-over
+
+    def lap(i, t0):
+        if stamps is not None:
+            spent[i] += perf_counter() - t0
+        return perf_counter()
+
+    def run(group):
+        """One model step over the reader batches of `group` [(feed, paths, lengths)], then per reader batch: loss, phase, files."""
+        t0 = perf_counter()
+        if len(group) == 1:
+            feed = group[0][0]
+        else:
+            feed = {}
+            for k, v0 in group[0][0].items():
+                vals = [g[0][k] for g in group]
+                feed[k] = None if v0 is None else (np.concatenate(vals) if isinstance(v0, np.ndarray) else torch.cat(vals))
+        t0 = lap(0, t0)
+        model.feed(**feed)
+        enhanced = model.enhanced_sources_oracle_phase if oracle_phase else model.enhanced_sources
+        t0 = lap(1, t0)
+        if len(group) == 1:
+            loss = model.loss                       # read back once, after the loop: no host round trip per batch
+            loss_list.append(loss.detach().clone() if hasattr(loss, 'detach') else float(loss))
+        else:
+            tgt, pred = model.target_spec_norm, model.prediction
+            msk = model.masks[:, :tgt.shape[1]]
+            reg = model.regularization * model.reg_loss if model.regularization else None
+            at = 0
+            for _, _, lengths in group:
+                sl = slice(at, at + len(lengths))
+                at += len(lengths)
+                parts = [tgt[sl], pred[sl], msk[sl]]
+                parts = [x.contiguous() if x.storage_offset() % 4 == 0 else x.clone() for x in parts]     # 16-byte loads
+                out3, _ = ops.l1_loss(*parts)
+                loss_list.append((out3[0] + reg if reg is not None else out3[0]).detach().clone())
+        t0 = lap(2, t0)
+        masks = None if oracle_phase else model.masks
+        status = (ops.coop_status(device),)
+
+        def deliver():
+            """Phase refinement and files of this group.  Called AFTER the next group's model step has been enqueued: handing
+            32 reader batches to the writer waits for page-locked slots, i.e. for files of earlier batches to be on disk,
+            and the GPU would otherwise sit idle behind this thread (150 - 250 ms of a 4096-utterance run)."""
+            t1 = perf_counter()
+            if oracle_phase:
+                at = 0
+                for _, paths, lengths in group:
+                    writer.submit(enhanced[at:at + len(lengths)], paths, lengths, status)
+                    at += len(lengths)
+                    written(paths, lengths)
+                lap(3, t1)
+                return
+            if pending and (pending[0][0].shape[1:] != enhanced.shape[1:] or pending[0][1].shape[1:] != masks.shape[1:]):
+                flush()                             # a batch of another length: it cannot share the launch
+            # (enhanced and the fed masks are tensors of THIS step: the next step, already enqueued, has its own)
+            alone = enhanced.shape[0] >= lws_group and not pending
+            at = 0
+            for _, paths, lengths in group:
+                sl = slice(at, at + len(lengths))
+                at += len(lengths)
+                if alone or len(group) > 1:         # rows of the group's own tensors: no copy needed
+                    pending.append((enhanced[sl], masks[sl], paths, lengths))
+                else:                               # a single reader batch: its mask tensor is the reader's upload
+                    pending.append((enhanced[sl].clone(), masks[sl].clone(), paths, lengths))
+            if sum(len(p[3]) for p in pending) >= lws_group:
+                flush()
+            lap(3, t1)
+        return deliver
+
     print('Starting inference on dataset: {:s}'.format(data_path_test))
     stamp('lws + writer')
     waited = 0.0
+    group, held, started = [], 0, False
+    deferred = []                       # deliver() of the group whose model step was enqueued last
+
+    def step(batches):
+        d = run(batches)
+        while deferred:
+            deferred.pop(0)()
+        deferred.append(d)
+
     while True:
         try:
             if stamps is not None:
@@ -205,28 +323,24 @@ def infer(model_path, data_path_test, audio_path, out_file_prefix, norm=True, or
             feed, test_sample_path = unpack_batch(nxt, uses_embeddings(config))
             test_length = feed['sequence_lengths']
         except OutOfRangeError:
+            if group:
+                step(group)
+            while deferred:
+                deferred.pop(0)()
             flush()
             print('done.')
             break
-        model.feed(**feed)
-        enhanced = model.enhanced_sources_oracle_phase if oracle_phase else model.enhanced_sources
-        loss = model.loss                       # read back once, after the loop: no host round trip per batch
-        loss = loss.detach().clone() if hasattr(loss, 'detach') else float(loss)
-        loss_list.append(loss)
-        if oracle_phase:
-            writer.submit(enhanced, test_sample_path, test_length, (ops.coop_status(device),))
-            written(test_sample_path, test_length)
-            continue
-        masks = model.masks
-        if pending and (pending[0][0].shape[1:] != enhanced.shape[1:] or pending[0][1].shape[1:] != masks.shape[1:]):
-            flush()                             # a batch of another length: it cannot share the launch
-        if len(test_length) >= lws_group and not pending:
-            pending.append((enhanced, masks, test_sample_path, test_length))        # alone: no copy needed
-        else:
-            pending.append((enhanced.clone(), masks.clone(), test_sample_path, test_length))   # the model reuses its buffers
-        if sum(len(p[3]) for p in pending) >= lws_group:
-            flush()
-    stamp('loop (launches; %.1f ms of it waiting for the reader)' % (waited * 1e3))
+        if group and any(getattr(feed[k], 'shape', (0,))[1:] != getattr(group[0][0][k], 'shape', (0,))[1:] for k in feed):
+            step(group)                         # a batch of another shape cannot share the step
+            group, held = [], 0
+        group.append((feed, test_sample_path, test_length))
+        held += len(test_length)
+        # (the first group is a quarter of the others: the GPU starts after 256 utterances have been read, not 1024)
+        if held + len(test_length) > max(coalesce if started else min(coalesce, max(256, batch_size)), 1):
+            step(group)                         # the next batch of this size would not fit any more
+            group, held, started = [], 0, True
+    stamp('loop (launches; %.1f ms of it waiting for the reader, %.1f concatenating, %.1f launching the model steps, %.1f the losses, '
+          '%.1f handing over to LWS / the writer)' % ((waited * 1e3,) + tuple(1e3 * x for x in spent)))
     writer.close()          # every file is on disk (or its error raised) before the summary line
     stamp('GPU drained, files written')
     ops.coop_check()

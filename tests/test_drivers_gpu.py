@@ -154,6 +154,7 @@ def test_infer_collects_batches_for_one_lws_launch(experiment, monkeypatch):
         calls.append(int(enhanced.shape[0]))
         return orig(self, enhanced, masks, num_samples, **kw)
     monkeypatch.setattr(lws_mod.lws, "refine_enhanced", spy)
+    monkeypatch.setenv('AVSI_INFER_COALESCE', '0')         # one model step per reader batch: the LWS grouping alone
     outs = {}
     for group in (1, 4, 128):
         monkeypatch.setenv('AVSI_LWS_GROUP', str(group))
@@ -165,6 +166,41 @@ def test_infer_collects_batches_for_one_lws_launch(experiment, monkeypatch):
     for group in (4, 128):
         for a, b in zip(outs[1], outs[group]):
             assert np.array_equal(a, b)
+
+
+@pytest.mark.parametrize("oracle_phase", [True, False])
+def test_infer_runs_several_reader_batches_in_one_model_step(experiment, monkeypatch, capsys, oracle_phase):
+    """infer() coalesces the model step of several reader batches (AVSI_INFER_COALESCE utterances, round 6): utterances are
+    independent, so the files equal those of one step per batch (to the last bit of the int16 samples or one LSB: the
+    recurrence may run on another kernel family at the larger batch), the per-batch lines are printed as before, and the
+    mean over the reader batches' losses is the same number."""
+    from avsi_amd import inference, models
+    base, data, cfg = experiment
+    net = base / "logs" / "av_exp0" / "netmodel"
+    steps = []
+    orig = models.StackedBLSTMModel.feed
+
+    def spy(self, **kw):
+        if kw.get('sequence_lengths') is not None:
+            steps.append(len(kw['sequence_lengths']))
+        return orig(self, **kw)
+    monkeypatch.setattr(models.StackedBLSTMModel, "feed", spy)
+    res = {}
+    for coalesce in (0, 4, 1024):
+        monkeypatch.setenv('AVSI_INFER_COALESCE', str(coalesce))
+        steps.clear()
+        audio_out = base / ("audio_co%d_%d" % (coalesce, oracle_phase))
+        loss = inference.infer(str(net), os.path.join(data, "test-set"), str(audio_out), "c", norm=True,
+                               oracle_phase=oracle_phase, batch_size=2)
+        out = capsys.readouterr().out
+        assert steps == {0: [2, 2, 1], 4: [4, 1], 1024: [5]}[coalesce]
+        assert "Written 2 enhanced wavs. Total samples written so far 4." in out
+        assert "Written 1 enhanced wavs. Total samples written so far 5." in out
+        res[coalesce] = (loss, [wavfile.read(str(audio_out / ("clip_%03d" % i) / "enhanced" / "c.wav"))[1] for i in range(5)])
+    for coalesce in (4, 1024):
+        assert abs(res[coalesce][0] - res[0][0]) <= 2e-5 * abs(res[0][0])
+        for a, b in zip(res[0][1], res[coalesce][1]):
+            assert np.abs(a.astype(np.int32) - b.astype(np.int32)).max() <= 1
 
 
 @pytest.mark.parametrize("model_name,fmt", [("a-blstm-emb", "npz"), ("av-blstm-ssnn", "tf"), ("av-blstm-twosteps", "tf"),

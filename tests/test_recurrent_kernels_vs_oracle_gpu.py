@@ -54,7 +54,9 @@ def _packed_gate_columns(dz_dir):
 # (utterances, split): 0 = batch-stationary (rows_per_wg picks the 32-row or the 64-row ping-pong kernel), > 0 = workgroups per
 # tile of the reduction-split cooperative kernels, < 0 = column-split kernel with that many utterances per group
 FWD_KINDS = [(37, 0, 32), (70, 0, 64), (37, 4, 0), (70, 8, 0), (37, 16, 0), (70, 32, 0), (37, -16, 0), (70, -32, 0),
-             (37, 64, 0), (70, 64, 0)]        # 64: the 32-way kernel on 16-row halves (round 5)
+             (37, 64, 0), (70, 64, 0),        # 64: the 32-way kernel on 16-row halves (round 5)
+             (70, 0, 65), (70, 0, 66), (130, 0, 66)]   # rows_per_wg 65 / 66: both tiles in one MFMA phase / the quarter-product
+                                                       # kernel (round 6: the measured alternatives to the ping-pong kernel)
 
 
 @pytest.mark.parametrize("B,split,rows_per_wg", FWD_KINDS)

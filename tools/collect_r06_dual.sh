@@ -15,10 +15,10 @@ passes=(
  "TA_TA_BUSY_sum TA_BUSY_avr"
  "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_EA0_WRREQ_STALL_sum"
 )
-f=$out/r06_rec_fwd_dual_pmc.txt
+f=$out/${OUTNAME:-r06_rec_fwd_dual_pmc.txt}
 echo "== rocprofv3 --pmc <one line per pass> --kernel-trace -- python3 tools/rec_fwd_time.py 8192 250 <rows_per_wg>, commit $commit; values are sums over the counter's instances, median over the dispatches" > $f
-for rpw in 64 65; do
-    echo "==== rows_per_wg = $rpw ($([ $rpw = 64 ] && echo 'blstm_rec_fwd_pp_kernel: two tiles ping-pong, Wh streamed twice per step' || echo 'blstm_rec_fwd_kernel<2>: both tiles in one MFMA phase, Wh streamed once per step'))" >> $f
+for rpw in ${RPWS:-64 65}; do
+    echo "==== rows_per_wg = $rpw ($([ $rpw = 64 ] && echo 'blstm_rec_fwd_pp_kernel: two tiles ping-pong, Wh streamed twice per step' || ([ $rpw = 66 ] && echo 'blstm_rec_fwd_q_kernel: quarter products, paired waves on the same fragments' || echo 'blstm_rec_fwd_kernel<2>: both tiles in one MFMA phase, Wh streamed once per step')))" >> $f
     python3 $R/tools/rec_fwd_time.py 8192 250 $rpw >> $f 2>&1
     i=0
     for p in "${passes[@]}"; do
