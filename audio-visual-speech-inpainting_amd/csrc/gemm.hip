@@ -58,7 +58,7 @@ struct GemmArgs {
     // N = 256 n + 1 on the 256-wide tile (the 257-bin projection): column N - 1 is not a tile of its own -- the workgroups of the
     // last column block take it on the VALU, as a dot product of the A rows they have staged in LDS anyway (gemm_dma_kernel<.., TAIL>)
     int tail_col;          // that column's index, or -1
-    int diag;              // AVSI_GEMM_DIAG (timing experiments, results WRONG): 1 = the wide tile's fast epilogue stores nothing
+    int diag;              // AVSI_GEMM_DIAG (timing experiments): 1 = the wide tile's fast epilogue stores nothing (results WRONG), 2 = it stores non-temporally
     int n_group;           // N-blocks per column group of the block -> tile order (see tile_of_block)
     // up to two 16-deep k-tiles that END in zero padding (avsi_gemm_epilogue::k_zero) and the number of their eight MFMA
     // steps that multiply anything: step 4 q + s multiplies k = 8 q + s and 8 q + 4 + s, so a tile with kv leading real k
@@ -366,10 +366,17 @@ __device__ __forceinline__ void dma16(const float* src, uint32_t lds_byte_addr) 
     asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(src), "s"(lds_byte_addr) : "memory");
 }
 
-template <bool TA, bool TB, int BK, int NST, bool CONV = false, int BNT = 128, bool TAIL = false>
+template <bool TA, bool TB, int BK, int NST, bool CONV = false, int BNT = 128, bool TAIL = false, bool PERS = false>
 __global__ __launch_bounds__(256, BNT == 256 ? 2 : (BK == 16 ? (NST == 3 ? 3 : 4) : 2)) void gemm_dma_kernel(const GemmArgs g) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     static_assert(!TAIL || (BNT == 256 && !TA && !TB && !CONV && BK == 16), "the folded last column exists for A . B on the 256-wide tile");
+    // PERS (round 6): the grid is the RESIDENT workgroups (two per CU) and a workgroup walks the tiles b, b + grid, ...  What that
+    // buys is the seam between two tiles: the next tile's first two k-tiles are requested BEFORE this tile's 512 stores per wave
+    // are issued, so the DMA latency, and the end of a workgroup / start of the next one that used to sit there (store
+    // acknowledgement, teardown, launch, offsets, prologue: ~7 us of a 58 us tile at K = 272), run under the stores.  Measured
+    // with the stores taken out (AVSI_GEMM_DIAG=1): 17.5 -> 15.4 ms at K = 272, 31.5 -> 29.9 at 512 -- the stores cost 1.6 - 2.1 ms a
+    // launch whatever K, i.e. about what 16.8 GB take to write at the memory's rate, nothing of it hidden.
+    static_assert(!PERS || (BNT == 256 && !TA && !TB && !CONV && BK == 16 && NST == 3), "persistent form: A . B on the 256-wide tile");
     static_assert((BK == 16 && (NST == 3 || NST == 2)) || (BK == 32 && NST == 2), "tile shapes this kernel was tuned for");
     static_assert(!CONV || (!TB && BK == 16), "the implicit-GEMM gathers are written for A . B and A^T . B with 16-deep tiles");
     static_assert(BNT == 128 || ((BNT == 64 || BNT == 32 || BNT == 256) && !TB && BK == 16 && NST == 3),
@@ -398,7 +405,7 @@ __global__ __launch_bounds__(256, BNT == 256 ? 2 : (BK == 16 ? (NST == 3 ? 3 : 4
 
     int bm, bn;
     tile_of_block(g, blockIdx.x, bm, bn);
-    const int m0 = bm * BM, n0 = bn * BNT;
+    int m0 = bm * BM, n0 = bn * BNT;
     const int kbeg = blockIdx.z * g.k_split_len;
     const int kend = min(g.K, kbeg + g.k_split_len);
     const int nk = (kend - kbeg) / BK;
@@ -408,26 +415,29 @@ __global__ __launch_bounds__(256, BNT == 256 ? 2 : (BK == 16 ? (NST == 3 ? 3 : 4
     constexpr int PPM = PPW > PPWB ? PPW : PPWB;
     int64_t offa[PPM], offb[PPM];
     const int pb0 = BNT >= 128 ? wave * PPWB : (BNT == 64 ? wave : (wave & 1));   // first B piece of this wave
+    auto place = [&]() {          // (for the tile at m0, n0)
 #pragma unroll
-    for (int j = 0; j < PPM; ++j) {
-        const int p = wave * PPW + j;  // 1-KiB piece of the tile
-        if (j >= PPW) {
-        } else if (!TA) {  // row tile [m][k]
-            const int row = p * RPP + lane / CPR, cl = (lane % CPR) ^ swz(row);
-            offa[j] = (int64_t)(min(m0 + row, g.M - 1) - m0) * g.lda + cl * 4;
-        } else {    // col tile [k][m]
-            const int x = min(m0 + 4 * (lane & 31), ((g.M + 3) & ~3) - 4) - m0;
-            offa[j] = (int64_t)(2 * p + (lane >> 5)) * g.lda + x;
+        for (int j = 0; j < PPM; ++j) {
+            const int p = wave * PPW + j;  // 1-KiB piece of the tile
+            if (j >= PPW) {
+            } else if (!TA) {  // row tile [m][k]
+                const int row = p * RPP + lane / CPR, cl = (lane % CPR) ^ swz(row);
+                offa[j] = (int64_t)(min(m0 + row, g.M - 1) - m0) * g.lda + cl * 4;
+            } else {    // col tile [k][m]
+                const int x = min(m0 + 4 * (lane & 31), ((g.M + 3) & ~3) - 4) - m0;
+                offa[j] = (int64_t)(2 * p + (lane >> 5)) * g.lda + x;
+            }
+            if (TB) {   // row tile [n][k]
+                const int row = p * RPP + lane / CPR, cl = (lane % CPR) ^ swz(row);
+                offb[j] = (int64_t)(min(n0 + row, g.N - 1) - n0) * g.ldb + cl * 4;
+            } else if (j < PPWB) {    // col tile [k][n]: one piece = 256 / BNT k-rows of BNT floats
+                constexpr int XQ = BNT / 4;
+                const int x = min(n0 + 4 * (lane % XQ), ((g.N + 3) & ~3) - 4) - n0;
+                offb[j] = (int64_t)((pb0 + j) * (256 / BNT) + lane / XQ) * g.ldb + x;
+            }
         }
-        if (TB) {   // row tile [n][k]
-            const int row = p * RPP + lane / CPR, cl = (lane % CPR) ^ swz(row);
-            offb[j] = (int64_t)(min(n0 + row, g.N - 1) - n0) * g.ldb + cl * 4;
-        } else if (j < PPWB) {    // col tile [k][n]: one piece = 256 / BNT k-rows of BNT floats
-            constexpr int XQ = BNT / 4;
-            const int x = min(n0 + 4 * (lane % XQ), ((g.N + 3) & ~3) - 4) - n0;
-            offb[j] = (int64_t)((pb0 + j) * (256 / BNT) + lane / XQ) * g.ldb + x;
-        }
-    }
+    };
+    place();
     // implicit GEMM: output pixel (b, h, w) of this lane's rows, and its 16-byte chunk inside a 16-deep k tile
     int cvh[PPW], cvw[PPW], cvb[PPW], cvcl[PPW];
     bool cvok[PPW];
@@ -458,6 +468,8 @@ __global__ __launch_bounds__(256, BNT == 256 ? 2 : (BK == 16 ? (NST == 3 ? 3 : 4
     }
     const float* a_org = TA ? g.A + (int64_t)kbeg * g.lda + m0 : g.A + (int64_t)m0 * g.lda + kbeg;
     const float* b_org = TB ? g.B + (int64_t)n0 * g.ldb + kbeg : g.B + (int64_t)kbeg * g.ldb + n0;
+    const int total_tiles = g.m_blocks * g.n_blocks;
+    int tile_id = blockIdx.x;
     const int64_t a_step = TA ? (int64_t)BK * g.lda : BK, b_step = TB ? BK : (int64_t)BK * g.ldb;
 
     auto issue = [&](int kt) {
@@ -577,19 +589,23 @@ __global__ __launch_bounds__(256, BNT == 256 ? 2 : (BK == 16 ? (NST == 3 ? 3 : 4
     constexpr int PPT = PPW + PPWB;     // DMA instructions per wave and k-tile
     if (nk > 0) issue(0);
     if (NST == 3 && nk > 1) issue(1);
+    bool first_tile = true;
+    float af[2][TM][4], bf[2][TN][4];
+#pragma unroll 1
+    for (;;) {      // (one pass unless PERS)
     if (NST == 3 && nk > 1)
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPT) : "memory");
-    else
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPT) : "memory");      // (PERS, from the second tile on: this tile's first k-tile
+    else                                                                //  AND all but the last few stores of the tile before)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if (TAIL) {
+    if (TAIL && first_tile) {
 #pragma unroll
         for (int j = 0; j < 4; ++j)
             if (tid + 256 * j < g.K) sW[tid + 256 * j] = wcol[j];
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     }
+    first_tile = false;
     __builtin_amdgcn_s_barrier();
 
-    float af[2][TM][4], bf[2][TN][4];
     // tile kt+1 must have landed before anyone reads it; with three stages tile kt+2's DMAs (just issued) stay in flight
     // across the barrier
     auto tile_done = [&](int kt) {
@@ -653,17 +669,35 @@ __global__ __launch_bounds__(256, BNT == 256 ? 2 : (BK == 16 ? (NST == 3 ? 3 : 4
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
+    // PERS: the tile after this one -- its offsets, and the DMAs of its first two k-tiles (every stage of the ring is free: the
+    // last barrier above is behind the last fragment read) -- BEFORE this tile's stores; m0 / n0 of the epilogue are kept aside
+    const int em0 = m0, en0 = n0;
+    bool more = false;
+    if (PERS) {
+        tile_id += gridDim.x;
+        more = tile_id < total_tiles;
+        if (more) {
+            tile_of_block(g, tile_id, bm, bn);
+            m0 = bm * BM, n0 = bn * BNT;
+            place();
+            a_org = g.A + (int64_t)m0 * g.lda + kbeg;
+            b_org = g.B + (int64_t)kbeg * g.ldb + n0;
+            if (nk > 0) issue(0);
+            if (nk > 1) issue(1);
+        }
+    }
+
     const bool accumulate = g.beta != 0.f;
     float bv[TN];
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
-        const int col = n0 + wn * (32 * TN) + j * 32 + li;
+        const int col = en0 + wn * (32 * TN) + j * 32 + li;
         bv[j] = (g.bias && col < g.N && blockIdx.z == 0) ? g.bias[col] : 0.f;      // (split launches: the bias goes into slab 0)
     }
     if (TAIL) {
         // the folded column: the two halves of a row's dot product sit in neighbouring lanes
         const float dot = tail_acc + __shfl_xor(tail_acc, 1, 64);
-        const int row = m0 + (tid >> 1);
+        const int row = em0 + (tid >> 1);
         if (!(tid & 1) && row < g.M) {
             int64_t orow = row;
             bool live = true;
@@ -682,12 +716,14 @@ __global__ __launch_bounds__(256, BNT == 256 ? 2 : (BK == 16 ? (NST == 3 ? 3 : 4
     // store instead of the general addressing / masking / row-map code below.  Measured on the three layer GEMMs
     // of the benchmark step (ms): 128-wide general 84.6 / fast 85.4, 256-wide general 86.1 / fast 82.9 -- so the
     // narrow tiles keep the general form.
-    if (BNT == 256 && g.row_map_bp == 0 && !g.row_scale && !accumulate && m0 + BM <= g.M && n0 + BNT <= g.N) {
+    bool fast_done = false;
+    if (BNT == 256 && g.row_map_bp == 0 && !g.row_scale && !accumulate && em0 + BM <= g.M && en0 + BNT <= g.N) {
         if (g.diag & 1) {                    // (timing experiment: what the stores of a tile cost; one lane keeps the arithmetic alive)
             if (acc[0][0][0] == 12345.678f) C[0] = acc[1][3][15];
-            return;
+            fast_done = true;
         }
-        float* cw = C + (int64_t)(m0 + wm * (32 * TM) + 4 * hi) * g.ldc + n0 + wn * (32 * TN) + li;
+        if (!fast_done) {
+        float* cw = C + (int64_t)(em0 + wm * (32 * TM) + 4 * hi) * g.ldc + en0 + wn * (32 * TN) + li;
         const int64_t ld4 = (int64_t)4 * g.ldc;
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
@@ -698,13 +734,19 @@ __global__ __launch_bounds__(256, BNT == 256 ? 2 : (BK == 16 ? (NST == 3 ? 3 : 4
 #pragma unroll
                 for (int r3 = 0; r3 < 4; ++r3) {
 #pragma unroll
-                    for (int j = 0; j < TN; ++j) cr[j * 32] = g.alpha * acc[i][j][4 * rq + r3] + bv[j];
+                    for (int j = 0; j < TN; ++j) {
+                        const float v = g.alpha * acc[i][j][4 * rq + r3] + bv[j];
+                        if (g.diag & 2) __builtin_nontemporal_store(v, cr + j * 32);     // (A/B: streaming stores)
+                        else cr[j * 32] = v;
+                    }
                     cr += g.ldc;
                 }
             }
         }
-        return;
+        }
+        fast_done = true;
     }
+    if (!fast_done) {
     float st1[TN], st2[TN];
 #pragma unroll
     for (int j = 0; j < TN; ++j) st1[j] = st2[j] = 0.f;
@@ -712,7 +754,7 @@ __global__ __launch_bounds__(256, BNT == 256 ? 2 : (BK == 16 ? (NST == 3 ? 3 : 4
     for (int i = 0; i < TM; ++i) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const int row = m0 + wm * (32 * TM) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+            const int row = em0 + wm * (32 * TM) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
             if (row >= g.M) continue;
             int64_t orow = row;
             if (g.row_map_bp > 0) {
@@ -723,7 +765,7 @@ __global__ __launch_bounds__(256, BNT == 256 ? 2 : (BK == 16 ? (NST == 3 ? 3 : 4
             const float rsc = g.row_scale ? g.row_scale[row] : 1.f;
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
-                const int col = n0 + wn * (32 * TN) + j * 32 + li;
+                const int col = en0 + wn * (32 * TN) + j * 32 + li;
                 if (col >= g.N) continue;
                 float* c = C + orow * g.ldc + col;
                 float v = (g.alpha * acc[i][j][r] + bv[j]) * rsc;
@@ -739,10 +781,21 @@ __global__ __launch_bounds__(256, BNT == 256 ? 2 : (BK == 16 ? (NST == 3 ? 3 : 4
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
             const float t1 = st1[j] + __shfl_xor(st1[j], 32, 64), t2 = st2[j] + __shfl_xor(st2[j], 32, 64);
-            const int col = n0 + wn * (32 * TN) + j * 32 + li;
+            const int col = en0 + wn * (32 * TN) + j * 32 + li;
             if (hi == 0 && col < g.N) part[col] = t1, part[g.N + col] = t2;
         }
     }
+    }
+    if (!PERS || !more) break;
+    // the next tile starts from zero
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    tail_acc = 0.f;
+    }   // tiles of this workgroup
 }
 
 // Diagnostic switches, read once per process (a getenv per launch is a linear scan of the environment, and a small-batch
@@ -774,12 +827,28 @@ int launch_dma(const GemmArgs& g, int splits, hipStream_t st) {
                            2 * 2 * 128 * 16 * 4, st, g);
         return avsi_launch_status();
     }
-    if (!TA && !TB && g.bnt == 256 && g.tail_col >= 0) {
-        const size_t lds_t = (size_t)3 * (128 + 256) * 16 * 4 + (size_t)g.K * 4;
-        (void)hipFuncSetAttribute((const void*)gemm_dma_kernel<false, false, 16, 3, false, 256, true>,
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_t);
-        hipLaunchKernelGGL((gemm_dma_kernel<false, false, 16, 3, false, 256, true>), dim3(g.m_blocks * g.n_blocks, 1, 1), dim3(256),
-                           lds_t, st, g);
+    if (!TA && !TB && g.bnt == 256) {
+        // 72 KiB: two workgroups per CU (+ K floats for the folded last column).  AVSI_GEMM_PERSIST=0: one workgroup per tile
+        // (A/B); the persistent form needs enough tiles per resident workgroup to pay for its fixed order
+        static const bool persist = !(getenv("AVSI_GEMM_PERSIST") && atoi(getenv("AVSI_GEMM_PERSIST")) == 0);
+        const size_t lds_t = (size_t)3 * (128 + 256) * 16 * 4 + (g.tail_col >= 0 ? (size_t)g.K * 4 : 0);
+        const int tiles = g.m_blocks * g.n_blocks, resident = 2 * AVSI_NUM_CU;
+        const bool pers = persist && splits == 1 && tiles >= 4 * resident;
+#define AVSI_WIDE_LAUNCH(TAILV, PERSV)                                                                                            \
+    do {                                                                                                                          \
+        (void)hipFuncSetAttribute((const void*)gemm_dma_kernel<false, false, 16, 3, false, 256, TAILV, PERSV>,                    \
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_t);                                        \
+        hipLaunchKernelGGL((gemm_dma_kernel<false, false, 16, 3, false, 256, TAILV, PERSV>),                                      \
+                           dim3((PERSV) ? resident : tiles, 1, (PERSV) ? 1 : splits), dim3(256), lds_t, st, g);                   \
+    } while (0)
+        if (g.tail_col >= 0) {
+            if (pers) AVSI_WIDE_LAUNCH(true, true);
+            else AVSI_WIDE_LAUNCH(true, false);
+        } else {
+            if (pers) AVSI_WIDE_LAUNCH(false, true);
+            else AVSI_WIDE_LAUNCH(false, false);
+        }
+#undef AVSI_WIDE_LAUNCH
         return avsi_launch_status();
     }
     if (!TB && g.bnt == 256) {

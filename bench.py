@@ -641,29 +641,44 @@ def e2e_workloads(torch, device):
             "per_gpu_batch": 32, "ms_per_step": min(epochs) / steps * 1e3, "value": 32 * steps / min(epochs), "unit": "utterances/s",
             "whole_call_s": t_train, "epochs_s": epochs}
 
-        def run_infer(n, batch, oracle_phase, tag_):
+        def run_infer(n, batch, oracle_phase, tag_, coalesce=None):
             sub = os.path.join(base, "sub_%s" % tag_)
             os.makedirs(sub)
             for i in range(n):
                 os.link(os.path.join(root, "data_%05d.tfrecord" % (i + 1)), os.path.join(sub, "data_%05d.tfrecord" % (i + 1)))
             best = None
-            for rep in range(2):
-                t0_ = time.perf_counter()
-                with contextlib.redirect_stdout(io.StringIO()):
-                    inference.infer(net, sub, os.path.join(base, "audio_%s_%d" % (tag_, rep)), "enh", norm=True,
-                                    oracle_phase=oracle_phase, batch_size=batch)
-                dt = time.perf_counter() - t0_
-                best = dt if best is None else min(best, dt)
-                shutil.rmtree(os.path.join(base, "audio_%s_%d" % (tag_, rep)), ignore_errors=True)
-            return {"workload": "inference.infer() end to end: %d TFRecord files -> int16 WAV files under /dev/shm, batch %d, %s; whole "
-                                "call including model construction and checkpoint restore, best of 2" % (
-                                    n, batch, "oracle phase" if oracle_phase else "LWS phase refinement (the reference's default)"),
+            before = os.environ.get('AVSI_INFER_COALESCE')
+            if coalesce is not None:
+                os.environ['AVSI_INFER_COALESCE'] = str(coalesce)
+            try:
+                for rep in range(2):
+                    t0_ = time.perf_counter()
+                    with contextlib.redirect_stdout(io.StringIO()):
+                        inference.infer(net, sub, os.path.join(base, "audio_%s_%d" % (tag_, rep)), "enh", norm=True,
+                                        oracle_phase=oracle_phase, batch_size=batch)
+                    dt = time.perf_counter() - t0_
+                    best = dt if best is None else min(best, dt)
+                    shutil.rmtree(os.path.join(base, "audio_%s_%d" % (tag_, rep)), ignore_errors=True)
+            finally:
+                if coalesce is not None:
+                    if before is None:
+                        os.environ.pop('AVSI_INFER_COALESCE', None)
+                    else:
+                        os.environ['AVSI_INFER_COALESCE'] = before
+            how = ("one model step per reader batch (AVSI_INFER_COALESCE=0: the reference's sess.run granularity)" if coalesce == 0 else
+                   "the driver's default: the model steps of up to 1024 utterances' reader batches run as one launch sequence "
+                   "(utterances are independent; files, per-batch lines and per-batch losses as with one step per batch)")
+            return {"workload": "inference.infer() end to end: %d TFRecord files -> int16 WAV files under /dev/shm, batch_size %d, %s; %s; "
+                                "whole call including model construction and checkpoint restore, best of 2" % (
+                                    n, batch, "oracle phase" if oracle_phase else "LWS phase refinement (the reference's default)", how),
                     "per_gpu_batch": batch, "utterances": n, "seconds": best, "ms_per_step": best / (n / batch) * 1e3,
                     "value": n / best, "unit": "utterances/s"}
         out["e2e_infer_b1024_oracle_phase"] = run_infer(n_infer, 1024, True, "o1024")
         out["e2e_infer_b1024"] = run_infer(n_infer, 1024, False, "l1024")
         out["e2e_infer_b32_oracle_phase"] = run_infer(4096, 32, True, "o32")
         out["e2e_infer_b32"] = run_infer(4096, 32, False, "l32")
+        out["e2e_infer_b32_oracle_phase_step_per_batch"] = run_infer(4096, 32, True, "o32s", coalesce=0)
+        out["e2e_infer_b32_step_per_batch"] = run_infer(4096, 32, False, "l32s", coalesce=0)
         out["e2e_dataset"] = {"files": n_infer, "bytes_per_file": len(payload) + 16, "written_in_s": t_write, "where": base.rsplit('/', 1)[0]}
     finally:
         shutil.rmtree(base, ignore_errors=True)
@@ -1054,28 +1069,31 @@ def main():
     if rank == 0 and not train:
         gemm_in, rec, proj = algorithmic_flops(B)
         t_rec, n_rec = totals["blstm_rec_fwd_kernel"]
-        # ops.gemm is called 5 times per step: the three layer input projections and the first 256 bins of the output
-        # projection (all four on the kernel symbol gemm_dma_kernel<false, false, 16, 3, false, 256>, the dominant
-        # kernel: the roofline block covers every launch of that symbol, as rocprofv3 --stats averages them), then
-        # the 257th bin on the 32-wide tile.  AVSI_PROJ_SPLIT=0: 4 calls, the projection on five 64-wide tiles
+        # ops.gemm is called 4 times per step: the three layer input projections -- one kernel symbol since round 6,
+        # gemm_dma_kernel<false, false, 16, 3, false, 256, false, true> (wide tile, persistent workgroups), the dominant kernel: the
+        # roofline block covers its three launches, as rocprofv3 --stats averages them -- and the 257-bin output projection
+        # on <..., 256, true, true> (the same tile with the 257th bin folded in: a symbol of its own, in `others`).
+        # AVSI_GEMM_FOLD_TAIL=0: 5 calls (256 bins on the wide tile + the last bin on a 32-wide tile); AVSI_PROJ_SPLIT=0 on top:
+        # 4 calls, the projection on five 64-wide tiles
         ev = timer.events["gemm_dma_kernel"]
         per_step = len(ev) // args.steps
         ms = [s_.elapsed_time(e_) for s_, e_ in ev]
+        folded = per_step == 4 and os.environ.get('AVSI_GEMM_FOLD_TAIL', '1') != '0'
         if args.precision == "bf16x3":      # exploratory: the layer projections are the split-bf16 launches
             layer_ms = [s_.elapsed_time(e_) for s_, e_ in timer.events["gemm_bf16x3_kernel"]]
             proj_ms, wide_proj_ms = ms, []
         else:
             layer_ms = [t for i, t in enumerate(ms) if i % per_step < 3]
             proj_ms = [t for i, t in enumerate(ms) if i % per_step >= 3]
-            wide_proj_ms = [t for i, t in enumerate(ms) if i % per_step == 3] if per_step == 5 else []
+            wide_proj_ms = [t for i, t in enumerate(ms) if i % per_step == 3] if (per_step == 5 or folded) else []
         t_layer = sum(layer_ms)
-        t_gemm, n_gemm = t_layer + sum(wide_proj_ms), len(layer_ms) + len(wide_proj_ms)
+        t_gemm, n_gemm = t_layer, len(layer_ms)
         t_proj = sum(proj_ms)
         t_fe, n_fe = totals["frontend_kernel"]
         fe_ms = sorted(s_.elapsed_time(e_) for s_, e_ in timer.events["frontend_kernel"])
         rec_tf = rec * n_rec / (t_rec * 1e-3) / 1e12
         layer_tf = sum(gemm_in) * args.steps / (t_layer * 1e-3) / 1e12
-        gemm_tf = (sum(gemm_in) + (proj * 256.0 / 257.0 if wide_proj_ms else 0.0)) * args.steps / (t_gemm * 1e-3) / 1e12
+        gemm_tf = layer_tf
         proj_tf = proj * args.steps / (t_proj * 1e-3) / 1e12
         fe_gbs = 706000.0 * B * n_fe / (t_fe * 1e-3) / 1e9
         if t_rec >= t_gemm:
@@ -1085,7 +1103,7 @@ def main():
                     "traffic": traffic, "traffic_source": traffic_src, "avg_launch_ms": t_rec / n_rec}
         else:
             traffic, traffic_src = profiled_traffic("gemm_dma_kernel", B)
-            roof = {"kernel": "gemm_dma_kernel<false, false, 16, 3, false, 256>", "bound": "mfma", "achieved": gemm_tf,
+            roof = {"kernel": "gemm_dma_kernel<false, false, 16, 3, false, 256, false, true>", "bound": "mfma", "achieved": gemm_tf,
                     "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": gemm_tf / FP32_MFMA_PEAK_TFLOPS,
                     "traffic": traffic, "traffic_source": traffic_src, "avg_launch_ms": t_gemm / n_gemm}
         if args.precision == "bf16x3":
@@ -1096,8 +1114,9 @@ def main():
         roof["others"] = {
             "blstm_rec_fwd_kernel": {"TFLOP/s": rec_tf, "ms_per_step": t_rec / args.steps},
             "gemm_dma_kernel(layer input projections)": {"TFLOP/s": layer_tf, "ms_per_step": t_layer / args.steps},
-            "gemm_dma_kernel(257-bin projection: %s)" % ("256 bins on the wide tile + 1 bin on a 32-wide tile"
-                                                         if wide_proj_ms else "64-wide tiles"):
+            "gemm_dma_kernel(257-bin projection: %s)" % (
+                "one launch on the wide tile, the 257th bin folded in: gemm_dma_kernel<false, false, 16, 3, false, 256, true, true>"
+                if folded else ("256 bins on the wide tile + 1 bin on a 32-wide tile" if wide_proj_ms else "64-wide tiles")):
                 {"TFLOP/s": proj_tf, "ms_per_step": t_proj / args.steps},
             "frontend_kernel": {"GB/s": fe_gbs, "frac_of_hbm_peak": fe_gbs / HBM_PEAK_GBS,
                                 "ms_per_step": t_fe / args.steps,

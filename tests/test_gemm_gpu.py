@@ -98,6 +98,56 @@ def test_projection_with_the_last_bin_folded_into_the_wide_tile(ops, T, B, Bp, p
     np.testing.assert_allclose(two.view(B, T, N).cpu().numpy(), ref[:, :B].transpose(1, 0, 2), atol=2e-4)
 
 
+@pytest.mark.parametrize("K,ranges", [(272, ((257, 272),)), (512, ((250, 256), (506, 512)))])
+def test_persistent_wide_tiles_equal_one_workgroup_per_tile(ops, K, ranges):
+    """From 2048 wide (128 x 256) tiles on, A . B runs on RESIDENT workgroups that walk the tiles and request the next
+    tile's first k-tiles before they store the current one (round 6).  The MFMA chains are the same, so the product over
+    262,221 rows (16,392 tiles: 32 per workgroup, a ragged last row block) equals, bit for bit, the same rows computed
+    in pieces of 8192 rows (512 tiles each: one workgroup per tile), and numpy to rounding."""
+    M, N = 262144 + 77, 2048
+    g = torch.Generator(device='cuda')
+    g.manual_seed(K)
+    a = torch.randn(M, K, device='cuda', generator=g)
+    b = torch.randn(K, N, device='cuda', generator=g) * 0.05
+    for lo, hi in ranges:
+        b[lo:hi] = 0
+    bias = torch.randn(N, device='cuda', generator=g)
+    full = torch.full((M, N), 7.0, device='cuda')
+    ops.gemm(a, b, out=full, bias=bias, k_zero=ranges)
+    piece = torch.empty(8192, N, device='cuda')
+    for lo in range(0, M, 8192):
+        n = min(8192, M - lo)
+        ops.gemm(a[lo:lo + n], b, out=piece[:n], bias=bias, k_zero=ranges)
+        assert torch.equal(full[lo:lo + n], piece[:n]), lo
+    rows = torch.tensor([0, 127, 128, 65535, 131072, M - 78, M - 1], device='cuda')
+    ref = a[rows].double() @ b.double() + bias.double()
+    assert float((full[rows].double() - ref).abs().max()) < 2e-6 * K * 4
+
+
+def test_persistent_projection_with_the_folded_last_bin(ops):
+    """The 257-bin projection at a size where the wide tile is persistent (2375 row blocks): the folded 257th bin's column of
+    W is staged once per WORKGROUP there, and its accumulator restarts with every tile -- against numpy on sampled rows."""
+    T, B, Bp, K, N = 250, 1200, 1216, 512, 257
+    g = torch.Generator(device='cuda')
+    g.manual_seed(3)
+    x = torch.randn(T * Bp, K, device='cuda', generator=g)
+    w = torch.zeros(K, 260, device='cuda')
+    w[:, :N] = torch.randn(K, N, device='cuda', generator=g) * 0.05
+    w[250:256] = 0
+    w[506:512] = 0
+    bias = torch.randn(260, device='cuda', generator=g)
+    rs = (torch.rand(T * Bp, device='cuda', generator=g) > 0.3).float()
+    out = torch.full((B * T, N), 7.0, device='cuda')
+    ops.gemm(x, w, out=out, n=N, bias=bias, row_scale=rs, row_map=(Bp, T, B), k_zero=((250, 256), (506, 512)))
+    ts = torch.tensor([0, 1, 100, 249], device='cuda')
+    bs = torch.tensor([0, 31, 32, 640, 1199], device='cuda')
+    rows = (ts[:, None] * Bp + bs[None, :]).reshape(-1)
+    ref = (x[rows].double() @ w[:, :N].double() + bias[:N].double()) * rs[rows, None].double()
+    got = out.view(B, T, N)[bs[None, :].expand(4, 5).reshape(-1), ts[:, None].expand(4, 5).reshape(-1)]
+    assert float((got.double() - ref).abs().max()) < 2e-4
+    assert float(out.min()) > -50 and float(out.max()) < 50 and not bool((out == 7.0).all(dim=1).any())
+
+
 @pytest.mark.parametrize("N", [1, 5, 32])
 def test_at_most_32_columns_take_the_narrow_tile(ops, N):
     M, K = 1000, 272

@@ -11,11 +11,13 @@ import csv
 import json
 import sys
 
-# launches per step: the 128 x 256 GEMM tile runs the three layer products AND (since round 3) the first 256 bins of the
-# projection -- the four launches `roofline` of the bench line covers
+# launches per step: the 128 x 256 GEMM tile runs the three layer products (round 6: persistent workgroups, symbol <..., 256, false, true>:
+# the three launches `roofline` of the bench line covers) and the 257-bin projection (<..., 256, true, true>: the last bin folded in);
+# rounds 3 - 5: one symbol <..., 256> for the three layer products AND the first 256 bins of the projection
 # (frontend_kernel<12, 4, 2, true, 1>: the default step; with AVSI_LOSS_FROM_WAV=1 the step's launch is <..., 2> (masked features
 #  only) and the loss a second launch of the same kernel in its loss form, <..., 3>, instead of l1_partial_kernel)
 KERNELS = {'frontend_kernel<12, 4, 2, true, 2>': 1, 'frontend_kernel<12, 4, 2, true, 3>': 1, 'frontend_kernel<12, 4, 2, true, 1>': 1,
+           'gemm_dma_kernel<false, false, 16, 3, false, 256, false, true>': 3, 'gemm_dma_kernel<false, false, 16, 3, false, 256, true, true>': 1,
            'gemm_dma_kernel<false, false, 16, 3, false, 256>': 4, 'blstm_rec_fwd_pp': 3, 'l1_partial_kernel': 1}
 
 
