@@ -58,7 +58,7 @@ struct GemmArgs {
     // N = 256 n + 1 on the 256-wide tile (the 257-bin projection): column N - 1 is not a tile of its own -- the workgroups of the
     // last column block take it on the VALU, as a dot product of the A rows they have staged in LDS anyway (gemm_dma_kernel<.., TAIL>)
     int tail_col;          // that column's index, or -1
-    int diag;              // AVSI_GEMM_DIAG (timing experiments): 1 = the wide tile's fast epilogue stores nothing (results WRONG), 2 = it stores non-temporally
+    int diag;              // AVSI_GEMM_DIAG (timing experiments): 1 = the wide tile's fast epilogue stores nothing (results WRONG), 2 = it stores non-temporally, 8 = 16-byte stores behind a quad transpose (measured slower)
     int n_group;           // N-blocks per column group of the block -> tile order (see tile_of_block)
     // up to two 16-deep k-tiles that END in zero padding (avsi_gemm_epilogue::k_zero) and the number of their eight MFMA
     // steps that multiply anything: step 4 q + s multiplies k = 8 q + s and 8 q + 4 + s, so a tile with kv leading real k
@@ -364,6 +364,21 @@ typedef __attribute__((address_space(3))) void* lvoid_t;
 // register the compiler does not allocate; nothing else in this kernel uses it.
 __device__ __forceinline__ void dma16(const float* src, uint32_t lds_byte_addr) {
     asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(src), "s"(lds_byte_addr) : "memory");
+}
+
+// 4 x 4 transpose inside every quad of lanes: on return register c of lane b (b = lane & 3) holds what register b of lane c held.
+// Two exchanges: with lane ^ 1 over the register pairs (0, 1) and (2, 3), then with lane ^ 2 over (0, 2) and (1, 3).
+template <int CTRL>
+__device__ __forceinline__ float quad_perm(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
+__device__ __forceinline__ void quad_transpose(float& r0, float& r1, float& r2, float& r3, bool odd1, bool odd2) {
+    float s = odd1 ? r0 : r1, t = odd1 ? r2 : r3;
+    s = quad_perm<0xB1>(s), t = quad_perm<0xB1>(t);         // quad_perm [1, 0, 3, 2]
+    r0 = odd1 ? s : r0, r1 = odd1 ? r1 : s, r2 = odd1 ? t : r2, r3 = odd1 ? r3 : t;
+    float u = odd2 ? r0 : r2, v = odd2 ? r1 : r3;
+    u = quad_perm<0x4E>(u), v = quad_perm<0x4E>(v);         // quad_perm [2, 3, 0, 1]
+    r0 = odd2 ? u : r0, r1 = odd2 ? v : r1, r2 = odd2 ? r2 : u, r3 = odd2 ? r3 : v;
 }
 
 template <bool TA, bool TB, int BK, int NST, bool CONV = false, int BNT = 128, bool TAIL = false, bool PERS = false>
@@ -720,6 +735,32 @@ __global__ __launch_bounds__(256, BNT == 256 ? 2 : (BK == 16 ? (NST == 3 ? 3 : 4
     if (BNT == 256 && g.row_map_bp == 0 && !g.row_scale && !accumulate && em0 + BM <= g.M && en0 + BNT <= g.N) {
         if (g.diag & 1) {                    // (timing experiment: what the stores of a tile cost; one lane keeps the arithmetic alive)
             if (acc[0][0][0] == 12345.678f) C[0] = acc[1][3][15];
+            fast_done = true;
+        }
+        if (!fast_done && (g.diag & 8) && !(g.ldc & 3) && !(reinterpret_cast<uintptr_t>(C) & 15)) {
+            // AVSI_GEMM_DIAG=8 (A/B, results right): 16-byte stores.  The idea: a wave can have 63 vector-memory operations in
+            // flight (vmcnt is six bits), so 512 dword stores per wave and tile might be bound by acknowledgement round trips.  The
+            // C / D layout has a lane's four consecutive registers on four consecutive ROWS of one column; a 4 x 4 transpose inside
+            // every quad of lanes (two DPP exchanges per register pair) turns them into four consecutive COLUMNS of one row: 128
+            // stores of 16 bytes per wave.  MEASURED SLOWER, same box: K = 272 17.86 against 17.35 ms, K = 512 31.72 against 31.12
+            // (an instruction then touches eight rows' 128-byte segments instead of two): the dword form below stays.
+            const bool odd1 = lane & 1, odd2 = lane & 2;
+            float* cw = C + (int64_t)(em0 + wm * (32 * TM) + 4 * hi + (lane & 3)) * g.ldc + en0 + wn * (32 * TN) + 4 * (li >> 2);
+            const int64_t ld8 = (int64_t)8 * g.ldc;
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+#pragma unroll
+                for (int rq = 0; rq < 4; ++rq) {                  // rows 8 rq + 4 hi + (0..3)
+                    float* cr = cw + (int64_t)(i * 32) * g.ldc + rq * ld8;
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) {
+                        float r0 = g.alpha * acc[i][j][4 * rq + 0] + bv[j], r1 = g.alpha * acc[i][j][4 * rq + 1] + bv[j];
+                        float r2 = g.alpha * acc[i][j][4 * rq + 2] + bv[j], r3 = g.alpha * acc[i][j][4 * rq + 3] + bv[j];
+                        quad_transpose(r0, r1, r2, r3, odd1, odd2);
+                        *reinterpret_cast<float4*>(cr + j * 32) = make_float4(r0, r1, r2, r3);
+                    }
+                }
+            }
             fast_done = true;
         }
         if (!fast_done) {
