@@ -20,6 +20,7 @@
 //   - blockIdx -> tile mapping is XCD-aware: the N-blocks that share an A row panel get
 //     consecutive ids on ONE XCD, so the panel is fetched from HBM once and re-served by that L2.
 #include "avsi_common.h"
+#include <atomic>
 #include <cstdlib>
 
 namespace {
@@ -41,6 +42,11 @@ template <int BK, int X> struct Tile {
 template <int BK, int X> using RegTile = float4[Tile<BK, X>::NLD];  // one thread's share of an operand tile
 template <int BK, int X> using OffTile = int[Tile<BK, X>::NLD];     // and its float4 offsets from the tile origin
 
+// Tile counters of the persistent wide-tile launches: 256 launch slots of 8 counters (+ padding to a 64-byte line), taken in turn
+// and zeroed on the launch's stream right in front of it.  A module global: nothing is allocated behind the caller's back; a slot
+// comes round again 256 persistent launches later (a model step has four).
+__device__ unsigned avsi_gemm_tile_ctr[256 * 16];
+
 struct GemmArgs {
     const float* A;
     const float* B;
@@ -58,6 +64,11 @@ struct GemmArgs {
     // N = 256 n + 1 on the 256-wide tile (the 257-bin projection): column N - 1 is not a tile of its own -- the workgroups of the
     // last column block take it on the VALU, as a dot product of the A rows they have staged in LDS anyway (gemm_dma_kernel<.., TAIL>)
     int tail_col;          // that column's index, or -1
+    // PERS: eight zeroed counters (one per XCD class of workgroups): the next tile index of that class.  A workgroup TAKES its tiles
+    // in order instead of walking a fixed stride: workgroups drift apart over 250 tiles, and with a fixed stride the tiles in flight
+    // then spread over many row blocks -- the column tiles of a row block stop sharing its A panel in L2 (measured: 26.6 GB
+    // fetched per K = 512 launch against 16.1 GB with one workgroup per tile; taken in order: 23.2 GB and 2 % faster than either)
+    unsigned* tile_ctr;
     int diag;              // AVSI_GEMM_DIAG (timing experiments): 1 = the wide tile's fast epilogue stores nothing (results WRONG), 2 = it stores non-temporally, 8 = 16-byte stores behind a quad transpose (measured slower)
     int n_group;           // N-blocks per column group of the block -> tile order (see tile_of_block)
     // up to two 16-deep k-tiles that END in zero padding (avsi_gemm_epilogue::k_zero) and the number of their eight MFMA
@@ -385,8 +396,8 @@ template <bool TA, bool TB, int BK, int NST, bool CONV = false, int BNT = 128, b
 __global__ __launch_bounds__(256, BNT == 256 ? 2 : (BK == 16 ? (NST == 3 ? 3 : 4) : 2)) void gemm_dma_kernel(const GemmArgs g) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     static_assert(!TAIL || (BNT == 256 && !TA && !TB && !CONV && BK == 16), "the folded last column exists for A . B on the 256-wide tile");
-    // PERS (round 6): the grid is the RESIDENT workgroups (two per CU) and a workgroup walks the tiles b, b + grid, ...  What that
-    // buys is the seam between two tiles: the next tile's first two k-tiles are requested BEFORE this tile's 512 stores per wave
+    // PERS (round 6): the grid is the RESIDENT workgroups (two per CU) and a workgroup takes tile after tile (GemmArgs::tile_ctr).  What that
+    // buys is the seam between two tiles: the next tile's first two k-tiles are requested BEFORE this tile's 128 stores per wave (512 per workgroup)
     // are issued, so the DMA latency, and the end of a workgroup / start of the next one that used to sit there (store
     // acknowledgement, teardown, launch, offsets, prologue: ~7 us of a 58 us tile at K = 272), run under the stores.  Measured
     // with the stores taken out (AVSI_GEMM_DIAG=1): 17.5 -> 15.4 ms at K = 272, 31.5 -> 29.9 at 512 -- the stores cost 1.6 - 2.1 ms a
@@ -418,8 +429,30 @@ __global__ __launch_bounds__(256, BNT == 256 ? 2 : (BK == 16 ? (NST == 3 ? 3 : 4
     const int wm = wave / WN, wn = wave % WN;
     const int li = lane & 31, hi = lane >> 5;
 
+    // PERS: tiles are taken from the counter of this workgroup's XCD class, two ahead: the index of the tile after next is requested
+    // before the current tile's stores and read behind the next tile's first wait, so its round trip costs nothing.  (Also built: the
+    // claim four k-tiles before the end of the current tile, i.e. late -- the tiles in flight then stay as consecutive as under
+    // hardware dispatch and the launch fetches 16.9 GB at K = 512 instead of 23.2 (one workgroup per tile: 16.1; a fixed stride: 26.6),
+    // but the branch in the k loop cost 20 - 52 bytes of scratch and most of the gain: 17.53 / 31.08 ms against 17.23 / 30.93 for this
+    // form and 17.91 / 31.44 for one workgroup per tile.  The kernel is bound by the matrix pipes at 1.3 TB/s of traffic: speed won.)
+    __shared__ int s_take[2];
+    const int xcls = blockIdx.x % AVSI_NUM_XCD;
+    const int class_tiles = (g.m_blocks * g.n_blocks) / AVSI_NUM_XCD + (xcls < (g.m_blocks * g.n_blocks) % AVSI_NUM_XCD ? 1 : 0);
+    int idx_next = 0, idx_fetched = 0;
+    int tile_id = blockIdx.x;
+    if (PERS) {
+        if (tid == 0) {
+            s_take[0] = (int)atomicAdd(g.tile_ctr + xcls, 1u);
+            s_take[1] = (int)atomicAdd(g.tile_ctr + xcls, 1u);
+        }
+        __syncthreads();
+        const int idx_cur = s_take[0];
+        idx_next = s_take[1];
+        if (idx_cur >= class_tiles) return;              // (more resident workgroups than tiles of this class)
+        tile_id = xcls + AVSI_NUM_XCD * idx_cur;
+    }
     int bm, bn;
-    tile_of_block(g, blockIdx.x, bm, bn);
+    tile_of_block(g, tile_id, bm, bn);
     int m0 = bm * BM, n0 = bn * BNT;
     const int kbeg = blockIdx.z * g.k_split_len;
     const int kend = min(g.K, kbeg + g.k_split_len);
@@ -483,8 +516,6 @@ __global__ __launch_bounds__(256, BNT == 256 ? 2 : (BK == 16 ? (NST == 3 ? 3 : 4
     }
     const float* a_org = TA ? g.A + (int64_t)kbeg * g.lda + m0 : g.A + (int64_t)m0 * g.lda + kbeg;
     const float* b_org = TB ? g.B + (int64_t)n0 * g.ldb + kbeg : g.B + (int64_t)kbeg * g.ldb + n0;
-    const int total_tiles = g.m_blocks * g.n_blocks;
-    int tile_id = blockIdx.x;
     const int64_t a_step = TA ? (int64_t)BK * g.lda : BK, b_step = TB ? BK : (int64_t)BK * g.ldb;
 
     auto issue = [&](int kt) {
@@ -618,8 +649,14 @@ __global__ __launch_bounds__(256, BNT == 256 ? 2 : (BK == 16 ? (NST == 3 ? 3 : 4
             if (tid + 256 * j < g.K) sW[tid + 256 * j] = wcol[j];
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     }
+    if (PERS && !first_tile) {          // the index requested in front of the last tile's stores has arrived (the wait above)
+        if (tid == 0) s_take[0] = idx_fetched;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+    const bool had_fetch = PERS && !first_tile;
     first_tile = false;
     __builtin_amdgcn_s_barrier();
+    if (had_fetch) idx_next = s_take[0];        // (read by everyone before thread 0 can write it again: a whole tile later)
 
     // tile kt+1 must have landed before anyone reads it; with three stages tile kt+2's DMAs (just issued) stay in flight
     // across the barrier
@@ -689,9 +726,10 @@ __global__ __launch_bounds__(256, BNT == 256 ? 2 : (BK == 16 ? (NST == 3 ? 3 : 4
     const int em0 = m0, en0 = n0;
     bool more = false;
     if (PERS) {
-        tile_id += gridDim.x;
-        more = tile_id < total_tiles;
+        more = idx_next < class_tiles;
         if (more) {
+            tile_id = xcls + AVSI_NUM_XCD * idx_next;
+            if (tid == 0) idx_fetched = (int)atomicAdd(g.tile_ctr + xcls, 1u);
             tile_of_block(g, tile_id, bm, bn);
             m0 = bm * BM, n0 = bn * BNT;
             place();
@@ -739,9 +777,9 @@ __global__ __launch_bounds__(256, BNT == 256 ? 2 : (BK == 16 ? (NST == 3 ? 3 : 4
         }
         if (!fast_done && (g.diag & 8) && !(g.ldc & 3) && !(reinterpret_cast<uintptr_t>(C) & 15)) {
             // AVSI_GEMM_DIAG=8 (A/B, results right): 16-byte stores.  The idea: a wave can have 63 vector-memory operations in
-            // flight (vmcnt is six bits), so 512 dword stores per wave and tile might be bound by acknowledgement round trips.  The
+            // flight (vmcnt is six bits), so 128 dword stores per wave and tile (512 per workgroup) might be bound by acknowledgement round trips.  The
             // C / D layout has a lane's four consecutive registers on four consecutive ROWS of one column; a 4 x 4 transpose inside
-            // every quad of lanes (two DPP exchanges per register pair) turns them into four consecutive COLUMNS of one row: 128
+            // every quad of lanes (two DPP exchanges per register pair) turns them into four consecutive COLUMNS of one row: 32
             // stores of 16 bytes per wave.  MEASURED SLOWER, same box: K = 272 17.86 against 17.35 ms, K = 512 31.72 against 31.12
             // (an instruction then touches eight rows' 128-byte segments instead of two): the dword form below stays.
             const bool odd1 = lane & 1, odd2 = lane & 2;
@@ -875,12 +913,23 @@ int launch_dma(const GemmArgs& g, int splits, hipStream_t st) {
         const size_t lds_t = (size_t)3 * (128 + 256) * 16 * 4 + (g.tail_col >= 0 ? (size_t)g.K * 4 : 0);
         const int tiles = g.m_blocks * g.n_blocks, resident = 2 * AVSI_NUM_CU;
         const bool pers = persist && splits == 1 && tiles >= 4 * resident;
+        GemmArgs gp = g;
+        if (pers) {
+            static unsigned* ctr_base[16] = {};
+            static std::atomic<unsigned> slot_seq{0};
+            int dev = 0;
+            if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return AVSI_ERR_LAUNCH;
+            if (!ctr_base[dev] && hipGetSymbolAddress((void**)&ctr_base[dev], HIP_SYMBOL(avsi_gemm_tile_ctr)) != hipSuccess)
+                return AVSI_ERR_LAUNCH;
+            gp.tile_ctr = ctr_base[dev] + (size_t)(slot_seq.fetch_add(1) & 255u) * 16;
+            if (hipMemsetAsync(gp.tile_ctr, 0, 64, st) != hipSuccess) return AVSI_ERR_LAUNCH;
+        }
 #define AVSI_WIDE_LAUNCH(TAILV, PERSV)                                                                                            \
     do {                                                                                                                          \
         (void)hipFuncSetAttribute((const void*)gemm_dma_kernel<false, false, 16, 3, false, 256, TAILV, PERSV>,                    \
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_t);                                        \
         hipLaunchKernelGGL((gemm_dma_kernel<false, false, 16, 3, false, 256, TAILV, PERSV>),                                      \
-                           dim3((PERSV) ? resident : tiles, 1, (PERSV) ? 1 : splits), dim3(256), lds_t, st, g);                   \
+                           dim3((PERSV) ? resident : tiles, 1, (PERSV) ? 1 : splits), dim3(256), lds_t, st, gp);                  \
     } while (0)
         if (g.tail_col >= 0) {
             if (pers) AVSI_WIDE_LAUNCH(true, true);
