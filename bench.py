@@ -431,6 +431,11 @@ def dp_train_block(torch, dist, models, ops, ap_mod, cfg, device, rank, world):
         lo = _all_reduce(torch, dist, bits.clone(), dist.ReduceOp.MIN)
         check["ranks_bit_identical"] = bool((hi == lo).all().item())
         mean_losses = _all_reduce(torch, dist, losses.double().clone(), dist.ReduceOp.SUM) / world
+        # (ranks that SHARE a GPU -- the gloo rehearsals -- can starve each other's cooperative groups and fall back, each on its
+        #  own: the ranks' kernel families may then differ from the ones rank 0 repeats the shards on, which is summation order again)
+        levels = torch.tensor([float(ops.coop_level())], device=device)
+        mixed = bool(_all_reduce(torch, dist, levels.clone(), dist.ReduceOp.MAX).item() !=
+                     _all_reduce(torch, dist, levels.clone(), dist.ReduceOp.MIN).item())
         dist.barrier()
         if rank == 0:
             with parallel.solo():
@@ -440,7 +445,10 @@ def dp_train_block(torch, dist, models, ops, ap_mod, cfg, device, rank, world):
             # the ranks' kernels, gradients summed in rank order -- only the collective (and its order of adding the
             # ranks' terms) differs, so the variables agree to the last bits of the gradient sums
             check["max_abs_diff_vs_single_process"] = float((ref - flat).abs().max())
-            check["bar"] = 2e-5
+            check["bar"] = 2e-4 if mixed else 2e-5
+            if mixed:
+                check["bar_note"] = "the ranks ended on different fall-back levels (kernel families): summation order differs, bar 2e-4"
+
             check["loss_max_rel_diff_vs_single_process"] = float(((mean_losses - ref_losses.double()).abs()
                                                                   / ref_losses.double().abs()).max())
             # (2) the SUMMED gradient of the first step against the reference's sum.  Adam's update is (almost) invariant

@@ -110,7 +110,11 @@ def test_multi_rank_launch_as_the_driver_does(mode, ranks):
         assert dp["coop_fallbacks"] in (0, 1, 2)
         c = dp["check"]
         assert c["ranks_bit_identical"] is True and c["global_batch"] == 32 * ranks and c["frames"] == 250
-        assert c["max_abs_diff_vs_single_process"] < c["bar"] <= 2e-4 < 1e-3 < c["max_abs_update"] and c["ok"] is True
+        # r6: the reference takes the same steps shard by shard on the ranks' kernels (parallel.shards_step): bar 2e-5 again,
+        # and the summed gradient of the first step is compared as well (Adam's variables cannot show a missed bucket)
+        assert c["max_abs_diff_vs_single_process"] < c["bar"] <= (2e-4 if "bar_note" in c else 2e-5) < 1e-3 < c["max_abs_update"]
+        assert c["ok"] is True
+        assert c["first_step_summed_gradient_max_abs_diff_rel"] < c["gradient_bar"] <= 1e-4
         assert c["loss_max_rel_diff_vs_single_process"] < 2e-4
         assert dp["weak_32_per_gpu"]["global_batch"] == 32 * ranks and dp["fixed_global_256"]["per_gpu_batch"] == 256 // ranks
         assert dp["fixed_global_256"]["global_batch"] == 256
