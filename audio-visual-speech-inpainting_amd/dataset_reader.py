@@ -10,7 +10,9 @@ Batch layout ('fixed' mode, dataset_reader.py:77-79): ``(sequence_length int32[B
 labels_length int32[B], target_audio_wav int32[B, N] (tf.to_int32 truncation),
 sample_path [B] bytes, labels f32[B, L], video_features f32[B, T, Dv], mask f32[B, T, F])``;
 with ``embedding_size`` the f32[B, E] ``embedding`` context feature is inserted after the audio
-(dataset_reader_emb.py:63-81).  Only the 'fixed' schema is supported.
+(dataset_reader_emb.py:63-81).  'var' mode (dataset_reader.py:82-99, read side only in the reference: its writer cannot run,
+SURVEY App. B11): everything but the two lengths is a feature list, batches are zero-padded to the longest record
+(``padded_batch``), the audio stays float32 and the sample path is a row of character codes; parsed in Python, host arrays.
 
 Like the reference's tf.data pipeline, parsing is native and runs ahead of the consumer: records go
 through the shuffle buffer as raw payloads, a batch is parsed by ``avsi_sequence_example_decode_fixed_host``
@@ -317,7 +319,7 @@ class BatchIterator(object):
 
     def _make(self, payloads):
         if self.decode_batch is None:
-            batch = _collate([self.dataset.parse(p) for p in payloads])
+            batch = getattr(self, 'collate', _collate)([self.dataset.parse(p) for p in payloads])
         elif self._arenas is not None:
             arena = self._arenas[self._made % len(self._arenas)]
             self._made += 1
@@ -410,13 +412,32 @@ def _collate(batch):
     return tuple(out)
 
 
+def _collate_padded(batch):
+    """tf.data padded_batch with zero padding: every field becomes [B, longest, ...]."""
+    out = []
+    for col in zip(*batch):
+        first = np.asarray(col[0])
+        if first.ndim == 0:
+            out.append(np.stack([np.asarray(c) for c in col]))
+            continue
+        shape = tuple(max(np.asarray(c).shape[d] for c in col) for d in range(first.ndim))
+        arr = np.zeros((len(col),) + shape, dtype=first.dtype)
+        for i, c in enumerate(col):
+            c = np.asarray(c)
+            arr[(i,) + tuple(slice(0, n) for n in c.shape)] = c
+        out.append(arr)
+    return tuple(out)
+
+
 class DataManager:
     """Utilities to read TFRecords"""
 
     def __init__(self, num_audio_samples=48000, audio_feat_size=257, video_feat_size=136, buffer_size=1000,
                  mode='fixed', embedding_size=None):
-        if mode != 'fixed':
-            raise ValueError("only the 'fixed' TFRecord schema is supported (the reference's 'var' writer is broken)")
+        if mode not in ('fixed', 'var'):
+            raise ValueError("TFRecord schema must be 'fixed' or 'var'")
+        if mode == 'var' and embedding_size:
+            raise ValueError("the 'var' schema has no embedding feature (dataset_reader_emb.py reads 'fixed' records only)")
         self.num_audio_samples = num_audio_samples
         self.audio_feat_size = audio_feat_size
         self.video_feat_size = video_feat_size
@@ -425,6 +446,10 @@ class DataManager:
         self.mode = mode
 
     def get_dataset(self, file_list, shuffle=True, seed=None):
+        if self.mode == 'var':
+            ds = Dataset(file_list, shuffle, seed, self.buffer_size, self.read_data_format_var)
+            ds.record_files = False         # (the one-record-per-file fast path parses 'fixed' records natively)
+            return ds
         return Dataset(file_list, shuffle, seed, self.buffer_size, self.read_data_format_fixed)
 
     def get_iterator(self, dataset, batch_size=16, n_epochs=None, drop_remainder=False, shard=(0, 1), native=True,
@@ -433,6 +458,14 @@ class DataManager:
         parses with the pure-Python decoder, `prefetch=0` parses on the caller's thread, `device` (e.g. 'cuda')
         also uploads audio / video / mask from the prefetch thread (see `Batch`), `even_rounds` gives every rank the same
         number of (full) batches -- what a training loop with one collective per step needs."""
+        if self.mode == 'var':
+            # dataset.padded_batch(batch_size, padded_shapes=([], [], [None], [None], [None], [None, None], [None, None])) of the
+            # reference (dataset_reader.py:49-55): every field padded with zeros to the longest of the batch; parsed in Python
+            # (48,000 one-float features per record: a format for small corpora), host arrays only
+            it = BatchIterator(dataset, batch_size, n_epochs, drop_remainder, shard, decode_batch=None, prefetch=prefetch,
+                               device=None, even_rounds=even_rounds)
+            it.collate = _collate_padded
+            return it, it
         it = BatchIterator(dataset, batch_size, n_epochs, drop_remainder, shard,
                            decode_batch=self.decode_batch if native else None, prefetch=prefetch, device=device,
                            upload_fields=(2, 3, -2, -1) if self.embedding_size else (2, -2, -1), even_rounds=even_rounds,
@@ -534,6 +567,28 @@ class DataManager:
         if E:
             out.append(emb)
         return tuple(out + [sample_paths, labels, video, mask])
+
+    def read_data_format_var(self, sample):
+        """Parse one serialized 'var' SequenceExample (reference dataset_reader.py:82-99): (sequence_length int32, labels_length
+        int32, target_audio_wav f32 [n] -- no int truncation in this mode --, sample_path int64 [chars], labels f32 [l],
+        video_features f32 [t, Dv], mask f32 [t, F])."""
+        ctx, seq = tfrecord_io.decode_sequence_example(sample)
+
+        def scalars(name, dtype):
+            steps = seq.get(name, [])
+            return np.array([s[0] for s in steps], dtype=dtype) if steps else np.zeros(0, dtype=dtype)
+
+        def vectors(name, width):
+            steps = seq.get(name, [])
+            if not steps:
+                return np.zeros((0, width), dtype=np.float32)
+            a = np.stack(steps).astype(np.float32)
+            if a.shape[1] != width:
+                raise ValueError("feature sizes of the record do not match the DataManager configuration")
+            return a
+        return (np.int32(ctx['sequence_length'][0]), np.int32(ctx['labels_length'][0]), scalars('target_audio_wav', np.float32),
+                scalars('sample_path', np.int64), scalars('labels', np.float32), vectors('video_features', self.video_feat_size),
+                vectors('mask', self.audio_feat_size))
 
     def read_data_format_fixed(self, sample):
         """Parse one serialized SequenceExample (reference dataset_reader.py:62-79)."""

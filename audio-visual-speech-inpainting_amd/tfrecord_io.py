@@ -222,3 +222,24 @@ def serialize_sample_fixed(seq_len, lab_len, target_audio_wav, video_features, m
         'labels': [np.asarray([lab], dtype=np.float32) for lab in labels],
     }
     return encode_sequence_example(context, lists)
+
+
+def serialize_sample_var(seq_len, lab_len, target_audio_wav, video_features, mask, labels, sample_path):
+    """The 'var' record of the reference (tfrecord_utils.py:43-64) AS ITS READER EXPECTS IT (dataset_reader.py:82-99): lengths
+    in the context, everything else as feature lists -- ``target_audio_wav`` one float per step, ``sample_path`` one int64
+    character code per step, ``labels`` one float per step, ``video_features`` / ``mask`` one vector per frame.  The reference's
+    own writer for this mode cannot run (it fills ``fl_target`` / ``fl_mix_audio_path``, names that do not exist: SURVEY App.
+    B11); this is the record it was meant to produce, so that datasets of that shape can be read."""
+    path = sample_path.decode() if isinstance(sample_path, bytes) else sample_path
+    context = {
+        'sequence_length': np.array([seq_len], dtype=np.int64),
+        'labels_length': np.array([lab_len], dtype=np.int64),
+    }
+    lists = {
+        'target_audio_wav': [np.asarray([v], dtype=np.float32) for v in np.asarray(target_audio_wav).reshape(-1)],
+        'video_features': [np.asarray(v, dtype=np.float32) for v in video_features],
+        'mask': [np.asarray(m, dtype=np.float32) for m in mask],
+        'labels': [np.asarray([lab], dtype=np.float32) for lab in labels],
+        'sample_path': [np.asarray([ord(ch)], dtype=np.int64) for ch in path],
+    }
+    return encode_sequence_example(context, lists)

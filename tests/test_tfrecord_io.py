@@ -356,3 +356,66 @@ def test_whole_file_reader_matches_the_framed_path(tmp_path, monkeypatch):
     _, it = dm.get_iterator(ds, batch_size=3, n_epochs=1, prefetch=0)
     with pytest.raises(ValueError, match="more than one record"):
         next(it)
+
+
+def test_var_schema_round_trip_and_padded_batches(tmp_path):
+    """The 'var' TFRecord schema (reference dataset_reader.py:82-99; get_iterator :49-55): lengths in the context, audio /
+    sample path / labels / video / mask as feature lists; batches padded with zeros to the longest record, the audio stays
+    float32, the sample path is a row of character codes.  The reference's writer for this mode cannot run:
+    the records come from serialize_sample_var, which writes what that reader parses."""
+    import avsi_amd  # noqa: F401
+    from avsi_amd import tfrecord_io as tio
+    from avsi_amd.dataset_reader import DataManager, OutOfRangeError
+    rng = np.random.default_rng(5)
+    samples = []
+    for i, (n, t) in enumerate([(700, 4), (960, 5), (500, 3), (640, 6), (320, 2)]):
+        wav = (rng.normal(size=n) * 1000).astype(np.float32) + 0.25          # (fractions survive: no tf.to_int32 in this mode)
+        video = rng.normal(size=(t, 6)).astype(np.float32)
+        mask = np.ones((t, 9), np.float32)
+        mask[1:2] = 0
+        labels = np.arange(2 + i, dtype=np.float32)
+        samples.append((t, 2 + i, wav, video, mask, labels, "dir/clip_%d" % i))
+    files = []
+    for k in range(2):                  # two files, three and two records
+        part = samples[3 * k: 3 * k + 3]
+        f = str(tmp_path / ("part%d.tfrecord" % k))
+        tio.write_records(f, [tio.serialize_sample_var(t, ll, w, v, m, lab, path) for t, ll, w, v, m, lab, path in part])
+        files.append(f)
+    # one record, field by field
+    ctx, seq = tio.decode_sequence_example(next(iter(tio.read_records(files[0]))))
+    assert sorted(ctx) == ['labels_length', 'sequence_length'] and int(ctx['sequence_length'][0]) == 4
+    assert sorted(seq) == ['labels', 'mask', 'sample_path', 'target_audio_wav', 'video_features']
+    assert len(seq['target_audio_wav']) == 700 and len(seq['sample_path']) == len("dir/clip_0")
+    dm = DataManager(num_audio_samples=0, audio_feat_size=9, video_feat_size=6, mode='var')
+    one = dm.read_data_format_var(next(iter(tio.read_records(files[0]))))
+    np.testing.assert_array_equal(one[2], samples[0][2])
+    assert one[2].dtype == np.float32 and one[3].dtype == np.int64 and bytes(one[3].tolist()).decode() == "dir/clip_0"
+    for drop, sizes in ((False, [2, 2, 1]), (True, [2, 2])):
+        _, it = dm.get_iterator(dm.get_dataset(files, shuffle=False), batch_size=2, n_epochs=1, drop_remainder=drop)
+        got = []
+        while True:
+            try:
+                got.append(it.get_next())
+            except OutOfRangeError:
+                break
+        assert [len(b[0]) for b in got] == sizes
+        at = 0
+        for b in got:
+            part = samples[at: at + len(b[0])]
+            at += len(b[0])
+            n_max, t_max = max(len(p[2]) for p in part), max(p[0] for p in part)
+            lab_max, path_max = max(len(p[5]) for p in part), max(len(p[6]) for p in part)
+            assert b[2].shape == (len(part), n_max) and b[3].shape == (len(part), path_max) and b[4].shape == (len(part), lab_max)
+            assert b[5].shape == (len(part), t_max, 6) and b[6].shape == (len(part), t_max, 9)
+            for i, (t, ll, w, v, m, lab, path) in enumerate(part):
+                assert b[0][i] == t and b[1][i] == ll
+                np.testing.assert_array_equal(b[2][i, :len(w)], w)
+                assert not b[2][i, len(w):].any() and not b[6][i, t:].any() and not b[5][i, t:].any()
+                np.testing.assert_array_equal(b[5][i, :t], v)
+                np.testing.assert_array_equal(b[6][i, :t], m)
+                np.testing.assert_array_equal(b[4][i, :len(lab)], lab)
+                assert bytes(b[3][i, :len(path)].tolist()).decode() == path
+    with pytest.raises(ValueError):
+        DataManager(mode='grouped')
+    with pytest.raises(ValueError):
+        DataManager(mode='var', embedding_size=512)
