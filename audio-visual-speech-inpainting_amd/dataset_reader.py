@@ -134,6 +134,56 @@ class Dataset(object):
             yield self.parse(payload)
 
 
+class InterleavedDataset(Dataset):
+    """``tf.data.Dataset.list_files(patterns, shuffle, seed).interleave(TFRecordDataset, cycle_length, block_length)`` (reference
+    dataset_reader.py:36-45, get_dataset_group): `cycle_length` files are open at a time and give `block_length` consecutive
+    records each in turn; a file that runs out is replaced by the next one of the list.  The file list is re-shuffled per
+    pass like list_files does (seeded: deterministic); no record-level shuffle buffer."""
+
+    def __init__(self, patterns, cycle_length, block_length, shuffle, seed, parse):
+        from glob import glob
+        files = []
+        for pat in ([patterns] if isinstance(patterns, str) else list(patterns)):
+            files.extend(sorted(glob(pat)) if any(ch in pat for ch in '*?[') else [pat])
+        Dataset.__init__(self, files, False, seed, 0, parse)
+        self.record_files = False
+        self.cycle_length, self.block_length, self.shuffle_files = max(1, int(cycle_length)), max(1, int(block_length)), shuffle
+
+    def payloads(self):
+        files = list(self.files)
+        if self.shuffle_files:
+            rng = np.random.default_rng(None if self.seed is None else self.seed + self._epoch)
+            rng.shuffle(files)
+        self._epoch += 1
+        waiting = iter(files)
+        cycle = []
+        for _ in range(self.cycle_length):
+            path = next(waiting, None)
+            if path is None:
+                break
+            cycle.append(iter(tfrecord_io.read_records(path)))
+        at = 0
+        while cycle:
+            at %= len(cycle)
+            taken = 0
+            while taken < self.block_length:
+                rec = next(cycle[at], None)
+                if rec is None:
+                    break
+                taken += 1
+                yield rec
+            if taken < self.block_length:           # this file is done: the next one of the list takes its place in the cycle
+                path = next(waiting, None)
+                if path is None:
+                    cycle.pop(at)
+                    continue
+                cycle[at] = iter(tfrecord_io.read_records(path))
+                if taken:
+                    at += 1
+                continue
+            at += 1
+
+
 class Batch(tuple):
     """The batch tuple of the module docstring (numpy arrays).  With ``get_iterator(..., device=...)`` the large
     arrays have also been copied to the GPU by the prefetch thread: ``device_arrays`` maps positions of the tuple
@@ -451,6 +501,11 @@ class DataManager:
             ds.record_files = False         # (the one-record-per-file fast path parses 'fixed' records natively)
             return ds
         return Dataset(file_list, shuffle, seed, self.buffer_size, self.read_data_format_fixed)
+
+    def get_dataset_group(self, file_list=(), cycle_length=100, block_length=16, shuffle=True, seed=None):
+        """Reference dataset_reader.py:36-45: records of `cycle_length` files interleaved in blocks of `block_length`."""
+        return InterleavedDataset(file_list, cycle_length, block_length, shuffle, seed,
+                                  self.read_data_format_var if self.mode == 'var' else self.read_data_format_fixed)
 
     def get_iterator(self, dataset, batch_size=16, n_epochs=None, drop_remainder=False, shard=(0, 1), native=True,
                      prefetch=2, device=None, even_rounds=False, count_gaps=False):

@@ -419,3 +419,27 @@ def test_var_schema_round_trip_and_padded_batches(tmp_path):
         DataManager(mode='grouped')
     with pytest.raises(ValueError):
         DataManager(mode='var', embedding_size=512)
+
+
+def test_get_dataset_group_interleaves_files_in_blocks(tmp_path):
+    """DataManager.get_dataset_group (reference dataset_reader.py:36-45: list_files + interleave(cycle_length, block_length)):
+    three files of 5, 2 and 4 records, two files open at a time, blocks of two records -- the order tf.data's interleave gives."""
+    import avsi_amd  # noqa: F401
+    from avsi_amd import tfrecord_io as tio
+    from avsi_amd.dataset_reader import DataManager
+    T, N = 3, 64
+    sizes = {'a': 5, 'b': 2, 'c': 4}
+    for name, n in sizes.items():
+        recs = [tio.serialize_sample_fixed(T, 1, np.full(N, 100 * (ord(name) - 96) + i, np.float32), np.zeros((T, 4), np.float32),
+                                           np.ones((T, 5), np.float32), np.zeros(1), "%s%d" % (name, i)) for i in range(n)]
+        tio.write_records(str(tmp_path / ("%s.tfrecord" % name)), recs)
+    dm = DataManager(num_audio_samples=N, audio_feat_size=5, video_feat_size=4)
+    ds = dm.get_dataset_group(str(tmp_path / "*.tfrecord"), cycle_length=2, block_length=2, shuffle=False)
+    order = [ex[3].decode() for ex in ds.examples()]
+    assert order == ['a0', 'a1', 'b0', 'b1', 'a2', 'a3', 'c0', 'c1', 'a4', 'c2', 'c3']
+    _, it = dm.get_iterator(ds, batch_size=4, n_epochs=1, prefetch=0)
+    batches = list(it)
+    assert [len(b[0]) for b in batches] == [4, 4, 3] and [p.decode() for p in batches[0][3]] == order[:4]
+    shuffled = dm.get_dataset_group([str(tmp_path / "*.tfrecord")], cycle_length=2, block_length=2, shuffle=True, seed=3)
+    first, second = [ex[3] for ex in shuffled.examples()], [ex[3] for ex in shuffled.examples()]
+    assert sorted(first) == sorted(second) == sorted(p.encode() for p in order) and len(first) == 11
