@@ -909,7 +909,12 @@ int launch_dma(const GemmArgs& g, int splits, hipStream_t st) {
     if (!TA && !TB && g.bnt == 256) {
         // 72 KiB: two workgroups per CU (+ K floats for the folded last column).  AVSI_GEMM_PERSIST=0: one workgroup per tile
         // (A/B); the persistent form needs enough tiles per resident workgroup to pay for its fixed order
-        static const bool persist = !(getenv("AVSI_GEMM_PERSIST") && atoi(getenv("AVSI_GEMM_PERSIST")) == 0);
+        // Not in a process that has been given a SHARE of the chip (AVSI_COOP_CUS < 256: several processes on one GPU, the
+        // rehearsals of tests/): resident workgroups hold the LDS of every CU for the whole launch, and another process's
+        // cooperative recurrent group, which needs whole CUs of one XCD at once, then waits for launch after launch
+        // (tests/test_bench_contract_gpu.py with four ranks on one GPU ran into its 2 s bound)
+        static const bool persist = !(getenv("AVSI_GEMM_PERSIST") && atoi(getenv("AVSI_GEMM_PERSIST")) == 0) &&
+                                    !(getenv("AVSI_COOP_CUS") && atoi(getenv("AVSI_COOP_CUS")) > 0 && atoi(getenv("AVSI_COOP_CUS")) < AVSI_NUM_CU);
         const size_t lds_t = (size_t)3 * (128 + 256) * 16 * 4 + (g.tail_col >= 0 ? (size_t)g.K * 4 : 0);
         const int tiles = g.m_blocks * g.n_blocks, resident = 2 * AVSI_NUM_CU;
         const bool pers = persist && splits == 1 && tiles >= 4 * resident;

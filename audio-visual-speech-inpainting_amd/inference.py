@@ -182,9 +182,10 @@ def infer(model_path, data_path_test, audio_path, out_file_prefix, norm=True, or
     loss_list = []
     device = torch.device('cuda', torch.cuda.current_device())
     writer = _WavWriter(audio_path, out_file_prefix, int(os.environ.get('AVSI_WAV_THREADS', '6')), device)
-    # The LWS sweeps are a pipeline of ~100 stages per utterance: small batches are collected until LWS_GROUP utterances
-    # wait for their phase, refined in one launch and written in the order they came (32 utterances 4.8 ms, 256: 15 ms,
-    # DESIGN 4.3d); the per-batch lines below are printed when their files are queued.
+    # The LWS sweeps are a pipeline of ~100 stages per utterance: batches are collected until LWS_GROUP utterances wait for their
+    # phase, refined in one launch and written in the order they came; the per-batch lines below are printed when their files
+    # are queued.  1024 since round 6: the two-utterances-per-wave kernel fills the chip at 512 pairs (33 us per utterance at
+    # 1024, 58 at 256, 150 at 32)
     lws_group = int(os.environ.get('AVSI_LWS_GROUP', '1024'))
     pending = []                    # (enhanced, masks, paths, lengths) of batches whose phase is still to be refined
 
