@@ -41,6 +41,7 @@ struct RecArgs {
     int T, Bp;
     unsigned long long* stamps;  // diagnostic builds only (-DAVSI_REC_STAMPS): [wg][wave][4] phase cycles
     int row0, rend;              // the utterances [row0, rend) of the batch are this launch's (the whole batch: 0, Bp)
+    int diag;                    // AVSI_REC_Q_DIAG (quarter-product kernel, timing experiments; results WRONG): see launch_rec_q
 };
 
 // In-kernel phase stamps (diagnostic build only; the shipped library never executes one).
@@ -442,13 +443,16 @@ __global__ __launch_bounds__(512, 2) void blstm_rec_fwd_pp_kernel(const RecArgs 
 //         Q10(s)  U1 columns, k in U0   ||  loads x_{s+1}[U0]
 //         -- barrier --
 //     h is double buffered (133 KB: one workgroup per CU, as the ping-pong kernel at this batch size);
+//   - measured (profiles/r06_rec_fwd_q_pmc.txt, r06_rec_fwd_q_hot.txt): as fast as the ping-pong kernel, no faster -- the L1 does
+//     not merge the pair's requests, and even a third fewer L2 requests (AVSI_REC_Q_DIAG=1: the second tile's waves read one hot
+//     group; results wrong) change neither the launch time nor the clock.  Kept as the measured alternative (rows_per_wg = 66);
 //   - sums: x + (k in U0) + (k in U1) for U0 columns, x + (k in U1) + (k in U0) for U1 columns -- another order than
 //     the other kernels' 0 .. 255: equal to rounding, not to the bit.
 // ------------------------------------------------------------------------------------------
 // MODE: 0 = matrix work only, 1 = + the cell of the OTHER unit set (one element per k group), 2 = + loads of its next
 // pre-activations (two elements per k group, groups 0 .. 7), 3 = cell and loads (loads in groups 8 .. 15: behind their cells)
 template <int KSET, int MODE, bool DO_MFMA, bool SAVE>
-__device__ __forceinline__ void q_block(f32x16 (&am)[4], const float* __restrict__ hx, const float4* __restrict__ wb, const int lane,
+__device__ __forceinline__ void q_block(f32x16 (&am)[4], const float* __restrict__ hx, const float4* __restrict__ wb, const int lane, const bool hot,
                                         f32x16 (&ac)[4], f32x16& cc, float* __restrict__ hy, const rsrc_t rh, const rsrc_t rr,
                                         const rsrc_t rx_next, const int voff_h, const int voff_r, const int voff_x) {
     constexpr int XROW = 2 * GP * 4, HROW = 2 * HP * 4, RROW = 2 * 5 * HP * 4;
@@ -457,7 +461,7 @@ __device__ __forceinline__ void q_block(f32x16 (&am)[4], const float* __restrict
     if (DO_MFMA) {
 #pragma unroll
         for (int g = 0; g < 4; ++g) bw[0][g] = ldg4(wrun, g * 64 + lane);
-        wrun = opaque_next(wrun, 256);
+        wrun = opaque_next(wrun, hot ? 0 : 256);
         af[0] = *reinterpret_cast<const float4*>(hx + 8 * (KSET * 4));
     }
 #pragma unroll
@@ -466,10 +470,10 @@ __device__ __forceinline__ void q_block(f32x16 (&am)[4], const float* __restrict
         if (DO_MFMA) {
             if (j + 1 < 16) {
                 const int qn = ((j + 1) >> 2) * 8 + KSET * 4 + ((j + 1) & 3);
-                if (((j + 1) & 3) == 0) wrun = opaque_next(wrun, 4 * 256);     // over the other set's four groups
+                if (((j + 1) & 3) == 0) wrun = opaque_next(wrun, hot ? 0 : 4 * 256);     // over the other set's four groups
 #pragma unroll
                 for (int g = 0; g < 4; ++g) bw[cb ^ 1][g] = ldg4(wrun, g * 64 + lane);
-                wrun = opaque_next(wrun, 256);
+                wrun = opaque_next(wrun, hot ? 0 : 256);
                 af[cb ^ 1] = *reinterpret_cast<const float4*>(hx + 8 * qn);
             }
             __builtin_amdgcn_sched_barrier(0);
@@ -543,6 +547,7 @@ __global__ __launch_bounds__(512, 2) void blstm_rec_fwd_q_kernel(const RecArgs a
     // the two unit blocks of this wave: fragments, and the lane's columns of xproj / hout / reserve
     const float4* __restrict__ wb0 = reinterpret_cast<const float4*>(a.whp) + (size_t)(dir * NWAVE + 2 * v) * (32 * 4 * 64);
     const float4* __restrict__ wb1 = wb0 + 32 * 4 * 64;
+    const bool diag_hot = (a.diag & 1) && trow != 0;      // (experiment: the second tile's waves read ONE fragment group over and over)
     const int voff_x0 = 4 * hi * XROW + (dir * GP + (2 * v) * 128 + li) * 4, voff_x1 = voff_x0 + 128 * 4;
     const int voff_h0 = 4 * hi * HROW + (dir * HP + (2 * v) * 32 + li) * 4, voff_h1 = voff_h0 + 32 * 4;
     const int voff_r0 = 4 * hi * RROW + (dir * 5 * HP + (2 * v) * 32 + li) * 4, voff_r1 = voff_r0 + 32 * 4;
@@ -578,7 +583,7 @@ __global__ __launch_bounds__(512, 2) void blstm_rec_fwd_q_kernel(const RecArgs a
     rsrc_t rh, rr;
     // prologue: h_{-1} = 0, the step-0 pre-activations are final.  cell U0 (step 0) -> buffer 0, loads x_1[U0]
     out_rsrc(0, rh, rr);
-    q_block<0, 3, false, SAVE>(acc1, hbuf + hx_off, wb0, lane, acc0, c0, hbuf + hy_off0, rh, rr, in_rsrc(1, T > 1), voff_h0, voff_r0,
+    q_block<0, 3, false, SAVE>(acc1, hbuf + hx_off, wb0, lane, diag_hot, acc0, c0, hbuf + hy_off0, rh, rr, in_rsrc(1, T > 1), voff_h0, voff_r0,
                                voff_x0);
     AVSI_LDS_BARRIER();
     for (int step = 1; step < T; ++step) {
@@ -586,22 +591,22 @@ __global__ __launch_bounds__(512, 2) void blstm_rec_fwd_q_kernel(const RecArgs a
         float* hnext = hbuf + (step & 1) * HBUF;
         // Q00 || cell U1 (step - 1) -> hcur[U1], loads x_step[U1]
         out_rsrc(step - 1, rh, rr);
-        q_block<0, 3, true, SAVE>(acc0, hcur + hx_off, wb0, lane, acc1, c1, hcur + hy_off1, rh, rr, in_rsrc(step, true), voff_h1,
+        q_block<0, 3, true, SAVE>(acc0, hcur + hx_off, wb0, lane, diag_hot, acc1, c1, hcur + hy_off1, rh, rr, in_rsrc(step, true), voff_h1,
                                   voff_r1, voff_x1);
         AVSI_LDS_BARRIER();
         // Q01
-        q_block<1, 0, true, SAVE>(acc0, hcur + hx_off, wb0, lane, acc1, c1, hcur + hy_off1, rh, rr, rh, voff_h1, voff_r1, voff_x1);
+        q_block<1, 0, true, SAVE>(acc0, hcur + hx_off, wb0, lane, diag_hot, acc1, c1, hcur + hy_off1, rh, rr, rh, voff_h1, voff_r1, voff_x1);
         // Q11 || cell U0 (step) -> hnext[U0]
         out_rsrc(step, rh, rr);
-        q_block<1, 1, true, SAVE>(acc1, hcur + hx_off, wb1, lane, acc0, c0, hnext + hy_off0, rh, rr, rh, voff_h0, voff_r0, voff_x0);
+        q_block<1, 1, true, SAVE>(acc1, hcur + hx_off, wb1, lane, diag_hot, acc0, c0, hnext + hy_off0, rh, rr, rh, voff_h0, voff_r0, voff_x0);
         // Q10 || loads x_{step+1}[U0]
-        q_block<0, 2, true, SAVE>(acc1, hcur + hx_off, wb1, lane, acc0, c0, hnext + hy_off0, rh, rr, in_rsrc(step + 1, step + 1 < T),
+        q_block<0, 2, true, SAVE>(acc1, hcur + hx_off, wb1, lane, diag_hot, acc0, c0, hnext + hy_off0, rh, rr, in_rsrc(step + 1, step + 1 < T),
                                   voff_h0, voff_r0, voff_x0);
         AVSI_LDS_BARRIER();
     }
     // epilogue: cell U1 (step T - 1)
     out_rsrc(T - 1, rh, rr);
-    q_block<0, 1, false, SAVE>(acc0, hbuf + hx_off, wb0, lane, acc1, c1, hbuf + ((T - 1) & 1) * HBUF + hy_off1, rh, rr, rh, voff_h1,
+    q_block<0, 1, false, SAVE>(acc0, hbuf + hx_off, wb0, lane, diag_hot, acc1, c1, hbuf + ((T - 1) & 1) * HBUF + hy_off1, rh, rr, rh, voff_h1,
                                voff_r1, voff_x1);
 }
 
@@ -648,7 +653,8 @@ extern "C" int avsi_blstm_rec_fwd_rows_f32(const float* xproj, const float* whp,
     if (Bp % 32) return AVSI_ERR_INVALID_ARG;  // batch is padded to whole 32-row MFMA tiles
     if (first_row < 0 || rows <= 0 || (first_row & 31) || (rows & 31) || first_row + rows > Bp) return AVSI_ERR_INVALID_ARG;
     if ((reinterpret_cast<uintptr_t>(whp) & 15)) return AVSI_ERR_UNSUPPORTED;
-    RecArgs a{xproj, whp, hout, reserve, T, Bp, nullptr, first_row, first_row + rows};
+    static const int q_diag = getenv("AVSI_REC_Q_DIAG") ? atoi(getenv("AVSI_REC_Q_DIAG")) : 0;
+    RecArgs a{xproj, whp, hout, reserve, T, Bp, nullptr, first_row, first_row + rows, q_diag};
     // 64 rows per workgroup halves the Wh stream per flop; 32 rows spreads a small batch wider: up to 4096 utterances
     // the 32-row workgroups (two directions x rows / 32) fit the chip in one round, beyond that they would need a second
     // round where the 64-row kernel still needs one (6144 utterances, whole inference step: 131 -> 119 ms)
@@ -672,7 +678,7 @@ extern "C" int avsi_blstm_rec_fwd_f32(const float* xproj, const float* whp, floa
 // Diagnostic entry (tools/rec_stamps.cpp): same kernel with phase stamps written to `stamps`.
 extern "C" int avsi_blstm_rec_fwd_stamps(const float* xproj, const float* whp, float* hout, int T, int Bp, int mt,
                                          unsigned long long* stamps, void* stream) {
-    RecArgs a{xproj, whp, hout, nullptr, T, Bp, stamps, 0, Bp};
+    RecArgs a{xproj, whp, hout, nullptr, T, Bp, stamps, 0, Bp, 0};
     avsi_clear_error();
     return mt == 64 ? launch_rec<2, false>(a, (hipStream_t)stream) : launch_rec<1, false>(a, (hipStream_t)stream);
 }
