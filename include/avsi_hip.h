@@ -122,6 +122,12 @@ int avsi_frontend_l1_loss_f32(const avsi_frontend_args* args, const float* pred,
  * batch pitch row_map_bp and output row (t, b) is stored at row b * row_map_t + t, rows with
  * b >= row_map_b are dropped (time-major -> reference [B, T, .] layout).
  * row_scale (optional, [M]) multiplies each finished row: tf.sequence_mask at models.py:136.
+ * Two forms the call chooses by itself (results as documented; nothing for the caller to do):
+ *   - A . B over many rows with N a multiple of 256 (the layer input projections): 128 x 256 output tiles; from 2048 tiles on
+ *     the launch is the 512 RESIDENT workgroups, which take tile after tile from a queue of the library's own (a module global,
+ *     zeroed on `stream` in front of the launch) -- not in a process that has declared a share of the chip (AVSI_COOP_CUS < 256);
+ *   - N = 257 over many rows (the logits matmul onto the reference's 257 bins): the same tile for 256 columns, the last column
+ *     taken by the same workgroups as a dot product over the rows they have staged (one launch instead of two).
  * ------------------------------------------------------------------------------------ */
 typedef struct avsi_gemm_epilogue {
     const float* bias;        /* [N] or null */
