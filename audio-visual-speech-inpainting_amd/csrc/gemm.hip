@@ -1077,6 +1077,10 @@ int avsi_gemm_launch(int transA, int transB, int M, int N, int K, float alpha, c
         const int64_t slice_bytes_per_block = (int64_t)g.k_split_len * g.bnt * 4;
         int ng = (int)((2 << 20) / (slice_bytes_per_block > 0 ? slice_bytes_per_block : 1));
         if (ng < 4) ng = 4;      // narrower groups re-read A more often than they save on B
+        // (groups of equal width: 272 deep x 256 wide slices gave a width of 7 for 8 column blocks -- groups of 7 and 1, and layer 0
+        //  took 17.4 ms where widths of 2 / 4 / 8 take 16.9 / 16.7 / 16.8: the next divisor of the block count below)
+        if (ng < g.n_blocks)
+            while (ng > 1 && g.n_blocks % ng) --ng;
         if (env.ngroup >= 0) ng = env.ngroup;
         g.n_group = ng < 1 ? 1 : (ng > g.n_blocks ? g.n_blocks : ng);
     }
